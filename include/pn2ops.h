@@ -1,0 +1,123 @@
+/*
+ * pn2ops.h -- C ABI of libpn2ops.so: the PointNet++ set-abstraction /
+ * feature-propagation operator kernels, hand-written for AMD MI355X (gfx950).
+ *
+ * Drop-in seam. The reference's TensorFlow op classes call free C++
+ * "Launcher" functions that are declared in the op .cpp and defined in the
+ * .cu. Every entry point below replaces exactly one
+ * of them and keeps its argument list (same order, same meaning, same
+ * row-major fp32/int32 layouts), plus
+ *     - a trailing `void *stream` (a hipStream_t; NULL = the null stream), and
+ *     - an `int` return: 0 ok, <0 invalid argument (PN2_E_*), >0 a hipError_t
+ *       raised by the launch (the reference launchers return void and never
+ *       check; validation lived in OpKernel::Compute as OP_REQUIRES).
+ *
+ * Ownership: the caller allocates every buffer (inputs, outputs, scratch);
+ * the library holds no state and no memory, never synchronises, and only
+ * enqueues work on `stream`. All pointers are DEVICE pointers. Entry points
+ * are re-entrant and thread-safe.
+ *
+ * Gradient entry points ZERO their output themselves (the reference made the
+ * caller do it: cudaMemset in tf_sampling.cpp:174, tf_grouping.cpp:204,
+ * memset in tf_interpolate.cpp:258) -- a documented, deliberate difference:
+ * the zero-fill is enqueued on the same stream right before the scatter.
+ */
+#ifndef PN2OPS_H
+#define PN2OPS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN2_OK 0
+#define PN2_E_NULL (-1)     /* a required pointer is NULL */
+#define PN2_E_SHAPE (-2)    /* negative / zero extent where the reference requires positive */
+#define PN2_E_ARG (-3)      /* attribute out of range (radius<=0, nsample<=0, npoint<=0, k<=0 ...) */
+#define PN2_E_TOO_LARGE (-4)/* extent beyond what the kernels index with int32 */
+
+/* library identification: returns "pn2ops <version> gfx950" */
+const char *pn2_version(void);
+
+/* ---- tf_ops/sampling ------------------------------------------------- */
+
+/* replaces farthestpointsamplingLauncher(int b,int n,int m,const float*inp,float*temp,int*out)
+ *   declared tf_ops/sampling/tf_sampling.cpp:94, defined tf_sampling_g.cu:203-205.
+ * inp (b,n,3) f32 -> out (b,m) i32.  temp: scratch of pn2_fps_temp_floats(b,n)
+ * floats (the reference allocates 32*n, tf_sampling.cpp:115); may be NULL when
+ * pn2_fps_temp_floats(b,n)==0 (the register-resident tiers need no scratch).
+ * Selection order and tie rule are the reference kernel's (ties -> smallest
+ * (k mod 512, k)). m<=0 is a no-op like tf_sampling_g.cu:106. */
+int pn2_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out, void *stream);
+long long pn2_fps_temp_floats(int b, int n);
+
+/* replaces gatherpointLauncher(b,n,m,inp,idx,out)  tf_sampling.cpp:125, tf_sampling_g.cu:206-208
+ * inp (b,n,3), idx (b,m) -> out (b,m,3) */
+int pn2_gather_point(int b, int n, int m, const float *inp, const int *idx, float *out, void *stream);
+
+/* replaces scatteraddpointLauncher(b,n,m,out_g,idx,inp_g)  tf_sampling.cpp:150, tf_sampling_g.cu:209-211
+ * out_g (b,m,3), idx (b,m) -> inp_g (b,n,3), zero-filled here then accumulated */
+int pn2_gather_point_grad(int b, int n, int m, const float *out_g, const int *idx, float *inp_g, void *stream);
+
+/* replaces probsampleLauncher(b,n,m,inp_p,inp_r,temp,out)  tf_sampling.cpp:65, tf_sampling_g.cu:198-201
+ * inp_p (b,n) weights, inp_r (b,m) uniforms in [0,1) -> out (b,m); temp: b*n floats */
+int pn2_prob_sample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out, void *stream);
+
+/* ---- tf_ops/grouping -------------------------------------------------- */
+
+/* replaces queryBallPointLauncher(b,n,m,radius,nsample,xyz1,xyz2,idx,pts_cnt)
+ *   tf_ops/grouping/tf_grouping.cpp:66, tf_grouping_g.cu:125-128 (CPU twin test/query_ball_point.cpp:19-47)
+ * xyz1 (b,n,3) dataset, xyz2 (b,m,3) queries -> idx (b,m,nsample), pts_cnt (b,m).
+ * Rows with no point in the ball are written as zeros (the reference leaves them
+ * uninitialised; its harness pre-zeroes, query_ball_point.cpp:94). */
+int pn2_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
+                         int *idx, int *pts_cnt, void *stream);
+
+/* replaces selectionSortLauncher(b,n,m,k,dist,outi,out)  tf_grouping.cpp:108, tf_grouping_g.cu:129-132
+ * dist (b,m,n) -> outi (b,m,n) i32, out (b,m,n) f32; the first k of each row are the k smallest, ascending */
+int pn2_selection_sort(int b, int n, int m, int k, const float *dist, int *outi, float *out, void *stream);
+
+/* replaces groupPointLauncher(b,n,c,m,nsample,points,idx,out)  tf_grouping.cpp:142, tf_grouping_g.cu:133-136
+ * points (b,n,c), idx (b,m,nsample) -> out (b,m,nsample,c) */
+int pn2_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx, float *out,
+                    void *stream);
+
+/* replaces groupPointGradLauncher(b,n,c,m,nsample,grad_out,idx,grad_points)  tf_grouping.cpp:173, tf_grouping_g.cu:137-141
+ * grad_out (b,m,nsample,c), idx -> grad_points (b,n,c), zero-filled here then accumulated */
+int pn2_group_point_grad(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
+                         float *grad_points, void *stream);
+
+/* ---- tf_ops/3d_interpolation ------------------------------------------ */
+
+/* replaces threenn_cpu(b,n,m,xyz1,xyz2,dist,idx)  tf_ops/3d_interpolation/tf_interpolate.cpp:60-103
+ * xyz1 (b,n,3) unknown, xyz2 (b,m,3) known -> dist (b,n,3) SQUARED distances ascending, idx (b,n,3) */
+int pn2_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx, void *stream);
+
+/* replaces threeinterpolate_cpu(b,m,c,n,points,idx,weight,out)  tf_interpolate.cpp:107-127
+ * points (b,m,c), idx/weight (b,n,3) -> out (b,n,c) */
+int pn2_three_interpolate(int b, int m, int c, int n, const float *points, const int *idx, const float *weight,
+                          float *out, void *stream);
+
+/* replaces threeinterpolate_grad_cpu(b,n,c,m,grad_out,idx,weight,grad_points)  tf_interpolate.cpp:131-153
+ * grad_out (b,n,c), idx/weight (b,n,3) -> grad_points (b,m,c), zero-filled here then accumulated */
+int pn2_three_interpolate_grad(int b, int n, int c, int m, const float *grad_out, const int *idx,
+                               const float *weight, float *grad_points, void *stream);
+
+/* ---- fused entry points (no reference counterpart) ---- */
+
+/* query_ball_point + group_point(xyz1, idx) - centroid in one pass over the
+ * LDS-resident cloud: what pointnet_util.py:44-46 computes with three ops.
+ * grouped_xyz (b,m,nsample,3) = xyz1[idx] - xyz2[:, :, None] when subtract_centroid!=0,
+ * else the plain group. idx / pts_cnt as pn2_query_ball_point (either may be NULL). */
+int pn2_query_ball_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
+                             int subtract_centroid, int *idx, int *pts_cnt, float *grouped_xyz, void *stream);
+
+/* ---- host helpers ------------------------------------------------------- */
+
+/* The exact fp32 threshold s* with  max(sqrtf(s),1e-20f) < radius  <=>  s < s*
+ * (host computation, monotonicity of correctly-rounded sqrtf). Exposed for tests. */
+float pn2_ball_threshold(float radius);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PN2OPS_H */

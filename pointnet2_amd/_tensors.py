@@ -1,0 +1,42 @@
+"""Tensor plumbing shared by the op wrappers: validation + raw pointers.
+
+PyTorch is used for device memory and streams only; the compute is in
+libpn2ops.so. The checks mirror the OP_REQUIRES validation that the reference
+performs in OpKernel::Compute (SURVEY.md section 8b "Error convention"), with
+the reference's message text.
+"""
+import torch
+
+
+def require(cond, msg):
+    if not cond:
+        raise ValueError(msg)
+
+
+def f32(t, name):
+    require(isinstance(t, torch.Tensor), "%s must be a torch.Tensor" % name)
+    require(t.dtype == torch.float32, "%s must be float32, got %s" % (name, t.dtype))
+    require(t.is_cuda, "%s must live on a ROCm device (got %s); there is no CPU path" % (name, t.device))
+    return t.contiguous()
+
+
+def i32(t, name):
+    require(isinstance(t, torch.Tensor), "%s must be a torch.Tensor" % name)
+    require(t.dtype == torch.int32, "%s must be int32, got %s" % (name, t.dtype))
+    require(t.is_cuda, "%s must live on a ROCm device (got %s); there is no CPU path" % (name, t.device))
+    return t.contiguous()
+
+
+def same_device(*ts):
+    dev = ts[0].device
+    for t in ts[1:]:
+        require(t.device == dev, "all tensors must be on the same device (%s vs %s)" % (dev, t.device))
+    return dev
+
+
+def ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,195 @@
+// ball_query.hip -- query_ball_point (+ optional fused group of xyz) for gfx950.
+//
+// Replaces query_ball_point_gpu / queryBallPointLauncher (reference
+// tf_ops/grouping/tf_grouping_g.cu:3-36, :125-128; CPU twin
+// tf_ops/grouping/test/query_ball_point.cpp:19-47). Index-exact:
+//   * the reference predicate max(sqrtf(s),1e-20f) < radius is evaluated as
+//     s < s*, with s* the smallest fp32 whose predicate is false, found on the
+//     host by bisection with the host's correctly rounded sqrtf
+//     (pn2_ball_threshold). sqrtf is monotone, so the two are identical for
+//     every s, and no device sqrt (whatever its rounding) is involved;
+//   * s itself is the fp32 value ((dx*dx)+(dy*dy))+(dz*dz), no FMA.
+//
+// Design (DESIGN.md "ball query"). The reference walks the cloud with ONE
+// thread per query. Here one 64-lane wave owns a query and sweeps the cloud 64
+// candidates at a time in ascending index order: the cloud is staged once per
+// workgroup in LDS as float4 (one ds_read_b128 per lane per step), the hit
+// mask is a v_cmp (ballot), v_mbcnt gives each hit its ordered output slot,
+// and the sweep stops (wave-uniformly) as soon as nsample hits are in. The
+// result row is assembled in an LDS row buffer and leaves the CU as ONE
+// coalesced store per query (the reference scatters 4-byte stores). With
+// FUSE the same epilogue also emits xyz1[idx]-centroid straight from the LDS
+// copy of the cloud (pointnet_util.py:44-46 needs three ops and two extra
+// passes over idx for this).
+#include "pn2_device.h"
+
+#include <limits.h>
+#include <math.h>
+#include <string.h>
+
+namespace pn2 {
+
+constexpr int kBqThreads = 256;
+constexpr int kBqWaves = kBqThreads / PN2_WAVE;
+constexpr int kBqMaxLdsPoints = 9600;  // 16 B/point + row buffers must stay under 160 KiB
+
+template <bool LDS_CLOUD, bool FUSE>
+__global__ __launch_bounds__(kBqThreads) void ball_query_kernel(int n, int m, int nsample, float thr, int qpb,
+                                                                const float *__restrict__ xyz1,
+                                                                const float *__restrict__ xyz2, int *__restrict__ idx,
+                                                                int *__restrict__ pts_cnt,
+                                                                float *__restrict__ grouped, int subtract)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *cloud = reinterpret_cast<float4 *>(smem);                                   // [n] when LDS_CLOUD
+    int *rowbuf_all = reinterpret_cast<int *>(smem + (LDS_CLOUD ? sizeof(float4) * (size_t)n : 0));
+
+    const int bi = blockIdx.y;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const float *__restrict__ data = xyz1 + (size_t)bi * n * 3;
+    int *rowbuf = rowbuf_all + w * nsample;
+
+    if (LDS_CLOUD) {
+        for (int k = t; k < n; k += kBqThreads) {
+            const float *p = data + (size_t)k * 3;
+            cloud[k] = make_float4(p[0], p[1], p[2], 0.0f);
+        }
+        __syncthreads();
+    }
+
+    const int q0 = blockIdx.x * qpb;
+    const int q1 = min(q0 + qpb, m);
+    for (int j = q0 + w; j < q1; j += kBqWaves) {
+        const size_t row = (size_t)bi * m + j;
+        const float qx = xyz2[row * 3 + 0], qy = xyz2[row * 3 + 1], qz = xyz2[row * 3 + 2];
+        int cnt = 0;     // wave-uniform
+        int first = 0;   // index of the first hit (pads the row), 0 when the ball is empty
+        for (int base = 0; base < n && cnt < nsample; base += 64) {
+            const int k = base + lane;
+            const bool valid = k < n;
+            const int kk = valid ? k : n - 1;
+            float px, py, pz;
+            if (LDS_CLOUD) {
+                const float4 p = cloud[kk];
+                px = p.x; py = p.y; pz = p.z;
+            } else {
+                px = data[(size_t)kk * 3 + 0]; py = data[(size_t)kk * 3 + 1]; pz = data[(size_t)kk * 3 + 2];
+            }
+            // reference operand order: (x2-x1) with x2 the query (query_ball_point.cpp:26-32)
+            const float s = sqdist(qx, qy, qz, px, py, pz);
+            const bool hit = valid && (s < thr);
+            const unsigned long long mask = __ballot(hit);
+            if (mask != 0ull) {
+                const int pos = cnt + mbcnt(mask);
+                if (hit && pos < nsample) rowbuf[pos] = k;
+                if (cnt == 0) first = base + __builtin_ctzll(mask);
+                cnt += __popcll(mask);
+            }
+        }
+        cnt = min(cnt, nsample);
+        // LDS ops of one wave execute in order; only the compiler must not reorder
+        asm volatile("" ::: "memory");
+        for (int l = lane; l < nsample; l += 64) {
+            const int v = (l < cnt) ? rowbuf[l] : first;
+            if (idx) idx[row * nsample + l] = v;
+            if (FUSE) {
+                float gx, gy, gz;
+                if (LDS_CLOUD) {
+                    const float4 p = cloud[v];
+                    gx = p.x; gy = p.y; gz = p.z;
+                } else {
+                    gx = data[(size_t)v * 3 + 0]; gy = data[(size_t)v * 3 + 1]; gz = data[(size_t)v * 3 + 2];
+                }
+                if (subtract) { gx = __fsub_rn(gx, qx); gy = __fsub_rn(gy, qy); gz = __fsub_rn(gz, qz); }
+                float *o = grouped + (row * nsample + l) * 3;
+                o[0] = gx; o[1] = gy; o[2] = gz;
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (lane == 0 && pts_cnt) pts_cnt[row] = cnt;
+    }
+}
+
+template <bool LDS_CLOUD, bool FUSE>
+static int launch_bq(int b, int n, int m, float thr, int nsample, const float *xyz1, const float *xyz2, int *idx,
+                     int *pts_cnt, float *grouped, int subtract, hipStream_t st)
+{
+    // aim at ~2 workgroups per CU over the whole launch; each stages the cloud once
+    long long total = (long long)b * m;
+    int qpb = (int)((total + 511) / 512);
+    qpb = ((qpb + kBqWaves - 1) / kBqWaves) * kBqWaves;
+    if (qpb < kBqWaves) qpb = kBqWaves;
+    if (qpb > m) qpb = ((m + kBqWaves - 1) / kBqWaves) * kBqWaves;
+    const int gx = (m + qpb - 1) / qpb;
+    const size_t lds = (LDS_CLOUD ? sizeof(float4) * (size_t)n : 0) + sizeof(int) * (size_t)nsample * kBqWaves;
+    if (lds > 160 * 1024) return PN2_E_TOO_LARGE;
+    auto kern = ball_query_kernel<LDS_CLOUD, FUSE>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(gx, b), dim3(kBqThreads), lds, st, n, m, nsample, thr, qpb, xyz1, xyz2, idx,
+                       pts_cnt, grouped, subtract);
+    return launch_status();
+}
+
+static int ball_query_common(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
+                             int subtract, int *idx, int *pts_cnt, float *grouped, bool fuse, void *stream)
+{
+    if (!(radius > 0.0f) || nsample <= 0) return PN2_E_ARG;   // tf_grouping.cpp:71,74
+    if (b < 0 || n <= 0 || m < 0) return PN2_E_SHAPE;
+    if (b == 0 || m == 0) return PN2_OK;
+    if (!xyz1 || !xyz2) return PN2_E_NULL;
+    if (fuse ? !grouped : !idx) return PN2_E_NULL;
+    if ((long long)b * n * 3 > INT_MAX || (long long)b * m * nsample * 3 > (1ll << 40)) return PN2_E_TOO_LARGE;
+    if (b > 65535) return PN2_E_TOO_LARGE;
+    const float thr = pn2_ball_threshold(radius);
+    hipStream_t st = as_stream(stream);
+    const bool lds = n <= kBqMaxLdsPoints &&
+                     sizeof(float4) * (size_t)n + sizeof(int) * (size_t)nsample * kBqWaves <= 160 * 1024;
+    if (fuse)
+        return lds ? launch_bq<true, true>(b, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt, grouped, subtract, st)
+                   : launch_bq<false, true>(b, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt, grouped, subtract, st);
+    return lds ? launch_bq<true, false>(b, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt, nullptr, 0, st)
+               : launch_bq<false, false>(b, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt, nullptr, 0, st);
+}
+
+}  // namespace pn2
+
+// Smallest fp32 s* for which max(sqrtf(s*),1e-20f) < radius is FALSE.
+// The predicate is monotone non-increasing in s >= 0 (sqrtf is correctly rounded,
+// hence monotone), so  in-ball <=> s < s*.  Bisection over the fp32 bit patterns.
+extern "C" float pn2_ball_threshold(float radius)
+{
+    if (!(radius > 0.0f) || !(1e-20f < radius)) return 0.0f;   // nothing is ever inside
+    uint32_t lo = 0u;           // s=+0: predicate true
+    uint32_t hi = 0x7f800000u;  // s=+inf: predicate false
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        float s;
+        memcpy(&s, &mid, sizeof s);
+        const float r = sqrtf(s);
+        const float d = (r < 1e-20f) ? 1e-20f : r;
+        if (d < radius) lo = mid; else hi = mid;
+    }
+    float out;
+    memcpy(&out, &hi, sizeof out);
+    return out;
+}
+
+extern "C" int pn2_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1,
+                                    const float *xyz2, int *idx, int *pts_cnt, void *stream)
+{
+    return pn2::ball_query_common(b, n, m, radius, nsample, xyz1, xyz2, 0, idx, pts_cnt, nullptr, false, stream);
+}
+
+extern "C" int pn2_query_ball_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz1,
+                                        const float *xyz2, int subtract_centroid, int *idx, int *pts_cnt,
+                                        float *grouped_xyz, void *stream)
+{
+    return pn2::ball_query_common(b, n, m, radius, nsample, xyz1, xyz2, subtract_centroid, idx, pts_cnt,
+                                  grouped_xyz, true, stream);
+}

@@ -1,0 +1,276 @@
+// fps.hip -- farthest point sampling for gfx950 (MI355X).
+//
+// Replaces farthestpointsamplingKernel/Launcher (reference
+// tf_ops/sampling/tf_sampling_g.cu:105-170, :203-205). Results are index-exact
+// with that kernel run in CPU arithmetic (oracle/pn2_oracle.c), including its
+// tie rule: among equal running-min distances the point with the smallest
+// (k mod 512, k) wins (512 = the reference's blockDim).
+//
+// Design (DESIGN.md "FPS"). FPS is a chain of m-1 dependent block-wide
+// arg-max steps; it is latency bound, not HBM bound. One workgroup owns one
+// cloud for the whole chain:
+//   * every point's x,y,z and running min-distance live in VGPRs for all m
+//     rounds (no per-round memory traffic at all; the reference round-trips
+//     `temp` through global memory every round);
+//   * points are dealt to threads in TIE-RANK order: thread t holds ranks
+//     t*P .. t*P+P-1 where rank(k) = (k mod 512)*ceil(n/512) + k/512. The
+//     reference's tie rule then degenerates to "first slot, lowest lane,
+//     lowest wave", which costs nothing in the reduction;
+//   * values are compared as signed-int bit patterns (they are >= 0, or -1
+//     for padding slots), so the wave arg-max is 4 DPP v_max_i32 steps,
+//     4 v_readlane, 3 s_max, one v_cmp_eq (the ballot) and an s_ff1;
+//   * one s_barrier per round: per-wave partials go through a parity
+//     double-buffered LDS slot array; every wave redundantly reduces the <=16
+//     partials, then broadcast-reads the winner's xyz from an LDS copy of
+//     the cloud.
+// Clouds too large for the register tiers fall back to a global-memory tier
+// that keeps the running distances in the caller's `temp` buffer.
+#include "pn2_device.h"
+
+#include <limits.h>
+
+namespace pn2 {
+
+constexpr int kRefThreads = 512;  // tie rule modulus: reference blockDim (tf_sampling_g.cu:204)
+
+// ---------------------------------------------------------------------------
+// Register-resident tier.  T threads, P points per thread, n <= T*P.
+// LDSXYZ: keep a float4 copy of the cloud in LDS for the winner broadcast
+// (16 B/point); otherwise the winner is re-read from global memory.
+// ---------------------------------------------------------------------------
+template <int T, int P, bool LDSXYZ>
+__global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int Q, const float *__restrict__ xyz,
+                                                    int *__restrict__ out)
+{
+    constexpr int W = T / PN2_WAVE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int2 *partial = reinterpret_cast<int2 *>(smem);                   // [2][W] (256 B reserved)
+    float4 *lds_xyz = reinterpret_cast<float4 *>(smem + 256);         // [n] when LDSXYZ
+
+    const int cloud = blockIdx.x;
+    const float *__restrict__ src = xyz + (size_t)cloud * n * 3;
+    int *__restrict__ dst = out + (size_t)cloud * m;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = t >> 6;
+
+    if (LDSXYZ) {
+        for (int k = t; k < n; k += T) {
+            const float *p = src + (size_t)k * 3;
+            lds_xyz[k] = make_float4(p[0], p[1], p[2], 0.0f);
+        }
+        __syncthreads();
+    }
+
+    float x[P], y[P], z[P], md[P];
+    int kidx[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int r = t * P + p;                       // tie rank of this slot
+        const int k = (r % Q) * kRefThreads + r / Q;   // original point index
+        const bool valid = (r < kRefThreads * Q) && (k < n);
+        kidx[p] = valid ? k : 0;
+        if (valid) {
+            if (LDSXYZ) {
+                const float4 v = lds_xyz[k];
+                x[p] = v.x; y[p] = v.y; z[p] = v.z;
+            } else {
+                x[p] = src[(size_t)k * 3 + 0]; y[p] = src[(size_t)k * 3 + 1]; z[p] = src[(size_t)k * 3 + 2];
+            }
+            md[p] = 1e38f;   // tf_sampling_g.cu:118
+        } else {
+            x[p] = 0.0f; y[p] = 0.0f; z[p] = 0.0f;
+            md[p] = -1.0f;   // padding slot: below every real value, never selected
+        }
+    }
+
+    int cur = 0;             // tf_sampling_g.cu:114
+    if (t == 0) dst[0] = 0;
+
+    for (int j = 1; j < m; ++j) {
+        float sx, sy, sz;
+        if (LDSXYZ) {
+            const float4 s = lds_xyz[cur];             // same address in every lane: LDS broadcast
+            sx = s.x; sy = s.y; sz = s.z;
+        } else {
+            sx = src[(size_t)cur * 3 + 0]; sy = src[(size_t)cur * 3 + 1]; sz = src[(size_t)cur * 3 + 2];
+        }
+        int bv = INT_MIN, bk = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const float d = sqdist(x[p], y[p], z[p], sx, sy, sz);
+            md[p] = __builtin_fminf(d, md[p]);         // min(d,td), :144
+            const int iv = __float_as_int(md[p]);
+            if (iv > bv) { bv = iv; bk = kidx[p]; }    // strict >, :146
+        }
+        // wave arg-max, ties -> lowest lane
+        const int wm = wave_max_i32(bv);
+        const unsigned long long hit = __ballot(bv == wm);
+        const int wl = __builtin_ctzll(hit);           // hit != 0: the max is held by some lane
+        const int wk = __builtin_amdgcn_readlane(bk, wl);
+        int2 *slot = partial + (j & 1) * W;
+        if (lane == 0) slot[w] = make_int2(wm, wk);
+        __syncthreads();
+        // block arg-max over the W partials, ties -> lowest wave
+        if (W == 1) {
+            cur = wk;
+        } else {
+            int2 pp = make_int2(INT_MIN, 0);
+            if (lane < W) pp = slot[lane];
+            int bm;
+            if (W <= 16) bm = __builtin_amdgcn_readfirstlane(row16_max_i32(pp.x));
+            else bm = wave_max_i32(pp.x);
+            const unsigned long long hit2 = __ballot(pp.x == bm);
+            const int l2 = __builtin_ctzll(hit2);
+            cur = __builtin_amdgcn_readlane(pp.y, l2);
+        }
+        if (t == 0) dst[j] = cur;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Generic tier: any n. Running distances in global `temp` (b*n floats), cloud
+// re-read from global/L2 each round, 64-bit (value, tie-key) reduction.
+// Slow path for clouds beyond the register tiers (n > 16384).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m)
+{
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, m, 64);
+    const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), m, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(1024) void fps_generic_kernel(int n, int m, const float *__restrict__ xyz,
+                                                           float *__restrict__ temp, int *__restrict__ out)
+{
+    constexpr int T = 1024, W = T / PN2_WAVE;
+    __shared__ unsigned long long part[2][W];
+    const int cloud = blockIdx.x;
+    const float *__restrict__ src = xyz + (size_t)cloud * n * 3;
+    float *__restrict__ mind = temp + (size_t)cloud * n;
+    int *__restrict__ dst = out + (size_t)cloud * m;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    for (int k = t; k < n; k += T) mind[k] = 1e38f;
+    int cur = 0;
+    if (t == 0) dst[0] = 0;
+    // each thread only ever touches its own mind[k] (k = t mod T): no barrier needed for temp
+    for (int j = 1; j < m; ++j) {
+        const float sx = src[(size_t)cur * 3 + 0], sy = src[(size_t)cur * 3 + 1], sz = src[(size_t)cur * 3 + 2];
+        unsigned long long best = 0ull;  // (value bits << 32) | ~tiekey ; real candidates are > 0
+        for (int k = t; k < n; k += T) {
+            const float d = sqdist(src[(size_t)k * 3 + 0], src[(size_t)k * 3 + 1], src[(size_t)k * 3 + 2], sx, sy, sz);
+            const float d2 = __builtin_fminf(d, mind[k]);
+            mind[k] = d2;
+            const unsigned tiekey = ((unsigned)(k & (kRefThreads - 1)) << 22) | (unsigned)(k >> 9);
+            const unsigned long long key =
+                ((unsigned long long)(unsigned)__float_as_int(d2) << 32) | (unsigned long long)(0xFFFFFFFFu - tiekey);
+            best = key > best ? key : best;
+        }
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const unsigned long long o = shfl_xor_u64(best, s);
+            best = o > best ? o : best;
+        }
+        if (lane == 0) part[j & 1][w] = best;
+        __syncthreads();
+        unsigned long long v = (lane < W) ? part[j & 1][lane] : 0ull;
+#pragma unroll
+        for (int s = 1; s < W; s <<= 1) {
+            const unsigned long long o = shfl_xor_u64(v, s);
+            v = o > v ? o : v;
+        }
+        const unsigned tiekey = 0xFFFFFFFFu - (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+        cur = (int)(((tiekey & 0x3FFFFFu) << 9) | (tiekey >> 22));
+        if (t == 0) dst[j] = cur;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+template <int T, int P, bool LDSXYZ>
+static int launch_reg(int b, int n, int m, int Q, const float *inp, int *out, hipStream_t st)
+{
+    const size_t lds = 256 + (LDSXYZ ? sizeof(float4) * (size_t)n : 0);
+    auto kern = fps_reg_kernel<T, P, LDSXYZ>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(b), dim3(T), lds, st, n, m, Q, inp, out);
+    return launch_status();
+}
+
+constexpr int kMaxLdsPoints = 10200;   // 256 B + 16 B/point <= 160 KiB
+constexpr int kMaxRegPoints = 16384;
+
+template <int T, bool LDSXYZ>
+static int dispatch_p(int P, int b, int n, int m, int Q, const float *inp, int *out, hipStream_t st)
+{
+    switch (P) {
+    case 1: return launch_reg<T, 1, LDSXYZ>(b, n, m, Q, inp, out, st);
+    case 2: return launch_reg<T, 2, LDSXYZ>(b, n, m, Q, inp, out, st);
+    case 4: return launch_reg<T, 4, LDSXYZ>(b, n, m, Q, inp, out, st);
+    case 8: return launch_reg<T, 8, LDSXYZ>(b, n, m, Q, inp, out, st);
+    case 16: return launch_reg<T, 16, LDSXYZ>(b, n, m, Q, inp, out, st);
+    case 32:
+        if constexpr (T <= 512) return launch_reg<T, 32, LDSXYZ>(b, n, m, Q, inp, out, st);
+        break;
+    default: break;
+    }
+    return PN2_E_ARG;
+}
+
+static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+// force a (T,P) configuration: used by the tuning harness (bench.py --fps-sweep)
+static int fps_launch_config(int T, int P, int b, int n, int m, const float *inp, int *out, hipStream_t st)
+{
+    const int Q = (n + kRefThreads - 1) / kRefThreads;
+    if ((long long)T * P < (long long)kRefThreads * Q) return PN2_E_ARG;
+    const bool lds = n <= kMaxLdsPoints;
+    switch (T) {
+    case 256: return lds ? dispatch_p<256, true>(P, b, n, m, Q, inp, out, st) : dispatch_p<256, false>(P, b, n, m, Q, inp, out, st);
+    case 512: return lds ? dispatch_p<512, true>(P, b, n, m, Q, inp, out, st) : dispatch_p<512, false>(P, b, n, m, Q, inp, out, st);
+    case 1024: return lds ? dispatch_p<1024, true>(P, b, n, m, Q, inp, out, st) : dispatch_p<1024, false>(P, b, n, m, Q, inp, out, st);
+    default: return PN2_E_ARG;
+    }
+}
+
+}  // namespace pn2
+
+extern "C" long long pn2_fps_temp_floats(int b, int n)
+{
+    if (b <= 0 || n <= 0) return 0;
+    return n > pn2::kMaxRegPoints ? (long long)b * n : 0;
+}
+
+extern "C" int pn2_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out, void *stream)
+{
+    using namespace pn2;
+    if (m <= 0 || b == 0) return PN2_OK;          // tf_sampling_g.cu:106
+    if (b < 0 || n <= 0) return PN2_E_SHAPE;
+    if (!inp || !out) return PN2_E_NULL;
+    if ((long long)b * n * 3 > INT_MAX || (long long)b * m > INT_MAX) return PN2_E_TOO_LARGE;
+    hipStream_t st = as_stream(stream);
+    if (n > kMaxRegPoints) {
+        if (!temp) return PN2_E_NULL;
+        hipLaunchKernelGGL(fps_generic_kernel, dim3(b), dim3(1024), 0, st, n, m, inp, temp, out);
+        return launch_status();
+    }
+    const int Q = (n + kRefThreads - 1) / kRefThreads;
+    const int ranks = kRefThreads * Q;
+    // default geometry: as many threads as there are ranks up to 1024, then grow P
+    int T = ranks >= 1024 ? 1024 : 512;
+    int P = next_pow2((ranks + T - 1) / T);
+    return fps_launch_config(T, P, b, n, m, inp, out, st);
+}
+
+// tuning / test hook: run the register tier with an explicit geometry
+extern "C" int pn2_debug_fps_config(int T, int P, int b, int n, int m, const float *inp, int *out, void *stream)
+{
+    if (m <= 0 || b <= 0 || n <= 0 || !inp || !out) return PN2_E_ARG;
+    if (n > pn2::kMaxRegPoints) return PN2_E_TOO_LARGE;
+    return pn2::fps_launch_config(T, P, b, n, m, inp, out, pn2::as_stream(stream));
+}

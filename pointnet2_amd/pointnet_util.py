@@ -1,0 +1,182 @@
+"""PointNet++ layer library on the MI355X operators -- the consumer side of the
+drop-in boundary (reference utils/pointnet_util.py: sample_and_group :22,
+sample_and_group_all :59, pointnet_sa_module :87, pointnet_sa_module_msg :156,
+pointnet_fp_module :199).
+
+The geometric part (sampling, grouping, interpolation) calls the HIP operators;
+the learned part (1x1 conv + BN + ReLU stacks, the reference's tf_util.conv2d)
+is plain torch.nn -- it is outside the hot path this package accelerates.
+TF builds its variables inside `tf.variable_scope`; in torch the equivalent
+state lives in nn.Module objects, so each reference *function* with learned
+weights has a Module twin here (PointnetSAModule, PointnetSAModuleMSG,
+PointnetFPModule) whose forward() follows the reference function line by line
+in behaviour (concat order, pooling modes, weight formula).
+"""
+import torch
+import torch.nn as nn
+
+from .tf_sampling import farthest_point_sample, gather_point
+from .tf_grouping import query_ball_point, group_point, knn_point, query_ball_group_xyz
+from .tf_interpolate import three_nn, three_interpolate
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True, fused=None):
+    """reference: pointnet_util.py:22-56.
+
+    xyz (b, ndataset, 3), points (b, ndataset, channel) or None
+    -> new_xyz (b, npoint, 3), new_points (b, npoint, nsample, 3+channel),
+       idx (b, npoint, nsample), grouped_xyz (b, npoint, nsample, 3)
+
+    fused: use the single-pass ball-query+group+centroid-subtract kernel for the
+    xyz branch (bit-identical values). Default: whenever xyz needs no gradient.
+    """
+    new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))           # :40
+    if fused is None:
+        fused = not (torch.is_grad_enabled() and xyz.requires_grad)
+    if knn:
+        _, idx = knn_point(nsample, xyz, new_xyz)                             # :42
+        grouped_xyz = group_point(xyz, idx) - new_xyz.unsqueeze(2)
+    elif fused:
+        idx, _, grouped_xyz = query_ball_group_xyz(radius, nsample, xyz, new_xyz, subtract_centroid=True)
+    else:
+        idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)              # :44
+        grouped_xyz = group_point(xyz, idx)                                   # :45
+        grouped_xyz = grouped_xyz - new_xyz.unsqueeze(2)                      # :46 translation normalisation
+    if points is not None:
+        grouped_points = group_point(points, idx)                             # :48
+        if use_xyz:
+            new_points = torch.cat([grouped_xyz, grouped_points], dim=-1)     # :50 xyz FIRST
+        else:
+            new_points = grouped_points
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def sample_and_group_all(xyz, points, use_xyz=True):
+    """reference: pointnet_util.py:59-84 (one group holding every point, centroid (0,0,0))."""
+    b, n, _ = xyz.shape
+    new_xyz = torch.zeros((b, 1, 3), dtype=torch.float32, device=xyz.device)
+    idx = torch.arange(n, dtype=torch.int32, device=xyz.device).reshape(1, 1, n).repeat(b, 1, 1)
+    grouped_xyz = xyz.reshape(b, 1, n, 3)
+    if points is not None:
+        new_points = torch.cat([xyz, points], dim=2) if use_xyz else points
+        new_points = new_points.unsqueeze(1)
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def three_nn_weights(xyz1, xyz2):
+    """Inverse-squared-distance weights of pointnet_fp_module (pointnet_util.py:211-215)."""
+    dist, idx = three_nn(xyz1, xyz2)
+    dist = torch.clamp(dist, min=1e-10)                                       # :212
+    inv = 1.0 / dist
+    norm = inv.sum(dim=2, keepdim=True)                                       # :213
+    weight = inv / norm                                                       # :215
+    return idx, weight
+
+
+class _SharedMLP(nn.Module):
+    """Stack of tf_util.conv2d([1,1]) + BN + ReLU (tf_util.py conv2d; BN eps 1e-3 is
+    tf.contrib.layers.batch_norm's default). Operates on (b, C, h, w)."""
+
+    def __init__(self, c_in, widths, bn=True):
+        super().__init__()
+        layers = []
+        for w in widths:
+            layers.append(nn.Conv2d(c_in, w, kernel_size=1, bias=True))
+            if bn:
+                layers.append(nn.BatchNorm2d(w, eps=1e-3))
+            layers.append(nn.ReLU(inplace=True))
+            c_in = w
+        self.net = nn.Sequential(*layers)
+        self.c_out = c_in
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class PointnetSAModule(nn.Module):
+    """reference: pointnet_sa_module, pointnet_util.py:87-154."""
+
+    def __init__(self, c_in, npoint, radius, nsample, mlp, mlp2=None, group_all=False, bn=True, pooling="max",
+                 knn=False, use_xyz=True):
+        super().__init__()
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.group_all, self.pooling, self.knn, self.use_xyz = group_all, pooling, knn, use_xyz
+        feat = 3 if c_in == 0 else (c_in + 3 if use_xyz else c_in)
+        self.mlp = _SharedMLP(feat, mlp, bn)
+        c = self.mlp.c_out * (2 if pooling == "max_and_avg" else 1)
+        self.mlp2 = _SharedMLP(c, mlp2, bn) if mlp2 else None
+
+    def forward(self, xyz, points):
+        if self.group_all:
+            new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, self.use_xyz)
+        else:
+            new_xyz, new_points, idx, grouped_xyz = sample_and_group(self.npoint, self.radius, self.nsample, xyz,
+                                                                     points, self.knn, self.use_xyz)
+        x = self.mlp(new_points.permute(0, 3, 1, 2))                 # (b, C, npoint, nsample)
+        if self.pooling == "max":
+            x = x.max(dim=3, keepdim=True)[0]
+        elif self.pooling == "avg":
+            x = x.mean(dim=3, keepdim=True)
+        elif self.pooling == "weighted_avg":                          # :130-136
+            dists = grouped_xyz.norm(dim=-1, keepdim=True)
+            w = torch.exp(-dists * 5)
+            w = (w / w.sum(dim=2, keepdim=True)).permute(0, 3, 1, 2)
+            x = (x * w).sum(dim=3, keepdim=True)
+        elif self.pooling == "max_and_avg":                           # :137-140: concat([avg, max])
+            x = torch.cat([x.mean(dim=3, keepdim=True), x.max(dim=3, keepdim=True)[0]], dim=1)
+        else:
+            raise ValueError("unknown pooling %r" % (self.pooling,))
+        if self.mlp2 is not None:
+            x = self.mlp2(x)
+        return new_xyz, x.squeeze(3).permute(0, 2, 1).contiguous(), idx
+
+
+class PointnetSAModuleMSG(nn.Module):
+    """reference: pointnet_sa_module_msg, pointnet_util.py:156-196 (one FPS, several radii;
+    concat order features FIRST, :184 -- the opposite of the single-scale module)."""
+
+    def __init__(self, c_in, npoint, radius_list, nsample_list, mlp_list, bn=True, use_xyz=True):
+        super().__init__()
+        self.npoint, self.radius_list, self.nsample_list, self.use_xyz = npoint, radius_list, nsample_list, use_xyz
+        feat = 3 if c_in == 0 else (c_in + 3 if use_xyz else c_in)
+        self.mlps = nn.ModuleList([_SharedMLP(feat, widths, bn) for widths in mlp_list])
+
+    def forward(self, xyz, points):
+        new_xyz = gather_point(xyz, farthest_point_sample(self.npoint, xyz))   # :173
+        fused = not (torch.is_grad_enabled() and xyz.requires_grad)
+        outs = []
+        for radius, nsample, mlp in zip(self.radius_list, self.nsample_list, self.mlps):
+            if fused:
+                idx, _, grouped_xyz = query_ball_group_xyz(radius, nsample, xyz, new_xyz, True,
+                                                           want_idx=points is not None)
+            else:
+                idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)       # :178
+                grouped_xyz = group_point(xyz, idx) - new_xyz.unsqueeze(2)     # :179-180
+            if points is not None:
+                grouped = group_point(points, idx)                             # :182
+                if self.use_xyz:
+                    grouped = torch.cat([grouped, grouped_xyz], dim=-1)        # :184 features FIRST
+            else:
+                grouped = grouped_xyz
+            x = mlp(grouped.permute(0, 3, 1, 2))
+            outs.append(x.max(dim=3)[0])                                        # :193
+        return new_xyz, torch.cat(outs, dim=1).permute(0, 2, 1).contiguous()    # :195
+
+
+class PointnetFPModule(nn.Module):
+    """reference: pointnet_fp_module, pointnet_util.py:199-229."""
+
+    def __init__(self, c_in, mlp, bn=True):
+        super().__init__()
+        self.mlp = _SharedMLP(c_in, mlp, bn)
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        idx, weight = three_nn_weights(xyz1, xyz2)                              # :211-215
+        interpolated = three_interpolate(points2, idx, weight)                  # :216
+        x = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated   # :219
+        x = self.mlp(x.permute(0, 2, 1).unsqueeze(2))                           # (b, C, 1, n)
+        return x.squeeze(2).permute(0, 2, 1).contiguous()

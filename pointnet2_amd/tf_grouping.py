@@ -1,0 +1,151 @@
+"""Grouping ops -- the Python surface of the reference's tf_ops/grouping/tf_grouping.py
+(query_ball_point :8, select_top_k :22, group_point :33, knn_point :48) on torch
+tensors resident on an MI355X, backed by csrc/ball_query.hip, group.hip and
+topk.hip through the C ABI (include/pn2ops.h).
+
+Differentiability as registered in the reference: GroupPoint has a gradient
+w.r.t. `points` (tf_grouping.py:42-46); QueryBallPoint and SelectionSort are
+NoGradient (:21, :32).
+"""
+import torch
+
+from . import _C
+from ._tensors import f32, i32, ptr, require, same_device, stream_ptr
+
+
+def query_ball_point(radius, nsample, xyz1, xyz2):
+    """radius float, nsample int, xyz1 (b, ndataset, 3), xyz2 (b, npoint, 3)
+    -> idx (b, npoint, nsample) i32, pts_cnt (b, npoint) i32.
+
+    reference: tf_grouping.py:8-20, op QueryBallPoint tf_grouping.cpp:67-106.
+    """
+    require(float(radius) > 0, "QueryBallPoint expects positive radius")
+    require(int(nsample) > 0, "QueryBallPoint expects positive nsample")
+    xyz1 = f32(xyz1.detach(), "xyz1")
+    xyz2 = f32(xyz2.detach(), "xyz2")
+    require(xyz1.dim() == 3 and xyz1.shape[2] == 3, "QueryBallPoint expects (batch_size, ndataset, 3) xyz1 shape.")
+    require(xyz2.dim() == 3 and xyz2.shape[2] == 3 and xyz2.shape[0] == xyz1.shape[0],
+            "QueryBallPoint expects (batch_size, npoint, 3) xyz2 shape.")
+    dev = same_device(xyz1, xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    ns = int(nsample)
+    idx = torch.empty((b, m, ns), dtype=torch.int32, device=dev)
+    cnt = torch.empty((b, m), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _C.check(_C.lib().pn2_query_ball_point(b, n, m, float(radius), ns, ptr(xyz1), ptr(xyz2), ptr(idx), ptr(cnt),
+                                               stream_ptr(dev)), "query_ball_point")
+    return idx, cnt
+
+
+def query_ball_group_xyz(radius, nsample, xyz1, xyz2, subtract_centroid=True, want_idx=True):
+    """Fused query_ball_point + group_point(xyz1, idx) [- centroid] in one pass
+    (what pointnet_util.py:44-46 does with three ops). No reference counterpart
+    (SURVEY.md 8f1); NOT differentiable -- used on the inference path and by
+    sample_and_group when xyz does not require grad.
+
+    -> idx (b,m,nsample) i32 or None, pts_cnt (b,m) i32, grouped_xyz (b,m,nsample,3) f32
+    """
+    require(float(radius) > 0, "QueryBallPoint expects positive radius")
+    require(int(nsample) > 0, "QueryBallPoint expects positive nsample")
+    xyz1 = f32(xyz1.detach(), "xyz1")
+    xyz2 = f32(xyz2.detach(), "xyz2")
+    require(xyz1.dim() == 3 and xyz1.shape[2] == 3, "QueryBallPoint expects (batch_size, ndataset, 3) xyz1 shape.")
+    require(xyz2.dim() == 3 and xyz2.shape[2] == 3 and xyz2.shape[0] == xyz1.shape[0],
+            "QueryBallPoint expects (batch_size, npoint, 3) xyz2 shape.")
+    dev = same_device(xyz1, xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    ns = int(nsample)
+    idx = torch.empty((b, m, ns), dtype=torch.int32, device=dev) if want_idx else None
+    cnt = torch.empty((b, m), dtype=torch.int32, device=dev)
+    grouped = torch.empty((b, m, ns, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _C.check(_C.lib().pn2_query_ball_group_xyz(b, n, m, float(radius), ns, ptr(xyz1), ptr(xyz2),
+                                                   1 if subtract_centroid else 0, ptr(idx), ptr(cnt), ptr(grouped),
+                                                   stream_ptr(dev)), "query_ball_group_xyz")
+    return idx, cnt, grouped
+
+
+def select_top_k(k, dist):
+    """k int, dist (b, m, n) f32 -> idx (b, m, n) i32, dist_out (b, m, n) f32;
+    the first k entries of each row are the k smallest, ascending.
+
+    reference: tf_grouping.py:22-31, op SelectionSort tf_grouping.cpp:109-139.
+    """
+    require(int(k) > 0, "SelectionSort expects positive k")
+    dist = f32(dist.detach(), "dist")
+    require(dist.dim() == 3, "SelectionSort expects (b,m,n) dist shape.")
+    b, m, n = dist.shape
+    dev = dist.device
+    outi = torch.empty((b, m, n), dtype=torch.int32, device=dev)
+    out = torch.empty((b, m, n), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _C.check(_C.lib().pn2_selection_sort(b, n, m, int(k), ptr(dist), ptr(outi), ptr(out), stream_ptr(dev)),
+                 "select_top_k")
+    return outi, out
+
+
+class _GroupPoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx):
+        b, n, c = points.shape
+        _, m, ns = idx.shape
+        dev = points.device
+        out = torch.empty((b, m, ns, c), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _C.check(_C.lib().pn2_group_point(b, n, c, m, ns, ptr(points), ptr(idx), ptr(out), stream_ptr(dev)),
+                     "group_point")
+        ctx.save_for_backward(idx)
+        ctx.shape = (b, n, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        b, n, c = ctx.shape
+        _, m, ns = idx.shape
+        dev = grad_out.device
+        grad_points = torch.empty((b, n, c), dtype=torch.float32, device=dev)   # zero-filled by the library
+        with torch.cuda.device(dev):
+            _C.check(_C.lib().pn2_group_point_grad(b, n, c, m, ns, ptr(grad_out), ptr(idx), ptr(grad_points),
+                                                   stream_ptr(dev)), "group_point_grad")
+        return grad_points, None
+
+
+def group_point(points, idx):
+    """points (b, ndataset, channel) f32, idx (b, npoint, nsample) i32
+    -> (b, npoint, nsample, channel) f32.
+
+    reference: tf_grouping.py:33-41, op GroupPoint tf_grouping.cpp:143-171.
+    """
+    points = f32(points, "points")
+    idx = i32(idx, "idx")
+    require(points.dim() == 3, "GroupPoint expects (batch_size, num_points, channel) points shape")
+    require(idx.dim() == 3 and idx.shape[0] == points.shape[0],
+            "GroupPoint expects (batch_size, npoints, nsample) idx shape")
+    same_device(points, idx)
+    return _GroupPoint.apply(points, idx)
+
+
+def knn_point(k, xyz1, xyz2):
+    """k int, xyz1 (b, ndataset, c), xyz2 (b, npoint, c) -> val (b, npoint, k) f32
+    squared L2 distances, idx (b, npoint, k) i32.
+
+    reference: tf_grouping.py:48-73 -- a pairwise squared-distance matrix
+    reduce_sum((xyz1-xyz2)**2, -1) followed by select_top_k and a slice.
+    The matrix is built with torch elementwise ops (same per-pair arithmetic:
+    differences, squares, a sum over c), the selection is the HIP selection sort.
+    """
+    xyz1 = f32(xyz1.detach(), "xyz1")
+    xyz2 = f32(xyz2.detach(), "xyz2")
+    require(xyz1.dim() == 3 and xyz2.dim() == 3 and xyz1.shape[0] == xyz2.shape[0] and
+            xyz1.shape[2] == xyz2.shape[2], "knn_point expects (b,n,c) xyz1 and (b,m,c) xyz2")
+    diff = xyz1.unsqueeze(1) - xyz2.unsqueeze(2)           # (b, m, n, c)
+    sq = diff * diff
+    dist = sq[..., 0].clone()
+    for ch in range(1, sq.shape[-1]):                      # fixed left-to-right sum over c
+        dist += sq[..., ch]
+    outi, out = select_top_k(k, dist)
+    return out[:, :, :k].contiguous(), outi[:, :, :k].contiguous()

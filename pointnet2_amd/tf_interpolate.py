@@ -1,0 +1,82 @@
+"""Interpolation ops -- the Python surface of the reference's
+tf_ops/3d_interpolation/tf_interpolate.py (three_nn :8, three_interpolate :19) on
+torch tensors resident on an MI355X, backed by csrc/interpolate.hip through the
+C ABI (include/pn2ops.h). The reference runs these ops on the CPU only
+(tf_interpolate.cpp:187,222,262).
+
+Differentiability as registered in the reference: ThreeInterpolate has a
+gradient w.r.t. `points` only (tf_interpolate.py:29-34); ThreeNN is NoGradient (:18).
+"""
+import torch
+
+from . import _C
+from ._tensors import f32, i32, ptr, require, same_device, stream_ptr
+
+
+def three_nn(xyz1, xyz2):
+    """xyz1 (b, n, 3) unknown, xyz2 (b, m, 3) known -> dist (b, n, 3) f32 SQUARED
+    distances ascending, idx (b, n, 3) i32.
+
+    reference: tf_interpolate.py:8-17, op ThreeNN tf_interpolate.cpp:157-187,
+    loop threenn_cpu :60-103.
+    """
+    xyz1 = f32(xyz1.detach(), "xyz1")
+    xyz2 = f32(xyz2.detach(), "xyz2")
+    require(xyz1.dim() == 3 and xyz1.shape[2] == 3, "ThreeNN expects (b,n,3) xyz1 shape")
+    require(xyz2.dim() == 3 and xyz2.shape[2] == 3 and xyz2.shape[0] == xyz1.shape[0],
+            "ThreeNN expects (b,m,3) xyz2 shape")
+    dev = same_device(xyz1, xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    dist = torch.empty((b, n, 3), dtype=torch.float32, device=dev)
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _C.check(_C.lib().pn2_three_nn(b, n, m, ptr(xyz1), ptr(xyz2), ptr(dist), ptr(idx), stream_ptr(dev)),
+                 "three_nn")
+    return dist, idx
+
+
+class _ThreeInterpolate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx, weight):
+        b, m, c = points.shape
+        n = idx.shape[1]
+        dev = points.device
+        out = torch.empty((b, n, c), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _C.check(_C.lib().pn2_three_interpolate(b, m, c, n, ptr(points), ptr(idx), ptr(weight), ptr(out),
+                                                    stream_ptr(dev)), "three_interpolate")
+        ctx.save_for_backward(idx, weight)
+        ctx.shape = (b, m, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        b, m, c = ctx.shape
+        n = idx.shape[1]
+        dev = grad_out.device
+        grad_points = torch.empty((b, m, c), dtype=torch.float32, device=dev)   # zero-filled by the library
+        with torch.cuda.device(dev):
+            _C.check(_C.lib().pn2_three_interpolate_grad(b, n, c, m, ptr(grad_out), ptr(idx), ptr(weight),
+                                                         ptr(grad_points), stream_ptr(dev)),
+                     "three_interpolate_grad")
+        return grad_points, None, None
+
+
+def three_interpolate(points, idx, weight):
+    """points (b, m, c) f32 known features, idx (b, n, 3) i32, weight (b, n, 3) f32
+    -> (b, n, c) f32.
+
+    reference: tf_interpolate.py:19-28, op ThreeInterpolate tf_interpolate.cpp:191-222.
+    """
+    points = f32(points, "points")
+    idx = i32(idx, "idx")
+    weight = f32(weight.detach(), "weight")
+    require(points.dim() == 3, "ThreeInterpolate expects (b,m,c) points shape")
+    b = points.shape[0]
+    require(idx.dim() == 3 and idx.shape[0] == b and idx.shape[2] == 3, "ThreeInterpolate expects (b,n,3) idx shape")
+    require(weight.dim() == 3 and weight.shape == idx.shape, "ThreeInterpolate expects (b,n,3) weight shape")
+    same_device(points, idx, weight)
+    return _ThreeInterpolate.apply(points, idx, weight)

@@ -1,0 +1,97 @@
+"""Sampling ops -- the Python surface of the reference's tf_ops/sampling/tf_sampling.py
+(prob_sample :13, gather_point :29, farthest_point_sample :48), on torch tensors
+resident on an MI355X, backed by the HIP kernels in csrc/fps.hip, group.hip and
+prob_sample.hip through the C ABI (include/pn2ops.h).
+
+Same names, argument order (hyper-parameters first, tensors last) and return
+arity as the reference; differentiability as registered there: GatherPoint has a
+gradient w.r.t. its first input (tf_sampling.py:43-47), FarthestPointSample and
+ProbSample are NoGradient (:22, :57).
+"""
+import torch
+
+from . import _C
+from ._tensors import f32, i32, ptr, require, same_device, stream_ptr
+
+
+def prob_sample(inp, inpr):
+    """inp (b, ncategory) f32 weights, inpr (b, npoints) f32 uniforms -> (b, npoints) i32.
+
+    reference: tf_sampling.py:13-21, op ProbSample tf_sampling.cpp:66-92.
+    """
+    inp = f32(inp, "inp")
+    inpr = f32(inpr, "inpr")
+    require(inp.dim() == 2, "ProbSample expects (batch_size,num_choices) inp shape")
+    b, n = inp.shape
+    require(inpr.dim() == 2 and inpr.shape[0] == b, "ProbSample expects (batch_size,num_points) inpr shape")
+    m = inpr.shape[1]
+    dev = same_device(inp, inpr)
+    out = torch.empty((b, m), dtype=torch.int32, device=dev)
+    temp = torch.empty((b, n), dtype=torch.float32, device=dev)   # allocate_temp, tf_sampling.cpp:87
+    with torch.cuda.device(dev):
+        _C.check(_C.lib().pn2_prob_sample(b, n, m, ptr(inp), ptr(inpr), ptr(temp), ptr(out), stream_ptr(dev)),
+                 "prob_sample")
+    return out
+
+
+class _GatherPoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, idx):
+        b, n, _ = inp.shape
+        m = idx.shape[1]
+        dev = inp.device
+        out = torch.empty((b, m, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _C.check(_C.lib().pn2_gather_point(b, n, m, ptr(inp), ptr(idx), ptr(out), stream_ptr(dev)),
+                     "gather_point")
+        ctx.save_for_backward(idx)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, out_g):
+        (idx,) = ctx.saved_tensors
+        out_g = out_g.contiguous()
+        b, m = idx.shape
+        dev = out_g.device
+        inp_g = torch.empty((b, ctx.n, 3), dtype=torch.float32, device=dev)   # zero-filled by the library
+        with torch.cuda.device(dev):
+            _C.check(_C.lib().pn2_gather_point_grad(b, ctx.n, m, ptr(out_g), ptr(idx), ptr(inp_g), stream_ptr(dev)),
+                     "gather_point_grad")
+        return inp_g, None
+
+
+def gather_point(inp, idx):
+    """inp (b, ndataset, 3) f32, idx (b, npoints) i32 -> (b, npoints, 3) f32.
+
+    reference: tf_sampling.py:29-37, op GatherPoint tf_sampling.cpp:126-148.
+    """
+    inp = f32(inp, "inp")
+    idx = i32(idx, "idx")
+    require(inp.dim() == 3 and inp.shape[2] == 3, "GatherPoint expects (batch_size,num_points,3) inp shape")
+    require(idx.dim() == 2 and idx.shape[0] == inp.shape[0], "GatherPoint expects (batch_size,num_result) idx shape")
+    same_device(inp, idx)
+    return _GatherPoint.apply(inp, idx)
+
+
+def farthest_point_sample(npoint, inp):
+    """npoint int, inp (b, ndataset, 3) f32 -> (b, npoint) i32, first index 0.
+
+    reference: tf_sampling.py:48-56, op FarthestPointSample tf_sampling.cpp:95-123,
+    kernel tf_sampling_g.cu:105-170 (tie rule: smallest (k mod 512, k)).
+    """
+    require(int(npoint) > 0, "FarthestPointSample expects positive npoint")
+    inp = f32(inp.detach() if isinstance(inp, torch.Tensor) else inp, "inp")
+    require(inp.dim() == 3 and inp.shape[2] == 3, "FarthestPointSample expects (batch_size,num_points,3) inp shape")
+    b, n, _ = inp.shape
+    require(n > 0 or b == 0, "FarthestPointSample expects at least one point per cloud")
+    m = int(npoint)
+    dev = inp.device
+    out = torch.empty((b, m), dtype=torch.int32, device=dev)
+    lib = _C.lib()
+    tf = lib.pn2_fps_temp_floats(b, n)
+    temp = torch.empty((tf,), dtype=torch.float32, device=dev) if tf > 0 else None   # allocate_temp, tf_sampling.cpp:115
+    with torch.cuda.device(dev):
+        _C.check(lib.pn2_farthest_point_sample(b, n, m, ptr(inp), ptr(temp), ptr(out), stream_ptr(dev)),
+                 "farthest_point_sample")
+    return out

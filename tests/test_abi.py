@@ -1,0 +1,109 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads (hipcc cross-compiles
+without a GPU) and exports every symbol include/pn2ops.h declares; the host-side
+wrappers validate like the reference's OP_REQUIRES checks; and the product never
+reaches for the oracle or a CPU fallback."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "pn2ops.h")
+
+
+def _declared():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pn2_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pointnet2_amd import _C
+    lib = ctypes.CDLL(_C.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), "libpn2ops.so does not export %s" % n
+    assert names == _C.EXPORTED                      # the Python binding covers the whole header
+    assert "gfx950" in _C.version()
+
+
+def test_library_contains_gfx950_code_object():
+    from pointnet2_amd import _C
+    blob = open(_C.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for kern in (b"fps_reg_kernel", b"ball_query_kernel", b"group_point", b"three_nn_kernel"):
+        assert kern in blob
+
+
+def test_ball_threshold_host_matches_oracle(oracle):
+    from pointnet2_amd import _C
+    for r in (0.05, 0.1, 0.2, 0.3, 0.4, 0.8, 1.0, 2.5, 1e-19, 1e-21, 7e-3):
+        assert _C.lib().pn2_ball_threshold(r) == oracle.ball_threshold(r)
+
+
+def test_c_abi_argument_validation_without_gpu():
+    """Invalid arguments are rejected before any launch (negative return codes)."""
+    from pointnet2_amd import _C
+    lib = _C.lib()
+    assert lib.pn2_query_ball_point(1, 8, 4, 0.0, 4, None, None, None, None, None) == -3      # radius
+    assert lib.pn2_query_ball_point(1, 8, 4, 0.1, 0, None, None, None, None, None) == -3      # nsample
+    assert lib.pn2_query_ball_point(1, 8, 4, 0.1, 4, None, None, None, None, None) == -1      # null
+    assert lib.pn2_farthest_point_sample(2, 0, 4, None, None, None, None) == -2               # n<=0
+    assert lib.pn2_farthest_point_sample(2, 16, 0, None, None, None, None) == 0               # m<=0: no-op
+    assert lib.pn2_farthest_point_sample(2, 16, 4, None, None, None, None) == -1
+    assert lib.pn2_selection_sort(1, 4, 2, 0, None, None, None, None) == -3                   # k
+    assert lib.pn2_group_point(1, 4, 0, 2, 2, None, None, None, None) == -2                   # c
+    assert lib.pn2_three_interpolate(1, 0, 4, 2, None, None, None, None, None) == -2
+    assert lib.pn2_fps_temp_floats(4, 4096) == 0 and lib.pn2_fps_temp_floats(2, 20000) == 40000
+
+
+def test_python_wrappers_validate_like_op_requires():
+    import pointnet2_amd as P
+    x = torch.zeros(2, 16, 3)
+    with pytest.raises(ValueError, match="ROCm device"):
+        P.farthest_point_sample(4, x)                     # CPU tensors are refused: no CPU path
+    with pytest.raises(ValueError, match="positive npoint"):
+        P.farthest_point_sample(0, x)
+    with pytest.raises(ValueError, match="positive radius"):
+        P.query_ball_point(0.0, 4, x, x)
+    with pytest.raises(ValueError, match="positive nsample"):
+        P.query_ball_point(0.1, 0, x, x)
+    with pytest.raises(ValueError, match="float32"):
+        P.gather_point(x.double(), torch.zeros(2, 4, dtype=torch.int32))
+    with pytest.raises(ValueError, match="positive k"):
+        P.select_top_k(0, torch.zeros(1, 2, 4))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """With libpn2ops.so absent the operators raise; nothing falls back to CPU code."""
+    code = (
+        "import sys, os\n"
+        "sys.path.insert(0, %r)\n"
+        "import pointnet2_amd._C as C\n"
+        "C.LIB_PATH = os.path.join(%r, 'nope.so')\n"
+        "C._lib = None\n"
+        "try:\n"
+        "    C.lib()\n"
+        "except C.Pn2LibraryMissing as e:\n"
+        "    print('RAISED', 'no CPU fallback' in str(e).lower() or 'no cpu fallback' in str(e).lower())\n"
+    ) % (ROOT, str(tmp_path))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "RAISED True" in out.stdout, out.stdout + out.stderr
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: no file under pointnet2_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "pointnet2_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), f
+                assert "pn2_cpu_" not in txt, f
+                assert "libpn2_oracle" not in txt, f
