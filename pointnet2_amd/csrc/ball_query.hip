@@ -15,8 +15,11 @@
 // candidates at a time in ascending index order: the cloud is staged once per
 // workgroup in LDS as float4 (one ds_read_b128 per lane per step), the hit
 // mask is a v_cmp (ballot), v_mbcnt gives each hit its ordered output slot,
-// and the sweep stops (wave-uniformly) as soon as nsample hits are in. The
-// result row is assembled in an LDS row buffer and leaves the CU as ONE
+// and the sweep stops (wave-uniformly) as soon as nsample hits are in. A wave
+// sweeps TWO queries at once over 128 candidates per trip, so every LDS read
+// feeds two distance chains and four independent chains are in flight per lane
+// (the one-query, one-chunk first version was latency bound: 123 us at the
+// metric shape). The result row is assembled in an LDS row buffer and leaves the CU as ONE
 // coalesced store per query (the reference scatters 4-byte stores). With
 // FUSE the same epilogue also emits xyz1[idx]-centroid straight from the LDS
 // copy of the cloud (pointnet_util.py:44-46 needs three ops and two extra
@@ -29,9 +32,47 @@
 
 namespace pn2 {
 
-constexpr int kBqThreads = 256;
+constexpr int kBqThreads = 512;
 constexpr int kBqWaves = kBqThreads / PN2_WAVE;
+constexpr int kBqQpw = 2;              // queries swept together by one wave (each LDS read serves both)
 constexpr int kBqMaxLdsPoints = 9600;  // 16 B/point + row buffers must stay under 160 KiB
+
+// ordered append of one 64-candidate chunk's hits to a query's row buffer (wave-uniform control flow)
+__device__ __forceinline__ void bq_append(unsigned long long mask, bool hit, int k, int chunk_base, int nsample,
+                                          int *rowbuf, int &cnt, int &first)
+{
+    if (mask != 0ull && cnt < nsample) {
+        const int pos = cnt + mbcnt(mask);
+        if (hit && pos < nsample) rowbuf[pos] = k;
+        if (cnt == 0) first = chunk_base + __builtin_ctzll(mask);
+        cnt += __popcll(mask);
+    }
+}
+
+template <bool LDS_CLOUD, bool FUSE>
+__device__ __forceinline__ void bq_emit(size_t row, int nsample, int cnt, int first, const int *rowbuf,
+                                        const float4 *cloud, const float *__restrict__ data, float qx, float qy,
+                                        float qz, int *__restrict__ idx, int *__restrict__ pts_cnt,
+                                        float *__restrict__ grouped, int subtract, int lane)
+{
+    for (int l = lane; l < nsample; l += 64) {
+        const int v = (l < cnt) ? rowbuf[l] : first;
+        if (idx) idx[row * nsample + l] = v;
+        if (FUSE) {
+            float gx, gy, gz;
+            if (LDS_CLOUD) {
+                const float4 p = cloud[v];
+                gx = p.x; gy = p.y; gz = p.z;
+            } else {
+                gx = data[(size_t)v * 3 + 0]; gy = data[(size_t)v * 3 + 1]; gz = data[(size_t)v * 3 + 2];
+            }
+            if (subtract) { gx = __fsub_rn(gx, qx); gy = __fsub_rn(gy, qy); gz = __fsub_rn(gz, qz); }
+            float *o = grouped + (row * nsample + l) * 3;
+            o[0] = gx; o[1] = gy; o[2] = gz;
+        }
+    }
+    if (lane == 0 && pts_cnt) pts_cnt[row] = cnt;
+}
 
 template <bool LDS_CLOUD, bool FUSE>
 __global__ __launch_bounds__(kBqThreads) void ball_query_kernel(int n, int m, int nsample, float thr, int qpb,
@@ -42,73 +83,79 @@ __global__ __launch_bounds__(kBqThreads) void ball_query_kernel(int n, int m, in
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *cloud = reinterpret_cast<float4 *>(smem);                                   // [n] when LDS_CLOUD
-    int *rowbuf_all = reinterpret_cast<int *>(smem + (LDS_CLOUD ? sizeof(float4) * (size_t)n : 0));
+    int *rowbuf_all = reinterpret_cast<int *>(smem + (LDS_CLOUD ? sizeof(float4) * (size_t)((n + 127) & ~127) : 0));
 
     const int bi = blockIdx.y;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const float *__restrict__ data = xyz1 + (size_t)bi * n * 3;
-    int *rowbuf = rowbuf_all + w * nsample;
+    int *rowbuf0 = rowbuf_all + (w * kBqQpw + 0) * nsample;
+    int *rowbuf1 = rowbuf_all + (w * kBqQpw + 1) * nsample;
 
+    // LDS copy of the cloud, padded to a multiple of 128 with points at +inf: a padded candidate's
+    // distance is +inf (or NaN), never < thr, so the sweep needs no bounds predicate.
+    const int npad = (n + 127) & ~127;
     if (LDS_CLOUD) {
-        for (int k = t; k < n; k += kBqThreads) {
-            const float *p = data + (size_t)k * 3;
-            cloud[k] = make_float4(p[0], p[1], p[2], 0.0f);
+        for (int k = t; k < npad; k += kBqThreads) {
+            if (k < n) {
+                const float *p = data + (size_t)k * 3;
+                cloud[k] = make_float4(p[0], p[1], p[2], 0.0f);
+            } else {
+                cloud[k] = make_float4(INFINITY, INFINITY, INFINITY, 0.0f);
+            }
         }
         __syncthreads();
     }
 
     const int q0 = blockIdx.x * qpb;
     const int q1 = min(q0 + qpb, m);
-    for (int j = q0 + w; j < q1; j += kBqWaves) {
-        const size_t row = (size_t)bi * m + j;
-        const float qx = xyz2[row * 3 + 0], qy = xyz2[row * 3 + 1], qz = xyz2[row * 3 + 2];
-        int cnt = 0;     // wave-uniform
-        int first = 0;   // index of the first hit (pads the row), 0 when the ball is empty
-        for (int base = 0; base < n && cnt < nsample; base += 64) {
-            const int k = base + lane;
-            const bool valid = k < n;
-            const int kk = valid ? k : n - 1;
-            float px, py, pz;
+    for (int j = q0 + w * kBqQpw; j < q1; j += kBqWaves * kBqQpw) {
+        const bool two = (j + 1) < q1;                       // wave-uniform
+        const size_t row0 = (size_t)bi * m + j;
+        const size_t row1 = row0 + (two ? 1 : 0);
+        const float ax = xyz2[row0 * 3 + 0], ay = xyz2[row0 * 3 + 1], az = xyz2[row0 * 3 + 2];
+        const float bx = xyz2[row1 * 3 + 0], by = xyz2[row1 * 3 + 1], bz = xyz2[row1 * 3 + 2];
+        int cnt0 = 0, cnt1 = two ? 0 : nsample;              // wave-uniform hit counters
+        int first0 = 0, first1 = 0;                          // first hit pads the row; 0 when the ball is empty
+        // 128 candidates per trip: two chunks x two queries = four independent distance chains per lane
+        for (int base = 0; base < n && (cnt0 < nsample || cnt1 < nsample); base += 128) {
+            const int kA = base + lane, kB = base + 64 + lane;
+            float pax, pay, paz, pbx, pby, pbz;
             if (LDS_CLOUD) {
-                const float4 p = cloud[kk];
-                px = p.x; py = p.y; pz = p.z;
+                const float4 pa = cloud[kA];
+                const float4 pb = cloud[kB];
+                pax = pa.x; pay = pa.y; paz = pa.z; pbx = pb.x; pby = pb.y; pbz = pb.z;
             } else {
-                px = data[(size_t)kk * 3 + 0]; py = data[(size_t)kk * 3 + 1]; pz = data[(size_t)kk * 3 + 2];
+                const float inf = INFINITY;
+                const float *pa = data + (size_t)min(kA, n - 1) * 3;
+                const float *pb = data + (size_t)min(kB, n - 1) * 3;
+                pax = kA < n ? pa[0] : inf; pay = pa[1]; paz = pa[2];
+                pbx = kB < n ? pb[0] : inf; pby = pb[1]; pbz = pb[2];
             }
             // reference operand order: (x2-x1) with x2 the query (query_ball_point.cpp:26-32)
-            const float s = sqdist(qx, qy, qz, px, py, pz);
-            const bool hit = valid && (s < thr);
-            const unsigned long long mask = __ballot(hit);
-            if (mask != 0ull) {
-                const int pos = cnt + mbcnt(mask);
-                if (hit && pos < nsample) rowbuf[pos] = k;
-                if (cnt == 0) first = base + __builtin_ctzll(mask);
-                cnt += __popcll(mask);
-            }
+            const float sA0 = sqdist(ax, ay, az, pax, pay, paz);
+            const float sB0 = sqdist(ax, ay, az, pbx, pby, pbz);
+            const float sA1 = sqdist(bx, by, bz, pax, pay, paz);
+            const float sB1 = sqdist(bx, by, bz, pbx, pby, pbz);
+            const bool hA0 = sA0 < thr, hB0 = sB0 < thr, hA1 = sA1 < thr, hB1 = sB1 < thr;
+            const unsigned long long mA0 = __ballot(hA0), mB0 = __ballot(hB0);
+            const unsigned long long mA1 = __ballot(hA1), mB1 = __ballot(hB1);
+            bq_append(mA0, hA0, kA, base, nsample, rowbuf0, cnt0, first0);
+            bq_append(mB0, hB0, kB, base + 64, nsample, rowbuf0, cnt0, first0);
+            bq_append(mA1, hA1, kA, base, nsample, rowbuf1, cnt1, first1);
+            bq_append(mB1, hB1, kB, base + 64, nsample, rowbuf1, cnt1, first1);
         }
-        cnt = min(cnt, nsample);
+        cnt0 = min(cnt0, nsample);
+        cnt1 = min(cnt1, nsample);
         // LDS ops of one wave execute in order; only the compiler must not reorder
         asm volatile("" ::: "memory");
-        for (int l = lane; l < nsample; l += 64) {
-            const int v = (l < cnt) ? rowbuf[l] : first;
-            if (idx) idx[row * nsample + l] = v;
-            if (FUSE) {
-                float gx, gy, gz;
-                if (LDS_CLOUD) {
-                    const float4 p = cloud[v];
-                    gx = p.x; gy = p.y; gz = p.z;
-                } else {
-                    gx = data[(size_t)v * 3 + 0]; gy = data[(size_t)v * 3 + 1]; gz = data[(size_t)v * 3 + 2];
-                }
-                if (subtract) { gx = __fsub_rn(gx, qx); gy = __fsub_rn(gy, qy); gz = __fsub_rn(gz, qz); }
-                float *o = grouped + (row * nsample + l) * 3;
-                o[0] = gx; o[1] = gy; o[2] = gz;
-            }
-        }
+        bq_emit<LDS_CLOUD, FUSE>(row0, nsample, cnt0, first0, rowbuf0, cloud, data, ax, ay, az, idx, pts_cnt, grouped,
+                                 subtract, lane);
+        if (two)
+            bq_emit<LDS_CLOUD, FUSE>(row1, nsample, cnt1, first1, rowbuf1, cloud, data, bx, by, bz, idx, pts_cnt,
+                                     grouped, subtract, lane);
         asm volatile("" ::: "memory");
-        if (lane == 0 && pts_cnt) pts_cnt[row] = cnt;
     }
 }
 
@@ -117,13 +164,14 @@ static int launch_bq(int b, int n, int m, float thr, int nsample, const float *x
                      int *pts_cnt, float *grouped, int subtract, hipStream_t st)
 {
     // aim at ~2 workgroups per CU over the whole launch; each stages the cloud once
+    constexpr int kGran = kBqWaves * kBqQpw;
     long long total = (long long)b * m;
     int qpb = (int)((total + 511) / 512);
-    qpb = ((qpb + kBqWaves - 1) / kBqWaves) * kBqWaves;
-    if (qpb < kBqWaves) qpb = kBqWaves;
-    if (qpb > m) qpb = ((m + kBqWaves - 1) / kBqWaves) * kBqWaves;
+    qpb = ((qpb + kGran - 1) / kGran) * kGran;
+    if (qpb < kGran) qpb = kGran;
+    if (qpb > m) qpb = ((m + kGran - 1) / kGran) * kGran;
     const int gx = (m + qpb - 1) / qpb;
-    const size_t lds = (LDS_CLOUD ? sizeof(float4) * (size_t)n : 0) + sizeof(int) * (size_t)nsample * kBqWaves;
+    const size_t lds = (LDS_CLOUD ? sizeof(float4) * (size_t)((n + 127) & ~127) : 0) + sizeof(int) * (size_t)nsample * kGran;
     if (lds > 160 * 1024) return PN2_E_TOO_LARGE;
     auto kern = ball_query_kernel<LDS_CLOUD, FUSE>;
     if (lds > 48 * 1024) {
@@ -149,7 +197,7 @@ static int ball_query_common(int b, int n, int m, float radius, int nsample, con
     const float thr = pn2_ball_threshold(radius);
     hipStream_t st = as_stream(stream);
     const bool lds = n <= kBqMaxLdsPoints &&
-                     sizeof(float4) * (size_t)n + sizeof(int) * (size_t)nsample * kBqWaves <= 160 * 1024;
+                     sizeof(float4) * (size_t)((n + 127) & ~127) + sizeof(int) * (size_t)nsample * kBqWaves * kBqQpw <= 160 * 1024;
     if (fuse)
         return lds ? launch_bq<true, true>(b, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt, grouped, subtract, st)
                    : launch_bq<false, true>(b, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt, grouped, subtract, st);

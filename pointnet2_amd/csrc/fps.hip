@@ -17,12 +17,21 @@
 //     reference's tie rule then degenerates to "first slot, lowest lane,
 //     lowest wave", which costs nothing in the reduction;
 //   * values are compared as signed-int bit patterns (they are >= 0, or -1
-//     for padding slots), so the wave arg-max is 4 DPP v_max_i32 steps,
-//     4 v_readlane, 3 s_max, one v_cmp_eq (the ballot) and an s_ff1;
+//     for padding slots), so the wave arg-max is 6 single-instruction
+//     v_max_i32_dpp steps (quad_perm x2, row_half_mirror, row_mirror,
+//     row_bcast:15, row_bcast:31), one v_readlane, one v_cmp_eq (the ballot)
+//     and an s_ff1;
 //   * one s_barrier per round: per-wave partials go through a parity
-//     double-buffered LDS slot array; every wave redundantly reduces the <=16
-//     partials, then broadcast-reads the winner's xyz from an LDS copy of
-//     the cloud.
+//     double-buffered LDS slot array; every wave redundantly picks the winner
+//     from broadcast reads of the <=8 partials (a short VALU select chain on
+//     wave-uniform data; the 16-wave geometry reduces them with DPP instead),
+//     then broadcast-reads the winner's xyz from an LDS copy of the cloud.
+// Measured on MI355X (scripts/fps_lab.hip, B=32 N=4096): the round costs
+// ~540 ns at 512 threads x 8 points, of which ~290 ns is the synchronisation
+// chain and ~250 ns the distance update; 256x16 and 1024x4 are slower
+// (a lone wave per SIMD issues VALU at ~3 cycles/op, 16 waves pay for 16
+// redundant reductions). LDS atomics (ds_max_u64) were tried and rejected:
+// same-address LDS atomics serialise at ~30 cycles each.
 // Clouds too large for the register tiers fall back to a global-memory tier
 // that keeps the running distances in the caller's `temp` buffer.
 #include "pn2_device.h"
@@ -32,6 +41,37 @@
 namespace pn2 {
 
 constexpr int kRefThreads = 512;  // tie rule modulus: reference blockDim (tf_sampling_g.cu:204)
+
+// min(d, td) of tf_sampling_g.cu:144 as ONE v_min_f32 (the builtin adds a canonicalising v_max per
+// operand). v_min_f32 returns the non-NaN operand, like CUDA's min(float,float).
+#ifndef PN2_FPS_VMIN_ASM
+#define PN2_FPS_VMIN_ASM 1
+#endif
+__device__ __forceinline__ float vmin_f32(float a, float b)
+{
+#if PN2_FPS_VMIN_ASM
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return __builtin_fminf(a, b);
+#endif
+}
+
+// Wave-wide signed max as a wave-uniform scalar: six single-instruction DPP steps (the two wait
+// states a DPP source needs after a VALU write are spelled as s_nop 1), then one v_readlane.
+#define PN2_DPP_MAX(v, ctrl) \
+    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 " ctrl " bank_mask:0xf" : "+v"(v))
+__device__ __forceinline__ int wave_max_i32_fast(int v)
+{
+    PN2_DPP_MAX(v, "quad_perm:[1,0,3,2] row_mask:0xf");
+    PN2_DPP_MAX(v, "quad_perm:[2,3,0,1] row_mask:0xf");
+    PN2_DPP_MAX(v, "row_half_mirror row_mask:0xf");
+    PN2_DPP_MAX(v, "row_mirror row_mask:0xf");
+    PN2_DPP_MAX(v, "row_bcast:15 row_mask:0xa");
+    PN2_DPP_MAX(v, "row_bcast:31 row_mask:0xc");
+    return __builtin_amdgcn_readlane(v, 63);
+}
 
 // ---------------------------------------------------------------------------
 // Register-resident tier.  T threads, P points per thread, n <= T*P.
@@ -62,7 +102,16 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int Q, const f
         __syncthreads();
     }
 
+#ifndef PN2_FPS_VEC
+#define PN2_FPS_VEC 0
+#endif
+#if PN2_FPS_VEC
+    typedef float vecP __attribute__((ext_vector_type(P)));
+    vecP x, y, z;
+    float md[P];
+#else
     float x[P], y[P], z[P], md[P];
+#endif
     int kidx[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -99,12 +148,12 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int Q, const f
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const float d = sqdist(x[p], y[p], z[p], sx, sy, sz);
-            md[p] = __builtin_fminf(d, md[p]);         // min(d,td), :144
+            md[p] = vmin_f32(d, md[p]);                // min(d,td), :144
             const int iv = __float_as_int(md[p]);
             if (iv > bv) { bv = iv; bk = kidx[p]; }    // strict >, :146
         }
         // wave arg-max, ties -> lowest lane
-        const int wm = wave_max_i32(bv);
+        const int wm = wave_max_i32_fast(bv);
         const unsigned long long hit = __ballot(bv == wm);
         const int wl = __builtin_ctzll(hit);           // hit != 0: the max is held by some lane
         const int wk = __builtin_amdgcn_readlane(bk, wl);
@@ -114,6 +163,16 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int Q, const f
         // block arg-max over the W partials, ties -> lowest wave
         if (W == 1) {
             cur = wk;
+        } else if (W <= 8) {
+            // every lane reads all W partials (same addresses: LDS broadcasts) and selects on
+            // wave-uniform data; strict > keeps the lowest wave on ties
+            int bm = slot[0].x;
+            cur = slot[0].y;
+#pragma unroll
+            for (int i = 1; i < W; ++i) {
+                const int2 q = slot[i];
+                if (q.x > bm) { bm = q.x; cur = q.y; }
+            }
         } else {
             int2 pp = make_int2(INT_MIN, 0);
             if (lane < W) pp = slot[lane];
@@ -261,9 +320,9 @@ extern "C" int pn2_farthest_point_sample(int b, int n, int m, const float *inp, 
     }
     const int Q = (n + kRefThreads - 1) / kRefThreads;
     const int ranks = kRefThreads * Q;
-    // default geometry: as many threads as there are ranks up to 1024, then grow P
-    int T = ranks >= 1024 ? 1024 : 512;
-    int P = next_pow2((ranks + T - 1) / T);
+    // default geometry (measured, scripts/fps_lab.hip): 256 threads up to 1024 ranks, else 512
+    const int T = ranks <= 1024 ? 256 : 512;
+    const int P = next_pow2((ranks + T - 1) / T);
     return fps_launch_config(T, P, b, n, m, inp, out, st);
 }
 

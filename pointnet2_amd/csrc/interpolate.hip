@@ -23,8 +23,21 @@
 
 namespace pn2 {
 
-constexpr int kNnThreads = 256;
+constexpr int kNnThreads = 128;
 constexpr int kNnTile = 2048;   // known points per LDS tile (32 KiB)
+
+// strict-< insertion of candidate (d, kk) into the ascending triple (tf_interpolate.cpp:74-89), branch-free
+__device__ __forceinline__ void nn_insert(float d, int kk, float &b1, float &b2, float &b3, int &i1, int &i2, int &i3)
+{
+    const bool c1 = d < b1, c2 = d < b2, c3 = d < b3;
+    const float nb3 = c2 ? b2 : (c3 ? d : b3);
+    const int ni3 = c2 ? i2 : (c3 ? kk : i3);
+    const float nb2 = c1 ? b1 : (c2 ? d : b2);
+    const int ni2 = c1 ? i1 : (c2 ? kk : i2);
+    b1 = c1 ? d : b1;
+    i1 = c1 ? kk : i1;
+    b2 = nb2; i2 = ni2; b3 = nb3; i3 = ni3;
+}
 
 __global__ __launch_bounds__(kNnThreads) void three_nn_kernel(int n, int m, const float *__restrict__ xyz1,
                                                               const float *__restrict__ xyz2,
@@ -42,27 +55,32 @@ __global__ __launch_bounds__(kNnThreads) void three_nn_kernel(int n, int m, cons
     int i1 = 0, i2 = 0, i3 = 0;
     for (int base = 0; base < m; base += kNnTile) {
         const int cnt = min(kNnTile, m - base);
+        const int cnt4 = (cnt + 3) & ~3;
         __syncthreads();
-        for (int k = threadIdx.x; k < cnt; k += kNnThreads) {
-            const float *p = known + (size_t)(base + k) * 3;
-            tile[k] = make_float4(p[0], p[1], p[2], 0.0f);
+        for (int k = threadIdx.x; k < cnt4; k += kNnThreads) {
+            if (k < cnt) {
+                const float *p = known + (size_t)(base + k) * 3;
+                tile[k] = make_float4(p[0], p[1], p[2], 0.0f);
+            } else {
+                tile[k] = make_float4(INFINITY, INFINITY, INFINITY, 0.0f);   // pad: distance +inf (or NaN), never inserted
+            }
         }
         __syncthreads();
-        for (int k = 0; k < cnt; ++k) {
-            const float4 p = tile[k];                     // same address in all lanes: broadcast
-            const float d = sqdist(p.x, p.y, p.z, ux, uy, uz);   // (x2-x1)..., x2 the known point (:69-73)
-            const bool c3 = d < b3;
-            if (__any(c3)) {
-                const bool c1 = d < b1, c2 = d < b2;
+        // four known points per trip: four independent distance chains, one wave-uniform test
+        for (int k = 0; k < cnt4; k += 4) {
+            const float4 p0 = tile[k], p1 = tile[k + 1], p2 = tile[k + 2], p3 = tile[k + 3];   // LDS broadcasts
+            // (x2-x1)..., x2 the known point (tf_interpolate.cpp:69-73)
+            const float d0 = sqdist(p0.x, p0.y, p0.z, ux, uy, uz);
+            const float d1 = sqdist(p1.x, p1.y, p1.z, ux, uy, uz);
+            const float d2 = sqdist(p2.x, p2.y, p2.z, ux, uy, uz);
+            const float d3 = sqdist(p3.x, p3.y, p3.z, ux, uy, uz);
+            const bool better = (d0 < b3) | (d1 < b3) | (d2 < b3) | (d3 < b3);
+            if (__any(better)) {
                 const int kk = base + k;
-                // strict-< cascade of :74-89, branch-free
-                const float nb3 = c2 ? b2 : (c3 ? d : b3);
-                const int ni3 = c2 ? i2 : (c3 ? kk : i3);
-                const float nb2 = c1 ? b1 : (c2 ? d : b2);
-                const int ni2 = c1 ? i1 : (c2 ? kk : i2);
-                b1 = c1 ? d : b1;
-                i1 = c1 ? kk : i1;
-                b2 = nb2; i2 = ni2; b3 = nb3; i3 = ni3;
+                nn_insert(d0, kk, b1, b2, b3, i1, i2, i3);       // ascending k: keeps the (d,k) order key
+                nn_insert(d1, kk + 1, b1, b2, b3, i1, i2, i3);
+                nn_insert(d2, kk + 2, b1, b2, b3, i1, i2, i3);
+                nn_insert(d3, kk + 3, b1, b2, b3, i1, i2, i3);
             }
         }
     }

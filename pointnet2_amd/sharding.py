@@ -1,0 +1,62 @@
+"""Multi-GPU layout of the hot path: one process per GPU, clouds sharded by batch index.
+
+Every operator of the path indexes by cloud and never reads across clouds
+(reference tf_sampling_g.cu:113, tf_grouping_g.cu:4-8, tf_interpolate.cpp:61), so
+the forward path needs NO collective: each rank runs the kernels on its own
+contiguous slice of the batch, exactly the `tf.slice(pointclouds_pl,
+[i*DEVICE_BATCH_SIZE,0,0], ...)` of the reference's tower loop
+(train_multi_gpu.py:185-188, with BATCH_SIZE % NUM_GPUS == 0 asserted at :46).
+
+The only exchange step the reference has is training's per-variable gradient
+mean over towers (`average_gradients`, train_multi_gpu.py:91-126, used :210).
+`allreduce_mean_` restates it as ONE all-reduce(sum) over a flat fp32 bucket
+followed by a 1/G scale -- RCCL over xGMI with backend "nccl", gloo in the CPU
+tests. At 4-6 MB the message is latency bound, so a single bucket is the right
+shape for xGMI's point-to-point links.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(batch, world_size, rank):
+    """[lo, hi) of this rank's contiguous slice; batch must divide evenly (train_multi_gpu.py:46)."""
+    if batch % world_size != 0:
+        raise ValueError("batch size %d is not divisible by the number of GPUs %d" % (batch, world_size))
+    per = batch // world_size
+    return rank * per, (rank + 1) * per
+
+
+def shard_batch(tensor, world_size=None, rank=None):
+    """This rank's slice of a batch-major tensor (a view, no copy)."""
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    lo, hi = shard_bounds(tensor.shape[0], world_size, rank)
+    return tensor[lo:hi]
+
+
+def max_over_ranks(seconds, device=None):
+    """Whole-job wall time = the slowest rank's (bench.py contract)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(seconds)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def allreduce_mean_(tensors):
+    """In-place mean over ranks of a list of gradient tensors through one flat fp32 bucket
+    (replaces average_gradients, train_multi_gpu.py:91-126)."""
+    tensors = [t for t in tensors if t is not None]
+    if not tensors or not dist.is_initialized() or dist.get_world_size() == 1:
+        return tensors
+    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.mul_(1.0 / dist.get_world_size())
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
+    return tensors

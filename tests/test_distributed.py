@@ -1,0 +1,83 @@
+"""world_size-2 CPU tests (gloo) of the multi-GPU layout: batch sharding as in the reference's
+tower loop (train_multi_gpu.py:185-188), the max-over-ranks timing bench.py reports, and the
+flat-bucket gradient mean that replaces average_gradients (train_multi_gpu.py:91-126)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pointnet2_amd import sharding
+        # 1. sharding: contiguous, disjoint, covering
+        batch = torch.arange(8 * 5 * 3, dtype=torch.float32).reshape(8, 5, 3)
+        mine = sharding.shard_batch(batch)
+        lo, hi = sharding.shard_bounds(8, world, rank)
+        assert mine.shape[0] == 8 // world and torch.equal(mine, batch[lo:hi])
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine.contiguous())
+        assert torch.equal(torch.cat(gathered), batch)
+        try:
+            sharding.shard_bounds(7, world, rank)
+            raise AssertionError("indivisible batch accepted")
+        except ValueError:
+            pass
+        # 2. timing: max over ranks
+        t = sharding.max_over_ranks(1.0 + rank)
+        assert t == float(world)
+        # 3. gradient mean through one flat bucket == mean over ranks, per tensor
+        g = torch.Generator().manual_seed(100 + rank)
+        grads = [torch.randn(7, 3, generator=g), torch.randn(11, generator=g), None, torch.randn(2, 2, 2, generator=g)]
+        ref = []
+        for r in range(world):
+            gr = torch.Generator().manual_seed(100 + r)
+            ref.append([torch.randn(7, 3, generator=gr), torch.randn(11, generator=gr), torch.randn(2, 2, 2, generator=gr)])
+        want = [sum(x[i] for x in ref) / world for i in range(3)]
+        out = sharding.allreduce_mean_(grads)
+        for a, b in zip(out, want):
+            assert torch.allclose(a, b, atol=1e-6)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, "FAIL: %r" % (e,)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world_size_2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_single_process_fallbacks():
+    from pointnet2_amd import sharding
+    x = torch.zeros(4, 2)
+    assert sharding.shard_batch(x, 1, 0).shape[0] == 4
+    assert sharding.max_over_ranks(0.5) == 0.5
+    g = [torch.ones(3)]
+    assert sharding.allreduce_mean_(g)[0].sum() == 3
