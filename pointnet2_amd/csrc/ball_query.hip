@@ -37,24 +37,35 @@ constexpr int kBqWaves = kBqThreads / PN2_WAVE;
 constexpr int kBqQpw = 2;              // queries swept together by one wave (each LDS read serves both)
 constexpr int kBqMaxLdsPoints = 9600;  // 16 B/point + row buffers must stay under 160 KiB
 
-// ordered append of one 64-candidate chunk's hits to a query's row buffer (wave-uniform control flow)
-__device__ __forceinline__ void bq_append(unsigned long long mask, bool hit, int k, int chunk_base, int nsample,
-                                          int *rowbuf, int &cnt, int &first)
+// popcount(mask) + acc as two VALU ops on a VGPR accumulator. On gfx9-class CUs a scalar op costs a
+// SIMD issue slot of 4 cycles (a VALU op 2), and the first version of this kernel was bound by its
+// ~60 scalar ops per trip (rocprofv3: 64 us at the metric shape); the hit counters therefore live in
+// VGPRs (wave-uniform values) and only the exec-mask updates of the predicated stores stay scalar.
+__device__ __forceinline__ int vbcnt_acc(unsigned long long mask, int acc)
 {
-    if (mask != 0ull && cnt < nsample) {
-        const int pos = cnt + mbcnt(mask);
-        if (hit && pos < nsample) rowbuf[pos] = k;
-        if (cnt == 0) first = chunk_base + __builtin_ctzll(mask);
-        cnt += __popcll(mask);
-    }
+    int r;
+    asm("v_bcnt_u32_b32 %0, %1, %2\n\tv_bcnt_u32_b32 %0, %3, %0"
+        : "=&v"(r)
+        : "s"((unsigned)mask), "v"(acc), "s"((unsigned)(mask >> 32)));
+    return r;
+}
+
+// ordered append of one 64-candidate chunk's hits to a query's row buffer; cnt is a wave-uniform VGPR
+__device__ __forceinline__ void bq_append(unsigned long long mask, bool hit, int k, int nsample, int *rowbuf, int &cnt)
+{
+    const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                   __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)cnt));
+    if (hit && pos < nsample) rowbuf[pos] = k;
+    cnt = vbcnt_acc(mask, cnt);
 }
 
 template <bool LDS_CLOUD, bool FUSE>
-__device__ __forceinline__ void bq_emit(size_t row, int nsample, int cnt, int first, const int *rowbuf,
+__device__ __forceinline__ void bq_emit(size_t row, int nsample, int cnt, const int *rowbuf,
                                         const float4 *cloud, const float *__restrict__ data, float qx, float qy,
                                         float qz, int *__restrict__ idx, int *__restrict__ pts_cnt,
                                         float *__restrict__ grouped, int subtract, int lane)
 {
+    const int first = cnt > 0 ? rowbuf[0] : 0;   // the first hit pads the row; zeros when the ball is empty
     for (int l = lane; l < nsample; l += 64) {
         const int v = (l < cnt) ? rowbuf[l] : first;
         if (idx) idx[row * nsample + l] = v;
@@ -116,10 +127,12 @@ __global__ __launch_bounds__(kBqThreads) void ball_query_kernel(int n, int m, in
         const size_t row1 = row0 + (two ? 1 : 0);
         const float ax = xyz2[row0 * 3 + 0], ay = xyz2[row0 * 3 + 1], az = xyz2[row0 * 3 + 2];
         const float bx = xyz2[row1 * 3 + 0], by = xyz2[row1 * 3 + 1], bz = xyz2[row1 * 3 + 2];
-        int cnt0 = 0, cnt1 = two ? 0 : nsample;              // wave-uniform hit counters
-        int first0 = 0, first1 = 0;                          // first hit pads the row; 0 when the ball is empty
+        // hit counters: wave-uniform values kept in VGPRs (see vbcnt_acc)
+        int cnt0 = 0, cnt1 = two ? 0 : nsample;
+        asm volatile("v_mov_b32 %0, %0" : "+v"(cnt0));
+        asm volatile("v_mov_b32 %0, %0" : "+v"(cnt1));
         // 128 candidates per trip: two chunks x two queries = four independent distance chains per lane
-        for (int base = 0; base < n && (cnt0 < nsample || cnt1 < nsample); base += 128) {
+        for (int base = 0; base < n; base += 128) {
             const int kA = base + lane, kB = base + 64 + lane;
             float pax, pay, paz, pbx, pby, pbz;
             if (LDS_CLOUD) {
@@ -141,19 +154,21 @@ __global__ __launch_bounds__(kBqThreads) void ball_query_kernel(int n, int m, in
             const bool hA0 = sA0 < thr, hB0 = sB0 < thr, hA1 = sA1 < thr, hB1 = sB1 < thr;
             const unsigned long long mA0 = __ballot(hA0), mB0 = __ballot(hB0);
             const unsigned long long mA1 = __ballot(hA1), mB1 = __ballot(hB1);
-            bq_append(mA0, hA0, kA, base, nsample, rowbuf0, cnt0, first0);
-            bq_append(mB0, hB0, kB, base + 64, nsample, rowbuf0, cnt0, first0);
-            bq_append(mA1, hA1, kA, base, nsample, rowbuf1, cnt1, first1);
-            bq_append(mB1, hB1, kB, base + 64, nsample, rowbuf1, cnt1, first1);
+            bq_append(mA0, hA0, kA, nsample, rowbuf0, cnt0);
+            bq_append(mB0, hB0, kB, nsample, rowbuf0, cnt0);
+            bq_append(mA1, hA1, kA, nsample, rowbuf1, cnt1);
+            bq_append(mB1, hB1, kB, nsample, rowbuf1, cnt1);
+            // stop as soon as both rows are full (reference: break at cnt == nsample, :23-24)
+            if (__builtin_amdgcn_readfirstlane(min(cnt0, cnt1)) >= nsample) break;
         }
-        cnt0 = min(cnt0, nsample);
-        cnt1 = min(cnt1, nsample);
+        cnt0 = __builtin_amdgcn_readfirstlane(min(cnt0, nsample));
+        cnt1 = __builtin_amdgcn_readfirstlane(min(cnt1, nsample));
         // LDS ops of one wave execute in order; only the compiler must not reorder
         asm volatile("" ::: "memory");
-        bq_emit<LDS_CLOUD, FUSE>(row0, nsample, cnt0, first0, rowbuf0, cloud, data, ax, ay, az, idx, pts_cnt, grouped,
+        bq_emit<LDS_CLOUD, FUSE>(row0, nsample, cnt0, rowbuf0, cloud, data, ax, ay, az, idx, pts_cnt, grouped,
                                  subtract, lane);
         if (two)
-            bq_emit<LDS_CLOUD, FUSE>(row1, nsample, cnt1, first1, rowbuf1, cloud, data, bx, by, bz, idx, pts_cnt,
+            bq_emit<LDS_CLOUD, FUSE>(row1, nsample, cnt1, rowbuf1, cloud, data, bx, by, bz, idx, pts_cnt,
                                      grouped, subtract, lane);
         asm volatile("" ::: "memory");
     }
