@@ -44,6 +44,9 @@ constexpr int kRefThreads = 512;  // tie rule modulus: reference blockDim (tf_sa
 
 // min(d, td) of tf_sampling_g.cu:144 as ONE v_min_f32 (the builtin adds a canonicalising v_max per
 // operand). v_min_f32 returns the non-NaN operand, like CUDA's min(float,float).
+#ifndef PN2_FPS_WINNER_WRITES
+#define PN2_FPS_WINNER_WRITES 0
+#endif
 #ifndef PN2_FPS_VMIN_ASM
 #define PN2_FPS_VMIN_ASM 1
 #endif
@@ -75,8 +78,22 @@ __device__ __forceinline__ int wave_max_i32_fast(int v)
 
 // ---------------------------------------------------------------------------
 // Register-resident tier.  T threads, P points per thread, n <= T*P.
-// LDSXYZ: keep a float4 copy of the cloud in LDS for the winner broadcast
-// (16 B/point); otherwise the winner is re-read from global memory.
+//
+// Every slot r = t*P+p is a tie RANK. The cloud is mirrored in LDS in rank order as
+// (x, y, z, bits(k)) so the winner's coordinates AND its original index come back in
+// one broadcast ds_read_b128 (LDSXYZ). Without the LDS mirror (clouds of 8193..16384
+// points) only a rank -> k table lives in LDS and the winner is re-read from L2.
+//
+// A wave's candidate is published as ONE 64-bit key
+//     key = (value bits << 32) | (0xFFFFFFFF - rank)
+// whose unsigned order is exactly "larger value, then smaller rank". After the
+// barrier every wave max-reduces the W keys from broadcast reads (a depth-log2(W)
+// tree of v_cmp_gt_u64 + 2 v_cndmask on wave-uniform data) and reads the winner's
+// point: two dependent LDS trips per round. (The first version selected a byte
+// offset, then fetched the index, then the coordinates: three trips; the s_memtime
+// profile in scripts/fps_prof.hip showed that chain at ~540 of ~1340 cycles.)
+// Padding slots carry value +0.0: they can only tie with real zero-distance
+// points, and rank 0 (k = 0, always real) then wins, as in the reference.
 // ---------------------------------------------------------------------------
 template <int T, int P, bool LDSXYZ>
 __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int Q, const float *__restrict__ xyz,
@@ -84,107 +101,97 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int Q, const f
 {
     constexpr int W = T / PN2_WAVE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int2 *partial = reinterpret_cast<int2 *>(smem);                   // [2][W] (256 B reserved)
-    float4 *lds_xyz = reinterpret_cast<float4 *>(smem + 256);         // [n] when LDSXYZ
+    unsigned long long *partial = reinterpret_cast<unsigned long long *>(smem);   // [2][W] (256 B reserved)
+    float4 *lds_rank = reinterpret_cast<float4 *>(smem + 256);                    // [T*P] when LDSXYZ
+    int *lds_k = reinterpret_cast<int *>(smem + 256);                             // [T*P] otherwise
 
     const int cloud = blockIdx.x;
     const float *__restrict__ src = xyz + (size_t)cloud * n * 3;
     int *__restrict__ dst = out + (size_t)cloud * m;
     const int t = threadIdx.x;
     const int lane = t & 63;
-    const int w = t >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
 
-    if (LDSXYZ) {
-        for (int k = t; k < n; k += T) {
-            const float *p = src + (size_t)k * 3;
-            lds_xyz[k] = make_float4(p[0], p[1], p[2], 0.0f);
-        }
-        __syncthreads();
-    }
-
-#ifndef PN2_FPS_VEC
-#define PN2_FPS_VEC 0
-#endif
-#if PN2_FPS_VEC
-    typedef float vecP __attribute__((ext_vector_type(P)));
-    vecP x, y, z;
-    float md[P];
-#else
     float x[P], y[P], z[P], md[P];
-#endif
-    int kidx[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const int r = t * P + p;                       // tie rank of this slot
         const int k = (r % Q) * kRefThreads + r / Q;   // original point index
         const bool valid = (r < kRefThreads * Q) && (k < n);
-        kidx[p] = valid ? k : 0;
-        if (valid) {
-            if (LDSXYZ) {
-                const float4 v = lds_xyz[k];
-                x[p] = v.x; y[p] = v.y; z[p] = v.z;
-            } else {
-                x[p] = src[(size_t)k * 3 + 0]; y[p] = src[(size_t)k * 3 + 1]; z[p] = src[(size_t)k * 3 + 2];
-            }
-            md[p] = 1e38f;   // tf_sampling_g.cu:118
-        } else {
-            x[p] = 0.0f; y[p] = 0.0f; z[p] = 0.0f;
-            md[p] = -1.0f;   // padding slot: below every real value, never selected
-        }
+        const int kk = valid ? k : 0;
+        x[p] = valid ? src[(size_t)kk * 3 + 0] : 0.0f;
+        y[p] = valid ? src[(size_t)kk * 3 + 1] : 0.0f;
+        z[p] = valid ? src[(size_t)kk * 3 + 2] : 0.0f;
+        md[p] = valid ? 1e38f : 0.0f;                  // tf_sampling_g.cu:118; padding: see header
+        if (LDSXYZ) lds_rank[r] = make_float4(x[p], y[p], z[p], __int_as_float(kk));
+        else lds_k[r] = kk;
+    }
+    __syncthreads();
+
+    if (t == 0) dst[0] = 0;                            // tf_sampling_g.cu:114-116
+    float sx, sy, sz;                                  // the point selected last (starts at k = 0 = rank 0)
+    if (LDSXYZ) {
+        const float4 s = lds_rank[0];
+        sx = s.x; sy = s.y; sz = s.z;
+    } else {
+        sx = src[0]; sy = src[1]; sz = src[2];
     }
 
-    int cur = 0;             // tf_sampling_g.cu:114
-    if (t == 0) dst[0] = 0;
-
-    for (int j = 1; j < m; ++j) {
-        float sx, sy, sz;
-        if (LDSXYZ) {
-            const float4 s = lds_xyz[cur];             // same address in every lane: LDS broadcast
-            sx = s.x; sy = s.y; sz = s.z;
-        } else {
-            sx = src[(size_t)cur * 3 + 0]; sy = src[(size_t)cur * 3 + 1]; sz = src[(size_t)cur * 3 + 2];
-        }
-        int bv = INT_MIN, bk = 0;
+    const unsigned low0 = 0xFFFFFFFFu - (unsigned)(t * P);   // key low word of this thread's slot 0
+    // one round; `par` (the partial buffer parity) is a literal at both call sites so the slot
+    // addresses fold to constants (scalar address arithmetic costs 4-cycle issue slots)
+    auto round = [&](const int j, const int par) __attribute__((always_inline)) {
+        int bv = -1, bp = 0;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const float d = sqdist(x[p], y[p], z[p], sx, sy, sz);
             md[p] = vmin_f32(d, md[p]);                // min(d,td), :144
-            const int iv = __float_as_int(md[p]);
-            if (iv > bv) { bv = iv; bk = kidx[p]; }    // strict >, :146
+            const int iv = __float_as_int(md[p]);      // >= 0: int order == float order
+            if (iv > bv) { bv = iv; bp = p; }          // strict >, :146 (slots ascend in rank)
         }
-        // wave arg-max, ties -> lowest lane
+        // wave arg-max, ties -> lowest lane (= lowest rank). The low key word of this lane's
+        // candidate is formed in VALU before the reduction; the winning lane stores its own key
+        // (no v_readlane round trip through the scalar unit for the payload).
+        unsigned mylow = low0 - (unsigned)bp;
+#if PN2_FPS_WINNER_WRITES
+        asm volatile("" : "+v"(mylow));                // keep the slot select out of the store branch
+#endif
         const int wm = wave_max_i32_fast(bv);
-        const unsigned long long hit = __ballot(bv == wm);
-        const int wl = __builtin_ctzll(hit);           // hit != 0: the max is held by some lane
-        const int wk = __builtin_amdgcn_readlane(bk, wl);
-        int2 *slot = partial + (j & 1) * W;
-        if (lane == 0) slot[w] = make_int2(wm, wk);
+        const int wl = __builtin_ctzll(__ballot(bv == wm));   // the max is held by some lane
+        unsigned long long *slot = partial + par * W;
+#if PN2_FPS_WINNER_WRITES
+        if (lane == wl) slot[w] = ((unsigned long long)(unsigned)bv << 32) | (unsigned long long)mylow;
+#else
+        const unsigned wlow = (unsigned)__builtin_amdgcn_readlane((int)mylow, wl);
+        if (lane == 0) slot[w] = ((unsigned long long)(unsigned)wm << 32) | (unsigned long long)wlow;
+#endif
         __syncthreads();
-        // block arg-max over the W partials, ties -> lowest wave
-        if (W == 1) {
-            cur = wk;
-        } else if (W <= 8) {
-            // every lane reads all W partials (same addresses: LDS broadcasts) and selects on
-            // wave-uniform data; strict > keeps the lowest wave on ties
-            int bm = slot[0].x;
-            cur = slot[0].y;
+        // block arg-max: unsigned max of the W keys, every wave redundantly, on wave-uniform data
+        unsigned long long key[W];
 #pragma unroll
-            for (int i = 1; i < W; ++i) {
-                const int2 q = slot[i];
-                if (q.x > bm) { bm = q.x; cur = q.y; }
-            }
+        for (int i = 0; i < W; ++i) key[i] = slot[i];
+#pragma unroll
+        for (int st = 1; st < W; st <<= 1)
+#pragma unroll
+            for (int i = 0; i + st < W; i += 2 * st) key[i] = key[i + st] > key[i] ? key[i + st] : key[i];
+        const unsigned rank = 0xFFFFFFFFu - (unsigned)key[0];
+        int k;
+        if (LDSXYZ) {
+            const float4 s = lds_rank[rank];           // same address in every lane: LDS broadcast
+            sx = s.x; sy = s.y; sz = s.z;
+            k = __float_as_int(s.w);
         } else {
-            int2 pp = make_int2(INT_MIN, 0);
-            if (lane < W) pp = slot[lane];
-            int bm;
-            if (W <= 16) bm = __builtin_amdgcn_readfirstlane(row16_max_i32(pp.x));
-            else bm = wave_max_i32(pp.x);
-            const unsigned long long hit2 = __ballot(pp.x == bm);
-            const int l2 = __builtin_ctzll(hit2);
-            cur = __builtin_amdgcn_readlane(pp.y, l2);
+            k = lds_k[rank];
+            sx = src[(size_t)k * 3 + 0]; sy = src[(size_t)k * 3 + 1]; sz = src[(size_t)k * 3 + 2];
         }
-        if (t == 0) dst[j] = cur;
+        if (t == 0) dst[j] = k;
+    };
+    int j = 1;
+    for (; j + 1 < m; j += 2) {
+        round(j, 1);
+        round(j + 1, 0);
     }
+    if (j < m) round(j, 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(1024) void fps_generic_kernel(int n, int m, const f
 template <int T, int P, bool LDSXYZ>
 static int launch_reg(int b, int n, int m, int Q, const float *inp, int *out, hipStream_t st)
 {
-    const size_t lds = 256 + (LDSXYZ ? sizeof(float4) * (size_t)n : 0);
+    const size_t lds = 256 + (LDSXYZ ? sizeof(float4) : sizeof(int)) * (size_t)T * P;
     auto kern = fps_reg_kernel<T, P, LDSXYZ>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -261,7 +268,7 @@ static int launch_reg(int b, int n, int m, int Q, const float *inp, int *out, hi
     return launch_status();
 }
 
-constexpr int kMaxLdsPoints = 10200;   // 256 B + 16 B/point <= 160 KiB
+constexpr int kMaxLdsSlots = 8192;     // 256 B + 16 B per rank slot <= 160 KiB
 constexpr int kMaxRegPoints = 16384;
 
 template <int T, bool LDSXYZ>
@@ -288,7 +295,7 @@ static int fps_launch_config(int T, int P, int b, int n, int m, const float *inp
 {
     const int Q = (n + kRefThreads - 1) / kRefThreads;
     if ((long long)T * P < (long long)kRefThreads * Q) return PN2_E_ARG;
-    const bool lds = n <= kMaxLdsPoints;
+    const bool lds = (long long)T * P <= kMaxLdsSlots;
     switch (T) {
     case 256: return lds ? dispatch_p<256, true>(P, b, n, m, Q, inp, out, st) : dispatch_p<256, false>(P, b, n, m, Q, inp, out, st);
     case 512: return lds ? dispatch_p<512, true>(P, b, n, m, Q, inp, out, st) : dispatch_p<512, false>(P, b, n, m, Q, inp, out, st);
