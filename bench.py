@@ -9,8 +9,14 @@ One "step" = one pass of the hot path over one batch of synthetic clouds already
     idx, cnt = query_ball_point(0.2, 32, xyz, new_xyz)   -> (32,1024,32) i32, (32,1024) i32
     grouped  = group_point(xyz, idx)                     -> (32,1024,32,3) f32
 
-i.e. reference utils/pointnet_util.py:40-45, launched through the C ABI of libpn2ops.so
+i.e. reference utils/pointnet_util.py:40-46, launched through the C ABI of libpn2ops.so
 (include/pn2ops.h) on torch's current HIP stream with caller-allocated outputs.
+
+--path fused (default) is what pointnet2_amd.pointnet_util.sample_and_group launches: the same
+outputs from TWO kernels -- pn2_farthest_point_sample_gather (fps_idx + new_xyz) and
+pn2_query_ball_group_xyz (idx + pts_cnt + grouped_xyz with the centroid subtracted, :46).
+--path ops launches the four reference-shaped operators one by one. Both are parity-tested
+bit-exact against the oracle; `kernels` always reports the four op-level kernels.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -87,18 +93,34 @@ class Stage:
         _C.check(self.lib.pn2_group_point(B, N, 3, M, NS, self.xyz.data_ptr(), self.idx.data_ptr(),
                                           self.grouped.data_ptr(), self.stream), "group")
 
-    def step(self):
+    def fps_gather_(self):
+        _C.check(self.lib.pn2_farthest_point_sample_gather(B, N, M, self.xyz.data_ptr(), None, self.fps.data_ptr(),
+                                                           self.new_xyz.data_ptr(), self.stream), "fps_gather")
+
+    def ball_group_(self):
+        _C.check(self.lib.pn2_query_ball_group_xyz(B, N, M, RADIUS, NS, self.xyz.data_ptr(), self.new_xyz.data_ptr(),
+                                                   1, self.idx.data_ptr(), self.cnt.data_ptr(),
+                                                   self.grouped.data_ptr(), self.stream), "ball_group")
+
+    def step_ops(self):
         self.fps_()
         self.gather_()
         self.ball_()
         self.group_()
 
+    def step_fused(self):
+        self.fps_gather_()
+        self.ball_group_()
 
-def kernel_times(stage, reps=10):
+
+def kernel_times(stage, reps=10, fused=False):
     """Average duration of each kernel, HIP events on the launch stream (torch's current stream)."""
     out = {}
-    for name, fn in (("farthest_point_sample", stage.fps_), ("gather_point", stage.gather_),
-                     ("query_ball_point", stage.ball_), ("group_point", stage.group_)):
+    table = ((("farthest_point_sample_gather", stage.fps_gather_), ("query_ball_group_xyz", stage.ball_group_))
+             if fused else
+             (("farthest_point_sample", stage.fps_), ("gather_point", stage.gather_),
+              ("query_ball_point", stage.ball_), ("group_point", stage.group_)))
+    for name, fn in table:
         fn()
         torch.cuda.synchronize()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
@@ -138,6 +160,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--path", choices=("fused", "ops"), default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
@@ -156,15 +179,16 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     stage = Stage(dev, seed=1000 + rank)          # every rank owns its own B=32 batch (weak scaling)
+    step = stage.step_fused if args.path == "fused" else stage.step_ops
     for _ in range(max(args.warmup, 1)):
-        stage.step()
+        step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        stage.step()
+        step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -174,6 +198,7 @@ def main():
 
     if rank == 0:
         kt = kernel_times(stage)
+        ktf = kernel_times(stage, fused=True)
         dom = max(kt, key=kt.get)
         achieved = BYTES[dom] * B / kt[dom] / 1e9
         traffic = None
@@ -200,6 +225,8 @@ def main():
             "config": {"workload": "SA stage FPS+gather+ball_query+group, B=32 per GPU, N=4096->npoint=1024, "
                                    "radius=0.2, nsample=32, xyz only (BASELINE configs: metric shape)",
                        "clouds": "D1: unit-sphere surface x U(0.9,1.0), pc_normalize'd, seeded per rank",
+                       "path": args.path + (" (2 launches: FPS+gather, ball query+group+centroid subtract)"
+                                            if args.path == "fused" else " (4 reference-shaped operator launches)"),
                        "sharding": "%d independent batch shard(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -207,7 +234,9 @@ def main():
                                  "is latency bound, see DESIGN.md" % (kt["farthest_point_sample"] / (M - 1) * 1e9)},
             "kernels": {k: {"us": v * 1e6, "algorithmic_GBps": BYTES[k] * B / v / 1e9,
                             "frac_of_hbm_peak": BYTES[k] * B / v / 1e9 / HBM_PEAK_GBS} for k, v in kt.items()},
+            "fused_kernels": {k: {"us": v * 1e6} for k, v in ktf.items()},
             "stage": {"bytes_per_cloud": STAGE_BYTES, "sum_kernel_us": total_k * 1e6,
+                      "sum_fused_kernel_us": sum(ktf.values()) * 1e6,
                       "algorithmic_GBps": STAGE_BYTES * B / total_k / 1e9,
                       "frac_of_hbm_peak": STAGE_BYTES * B / total_k / 1e9 / HBM_PEAK_GBS},
         }

@@ -104,6 +104,12 @@ int pn2_three_interpolate_grad(int b, int n, int c, int m, const float *grad_out
 
 /* ---- fused entry points (no reference counterpart) ---- */
 
+/* farthest_point_sample + gather_point(inp, out) in one launch: what
+ * pointnet_util.py:40 computes with two ops. out (b,m) i32 as pn2_farthest_point_sample,
+ * out_xyz (b,m,3) f32 = inp[out] (bit-exact copies). temp as pn2_farthest_point_sample. */
+int pn2_farthest_point_sample_gather(int b, int n, int m, const float *inp, float *temp, int *out, float *out_xyz,
+                                     void *stream);
+
 /* query_ball_point + group_point(xyz1, idx) - centroid in one pass over the
  * LDS-resident cloud: what pointnet_util.py:44-46 computes with three ops.
  * grouped_xyz (b,m,nsample,3) = xyz1[idx] - xyz2[:, :, None] when subtract_centroid!=0,

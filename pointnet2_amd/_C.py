@@ -27,6 +27,7 @@ _f = ctypes.c_float
 # name -> argtypes (all return int unless listed in _RESTYPES)
 _SIGNATURES = {
     "pn2_farthest_point_sample": [_i, _i, _i, _vp, _vp, _vp, _vp],
+    "pn2_farthest_point_sample_gather": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pn2_fps_temp_floats": [_i, _i],
     "pn2_gather_point": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "pn2_gather_point_grad": [_i, _i, _i, _vp, _vp, _vp, _vp],

@@ -12,7 +12,8 @@ HIP for gfx950, C ABI in include/pn2ops.h); importing an operator without the
 built library raises -- there is no CPU fallback.
 """
 from . import _C  # noqa: F401
-from .tf_sampling import farthest_point_sample, gather_point, prob_sample  # noqa: F401
+from .tf_sampling import (farthest_point_sample, farthest_point_sample_gather, gather_point,  # noqa: F401
+                          prob_sample)
 from .tf_grouping import (query_ball_point, group_point, knn_point, select_top_k,  # noqa: F401
                           query_ball_group_xyz)
 from .tf_interpolate import three_nn, three_interpolate  # noqa: F401

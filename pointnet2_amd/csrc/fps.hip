@@ -97,7 +97,7 @@ __device__ __forceinline__ int wave_max_i32_fast(int v)
 // ---------------------------------------------------------------------------
 template <int T, int P, bool LDSXYZ>
 __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int Q, const float *__restrict__ xyz,
-                                                    int *__restrict__ out)
+                                                    int *__restrict__ out, float *__restrict__ out_xyz)
 {
     constexpr int W = T / PN2_WAVE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -108,6 +108,7 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int Q, const f
     const int cloud = blockIdx.x;
     const float *__restrict__ src = xyz + (size_t)cloud * n * 3;
     int *__restrict__ dst = out + (size_t)cloud * m;
+    float *__restrict__ dxyz = out_xyz ? out_xyz + (size_t)cloud * m * 3 : nullptr;   // fused gather_point
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -128,13 +129,16 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int Q, const f
     }
     __syncthreads();
 
-    if (t == 0) dst[0] = 0;                            // tf_sampling_g.cu:114-116
     float sx, sy, sz;                                  // the point selected last (starts at k = 0 = rank 0)
     if (LDSXYZ) {
         const float4 s = lds_rank[0];
         sx = s.x; sy = s.y; sz = s.z;
     } else {
         sx = src[0]; sy = src[1]; sz = src[2];
+    }
+    if (t == 0) {
+        dst[0] = 0;                                    // tf_sampling_g.cu:114-116
+        if (dxyz) { dxyz[0] = sx; dxyz[1] = sy; dxyz[2] = sz; }
     }
 
     const unsigned low0 = 0xFFFFFFFFu - (unsigned)(t * P);   // key low word of this thread's slot 0
@@ -184,7 +188,10 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int Q, const f
             k = lds_k[rank];
             sx = src[(size_t)k * 3 + 0]; sy = src[(size_t)k * 3 + 1]; sz = src[(size_t)k * 3 + 2];
         }
-        if (t == 0) dst[j] = k;
+        if (t == 0) {
+            dst[j] = k;
+            if (dxyz) { dxyz[j * 3 + 0] = sx; dxyz[j * 3 + 1] = sy; dxyz[j * 3 + 2] = sz; }
+        }
     };
     int j = 1;
     for (; j + 1 < m; j += 2) {
@@ -207,7 +214,8 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 }
 
 __global__ __launch_bounds__(1024) void fps_generic_kernel(int n, int m, const float *__restrict__ xyz,
-                                                           float *__restrict__ temp, int *__restrict__ out)
+                                                           float *__restrict__ temp, int *__restrict__ out,
+                                                           float *__restrict__ out_xyz)
 {
     constexpr int T = 1024, W = T / PN2_WAVE;
     __shared__ unsigned long long part[2][W];
@@ -217,8 +225,12 @@ __global__ __launch_bounds__(1024) void fps_generic_kernel(int n, int m, const f
     int *__restrict__ dst = out + (size_t)cloud * m;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     for (int k = t; k < n; k += T) mind[k] = 1e38f;
+    float *__restrict__ dxyz = out_xyz ? out_xyz + (size_t)cloud * m * 3 : nullptr;
     int cur = 0;
-    if (t == 0) dst[0] = 0;
+    if (t == 0) {
+        dst[0] = 0;
+        if (dxyz) { dxyz[0] = src[0]; dxyz[1] = src[1]; dxyz[2] = src[2]; }
+    }
     // each thread only ever touches its own mind[k] (k = t mod T): no barrier needed for temp
     for (int j = 1; j < m; ++j) {
         const float sx = src[(size_t)cur * 3 + 0], sy = src[(size_t)cur * 3 + 1], sz = src[(size_t)cur * 3 + 2];
@@ -247,7 +259,14 @@ __global__ __launch_bounds__(1024) void fps_generic_kernel(int n, int m, const f
         }
         const unsigned tiekey = 0xFFFFFFFFu - (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
         cur = (int)(((tiekey & 0x3FFFFFu) << 9) | (tiekey >> 22));
-        if (t == 0) dst[j] = cur;
+        if (t == 0) {
+            dst[j] = cur;
+            if (dxyz) {
+                dxyz[j * 3 + 0] = src[(size_t)cur * 3 + 0];
+                dxyz[j * 3 + 1] = src[(size_t)cur * 3 + 1];
+                dxyz[j * 3 + 2] = src[(size_t)cur * 3 + 2];
+            }
+        }
     }
 }
 
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(1024) void fps_generic_kernel(int n, int m, const f
 // host side
 // ---------------------------------------------------------------------------
 template <int T, int P, bool LDSXYZ>
-static int launch_reg(int b, int n, int m, int Q, const float *inp, int *out, hipStream_t st)
+static int launch_reg(int b, int n, int m, int Q, const float *inp, int *out, float *oxyz, hipStream_t st)
 {
     const size_t lds = 256 + (LDSXYZ ? sizeof(float4) : sizeof(int)) * (size_t)T * P;
     auto kern = fps_reg_kernel<T, P, LDSXYZ>;
@@ -264,7 +283,7 @@ static int launch_reg(int b, int n, int m, int Q, const float *inp, int *out, hi
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(b), dim3(T), lds, st, n, m, Q, inp, out);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(T), lds, st, n, m, Q, inp, out, oxyz);
     return launch_status();
 }
 
@@ -272,16 +291,16 @@ constexpr int kMaxLdsSlots = 8192;     // 256 B + 16 B per rank slot <= 160 KiB
 constexpr int kMaxRegPoints = 16384;
 
 template <int T, bool LDSXYZ>
-static int dispatch_p(int P, int b, int n, int m, int Q, const float *inp, int *out, hipStream_t st)
+static int dispatch_p(int P, int b, int n, int m, int Q, const float *inp, int *out, float *oxyz, hipStream_t st)
 {
     switch (P) {
-    case 1: return launch_reg<T, 1, LDSXYZ>(b, n, m, Q, inp, out, st);
-    case 2: return launch_reg<T, 2, LDSXYZ>(b, n, m, Q, inp, out, st);
-    case 4: return launch_reg<T, 4, LDSXYZ>(b, n, m, Q, inp, out, st);
-    case 8: return launch_reg<T, 8, LDSXYZ>(b, n, m, Q, inp, out, st);
-    case 16: return launch_reg<T, 16, LDSXYZ>(b, n, m, Q, inp, out, st);
+    case 1: return launch_reg<T, 1, LDSXYZ>(b, n, m, Q, inp, out, oxyz, st);
+    case 2: return launch_reg<T, 2, LDSXYZ>(b, n, m, Q, inp, out, oxyz, st);
+    case 4: return launch_reg<T, 4, LDSXYZ>(b, n, m, Q, inp, out, oxyz, st);
+    case 8: return launch_reg<T, 8, LDSXYZ>(b, n, m, Q, inp, out, oxyz, st);
+    case 16: return launch_reg<T, 16, LDSXYZ>(b, n, m, Q, inp, out, oxyz, st);
     case 32:
-        if constexpr (T <= 512) return launch_reg<T, 32, LDSXYZ>(b, n, m, Q, inp, out, st);
+        if constexpr (T <= 512) return launch_reg<T, 32, LDSXYZ>(b, n, m, Q, inp, out, oxyz, st);
         break;
     default: break;
     }
@@ -291,15 +310,16 @@ static int dispatch_p(int P, int b, int n, int m, int Q, const float *inp, int *
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 // force a (T,P) configuration: used by the tuning harness (bench.py --fps-sweep)
-static int fps_launch_config(int T, int P, int b, int n, int m, const float *inp, int *out, hipStream_t st)
+static int fps_launch_config(int T, int P, int b, int n, int m, const float *inp, int *out, float *oxyz,
+                             hipStream_t st)
 {
     const int Q = (n + kRefThreads - 1) / kRefThreads;
     if ((long long)T * P < (long long)kRefThreads * Q) return PN2_E_ARG;
     const bool lds = (long long)T * P <= kMaxLdsSlots;
     switch (T) {
-    case 256: return lds ? dispatch_p<256, true>(P, b, n, m, Q, inp, out, st) : dispatch_p<256, false>(P, b, n, m, Q, inp, out, st);
-    case 512: return lds ? dispatch_p<512, true>(P, b, n, m, Q, inp, out, st) : dispatch_p<512, false>(P, b, n, m, Q, inp, out, st);
-    case 1024: return lds ? dispatch_p<1024, true>(P, b, n, m, Q, inp, out, st) : dispatch_p<1024, false>(P, b, n, m, Q, inp, out, st);
+    case 256: return lds ? dispatch_p<256, true>(P, b, n, m, Q, inp, out, oxyz, st) : dispatch_p<256, false>(P, b, n, m, Q, inp, out, oxyz, st);
+    case 512: return lds ? dispatch_p<512, true>(P, b, n, m, Q, inp, out, oxyz, st) : dispatch_p<512, false>(P, b, n, m, Q, inp, out, oxyz, st);
+    case 1024: return lds ? dispatch_p<1024, true>(P, b, n, m, Q, inp, out, oxyz, st) : dispatch_p<1024, false>(P, b, n, m, Q, inp, out, oxyz, st);
     default: return PN2_E_ARG;
     }
 }
@@ -312,17 +332,17 @@ extern "C" long long pn2_fps_temp_floats(int b, int n)
     return n > pn2::kMaxRegPoints ? (long long)b * n : 0;
 }
 
-extern "C" int pn2_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out, void *stream)
+static int fps_entry(int b, int n, int m, const float *inp, float *temp, int *out, float *out_xyz, void *stream)
 {
     using namespace pn2;
     if (m <= 0 || b == 0) return PN2_OK;          // tf_sampling_g.cu:106
     if (b < 0 || n <= 0) return PN2_E_SHAPE;
     if (!inp || !out) return PN2_E_NULL;
-    if ((long long)b * n * 3 > INT_MAX || (long long)b * m > INT_MAX) return PN2_E_TOO_LARGE;
+    if ((long long)b * n * 3 > INT_MAX || (long long)b * m * 3 > INT_MAX) return PN2_E_TOO_LARGE;
     hipStream_t st = as_stream(stream);
     if (n > kMaxRegPoints) {
         if (!temp) return PN2_E_NULL;
-        hipLaunchKernelGGL(fps_generic_kernel, dim3(b), dim3(1024), 0, st, n, m, inp, temp, out);
+        hipLaunchKernelGGL(fps_generic_kernel, dim3(b), dim3(1024), 0, st, n, m, inp, temp, out, out_xyz);
         return launch_status();
     }
     const int Q = (n + kRefThreads - 1) / kRefThreads;
@@ -330,7 +350,19 @@ extern "C" int pn2_farthest_point_sample(int b, int n, int m, const float *inp, 
     // default geometry (measured, scripts/fps_lab.hip): 256 threads up to 1024 ranks, else 512
     const int T = ranks <= 1024 ? 256 : 512;
     const int P = next_pow2((ranks + T - 1) / T);
-    return fps_launch_config(T, P, b, n, m, inp, out, st);
+    return fps_launch_config(T, P, b, n, m, inp, out, out_xyz, st);
+}
+
+extern "C" int pn2_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out, void *stream)
+{
+    return fps_entry(b, n, m, inp, temp, out, nullptr, stream);
+}
+
+extern "C" int pn2_farthest_point_sample_gather(int b, int n, int m, const float *inp, float *temp, int *out,
+                                                float *out_xyz, void *stream)
+{
+    if (m > 0 && b > 0 && !out_xyz) return PN2_E_NULL;
+    return fps_entry(b, n, m, inp, temp, out, out_xyz, stream);
 }
 
 // tuning / test hook: run the register tier with an explicit geometry
@@ -338,5 +370,5 @@ extern "C" int pn2_debug_fps_config(int T, int P, int b, int n, int m, const flo
 {
     if (m <= 0 || b <= 0 || n <= 0 || !inp || !out) return PN2_E_ARG;
     if (n > pn2::kMaxRegPoints) return PN2_E_TOO_LARGE;
-    return pn2::fps_launch_config(T, P, b, n, m, inp, out, pn2::as_stream(stream));
+    return pn2::fps_launch_config(T, P, b, n, m, inp, out, nullptr, pn2::as_stream(stream));
 }

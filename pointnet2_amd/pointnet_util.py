@@ -15,7 +15,7 @@ in behaviour (concat order, pooling modes, weight formula).
 import torch
 import torch.nn as nn
 
-from .tf_sampling import farthest_point_sample, gather_point
+from .tf_sampling import farthest_point_sample, farthest_point_sample_gather, gather_point
 from .tf_grouping import query_ball_point, group_point, knn_point, query_ball_group_xyz
 from .tf_interpolate import three_nn, three_interpolate
 
@@ -30,9 +30,12 @@ def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=Tr
     fused: use the single-pass ball-query+group+centroid-subtract kernel for the
     xyz branch (bit-identical values). Default: whenever xyz needs no gradient.
     """
-    new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))           # :40
     if fused is None:
         fused = not (torch.is_grad_enabled() and xyz.requires_grad)
+    if fused:
+        _, new_xyz = farthest_point_sample_gather(npoint, xyz)                # :40 in one launch
+    else:
+        new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))       # :40
     if knn:
         _, idx = knn_point(nsample, xyz, new_xyz)                             # :42
         grouped_xyz = group_point(xyz, idx) - new_xyz.unsqueeze(2)
@@ -146,8 +149,11 @@ class PointnetSAModuleMSG(nn.Module):
         self.mlps = nn.ModuleList([_SharedMLP(feat, widths, bn) for widths in mlp_list])
 
     def forward(self, xyz, points):
-        new_xyz = gather_point(xyz, farthest_point_sample(self.npoint, xyz))   # :173
         fused = not (torch.is_grad_enabled() and xyz.requires_grad)
+        if fused:
+            _, new_xyz = farthest_point_sample_gather(self.npoint, xyz)        # :173 in one launch
+        else:
+            new_xyz = gather_point(xyz, farthest_point_sample(self.npoint, xyz))   # :173
         outs = []
         for radius, nsample, mlp in zip(self.radius_list, self.nsample_list, self.mlps):
             if fused:

@@ -74,6 +74,31 @@ def gather_point(inp, idx):
     return _GatherPoint.apply(inp, idx)
 
 
+def farthest_point_sample_gather(npoint, inp):
+    """Fused farthest_point_sample + gather_point (pointnet_util.py:40 in one launch).
+
+    npoint int, inp (b, ndataset, 3) f32 -> idx (b, npoint) i32, new_xyz (b, npoint, 3) f32
+    with new_xyz == gather_point(inp, idx) bit for bit. No reference counterpart
+    (SURVEY.md 8f1); not differentiable -- use gather_point when inp needs a gradient.
+    """
+    require(int(npoint) > 0, "FarthestPointSample expects positive npoint")
+    inp = f32(inp.detach() if isinstance(inp, torch.Tensor) else inp, "inp")
+    require(inp.dim() == 3 and inp.shape[2] == 3, "FarthestPointSample expects (batch_size,num_points,3) inp shape")
+    b, n, _ = inp.shape
+    require(n > 0 or b == 0, "FarthestPointSample expects at least one point per cloud")
+    m = int(npoint)
+    dev = inp.device
+    out = torch.empty((b, m), dtype=torch.int32, device=dev)
+    new_xyz = torch.empty((b, m, 3), dtype=torch.float32, device=dev)
+    lib = _C.lib()
+    tf = lib.pn2_fps_temp_floats(b, n)
+    temp = torch.empty((tf,), dtype=torch.float32, device=dev) if tf > 0 else None
+    with torch.cuda.device(dev):
+        _C.check(lib.pn2_farthest_point_sample_gather(b, n, m, ptr(inp), ptr(temp), ptr(out), ptr(new_xyz),
+                                                      stream_ptr(dev)), "farthest_point_sample_gather")
+    return out, new_xyz
+
+
 def farthest_point_sample(npoint, inp):
     """npoint int, inp (b, ndataset, 3) f32 -> (b, npoint) i32, first index 0.
 

@@ -97,6 +97,16 @@ def test_fps_all_geometries_agree(cuda, oracle):
             assert np.array_equal(host(out), want), (T, Pp)
 
 
+def test_fps_gather_fused(cuda, oracle):
+    import pointnet2_amd as P
+    for xyz, m in [(S.duplicated_clouds(3, 1024, 22), 256), (S.uniform_clouds(2, 12000, 23), 40),
+                   (S.uniform_clouds(1, 20000, 24), 20), (S.sphere_clouds(2, 300, 25), 64)]:
+        idx, new_xyz = P.farthest_point_sample_gather(m, dev(xyz, cuda))
+        want = oracle.farthest_point_sample(m, xyz)
+        assert np.array_equal(host(idx), want)
+        assert np.array_equal(host(new_xyz), oracle.gather_point(xyz, want))
+
+
 def test_fps_golden(cuda, golden_dir):
     import pointnet2_amd as P
     g = _load(golden_dir, "fps_literal.npz")
