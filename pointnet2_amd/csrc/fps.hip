@@ -50,6 +50,9 @@ constexpr int kRefThreads = 512;  // tie rule modulus: reference blockDim (tf_sa
 #ifndef PN2_FPS_VMIN_ASM
 #define PN2_FPS_VMIN_ASM 1
 #endif
+#ifndef PN2_FPS_TREE_ARGMAX
+#define PN2_FPS_TREE_ARGMAX 0
+#endif
 __device__ __forceinline__ float vmin_f32(float a, float b)
 {
 #if PN2_FPS_VMIN_ASM
@@ -74,6 +77,24 @@ __device__ __forceinline__ int wave_max_i32_fast(int v)
     PN2_DPP_MAX(v, "row_bcast:15 row_mask:0xa");
     PN2_DPP_MAX(v, "row_bcast:31 row_mask:0xc");
     return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Fused gather_point: new_xyz[j] = inp[idx[j]], written once after the last round by the whole
+// workgroup (coalesced). Doing it inside the round loop costs: the extra live scalars made hipcc
+// switch the arg-max compares from SGPR-pair to VCC encodings, which serialised the selects
+// (+27 % per round, measured).
+template <int T>
+__device__ __forceinline__ void fps_gather_epilogue(int m, const float *__restrict__ src, const int *dst,
+                                                    float *__restrict__ dxyz)
+{
+    if (!dxyz) return;                             // uniform
+    __syncthreads();                               // thread 0's index stores are visible to the workgroup
+    for (int j = threadIdx.x; j < m; j += T) {
+        const int k = __builtin_nontemporal_load(dst + j);
+        dxyz[j * 3 + 0] = src[(size_t)k * 3 + 0];
+        dxyz[j * 3 + 1] = src[(size_t)k * 3 + 1];
+        dxyz[j * 3 + 2] = src[(size_t)k * 3 + 2];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -136,15 +157,33 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int Q, const f
     } else {
         sx = src[0]; sy = src[1]; sz = src[2];
     }
-    if (t == 0) {
-        dst[0] = 0;                                    // tf_sampling_g.cu:114-116
-        if (dxyz) { dxyz[0] = sx; dxyz[1] = sy; dxyz[2] = sz; }
-    }
+    if (t == 0) dst[0] = 0;                            // tf_sampling_g.cu:114-116
 
     const unsigned low0 = 0xFFFFFFFFu - (unsigned)(t * P);   // key low word of this thread's slot 0
     // one round; `par` (the partial buffer parity) is a literal at both call sites so the slot
     // addresses fold to constants (scalar address arithmetic costs 4-cycle issue slots)
     auto round = [&](const int j, const int par) __attribute__((always_inline)) {
+#if PN2_FPS_TREE_ARGMAX
+        // distances first, then a pairwise tournament over the P slots: independent compares at
+        // each level (strict >, the lower slot survives a tie, :146: slots ascend in rank)
+        int tv[P], tp[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const float d = sqdist(x[p], y[p], z[p], sx, sy, sz);
+            md[p] = vmin_f32(d, md[p]);                // min(d,td), :144
+            tv[p] = __float_as_int(md[p]);             // >= 0: int order == float order
+            tp[p] = p;
+        }
+#pragma unroll
+        for (int st = 1; st < P; st <<= 1)
+#pragma unroll
+            for (int i = 0; i + st < P; i += 2 * st) {
+                const bool c = tv[i + st] > tv[i];
+                tp[i] = c ? tp[i + st] : tp[i];
+                tv[i] = c ? tv[i + st] : tv[i];
+            }
+        const int bv = tv[0], bp = tp[0];
+#else
         int bv = -1, bp = 0;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -153,6 +192,7 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int Q, const f
             const int iv = __float_as_int(md[p]);      // >= 0: int order == float order
             if (iv > bv) { bv = iv; bp = p; }          // strict >, :146 (slots ascend in rank)
         }
+#endif
         // wave arg-max, ties -> lowest lane (= lowest rank). The low key word of this lane's
         // candidate is formed in VALU before the reduction; the winning lane stores its own key
         // (no v_readlane round trip through the scalar unit for the payload).
@@ -188,10 +228,7 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int Q, const f
             k = lds_k[rank];
             sx = src[(size_t)k * 3 + 0]; sy = src[(size_t)k * 3 + 1]; sz = src[(size_t)k * 3 + 2];
         }
-        if (t == 0) {
-            dst[j] = k;
-            if (dxyz) { dxyz[j * 3 + 0] = sx; dxyz[j * 3 + 1] = sy; dxyz[j * 3 + 2] = sz; }
-        }
+        if (t == 0) dst[j] = k;
     };
     int j = 1;
     for (; j + 1 < m; j += 2) {
@@ -199,6 +236,7 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int Q, const f
         round(j + 1, 0);
     }
     if (j < m) round(j, 1);
+    fps_gather_epilogue<T>(m, src, dst, dxyz);
 }
 
 // ---------------------------------------------------------------------------
