@@ -13,25 +13,26 @@
 //     rounds (no per-round memory traffic at all; the reference round-trips
 //     `temp` through global memory every round);
 //   * points are dealt to threads in TIE-RANK order: thread t holds ranks
-//     t*P .. t*P+P-1 where rank(k) = (k mod 512)*ceil(n/512) + k/512. The
-//     reference's tie rule then degenerates to "first slot, lowest lane,
-//     lowest wave", which costs nothing in the reduction;
-//   * values are compared as signed-int bit patterns (they are >= 0, or -1
-//     for padding slots), so the wave arg-max is 6 single-instruction
-//     v_max_i32_dpp steps (quad_perm x2, row_half_mirror, row_mirror,
-//     row_bcast:15, row_bcast:31), one v_readlane, one v_cmp_eq (the ballot)
-//     and an s_ff1;
-//   * one s_barrier per round: per-wave partials go through a parity
-//     double-buffered LDS slot array; every wave redundantly picks the winner
-//     from broadcast reads of the <=8 partials (a short VALU select chain on
-//     wave-uniform data; the 16-wave geometry reduces them with DPP instead),
-//     then broadcast-reads the winner's xyz from an LDS copy of the cloud.
-// Measured on MI355X (scripts/fps_lab.hip, B=32 N=4096): the round costs
-// ~540 ns at 512 threads x 8 points, of which ~290 ns is the synchronisation
-// chain and ~250 ns the distance update; 256x16 and 1024x4 are slower
-// (a lone wave per SIMD issues VALU at ~3 cycles/op, 16 waves pay for 16
-// redundant reductions). LDS atomics (ds_max_u64) were tried and rejected:
-// same-address LDS atomics serialise at ~30 cycles each.
+//     t*P .. t*P+P-1 where rank(k) = (k mod 512)*ceil(n/512) + k/512, so the
+//     reference's tie rule becomes "smaller rank wins";
+//   * a candidate is the 64-bit key (value bits : T*P - 1 - rank). Read as
+//     an fp64 number that pattern is positive, finite and ordered exactly like
+//     (larger value, then smaller rank), so EVERY level of the arg-max is a
+//     plain v_max_f64: P-1 per lane, six DPP steps per wave (two v_mov_b32_dpp
+//     + one v_max_f64 each, no scalar unit), W-1 per wave after the barrier;
+//   * one s_barrier per round: lane 63 of each wave publishes the wave key in
+//     a parity double-buffered LDS slot array, every wave max-reduces the W
+//     keys from broadcast reads and broadcast-reads the winner's (x,y,z,k) from
+//     an LDS mirror of the cloud kept in rank order: two dependent LDS trips.
+// Round time on MI355X at B=32, N=4096 (512 threads x 8 points), scripts/fps_prod_lab.hip:
+//   650 ns  first version (int compares + v_cndmask, DPP + v_readlane + ballot, 3 LDS trips)
+//   557 ns  asm DPP ladder, broadcast select, -fno-slp-vectorize (hipcc's v_pk_* packing cost 11 %)
+//   506 ns  64-bit rank keys (2 LDS trips), key low word formed in VALU
+//   425 ns  v_max_f64 on the keys at all three levels
+// Rejected after measurement: ds_max_u64 LDS atomics (~30 cycles per same-address op);
+// scalar-unit resolution of lane/slot (SALU ops cost a 4-cycle issue slot); box-pruned
+// updates over Morton-sorted 64-point regions (exact, but 784 ns: the per-slot scalar
+// branches and a non-rank-ordered lane arg-max cost more than the skipped distances).
 // Clouds too large for the register tiers fall back to a global-memory tier
 // that keeps the running distances in the caller's `temp` buffer.
 #include "pn2_device.h"
@@ -44,14 +45,8 @@ constexpr int kRefThreads = 512;  // tie rule modulus: reference blockDim (tf_sa
 
 // min(d, td) of tf_sampling_g.cu:144 as ONE v_min_f32 (the builtin adds a canonicalising v_max per
 // operand). v_min_f32 returns the non-NaN operand, like CUDA's min(float,float).
-#ifndef PN2_FPS_WINNER_WRITES
-#define PN2_FPS_WINNER_WRITES 0
-#endif
 #ifndef PN2_FPS_VMIN_ASM
 #define PN2_FPS_VMIN_ASM 1
-#endif
-#ifndef PN2_FPS_TREE_ARGMAX
-#define PN2_FPS_TREE_ARGMAX 0
 #endif
 __device__ __forceinline__ float vmin_f32(float a, float b)
 {
@@ -64,19 +59,37 @@ __device__ __forceinline__ float vmin_f32(float a, float b)
 #endif
 }
 
-// Wave-wide signed max as a wave-uniform scalar: six single-instruction DPP steps (the two wait
-// states a DPP source needs after a VALU write are spelled as s_nop 1), then one v_readlane.
-#define PN2_DPP_MAX(v, ctrl) \
-    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 " ctrl " bank_mask:0xf" : "+v"(v))
-__device__ __forceinline__ int wave_max_i32_fast(int v)
+// Wave-wide max of a positive finite double (a (value:low) key, see fps_reg_kernel) WITHOUT the scalar
+// unit: per DPP step two v_mov_b32_dpp fetch the partner lane's halves and one v_max_f64 combines.
+// After the six steps lane 63 holds the wave maximum (rows 1/3 after row_bcast:15, rows 2/3 after
+// row_bcast:31). For the two broadcast steps the unwritten rows keep `old` = the lane's own value.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max_f64_step(double v)
 {
-    PN2_DPP_MAX(v, "quad_perm:[1,0,3,2] row_mask:0xf");
-    PN2_DPP_MAX(v, "quad_perm:[2,3,0,1] row_mask:0xf");
-    PN2_DPP_MAX(v, "row_half_mirror row_mask:0xf");
-    PN2_DPP_MAX(v, "row_mirror row_mask:0xf");
-    PN2_DPP_MAX(v, "row_bcast:15 row_mask:0xa");
-    PN2_DPP_MAX(v, "row_bcast:31 row_mask:0xc");
-    return __builtin_amdgcn_readlane(v, 63);
+    const int hi = __double2hiint(v), lo = __double2loint(v);
+    int ohi, olo;
+    if (ROW_MASK == 0xf) {
+        // every lane has a valid source: the destination needs no initial value (saves two v_mov)
+        ohi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+        olo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    } else {
+        ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+        olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    }
+    const double o = __hiloint2double(ohi, olo);
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(v), "v"(o));
+    return r;
+}
+__device__ __forceinline__ double wave_max_f64_lane63(double v)
+{
+    v = dpp_max_f64_step<0xB1, 0xf>(v);    // quad_perm:[1,0,3,2]
+    v = dpp_max_f64_step<0x4E, 0xf>(v);    // quad_perm:[2,3,0,1]
+    v = dpp_max_f64_step<0x141, 0xf>(v);   // row_half_mirror
+    v = dpp_max_f64_step<0x140, 0xf>(v);   // row_mirror
+    v = dpp_max_f64_step<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
+    v = dpp_max_f64_step<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
+    return v;
 }
 
 // Fused gather_point: new_xyz[j] = inp[idx[j]], written once after the last round by the whole
@@ -105,14 +118,9 @@ __device__ __forceinline__ void fps_gather_epilogue(int m, const float *__restri
 // one broadcast ds_read_b128 (LDSXYZ). Without the LDS mirror (clouds of 8193..16384
 // points) only a rank -> k table lives in LDS and the winner is re-read from L2.
 //
-// A wave's candidate is published as ONE 64-bit key
-//     key = (value bits << 32) | (0xFFFFFFFF - rank)
-// whose unsigned order is exactly "larger value, then smaller rank". After the
-// barrier every wave max-reduces the W keys from broadcast reads (a depth-log2(W)
-// tree of v_cmp_gt_u64 + 2 v_cndmask on wave-uniform data) and reads the winner's
-// point: two dependent LDS trips per round. (The first version selected a byte
-// offset, then fetched the index, then the coordinates: three trips; the s_memtime
-// profile in scripts/fps_prof.hip showed that chain at ~540 of ~1340 cycles.)
+// Keys: (value bits << 32) | (T*P - 1 - rank), compared as fp64 (header). The value
+// is <= 1e38f < 0x7FF00000, so the pattern is never an fp64 Inf/NaN; small values give
+// fp64 denormals, which gfx9 never flushes for v_max_f64 operands.
 // Padding slots carry value +0.0: they can only tie with real zero-distance
 // points, and rank 0 (k = 0, always real) then wins, as in the reference.
 // ---------------------------------------------------------------------------
@@ -121,6 +129,7 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int Q, const f
                                                     int *__restrict__ out, float *__restrict__ out_xyz)
 {
     constexpr int W = T / PN2_WAVE;
+    constexpr int NS = T * P;                      // rank slots
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long *partial = reinterpret_cast<unsigned long long *>(smem);   // [2][W] (256 B reserved)
     float4 *lds_rank = reinterpret_cast<float4 *>(smem + 256);                    // [T*P] when LDSXYZ
@@ -145,87 +154,66 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int Q, const f
         y[p] = valid ? src[(size_t)kk * 3 + 1] : 0.0f;
         z[p] = valid ? src[(size_t)kk * 3 + 2] : 0.0f;
         md[p] = valid ? 1e38f : 0.0f;                  // tf_sampling_g.cu:118; padding: see header
-        if (LDSXYZ) lds_rank[r] = make_float4(x[p], y[p], z[p], __int_as_float(kk));
-        else lds_k[r] = kk;
+        // mirrors are indexed by the key's low word (kMaxLow - rank): one shift-add to the address
+        if (LDSXYZ) lds_rank[NS - 1 - r] = make_float4(x[p], y[p], z[p], __int_as_float(kk));
+        else lds_k[NS - 1 - r] = kk;
     }
     __syncthreads();
 
     float sx, sy, sz;                                  // the point selected last (starts at k = 0 = rank 0)
     if (LDSXYZ) {
-        const float4 s = lds_rank[0];
+        const float4 s = lds_rank[NS - 1];
         sx = s.x; sy = s.y; sz = s.z;
     } else {
         sx = src[0]; sy = src[1]; sz = src[2];
     }
     if (t == 0) dst[0] = 0;                            // tf_sampling_g.cu:114-116
 
-    const unsigned low0 = 0xFFFFFFFFu - (unsigned)(t * P);   // key low word of this thread's slot 0
+    const unsigned low0 = (unsigned)(NS - 1 - t * P);   // key low word of this thread's slot 0: larger = smaller rank
     // one round; `par` (the partial buffer parity) is a literal at both call sites so the slot
     // addresses fold to constants (scalar address arithmetic costs 4-cycle issue slots)
     auto round = [&](const int j, const int par) __attribute__((always_inline)) {
-#if PN2_FPS_TREE_ARGMAX
-        // distances first, then a pairwise tournament over the P slots: independent compares at
-        // each level (strict >, the lower slot survives a tie, :146: slots ascend in rank)
-        int tv[P], tp[P];
+        // Lane arg-max as ONE v_max_f64 per slot: the 64-bit pattern (value bits : low key word) of a
+        // slot, read as a double, is positive, finite (value <= 1e38f < 0x7FF00000) and ordered exactly
+        // like the pair (value, smaller rank first); fp64 denormals are never flushed on gfx9.
+        double kd[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const float d = sqdist(x[p], y[p], z[p], sx, sy, sz);
             md[p] = vmin_f32(d, md[p]);                // min(d,td), :144
-            tv[p] = __float_as_int(md[p]);             // >= 0: int order == float order
-            tp[p] = p;
+            kd[p] = __hiloint2double(__float_as_int(md[p]), (int)(low0 - (unsigned)p));
         }
 #pragma unroll
-        for (int st = 1; st < P; st <<= 1)
+        for (int st = 1; st < P; st <<= 1)             // tournament: depth log2(P), independent v_max_f64 per level
 #pragma unroll
-            for (int i = 0; i + st < P; i += 2 * st) {
-                const bool c = tv[i + st] > tv[i];
-                tp[i] = c ? tp[i + st] : tp[i];
-                tv[i] = c ? tv[i + st] : tv[i];
-            }
-        const int bv = tv[0], bp = tp[0];
-#else
-        int bv = -1, bp = 0;
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const float d = sqdist(x[p], y[p], z[p], sx, sy, sz);
-            md[p] = vmin_f32(d, md[p]);                // min(d,td), :144
-            const int iv = __float_as_int(md[p]);      // >= 0: int order == float order
-            if (iv > bv) { bv = iv; bp = p; }          // strict >, :146 (slots ascend in rank)
-        }
-#endif
-        // wave arg-max, ties -> lowest lane (= lowest rank). The low key word of this lane's
-        // candidate is formed in VALU before the reduction; the winning lane stores its own key
-        // (no v_readlane round trip through the scalar unit for the payload).
-        unsigned mylow = low0 - (unsigned)bp;
-#if PN2_FPS_WINNER_WRITES
-        asm volatile("" : "+v"(mylow));                // keep the slot select out of the store branch
-#endif
-        const int wm = wave_max_i32_fast(bv);
-        const int wl = __builtin_ctzll(__ballot(bv == wm));   // the max is held by some lane
+            for (int i = 0; i + st < P; i += 2 * st)
+                asm("v_max_f64 %0, %1, %2" : "=v"(kd[i]) : "v"(kd[i]), "v"(kd[i + st]));
+        const double bestd = kd[0];
+        // whole-wave key max in VALU only; lane 63 ends up with it and publishes it
         unsigned long long *slot = partial + par * W;
-#if PN2_FPS_WINNER_WRITES
-        if (lane == wl) slot[w] = ((unsigned long long)(unsigned)bv << 32) | (unsigned long long)mylow;
-#else
-        const unsigned wlow = (unsigned)__builtin_amdgcn_readlane((int)mylow, wl);
-        if (lane == 0) slot[w] = ((unsigned long long)(unsigned)wm << 32) | (unsigned long long)wlow;
-#endif
+        {
+            const double wd = wave_max_f64_lane63(bestd);
+            if (lane == 63) reinterpret_cast<double *>(slot)[w] = wd;
+        }
         __syncthreads();
-        // block arg-max: unsigned max of the W keys, every wave redundantly, on wave-uniform data
-        unsigned long long key[W];
+        // block arg-max: v_max_f64 tournament over the W keys, every wave redundantly (wave-uniform data)
+        const double *dslot = reinterpret_cast<const double *>(slot);
+        double key[W];
 #pragma unroll
-        for (int i = 0; i < W; ++i) key[i] = slot[i];
+        for (int i = 0; i < W; ++i) key[i] = dslot[i];
 #pragma unroll
         for (int st = 1; st < W; st <<= 1)
 #pragma unroll
-            for (int i = 0; i + st < W; i += 2 * st) key[i] = key[i + st] > key[i] ? key[i + st] : key[i];
-        const unsigned rank = 0xFFFFFFFFu - (unsigned)key[0];
+            for (int i = 0; i + st < W; i += 2 * st)
+                asm("v_max_f64 %0, %1, %2" : "=v"(key[i]) : "v"(key[i]), "v"(key[i + st]));
+        const unsigned win = (unsigned)__double2loint(key[0]);   // low word of the winning key = mirror index
         int k;
         if (LDSXYZ) {
-            const float4 s = lds_rank[rank];           // same address in every lane: LDS broadcast
+            const float4 s = lds_rank[win];            // same address in every lane: LDS broadcast
             sx = s.x; sy = s.y; sz = s.z;
             k = __float_as_int(s.w);
         } else {
-            k = lds_k[rank];
+            k = lds_k[win];
             sx = src[(size_t)k * 3 + 0]; sy = src[(size_t)k * 3 + 1]; sz = src[(size_t)k * 3 + 2];
         }
         if (t == 0) dst[j] = k;
