@@ -70,3 +70,56 @@ def test_reference_ball_query_kernel_equals_oracle_and_product(cuda, oracle):
         assert same.mean() > 0.999
         pidx, pcnt = P.query_ball_point(r, ns, x, qq)
         assert np.array_equal(pidx.cpu().numpy(), widx) and np.array_equal(pcnt.cpu().numpy(), wcnt)
+
+
+def test_reference_prob_sample_kernel_equals_oracle_and_product(cuda, oracle):
+    """Pins the oracle's restatement of the fp32 tiled scan (tf_sampling_g.cu:7-104) against the
+    reference kernels themselves (probsampleLauncher = cumsumKernel + binarysearchKernel)."""
+    _need(oracle, "sampling_gpu")
+    import pointnet2_amd as P
+    launch = oracle.ref_fn("sampling_gpu", "probsampleLauncher")
+    launch.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4
+    rng = np.random.default_rng(11)
+    for (b, n, m) in [(2, 9000, 400), (3, 100, 64), (1, 8192, 33), (2, 16385, 100), (40, 700, 50), (2, 5, 10)]:
+        p = rng.random((b, n), dtype=np.float32)
+        r = rng.random((b, m), dtype=np.float32)
+        dp, dr = torch.from_numpy(p).to(cuda), torch.from_numpy(r).to(cuda)
+        temp = torch.empty((b, n), dtype=torch.float32, device=cuda)
+        out = torch.zeros((b, m), dtype=torch.int32, device=cuda)
+        torch.cuda.synchronize()
+        launch(b, n, m, dp.data_ptr(), dr.data_ptr(), temp.data_ptr(), out.data_ptr())
+        torch.cuda.synchronize()
+        ref = out.cpu().numpy()
+        assert np.array_equal(ref, oracle.prob_sample(p, r)), ("oracle != reference kernel", b, n, m)
+        assert np.array_equal(ref, P.prob_sample(dp, dr).cpu().numpy()), ("product != reference kernel", b, n, m)
+
+
+def test_reference_selection_sort_and_group_kernels(cuda, oracle):
+    _need(oracle, "grouping_gpu")
+    import pointnet2_amd as P
+    sel = oracle.ref_fn("grouping_gpu", "selectionSortLauncher")
+    sel.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3
+    grp = oracle.ref_fn("grouping_gpu", "groupPointLauncher")
+    grp.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3
+    rng = np.random.default_rng(12)
+    for (b, m, n, k) in [(2, 9, 100, 7), (1, 5, 64, 64), (2, 3, 1000, 32)]:
+        dist = np.round(rng.random((b, m, n), dtype=np.float32) * 40) / 40
+        d = torch.from_numpy(dist).to(cuda)
+        outi = torch.zeros((b, m, n), dtype=torch.int32, device=cuda)
+        out = torch.zeros((b, m, n), dtype=torch.float32, device=cuda)
+        torch.cuda.synchronize()
+        sel(b, n, m, k, d.data_ptr(), outi.data_ptr(), out.data_ptr())
+        torch.cuda.synchronize()
+        wi, wo = oracle.select_top_k(k, dist)
+        assert np.array_equal(outi.cpu().numpy(), wi) and np.array_equal(out.cpu().numpy(), wo)
+        pi, po = P.select_top_k(k, d)
+        assert np.array_equal(pi.cpu().numpy(), wi) and np.array_equal(po.cpu().numpy(), wo)
+    pts = rng.random((3, 200, 7), dtype=np.float32)
+    idx = rng.integers(0, 200, size=(3, 30, 16)).astype(np.int32)
+    dp, di = torch.from_numpy(pts).to(cuda), torch.from_numpy(idx).to(cuda)
+    out = torch.zeros((3, 30, 16, 7), dtype=torch.float32, device=cuda)
+    torch.cuda.synchronize()
+    grp(3, 200, 7, 30, 16, dp.data_ptr(), di.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), oracle.group_point(pts, idx))
+    assert np.array_equal(out.cpu().numpy(), P.group_point(dp, di).cpu().numpy())
