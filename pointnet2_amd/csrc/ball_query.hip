@@ -50,13 +50,55 @@ __device__ __forceinline__ int vbcnt_acc(unsigned long long mask, int acc)
     return r;
 }
 
-// ordered append of one 64-candidate chunk's hits to a query's row buffer; cnt is a wave-uniform VGPR
-__device__ __forceinline__ void bq_append(unsigned long long mask, bool hit, int k, int nsample, int *rowbuf, int &cnt)
+// A query's hits are kept as a BITMAP while the cloud is swept: the ballot of chunk c (64 candidates)
+// is the c-th 64-bit word, parked in lane c of two VGPRs (one v_cndmask per half word, no
+// LDS traffic, no exec-mask juggling). One "window" is 64 chunks = 4096 candidates; bq_flush turns
+// the window's bitmap into the ordered index list: a wave-wide prefix sum of the word popcounts gives
+// every lane its first output slot, then each lane peels its set bits in ascending order.
+// The ordered-compaction-per-chunk version of this kernel spent more issue slots on appending hits
+// (7 VALU + 3 SALU per chunk and query) than on the distances themselves.
+// Park the two queries' ballots of chunk c in lane c of their bitmap registers (`sel` = lane id == c,
+// one v_cmp per chunk shared by the four half words). v_writelane_b32 would need two scalar operands
+// (value + lane select), which gfx9's single constant-bus port only allows through M0.
+__device__ __forceinline__ void bq_park(unsigned &a_lo, unsigned &a_hi, unsigned &b_lo, unsigned &b_hi,
+                                        unsigned long long ma, unsigned long long mb, bool sel)
 {
-    const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                   __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)cnt));
-    if (hit && pos < nsample) rowbuf[pos] = k;
-    cnt = vbcnt_acc(mask, cnt);
+    a_lo = sel ? (unsigned)ma : a_lo;
+    a_hi = sel ? (unsigned)(ma >> 32) : a_hi;
+    b_lo = sel ? (unsigned)mb : b_lo;
+    b_hi = sel ? (unsigned)(mb >> 32) : b_hi;
+}
+
+__device__ __forceinline__ int wave_prefix_sum_incl(int v)
+{
+    // Hillis-Steele over DPP row shifts, then the two cross-row broadcasts
+    int t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); v += t;    // row_shr:1
+    t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true); v += t;    // row_shr:2
+    t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true); v += t;    // row_shr:4
+    t = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true); v += t;    // row_shr:8
+    t = __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); v += t;   // row_bcast:15 -> rows 1,3
+    t = __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); v += t;   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// Append the window's hits (bitmap words mlo/mhi, lane c = chunk c) to rowbuf in ascending index order.
+// `done` = hits already in rowbuf (wave-uniform); returns the new total (may exceed nsample).
+__device__ __forceinline__ int bq_flush(unsigned mlo, unsigned mhi, int window_base, int done, int nsample,
+                                        int *rowbuf, int lane)
+{
+    const int pc = __popc(mlo) + __popc(mhi);
+    const int incl = wave_prefix_sum_incl(pc);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    int pos = done + incl - pc;                       // first output slot of this lane's word
+    unsigned long long word = ((unsigned long long)mhi << 32) | mlo;
+    const int kbase = window_base + lane * 64;
+    while (__any(word != 0ull && pos < nsample)) {
+        if (word != 0ull && pos < nsample) rowbuf[pos] = kbase + __builtin_ctzll(word);
+        word &= word - 1ull;
+        ++pos;
+    }
+    return done + total;
 }
 
 template <bool LDS_CLOUD, bool FUSE>
@@ -127,38 +169,46 @@ __global__ __launch_bounds__(kBqThreads) void ball_query_kernel(int n, int m, in
         const size_t row1 = row0 + (two ? 1 : 0);
         const float ax = xyz2[row0 * 3 + 0], ay = xyz2[row0 * 3 + 1], az = xyz2[row0 * 3 + 2];
         const float bx = xyz2[row1 * 3 + 0], by = xyz2[row1 * 3 + 1], bz = xyz2[row1 * 3 + 2];
-        // hit counters: wave-uniform values kept in VGPRs (see vbcnt_acc)
+        // hit counters: wave-uniform values kept in VGPRs (see vbcnt_acc); bitmap words: lane c = chunk c
         int cnt0 = 0, cnt1 = two ? 0 : nsample;
         asm volatile("v_mov_b32 %0, %0" : "+v"(cnt0));
         asm volatile("v_mov_b32 %0, %0" : "+v"(cnt1));
-        // 128 candidates per trip: two chunks x two queries = four independent distance chains per lane
-        for (int base = 0; base < n; base += 128) {
-            const int kA = base + lane, kB = base + 64 + lane;
-            float pax, pay, paz, pbx, pby, pbz;
-            if (LDS_CLOUD) {
-                const float4 pa = cloud[kA];
-                const float4 pb = cloud[kB];
-                pax = pa.x; pay = pa.y; paz = pa.z; pbx = pb.x; pby = pb.y; pbz = pb.z;
-            } else {
-                const float inf = INFINITY;
-                const float *pa = data + (size_t)min(kA, n - 1) * 3;
-                const float *pb = data + (size_t)min(kB, n - 1) * 3;
-                pax = kA < n ? pa[0] : inf; pay = pa[1]; paz = pa[2];
-                pbx = kB < n ? pb[0] : inf; pby = pb[1]; pbz = pb[2];
+        int done0 = 0, done1 = 0;                            // hits already flushed to the row buffers
+        for (int wbase = 0; wbase < n; wbase += 4096) {      // one window = 64 chunks of 64 candidates
+            unsigned m0lo = 0u, m0hi = 0u, m1lo = 0u, m1hi = 0u;
+            const int wend = min(n, wbase + 4096);
+            // 128 candidates per trip: two chunks x two queries = four independent distance chains per lane
+            for (int base = wbase; base < wend; base += 128) {
+                const int kA = base + lane, kB = base + 64 + lane;
+                float pax, pay, paz, pbx, pby, pbz;
+                if (LDS_CLOUD) {
+                    const float4 pa = cloud[kA];
+                    const float4 pb = cloud[kB];
+                    pax = pa.x; pay = pa.y; paz = pa.z; pbx = pb.x; pby = pb.y; pbz = pb.z;
+                } else {
+                    const float inf = INFINITY;
+                    const float *pa = data + (size_t)min(kA, n - 1) * 3;
+                    const float *pb = data + (size_t)min(kB, n - 1) * 3;
+                    pax = kA < n ? pa[0] : inf; pay = pa[1]; paz = pa[2];
+                    pbx = kB < n ? pb[0] : inf; pby = pb[1]; pbz = pb[2];
+                }
+                // reference operand order: (x2-x1) with x2 the query (query_ball_point.cpp:26-32)
+                const float sA0 = sqdist(ax, ay, az, pax, pay, paz);
+                const float sB0 = sqdist(ax, ay, az, pbx, pby, pbz);
+                const float sA1 = sqdist(bx, by, bz, pax, pay, paz);
+                const float sB1 = sqdist(bx, by, bz, pbx, pby, pbz);
+                const unsigned long long mA0 = __ballot(sA0 < thr), mB0 = __ballot(sB0 < thr);
+                const unsigned long long mA1 = __ballot(sA1 < thr), mB1 = __ballot(sB1 < thr);
+                const int cA = (base - wbase) >> 6;          // chunk number inside the window (scalar)
+                bq_park(m0lo, m0hi, m1lo, m1hi, mA0, mA1, lane == cA);
+                bq_park(m0lo, m0hi, m1lo, m1hi, mB0, mB1, lane == cA + 1);
+                cnt0 = vbcnt_acc(mB0, vbcnt_acc(mA0, cnt0));
+                cnt1 = vbcnt_acc(mB1, vbcnt_acc(mA1, cnt1));
+                // stop as soon as both rows are full (reference: break at cnt == nsample, :23-24)
+                if (__builtin_amdgcn_readfirstlane(min(cnt0, cnt1)) >= nsample) break;
             }
-            // reference operand order: (x2-x1) with x2 the query (query_ball_point.cpp:26-32)
-            const float sA0 = sqdist(ax, ay, az, pax, pay, paz);
-            const float sB0 = sqdist(ax, ay, az, pbx, pby, pbz);
-            const float sA1 = sqdist(bx, by, bz, pax, pay, paz);
-            const float sB1 = sqdist(bx, by, bz, pbx, pby, pbz);
-            const bool hA0 = sA0 < thr, hB0 = sB0 < thr, hA1 = sA1 < thr, hB1 = sB1 < thr;
-            const unsigned long long mA0 = __ballot(hA0), mB0 = __ballot(hB0);
-            const unsigned long long mA1 = __ballot(hA1), mB1 = __ballot(hB1);
-            bq_append(mA0, hA0, kA, nsample, rowbuf0, cnt0);
-            bq_append(mB0, hB0, kB, nsample, rowbuf0, cnt0);
-            bq_append(mA1, hA1, kA, nsample, rowbuf1, cnt1);
-            bq_append(mB1, hB1, kB, nsample, rowbuf1, cnt1);
-            // stop as soon as both rows are full (reference: break at cnt == nsample, :23-24)
+            if (done0 < nsample) done0 = bq_flush(m0lo, m0hi, wbase, done0, nsample, rowbuf0, lane);
+            if (done1 < nsample && two) done1 = bq_flush(m1lo, m1hi, wbase, done1, nsample, rowbuf1, lane);
             if (__builtin_amdgcn_readfirstlane(min(cnt0, cnt1)) >= nsample) break;
         }
         cnt0 = __builtin_amdgcn_readfirstlane(min(cnt0, nsample));
