@@ -40,3 +40,26 @@ def ptr(t):
 
 def stream_ptr(device):
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class on_device:
+    """Make `device` current for a launch, like torch.cuda.device(), but free when it already is
+    (the common case): torch.cuda.device() alone costs several microseconds per operator call."""
+
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device):
+        self.idx = device.index if device.index is not None else torch.cuda.current_device()
+        self.prev = None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            torch.cuda.set_device(self.idx)
+            self.prev = cur
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+        return False

@@ -10,7 +10,7 @@ NoGradient (:21, :32).
 import torch
 
 from . import _C
-from ._tensors import f32, i32, ptr, require, same_device, stream_ptr
+from ._tensors import f32, i32, on_device, ptr, require, same_device, stream_ptr
 
 
 def query_ball_point(radius, nsample, xyz1, xyz2):
@@ -32,7 +32,7 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     ns = int(nsample)
     idx = torch.empty((b, m, ns), dtype=torch.int32, device=dev)
     cnt = torch.empty((b, m), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _C.check(_C.lib().pn2_query_ball_point(b, n, m, float(radius), ns, ptr(xyz1), ptr(xyz2), ptr(idx), ptr(cnt),
                                                stream_ptr(dev)), "query_ball_point")
     return idx, cnt
@@ -60,7 +60,7 @@ def query_ball_group_xyz(radius, nsample, xyz1, xyz2, subtract_centroid=True, wa
     idx = torch.empty((b, m, ns), dtype=torch.int32, device=dev) if want_idx else None
     cnt = torch.empty((b, m), dtype=torch.int32, device=dev)
     grouped = torch.empty((b, m, ns, 3), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _C.check(_C.lib().pn2_query_ball_group_xyz(b, n, m, float(radius), ns, ptr(xyz1), ptr(xyz2),
                                                    1 if subtract_centroid else 0, ptr(idx), ptr(cnt), ptr(grouped),
                                                    stream_ptr(dev)), "query_ball_group_xyz")
@@ -80,7 +80,7 @@ def select_top_k(k, dist):
     dev = dist.device
     outi = torch.empty((b, m, n), dtype=torch.int32, device=dev)
     out = torch.empty((b, m, n), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _C.check(_C.lib().pn2_selection_sort(b, n, m, int(k), ptr(dist), ptr(outi), ptr(out), stream_ptr(dev)),
                  "select_top_k")
     return outi, out
@@ -93,7 +93,7 @@ class _GroupPoint(torch.autograd.Function):
         _, m, ns = idx.shape
         dev = points.device
         out = torch.empty((b, m, ns, c), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _C.check(_C.lib().pn2_group_point(b, n, c, m, ns, ptr(points), ptr(idx), ptr(out), stream_ptr(dev)),
                      "group_point")
         ctx.save_for_backward(idx)
@@ -108,7 +108,7 @@ class _GroupPoint(torch.autograd.Function):
         _, m, ns = idx.shape
         dev = grad_out.device
         grad_points = torch.empty((b, n, c), dtype=torch.float32, device=dev)   # zero-filled by the library
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _C.check(_C.lib().pn2_group_point_grad(b, n, c, m, ns, ptr(grad_out), ptr(idx), ptr(grad_points),
                                                    stream_ptr(dev)), "group_point_grad")
         return grad_points, None

@@ -10,7 +10,7 @@ gradient w.r.t. `points` only (tf_interpolate.py:29-34); ThreeNN is NoGradient (
 import torch
 
 from . import _C
-from ._tensors import f32, i32, ptr, require, same_device, stream_ptr
+from ._tensors import f32, i32, on_device, ptr, require, same_device, stream_ptr
 
 
 def three_nn(xyz1, xyz2):
@@ -30,7 +30,7 @@ def three_nn(xyz1, xyz2):
     m = xyz2.shape[1]
     dist = torch.empty((b, n, 3), dtype=torch.float32, device=dev)
     idx = torch.empty((b, n, 3), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _C.check(_C.lib().pn2_three_nn(b, n, m, ptr(xyz1), ptr(xyz2), ptr(dist), ptr(idx), stream_ptr(dev)),
                  "three_nn")
     return dist, idx
@@ -43,7 +43,7 @@ class _ThreeInterpolate(torch.autograd.Function):
         n = idx.shape[1]
         dev = points.device
         out = torch.empty((b, n, c), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _C.check(_C.lib().pn2_three_interpolate(b, m, c, n, ptr(points), ptr(idx), ptr(weight), ptr(out),
                                                     stream_ptr(dev)), "three_interpolate")
         ctx.save_for_backward(idx, weight)
@@ -58,7 +58,7 @@ class _ThreeInterpolate(torch.autograd.Function):
         n = idx.shape[1]
         dev = grad_out.device
         grad_points = torch.empty((b, m, c), dtype=torch.float32, device=dev)   # zero-filled by the library
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _C.check(_C.lib().pn2_three_interpolate_grad(b, n, c, m, ptr(grad_out), ptr(idx), ptr(weight),
                                                          ptr(grad_points), stream_ptr(dev)),
                      "three_interpolate_grad")

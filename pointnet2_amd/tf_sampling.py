@@ -11,7 +11,7 @@ ProbSample are NoGradient (:22, :57).
 import torch
 
 from . import _C
-from ._tensors import f32, i32, ptr, require, same_device, stream_ptr
+from ._tensors import f32, i32, on_device, ptr, require, same_device, stream_ptr
 
 
 def prob_sample(inp, inpr):
@@ -28,7 +28,7 @@ def prob_sample(inp, inpr):
     dev = same_device(inp, inpr)
     out = torch.empty((b, m), dtype=torch.int32, device=dev)
     temp = torch.empty((b, n), dtype=torch.float32, device=dev)   # allocate_temp, tf_sampling.cpp:87
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _C.check(_C.lib().pn2_prob_sample(b, n, m, ptr(inp), ptr(inpr), ptr(temp), ptr(out), stream_ptr(dev)),
                  "prob_sample")
     return out
@@ -41,7 +41,7 @@ class _GatherPoint(torch.autograd.Function):
         m = idx.shape[1]
         dev = inp.device
         out = torch.empty((b, m, 3), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _C.check(_C.lib().pn2_gather_point(b, n, m, ptr(inp), ptr(idx), ptr(out), stream_ptr(dev)),
                      "gather_point")
         ctx.save_for_backward(idx)
@@ -55,7 +55,7 @@ class _GatherPoint(torch.autograd.Function):
         b, m = idx.shape
         dev = out_g.device
         inp_g = torch.empty((b, ctx.n, 3), dtype=torch.float32, device=dev)   # zero-filled by the library
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _C.check(_C.lib().pn2_gather_point_grad(b, ctx.n, m, ptr(out_g), ptr(idx), ptr(inp_g), stream_ptr(dev)),
                      "gather_point_grad")
         return inp_g, None
@@ -93,7 +93,7 @@ def farthest_point_sample_gather(npoint, inp):
     lib = _C.lib()
     tf = lib.pn2_fps_temp_floats(b, n)
     temp = torch.empty((tf,), dtype=torch.float32, device=dev) if tf > 0 else None
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _C.check(lib.pn2_farthest_point_sample_gather(b, n, m, ptr(inp), ptr(temp), ptr(out), ptr(new_xyz),
                                                       stream_ptr(dev)), "farthest_point_sample_gather")
     return out, new_xyz
@@ -116,7 +116,7 @@ def farthest_point_sample(npoint, inp):
     lib = _C.lib()
     tf = lib.pn2_fps_temp_floats(b, n)
     temp = torch.empty((tf,), dtype=torch.float32, device=dev) if tf > 0 else None   # allocate_temp, tf_sampling.cpp:115
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _C.check(lib.pn2_farthest_point_sample(b, n, m, ptr(inp), ptr(temp), ptr(out), stream_ptr(dev)),
                  "farthest_point_sample")
     return out
