@@ -12,11 +12,13 @@ One "step" = one pass of the hot path over one batch of synthetic clouds already
 i.e. reference utils/pointnet_util.py:40-46, launched through the C ABI of libpn2ops.so
 (include/pn2ops.h) on torch's current HIP stream with caller-allocated outputs.
 
---path fused (default) is what pointnet2_amd.pointnet_util.sample_and_group launches: the same
-outputs from TWO kernels -- pn2_farthest_point_sample_gather (fps_idx + new_xyz) and
-pn2_query_ball_group_xyz (idx + pts_cnt + grouped_xyz with the centroid subtracted, :46).
---path ops launches the four reference-shaped operators one by one. Both are parity-tested
-bit-exact against the oracle; `kernels` always reports the four op-level kernels.
+--path overlap (default) is what pointnet2_amd.pointnet_util.sample_and_group launches: ONE kernel
+(pn2_sample_and_group_xyz) whose FPS workgroups publish every sample as it is selected while
+ball-query+group workgroups on the other CUs consume them, so the queries hide under the serial
+FPS chain. --path fused: TWO kernels (pn2_farthest_point_sample_gather, pn2_query_ball_group_xyz).
+--path ops: the four reference-shaped operators one by one. All three produce the same outputs
+(fps_idx, new_xyz, idx, pts_cnt, grouped_xyz) and are parity-tested bit-exact against the oracle;
+`kernels` always reports the four op-level kernels.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -75,6 +77,7 @@ class Stage:
         self.idx = torch.empty((B, M, NS), dtype=torch.int32, device=dev)
         self.cnt = torch.empty((B, M), dtype=torch.int32, device=dev)
         self.grouped = torch.empty((B, M, NS, 3), dtype=torch.float32, device=dev)
+        self.ws = torch.empty((self.lib.pn2_sample_and_group_ws_bytes(B, M),), dtype=torch.uint8, device=dev)
         self.stream = torch.cuda.current_stream(dev).cuda_stream
 
     def fps_(self):
@@ -101,6 +104,15 @@ class Stage:
         _C.check(self.lib.pn2_query_ball_group_xyz(B, N, M, RADIUS, NS, self.xyz.data_ptr(), self.new_xyz.data_ptr(),
                                                    1, self.idx.data_ptr(), self.cnt.data_ptr(),
                                                    self.grouped.data_ptr(), self.stream), "ball_group")
+
+    def overlap_(self):
+        _C.check(self.lib.pn2_sample_and_group_xyz(B, N, M, RADIUS, NS, self.xyz.data_ptr(), self.ws.data_ptr(),
+                                                   self.fps.data_ptr(), self.new_xyz.data_ptr(), self.idx.data_ptr(),
+                                                   self.cnt.data_ptr(), self.grouped.data_ptr(), 1, self.stream),
+                 "sample_and_group_xyz")
+
+    def step_overlap(self):
+        self.overlap_()
 
     def step_ops(self):
         self.fps_()
@@ -133,6 +145,18 @@ def kernel_times(stage, reps=10, fused=False):
     return out
 
 
+def one_kernel_time(fn, reps=10):
+    fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for s, e in evs:
+        s.record()
+        fn()
+        e.record()
+    torch.cuda.synchronize()
+    return float(np.median([s.elapsed_time(e) for s, e in evs])) * 1e-3
+
+
 def concurrent_throughput(dev, rank, path, streams, steps):
     """EXTRA figure (not `value`): the same step on `streams` independent B=32 batches in flight on
     separate HIP streams. One FPS launch occupies 32 of the 256 CUs for its whole serial chain, so
@@ -142,7 +166,7 @@ def concurrent_throughput(dev, rank, path, streams, steps):
     for i, st in enumerate(ss):
         with torch.cuda.stream(st):
             stages.append(Stage(dev, seed=2000 + 97 * rank + i))
-    fns = [(sg.step_fused if path == "fused" else sg.step_ops) for sg in stages]
+    fns = [{"overlap": sg.step_overlap, "fused": sg.step_fused, "ops": sg.step_ops}[path] for sg in stages]
     for st, fn in zip(ss, fns):
         with torch.cuda.stream(st):
             fn()
@@ -186,7 +210,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--path", choices=("fused", "ops"), default="fused")
+    ap.add_argument("--path", choices=("overlap", "fused", "ops"), default="overlap")
     ap.add_argument("--streams", type=int, default=8, help="batches in flight for the extra `concurrent` figure (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -206,7 +230,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     stage = Stage(dev, seed=1000 + rank)          # every rank owns its own B=32 batch (weak scaling)
-    step = stage.step_fused if args.path == "fused" else stage.step_ops
+    step = {"overlap": stage.step_overlap, "fused": stage.step_fused, "ops": stage.step_ops}[args.path]
     for _ in range(max(args.warmup, 1)):
         step()
     torch.cuda.synchronize()
@@ -229,6 +253,7 @@ def main():
     if rank == 0:
         kt = kernel_times(stage)
         ktf = kernel_times(stage, fused=True)
+        kto = one_kernel_time(stage.overlap_)
         dom = max(kt, key=kt.get)
         achieved = BYTES[dom] * B / kt[dom] / 1e9
         traffic = None
@@ -255,8 +280,11 @@ def main():
             "config": {"workload": "SA stage FPS+gather+ball_query+group, B=32 per GPU, N=4096->npoint=1024, "
                                    "radius=0.2, nsample=32, xyz only (BASELINE configs: metric shape)",
                        "clouds": "D1: unit-sphere surface x U(0.9,1.0), pc_normalize'd, seeded per rank",
-                       "path": args.path + (" (2 launches: FPS+gather, ball query+group+centroid subtract)"
-                                            if args.path == "fused" else " (4 reference-shaped operator launches)"),
+                       "path": args.path + {
+                           "overlap": " (1 launch: FPS producers publish samples, ball-query+group consumers on the "
+                                      "other CUs start query j when sample j exists; what sample_and_group launches)",
+                           "fused": " (2 launches: FPS+gather, ball query+group+centroid subtract)",
+                           "ops": " (4 reference-shaped operator launches)"}[args.path],
                        "sharding": "%d independent batch shard(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -265,6 +293,7 @@ def main():
             "kernels": {k: {"us": v * 1e6, "algorithmic_GBps": BYTES[k] * B / v / 1e9,
                             "frac_of_hbm_peak": BYTES[k] * B / v / 1e9 / HBM_PEAK_GBS} for k, v in kt.items()},
             "fused_kernels": {k: {"us": v * 1e6} for k, v in ktf.items()},
+            "overlap_kernel": {"sample_and_group_xyz": {"us": kto * 1e6}},
             "stage": {"bytes_per_cloud": STAGE_BYTES, "sum_kernel_us": total_k * 1e6,
                       "sum_fused_kernel_us": sum(ktf.values()) * 1e6,
                       "algorithmic_GBps": STAGE_BYTES * B / total_k / 1e9,

@@ -117,6 +117,20 @@ int pn2_farthest_point_sample_gather(int b, int n, int m, const float *inp, floa
 int pn2_query_ball_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
                              int subtract_centroid, int *idx, int *pts_cnt, float *grouped_xyz, void *stream);
 
+/* The whole xyz half of sample_and_group (pointnet_util.py:40-46) in ONE launch, with the ball
+ * queries overlapped under the farthest-point-sampling chain: producer workgroups (one per cloud)
+ * publish each sample as they select it, consumer workgroups on the other CUs run query j as soon as
+ * sample j exists. Outputs are bit-identical to the separate operators:
+ *   fps_idx (b,m) i32, new_xyz (b,m,3) f32, idx (b,m,nsample) i32, pts_cnt (b,m) i32,
+ *   grouped_xyz (b,m,nsample,3) f32 (minus the centroid when subtract_centroid != 0).
+ * ws: device scratch of pn2_sample_and_group_ws_bytes(b,m) bytes (zeroed here on `stream`).
+ * Returns PN2_E_TOO_LARGE for shapes outside the overlapped launch's envelope (b > 128, n > 8192,
+ * n < 64, nsample > 256): use pn2_farthest_point_sample_gather + pn2_query_ball_group_xyz then. */
+int pn2_sample_and_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,
+                             int *fps_idx, float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz,
+                             int subtract_centroid, void *stream);
+long long pn2_sample_and_group_ws_bytes(int b, int m);
+
 /* ---- host helpers ------------------------------------------------------- */
 
 /* The exact fp32 threshold s* with  max(sqrtf(s),1e-20f) < radius  <=>  s < s*

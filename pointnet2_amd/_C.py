@@ -40,12 +40,15 @@ _SIGNATURES = {
     "pn2_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pn2_three_interpolate_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pn2_query_ball_group_xyz": [_i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "pn2_sample_and_group_xyz": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "pn2_sample_and_group_ws_bytes": [_i, _i],
     "pn2_ball_threshold": [_f],
     "pn2_version": [],
     "pn2_debug_fps_config": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
 }
 _RESTYPES = {
     "pn2_fps_temp_floats": ctypes.c_longlong,
+    "pn2_sample_and_group_ws_bytes": ctypes.c_longlong,
     "pn2_ball_threshold": ctypes.c_float,
     "pn2_version": ctypes.c_char_p,
 }

@@ -1,0 +1,121 @@
+// sa_fused.hip -- the xyz half of sample_and_group in ONE launch, with the ball queries overlapped
+// under the farthest-point-sampling chain.
+//
+// What it computes is exactly reference utils/pointnet_util.py:40-46:
+//     fps_idx = farthest_point_sample(npoint, xyz);  new_xyz = gather_point(xyz, fps_idx)
+//     idx, pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)
+//     grouped_xyz = group_point(xyz, idx) [- new_xyz]
+// with the same kernels' device bodies (fps_body.h, ball_query_body.h), so every output is
+// bit-identical to the separate operators (tests/test_parity_gpu.py::test_sample_and_group_overlapped).
+//
+// Why: FPS is a serial chain that keeps ONE CU per cloud busy for its whole duration (32 of 256 CUs at
+// B=32) while the ball queries (a whole-GPU kernel, 56 us at the metric shape) can only start after it
+// in a stream. Query j, however, needs nothing but sample j. Here the grid is heterogeneous:
+//     blocks [0, b)          FPS producers, one per cloud; thread 0 publishes every selected index as
+//                            an 8-byte {tag, index} granule with one write-through store;
+//     blocks [b, b + nq*b)   ball-query consumers, ordered by query range first, cloud second; each wave
+//                            polls the granules of its two queries, then sweeps the LDS copy of the cloud.
+// Hand-off: form R2 of the CDNA programming guide (Guideline 16) -- the data is the flag, agent-scope
+// relaxed 8-byte atomics on both sides, no fences; the granule array is zeroed on the stream before the
+// launch, tag = 1. Every workgroup asks for more than half of the CU's LDS, so producers never share
+// a CU with consumers (a co-resident consumer would steal issue slots from the latency-bound chain).
+//
+// Residency: consumers spin until their producer has advanced; this is deadlock-free as long as the
+// b producer blocks are resident, which holds because workgroups are dispatched in block-index order
+// (producers first) and b <= kMaxClouds << 256 CUs. HIP does not promise that order, so the spin is
+// bounded and traps instead of hanging, and the entry point refuses shapes outside the envelope
+// (callers fall back to the two-launch path: pn2_farthest_point_sample_gather + pn2_query_ball_group_xyz).
+#include "ball_query_body.h"
+#include "fps_body.h"
+
+#include <limits.h>
+
+namespace pn2 {
+
+constexpr int kFusedThreads = 512;
+constexpr int kFusedMaxClouds = 128;            // producers must leave most CUs to the consumers
+constexpr size_t kFusedMinLds = 82 * 1024;      // > 160 KiB / 2: one workgroup per CU
+
+template <int P>
+__global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, int m, int Q, int nsample, float thr,
+                                                                 int qpb, const float *__restrict__ xyz,
+                                                                 unsigned long long *__restrict__ tagged,
+                                                                 int *__restrict__ fps_idx,
+                                                                 float *__restrict__ new_xyz, int *__restrict__ idx,
+                                                                 int *__restrict__ pts_cnt,
+                                                                 float *__restrict__ grouped, int subtract)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int blk = blockIdx.x;
+    if (blk < b) {
+        fps_reg_body<kFusedThreads, P, true, true>(n, m, Q, blk, xyz, fps_idx, nullptr, tagged, smem);
+    } else {
+        const int id = blk - b;
+        const int cloud = id % b;                // query range first, cloud second: the consumers that can
+        const int q0 = (id / b) * qpb;           // start earliest are dispatched first
+        bq_block_body<true, true, true>(n, m, nsample, thr, cloud, q0, min(q0 + qpb, m), xyz, nullptr, tagged,
+                                        new_xyz, idx, pts_cnt, grouped, subtract, smem);
+    }
+}
+
+template <int P>
+static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, const float *xyz,
+                        unsigned long long *ws, int *fps_idx, float *new_xyz, int *idx, int *pts_cnt,
+                        float *grouped, int subtract, hipStream_t st)
+{
+    constexpr int kGran = kBqWaves * kBqQpw;
+    // consumers: about one per free CU and query range; a range is a multiple of 16 queries
+    int qpb = 64;
+    if (qpb > m) qpb = ((m + kGran - 1) / kGran) * kGran;
+    const int nq = (m + qpb - 1) / qpb;
+    size_t lds_f = 256 + sizeof(float4) * (size_t)kFusedThreads * P;
+    size_t lds_q = sizeof(float4) * (size_t)((n + 127) & ~127) + sizeof(int) * (size_t)nsample * kGran;
+    size_t lds = lds_f > lds_q ? lds_f : lds_q;
+    if (lds < kFusedMinLds) lds = kFusedMinLds;
+    if (lds > 160 * 1024) return PN2_E_TOO_LARGE;
+    auto kern = sa_fused_kernel<P>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(ws, 0, sizeof(unsigned long long) * (size_t)b * m, st);   // tags = 0: nothing published yet
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(b + nq * b), dim3(kFusedThreads), lds, st, b, n, m, Q, nsample, thr, qpb, xyz, ws,
+                       fps_idx, new_xyz, idx, pts_cnt, grouped, subtract);
+    return launch_status();
+}
+
+}  // namespace pn2
+
+extern "C" long long pn2_sample_and_group_ws_bytes(int b, int m)
+{
+    if (b <= 0 || m <= 0) return 0;
+    return (long long)sizeof(unsigned long long) * b * m;
+}
+
+extern "C" int pn2_sample_and_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,
+                                        int *fps_idx, float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz,
+                                        int subtract_centroid, void *stream)
+{
+    using namespace pn2;
+    if (!(radius > 0.0f) || nsample <= 0 || m <= 0) return PN2_E_ARG;
+    if (b <= 0 || n <= 0) return PN2_E_SHAPE;
+    if (!xyz || !ws || !fps_idx || !new_xyz || !idx || !pts_cnt || !grouped_xyz) return PN2_E_NULL;
+    // envelope of the overlapped launch (outside it the caller uses the two-launch path)
+    if (b > kFusedMaxClouds || n > 8192 || n < 64 || nsample > 256) return PN2_E_TOO_LARGE;
+    if ((long long)b * m * nsample * 3 > INT_MAX) return PN2_E_TOO_LARGE;
+    const int Q = (n + kRefThreads - 1) / kRefThreads;
+    const int ranks = kRefThreads * Q;
+    int P = 1;
+    while (kFusedThreads * P < ranks) P <<= 1;
+    const float thr = pn2_ball_threshold(radius);
+    hipStream_t st = as_stream(stream);
+    unsigned long long *w = reinterpret_cast<unsigned long long *>(ws);
+    switch (P) {
+    case 1: return launch_fused<1>(b, n, m, Q, nsample, thr, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
+    case 2: return launch_fused<2>(b, n, m, Q, nsample, thr, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
+    case 4: return launch_fused<4>(b, n, m, Q, nsample, thr, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
+    case 8: return launch_fused<8>(b, n, m, Q, nsample, thr, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
+    case 16: return launch_fused<16>(b, n, m, Q, nsample, thr, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
+    default: return PN2_E_TOO_LARGE;
+    }
+}

@@ -16,7 +16,8 @@ import torch
 import torch.nn as nn
 
 from .tf_sampling import farthest_point_sample, farthest_point_sample_gather, gather_point
-from .tf_grouping import query_ball_point, group_point, knn_point, query_ball_group_xyz
+from .tf_grouping import (query_ball_point, group_point, knn_point, query_ball_group_xyz,
+                          sample_and_group_xyz)
 from .tf_interpolate import three_nn, three_interpolate
 
 
@@ -27,20 +28,23 @@ def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=Tr
     -> new_xyz (b, npoint, 3), new_points (b, npoint, nsample, 3+channel),
        idx (b, npoint, nsample), grouped_xyz (b, npoint, nsample, 3)
 
-    fused: use the single-pass ball-query+group+centroid-subtract kernel for the
-    xyz branch (bit-identical values). Default: whenever xyz needs no gradient.
+    fused: use the fused kernels for the xyz branch (bit-identical values): the single overlapped
+    launch of csrc/sa_fused.hip (or, with knn, FPS+gather in one launch). Default: whenever xyz
+    needs no gradient.
     """
     if fused is None:
         fused = not (torch.is_grad_enabled() and xyz.requires_grad)
-    if fused:
+    if fused and not knn:
+        _, new_xyz, idx, _, grouped_xyz = sample_and_group_xyz(npoint, radius, nsample, xyz, True)   # :40-46
+    elif fused:
         _, new_xyz = farthest_point_sample_gather(npoint, xyz)                # :40 in one launch
     else:
         new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))       # :40
-    if knn:
+    if fused and not knn:
+        pass
+    elif knn:
         _, idx = knn_point(nsample, xyz, new_xyz)                             # :42
         grouped_xyz = group_point(xyz, idx) - new_xyz.unsqueeze(2)
-    elif fused:
-        idx, _, grouped_xyz = query_ball_group_xyz(radius, nsample, xyz, new_xyz, subtract_centroid=True)
     else:
         idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)              # :44
         grouped_xyz = group_point(xyz, idx)                                   # :45

@@ -67,6 +67,44 @@ def query_ball_group_xyz(radius, nsample, xyz1, xyz2, subtract_centroid=True, wa
     return idx, cnt, grouped
 
 
+def sample_and_group_xyz(npoint, radius, nsample, xyz, subtract_centroid=True):
+    """The xyz half of sample_and_group (pointnet_util.py:40-46) in ONE launch: farthest point
+    sampling, gather, ball query and grouping of xyz, with the ball queries running on the idle CUs
+    while the FPS chain is still selecting (csrc/sa_fused.hip). Bit-identical to the separate
+    operators. Not differentiable. Shapes outside the overlapped launch's envelope fall back to the
+    two-launch path (farthest_point_sample_gather + query_ball_group_xyz).
+
+    -> fps_idx (b,m) i32, new_xyz (b,m,3) f32, idx (b,m,nsample) i32, pts_cnt (b,m) i32,
+       grouped_xyz (b,m,nsample,3) f32
+    """
+    require(int(npoint) > 0, "FarthestPointSample expects positive npoint")
+    require(float(radius) > 0, "QueryBallPoint expects positive radius")
+    require(int(nsample) > 0, "QueryBallPoint expects positive nsample")
+    xyz = f32(xyz.detach(), "xyz")
+    require(xyz.dim() == 3 and xyz.shape[2] == 3, "FarthestPointSample expects (batch_size,num_points,3) inp shape")
+    b, n, _ = xyz.shape
+    m, ns = int(npoint), int(nsample)
+    dev = xyz.device
+    lib = _C.lib()
+    if b == 0 or not (b <= 128 and 64 <= n <= 8192 and ns <= 256):
+        from .tf_sampling import farthest_point_sample_gather
+        fps_idx, new_xyz = farthest_point_sample_gather(m, xyz)
+        idx, cnt, grouped = query_ball_group_xyz(radius, ns, xyz, new_xyz, subtract_centroid)
+        return fps_idx, new_xyz, idx, cnt, grouped
+    fps_idx = torch.empty((b, m), dtype=torch.int32, device=dev)
+    new_xyz = torch.empty((b, m, 3), dtype=torch.float32, device=dev)
+    idx = torch.empty((b, m, ns), dtype=torch.int32, device=dev)
+    cnt = torch.empty((b, m), dtype=torch.int32, device=dev)
+    grouped = torch.empty((b, m, ns, 3), dtype=torch.float32, device=dev)
+    ws = torch.empty((lib.pn2_sample_and_group_ws_bytes(b, m),), dtype=torch.uint8, device=dev)
+    with on_device(dev):
+        _C.check(lib.pn2_sample_and_group_xyz(b, n, m, float(radius), ns, ptr(xyz), ptr(ws), ptr(fps_idx),
+                                              ptr(new_xyz), ptr(idx), ptr(cnt), ptr(grouped),
+                                              1 if subtract_centroid else 0, stream_ptr(dev)),
+                 "sample_and_group_xyz")
+    return fps_idx, new_xyz, idx, cnt, grouped
+
+
 def select_top_k(k, dist):
     """k int, dist (b, m, n) f32 -> idx (b, m, n) i32, dist_out (b, m, n) f32;
     the first k entries of each row are the k smallest, ascending.

@@ -362,6 +362,47 @@ def test_sample_and_group_matches_oracle_composition(cuda, oracle):
         assert np.array_equal(host(g), gx) and np.array_equal(host(npts), want)
 
 
+@pytest.mark.parametrize("b,n,m,r,ns,gen", [
+    (2, 1024, 256, 0.2, 32, "sphere"),      # BASELINE config 1
+    (32, 4096, 1024, 0.2, 32, "sphere"),    # the metric shape
+    (3, 700, 300, 0.3, 64, "dup"),          # ties everywhere, n not a multiple of anything
+    (2, 8192, 512, 0.1, 32, "uniform"),     # sem_seg SA1, two bitmap windows
+    (5, 100, 100, 0.5, 200, "uniform"),     # every point sampled, nsample > n
+    (2, 64, 7, 0.05, 1, "uniform"),
+])
+def test_sample_and_group_overlapped(cuda, oracle, b, n, m, r, ns, gen):
+    """The single overlapped launch (producers publish samples, consumers poll them) against the oracle
+    composition FPS -> gather -> ball query -> group - centroid, bit for bit. Run several times: the
+    hand-off is timing dependent."""
+    import pointnet2_amd as P
+    xyz = {"sphere": S.sphere_clouds, "dup": S.duplicated_clouds, "uniform": S.uniform_clouds}[gen](b, n, 123)
+    fps = oracle.farthest_point_sample(m, xyz)
+    new_xyz = oracle.gather_point(xyz, fps)
+    idx, cnt = oracle.query_ball_point(r, ns, xyz, new_xyz)
+    gx = oracle.group_point(xyz, idx) - new_xyz[:, :, None, :]
+    x = dev(xyz, cuda)
+    for rep in range(3):
+        f, nx, i, c, g = P.sample_and_group_xyz(m, r, ns, x, True)
+        assert np.array_equal(host(f), fps), rep
+        assert np.array_equal(host(nx), new_xyz), rep
+        assert np.array_equal(host(i), idx) and np.array_equal(host(c), cnt), rep
+        assert np.array_equal(host(g), gx), rep
+    f, nx, i, c, g = P.sample_and_group_xyz(m, r, ns, x, False)
+    assert np.array_equal(host(g), oracle.group_point(xyz, idx))
+
+
+def test_sample_and_group_envelope_fallback(cuda, oracle):
+    """Shapes outside the overlapped launch's envelope take the two-launch path, same results."""
+    import pointnet2_amd as P
+    xyz = S.uniform_clouds(1, 9000, 7)
+    f, nx, i, c, g = P.sample_and_group_xyz(64, 0.1, 16, dev(xyz, cuda), True)
+    fps = oracle.farthest_point_sample(64, xyz)
+    q = oracle.gather_point(xyz, fps)
+    idx, cnt = oracle.query_ball_point(0.1, 16, xyz, q)
+    assert np.array_equal(host(f), fps) and np.array_equal(host(i), idx) and np.array_equal(host(c), cnt)
+    assert np.array_equal(host(g), oracle.group_point(xyz, idx) - q[:, :, None, :])
+
+
 def test_fp_weights_and_interpolation(cuda, oracle):
     from pointnet2_amd.pointnet_util import three_nn_weights
     import pointnet2_amd as P
