@@ -154,13 +154,20 @@ class PointnetSAModuleMSG(nn.Module):
 
     def forward(self, xyz, points):
         fused = not (torch.is_grad_enabled() and xyz.requires_grad)
+        first = None
         if fused:
-            _, new_xyz = farthest_point_sample_gather(self.npoint, xyz)        # :173 in one launch
+            # FPS + the first scale's ball query/group in the single overlapped launch (:173-180);
+            # the other scales reuse new_xyz
+            _, new_xyz, idx0, _, gx0 = sample_and_group_xyz(self.npoint, self.radius_list[0],
+                                                            self.nsample_list[0], xyz, True)
+            first = (idx0, gx0)
         else:
             new_xyz = gather_point(xyz, farthest_point_sample(self.npoint, xyz))   # :173
         outs = []
-        for radius, nsample, mlp in zip(self.radius_list, self.nsample_list, self.mlps):
-            if fused:
+        for si, (radius, nsample, mlp) in enumerate(zip(self.radius_list, self.nsample_list, self.mlps)):
+            if fused and si == 0:
+                idx, grouped_xyz = first
+            elif fused:
                 idx, _, grouped_xyz = query_ball_group_xyz(radius, nsample, xyz, new_xyz, True,
                                                            want_idx=points is not None)
             else:
