@@ -11,11 +11,13 @@
 //   * three_interpolate is bit-exact too: (p1*w1 + p2*w2) + p3*w3, no FMA.
 //   * the gradient accumulates with fp32 atomics (order not fixed).
 //
-// Design (DESIGN.md "three_nn"). One lane per unknown point; the known points
-// are staged through LDS in float4 tiles and read as wave-wide broadcasts, so
-// the inner loop is VALU only. The 3-slot insertion is skipped wave-uniformly
-// whenever no lane improves its third best (the common case after the first
-// few hundred candidates).
+// Design (DESIGN.md "three_nn"). FOUR lanes (a DPP quad) per unknown point: the known points are
+// staged through LDS in float4 tiles, lane q of the quad scans the q-th quarter of every tile in
+// ascending order with the reference's strict-< insertion (four candidates per trip, one wave-
+// uniform skip test), and at the end the quad merges its four triples with two quad_perm exchanges
+// under the explicit order key (d, k) -- the key the reference's single ascending scan implies.
+// The first version used one lane per point: at the largest FP layer (8 x 8192 unknown points) that
+// is one wave per SIMD, a pure latency chain (115 us); the quad split quadruples the waves in flight.
 #include "pn2_device.h"
 
 #include <limits.h>
@@ -23,8 +25,9 @@
 
 namespace pn2 {
 
-constexpr int kNnThreads = 128;
-constexpr int kNnTile = 2048;   // known points per LDS tile (32 KiB)
+constexpr int kNnThreads = 256;             // 64 unknown points x 4 lanes
+constexpr int kNnPoints = kNnThreads / 4;
+constexpr int kNnTile = 2048;               // known points per LDS tile (32 KiB), a multiple of 16
 
 // strict-< insertion of candidate (d, kk) into the ascending triple (tf_interpolate.cpp:74-89), branch-free
 __device__ __forceinline__ void nn_insert(float d, int kk, float &b1, float &b2, float &b3, int &i1, int &i2, int &i3)
@@ -39,13 +42,53 @@ __device__ __forceinline__ void nn_insert(float d, int kk, float &b1, float &b2,
     b2 = nb2; i2 = ni2; b3 = nb3; i3 = ni3;
 }
 
+// the same insertion under the explicit key (d, k): used only to merge the four lanes' triples.
+// Empty slots are (+inf, 0); a real candidate with d = +inf is never inserted by the reference
+// (inf < 1e40 is false), and (inf, k) < (inf, 0) is false here too.
+__device__ __forceinline__ bool nn_less(float d, int k, float b, int i) { return d < b || (d == b && k < i); }
+__device__ __forceinline__ void nn_insert_lex(float d, int kk, float &b1, float &b2, float &b3, int &i1, int &i2,
+                                              int &i3)
+{
+    const bool c1 = nn_less(d, kk, b1, i1), c2 = nn_less(d, kk, b2, i2), c3 = nn_less(d, kk, b3, i3);
+    const float nb3 = c2 ? b2 : (c3 ? d : b3);
+    const int ni3 = c2 ? i2 : (c3 ? kk : i3);
+    const float nb2 = c1 ? b1 : (c2 ? d : b2);
+    const int ni2 = c1 ? i1 : (c2 ? kk : i2);
+    b1 = c1 ? d : b1;
+    i1 = c1 ? kk : i1;
+    b2 = nb2; i2 = ni2; b3 = nb3; i3 = ni3;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float quad_xchg_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int quad_xchg_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+
+// merge the partner lane's triple (quad_perm CTRL) into this lane's
+template <int CTRL>
+__device__ __forceinline__ void nn_merge(float &b1, float &b2, float &b3, int &i1, int &i2, int &i3)
+{
+    const float o1 = quad_xchg_f<CTRL>(b1), o2 = quad_xchg_f<CTRL>(b2), o3 = quad_xchg_f<CTRL>(b3);
+    const int j1 = quad_xchg_i<CTRL>(i1), j2 = quad_xchg_i<CTRL>(i2), j3 = quad_xchg_i<CTRL>(i3);
+    nn_insert_lex(o1, j1, b1, b2, b3, i1, i2, i3);
+    nn_insert_lex(o2, j2, b1, b2, b3, i1, i2, i3);
+    nn_insert_lex(o3, j3, b1, b2, b3, i1, i2, i3);
+}
+
 __global__ __launch_bounds__(kNnThreads) void three_nn_kernel(int n, int m, const float *__restrict__ xyz1,
                                                               const float *__restrict__ xyz2,
                                                               float *__restrict__ dist, int *__restrict__ idx)
 {
     __shared__ float4 tile[kNnTile];
     const int bi = blockIdx.y;
-    const int j = blockIdx.x * kNnThreads + threadIdx.x;
+    const int sub = threadIdx.x & 3;                       // lane of the quad
+    const int j = blockIdx.x * kNnPoints + (threadIdx.x >> 2);
     const bool live = j < n;
     const float *u = xyz1 + ((size_t)bi * n + (live ? j : 0)) * 3;
     const float ux = u[0], uy = u[1], uz = u[2];
@@ -55,9 +98,10 @@ __global__ __launch_bounds__(kNnThreads) void three_nn_kernel(int n, int m, cons
     int i1 = 0, i2 = 0, i3 = 0;
     for (int base = 0; base < m; base += kNnTile) {
         const int cnt = min(kNnTile, m - base);
-        const int cnt4 = (cnt + 3) & ~3;
+        const int cnt16 = (cnt + 15) & ~15;                // four quarters, each a multiple of 4
+        const int quarter = cnt16 >> 2;
         __syncthreads();
-        for (int k = threadIdx.x; k < cnt4; k += kNnThreads) {
+        for (int k = threadIdx.x; k < cnt16; k += kNnThreads) {
             if (k < cnt) {
                 const float *p = known + (size_t)(base + k) * 3;
                 tile[k] = make_float4(p[0], p[1], p[2], 0.0f);
@@ -66,9 +110,10 @@ __global__ __launch_bounds__(kNnThreads) void three_nn_kernel(int n, int m, cons
             }
         }
         __syncthreads();
-        // four known points per trip: four independent distance chains, one wave-uniform test
-        for (int k = 0; k < cnt4; k += 4) {
-            const float4 p0 = tile[k], p1 = tile[k + 1], p2 = tile[k + 2], p3 = tile[k + 3];   // LDS broadcasts
+        // this lane's quarter of the tile, ascending; four known points per trip
+        const int k0 = sub * quarter;
+        for (int k = k0; k < k0 + quarter; k += 4) {
+            const float4 p0 = tile[k], p1 = tile[k + 1], p2 = tile[k + 2], p3 = tile[k + 3];   // 4 addresses per wave
             // (x2-x1)..., x2 the known point (tf_interpolate.cpp:69-73)
             const float d0 = sqdist(p0.x, p0.y, p0.z, ux, uy, uz);
             const float d1 = sqdist(p1.x, p1.y, p1.z, ux, uy, uz);
@@ -77,14 +122,16 @@ __global__ __launch_bounds__(kNnThreads) void three_nn_kernel(int n, int m, cons
             const bool better = (d0 < b3) | (d1 < b3) | (d2 < b3) | (d3 < b3);
             if (__any(better)) {
                 const int kk = base + k;
-                nn_insert(d0, kk, b1, b2, b3, i1, i2, i3);       // ascending k: keeps the (d,k) order key
+                nn_insert(d0, kk, b1, b2, b3, i1, i2, i3);       // ascending k within the lane
                 nn_insert(d1, kk + 1, b1, b2, b3, i1, i2, i3);
                 nn_insert(d2, kk + 2, b1, b2, b3, i1, i2, i3);
                 nn_insert(d3, kk + 3, b1, b2, b3, i1, i2, i3);
             }
         }
     }
-    if (live) {
+    nn_merge<0xB1>(b1, b2, b3, i1, i2, i3);                // quad_perm:[1,0,3,2]
+    nn_merge<0x4E>(b1, b2, b3, i1, i2, i3);                // quad_perm:[2,3,0,1]
+    if (live && sub == 0) {
         float *od = dist + ((size_t)bi * n + j) * 3;
         int *oi = idx + ((size_t)bi * n + j) * 3;
         od[0] = b1; od[1] = b2; od[2] = b3;
@@ -185,7 +232,7 @@ extern "C" int pn2_three_nn(int b, int n, int m, const float *xyz1, const float 
     if (b == 0 || n == 0) return PN2_OK;
     if (!xyz1 || !dist || !idx || (m > 0 && !xyz2)) return PN2_E_NULL;
     if (b > 65535) return PN2_E_TOO_LARGE;
-    hipLaunchKernelGGL(three_nn_kernel, dim3((n + kNnThreads - 1) / kNnThreads, b), dim3(kNnThreads), 0,
+    hipLaunchKernelGGL(three_nn_kernel, dim3((n + kNnPoints - 1) / kNnPoints, b), dim3(kNnThreads), 0,
                        as_stream(stream), n, m, xyz1, xyz2, dist, idx);
     return launch_status();
 }
