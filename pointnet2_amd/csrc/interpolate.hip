@@ -12,10 +12,10 @@
 //   * the gradient accumulates with fp32 atomics (order not fixed).
 //
 // Design (DESIGN.md "three_nn"). FOUR lanes (a DPP quad) per unknown point: the known points are
-// staged through LDS in float4 tiles, lane q of the quad scans the q-th quarter of every tile in
-// ascending order with the reference's strict-< insertion (four candidates per trip, one wave-
-// uniform skip test), and at the end the quad merges its four triples with two quad_perm exchanges
-// under the explicit order key (d, k) -- the key the reference's single ascending scan implies.
+// staged through LDS in float4 tiles (index in .w), lane q of the quad takes every fourth candidate,
+// and at the end the quad merges its four triples with two quad_perm exchanges. The running top-3 is a
+// v_min_f64 / v_max_f64 network on (d : k) keys -- the order key the reference's single ascending
+// strict-< scan implies -- so visiting order is irrelevant and there are no compares or selects.
 // The first version used one lane per point: at the largest FP layer (8 x 8192 unknown points) that
 // is one wave per SIMD, a pure latency chain (115 us); the quad split quadruples the waves in flight.
 #include "pn2_device.h"
@@ -29,56 +29,42 @@ constexpr int kNnThreads = 256;             // 64 unknown points x 4 lanes
 constexpr int kNnPoints = kNnThreads / 4;
 constexpr int kNnTile = 2048;               // known points per LDS tile (32 KiB), a multiple of 16
 
-// strict-< insertion of candidate (d, kk) into the ascending triple (tf_interpolate.cpp:74-89), branch-free
-__device__ __forceinline__ void nn_insert(float d, int kk, float &b1, float &b2, float &b3, int &i1, int &i2, int &i3)
+// Top-3 as a min/max network on 64-bit keys (d bits : k). Read as fp64 the pattern is positive and
+// finite for every fp32 d >= 0 including +inf and NaN payloads (exponent field < 0x7FF), and ordered
+// exactly like the reference's scan order key (d, k): smaller d first, then smaller k. Inserting x
+// into the ascending triple is five v_min_f64/v_max_f64, no compares, no selects:
+//     t1 = min(b1,x); x = max(b1,x); t2 = min(b2,x); x = max(b2,x); t3 = min(b3,x)
+// The empty slot is (+inf : 0): a candidate with d = +inf has a key >= it and never enters, exactly as
+// `inf < 1e40` is false in the reference (tf_interpolate.cpp:74); NaN keys are larger still.
+__device__ __forceinline__ double nn_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double nn_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ void nn_insert(double x, double &b1, double &b2, double &b3)
 {
-    const bool c1 = d < b1, c2 = d < b2, c3 = d < b3;
-    const float nb3 = c2 ? b2 : (c3 ? d : b3);
-    const int ni3 = c2 ? i2 : (c3 ? kk : i3);
-    const float nb2 = c1 ? b1 : (c2 ? d : b2);
-    const int ni2 = c1 ? i1 : (c2 ? kk : i2);
-    b1 = c1 ? d : b1;
-    i1 = c1 ? kk : i1;
-    b2 = nb2; i2 = ni2; b3 = nb3; i3 = ni3;
-}
-
-// the same insertion under the explicit key (d, k): used only to merge the four lanes' triples.
-// Empty slots are (+inf, 0); a real candidate with d = +inf is never inserted by the reference
-// (inf < 1e40 is false), and (inf, k) < (inf, 0) is false here too.
-__device__ __forceinline__ bool nn_less(float d, int k, float b, int i) { return d < b || (d == b && k < i); }
-__device__ __forceinline__ void nn_insert_lex(float d, int kk, float &b1, float &b2, float &b3, int &i1, int &i2,
-                                              int &i3)
-{
-    const bool c1 = nn_less(d, kk, b1, i1), c2 = nn_less(d, kk, b2, i2), c3 = nn_less(d, kk, b3, i3);
-    const float nb3 = c2 ? b2 : (c3 ? d : b3);
-    const int ni3 = c2 ? i2 : (c3 ? kk : i3);
-    const float nb2 = c1 ? b1 : (c2 ? d : b2);
-    const int ni2 = c1 ? i1 : (c2 ? kk : i2);
-    b1 = c1 ? d : b1;
-    i1 = c1 ? kk : i1;
-    b2 = nb2; i2 = ni2; b3 = nb3; i3 = ni3;
+    const double t1 = nn_min(b1, x);
+    x = nn_max(b1, x);
+    const double t2 = nn_min(b2, x);
+    x = nn_max(b2, x);
+    b3 = nn_min(b3, x);
+    b1 = t1;
+    b2 = t2;
 }
 
 template <int CTRL>
-__device__ __forceinline__ float quad_xchg_f(float v)
+__device__ __forceinline__ double quad_xchg_d(double v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-template <int CTRL>
-__device__ __forceinline__ int quad_xchg_i(int v)
-{
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
 }
 
 // merge the partner lane's triple (quad_perm CTRL) into this lane's
 template <int CTRL>
-__device__ __forceinline__ void nn_merge(float &b1, float &b2, float &b3, int &i1, int &i2, int &i3)
+__device__ __forceinline__ void nn_merge(double &b1, double &b2, double &b3)
 {
-    const float o1 = quad_xchg_f<CTRL>(b1), o2 = quad_xchg_f<CTRL>(b2), o3 = quad_xchg_f<CTRL>(b3);
-    const int j1 = quad_xchg_i<CTRL>(i1), j2 = quad_xchg_i<CTRL>(i2), j3 = quad_xchg_i<CTRL>(i3);
-    nn_insert_lex(o1, j1, b1, b2, b3, i1, i2, i3);
-    nn_insert_lex(o2, j2, b1, b2, b3, i1, i2, i3);
-    nn_insert_lex(o3, j3, b1, b2, b3, i1, i2, i3);
+    const double o1 = quad_xchg_d<CTRL>(b1), o2 = quad_xchg_d<CTRL>(b2), o3 = quad_xchg_d<CTRL>(b3);
+    nn_insert(o1, b1, b2, b3);
+    nn_insert(o2, b1, b2, b3);
+    nn_insert(o3, b1, b2, b3);
 }
 
 __global__ __launch_bounds__(kNnThreads) void three_nn_kernel(int n, int m, const float *__restrict__ xyz1,
@@ -94,48 +80,46 @@ __global__ __launch_bounds__(kNnThreads) void three_nn_kernel(int n, int m, cons
     const float ux = u[0], uy = u[1], uz = u[2];
     const float *__restrict__ known = xyz2 + (size_t)bi * m * 3;
 
-    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;   // (float)1e40, tf_interpolate.cpp:67
-    int i1 = 0, i2 = 0, i3 = 0;
+    const double empty = __hiloint2double(0x7F800000, 0);  // (+inf : 0) = the reference's (float)1e40, index 0 (:67)
+    double b1 = empty, b2 = empty, b3 = empty;
     for (int base = 0; base < m; base += kNnTile) {
         const int cnt = min(kNnTile, m - base);
-        const int cnt16 = (cnt + 15) & ~15;                // four quarters, each a multiple of 4
-        const int quarter = cnt16 >> 2;
+        const int cnt16 = (cnt + 15) & ~15;                // whole trips of 16 candidates per quad
         __syncthreads();
         for (int k = threadIdx.x; k < cnt16; k += kNnThreads) {
             if (k < cnt) {
                 const float *p = known + (size_t)(base + k) * 3;
-                tile[k] = make_float4(p[0], p[1], p[2], 0.0f);
+                tile[k] = make_float4(p[0], p[1], p[2], __int_as_float(base + k));   // .w = the index, bit for bit
             } else {
-                tile[k] = make_float4(INFINITY, INFINITY, INFINITY, 0.0f);   // pad: distance +inf (or NaN), never inserted
+                tile[k] = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(0));   // pad: d = +inf, never enters
             }
         }
         __syncthreads();
-        // this lane's quarter of the tile, ascending; four known points per trip
-        const int k0 = sub * quarter;
-        for (int k = k0; k < k0 + quarter; k += 4) {
-            const float4 p0 = tile[k], p1 = tile[k + 1], p2 = tile[k + 2], p3 = tile[k + 3];   // 4 addresses per wave
+        // 16 candidates per quad and trip, lane q takes 4c+q (c = 0..3): the four lanes of a quad read
+        // four CONSECUTIVE float4 per instruction -- different LDS banks. (Giving each lane a contiguous
+        // quarter of the tile put the quad on one bank: a 4-way conflict on every read made the kernel
+        // LDS bound, 241 us instead of 64 at 32 x 8192 x 1024.) Order of visit is irrelevant: keyed network.
+        for (int k = sub; k < cnt16; k += 16) {
+            const float4 p0 = tile[k], p1 = tile[k + 4], p2 = tile[k + 8], p3 = tile[k + 12];
             // (x2-x1)..., x2 the known point (tf_interpolate.cpp:69-73)
             const float d0 = sqdist(p0.x, p0.y, p0.z, ux, uy, uz);
             const float d1 = sqdist(p1.x, p1.y, p1.z, ux, uy, uz);
             const float d2 = sqdist(p2.x, p2.y, p2.z, ux, uy, uz);
             const float d3 = sqdist(p3.x, p3.y, p3.z, ux, uy, uz);
-            const bool better = (d0 < b3) | (d1 < b3) | (d2 < b3) | (d3 < b3);
-            if (__any(better)) {
-                const int kk = base + k;
-                nn_insert(d0, kk, b1, b2, b3, i1, i2, i3);       // ascending k within the lane
-                nn_insert(d1, kk + 1, b1, b2, b3, i1, i2, i3);
-                nn_insert(d2, kk + 2, b1, b2, b3, i1, i2, i3);
-                nn_insert(d3, kk + 3, b1, b2, b3, i1, i2, i3);
-            }
+            nn_insert(__hiloint2double(__float_as_int(d0), __float_as_int(p0.w)), b1, b2, b3);
+            nn_insert(__hiloint2double(__float_as_int(d1), __float_as_int(p1.w)), b1, b2, b3);
+            nn_insert(__hiloint2double(__float_as_int(d2), __float_as_int(p2.w)), b1, b2, b3);
+            nn_insert(__hiloint2double(__float_as_int(d3), __float_as_int(p3.w)), b1, b2, b3);
         }
     }
-    nn_merge<0xB1>(b1, b2, b3, i1, i2, i3);                // quad_perm:[1,0,3,2]
-    nn_merge<0x4E>(b1, b2, b3, i1, i2, i3);                // quad_perm:[2,3,0,1]
+    nn_merge<0xB1>(b1, b2, b3);                            // quad_perm:[1,0,3,2]
+    nn_merge<0x4E>(b1, b2, b3);                            // quad_perm:[2,3,0,1]
     if (live && sub == 0) {
         float *od = dist + ((size_t)bi * n + j) * 3;
         int *oi = idx + ((size_t)bi * n + j) * 3;
-        od[0] = b1; od[1] = b2; od[2] = b3;
-        oi[0] = i1; oi[1] = i2; oi[2] = i3;
+        od[0] = __int_as_float(__double2hiint(b1)); od[1] = __int_as_float(__double2hiint(b2));
+        od[2] = __int_as_float(__double2hiint(b3));
+        oi[0] = __double2loint(b1); oi[1] = __double2loint(b2); oi[2] = __double2loint(b3);
     }
 }
 
