@@ -38,7 +38,14 @@ def ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device):
+    """The current HIP stream of `device` as an integer handle (the raw getter skips building a
+    torch.cuda.Stream object: ~0.3 us instead of ~2 us per operator call)."""
+    if _raw_stream is not None:
+        return _raw_stream(device.index if device.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(device).cuda_stream
 
 

@@ -171,6 +171,18 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
         __syncthreads();
         // block arg-max: v_max_f64 tournament over the W keys, every wave redundantly (wave-uniform data)
         const double *dslot = reinterpret_cast<const double *>(slot);
+        unsigned win;                                  // low word of the winning key = mirror index
+        if (W >= 16) {
+        // lane i reads key i mod W (ONE LDS read per wave instead of W/2 broadcast reads) and the W
+        // keys are combined across lanes with log2(W) butterfly DPP steps: every lane ends with the max
+        double kq = dslot[lane & (W - 1)];
+        if (W >= 2) kq = dpp_max_f64_step<0xB1, 0xf>(kq);    // lane ^ 1
+        if (W >= 4) kq = dpp_max_f64_step<0x4E, 0xf>(kq);    // lane ^ 2
+        if (W >= 8) kq = dpp_max_f64_step<0x141, 0xf>(kq);   // other quad of the half row
+        if (W >= 16) kq = dpp_max_f64_step<0x140, 0xf>(kq);  // other half row
+        win = (unsigned)__double2loint(kq);
+        } else {
+        // W <= 8: broadcast-read all keys, tournament on wave-uniform data (measured faster: 408 vs 441 ns)
         double key[W];
 #pragma unroll
         for (int i = 0; i < W; ++i) key[i] = dslot[i];
@@ -179,7 +191,8 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
 #pragma unroll
             for (int i = 0; i + st < W; i += 2 * st)
                 asm("v_max_f64 %0, %1, %2" : "=v"(key[i]) : "v"(key[i]), "v"(key[i + st]));
-        const unsigned win = (unsigned)__double2loint(key[0]);   // low word of the winning key = mirror index
+        win = (unsigned)__double2loint(key[0]);
+        }
         int k;
         if (LDSXYZ) {
             const float4 s = lds_rank[win];            // same address in every lane: LDS broadcast
