@@ -17,7 +17,9 @@ def sphere_clouds(b, n, seed=0):
     v /= np.linalg.norm(v, axis=2, keepdims=True) + 1e-12
     v *= rng.uniform(0.9, 1.0, size=(b, n, 1))
     v -= v.mean(axis=1, keepdims=True)
-    v /= np.max(np.linalg.norm(v, axis=2), axis=1)[:, None, None]
+    scale = np.max(np.linalg.norm(v, axis=2), axis=1)
+    scale[scale == 0] = 1.0                     # a one-point cloud normalises to the origin
+    v /= scale[:, None, None]
     return v.astype(np.float32)
 
 

@@ -190,3 +190,59 @@ def test_prob_sample_is_inverse_cdf(oracle):
     for b in range(2):
         want = np.searchsorted(cdf[b], r[b].astype(np.float64) * cdf[b, -1], side="left")
         assert np.abs(out[b] - np.minimum(want, 8999)).max() <= 1     # fp32 vs fp64 cdf: off by at most one bin
+
+
+# ------------------------------------------------------------------ hypothesis properties
+def _np_three_nn(xyz1, xyz2):
+    """numpy re-derivation: fp32 squared distances, top-3 by (d, k)."""
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    dist = np.full((b, n, 3), np.inf, np.float32)
+    idx = np.zeros((b, n, 3), np.int32)
+    for i in range(b):
+        d = ((xyz2[i, None, :, 0] - xyz1[i, :, None, 0]) ** 2 + (xyz2[i, None, :, 1] - xyz1[i, :, None, 1]) ** 2) + \
+            (xyz2[i, None, :, 2] - xyz1[i, :, None, 2]) ** 2                      # (n, m) fp32
+        order = np.lexsort((np.broadcast_to(np.arange(m), d.shape), d), axis=1)  # by d, then k
+        for t in range(min(3, m)):
+            idx[i, :, t] = order[:, t]
+            dist[i, :, t] = np.take_along_axis(d, order[:, t:t + 1], axis=1)[:, 0]
+    return dist, idx
+
+
+def test_three_nn_matches_numpy_lexsort(oracle):
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(1, 3), st.integers(1, 40), st.integers(1, 30), st.integers(0, 10 ** 6), st.booleans())
+    def run(b, n, m, seed, lattice):
+        gen = S.lattice_clouds if lattice else S.uniform_clouds       # lattice: many exact distance ties
+        xyz1, xyz2 = gen(b, n, seed), gen(b, m, seed + 1)
+        d, i = oracle.three_nn(xyz1, xyz2)
+        wd, wi = _np_three_nn(xyz1, xyz2)
+        assert np.array_equal(i, wi) and np.array_equal(d, wd)
+
+    run()
+
+
+def test_fps_matches_numpy_on_random_small_clouds(oracle):
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=30, deadline=None)
+    @given(st.integers(1, 700), st.integers(1, 60), st.integers(0, 10 ** 6), st.sampled_from(["lattice", "dup", "uni"]))
+    def run(n, m, seed, kind):
+        gen = {"lattice": S.lattice_clouds, "dup": S.duplicated_clouds, "uni": S.uniform_clouds}[kind]
+        p = gen(1, n, seed)[0]
+        want = oracle.farthest_point_sample(m, p[None])[0]
+        mind = np.full(n, np.float32(1e38), np.float32)
+        k = np.arange(n)
+        key = (k % 512) * 100000 + k
+        got = [0]
+        for _ in range(1, m):
+            q = p[got[-1]]
+            d = ((p[:, 0] - q[0]) ** 2 + (p[:, 1] - q[1]) ** 2).astype(np.float32) + ((p[:, 2] - q[2]) ** 2).astype(np.float32)
+            mind = np.minimum(mind, d.astype(np.float32))
+            cand = np.where(mind == mind.max())[0]
+            got.append(int(cand[np.argmin(key[cand])]))
+        assert got == want.tolist()
+
+    run()
