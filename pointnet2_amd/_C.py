@@ -45,12 +45,14 @@ _SIGNATURES = {
     "pn2_ball_threshold": [_f],
     "pn2_version": [],
     "pn2_debug_fps_config": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "pn2_debug_bq_config": [_i, _i],
 }
 _RESTYPES = {
     "pn2_fps_temp_floats": ctypes.c_longlong,
     "pn2_sample_and_group_ws_bytes": ctypes.c_longlong,
     "pn2_ball_threshold": ctypes.c_float,
     "pn2_version": ctypes.c_char_p,
+    "pn2_debug_bq_config": None,
 }
 
 # every symbol include/pn2ops.h declares (pn2_debug_* are tuning hooks, not part of the ABI)

@@ -122,7 +122,7 @@ __device__ __forceinline__ int bq_poll_sample(const unsigned long long *tagged)
 // One workgroup's share of the ball queries of cloud `bi`: queries [q0, q1).
 // POLL: the query points are not read from xyz2; they are the FPS samples of the same launch, taken
 // from the tagged index stream as soon as they exist (and written to new_xyz on the way).
-template <bool LDS_CLOUD, bool FUSE, bool POLL>
+template <bool LDS_CLOUD, bool FUSE, bool POLL, int NT = kBqThreads>
 __device__ __forceinline__ void bq_block_body(int n, int m, int nsample, float thr, int bi, int q0, int q1,
                                               const float *__restrict__ xyz1, const float *__restrict__ xyz2,
                                               const unsigned long long *__restrict__ tagged,
@@ -144,7 +144,7 @@ __device__ __forceinline__ void bq_block_body(int n, int m, int nsample, float t
     // distance is +inf (or NaN), never < thr, so the sweep needs no bounds predicate.
     const int npad = (n + 127) & ~127;
     if (LDS_CLOUD) {
-        for (int k = t; k < npad; k += kBqThreads) {
+        for (int k = t; k < npad; k += NT) {
             if (k < n) {
                 const float *p = data + (size_t)k * 3;
                 cloud[k] = make_float4(p[0], p[1], p[2], 0.0f);
@@ -155,7 +155,7 @@ __device__ __forceinline__ void bq_block_body(int n, int m, int nsample, float t
         __syncthreads();
     }
 
-    for (int j = q0 + w * kBqQpw; j < q1; j += kBqWaves * kBqQpw) {
+    for (int j = q0 + w * kBqQpw; j < q1; j += (NT / PN2_WAVE) * kBqQpw) {
         const bool two = (j + 1) < q1;                       // wave-uniform
         const size_t row0 = (size_t)bi * m + j;
         const size_t row1 = row0 + (two ? 1 : 0);
@@ -229,5 +229,448 @@ __device__ __forceinline__ void bq_block_body(int n, int m, int nsample, float t
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Cell-list variant. The brute-force sweep above evaluates every (query, candidate) pair until the
+// row is full; at the metric shape that is ~2400 of 4096 candidates per query for ~40 hits. Here each
+// workgroup first bins its cloud into a uniform grid (counting sort in LDS, cells of edge >= the
+// search radius), and a query only visits the <= 3x3 runs of x-adjacent cells around it. The result
+// is still index-exact: the hit predicate is the same fp32 expression on the same operands, every
+// in-ball point lies in a visited cell (see bq_cell / the reach margin), and the ORDER comes from the
+// hit bitmap (indexed by original point number), not from the visiting order.
+constexpr int kBqGridMax = 12;                                      // cells per axis
+constexpr int kBqCellsMax = kBqGridMax * kBqGridMax * kBqGridMax;   // 1728 -> 6.75 KiB of cell ends
+constexpr int kBqMinCells = 64;        // coarser grids prune nothing: the sweep with its early exit wins
+constexpr int kBqMiscBytes = 1024;     // reduction scratch of the binning pass
+
+struct BqGrid {
+    float ox, oy, oz, ix, iy, iz;
+    int gx, gy, gz;
+};
+
+// Monotone non-decreasing in v (every fp32 operation below is), which is all the pruning needs:
+// cell(a) <= cell(p) <= cell(b) whenever a <= p <= b. NaN lands in cell 0; it can never be a hit.
+__device__ __forceinline__ int bq_cell(float v, float o, float inv, int g)
+{
+    const float f = __fmul_rn(__fsub_rn(v, o), inv);
+    return (f >= 0.0f) ? (int)fminf(f, (float)(g - 1)) : 0;
+}
+
+// Wave-wide min / max that leave the result in lane 63: DPP row shifts + the two row broadcasts
+// (6 VALU ops per value; the ds_bpermute butterfly this replaces cost an LDS round trip per step).
+// A lane without a DPP source keeps its own value (old = v, bound_ctrl off).
+template <bool MAX>
+__device__ __forceinline__ float wave_minmax_lane63(float v)
+{
+#define PN2_BQ_STEP(ctrl, rmask)                                                                              \
+    {                                                                                                         \
+        const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, \
+                                                                   rmask, 0xf, false));                       \
+        v = MAX ? fmaxf(v, o) : fminf(v, o);                                                                  \
+    }
+    PN2_BQ_STEP(0x111, 0xf)   // row_shr:1
+    PN2_BQ_STEP(0x112, 0xf)   // row_shr:2
+    PN2_BQ_STEP(0x114, 0xf)   // row_shr:4
+    PN2_BQ_STEP(0x118, 0xf)   // row_shr:8   -> lane 15 of each row holds the row result
+    PN2_BQ_STEP(0x142, 0xa)   // row_bcast:15 -> rows 1, 3
+    PN2_BQ_STEP(0x143, 0xc)   // row_bcast:31 -> rows 2, 3: lane 63 holds the wave result
+#undef PN2_BQ_STEP
+    return v;
+}
+
+__device__ __forceinline__ int wave_max_i32_lane63(int v)
+{
+#define PN2_BQ_STEP(ctrl, rmask) v = max(v, __builtin_amdgcn_update_dpp(v, v, ctrl, rmask, 0xf, false));
+    PN2_BQ_STEP(0x111, 0xf) PN2_BQ_STEP(0x112, 0xf) PN2_BQ_STEP(0x114, 0xf) PN2_BQ_STEP(0x118, 0xf)
+    PN2_BQ_STEP(0x142, 0xa) PN2_BQ_STEP(0x143, 0xc)
+#undef PN2_BQ_STEP
+    return v;
+}
+
+// LDS layout of the cell-list kernel:
+//   sorted points float4[n] | cell table int[kBqCellsMax + 4] | per wave {G bitmaps, G rows} | scratch
+// G = 64 / LPQ queries are in flight per wave, LPQ lanes each.
+constexpr int kBqTabInts = kBqCellsMax + 4;                         // tab[0] = 0, tab[c + 1] = end of cell c
+__host__ __device__ __forceinline__ size_t bq_cells_wave_bytes(int n, int nsample, int lpq)
+{
+    const size_t nwin = ((size_t)n + 4095) / 4096;
+    return (size_t)(64 / lpq) * (nwin * 512 + sizeof(int) * (size_t)nsample);
+}
+__host__ __device__ __forceinline__ size_t bq_cells_lds_bytes(int n, int nsample, int lpq, int nthreads)
+{
+    return sizeof(float4) * (size_t)n + sizeof(int) * (size_t)kBqTabInts +
+           (size_t)(nthreads / 64) * bq_cells_wave_bytes(n, nsample, lpq) + kBqMiscBytes;
+}
+
+constexpr int kBqCellsMaxPoints = 8192;                            // 16 points per thread in registers
+
+// Count one point per lane into its cell. Points of one wave instruction that share a cell are common
+// (duplicated points, the reference's dropout-to-first-point augmentation: up to 87 % of a cloud in ONE
+// cell) and same-address LDS atomics serialise, so the cell of the first lane is peeled with a single
+// aggregated atomic; the rest go one per lane. Nothing is returned: the atomics are fire-and-forget.
+__device__ __forceinline__ void bq_cell_count(int *cellend, int c, bool valid, int lane)
+{
+    const unsigned long long act = __ballot(valid);
+    if (act == 0ull) return;
+    const int leader = __builtin_ctzll(act);
+    const int c0 = __builtin_amdgcn_readlane(c, leader);
+    const bool mine = valid && c == c0;
+    const unsigned long long mask = __ballot(mine);
+    if (lane == leader) atomicAdd(&cellend[c0], __popcll(mask));
+    if (valid && !mine) atomicAdd(&cellend[c], 1);
+}
+
+// Bin the cloud (n <= kBqCellsMaxPoints). Returns false (block-uniform) when the grid would be too
+// coarse to prune or one cell holds a large share of the cloud (a sweep with its early exit is the
+// better tool for both); `sorted` has not been written in that case.
+template <int NT>
+__device__ __forceinline__ bool bq_build_grid(int n, float reach, const float *__restrict__ data, float4 *sorted,
+                                              int *cellend, float *misc, BqGrid &g)
+{
+    constexpr int kBqPtsPerThread = kBqCellsMaxPoints / NT, kBqWavesT = NT / 64;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const float inf = INFINITY;
+    // the thread's points live in registers for all three passes: one trip to memory
+    float px[kBqPtsPerThread], py[kBqPtsPerThread], pz[kBqPtsPerThread];
+#pragma unroll
+    for (int i = 0; i < kBqPtsPerThread; ++i) {
+        px[i] = py[i] = pz[i] = 0.0f;
+        if (i * NT < n) {                                        // block-uniform: slots past n cost nothing
+            const int k = t + i * NT;
+            const float *p = data + (size_t)(k < n ? k : 0) * 3;
+            px[i] = p[0]; py[i] = p[1]; pz[i] = p[2];
+        }
+    }
+    float lx = inf, ly = inf, lz = inf, hx = -inf, hy = -inf, hz = -inf;
+#pragma unroll
+    for (int i = 0; i < kBqPtsPerThread; ++i) {
+        if (t + i * NT < n) {
+            const float x = px[i], y = py[i], z = pz[i];
+            if (fabsf(x) < inf) { lx = fminf(lx, x); hx = fmaxf(hx, x); }     // non-finite coordinates never hit
+            if (fabsf(y) < inf) { ly = fminf(ly, y); hy = fmaxf(hy, y); }
+            if (fabsf(z) < inf) { lz = fminf(lz, z); hz = fmaxf(hz, z); }
+        }
+    }
+    lx = wave_minmax_lane63<false>(lx); ly = wave_minmax_lane63<false>(ly); lz = wave_minmax_lane63<false>(lz);
+    hx = wave_minmax_lane63<true>(hx); hy = wave_minmax_lane63<true>(hy); hz = wave_minmax_lane63<true>(hz);
+    // scratch layout: float[6][16] wave partials (read back as float4: 96 scalar LDS reads per thread
+    // were a visible part of the binning time), then int[16] wave sums and int[16] wave maxima
+    if (lane == 63) {
+        misc[0 * 16 + w] = lx; misc[1 * 16 + w] = ly; misc[2 * 16 + w] = lz;
+        misc[3 * 16 + w] = hx; misc[4 * 16 + w] = hy; misc[5 * 16 + w] = hz;
+    }
+    __syncthreads();
+    lx = ly = lz = inf;
+    hx = hy = hz = -inf;
+    {
+        const float4 *m4 = reinterpret_cast<const float4 *>(misc);
+#pragma unroll
+        for (int v = 0; v < kBqWavesT / 4; ++v) {
+            const float4 a = m4[0 * 4 + v], b = m4[1 * 4 + v], c = m4[2 * 4 + v];
+            const float4 d = m4[3 * 4 + v], e = m4[4 * 4 + v], f = m4[5 * 4 + v];
+            lx = fminf(fminf(lx, fminf(a.x, a.y)), fminf(a.z, a.w));
+            ly = fminf(fminf(ly, fminf(b.x, b.y)), fminf(b.z, b.w));
+            lz = fminf(fminf(lz, fminf(c.x, c.y)), fminf(c.z, c.w));
+            hx = fmaxf(fmaxf(hx, fmaxf(d.x, d.y)), fmaxf(d.z, d.w));
+            hy = fmaxf(fmaxf(hy, fmaxf(e.x, e.y)), fmaxf(e.z, e.w));
+            hz = fmaxf(fmaxf(hz, fmaxf(f.x, f.y)), fmaxf(f.z, f.w));
+        }
+    }
+    if (!(lx <= hx)) lx = hx = 0.0f;
+    if (!(ly <= hy)) ly = hy = 0.0f;
+    if (!(lz <= hz)) lz = hz = 0.0f;
+    // cell edge: at least the reach (so a ball spans <= 3 cells per axis), at least extent/kBqGridMax
+    const float edge_min = reach * 1.0001f;
+    const float ex = hx - lx, ey = hy - ly, ez = hz - lz;
+    const float cx = fmaxf(edge_min, ex * (1.0f / kBqGridMax));
+    const float cy = fmaxf(edge_min, ey * (1.0f / kBqGridMax));
+    const float cz = fmaxf(edge_min, ez * (1.0f / kBqGridMax));
+    auto dim = [](float ext, float edge) {
+        const float q = ext / edge;                              // NaN (inf/inf, 0/0) -> 1 cell
+        return (q >= 0.0f) ? min(kBqGridMax, (int)fminf(q, (float)kBqGridMax) + 1) : 1;
+    };
+    g.ox = lx; g.oy = ly; g.oz = lz;
+    g.ix = 1.0f / cx; g.iy = 1.0f / cy; g.iz = 1.0f / cz;
+    g.gx = dim(ex, cx); g.gy = dim(ey, cy); g.gz = dim(ez, cz);
+    const int ncells = g.gx * g.gy * g.gz;
+    if (ncells < kBqMinCells) return false;
+
+    for (int c = t; c < ncells; c += NT) cellend[c] = 0;
+    __syncthreads();
+    int cell[kBqPtsPerThread];
+#pragma unroll
+    for (int i = 0; i < kBqPtsPerThread; ++i) {
+        cell[i] = 0;
+        if (i * NT < n) {                                        // block-uniform
+            cell[i] = (bq_cell(pz[i], g.oz, g.iz, g.gz) * g.gy + bq_cell(py[i], g.oy, g.iy, g.gy)) * g.gx +
+                      bq_cell(px[i], g.ox, g.ix, g.gx);
+            bq_cell_count(cellend, cell[i], t + i * NT < n, lane);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the counts: a contiguous slab of cells per thread, wave scan, wave offsets
+    int *wsum = reinterpret_cast<int *>(misc + 6 * 16);
+    int *wmax = wsum + 16;
+    const int per = (ncells + NT - 1) / NT;
+    const int c0 = min(ncells, t * per), c1 = min(ncells, c0 + per);
+    int sum = 0, big = 0;
+    for (int c = c0; c < c1; ++c) {
+        const int v = cellend[c];
+        sum += v;
+        big = max(big, v);
+    }
+    const int incl = wave_prefix_sum_incl(sum);
+    big = wave_max_i32_lane63(big);
+    if (lane == 63) { wsum[w] = incl; wmax[w] = big; }
+    __syncthreads();
+    int run = incl - sum;
+    {
+        const int4 *s4 = reinterpret_cast<const int4 *>(wsum), *x4 = reinterpret_cast<const int4 *>(wmax);
+#pragma unroll
+        for (int v = 0; v < kBqWavesT / 4; ++v) {
+            const int4 a = s4[v], b = x4[v];
+            run += (4 * v + 0 < w ? a.x : 0) + (4 * v + 1 < w ? a.y : 0) + (4 * v + 2 < w ? a.z : 0) + (4 * v + 3 < w ? a.w : 0);
+            big = max(max(big, max(b.x, b.y)), max(b.z, b.w));
+        }
+    }
+    // a crowded cell means crowded balls (the sweep's early exit is at its best) and a contended scatter
+    if (big > max(128, n / 16)) return false;                    // block-uniform
+    for (int c = c0; c < c1; ++c) {
+        const int cnt = cellend[c];
+        cellend[c] = run;                                        // start of the cell: the scatter cursor
+        run += cnt;
+    }
+    __syncthreads();
+    int pos[kBqPtsPerThread];
+#pragma unroll
+    for (int i = 0; i < kBqPtsPerThread; ++i)
+        if (t + i * NT < n) pos[i] = atomicAdd(&cellend[cell[i]], 1);
+#pragma unroll
+    for (int i = 0; i < kBqPtsPerThread; ++i) {
+        const int k = t + i * NT;
+        if (k < n) sorted[pos[i]] = make_float4(px[i], py[i], pz[i], __int_as_float(k));
+    }
+    __syncthreads();                                             // cellend[c] is now the END of cell c
+    return true;
+}
+
+// Inclusive prefix sum inside aligned groups of LPQ lanes (DPP row shifts; rows are 16 lanes).
+template <int LPQ>
+__device__ __forceinline__ int group_prefix_sum_incl(int v, int sub)
+{
+    int t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); v += (LPQ >= 16 || sub >= 1) ? t : 0;   // row_shr:1
+    t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true); v += (LPQ >= 16 || sub >= 2) ? t : 0;   // row_shr:2
+    t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true); v += (LPQ >= 16 || sub >= 4) ? t : 0;   // row_shr:4
+    if (LPQ >= 16) { t = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true); v += t; }              // row_shr:8
+    if (LPQ >= 32) { t = __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); v += t; }             // row_bcast:15
+    if (LPQ >= 64) { t = __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); v += t; }             // row_bcast:31
+    return v;
+}
+
+// The queries of one workgroup against its binned cloud. A wave works on G = 64 / LPQ queries at a
+// time, LPQ lanes each: the per-query arithmetic (cell ranges, run bounds, prefix sums) is then done
+// by all lanes at once for G queries instead of being wave-uniform work, which is what bounds the
+// one-query-per-wave form (~500 issue slots per query, most of them scalar-like bookkeeping).
+// A query's candidates are the <= 3x3 runs of x-adjacent cells around it; its LPQ lanes walk them run
+// by run. Hits go into the query's bitmap (bit k = point k) with LDS atomic ORs; the bitmap is then
+// turned into the ascending index list by a group prefix sum of popcounts and a bit-peeling loop.
+template <int NT, int LPQ, bool FUSE, bool POLL>
+__device__ __forceinline__ void bq_cells_query_loop(int n, int m, int nsample, float thr, float radius, float reach,
+                                                    int bi, int q0, int q1, const BqGrid &g,
+                                                    const float *__restrict__ data,
+                                                    const float *__restrict__ xyz2,
+                                                    const unsigned long long *__restrict__ tagged,
+                                                    float *__restrict__ new_xyz, int *__restrict__ idx,
+                                                    int *__restrict__ pts_cnt, float *__restrict__ grouped,
+                                                    int subtract, const float4 *sorted, const int *tab,
+                                                    char *wave_area)
+{
+    constexpr int G = 64 / LPQ;
+    constexpr int CW = 64 / LPQ;                                 // 64-bit bitmap words per lane and window
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int grp = lane / LPQ, sub = lane % LPQ;
+    const int nwin = (n + 4095) / 4096;
+    const int gwords = nwin * 128;                               // 32-bit words of one query's bitmap
+    unsigned *bm = reinterpret_cast<unsigned *>(wave_area + (size_t)w * bq_cells_wave_bytes(n, nsample, LPQ));
+    unsigned *bmq = bm + grp * gwords;
+    int *rowbuf = reinterpret_cast<int *>(bm + G * gwords) + grp * nsample;
+    for (int i = lane; i < G * gwords; i += 64) bm[i] = 0u;
+    // |q| beyond this and q -/+ reach may round past an in-ball point: such queries visit everything
+    const float lim = radius * 4096.0f;
+
+    float nqx = 0.f, nqy = 0.f, nqz = 0.f;                       // next query, loaded one trip ahead
+    if (!POLL) {
+        const int j = min(q0 + w * G + grp, q1 - 1);
+        const float *q = xyz2 + ((size_t)bi * m + j) * 3;
+        nqx = q[0]; nqy = q[1]; nqz = q[2];
+    }
+    for (int jb = q0 + w * G; jb < q1; jb += (NT / 64) * G) {
+        const int j = jb + grp;
+        const bool qvalid = j < q1;
+        const size_t row = (size_t)bi * m + (qvalid ? j : q1 - 1);
+        float qx, qy, qz;
+        if (POLL) {
+            const int ka = bq_poll_sample(tagged + row);
+            qx = data[(size_t)ka * 3 + 0]; qy = data[(size_t)ka * 3 + 1]; qz = data[(size_t)ka * 3 + 2];
+            if (sub == 0 && qvalid) {
+                float *o = new_xyz + row * 3;
+                o[0] = qx; o[1] = qy; o[2] = qz;
+            }
+        } else {
+            qx = nqx; qy = nqy; qz = nqz;
+            if (jb + (NT / 64) * G < q1) {
+                const int jn = min(j + (NT / 64) * G, q1 - 1);
+                const float *q = xyz2 + ((size_t)bi * m + jn) * 3;
+                nqx = q[0]; nqy = q[1]; nqz = q[2];
+            }
+        }
+        const int cx0 = bq_cell(__fsub_rn(qx, reach), g.ox, g.ix, g.gx), cx1 = bq_cell(__fadd_rn(qx, reach), g.ox, g.ix, g.gx);
+        const int cy0 = bq_cell(__fsub_rn(qy, reach), g.oy, g.iy, g.gy), cy1 = bq_cell(__fadd_rn(qy, reach), g.oy, g.iy, g.gy);
+        const int cz0 = bq_cell(__fsub_rn(qz, reach), g.oz, g.iz, g.gz), cz1 = bq_cell(__fadd_rn(qz, reach), g.oz, g.iz, g.gz);
+        const bool near_origin = fabsf(qx) <= lim && fabsf(qy) <= lim && fabsf(qz) <= lim;   // false for NaN
+        // cannot happen for a near query (cell edge > reach): kept so that a wrong range can never drop a hit
+        const bool everything = !near_origin || cy1 - cy0 > 2 || cz1 - cz0 > 2 || cy1 < cy0 || cz1 < cz0 || cx1 < cx0;
+        const int dx1 = cx1 - cx0 + 1;
+        int rb[9], re[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const int ry = r % 3, rz = r / 3;
+            const bool rvalid = qvalid && !everything && cy0 + ry <= cy1 && cz0 + rz <= cz1;
+            const int cfirst = rvalid ? ((cz0 + rz) * g.gy + (cy0 + ry)) * g.gx + cx0 : 0;
+            const int b0 = tab[cfirst], e0 = tab[cfirst + dx1];
+            rb[r] = rvalid ? b0 : 0;
+            re[r] = rvalid ? e0 : 0;
+        }
+        if (everything && qvalid) { rb[0] = 0; re[0] = n; }
+        // The nine runs are walked as ONE candidate stream per query (flat position f -> run by a compare
+        // chain against the running lengths; all lanes of a group hold the same bounds). Walking run by
+        // run in lockstep left three quarters of the lane slots empty (runs are ~10 points, a group has 8
+        // lanes, and the trip count is the maximum over the wave's 8 queries). Four reads in flight per lane.
+        int cum[10], adj[9];
+        cum[0] = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            cum[r + 1] = cum[r] + (re[r] - rb[r]);
+            adj[r] = rb[r] - cum[r];
+        }
+        const int ncand = cum[9];
+        for (int f0 = sub; __any(f0 < ncand); f0 += 4 * LPQ) {
+            float4 p[4];
+            bool act[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = f0 + u * LPQ;
+                act[u] = f < ncand;
+                int sel = adj[0];
+#pragma unroll
+                for (int r = 1; r < 9; ++r) sel = (f >= cum[r]) ? adj[r] : sel;
+                p[u] = sorted[act[u] ? f + sel : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                // reference operand order: (x2-x1) with x2 the query (query_ball_point.cpp:26-32)
+                const float s = sqdist(qx, qy, qz, p[u].x, p[u].y, p[u].z);
+                const int k = __float_as_int(p[u].w);
+                if (act[u] && s < thr) atomicOr(&bmq[k >> 5], 1u << (k & 31));
+            }
+        }
+        asm volatile("" ::: "memory");                           // LDS ops of one wave execute in order
+        int done = 0;                                            // hits of this query so far (group-uniform)
+        for (int win = 0; win < nwin; ++win) {
+            unsigned long long *wp = reinterpret_cast<unsigned long long *>(bmq + win * 128) + sub * CW;
+            unsigned long long wd[CW];
+            int ps[CW + 1];
+            ps[0] = 0;
+#pragma unroll
+            for (int i = 0; i < CW; ++i) {
+                wd[i] = wp[i];
+                wp[i] = 0ull;
+                ps[i + 1] = ps[i] + __popcll(wd[i]);
+            }
+            const int pc = ps[CW];
+            const int incl = group_prefix_sum_incl<LPQ>(pc, sub);
+            const int total = __shfl(incl, lane | (LPQ - 1));
+            const int start = done + incl - pc;
+            // every word knows its first output slot, so the words peel independently: three bits each in
+            // straight-line code (covers almost every word at the usual hit densities), then a loop for
+            // whatever is left
+#pragma unroll
+            for (int i = 0; i < CW; ++i) {
+                const int kbase = win * 4096 + (sub * CW + i) * 64;
+                int pos = start + ps[i];
+                unsigned long long word = wd[i];
+#pragma unroll
+                for (int step = 0; step < 3; ++step) {
+                    if (word != 0ull && pos < nsample) rowbuf[pos] = kbase + __builtin_ctzll(word);
+                    word &= word - 1ull;
+                    ++pos;
+                }
+                wd[i] = word;
+                ps[i] = pos;
+            }
+#pragma unroll
+            for (int i = 0; i < CW; ++i) {
+                const int kbase = win * 4096 + (sub * CW + i) * 64;
+                while (__any(wd[i] != 0ull && ps[i] < nsample)) {
+                    if (wd[i] != 0ull) {
+                        if (ps[i] < nsample) rowbuf[ps[i]] = kbase + __builtin_ctzll(wd[i]);
+                        wd[i] &= wd[i] - 1ull;
+                        ++ps[i];
+                    }
+                }
+            }
+            done += total;
+        }
+        const int cnt = min(done, nsample);
+        asm volatile("" ::: "memory");
+        if (qvalid) {
+            const int first = cnt > 0 ? rowbuf[0] : 0;           // the first hit pads the row; zeros when empty
+            for (int l = sub; l < nsample; l += LPQ) {
+                const int v = (l < cnt) ? rowbuf[l] : first;
+                if (idx) idx[row * nsample + l] = v;
+                if (FUSE) {
+                    float gx = data[(size_t)v * 3 + 0], gy = data[(size_t)v * 3 + 1], gz = data[(size_t)v * 3 + 2];
+                    if (subtract) { gx = __fsub_rn(gx, qx); gy = __fsub_rn(gy, qy); gz = __fsub_rn(gz, qz); }
+                    float *o = grouped + (row * nsample + l) * 3;
+                    o[0] = gx; o[1] = gy; o[2] = gz;
+                }
+            }
+            if (sub == 0 && pts_cnt) pts_cnt[row] = cnt;
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
+// Cell-list workgroup body with the brute-force sweep as the block-uniform fallback (coarse grid or
+// crowded cells). `radius` is the caller's radius; reach = radius * 1.001f exceeds the largest
+// |coordinate difference| of any hit (<= radius * (1 + 4 ulp)) by 0.1 %.
+template <int NT, int LPQ, bool FUSE, bool POLL>
+__device__ __forceinline__ void bq_cells_block_body(int n, int m, int nsample, float thr, float radius, int bi, int q0,
+                                                    int q1, const float *__restrict__ xyz1,
+                                                    const float *__restrict__ xyz2,
+                                                    const unsigned long long *__restrict__ tagged,
+                                                    float *__restrict__ new_xyz, int *__restrict__ idx,
+                                                    int *__restrict__ pts_cnt, float *__restrict__ grouped,
+                                                    int subtract, char *smem)
+{
+    float4 *sorted = reinterpret_cast<float4 *>(smem);
+    int *tab = reinterpret_cast<int *>(smem + sizeof(float4) * (size_t)n);
+    char *wave_area = reinterpret_cast<char *>(tab + kBqTabInts);
+    float *misc = reinterpret_cast<float *>(wave_area + (size_t)(NT / 64) * bq_cells_wave_bytes(n, nsample, LPQ));
+    const float *__restrict__ data = xyz1 + (size_t)bi * n * 3;
+    const float reach = radius * 1.001f;
+    BqGrid g;
+    if (threadIdx.x == 0) tab[0] = 0;
+    if (bq_build_grid<NT>(n, reach, data, sorted, tab + 1, misc, g)) {
+        bq_cells_query_loop<NT, LPQ, FUSE, POLL>(n, m, nsample, thr, radius, reach, bi, q0, q1, g, data, xyz2, tagged,
+                                             new_xyz, idx, pts_cnt, grouped, subtract, sorted, tab, wave_area);
+    } else {
+        __syncthreads();                                         // scratch was read by everyone before it is reused
+        bq_block_body<true, FUSE, POLL, NT>(n, m, nsample, thr, bi, q0, q1, xyz1, xyz2, tagged, new_xyz, idx, pts_cnt,
+                                        grouped, subtract, smem);
+    }
+}
 
 }  // namespace pn2
