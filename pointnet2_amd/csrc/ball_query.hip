@@ -24,6 +24,12 @@
 // FUSE the same epilogue also emits xyz1[idx]-centroid straight from the LDS
 // copy of the cloud (pointnet_util.py:44-46 needs three ops and two extra
 // passes over idx for this).
+//
+// Two kernels share the exact predicate and the output stage. The SWEEP kernel above is O(m*n) with
+// an early exit; the CELL-LIST kernel (ball_query_cells_kernel, device code in the second half of
+// ball_query_body.h) bins the cloud per workgroup and visits ~27 cells per query: 57 -> 24 us at the
+// metric shape. bq_use_cells() picks by shape; the cell-list kernel falls back to the sweep body by
+// itself when the data make the grid useless (coarse grid, crowded cells).
 #include "ball_query_body.h"
 
 #include <limits.h>

@@ -195,8 +195,9 @@ static int fps_entry(int b, int n, int m, const float *inp, float *temp, int *ou
     }
     const int Q = (n + kRefThreads - 1) / kRefThreads;
     const int ranks = kRefThreads * Q;
-    // default geometry (measured, scripts/fps_lab.hip): 256 threads up to 1024 ranks, else 512
-    const int T = ranks <= 1024 ? 256 : 512;
+    // default geometry (measured, scripts/fps_prod_lab.hip, ns per round at n = 1024/2048/4096/8192):
+    // 256 threads with the packed distance update 276/321/405/590, 512 threads (scalar) 302/335/408/555
+    const int T = ranks <= 4096 ? 256 : 512;
     const int P = next_pow2((ranks + T - 1) / T);
     return fps_launch_config(T, P, b, n, m, inp, out, out_xyz, st);
 }

@@ -90,6 +90,46 @@ __device__ __forceinline__ void fps_gather_epilogue(int m, const float *__restri
 // Padding slots carry value +0.0: they can only tie with real zero-distance
 // points, and rank 0 (k = 0, always real) then wins, as in the reference.
 // ---------------------------------------------------------------------------
+// Packed fp32 (VOP3P v_pk_*_f32: two IEEE fp32 operations per lane and instruction, each rounded
+// exactly like its scalar twin). The distance update is the VALU-throughput part of a round and packs
+// perfectly: two slots per instruction, the selected point broadcast from one half of a register pair
+// (op_sel), its negation folded into the add (neg_lo/neg_hi; a + (-s) == a - s bit for bit).
+// Measured (scripts/ubench_pk.hip, 2 waves per SIMD): 3.76 cycles per v_pk op vs 3.26 per scalar op,
+// i.e. 1.7x the fp32 rate. hipcc's own SLP packing of the scalar code was slower (-fno-slp-vectorize):
+// it assembles the pairs with extra moves on the critical path; here the slots LIVE as pairs.
+typedef float pn2_f2 __attribute__((ext_vector_type(2)));
+#ifndef PN2_FPS_PACK_512
+#define PN2_FPS_PACK_512 0
+#endif
+
+__device__ __forceinline__ pn2_f2 pk_sub_bcast_lo(pn2_f2 a, pn2_f2 s)   // a - s.x in both halves
+{
+    pn2_f2 r;
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(s));
+    return r;
+}
+
+__device__ __forceinline__ pn2_f2 pk_sub_bcast_hi(pn2_f2 a, pn2_f2 s)   // a - s.y in both halves
+{
+    pn2_f2 r;
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(s));
+    return r;
+}
+
+__device__ __forceinline__ pn2_f2 pk_mul(pn2_f2 a, pn2_f2 b)
+{
+    pn2_f2 r;
+    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ pn2_f2 pk_add(pn2_f2 a, pn2_f2 b)
+{
+    pn2_f2 r;
+    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // PUBLISH: thread 0 additionally stores every selected index as an 8-byte {tag = 1, index} granule
 // with ONE write-through (sc1, agent-scope relaxed atomic) store, so other workgroups of the same
 // launch can consume the samples while the chain is still running (sa_fused.hip; hand-off form R2 of
@@ -113,7 +153,12 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
     const int lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
 
+    // slots live as register pairs (see pk_* above) -- except at 512 threads, where the packed form
+    // measured slower (2 waves per SIMD: 438 vs 411 ns per round at 512x8; PN2_FPS_PACK_512 is the lab switch)
+    constexpr bool PACKED = (P % 2 == 0) && (T != 512 || PN2_FPS_PACK_512);
+    constexpr int PH = PACKED ? P / 2 : 1;
     float x[P], y[P], z[P], md[P];
+    pn2_f2 xx[PH], yy[PH], zz[PH];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const int r = t * P + p;                       // tie rank of this slot
@@ -127,9 +172,14 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
         // mirrors are indexed by the key's low word (kMaxLow - rank): one shift-add to the address
         if (LDSXYZ) lds_rank[NS - 1 - r] = make_float4(x[p], y[p], z[p], __int_as_float(kk));
         else lds_k[NS - 1 - r] = kk;
+        if (PACKED) {
+            if (p & 1) { xx[p / 2].y = x[p]; yy[p / 2].y = y[p]; zz[p / 2].y = z[p]; }
+            else { xx[p / 2].x = x[p]; yy[p / 2].x = y[p]; zz[p / 2].x = z[p]; }
+        }
     }
     __syncthreads();
 
+    pn2_f2 sxy = {0.f, 0.f}, szk = {0.f, 0.f};         // the selected point as two register pairs (packed path)
     float sx, sy, sz;                                  // the point selected last (starts at k = 0 = rank 0)
     if (LDSXYZ) {
         const float4 s = lds_rank[NS - 1];
@@ -137,6 +187,7 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
     } else {
         sx = src[0]; sy = src[1]; sz = src[2];
     }
+    sxy.x = sx; sxy.y = sy; szk.x = sz;
     if (t == 0) {
         dst[0] = 0;                                    // tf_sampling_g.cu:114-116
         if (PUBLISH) __hip_atomic_store(gtag, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -150,11 +201,40 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
         // slot, read as a double, is positive, finite (value <= 1e38f < 0x7FF00000) and ordered exactly
         // like the pair (value, smaller rank first); fp64 denormals are never flushed on gfx9.
         double kd[P];
+        if (PACKED) {
+            // breadth first (the asm statements are volatile, so this IS the issue order): every
+            // operation is >= PH instructions away from its producer
+            pn2_f2 dx[PH], dy[PH], dz[PH];
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const float d = sqdist(x[p], y[p], z[p], sx, sy, sz);
-            md[p] = vmin_f32(d, md[p]);                // min(d,td), :144
-            kd[p] = __hiloint2double(__float_as_int(md[p]), (int)(low0 - (unsigned)p));
+            for (int h = 0; h < PH; ++h) dx[h] = pk_sub_bcast_lo(xx[h], sxy);
+#pragma unroll
+            for (int h = 0; h < PH; ++h) dy[h] = pk_sub_bcast_hi(yy[h], sxy);
+#pragma unroll
+            for (int h = 0; h < PH; ++h) dz[h] = pk_sub_bcast_lo(zz[h], szk);
+#pragma unroll
+            for (int h = 0; h < PH; ++h) dx[h] = pk_mul(dx[h], dx[h]);
+#pragma unroll
+            for (int h = 0; h < PH; ++h) dy[h] = pk_mul(dy[h], dy[h]);
+#pragma unroll
+            for (int h = 0; h < PH; ++h) dz[h] = pk_mul(dz[h], dz[h]);
+#pragma unroll
+            for (int h = 0; h < PH; ++h) dx[h] = pk_add(dx[h], dy[h]);
+#pragma unroll
+            for (int h = 0; h < PH; ++h) dx[h] = pk_add(dx[h], dz[h]);
+#pragma unroll
+            for (int h = 0; h < PH; ++h) {
+                md[2 * h] = vmin_f32(dx[h].x, md[2 * h]);          // min(d,td), :144
+                md[2 * h + 1] = vmin_f32(dx[h].y, md[2 * h + 1]);
+                kd[2 * h] = __hiloint2double(__float_as_int(md[2 * h]), (int)(low0 - (unsigned)(2 * h)));
+                kd[2 * h + 1] = __hiloint2double(__float_as_int(md[2 * h + 1]), (int)(low0 - (unsigned)(2 * h + 1)));
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const float d = sqdist(x[p], y[p], z[p], sx, sy, sz);
+                md[p] = vmin_f32(d, md[p]);                // min(d,td), :144
+                kd[p] = __hiloint2double(__float_as_int(md[p]), (int)(low0 - (unsigned)p));
+            }
         }
 #pragma unroll
         for (int st = 1; st < P; st <<= 1)             // tournament: depth log2(P), independent v_max_f64 per level
@@ -197,10 +277,12 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
         if (LDSXYZ) {
             const float4 s = lds_rank[win];            // same address in every lane: LDS broadcast
             sx = s.x; sy = s.y; sz = s.z;
+            sxy.x = s.x; sxy.y = s.y; szk.x = s.z; szk.y = s.w;
             k = __float_as_int(s.w);
         } else {
             k = lds_k[win];
             sx = src[(size_t)k * 3 + 0]; sy = src[(size_t)k * 3 + 1]; sz = src[(size_t)k * 3 + 2];
+            sxy.x = sx; sxy.y = sy; szk.x = sz;
         }
         if (t == 0) {
             dst[j] = k;
