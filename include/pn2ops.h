@@ -102,6 +102,21 @@ int pn2_three_interpolate(int b, int m, int c, int n, const float *points, const
 int pn2_three_interpolate_grad(int b, int n, int c, int m, const float *grad_out, const int *idx,
                                const float *weight, float *grad_points, void *stream);
 
+/* ---- run-to-run reproducible gradients (no reference counterpart) -------------
+ * Same contracts as pn2_gather_point_grad / pn2_group_point_grad / pn2_three_interpolate_grad above
+ * (tf_sampling_g.cu:182-190, tf_grouping_g.cu:60-78, tf_interpolate.cpp:131-153), but the scatter-add
+ * accumulates 64-bit fixed-point integers, so the result does not depend on the order in which the
+ * atomics land: two calls on the same inputs return identical bits. `ws` is device scratch of
+ * pn2_det_grad_ws_bytes(b, rows, c) bytes (rows = n for gather/group, m for three_interpolate; c = 3 for
+ * gather); it needs no initialisation. Non-finite gradients fall back to the fp32-atomic accumulation. */
+long long pn2_det_grad_ws_bytes(int b, int rows, int c);
+int pn2_gather_point_grad_det(int b, int n, int m, const float *out_g, const int *idx, float *inp_g, void *ws,
+                              void *stream);
+int pn2_group_point_grad_det(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
+                             float *grad_points, void *ws, void *stream);
+int pn2_three_interpolate_grad_det(int b, int n, int c, int m, const float *grad_out, const int *idx,
+                                   const float *weight, float *grad_points, void *ws, void *stream);
+
 /* ---- fused entry points (no reference counterpart) ---- */
 
 /* farthest_point_sample + gather_point(inp, out) in one launch: what

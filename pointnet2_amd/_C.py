@@ -39,6 +39,10 @@ _SIGNATURES = {
     "pn2_three_nn": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pn2_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pn2_three_interpolate_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pn2_det_grad_ws_bytes": [_i, _i, _i],
+    "pn2_gather_point_grad_det": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pn2_group_point_grad_det": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pn2_three_interpolate_grad_det": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pn2_query_ball_group_xyz": [_i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "pn2_sample_and_group_xyz": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pn2_sample_and_group_ws_bytes": [_i, _i],
@@ -49,6 +53,7 @@ _SIGNATURES = {
 }
 _RESTYPES = {
     "pn2_fps_temp_floats": ctypes.c_longlong,
+    "pn2_det_grad_ws_bytes": ctypes.c_longlong,
     "pn2_sample_and_group_ws_bytes": ctypes.c_longlong,
     "pn2_ball_threshold": ctypes.c_float,
     "pn2_version": ctypes.c_char_p,

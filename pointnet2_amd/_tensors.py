@@ -70,3 +70,25 @@ class on_device:
         if self.prev is not None:
             torch.cuda.set_device(self.prev)
         return False
+
+
+_deterministic = False
+
+
+def set_deterministic(flag):
+    """Route the scatter-add gradients (gather_point, group_point, three_interpolate) through the
+    order-independent fixed-point kernels (pn2_*_grad_det): identical bits on every run, at about
+    twice the accumulation traffic. Off by default, like the reference (fp32 atomics). Also switched
+    on by torch.use_deterministic_algorithms(True)."""
+    global _deterministic
+    _deterministic = bool(flag)
+
+
+def is_deterministic():
+    return _deterministic or torch.are_deterministic_algorithms_enabled()
+
+
+def det_workspace(lib, b, rows, c, device):
+    """Scratch for one deterministic gradient call (int64 accumulators + header)."""
+    nbytes = lib.pn2_det_grad_ws_bytes(b, rows, c)
+    return torch.empty(((nbytes + 7) // 8,), dtype=torch.int64, device=device)

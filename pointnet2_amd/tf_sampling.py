@@ -11,7 +11,8 @@ ProbSample are NoGradient (:22, :57).
 import torch
 
 from . import _C
-from ._tensors import f32, i32, on_device, ptr, require, same_device, stream_ptr
+from ._tensors import (det_workspace, f32, i32, is_deterministic, on_device, ptr, require, same_device,
+                       stream_ptr)
 
 
 def prob_sample(inp, inpr):
@@ -56,8 +57,13 @@ class _GatherPoint(torch.autograd.Function):
         dev = out_g.device
         inp_g = torch.empty((b, ctx.n, 3), dtype=torch.float32, device=dev)   # zero-filled by the library
         with on_device(dev):
-            _C.check(_C.lib().pn2_gather_point_grad(b, ctx.n, m, ptr(out_g), ptr(idx), ptr(inp_g), stream_ptr(dev)),
-                     "gather_point_grad")
+            if is_deterministic():
+                ws = det_workspace(_C.lib(), b, ctx.n, 3, dev)
+                _C.check(_C.lib().pn2_gather_point_grad_det(b, ctx.n, m, ptr(out_g), ptr(idx), ptr(inp_g), ptr(ws),
+                                                            stream_ptr(dev)), "gather_point_grad")
+            else:
+                _C.check(_C.lib().pn2_gather_point_grad(b, ctx.n, m, ptr(out_g), ptr(idx), ptr(inp_g),
+                                                        stream_ptr(dev)), "gather_point_grad")
         return inp_g, None
 
 

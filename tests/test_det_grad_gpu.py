@@ -1,0 +1,130 @@
+"""Reproducible gradients (pn2_*_grad_det): identical bits on every run, the values of
+an exact (float64) accumulation to within fp32 rounding, fallback for non-finite gradients (GPU)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def deterministic():
+    import pointnet2_amd as P
+    P.set_deterministic(True)
+    yield P
+    P.set_deterministic(False)
+
+
+def _exact_scatter(b, rows, c, target, addend):
+    """float64 scatter-add: target (b, e) row numbers, addend (b, e, c)."""
+    out = np.zeros((b, rows, c), np.float64)
+    for i in range(b):
+        np.add.at(out[i], target[i], addend[i].astype(np.float64))
+    return out
+
+
+def _tol(addend, target, b, rows):
+    """fp32 rounding of the result (a few ulps of the sum of magnitudes) plus the fixed-point resolution:
+    every addend is rounded to a multiple of 2^-k, k = 62 - ceil(log2 entries) - e with 2^e > max |addend|,
+    i.e. at most 2^-(k+1) per addend -- relative to the LARGEST addend of the call, not to the target's own."""
+    mag = np.zeros((b, rows, addend.shape[2]), np.float64)
+    cnt = np.zeros((b, rows, 1), np.float64)
+    for i in range(b):
+        np.add.at(mag[i], target[i], np.abs(addend[i]).astype(np.float64))
+        np.add.at(cnt[i], target[i], 1.0)
+    amax = float(np.max(np.abs(addend))) if addend.size else 0.0
+    e = np.frexp(amax)[1] + 1 if amax > 0 else 0
+    k = 62 - int(np.ceil(np.log2(max(2, addend.shape[1])))) - e
+    return mag * 2.0 ** -23 + cnt * 2.0 ** -(k + 1) + 1e-30
+
+
+@pytest.mark.parametrize("skew", [False, True])
+def test_group_point_grad_det(cuda, deterministic, skew):
+    P = deterministic
+    rng = np.random.default_rng(1)
+    b, n, c, m, ns = 3, 700, 5, 90, 16
+    idx = rng.integers(0, n, size=(b, m, ns)).astype(np.int32)
+    if skew:
+        idx[:, :, ::2] = 7                                     # half of all samples hit one point
+    g = (rng.standard_normal((b, m, ns, c)) * 10.0 ** rng.integers(-6, 6, size=(b, m, ns, 1))).astype(np.float32)
+    pts = torch.zeros(b, n, c, device=cuda, requires_grad=True)
+    outs = []
+    for _ in range(6):
+        pts.grad = None
+        P.group_point(pts, torch.from_numpy(idx).to(cuda)).backward(torch.from_numpy(g).to(cuda))
+        outs.append(pts.grad.clone())
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    want = _exact_scatter(b, n, c, idx.reshape(b, -1), g.reshape(b, -1, c))
+    err = np.abs(outs[0].cpu().numpy().astype(np.float64) - want)
+    assert np.all(err <= _tol(g.reshape(b, -1, c), idx.reshape(b, -1), b, n))
+    # and the default (fp32 atomics) path agrees to accumulation noise
+    P.set_deterministic(False)
+    pts.grad = None
+    P.group_point(pts, torch.from_numpy(idx).to(cuda)).backward(torch.from_numpy(g).to(cuda))
+    assert np.all(np.abs(pts.grad.cpu().numpy() - want) <= 64 * _tol(g.reshape(b, -1, c), idx.reshape(b, -1), b, n))
+
+
+def test_gather_point_grad_det(cuda, deterministic):
+    P = deterministic
+    rng = np.random.default_rng(2)
+    b, n, m = 4, 300, 1000                                     # m > n: every point collects several gradients
+    idx = rng.integers(0, n, size=(b, m)).astype(np.int32)
+    g = rng.standard_normal((b, m, 3)).astype(np.float32)
+    inp = torch.zeros(b, n, 3, device=cuda, requires_grad=True)
+    outs = []
+    for _ in range(6):
+        inp.grad = None
+        P.gather_point(inp, torch.from_numpy(idx).to(cuda)).backward(torch.from_numpy(g).to(cuda))
+        outs.append(inp.grad.clone())
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    want = _exact_scatter(b, n, 3, idx, g)
+    assert np.all(np.abs(outs[0].cpu().numpy() - want) <= _tol(g, idx, b, n))
+
+
+def test_three_interpolate_grad_det(cuda, deterministic):
+    P = deterministic
+    rng = np.random.default_rng(3)
+    b, n, m, c = 2, 2000, 64, 7
+    idx = rng.integers(0, m, size=(b, n, 3)).astype(np.int32)
+    w = rng.random((b, n, 3), dtype=np.float32)
+    g = rng.standard_normal((b, n, c)).astype(np.float32)
+    pts = torch.zeros(b, m, c, device=cuda, requires_grad=True)
+    outs = []
+    for _ in range(6):
+        pts.grad = None
+        P.three_interpolate(pts, torch.from_numpy(idx).to(cuda), torch.from_numpy(w).to(cuda)).backward(
+            torch.from_numpy(g).to(cuda))
+        outs.append(pts.grad.clone())
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    addend = (g[:, :, None, :] * w[:, :, :, None]).astype(np.float32).reshape(b, n * 3, c)   # fp32 products, as the op forms them
+    want = _exact_scatter(b, m, c, idx.reshape(b, -1), addend)
+    assert np.all(np.abs(outs[0].cpu().numpy() - want) <= _tol(addend, idx.reshape(b, -1), b, m))
+
+
+def test_det_grad_edge_values(cuda, deterministic):
+    """All-zero gradients, huge and tiny magnitudes, and non-finite gradients (fp32-atomic fallback)."""
+    P = deterministic
+    b, n, c, m, ns = 1, 50, 2, 10, 4
+    idx = torch.randint(0, n, (b, m, ns), dtype=torch.int32, device=cuda)
+    pts = torch.zeros(b, n, c, device=cuda, requires_grad=True)
+
+    def grad_for(g):
+        pts.grad = None
+        P.group_point(pts, idx).backward(g)
+        return pts.grad.clone()
+
+    assert torch.count_nonzero(grad_for(torch.zeros(b, m, ns, c, device=cuda))) == 0
+    for scale in (1e-42, 1e-30, 1.0, 1e30, 3e38):
+        g = torch.full((b, m, ns, c), scale, device=cuda)
+        got = grad_for(g).cpu().numpy().astype(np.float64)
+        counts = np.zeros((n,), np.float64)
+        np.add.at(counts, idx.cpu().numpy().reshape(-1), 1.0)
+        with np.errstate(over="ignore"):
+            want = np.float32(counts[:, None] * np.float64(np.float32(scale))).astype(np.float64)
+        fin = np.isfinite(want)
+        assert np.allclose(got[0][fin[:, 0]], np.broadcast_to(want, (n, c))[fin[:, 0]], rtol=1e-6, atol=0), scale
+    g = torch.ones(b, m, ns, c, device=cuda)
+    g[0, 3, 1, 0] = float("inf")
+    g[0, 5, 2, 1] = float("nan")
+    got = grad_for(g)
+    assert torch.isinf(got[0, idx[0, 3, 1].item(), 0]) and torch.isnan(got[0, idx[0, 5, 2].item(), 1])
