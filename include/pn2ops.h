@@ -117,6 +117,24 @@ int pn2_group_point_grad_det(int b, int n, int c, int m, int nsample, const floa
 int pn2_three_interpolate_grad_det(int b, int n, int c, int m, const float *grad_out, const int *idx,
                                    const float *weight, float *grad_points, void *ws, void *stream);
 
+/* ---- grouped local MLP + max-pool of a set-abstraction layer, fused, on the matrix cores ---------
+ * (no reference kernel; replaces for INFERENCE the TF graph of utils/pointnet_util.py:44-50 + :117-127:
+ *  group_point(xyz)-new_xyz ++ group_point(points) -> 3 x [conv2d 1x1 + batch_norm + ReLU] -> reduce_max
+ *  over nsample). fp32 in, fp32 MFMA, fp32 out.
+ *   xyz (b,n,3), new_xyz (b,m,3), points (b,n,cfeat) or NULL when cfeat == 0, idx (b,m,nsample) i32
+ *   -> out (b,m,c3).  Input channel order is the reference's: [relative xyz (3), features (cfeat)].
+ * Limits (PN2_E_TOO_LARGE outside; callers keep the unfused path): 3 + cfeat <= 32, widths within
+ * (128,128,128) / (64,96,128) / (64,64,128) / (32,32,64), nsample == 16 or a multiple of 32.
+ * Weights: w_i (cin_i, cout_i) row-major = the reference's conv kernel [1,1,cin,cout] (tf_util.py:113-117)
+ * with batch norm folded in by the caller; pn2_sa_mlp3_pack (host code) permutes them into the layout the
+ * kernel keeps in LDS: wpacked / bpacked of the sizes pn2_sa_mlp3_config reports, uploaded by the caller. */
+int pn2_sa_mlp3_config(int cin, int c1, int c2, int c3, int *tiles3, long long *w_floats, long long *b_floats);
+int pn2_sa_mlp3_pack(int cin, int c1, int c2, int c3, const float *w1, const float *bias1, const float *w2,
+                     const float *bias2, const float *w3, const float *bias3, float *wpacked, float *bpacked);
+int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, const float *xyz, const float *new_xyz,
+                        const float *points, const int *idx, int c1, int c2, int c3, const float *wpacked,
+                        const float *bpacked, float *out, void *stream);
+
 /* ---- fused entry points (no reference counterpart) ---- */
 
 /* farthest_point_sample + gather_point(inp, out) in one launch: what

@@ -1,0 +1,318 @@
+// sa_mlp.hip -- the grouped local MLP of a set-abstraction layer fused with its max-pool, on the
+// matrix cores. gfx950.
+//
+// Replaces, for inference, reference utils/pointnet_util.py:44-50 + :117-127:
+//     grouped_xyz = group_point(xyz, idx) - new_xyz ; new_points = concat(grouped_xyz, group_point(points, idx))
+//     3 x [ tf_util.conv2d 1x1 + batch_norm (eps 1e-3) + ReLU ]  (tf_util.py:88-150, :512-531)
+//     new_points = reduce_max(new_points, axis=[2])
+// i.e. per centroid an (nsample x Cin) matrix through three dense layers and a column max. The
+// reference (and a plain PyTorch port) materialises the (b, m, nsample, C) tensor of every layer in
+// HBM: 128-640 MB per SA level in the segmentation configs. Here NOTHING between the idx tensor and
+// the (b, m, C3) result leaves the CU: rows are gathered straight into MFMA operand registers, the
+// activations of all three layers stay in accumulator registers, the max runs over lanes.
+// Batch norm is folded into the weights by the caller (inference statistics): W' = W*s, b' = (b-mu)*s+beta.
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 -- fp32 inputs, fp32 accumulate, exact fp32 products (an fma
+// chain), 64 FLOP/clk/SIMD = the fp32 peak of the chip (157 TFLOP/s). No reduced precision.
+//
+// Formulation. One wave owns 32 samples (one centroid at nsample = 32) and computes the TRANSPOSED
+// layer  H^T (channels x samples) = W^T (Cout x Cin) . X^T (Cin x samples):
+//   MFMA "A" operand = a 32x2 block of W^T: lane l supplies W[k][n = 32t + (l & 31)], k chosen below;
+//   MFMA "B" operand = a 2x32 block of X^T: lane l supplies X[sample = l & 31][k];
+//   C/D: lane l, register v holds H^T[channel 8(v>>2) + 4(l>>5) + (v&3)][sample l & 31].
+// The contraction index k may be visited in ANY order as long as A and B agree. Visiting, at step v of
+// input tile u, k = 32u + 8(v>>2) + (v&3) in lanes 0-31 and k + 4 in lanes 32-63 makes the B operand
+// of step v EXACTLY accumulator register v of the previous layer's tile u: the activations never move
+// between layers -- no LDS round trip, no shuffles. The weights are stored pre-permuted to match
+// (pn2_sa_mlp3_pack), in LDS, laid out so that one ds_read_b128 per lane feeds four MFMAs.
+#include "pn2_device.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace pn2 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMlpThreads = 256;          // 4 waves: one per SIMD; a second workgroup shares the CU when registers allow
+constexpr int kMlpMaxLds = 150 * 1024;
+
+// channel (within a 32-tile) that register v of lane-half h holds / must be fed with
+__host__ __device__ __forceinline__ int mlp_chan(int v, int h) { return 8 * (v >> 2) + 4 * h + (v & 3); }
+
+// packed sizes (floats): weights [t][u][q = 4][lane = 64][r = 4] per layer, bias [t][h = 2][v = 16]
+__host__ __device__ __forceinline__ size_t mlp_w_floats(int t_out, int t_in) { return (size_t)t_out * t_in * 1024; }
+__host__ __device__ __forceinline__ size_t mlp_b_floats(int t_out) { return (size_t)t_out * 32; }
+
+__device__ __forceinline__ f32x16 mlp_bias(const float *bp, int t, int h)
+{
+    const float4 *p = reinterpret_cast<const float4 *>(bp + (t * 2 + h) * 16);
+    const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+    f32x16 r = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    return r;
+}
+
+__device__ __forceinline__ f32x16 mlp_relu(f32x16 x)
+{
+#pragma unroll
+    for (int v = 0; v < 16; ++v) x[v] = fmaxf(x[v], 0.0f);
+    return x;
+}
+
+// One dense layer on the wave's 32 samples: out[t] = relu(bias + sum_u W^T[t][u] . in[u]), 16 MFMAs per
+// (t, u) pair. The weights of pair i + 1 are read from LDS while the MFMAs of pair i run (the compiler
+// fence keeps the prefetch where it is written; left alone, hipcc hoists EVERY weight read of the layer
+// to its top and runs out of registers). `quartets` = leading register quartets of `in` that can be
+// non-zero (4, except for a narrow first layer). MAXACC: out[t] = max(out[t], result) unless `first`.
+template <int TOUT, int TIN, bool MAXACC>
+__device__ __forceinline__ void mlp_layer(const float *wp, const float *bp, const f32x16 (&in)[TIN], f32x16 (&out)[TOUT],
+                                          int lane, int h, int quartets, bool first)
+{
+    const float4 *w4 = reinterpret_cast<const float4 *>(wp) + lane;
+    float4 cur[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur[q] = w4[q * 64];
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < TOUT * TIN; ++i) {
+        const int t = i / TIN, u = i % TIN;
+        float4 nxt[4];
+        if (i + 1 < TOUT * TIN) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nxt[q] = w4[(i + 1) * 256 + q * 64];
+        }
+        if (u == 0) acc = mlp_bias(bp, t, h);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < quartets) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].x, in[u][4 * q + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].y, in[u][4 * q + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].z, in[u][4 * q + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].w, in[u][4 * q + 3], acc, 0, 0, 0);
+            }
+        }
+        if (u == TIN - 1) {
+            const f32x16 r = mlp_relu(acc);
+            if (MAXACC && !first) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) out[t][v] = fmaxf(out[t][v], r[v]);
+            } else {
+                out[t] = r;
+            }
+        }
+        if (i + 1 < TOUT * TIN) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+        }
+    }
+}
+
+// max over the samples of one centroid: the SPAN lanes (16 or 32) of a lane half that share l >> log2(SPAN)
+template <int SPAN>
+__device__ __forceinline__ float mlp_span_max(float x)
+{
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true)));    // lane ^ 1
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true)));    // lane ^ 2
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xf, 0xf, true)));   // other quad of the half row
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, true)));   // other half row
+    if (SPAN == 32) x = fmaxf(x, __shfl_xor(x, 16));
+    return x;
+}
+
+// T1, T2, T3: output tiles (32 channels each) of the three layers; the input is one tile (Cin <= 32).
+// SPAN: samples per centroid inside one 32-sample group (32, or 16 when nsample = 16).
+template <int T1, int T2, int T3, int SPAN>
+__global__ __launch_bounds__(kMlpThreads) void sa_mlp3_kernel(int n, int m, int nsample, int cfeat, int c3, long long rows,
+                                                              const float *__restrict__ xyz,
+                                                              const float *__restrict__ new_xyz,
+                                                              const float *__restrict__ points,
+                                                              const int *__restrict__ idx,
+                                                              const float *__restrict__ wpacked,
+                                                              const float *__restrict__ bpacked, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *w1 = reinterpret_cast<float *>(smem);
+    float *w2 = w1 + mlp_w_floats(T1, 1);
+    float *w3 = w2 + mlp_w_floats(T2, T1);
+    float *b1 = w3 + mlp_w_floats(T3, T2);
+    float *b2 = b1 + mlp_b_floats(T1);
+    float *b3 = b2 + mlp_b_floats(T2);
+    {
+        const size_t wf = mlp_w_floats(T1, 1) + mlp_w_floats(T2, T1) + mlp_w_floats(T3, T2);
+        const size_t bf = mlp_b_floats(T1) + mlp_b_floats(T2) + mlp_b_floats(T3);
+        const float4 *src = reinterpret_cast<const float4 *>(wpacked);
+        float4 *dst = reinterpret_cast<float4 *>(w1);
+        for (size_t i = threadIdx.x; i < wf / 4; i += kMlpThreads) dst[i] = src[i];
+        for (size_t i = threadIdx.x; i < bf; i += kMlpThreads) b1[i] = bpacked[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5, s = lane & 31;
+    const int cin = 3 + cfeat;
+    const int quartets1 = (cin + 7) / 8;                 // register quartet q covers channels 8q .. 8q+7
+    const int parts = SPAN == 32 ? nsample / 32 : 1;     // 32-sample groups per centroid
+    const long long wave = (long long)blockIdx.x * (kMlpThreads / 64) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * (kMlpThreads / 64);
+    const long long groups = SPAN == 32 ? rows : (rows + 1) / 2;
+
+    for (long long g = wave; g < groups; g += nwaves) {
+        // the centroid (row of the (b*m) table) this lane's sample belongs to
+        const long long row_raw = SPAN == 32 ? g : g * 2 + (s >> 4);
+        const bool row_ok = row_raw < rows;
+        const long long row = row_ok ? row_raw : rows - 1;          // an odd tail at nsample = 16 recomputes the last row
+        const long long cloud = row / m;
+        const float cx = new_xyz[row * 3 + 0], cy = new_xyz[row * 3 + 1], cz = new_xyz[row * 3 + 2];
+        f32x16 best[T3];
+        for (int part = 0; part < parts; ++part) {
+            const int sample = SPAN == 32 ? part * 32 + s : (s & 15);
+            const int p = idx[row * nsample + sample];
+            const float *px = xyz + ((size_t)cloud * n + p) * 3;
+            const float *pf = points ? points + ((size_t)cloud * n + p) * cfeat : nullptr;
+            // layer-1 operand: register v <- input channel mlp_chan(v, h) of this lane's sample
+            f32x16 x0;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int k = mlp_chan(v, h);
+                float val = 0.0f;
+                if ((v >> 2) < quartets1) {
+                    if (k == 0) val = __fsub_rn(px[0], cx);
+                    else if (k == 1) val = __fsub_rn(px[1], cy);
+                    else if (k == 2) val = __fsub_rn(px[2], cz);
+                    else if (k < cin) val = pf[k - 3];
+                }
+                x0[v] = val;
+            }
+            f32x16 in0[1] = {x0}, h1[T1], h2[T2];
+            mlp_layer<T1, 1, false>(w1, b1, in0, h1, lane, h, quartets1, true);
+            mlp_layer<T2, T1, false>(w2, b2, h1, h2, lane, h, 4, true);
+            mlp_layer<T3, T2, true>(w3, b3, h2, best, lane, h, 4, part == 0);
+        }
+        // column max over the centroid's samples, then lane 0 of each span writes 4 channels per store
+#pragma unroll
+        for (int t = 0; t < T3; ++t) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) best[t][v] = mlp_span_max<SPAN>(best[t][v]);
+            if ((s & (SPAN - 1)) == 0 && row_ok) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = 32 * t + mlp_chan(4 * q, h);
+                    float *o = out + row * c3 + ch;
+                    if (ch + 3 < c3 && (c3 & 3) == 0) {
+                        *reinterpret_cast<float4 *>(o) = make_float4(best[t][4 * q], best[t][4 * q + 1], best[t][4 * q + 2], best[t][4 * q + 3]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (ch + r < c3) o[r] = best[t][4 * q + r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct MlpConfig { int t1, t2, t3; };
+
+// smallest instantiated tile configuration that covers (c1, c2, c3); padded channels carry zero
+// weights and zero bias, cost MFMA time and never reach memory
+static bool mlp_pick(int c1, int c2, int c3, MlpConfig &cfg)
+{
+    static const MlpConfig kConfigs[] = {{1, 1, 2}, {2, 2, 4}, {2, 3, 4}, {4, 4, 4}};
+    for (const MlpConfig &c : kConfigs)
+        if (c1 <= 32 * c.t1 && c2 <= 32 * c.t2 && c3 <= 32 * c.t3) { cfg = c; return true; }
+    return false;
+}
+
+static size_t mlp_total_w(const MlpConfig &c) { return mlp_w_floats(c.t1, 1) + mlp_w_floats(c.t2, c.t1) + mlp_w_floats(c.t3, c.t2); }
+static size_t mlp_total_b(const MlpConfig &c) { return mlp_b_floats(c.t1) + mlp_b_floats(c.t2) + mlp_b_floats(c.t3); }
+
+template <int T1, int T2, int T3>
+static int launch_mlp(int b, int n, int m, int nsample, int cfeat, int c3, const float *xyz, const float *new_xyz,
+                      const float *points, const int *idx, const float *wp, const float *bp, float *out, hipStream_t st)
+{
+    const MlpConfig cfg = {T1, T2, T3};
+    const size_t lds = sizeof(float) * (mlp_total_w(cfg) + mlp_total_b(cfg));
+    if (lds > (size_t)kMlpMaxLds) return PN2_E_TOO_LARGE;
+    const long long rows = (long long)b * m;
+    const bool half = nsample == 16;
+    const long long groups = half ? (rows + 1) / 2 : rows;
+    long long blocks = (groups + 3) / 4;
+    if (blocks > 512) blocks = 512;                       // persistent: every workgroup stages the weights once
+    auto kern = half ? sa_mlp3_kernel<T1, T2, T3, 16> : sa_mlp3_kernel<T1, T2, T3, 32>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kMlpThreads), lds, st, n, m, nsample, cfeat, c3, rows, xyz, new_xyz,
+                       points, idx, wp, bp, out);
+    return launch_status();
+}
+
+}  // namespace pn2
+
+extern "C" int pn2_sa_mlp3_config(int cin, int c1, int c2, int c3, int *tiles, long long *w_floats, long long *b_floats)
+{
+    using namespace pn2;
+    if (cin < 3 || c1 <= 0 || c2 <= 0 || c3 <= 0) return PN2_E_ARG;
+    MlpConfig cfg;
+    if (cin > 32 || !mlp_pick(c1, c2, c3, cfg)) return PN2_E_TOO_LARGE;
+    if (tiles) { tiles[0] = cfg.t1; tiles[1] = cfg.t2; tiles[2] = cfg.t3; }
+    if (w_floats) *w_floats = (long long)mlp_total_w(cfg);
+    if (b_floats) *b_floats = (long long)mlp_total_b(cfg);
+    return PN2_OK;
+}
+
+// Host-side packing (plain C loops, no device work): w_i is (cin_i, cout_i) row-major -- the layout of
+// the reference's conv kernel [1,1,cin,cout] (tf_util.py:113-117) -- with batch norm already folded in.
+extern "C" int pn2_sa_mlp3_pack(int cin, int c1, int c2, int c3, const float *w1, const float *bias1, const float *w2,
+                                const float *bias2, const float *w3, const float *bias3, float *wpacked, float *bpacked)
+{
+    using namespace pn2;
+    MlpConfig cfg;
+    if (cin < 3 || cin > 32 || c1 <= 0 || c2 <= 0 || c3 <= 0 || !mlp_pick(c1, c2, c3, cfg)) return PN2_E_TOO_LARGE;
+    if (!w1 || !w2 || !w3 || !bias1 || !bias2 || !bias3 || !wpacked || !bpacked) return PN2_E_NULL;
+    const float *ws[3] = {w1, w2, w3}, *bs[3] = {bias1, bias2, bias3};
+    const int kin[3] = {cin, c1, c2}, nout[3] = {c1, c2, c3};
+    const int tin[3] = {1, cfg.t1, cfg.t2}, tout[3] = {cfg.t1, cfg.t2, cfg.t3};
+    float *wp = wpacked, *bp = bpacked;
+    for (int L = 0; L < 3; ++L) {
+        for (int t = 0; t < tout[L]; ++t)
+            for (int u = 0; u < tin[L]; ++u)
+                for (int q = 0; q < 4; ++q)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int r = 0; r < 4; ++r) {
+                            const int k = 32 * u + mlp_chan(4 * q + r, lane >> 5), nn = 32 * t + (lane & 31);
+                            *wp++ = (k < kin[L] && nn < nout[L]) ? ws[L][(size_t)k * nout[L] + nn] : 0.0f;
+                        }
+        for (int t = 0; t < tout[L]; ++t)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int v = 0; v < 16; ++v) {
+                    const int ch = 32 * t + mlp_chan(v, hh);
+                    *bp++ = ch < nout[L] ? bs[L][ch] : 0.0f;
+                }
+    }
+    return PN2_OK;
+}
+
+extern "C" int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, const float *xyz, const float *new_xyz,
+                                   const float *points, const int *idx, int c1, int c2, int c3, const float *wpacked,
+                                   const float *bpacked, float *out, void *stream)
+{
+    using namespace pn2;
+    if (b < 0 || n <= 0 || m < 0 || cfeat < 0) return PN2_E_SHAPE;
+    if (nsample != 16 && (nsample <= 0 || nsample % 32 != 0)) return PN2_E_ARG;
+    if (b == 0 || m == 0) return PN2_OK;
+    if (!xyz || !new_xyz || !idx || !wpacked || !bpacked || !out || (cfeat > 0 && !points)) return PN2_E_NULL;
+    MlpConfig cfg;
+    if (3 + cfeat > 32 || !mlp_pick(c1, c2, c3, cfg)) return PN2_E_TOO_LARGE;
+    hipStream_t st = as_stream(stream);
+    const float *pts = cfeat > 0 ? points : nullptr;
+#define PN2_MLP_CASE(A, B, C) \
+    if (cfg.t1 == A && cfg.t2 == B && cfg.t3 == C) \
+        return launch_mlp<A, B, C>(b, n, m, nsample, cfeat, c3, xyz, new_xyz, pts, idx, wpacked, bpacked, out, st)
+    PN2_MLP_CASE(1, 1, 2);
+    PN2_MLP_CASE(2, 2, 4);
+    PN2_MLP_CASE(2, 3, 4);
+    PN2_MLP_CASE(4, 4, 4);
+#undef PN2_MLP_CASE
+    return PN2_E_TOO_LARGE;
+}

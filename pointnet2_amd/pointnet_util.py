@@ -19,6 +19,7 @@ from .tf_sampling import farthest_point_sample, farthest_point_sample_gather, ga
 from .tf_grouping import (query_ball_point, group_point, knn_point, query_ball_group_xyz,
                           sample_and_group_xyz)
 from .tf_interpolate import three_nn, three_interpolate
+from . import sa_mlp
 
 
 def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True, fused=None):
@@ -99,6 +100,16 @@ class _SharedMLP(nn.Module):
             c_in = w
         self.net = nn.Sequential(*layers)
         self.c_out = c_in
+        self.widths = tuple(widths)
+
+    def folded_layers(self):
+        """[(W (cin, cout), b (cout))] with eval-mode batch norm folded in (sa_mlp.fold_batch_norm)."""
+        out, mods = [], list(self.net)
+        for i, mod in enumerate(mods):
+            if isinstance(mod, nn.Conv2d):
+                bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d) else None
+                out.append(sa_mlp.fold_batch_norm(mod.weight, mod.bias, bn))
+        return out
 
     def forward(self, x):
         return self.net(x)
@@ -116,8 +127,36 @@ class PointnetSAModule(nn.Module):
         self.mlp = _SharedMLP(feat, mlp, bn)
         c = self.mlp.c_out * (2 if pooling == "max_and_avg" else 1)
         self.mlp2 = _SharedMLP(c, mlp2, bn) if mlp2 else None
+        self.fused_mlp = True          # eval-mode forward may use the fused MFMA kernel (sa_mlp.py)
+        self.last_path = None
+        self._pack_cache = None
+
+    def _fused_ok(self, xyz, points):
+        """Inference with max pooling on a layer stack pn2_sa_mlp3_maxpool covers (see sa_mlp.py)."""
+        if not self.fused_mlp or self.training or torch.is_grad_enabled() or self.group_all or self.knn:
+            return False
+        if self.pooling != "max" or self.mlp2 is not None or not xyz.is_cuda:
+            return False
+        if points is not None and not self.use_xyz:
+            return False
+        cin = 3 + (points.shape[2] if points is not None else 0)
+        return sa_mlp.supported(cin, self.mlp.widths, self.nsample)
+
+    def _packed(self, device):
+        """Folded + packed weights, rebuilt when a parameter or a running statistic changed."""
+        stamp = tuple((t.data_ptr(), t._version) for t in list(self.mlp.parameters()) + list(self.mlp.buffers()))
+        if self._pack_cache is None or self._pack_cache[0] != (stamp, device):
+            self._pack_cache = ((stamp, device), sa_mlp.PackedMLP3(self.mlp.folded_layers(), device))
+        return self._pack_cache[1]
 
     def forward(self, xyz, points):
+        if self._fused_ok(xyz, points):
+            # FPS + ball query in the overlapped launch, then ONE kernel from idx to the pooled features:
+            # the (b, npoint, nsample, C) tensors of pointnet_util.py:44-50 and :117-127 never exist
+            fps_idx, new_xyz, idx, _, _ = sample_and_group_xyz(self.npoint, self.radius, self.nsample, xyz, True)
+            self.last_path = "fused"
+            return new_xyz, sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, self._packed(xyz.device)), idx
+        self.last_path = "unfused"
         if self.group_all:
             new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, self.use_xyz)
         else:

@@ -1,0 +1,76 @@
+"""Fused grouped MLP + max-pool of a set-abstraction layer (inference), on the matrix cores.
+
+Reference: utils/pointnet_util.py:44-50 (group + centroid subtraction + concat) and :117-127
+(3 x tf_util.conv2d 1x1 + batch_norm + ReLU, reduce_max over nsample). The kernel and its limits are
+described in csrc/sa_mlp.hip and include/pn2ops.h (pn2_sa_mlp3_maxpool); SURVEY.md section 8 row f2.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _C
+from ._tensors import f32, i32, on_device, ptr, require, same_device, stream_ptr
+
+
+def fold_batch_norm(conv_weight, conv_bias, bn=None):
+    """(cout, cin[,1,1]) conv weight + bias and an optional eval-mode BatchNorm -> W (cin, cout), b (cout)
+    with the norm folded in: y = (xW + b - mean) * gamma / sqrt(var + eps) + beta."""
+    w = conv_weight.detach().double().reshape(conv_weight.shape[0], -1).t().contiguous()      # (cin, cout)
+    b = (conv_bias.detach().double() if conv_bias is not None else torch.zeros(w.shape[1], dtype=torch.float64,
+                                                                               device=w.device))
+    if bn is not None:
+        s = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+        w = w * s[None, :]
+        b = (b - bn.running_mean.detach().double()) * s + bn.bias.detach().double()
+    return w.float().cpu().numpy(), b.float().cpu().numpy()
+
+
+def supported(cin, widths, nsample):
+    """Can pn2_sa_mlp3_maxpool run this layer stack? (host-only check, needs the built library)"""
+    if len(widths) != 3 or cin < 3 or not (nsample == 16 or (nsample > 0 and nsample % 32 == 0)):
+        return False
+    return _C.lib().pn2_sa_mlp3_config(int(cin), int(widths[0]), int(widths[1]), int(widths[2]), None, None, None) == 0
+
+
+class PackedMLP3:
+    """Three folded layers in the kernel's LDS layout, resident on `device`."""
+
+    def __init__(self, layers, device):
+        require(len(layers) == 3, "pn2_sa_mlp3 takes exactly three layers")
+        ws = [np.ascontiguousarray(w, dtype=np.float32) for w, _ in layers]
+        bs = [np.ascontiguousarray(b, dtype=np.float32) for _, b in layers]
+        self.cin = ws[0].shape[0]
+        self.widths = tuple(int(w.shape[1]) for w in ws)
+        require(ws[1].shape[0] == self.widths[0] and ws[2].shape[0] == self.widths[1], "layer shapes do not chain")
+        lib = _C.lib()
+        wf, bf = ctypes.c_longlong(), ctypes.c_longlong()
+        _C.check(lib.pn2_sa_mlp3_config(self.cin, *self.widths, None, ctypes.byref(wf), ctypes.byref(bf)), "sa_mlp3_config")
+        wp = np.empty(wf.value, np.float32)
+        bp = np.empty(bf.value, np.float32)
+        _C.check(lib.pn2_sa_mlp3_pack(self.cin, *self.widths, ws[0].ctypes.data, bs[0].ctypes.data, ws[1].ctypes.data,
+                                      bs[1].ctypes.data, ws[2].ctypes.data, bs[2].ctypes.data, wp.ctypes.data,
+                                      bp.ctypes.data), "sa_mlp3_pack")
+        self.host = (wp, bp)
+        self.wp = torch.from_numpy(wp).to(device)
+        self.bp = torch.from_numpy(bp).to(device)
+
+
+def sa_mlp_maxpool(xyz, new_xyz, points, idx, packed):
+    """xyz (b,n,3), new_xyz (b,m,3), points (b,n,c) or None, idx (b,m,nsample) i32, packed: PackedMLP3
+    -> (b, m, c3) f32 = max over nsample of the three-layer MLP of [xyz[idx]-new_xyz, points[idx]]."""
+    xyz, new_xyz, idx = f32(xyz.detach(), "xyz"), f32(new_xyz.detach(), "new_xyz"), i32(idx, "idx")
+    b, n, _ = xyz.shape
+    m, ns = idx.shape[1], idx.shape[2]
+    cfeat = 0
+    if points is not None:
+        points = f32(points.detach(), "points")
+        cfeat = points.shape[2]
+    require(3 + cfeat == packed.cin, "packed MLP expects %d input channels, got %d" % (packed.cin, 3 + cfeat))
+    dev = same_device(xyz, new_xyz, idx, packed.wp) if points is None else same_device(xyz, new_xyz, idx, points, packed.wp)
+    out = torch.empty((b, m, packed.widths[2]), dtype=torch.float32, device=dev)
+    with on_device(dev):
+        _C.check(_C.lib().pn2_sa_mlp3_maxpool(b, n, m, ns, cfeat, ptr(xyz), ptr(new_xyz), ptr(points), ptr(idx),
+                                              packed.widths[0], packed.widths[1], packed.widths[2], ptr(packed.wp),
+                                              ptr(packed.bp), ptr(out), stream_ptr(dev)), "sa_mlp3_maxpool")
+    return out

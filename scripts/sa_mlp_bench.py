@@ -1,0 +1,79 @@
+"""Fused SA MLP + max-pool (pn2_sa_mlp3_maxpool) against the unfused PyTorch path, per reference
+configuration. Prints kernel time, useful TFLOP/s and the module-level
+forward time both ways. Development / measurement aid: python scripts/sa_mlp_bench.py [--json out]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import pointnet2_amd as P
+import pointnet2_amd.pointnet_util as U
+from pointnet2_amd import sa_mlp, synthetic as S
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+CONFIGS = [
+    # name, b, n, npoint, radius, nsample, cfeat, mlp
+    ("metric shape SA (B=32 N=4096->1024)", 32, 4096, 1024, 0.2, 32, 0, [64, 64, 128]),
+    ("cls_ssg SA1 (B=16 N=1024->512)", 16, 1024, 512, 0.2, 32, 0, [64, 64, 128]),
+    ("part_seg SA1 (B=32 N=2048->512, normals)", 32, 2048, 512, 0.2, 64, 3, [64, 64, 128]),
+    ("sem_seg SA1 (B=8 N=8192->1024)", 8, 8192, 1024, 0.1, 32, 0, [32, 32, 64]),
+    ("cls_msg SA1 scale 3 (B=16 N=1024->512 ns=128)", 16, 1024, 512, 0.4, 128, 0, [64, 96, 128]),
+]
+
+
+def main():
+    rows = []
+    for name, b, n, m, r, ns, cfeat, mlp in CONFIGS:
+        torch.manual_seed(1)
+        xyz = torch.from_numpy(S.sphere_clouds(b, n, 1)).to(dev)
+        pts = torch.randn(b, n, cfeat, device=dev) if cfeat else None
+        mod = U.PointnetSAModule(cfeat, m, r, ns, mlp).to(dev).eval()
+        cin = 3 + cfeat
+        flops = 2.0 * b * m * ns * (cin * mlp[0] + mlp[0] * mlp[1] + mlp[1] * mlp[2])
+        with torch.no_grad():
+            fps_idx, new_xyz, idx, _, _ = P.sample_and_group_xyz(m, r, ns, xyz, True)
+            packed = mod._packed(dev)
+            t_kernel = timeit(lambda: sa_mlp.sa_mlp_maxpool(xyz, new_xyz, pts, idx, packed))
+
+            def unfused_tail():
+                g = P.group_point(xyz, idx) - new_xyz[:, :, None, :]
+                if pts is not None:
+                    g = torch.cat([g, P.group_point(pts, idx)], dim=-1)
+                return mod.mlp(g.permute(0, 3, 1, 2)).max(dim=3)[0]
+            t_torch = timeit(unfused_tail)
+            mod.fused_mlp = True
+            t_mod_f = timeit(lambda: mod(xyz, pts), 10, 2)
+            mod.fused_mlp = False
+            t_mod_u = timeit(lambda: mod(xyz, pts), 10, 2)
+        row = {"config": name, "useful_gflop": flops / 1e9, "fused_kernel_us": t_kernel,
+               "fused_tflops": flops / t_kernel / 1e6, "frac_of_fp32_mfma_peak": flops / t_kernel / 1e6 / 157.3,
+               "torch_group_mlp_max_us": t_torch, "module_forward_fused_us": t_mod_f, "module_forward_unfused_us": t_mod_u}
+        rows.append(row)
+        print("%-50s kernel %7.1f us = %5.1f TFLOP/s (%4.1f%% of 157.3) | torch group+mlp+max %8.1f us (%.1fx) | "
+              "SA forward fused %8.1f us, unfused %8.1f us" % (name, t_kernel, row["fused_tflops"],
+              100 * row["frac_of_fp32_mfma_peak"], t_torch, t_torch / t_kernel, t_mod_f, t_mod_u), flush=True)
+    if "--json" in sys.argv:
+        with open(sys.argv[sys.argv.index("--json") + 1], "w") as f:
+            json.dump(rows, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
