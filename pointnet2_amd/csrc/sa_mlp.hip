@@ -25,6 +25,11 @@
 // of step v EXACTLY accumulator register v of the previous layer's tile u: the activations never move
 // between layers -- no LDS round trip, no shuffles. The weights are stored pre-permuted to match
 // (pn2_sa_mlp3_pack), in LDS, laid out so that one ds_read_b128 per lane feeds four MFMAs.
+// The LAST layer swaps the two MFMA operands (their lane maps are the same: index l & 31, k slot
+// l >> 5), which yields the untransposed H (samples x channels): a lane then holds 16 SAMPLES of one
+// channel, so the max-pool is 15 lane-local v_max plus one exchange with lane l ^ 32, and bias + ReLU
+// are applied once to the pooled value (x -> relu(x + b) is monotone, so max and it commute exactly).
+// Pooling across lanes instead (the first version) cost 5 cross-lane steps for each of 64 registers.
 #include "pn2_device.h"
 
 #include <math.h>
@@ -52,6 +57,14 @@ __device__ __forceinline__ f32x16 mlp_bias(const float *bp, int t, int h)
     return r;
 }
 
+// packed bias [t][h][v] holds channel 32t + mlp_chan(v, h); the inverse for one channel
+__device__ __forceinline__ float b3_at(const float *bp, int ch)
+{
+    const int t = ch >> 5, c = ch & 31;
+    const int hh = (c >> 2) & 1, v = 4 * (c >> 3) + (c & 3);
+    return bp[(t * 2 + hh) * 16 + v];
+}
+
 __device__ __forceinline__ f32x16 mlp_relu(f32x16 x)
 {
 #pragma unroll
@@ -64,7 +77,9 @@ __device__ __forceinline__ f32x16 mlp_relu(f32x16 x)
 // fence keeps the prefetch where it is written; left alone, hipcc hoists EVERY weight read of the layer
 // to its top and runs out of registers). `quartets` = leading register quartets of `in` that can be
 // non-zero (4, except for a narrow first layer). MAXACC: out[t] = max(out[t], result) unless `first`.
-template <int TOUT, int TIN, bool MAXACC>
+// LAST: operands swapped (see the header): out[t] holds raw sums H[sample][channel l & 31], no bias, no
+// ReLU, and is max-accumulated over the centroid's 32-sample groups.
+template <int TOUT, int TIN, bool LAST>
 __device__ __forceinline__ void mlp_layer(const float *wp, const float *bp, const f32x16 (&in)[TIN], f32x16 (&out)[TOUT],
                                           int lane, int h, int quartets, bool first)
 {
@@ -81,24 +96,39 @@ __device__ __forceinline__ void mlp_layer(const float *wp, const float *bp, cons
 #pragma unroll
             for (int q = 0; q < 4; ++q) nxt[q] = w4[(i + 1) * 256 + q * 64];
         }
-        if (u == 0) acc = mlp_bias(bp, t, h);
+        if (u == 0) {
+            if (LAST) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+            } else {
+                acc = mlp_bias(bp, t, h);
+            }
+        }
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (q < quartets) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].x, in[u][4 * q + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].y, in[u][4 * q + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].z, in[u][4 * q + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].w, in[u][4 * q + 3], acc, 0, 0, 0);
+                if (LAST) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(in[u][4 * q + 0], cur[q].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(in[u][4 * q + 1], cur[q].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(in[u][4 * q + 2], cur[q].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(in[u][4 * q + 3], cur[q].w, acc, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].x, in[u][4 * q + 0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].y, in[u][4 * q + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].z, in[u][4 * q + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].w, in[u][4 * q + 3], acc, 0, 0, 0);
+                }
             }
         }
         if (u == TIN - 1) {
-            const f32x16 r = mlp_relu(acc);
-            if (MAXACC && !first) {
-#pragma unroll
-                for (int v = 0; v < 16; ++v) out[t][v] = fmaxf(out[t][v], r[v]);
+            if (!LAST) {
+                out[t] = mlp_relu(acc);
+            } else if (first) {
+                out[t] = acc;
             } else {
-                out[t] = r;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) out[t][v] = fmaxf(out[t][v], acc[v]);
             }
         }
         if (i + 1 < TOUT * TIN) {
@@ -106,18 +136,6 @@ __device__ __forceinline__ void mlp_layer(const float *wp, const float *bp, cons
             for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
         }
     }
-}
-
-// max over the samples of one centroid: the SPAN lanes (16 or 32) of a lane half that share l >> log2(SPAN)
-template <int SPAN>
-__device__ __forceinline__ float mlp_span_max(float x)
-{
-    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true)));    // lane ^ 1
-    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true)));    // lane ^ 2
-    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xf, 0xf, true)));   // other quad of the half row
-    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, true)));   // other half row
-    if (SPAN == 32) x = fmaxf(x, __shfl_xor(x, 16));
-    return x;
 }
 
 // T1, T2, T3: output tiles (32 channels each) of the three layers; the input is one tile (Cin <= 32).
@@ -189,23 +207,28 @@ __global__ __launch_bounds__(kMlpThreads) void sa_mlp3_kernel(int n, int m, int 
             mlp_layer<T2, T1, false>(w2, b2, h1, h2, lane, h, 4, true);
             mlp_layer<T3, T2, true>(w3, b3, h2, best, lane, h, 4, part == 0);
         }
-        // column max over the centroid's samples, then lane 0 of each span writes 4 channels per store
+        // Pool: lane l holds channel 32t + (l & 31) for the samples 8(v >> 2) + 4(l >> 5) + (v & 3), v = 0..15
+        // (SPAN = 16: registers 0-7 are the first centroid's 16 samples, 8-15 the second's); bias and ReLU
+        // on the pooled value; one coalesced 128-byte store per tile and centroid.
 #pragma unroll
         for (int t = 0; t < T3; ++t) {
+            const int ch = 32 * t + s;
+            const float bias = b3_at(b3, ch);
+            if (SPAN == 32) {
+                float mx = best[t][0];
 #pragma unroll
-            for (int v = 0; v < 16; ++v) best[t][v] = mlp_span_max<SPAN>(best[t][v]);
-            if ((s & (SPAN - 1)) == 0 && row_ok) {
+                for (int v = 1; v < 16; ++v) mx = fmaxf(mx, best[t][v]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                if (h == 0 && ch < c3) out[row * c3 + ch] = fmaxf(__fadd_rn(mx, bias), 0.0f);
+            } else {
+                float m0 = best[t][0], m1 = best[t][8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int ch = 32 * t + mlp_chan(4 * q, h);
-                    float *o = out + row * c3 + ch;
-                    if (ch + 3 < c3 && (c3 & 3) == 0) {
-                        *reinterpret_cast<float4 *>(o) = make_float4(best[t][4 * q], best[t][4 * q + 1], best[t][4 * q + 2], best[t][4 * q + 3]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (ch + r < c3) o[r] = best[t][4 * q + r];
-                    }
+                for (int v = 1; v < 8; ++v) { m0 = fmaxf(m0, best[t][v]); m1 = fmaxf(m1, best[t][8 + v]); }
+                m0 = fmaxf(m0, __shfl_xor(m0, 32));
+                m1 = fmaxf(m1, __shfl_xor(m1, 32));
+                if (h == 0 && ch < c3) {
+                    out[(2 * g) * c3 + ch] = fmaxf(__fadd_rn(m0, bias), 0.0f);
+                    if (2 * g + 1 < rows) out[(2 * g + 1) * c3 + ch] = fmaxf(__fadd_rn(m1, bias), 0.0f);
                 }
             }
         }

@@ -29,18 +29,20 @@ def _mfma(a, b, acc):
     return out
 
 
-def _emulate_layer(wp, bp, t_out, t_in, acts):
-    """acts: list of t_in arrays (64 lanes, 16 regs) -> list of t_out arrays, exactly as mlp_layer walks them."""
+def _emulate_layer(wp, bp, t_out, t_in, acts, last=False):
+    """acts: list of t_in arrays (64 lanes, 16 regs) -> list of t_out arrays, exactly as mlp_layer walks them.
+    last: the kernel swaps the MFMA operands and starts from zero (bias + ReLU come after the pooling)."""
     wp = wp.reshape(t_out, t_in, 4, 64, 4)
     bp = bp.reshape(t_out, 2, 16)
     outs = []
     for t in range(t_out):
-        acc = np.stack([bp[t, l >> 5] for l in range(64)]).astype(np.float64)
+        acc = np.zeros((64, 16)) if last else np.stack([bp[t, l >> 5] for l in range(64)]).astype(np.float64)
         for u in range(t_in):
             for q in range(4):
                 for r in range(4):
-                    acc = _mfma(wp[t, u, q, :, r], acts[u][:, 4 * q + r], acc)
-        outs.append(np.maximum(acc, 0.0))
+                    w, x = wp[t, u, q, :, r], acts[u][:, 4 * q + r]
+                    acc = _mfma(x, w, acc) if last else _mfma(w, x, acc)
+        outs.append(acc if last else np.maximum(acc, 0.0))
     return outs
 
 
@@ -73,15 +75,20 @@ def test_pack_matches_emulated_dataflow(cin, widths):
     ob = np.cumsum([0] + sizes_b)
     acts = [x0]
     for L, (to, ti) in enumerate([(t1, 1), (t2, t1), (t3, t2)]):
-        acts = _emulate_layer(wp[ow[L]:ow[L + 1]], bp[ob[L]:ob[L + 1]], to, ti, acts)
-    # decode the final registers back to (sample, channel)
+        acts = _emulate_layer(wp[ow[L]:ow[L + 1]], bp[ob[L]:ob[L + 1]], to, ti, acts, last=(L == 2))
+    # the last layer's registers: lane l holds channel 32t + (l & 31) of sample 8(v >> 2) + 4(l >> 5) + (v & 3);
+    # the bias comes from the packed array through the kernel's inverse map (b3_at)
+    b3 = bp[ob[2]:ob[3]].reshape(t3, 2, 16)
     got = np.zeros((32, widths[2]))
     for t in range(t3):
         for l in range(64):
+            ch = 32 * t + (l & 31)
+            if ch >= widths[2]:
+                continue
+            c = ch & 31
+            bias = b3[t, (c >> 2) & 1, 4 * (c >> 3) + (c & 3)]
             for v in range(16):
-                ch = 32 * t + _chan(v, l >> 5)
-                if ch < widths[2]:
-                    got[l & 31, ch] = acts[t][l, v]
+                got[8 * (v >> 2) + 4 * (l >> 5) + (v & 3), ch] = max(acts[t][l, v] + bias, 0.0)
     want = x.astype(np.float64)
     for w, b in zip(ws, bs):
         want = np.maximum(want @ w.astype(np.float64) + b, 0.0)
