@@ -175,38 +175,57 @@ __global__ __launch_bounds__(kMlpThreads) void sa_mlp3_kernel(int n, int m, int 
     const long long nwaves = (long long)gridDim.x * (kMlpThreads / 64);
     const long long groups = SPAN == 32 ? rows : (rows + 1) / 2;
 
-    for (long long g = wave; g < groups; g += nwaves) {
-        // the centroid (row of the (b*m) table) this lane's sample belongs to
-        const long long row_raw = SPAN == 32 ? g : g * 2 + (s >> 4);
-        const bool row_ok = row_raw < rows;
-        const long long row = row_ok ? row_raw : rows - 1;          // an odd tail at nsample = 16 recomputes the last row
-        const long long cloud = row / m;
-        const float cx = new_xyz[row * 3 + 0], cy = new_xyz[row * 3 + 1], cz = new_xyz[row * 3 + 2];
-        f32x16 best[T3];
-        for (int part = 0; part < parts; ++part) {
-            const int sample = SPAN == 32 ? part * 32 + s : (s & 15);
-            const int p = idx[row * nsample + sample];
-            const float *px = xyz + ((size_t)cloud * n + p) * 3;
-            const float *pf = points ? points + ((size_t)cloud * n + p) * cfeat : nullptr;
-            // layer-1 operand: register v <- input channel mlp_chan(v, h) of this lane's sample
-            f32x16 x0;
+    // The gather is software-pipelined over the work items (a 32-sample group of a centroid): the index
+    // of item i + 1 is fetched when item i starts, its coordinates/features after item i's second layer
+    // (the index has arrived by then), so both dependent global round trips hide under MFMA work.
+    auto item_row = [&](long long g) -> long long {
+        const long long r = SPAN == 32 ? g : g * 2 + (s >> 4);
+        return r < rows ? r : rows - 1;                          // an odd tail at nsample = 16 recomputes the last row
+    };
+    auto load_index = [&](long long g, int part) -> int {
+        const int sample = SPAN == 32 ? part * 32 + s : (s & 15);
+        return idx[item_row(g) * nsample + sample];
+    };
+    // layer-1 operand: register v <- input channel mlp_chan(v, h) of this lane's sample
+    auto load_x0 = [&](long long g, int p) -> f32x16 {
+        const long long row = item_row(g), cloud = row / m;
+        const float *px = xyz + ((size_t)cloud * n + p) * 3;
+        const float *pf = points ? points + ((size_t)cloud * n + p) * cfeat : nullptr;
+        const float *c = new_xyz + row * 3;
+        f32x16 x0;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int k = mlp_chan(v, h);
-                float val = 0.0f;
-                if ((v >> 2) < quartets1) {
-                    if (k == 0) val = __fsub_rn(px[0], cx);
-                    else if (k == 1) val = __fsub_rn(px[1], cy);
-                    else if (k == 2) val = __fsub_rn(px[2], cz);
-                    else if (k < cin) val = pf[k - 3];
-                }
-                x0[v] = val;
+        for (int v = 0; v < 16; ++v) {
+            const int k = mlp_chan(v, h);
+            float val = 0.0f;
+            if ((v >> 2) < quartets1) {
+                if (k < 3) val = __fsub_rn(px[k], c[k]);
+                else if (k < cin) val = pf[k - 3];
             }
-            f32x16 in0[1] = {x0}, h1[T1], h2[T2];
-            mlp_layer<T1, 1, false>(w1, b1, in0, h1, lane, h, quartets1, true);
-            mlp_layer<T2, T1, false>(w2, b2, h1, h2, lane, h, 4, true);
-            mlp_layer<T3, T2, true>(w3, b3, h2, best, lane, h, 4, part == 0);
+            x0[v] = val;
         }
+        return x0;
+    };
+
+    long long g = wave;
+    int part = 0;
+    f32x16 x0;
+    if (g < groups) x0 = load_x0(g, load_index(g, 0));
+    f32x16 best[T3];
+    while (g < groups) {
+        // the item after this one
+        const bool last_part = part + 1 == parts;
+        const long long gn = last_part ? g + nwaves : g;
+        const int partn = last_part ? 0 : part + 1;
+        const bool more = gn < groups;
+        int pn = 0;
+        if (more) pn = load_index(gn, partn);
+        f32x16 in0[1] = {x0}, h1[T1], h2[T2];
+        mlp_layer<T1, 1, false>(w1, b1, in0, h1, lane, h, quartets1, true);
+        mlp_layer<T2, T1, false>(w2, b2, h1, h2, lane, h, 4, true);
+        if (more) x0 = load_x0(gn, pn);
+        mlp_layer<T3, T2, true>(w3, b3, h2, best, lane, h, 4, part == 0);
+        if (!last_part) { part = partn; continue; }
+        const long long row = item_row(g);
         // Pool: lane l holds channel 32t + (l & 31) for the samples 8(v >> 2) + 4(l >> 5) + (v & 3), v = 0..15
         // (SPAN = 16: registers 0-7 are the first centroid's 16 samples, 8-15 the second's); bias and ReLU
         // on the pooled value; one coalesced 128-byte store per tile and centroid.
@@ -232,6 +251,8 @@ __global__ __launch_bounds__(kMlpThreads) void sa_mlp3_kernel(int n, int m, int 
                 }
             }
         }
+        g = gn;
+        part = 0;
     }
 }
 
