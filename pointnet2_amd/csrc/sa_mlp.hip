@@ -33,6 +33,7 @@
 #include "pn2_device.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace pn2 {
@@ -186,8 +187,10 @@ __global__ __launch_bounds__(kMlpThreads) void sa_mlp3_kernel(int n, int m, int 
         const int sample = SPAN == 32 ? part * 32 + s : (s & 15);
         return idx[item_row(g) * nsample + sample];
     };
-    // layer-1 operand: register v <- input channel mlp_chan(v, h) of this lane's sample
-    auto load_x0 = [&](long long g, int p) -> f32x16 {
+    // layer-1 operand: register v <- input channel mlp_chan(v, h) of this lane's sample. The loads only
+    // (raw coordinates; `cen` = the centroid coordinate to subtract, 0 for feature channels): the
+    // subtraction is done when the operand is consumed, one item later, so no wait sits in the MFMA stream
+    auto load_x0 = [&](long long g, int p, f32x16 &cen) -> f32x16 {
         const long long row = item_row(g), cloud = row / m;
         const float *px = xyz + ((size_t)cloud * n + p) * 3;
         const float *pf = points ? points + ((size_t)cloud * n + p) * cfeat : nullptr;
@@ -196,20 +199,21 @@ __global__ __launch_bounds__(kMlpThreads) void sa_mlp3_kernel(int n, int m, int 
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int k = mlp_chan(v, h);
-            float val = 0.0f;
+            float val = 0.0f, sub = 0.0f;
             if ((v >> 2) < quartets1) {
-                if (k < 3) val = __fsub_rn(px[k], c[k]);
+                if (k < 3) { val = px[k]; sub = c[k]; }
                 else if (k < cin) val = pf[k - 3];
             }
             x0[v] = val;
+            cen[v] = sub;
         }
         return x0;
     };
 
     long long g = wave;
     int part = 0;
-    f32x16 x0;
-    if (g < groups) x0 = load_x0(g, load_index(g, 0));
+    f32x16 x0, cen;
+    if (g < groups) x0 = load_x0(g, load_index(g, 0), cen);
     f32x16 best[T3];
     while (g < groups) {
         // the item after this one
@@ -219,10 +223,14 @@ __global__ __launch_bounds__(kMlpThreads) void sa_mlp3_kernel(int n, int m, int 
         const bool more = gn < groups;
         int pn = 0;
         if (more) pn = load_index(gn, partn);
-        f32x16 in0[1] = {x0}, h1[T1], h2[T2];
+        f32x16 in0[1], h1[T1], h2[T2];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) in0[0][v] = __fsub_rn(x0[v], cen[v]);      // channels 0-2 live in registers 0-2 of lanes 0-31
+#pragma unroll
+        for (int v = 4; v < 16; ++v) in0[0][v] = x0[v];
         mlp_layer<T1, 1, false>(w1, b1, in0, h1, lane, h, quartets1, true);
         mlp_layer<T2, T1, false>(w2, b2, h1, h2, lane, h, 4, true);
-        if (more) x0 = load_x0(gn, pn);
+        if (more) x0 = load_x0(gn, pn, cen);
         mlp_layer<T3, T2, true>(w3, b3, h2, best, lane, h, 4, part == 0);
         if (!last_part) { part = partn; continue; }
         const long long row = item_row(g);
@@ -282,7 +290,9 @@ static int launch_mlp(int b, int n, int m, int nsample, int cfeat, int c3, const
     const bool half = nsample == 16;
     const long long groups = half ? (rows + 1) / 2 : rows;
     long long blocks = (groups + 3) / 4;
-    if (blocks > 512) blocks = 512;                       // persistent: every workgroup stages the weights once
+    long long cap = 512;                                  // persistent: every workgroup stages the weights once
+    if (const char *e = getenv("PN2_MLP_BLOCKS")) cap = atoll(e);   // tuning hook
+    if (blocks > cap) blocks = cap;
     auto kern = half ? sa_mlp3_kernel<T1, T2, T3, 16> : sa_mlp3_kernel<T1, T2, T3, 32>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
