@@ -123,14 +123,19 @@ int pn2_three_interpolate_grad_det(int b, int n, int c, int m, const float *grad
  *  over nsample). fp32 in, fp32 MFMA, fp32 out.
  *   xyz (b,n,3), new_xyz (b,m,3), points (b,n,cfeat) or NULL when cfeat == 0, idx (b,m,nsample) i32
  *   -> out (b,m,c3).  Input channel order is the reference's: [relative xyz (3), features (cfeat)].
- * Limits (PN2_E_TOO_LARGE outside; callers keep the unfused path): 3 + cfeat <= 32, widths within
- * (128,128,128) / (64,96,128) / (64,64,128) / (32,32,64), nsample == 16 or a multiple of 32.
+ * Two kernels behind one entry: weights resident in LDS (3 + cfeat <= 32, widths within (128,128,128);
+ * nsample 16 or a multiple of 32) or streamed through LDS (up to 384 input channels, widths within
+ * (128,128,256); nsample a multiple of 32). PN2_E_TOO_LARGE outside: callers keep the unfused path.
  * Weights: w_i (cin_i, cout_i) row-major = the reference's conv kernel [1,1,cin,cout] (tf_util.py:113-117)
- * with batch norm folded in by the caller; pn2_sa_mlp3_pack (host code) permutes them into the layout the
- * kernel keeps in LDS: wpacked / bpacked of the sizes pn2_sa_mlp3_config reports, uploaded by the caller. */
-int pn2_sa_mlp3_config(int cin, int c1, int c2, int c3, int *tiles3, long long *w_floats, long long *b_floats);
-int pn2_sa_mlp3_pack(int cin, int c1, int c2, int c3, const float *w1, const float *bias1, const float *w2,
-                     const float *bias2, const float *w3, const float *bias3, float *wpacked, float *bpacked);
+ * with batch norm folded in by the caller; xyz_first says whether the rows of w1 are [xyz, features]
+ * (pointnet_util.py:50) or [features, xyz] (:184, MSG). pn2_sa_mlp3_pack (host code) permutes them into the
+ * order the kernel consumes: wpacked / bpacked of the sizes pn2_sa_mlp3_config reports (info4 = {kind:
+ * 0 resident / 1 streamed, output tiles of the three layers}), uploaded by the caller. */
+int pn2_sa_mlp3_config(int cin, int c1, int c2, int c3, int nsample, int *info4, long long *w_floats,
+                       long long *b_floats);
+int pn2_sa_mlp3_pack(int cin, int c1, int c2, int c3, int nsample, int xyz_first, const float *w1, const float *bias1,
+                     const float *w2, const float *bias2, const float *w3, const float *bias3, float *wpacked,
+                     float *bpacked);
 int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, const float *xyz, const float *new_xyz,
                         const float *points, const int *idx, int c1, int c2, int c3, const float *wpacked,
                         const float *bpacked, float *out, void *stream);

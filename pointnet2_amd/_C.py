@@ -43,8 +43,8 @@ _SIGNATURES = {
     "pn2_gather_point_grad_det": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pn2_group_point_grad_det": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pn2_three_interpolate_grad_det": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
-    "pn2_sa_mlp3_config": [_i, _i, _i, _i, _vp, _vp, _vp],
-    "pn2_sa_mlp3_pack": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pn2_sa_mlp3_config": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "pn2_sa_mlp3_pack": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pn2_sa_mlp3_maxpool": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pn2_query_ball_group_xyz": [_i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "pn2_sample_and_group_xyz": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],

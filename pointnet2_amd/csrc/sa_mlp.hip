@@ -30,48 +30,12 @@
 // channel, so the max-pool is 15 lane-local v_max plus one exchange with lane l ^ 32, and bias + ReLU
 // are applied once to the pooled value (x -> relu(x + b) is monotone, so max and it commute exactly).
 // Pooling across lanes instead (the first version) cost 5 cross-lane steps for each of 64 registers.
-#include "pn2_device.h"
+#include "sa_mlp_common.h"
 
-#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
 namespace pn2 {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kMlpThreads = 256;          // 4 waves: one per SIMD; a second workgroup shares the CU when registers allow
-constexpr int kMlpMaxLds = 150 * 1024;
-
-// channel (within a 32-tile) that register v of lane-half h holds / must be fed with
-__host__ __device__ __forceinline__ int mlp_chan(int v, int h) { return 8 * (v >> 2) + 4 * h + (v & 3); }
-
-// packed sizes (floats): weights [t][u][q = 4][lane = 64][r = 4] per layer, bias [t][h = 2][v = 16]
-__host__ __device__ __forceinline__ size_t mlp_w_floats(int t_out, int t_in) { return (size_t)t_out * t_in * 1024; }
-__host__ __device__ __forceinline__ size_t mlp_b_floats(int t_out) { return (size_t)t_out * 32; }
-
-__device__ __forceinline__ f32x16 mlp_bias(const float *bp, int t, int h)
-{
-    const float4 *p = reinterpret_cast<const float4 *>(bp + (t * 2 + h) * 16);
-    const float4 a = p[0], b = p[1], c = p[2], d = p[3];
-    f32x16 r = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-    return r;
-}
-
-// packed bias [t][h][v] holds channel 32t + mlp_chan(v, h); the inverse for one channel
-__device__ __forceinline__ float b3_at(const float *bp, int ch)
-{
-    const int t = ch >> 5, c = ch & 31;
-    const int hh = (c >> 2) & 1, v = 4 * (c >> 3) + (c & 3);
-    return bp[(t * 2 + hh) * 16 + v];
-}
-
-__device__ __forceinline__ f32x16 mlp_relu(f32x16 x)
-{
-#pragma unroll
-    for (int v = 0; v < 16; ++v) x[v] = fmaxf(x[v], 0.0f);
-    return x;
-}
 
 // One dense layer on the wave's 32 samples: out[t] = relu(bias + sum_u W^T[t][u] . in[u]), 16 MFMAs per
 // (t, u) pair. The weights of pair i + 1 are read from LDS while the MFMAs of pair i run (the compiler
@@ -303,28 +267,62 @@ static int launch_mlp(int b, int n, int m, int nsample, int cfeat, int c3, const
 
 }  // namespace pn2
 
-extern "C" int pn2_sa_mlp3_config(int cin, int c1, int c2, int c3, int *tiles, long long *w_floats, long long *b_floats)
+using namespace pn2;
+
+// Which kernel runs a stack: the resident one when the input is narrow and the weights fit in LDS,
+// else the streamed one (sa_mlp_stream.hip). kind: 0 resident, 1 streamed.
+static bool mlp_choose(int cin, int c1, int c2, int c3, int nsample, int &kind, MlpConfig &rc, MlpStreamConfig &sc)
+{
+    if (cin <= 32 && mlp_pick(c1, c2, c3, rc) && sizeof(float) * (mlp_total_w(rc) + mlp_total_b(rc)) <= (size_t)kMlpMaxLds) {
+        kind = 0;
+        return true;
+    }
+    if (nsample != 16 && mlp_stream_pick(cin, c1, c2, c3, sc)) {
+        kind = 1;
+        return true;
+    }
+    return false;
+}
+
+extern "C" int pn2_sa_mlp3_config(int cin, int c1, int c2, int c3, int nsample, int *info4, long long *w_floats,
+                                  long long *b_floats)
 {
     using namespace pn2;
     if (cin < 3 || c1 <= 0 || c2 <= 0 || c3 <= 0) return PN2_E_ARG;
-    MlpConfig cfg;
-    if (cin > 32 || !mlp_pick(c1, c2, c3, cfg)) return PN2_E_TOO_LARGE;
-    if (tiles) { tiles[0] = cfg.t1; tiles[1] = cfg.t2; tiles[2] = cfg.t3; }
-    if (w_floats) *w_floats = (long long)mlp_total_w(cfg);
-    if (b_floats) *b_floats = (long long)mlp_total_b(cfg);
+    if (nsample != 16 && (nsample <= 0 || nsample % 32 != 0)) return PN2_E_ARG;
+    int kind;
+    MlpConfig rc;
+    MlpStreamConfig sc;
+    if (!mlp_choose(cin, c1, c2, c3, nsample, kind, rc, sc)) return PN2_E_TOO_LARGE;
+    if (info4) {
+        info4[0] = kind;
+        info4[1] = kind ? sc.t1 : rc.t1; info4[2] = kind ? sc.t2 : rc.t2; info4[3] = kind ? sc.t3 : rc.t3;
+    }
+    if (w_floats) *w_floats = (long long)(kind ? mlp_stream_w_floats(sc) : mlp_total_w(rc));
+    if (b_floats) *b_floats = (long long)(kind ? mlp_stream_b_floats(sc) : mlp_total_b(rc));
     return PN2_OK;
 }
 
 // Host-side packing (plain C loops, no device work): w_i is (cin_i, cout_i) row-major -- the layout of
 // the reference's conv kernel [1,1,cin,cout] (tf_util.py:113-117) -- with batch norm already folded in.
-extern "C" int pn2_sa_mlp3_pack(int cin, int c1, int c2, int c3, const float *w1, const float *bias1, const float *w2,
-                                const float *bias2, const float *w3, const float *bias3, float *wpacked, float *bpacked)
+// xyz_first: rows of w1 are [xyz (3), features] (pointnet_util.py:50, single-scale modules) or
+// [features, xyz (3)] (:184, the MSG module).
+extern "C" int pn2_sa_mlp3_pack(int cin, int c1, int c2, int c3, int nsample, int xyz_first, const float *w1,
+                                const float *bias1, const float *w2, const float *bias2, const float *w3,
+                                const float *bias3, float *wpacked, float *bpacked)
 {
     using namespace pn2;
+    int kind;
     MlpConfig cfg;
-    if (cin < 3 || cin > 32 || c1 <= 0 || c2 <= 0 || c3 <= 0 || !mlp_pick(c1, c2, c3, cfg)) return PN2_E_TOO_LARGE;
+    MlpStreamConfig sc;
+    if (cin < 3 || c1 <= 0 || c2 <= 0 || c3 <= 0 || !mlp_choose(cin, c1, c2, c3, nsample, kind, cfg, sc)) return PN2_E_TOO_LARGE;
     if (!w1 || !w2 || !w3 || !bias1 || !bias2 || !bias3 || !wpacked || !bpacked) return PN2_E_NULL;
     const float *ws[3] = {w1, w2, w3}, *bs[3] = {bias1, bias2, bias3};
+    if (kind == 1) {
+        mlp_stream_pack(sc, cin, c1, c2, c3, xyz_first, ws, bs, wpacked, bpacked);
+        return PN2_OK;
+    }
+    const int cfeat = cin - 3;
     const int kin[3] = {cin, c1, c2}, nout[3] = {c1, c2, c3};
     const int tin[3] = {1, cfg.t1, cfg.t2}, tout[3] = {cfg.t1, cfg.t2, cfg.t3};
     float *wp = wpacked, *bp = bpacked;
@@ -335,7 +333,10 @@ extern "C" int pn2_sa_mlp3_pack(int cin, int c1, int c2, int c3, const float *w1
                     for (int lane = 0; lane < 64; ++lane)
                         for (int r = 0; r < 4; ++r) {
                             const int k = 32 * u + mlp_chan(4 * q + r, lane >> 5), nn = 32 * t + (lane & 31);
-                            *wp++ = (k < kin[L] && nn < nout[L]) ? ws[L][(size_t)k * nout[L] + nn] : 0.0f;
+                            // kernel channel order of layer 1: [xyz, features]
+                            int row = k;
+                            if (L == 0 && !xyz_first && k < cin) row = k < 3 ? cfeat + k : k - 3;
+                            *wp++ = (k < kin[L] && nn < nout[L]) ? ws[L][(size_t)row * nout[L] + nn] : 0.0f;
                         }
         for (int t = 0; t < tout[L]; ++t)
             for (int hh = 0; hh < 2; ++hh)
@@ -356,10 +357,14 @@ extern "C" int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, 
     if (nsample != 16 && (nsample <= 0 || nsample % 32 != 0)) return PN2_E_ARG;
     if (b == 0 || m == 0) return PN2_OK;
     if (!xyz || !new_xyz || !idx || !wpacked || !bpacked || !out || (cfeat > 0 && !points)) return PN2_E_NULL;
+    int kind;
     MlpConfig cfg;
-    if (3 + cfeat > 32 || !mlp_pick(c1, c2, c3, cfg)) return PN2_E_TOO_LARGE;
+    MlpStreamConfig sc;
+    if (!mlp_choose(3 + cfeat, c1, c2, c3, nsample, kind, cfg, sc)) return PN2_E_TOO_LARGE;
     hipStream_t st = as_stream(stream);
     const float *pts = cfeat > 0 ? points : nullptr;
+    if (kind == 1)
+        return mlp_stream_launch(sc, b, n, m, nsample, cfeat, c3, xyz, new_xyz, pts ? pts : xyz, idx, wpacked, bpacked, out, st);
 #define PN2_MLP_CASE(A, B, C) \
     if (cfg.t1 == A && cfg.t2 == B && cfg.t3 == C) \
         return launch_mlp<A, B, C>(b, n, m, nsample, cfeat, c3, xyz, new_xyz, pts, idx, wpacked, bpacked, out, st)

@@ -1,0 +1,59 @@
+// sa_mlp_common.h -- helpers shared by the two fused-MLP kernels (sa_mlp.hip: weights resident in LDS;
+// sa_mlp_stream.hip: weights streamed through LDS). See sa_mlp.hip for the formulation.
+#pragma once
+#include "pn2_device.h"
+
+#include <math.h>
+
+namespace pn2 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMlpThreads = 256;          // 4 waves: one per SIMD; a second workgroup shares the CU when registers allow
+constexpr int kMlpMaxLds = 150 * 1024;
+
+// channel (within a 32-tile) that register v of lane-half h holds / must be fed with
+__host__ __device__ __forceinline__ int mlp_chan(int v, int h) { return 8 * (v >> 2) + 4 * h + (v & 3); }
+
+// packed sizes (floats): weights [t][u][q = 4][lane = 64][r = 4] per layer, bias [t][h = 2][v = 16]
+__host__ __device__ __forceinline__ size_t mlp_w_floats(int t_out, int t_in) { return (size_t)t_out * t_in * 1024; }
+__host__ __device__ __forceinline__ size_t mlp_b_floats(int t_out) { return (size_t)t_out * 32; }
+
+__device__ __forceinline__ f32x16 mlp_bias(const float *bp, int t, int h)
+{
+    const float4 *p = reinterpret_cast<const float4 *>(bp + (t * 2 + h) * 16);
+    const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+    f32x16 r = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    return r;
+}
+
+// packed bias [t][h][v] holds channel 32t + mlp_chan(v, h); the inverse for one channel
+__device__ __forceinline__ float b3_at(const float *bp, int ch)
+{
+    const int t = ch >> 5, c = ch & 31;
+    const int hh = (c >> 2) & 1, v = 4 * (c >> 3) + (c & 3);
+    return bp[(t * 2 + hh) * 16 + v];
+}
+
+__device__ __forceinline__ f32x16 mlp_relu(f32x16 x)
+{
+#pragma unroll
+    for (int v = 0; v < 16; ++v) x[v] = fmaxf(x[v], 0.0f);
+    return x;
+}
+
+
+// ---- streamed variant (sa_mlp_stream.hip) ------------------------------------------------------------
+constexpr int kMlpStagePairs = 4;          // 32x32 weight tile pairs per LDS stage (16 KiB)
+
+struct MlpStreamConfig { int ti, t1, t2, t3; };
+bool mlp_stream_pick(int cin, int c1, int c2, int c3, MlpStreamConfig &cfg);
+size_t mlp_stream_w_floats(const MlpStreamConfig &c);
+size_t mlp_stream_b_floats(const MlpStreamConfig &c);
+void mlp_stream_pack(const MlpStreamConfig &c, int cin, int c1, int c2, int c3, int xyz_first, const float *const *ws,
+                     const float *const *bs, float *wpacked, float *bpacked);
+int mlp_stream_launch(const MlpStreamConfig &c, int b, int n, int m, int nsample, int cfeat, int c3, const float *xyz,
+                      const float *new_xyz, const float *points, const int *idx, const float *wp, const float *bp,
+                      float *out, hipStream_t st);
+
+}  // namespace pn2

@@ -146,7 +146,7 @@ class PointnetSAModule(nn.Module):
         """Folded + packed weights, rebuilt when a parameter or a running statistic changed."""
         stamp = tuple((t.data_ptr(), t._version) for t in list(self.mlp.parameters()) + list(self.mlp.buffers()))
         if self._pack_cache is None or self._pack_cache[0] != (stamp, device):
-            self._pack_cache = ((stamp, device), sa_mlp.PackedMLP3(self.mlp.folded_layers(), device))
+            self._pack_cache = ((stamp, device), sa_mlp.PackedMLP3(self.mlp.folded_layers(), device, self.nsample, True))
         return self._pack_cache[1]
 
     def forward(self, xyz, points):

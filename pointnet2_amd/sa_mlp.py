@@ -30,13 +30,17 @@ def supported(cin, widths, nsample):
     """Can pn2_sa_mlp3_maxpool run this layer stack? (host-only check, needs the built library)"""
     if len(widths) != 3 or cin < 3 or not (nsample == 16 or (nsample > 0 and nsample % 32 == 0)):
         return False
-    return _C.lib().pn2_sa_mlp3_config(int(cin), int(widths[0]), int(widths[1]), int(widths[2]), None, None, None) == 0
+    return _C.lib().pn2_sa_mlp3_config(int(cin), int(widths[0]), int(widths[1]), int(widths[2]), int(nsample), None, None,
+                                       None) == 0
 
 
 class PackedMLP3:
-    """Three folded layers in the kernel's LDS layout, resident on `device`."""
+    """Three folded layers in the order the kernel consumes them, resident on `device`. The layout depends
+    on the kernel that will run (weights resident in LDS or streamed), which depends on nsample too.
+    xyz_first: rows of the first layer's weight are [xyz, features] (single-scale modules) or
+    [features, xyz] (the MSG module, pointnet_util.py:184)."""
 
-    def __init__(self, layers, device):
+    def __init__(self, layers, device, nsample=32, xyz_first=True):
         require(len(layers) == 3, "pn2_sa_mlp3 takes exactly three layers")
         ws = [np.ascontiguousarray(w, dtype=np.float32) for w, _ in layers]
         bs = [np.ascontiguousarray(b, dtype=np.float32) for _, b in layers]
@@ -44,16 +48,28 @@ class PackedMLP3:
         self.widths = tuple(int(w.shape[1]) for w in ws)
         require(ws[1].shape[0] == self.widths[0] and ws[2].shape[0] == self.widths[1], "layer shapes do not chain")
         lib = _C.lib()
+        self.nsample = int(nsample)
         wf, bf = ctypes.c_longlong(), ctypes.c_longlong()
-        _C.check(lib.pn2_sa_mlp3_config(self.cin, *self.widths, None, ctypes.byref(wf), ctypes.byref(bf)), "sa_mlp3_config")
+        info = (ctypes.c_int * 4)()
+        _C.check(lib.pn2_sa_mlp3_config(self.cin, *self.widths, self.nsample, info, ctypes.byref(wf), ctypes.byref(bf)),
+                 "sa_mlp3_config")
+        self.kind = "streamed" if info[0] else "resident"
         wp = np.empty(wf.value, np.float32)
         bp = np.empty(bf.value, np.float32)
-        _C.check(lib.pn2_sa_mlp3_pack(self.cin, *self.widths, ws[0].ctypes.data, bs[0].ctypes.data, ws[1].ctypes.data,
-                                      bs[1].ctypes.data, ws[2].ctypes.data, bs[2].ctypes.data, wp.ctypes.data,
-                                      bp.ctypes.data), "sa_mlp3_pack")
+        _C.check(lib.pn2_sa_mlp3_pack(self.cin, *self.widths, self.nsample, 1 if xyz_first else 0, ws[0].ctypes.data,
+                                      bs[0].ctypes.data, ws[1].ctypes.data, bs[1].ctypes.data, ws[2].ctypes.data,
+                                      bs[2].ctypes.data, wp.ctypes.data, bp.ctypes.data), "sa_mlp3_pack")
         self.host = (wp, bp)
         self.wp = torch.from_numpy(wp).to(device)
         self.bp = torch.from_numpy(bp).to(device)
+
+
+def _same_kernel(packed, ns):
+    """Would pn2_sa_mlp3_config choose the same kernel (hence the same packed layout) for this nsample?"""
+    info = (ctypes.c_int * 4)()
+    if _C.lib().pn2_sa_mlp3_config(packed.cin, *packed.widths, int(ns), info, None, None) != 0:
+        return False
+    return ("streamed" if info[0] else "resident") == packed.kind
 
 
 def sa_mlp_maxpool(xyz, new_xyz, points, idx, packed):
@@ -67,6 +83,9 @@ def sa_mlp_maxpool(xyz, new_xyz, points, idx, packed):
         points = f32(points.detach(), "points")
         cfeat = points.shape[2]
     require(3 + cfeat == packed.cin, "packed MLP expects %d input channels, got %d" % (packed.cin, 3 + cfeat))
+    require(ns == packed.nsample or (ns != 16 and packed.nsample != 16 and packed.kind == "streamed") or
+            (packed.kind == "resident" and _same_kernel(packed, ns)),
+            "packed for nsample=%d, called with %d" % (packed.nsample, ns))
     dev = same_device(xyz, new_xyz, idx, packed.wp) if points is None else same_device(xyz, new_xyz, idx, points, packed.wp)
     out = torch.empty((b, m, packed.widths[2]), dtype=torch.float32, device=dev)
     with on_device(dev):

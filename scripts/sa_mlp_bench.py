@@ -36,6 +36,12 @@ CONFIGS = [
     ("part_seg SA1 (B=32 N=2048->512, normals)", 32, 2048, 512, 0.2, 64, 3, [64, 64, 128]),
     ("sem_seg SA1 (B=8 N=8192->1024)", 8, 8192, 1024, 0.1, 32, 0, [32, 32, 64]),
     ("cls_msg SA1 scale 3 (B=16 N=1024->512 ns=128)", 16, 1024, 512, 0.4, 128, 0, [64, 96, 128]),
+    # wide inputs / SA2-SA3-sized stacks: the streamed-weights kernel
+    ("cls_ssg SA2 (B=16 N=512->128 ns=64 C=128)", 16, 512, 128, 0.4, 64, 128, [128, 128, 256]),
+    ("part_seg SA2 (B=32 N=512->128 ns=64 C=128)", 32, 512, 128, 0.4, 64, 128, [128, 128, 256]),
+    ("sem_seg SA2 (B=8 N=1024->256 ns=32 C=64)", 8, 1024, 256, 0.2, 32, 64, [64, 64, 128]),
+    ("sem_seg SA3 (B=8 N=256->64 ns=32 C=128)", 8, 256, 64, 0.4, 32, 128, [128, 128, 256]),
+    ("cls_msg SA2 scale 2 (B=16 N=512->128 ns=64 C=320)", 16, 512, 128, 0.4, 64, 320, [128, 128, 256]),
 ]
 
 

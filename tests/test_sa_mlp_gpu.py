@@ -25,7 +25,11 @@ def _reference(xyz, new_xyz, points, idx, layers):
 
 @pytest.mark.parametrize("cfeat,widths,ns", [(0, (64, 64, 128), 32), (0, (32, 32, 64), 16), (3, (64, 64, 128), 64),
                                              (6, (64, 96, 128), 32), (0, (32, 32, 64), 32), (3, (128, 128, 128), 32),
-                                             (0, (24, 40, 100), 128), (29, (64, 64, 128), 32), (1, (17, 33, 65), 16)])
+                                             (0, (24, 40, 100), 128), (29, (64, 64, 128), 32), (1, (17, 33, 65), 16),
+                                             # streamed-weights kernel: wide inputs / SA2-sized stacks
+                                             (64, (64, 64, 128), 32), (128, (128, 128, 256), 64),
+                                             (320, (128, 128, 256), 32), (61, (100, 120, 200), 32),
+                                             (0, (128, 128, 256), 32)])
 def test_fused_mlp_matches_torch(cuda, cfeat, widths, ns):
     import pointnet2_amd as P
     from pointnet2_amd import sa_mlp
@@ -39,13 +43,35 @@ def test_fused_mlp_matches_torch(cuda, cfeat, widths, ns):
     layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
                (0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32)) for i in range(3)]
     assert sa_mlp.supported(dims[0], widths, ns)
-    packed = sa_mlp.PackedMLP3(layers, cuda)
+    packed = sa_mlp.PackedMLP3(layers, cuda, ns)
+    assert packed.kind == ("streamed" if (cfeat > 29 or max(widths) > 128) else "resident")
     got = sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, packed)
     want = _reference(xyz, new_xyz, points, idx, layers)
     assert got.shape == (b, m, widths[2])
     err = (got.double() - want).abs().max().item()
     scale = want.abs().max().item()
     assert err <= 2e-5 * max(1.0, scale), (err, scale)
+
+
+@pytest.mark.parametrize("cfeat,widths", [(3, (64, 64, 128)), (64, (128, 128, 256))])
+def test_fused_mlp_features_first_order(cuda, cfeat, widths):
+    """xyz_first=False: the first layer's weight rows are [features, xyz] (the MSG module's concat order)."""
+    import pointnet2_amd as P
+    from pointnet2_amd import sa_mlp
+    rng = np.random.default_rng(17)
+    b, n, m, ns = 2, 512, 50, 32
+    xyz = torch.from_numpy(S.sphere_clouds(b, n, 2)).to(cuda)
+    new_xyz = P.gather_point(xyz, P.farthest_point_sample(m, xyz))
+    idx, _ = P.query_ball_point(0.4, ns, xyz, new_xyz)
+    points = torch.from_numpy(rng.standard_normal((b, n, cfeat)).astype(np.float32)).to(cuda)
+    dims = (3 + cfeat,) + tuple(widths)
+    layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
+               (0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32)) for i in range(3)]
+    got = sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, sa_mlp.PackedMLP3(layers, cuda, ns, xyz_first=False))
+    # reference with the rows moved to [xyz, features]
+    w1 = np.concatenate([layers[0][0][cfeat:], layers[0][0][:cfeat]], axis=0)
+    want = _reference(xyz, new_xyz, points, idx, [(w1, layers[0][1])] + layers[1:])
+    assert (got.double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
 
 
 def test_fused_mlp_in_sa_module(cuda):

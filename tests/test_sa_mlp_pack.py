@@ -14,19 +14,18 @@ def _chan(v, h):
     return 8 * (v >> 2) + 4 * h + (v & 3)
 
 
+_L = np.arange(64)
+_ROW = np.array([[8 * (v >> 2) + 4 * (l >> 5) + (v & 3) for v in range(16)] for l in range(64)])   # C/D row of (lane, reg)
+
+
 def _mfma(a, b, acc):
     """One v_mfma_f32_32x32x2_f32: a, b (64,) lane operands, acc (64, 16) -> acc + A.B in the C/D map."""
     A = np.zeros((32, 2))
     B = np.zeros((2, 32))
-    for l in range(64):
-        A[l & 31, l >> 5] = a[l]
-        B[l >> 5, l & 31] = b[l]
+    A[_L & 31, _L >> 5] = a
+    B[_L >> 5, _L & 31] = b
     D = A @ B
-    out = acc.copy()
-    for l in range(64):
-        for v in range(16):
-            out[l, v] += D[8 * (v >> 2) + 4 * (l >> 5) + (v & 3), l & 31]
-    return out
+    return acc + D[_ROW, (_L & 31)[:, None]]
 
 
 def _emulate_layer(wp, bp, t_out, t_in, acts, last=False):
@@ -54,13 +53,14 @@ def test_pack_matches_emulated_dataflow(cin, widths):
     dims = (cin,) + tuple(widths)
     ws = [rng.standard_normal((dims[i], dims[i + 1])).astype(np.float32) for i in range(3)]
     bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) for i in range(3)]
-    tiles = (ctypes.c_int * 3)()
+    tiles = (ctypes.c_int * 4)()
     wf, bf = ctypes.c_longlong(), ctypes.c_longlong()
-    assert lib.pn2_sa_mlp3_config(cin, *widths, tiles, ctypes.byref(wf), ctypes.byref(bf)) == 0
-    t1, t2, t3 = tiles
+    assert lib.pn2_sa_mlp3_config(cin, *widths, 32, tiles, ctypes.byref(wf), ctypes.byref(bf)) == 0
+    assert tiles[0] == 0                                            # resident kernel
+    _, t1, t2, t3 = tiles
     wp = np.empty(wf.value, np.float32)
     bp = np.empty(bf.value, np.float32)
-    assert lib.pn2_sa_mlp3_pack(cin, *widths, *[a.ctypes.data for pair in zip(ws, bs) for a in pair], wp.ctypes.data,
+    assert lib.pn2_sa_mlp3_pack(cin, *widths, 32, 1, *[a.ctypes.data for pair in zip(ws, bs) for a in pair], wp.ctypes.data,
                                 bp.ctypes.data) == 0
     x = rng.standard_normal((32, cin)).astype(np.float32)          # 32 samples
     # layer-1 operand registers: register v of lane l = input channel chan(v, l >> 5) of sample l & 31
@@ -98,7 +98,85 @@ def test_pack_matches_emulated_dataflow(cin, widths):
 def test_config_limits():
     from pointnet2_amd import _C
     lib = _C.lib()
-    assert lib.pn2_sa_mlp3_config(3, 64, 64, 128, None, None, None) == 0
-    assert lib.pn2_sa_mlp3_config(35, 64, 64, 128, None, None, None) != 0       # too many input channels
-    assert lib.pn2_sa_mlp3_config(3, 128, 128, 256, None, None, None) != 0      # SA2-sized: unfused path
-    assert lib.pn2_sa_mlp3_config(2, 64, 64, 128, None, None, None) != 0
+    info = (ctypes.c_int * 4)()
+    assert lib.pn2_sa_mlp3_config(3, 64, 64, 128, 32, info, None, None) == 0 and info[0] == 0
+    assert lib.pn2_sa_mlp3_config(67, 64, 64, 128, 32, info, None, None) == 0 and info[0] == 1    # wide input: streamed
+    assert lib.pn2_sa_mlp3_config(131, 128, 128, 256, 64, info, None, None) == 0 and list(info) == [1, 4, 4, 8]
+    assert lib.pn2_sa_mlp3_config(131, 128, 128, 256, 16, info, None, None) != 0   # streamed kernel: nsample % 32
+    assert lib.pn2_sa_mlp3_config(259, 256, 256, 512, 32, info, None, None) != 0   # SA4-sized: unfused path
+    assert lib.pn2_sa_mlp3_config(2, 64, 64, 128, 32, info, None, None) != 0
+    assert lib.pn2_sa_mlp3_config(3, 64, 64, 128, 48, info, None, None) != 0
+
+
+@pytest.mark.parametrize("cin,widths,xyz_first", [(67, (64, 64, 128), True), (131, (128, 128, 256), True),
+                                                   (40, (50, 64, 100), False), (323, (128, 128, 256), False)])
+def test_stream_pack_matches_emulated_dataflow(cin, widths, xyz_first):
+    """The streamed kernel's weight sequence: layer 1 input-tile-major with [features, xyz] channel order
+    and padding to whole stages, layers 2-3 output-tile-major; emulated exactly as sa_mlp_stream.hip walks it."""
+    from pointnet2_amd import _C
+    lib = _C.lib()
+    rng = np.random.default_rng(cin)
+    dims = (cin,) + tuple(widths)
+    ws = [rng.standard_normal((dims[i], dims[i + 1])).astype(np.float32) for i in range(3)]
+    bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) for i in range(3)]
+    info = (ctypes.c_int * 4)()
+    wf, bf = ctypes.c_longlong(), ctypes.c_longlong()
+    assert lib.pn2_sa_mlp3_config(cin, *widths, 32, info, ctypes.byref(wf), ctypes.byref(bf)) == 0
+    assert info[0] == 1
+    _, t1, t2, t3 = info
+    ti = (cin + 31) // 32
+    wp = np.empty(wf.value, np.float32)
+    bp = np.empty(bf.value, np.float32)
+    assert lib.pn2_sa_mlp3_pack(cin, *widths, 32, 1 if xyz_first else 0,
+                                *[a.ctypes.data for pair in zip(ws, bs) for a in pair], wp.ctypes.data, bp.ctypes.data) == 0
+    pairs = wp.reshape(-1, 4, 64, 4)
+    l1 = -(-ti * t1 // 4) * 4
+    assert pairs.shape[0] == l1 + t2 * t1 + t3 * t2
+    bias = bp.reshape(-1, 2, 16)
+    cfeat = cin - 3
+    xyz = rng.standard_normal((32, 3))
+    feat = rng.standard_normal((32, cfeat))
+    kern_in = np.concatenate([feat, xyz], axis=1)                  # the kernel's channel order
+    user_in = np.concatenate([xyz, feat], axis=1) if xyz_first else kern_in
+
+    def run_pair(pair, act, acc, swap=False):
+        for q in range(4):
+            for r in range(4):
+                w, x = pair[q, :, r], act[:, 4 * q + r]
+                acc = _mfma(x, w, acc) if swap else _mfma(w, x, acc)
+        return acc
+
+    lane_bias = lambda t0, t: np.stack([bias[t0 + t, l >> 5] for l in range(64)]).astype(np.float64)
+    h1 = [lane_bias(0, t) for t in range(t1)]
+    for u in range(ti):
+        x0 = np.zeros((64, 16))
+        for l in range(64):
+            for v in range(16):
+                k = 32 * u + _chan(v, l >> 5)
+                x0[l, v] = kern_in[l & 31, k] if k < cin else 0.0
+        for t in range(t1):
+            h1[t] = run_pair(pairs[u * t1 + t], x0, h1[t])
+    h1 = [np.maximum(a, 0.0) for a in h1]
+    h2 = []
+    for t in range(t2):
+        acc = lane_bias(t1, t)
+        for u in range(t1):
+            acc = run_pair(pairs[l1 + t * t1 + u], h1[u], acc)
+        h2.append(np.maximum(acc, 0.0))
+    got = np.zeros((32, widths[2]))
+    b3 = bias[t1 + t2:]
+    for t in range(t3):
+        acc = np.zeros((64, 16))
+        for u in range(t2):
+            acc = run_pair(pairs[l1 + t2 * t1 + t * t2 + u], h2[u], acc, swap=True)
+        for l in range(64):
+            ch = 32 * t + (l & 31)
+            if ch < widths[2]:
+                c = ch & 31
+                bb = b3[t, (c >> 2) & 1, 4 * (c >> 3) + (c & 3)]
+                for v in range(16):
+                    got[8 * (v >> 2) + 4 * (l >> 5) + (v & 3), ch] = max(acc[l, v] + bb, 0.0)
+    want = user_in.astype(np.float64)
+    for w, b in zip(ws, bs):
+        want = np.maximum(want @ w.astype(np.float64) + b, 0.0)
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
