@@ -190,8 +190,43 @@ class PointnetSAModuleMSG(nn.Module):
         self.npoint, self.radius_list, self.nsample_list, self.use_xyz = npoint, radius_list, nsample_list, use_xyz
         feat = 3 if c_in == 0 else (c_in + 3 if use_xyz else c_in)
         self.mlps = nn.ModuleList([_SharedMLP(feat, widths, bn) for widths in mlp_list])
+        self.fused_mlp = True          # eval-mode forward may use the fused MFMA kernel (sa_mlp.py)
+        self.last_path = None
+        self._pack_cache = {}
+
+    def _fused_ok(self, xyz, points):
+        if not self.fused_mlp or self.training or torch.is_grad_enabled() or not xyz.is_cuda:
+            return False
+        if points is not None and not self.use_xyz:
+            return False
+        cin = 3 + (points.shape[2] if points is not None else 0)
+        return all(sa_mlp.supported(cin, mlp.widths, ns) for mlp, ns in zip(self.mlps, self.nsample_list))
+
+    def _packed(self, si, device):
+        mlp = self.mlps[si]
+        stamp = (tuple((t.data_ptr(), t._version) for t in list(mlp.parameters()) + list(mlp.buffers())), device)
+        hit = self._pack_cache.get(si)
+        if hit is None or hit[0] != stamp:
+            # the MSG module concatenates features FIRST (:184): xyz_first=False
+            hit = (stamp, sa_mlp.PackedMLP3(mlp.folded_layers(), device, self.nsample_list[si], xyz_first=False))
+            self._pack_cache[si] = hit
+        return hit[1]
+
+    def _forward_fused(self, xyz, points):
+        """Inference: one overlapped launch for FPS + the first radius, a cell-list ball query per further
+        radius, and one fused MLP + max-pool kernel per scale; no grouped tensor is ever materialised."""
+        _, new_xyz, idx0, _, _ = sample_and_group_xyz(self.npoint, self.radius_list[0], self.nsample_list[0], xyz, True)
+        outs = []
+        for si, (radius, nsample) in enumerate(zip(self.radius_list, self.nsample_list)):
+            idx = idx0 if si == 0 else query_ball_point(radius, nsample, xyz, new_xyz)[0]
+            outs.append(sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, self._packed(si, xyz.device)))
+        return new_xyz, torch.cat(outs, dim=2)
 
     def forward(self, xyz, points):
+        if self._fused_ok(xyz, points):
+            self.last_path = "fused"
+            return self._forward_fused(xyz, points)
+        self.last_path = "unfused"
         fused = not (torch.is_grad_enabled() and xyz.requires_grad)
         first = None
         if fused:

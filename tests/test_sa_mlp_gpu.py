@@ -95,3 +95,29 @@ def test_fused_mlp_in_sa_module(cuda):
     assert mod.last_path == "fused"
     assert torch.equal(nx0, nx1)
     assert (f0 - f1).abs().max().item() <= 2e-5 * max(1.0, f0.abs().max().item())
+
+
+def test_fused_mlp_in_msg_module(cuda):
+    """PointnetSAModuleMSG (features-first concat, three radii) in eval mode: fused vs its own unfused path."""
+    import pointnet2_amd.pointnet_util as U
+    torch.manual_seed(1)
+    mod = U.PointnetSAModuleMSG(c_in=6, npoint=96, radius_list=[0.1, 0.2, 0.4], nsample_list=[16, 32, 128],
+                                mlp_list=[[32, 32, 64], [64, 64, 128], [64, 96, 128]]).to(cuda)
+    for mm in mod.modules():
+        if isinstance(mm, torch.nn.BatchNorm2d):
+            mm.running_mean.uniform_(-0.2, 0.2)
+            mm.running_var.uniform_(0.5, 1.5)
+            mm.weight.data.uniform_(0.5, 1.5)
+            mm.bias.data.uniform_(-0.1, 0.1)
+    mod.eval()
+    xyz = torch.from_numpy(S.sphere_clouds(3, 1024, 4)).to(cuda)
+    pts = torch.randn(3, 1024, 6, device=cuda)
+    with torch.no_grad():
+        mod.fused_mlp = False
+        nx0, f0 = mod(xyz, pts)
+        assert mod.last_path == "unfused"
+        mod.fused_mlp = True
+        nx1, f1 = mod(xyz, pts)
+    assert mod.last_path == "fused"
+    assert torch.equal(nx0, nx1) and f0.shape == f1.shape == (3, 96, 64 + 128 + 128)
+    assert (f0 - f1).abs().max().item() <= 2e-5 * max(1.0, f0.abs().max().item())
