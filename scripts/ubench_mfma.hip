@@ -45,9 +45,17 @@ template <int MODE> static void run(const char *name)
     CK(hipMalloc(&sink, 256 * 512 * 4)); CK(hipMalloc(&ticks, 16));
     const int iters = 512;
     for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(512), 0, 0, sink, ticks, iters); CK(hipDeviceSynchronize()); }
+    // wall time of a long launch: the sustained shader clock under this load = ticks / time
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int long_iters = iters * 16;
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(512), 0, 0, sink, ticks, long_iters);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     unsigned long long h[2]; CK(hipMemcpy(h, ticks, 16, hipMemcpyDeviceToHost));
-    printf("%-52s MFMA wave: %.1f ticks per MFMA;  other wave total %.0f ticks (%.2f per v_max)\n", name, (double)h[0] / iters / 16,
-           (double)h[1], (double)h[1] / iters / 256);
+    const double tot = (double)(h[0] > h[1] ? h[0] : h[1]);
+    printf("%-52s MFMA wave: %.1f ticks per MFMA;  other wave total %.0f ticks (%.2f per v_max); kernel %.3f ms -> %.2f G ticks/s\n", name,
+           (double)h[0] / long_iters / 16, (double)h[1], (double)h[1] / long_iters / 256, ms, tot / ms / 1e6);
     CK(hipFree(sink)); CK(hipFree(ticks));
 }
 
