@@ -121,3 +121,26 @@ def test_fused_mlp_in_msg_module(cuda):
     assert mod.last_path == "fused"
     assert torch.equal(nx0, nx1) and f0.shape == f1.shape == (3, 96, 64 + 128 + 128)
     assert (f0 - f1).abs().max().item() <= 2e-5 * max(1.0, f0.abs().max().item())
+
+
+@pytest.mark.parametrize("cfeat,widths,ns", [(0, (32, 32, 64), 32), (0, (32, 32, 64), 16), (64, (64, 64, 128), 32),
+                                             (128, (128, 128, 256), 64)])
+def test_fused_mlp_many_rows_and_repeatable(cuda, cfeat, widths, ns):
+    """More centroids than resident waves (every wave takes several work items, ragged tail), five runs:
+    identical bits every time (the streamed kernel's barrier-flipped LDS stages must never race)."""
+    import pointnet2_amd as P
+    from pointnet2_amd import sa_mlp
+    rng = np.random.default_rng(3)
+    b, n, m = 9, 600, 523                                        # 4707 rows: > 2048 waves, odd
+    xyz = torch.from_numpy(S.uniform_clouds(b, n, 5)).to(cuda)
+    new_xyz = P.gather_point(xyz, P.farthest_point_sample(m, xyz))
+    idx, _ = P.query_ball_point(0.25, ns, xyz, new_xyz)
+    points = torch.from_numpy(rng.standard_normal((b, n, cfeat)).astype(np.float32)).to(cuda) if cfeat else None
+    dims = (3 + cfeat,) + tuple(widths)
+    layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
+               (0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32)) for i in range(3)]
+    packed = sa_mlp.PackedMLP3(layers, cuda, ns)
+    outs = [sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, packed) for _ in range(5)]
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    want = _reference(xyz, new_xyz, points, idx, layers)
+    assert (outs[0].double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
