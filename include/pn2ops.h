@@ -117,6 +117,18 @@ int pn2_group_point_grad_det(int b, int n, int c, int m, int nsample, const floa
 int pn2_three_interpolate_grad_det(int b, int n, int c, int m, const float *grad_out, const int *idx,
                                    const float *weight, float *grad_points, void *ws, void *stream);
 
+/* ---- the same gradients as a segmented reduction (no reference counterpart) ----------------------
+ * idx is inverted first (counting sort by target row), then one lane group sums the grad_out rows of
+ * every output row: no float atomics, no zero-fill, ~3x the throughput of the atomic scatter from 16
+ * channels up. deterministic != 0: per-element 64-bit fixed-point sums (identical bits on every run).
+ * ws: pn2_seg_grad_ws_bytes(b, rows, entries) bytes of uninitialised device scratch
+ * (group_point: rows = n, entries = m * nsample; three_interpolate: rows = m, entries = 3 * n). */
+long long pn2_seg_grad_ws_bytes(int b, int rows, long long entries);
+int pn2_group_point_grad_seg(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
+                             float *grad_points, void *ws, int deterministic, void *stream);
+int pn2_three_interpolate_grad_seg(int b, int n, int c, int m, const float *grad_out, const int *idx,
+                                   const float *weight, float *grad_points, void *ws, int deterministic, void *stream);
+
 /* ---- grouped local MLP + max-pool of a set-abstraction layer, fused, on the matrix cores ---------
  * (no reference kernel; replaces for INFERENCE the TF graph of utils/pointnet_util.py:44-50 + :117-127:
  *  group_point(xyz)-new_xyz ++ group_point(points) -> 3 x [conv2d 1x1 + batch_norm + ReLU] -> reduce_max

@@ -43,6 +43,9 @@ _SIGNATURES = {
     "pn2_gather_point_grad_det": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pn2_group_point_grad_det": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pn2_three_interpolate_grad_det": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pn2_seg_grad_ws_bytes": [_i, _i, ctypes.c_longlong],
+    "pn2_group_point_grad_seg": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "pn2_three_interpolate_grad_seg": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pn2_sa_mlp3_config": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "pn2_sa_mlp3_pack": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pn2_sa_mlp3_maxpool": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
@@ -57,6 +60,7 @@ _SIGNATURES = {
 _RESTYPES = {
     "pn2_fps_temp_floats": ctypes.c_longlong,
     "pn2_det_grad_ws_bytes": ctypes.c_longlong,
+    "pn2_seg_grad_ws_bytes": ctypes.c_longlong,
     "pn2_sample_and_group_ws_bytes": ctypes.c_longlong,
     "pn2_ball_threshold": ctypes.c_float,
     "pn2_version": ctypes.c_char_p,

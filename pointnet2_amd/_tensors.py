@@ -92,3 +92,18 @@ def det_workspace(lib, b, rows, c, device):
     """Scratch for one deterministic gradient call (int64 accumulators + header)."""
     nbytes = lib.pn2_det_grad_ws_bytes(b, rows, c)
     return torch.empty(((nbytes + 7) // 8,), dtype=torch.int64, device=device)
+
+
+# When the scatter-add gradients run as a segmented reduction (csrc/seg_grad.hip) instead of atomics:
+# always from 16 channels up; below that only when the index inversion can use the one-workgroup-per-
+# cloud LDS path (>= 4 clouds, <= 24576 target rows), where it beats the atomics even at 3 channels.
+SEG_GRAD_MIN_CHANNELS = 16
+
+
+def use_segmented_grad(b, rows, c):
+    return c >= SEG_GRAD_MIN_CHANNELS or (b >= 4 and rows <= 24576)
+
+
+def seg_workspace(lib, b, rows, entries, device):
+    nbytes = lib.pn2_seg_grad_ws_bytes(b, rows, entries)
+    return torch.empty(((nbytes + 7) // 8,), dtype=torch.int64, device=device)

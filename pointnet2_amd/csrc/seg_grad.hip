@@ -1,0 +1,348 @@
+// seg_grad.hip -- gradients of group_point / three_interpolate as a SEGMENTED REDUCTION instead of a
+// scatter of fp32 atomics. gfx950.
+//
+// The reference kernels (tf_grouping_g.cu:60-78; tf_interpolate.cpp:131-153 is the CPU twin of the same
+// sum) add every element of grad_out into grad_points[idx] with an atomic. Measured on MI355X the
+// atomic scatter runs at ~1.3 TB/s of algorithmic traffic (16 % of HBM peak) whatever the channel
+// count, because the L2 atomic units, not the memory, are the limit. Here the index tensor is inverted
+// first (a counting sort of the b*m*nsample references by target point: int atomics, independent of
+// the channel count), then ONE lane group owns each output row and sums the grad_out rows that refer to
+// it: coalesced row reads, every output element written exactly once, no float atomics, no zero-fill.
+// Worth it from ~16 channels up (the inversion costs about as much as the atomic scatter of 8 channels).
+//
+// deterministic = 1: the order in which the counting sort fills a segment varies from run to run, so a
+// plain fp32 sum would too. The reproducible mode sums each output element in 64-bit FIXED POINT with a
+// scale chosen PER ELEMENT from the largest addend of its own segment (two passes over the segment, the
+// second one out of L2): integer sums and maxima do not depend on the order, so the result is identical
+// on every run, and it is within one rounding of the exact sum relative to the element's own largest
+// addend (the atomics-based pn2_*_grad_det scale by the largest addend of the whole tensor).
+#include "pn2_device.h"
+
+#include <limits.h>
+#include <math.h>
+
+namespace pn2 {
+
+constexpr int kSegThreads = 256;
+
+static inline unsigned seg_grid(long long work, int per_block = kSegThreads)
+{
+    long long g = (work + per_block - 1) / per_block;
+    if (g > 256 * 32) g = 256 * 32;
+    return (unsigned)(g > 0 ? g : 1);
+}
+
+// workspace: start int[b * (rows + 1)] | cursor int[b * rows] | list int[b * entries]
+struct SegWs {
+    int *start, *cursor, *list;
+};
+static inline SegWs seg_ws(void *ws, int b, int rows, long long entries)
+{
+    int *p = reinterpret_cast<int *>(ws);
+    return {p, p + (size_t)b * (rows + 1), p + (size_t)b * (rows + 1) + (size_t)b * rows};
+}
+
+__global__ __launch_bounds__(kSegThreads) void seg_count_kernel(long long total, long long entries, int rows,
+                                                                const int *__restrict__ idx, int *__restrict__ cnt)
+{
+    for (long long e = (long long)blockIdx.x * kSegThreads + threadIdx.x; e < total; e += (long long)gridDim.x * kSegThreads)
+        atomicAdd(cnt + (e / entries) * rows + idx[e], 1);
+}
+
+// one workgroup per cloud: exclusive scan of the counts -> start[0..rows], cursor = start
+__global__ __launch_bounds__(1024) void seg_scan_kernel(int rows, int *__restrict__ start, int *__restrict__ cursor)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    int *cnt = cursor + (size_t)blockIdx.x * rows;              // counts were accumulated in the cursor array
+    int *st = start + (size_t)blockIdx.x * (rows + 1);
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < rows; base += 1024) {
+        const int r = base + t;
+        const int v = r < rows ? cnt[r] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int off = carry_s;
+        for (int i = 0; i < w; ++i) off += wsum[i];
+        if (r < rows) {
+            st[r] = off + incl - v;
+            cnt[r] = off + incl - v;
+        }
+        __syncthreads();
+        if (t == 1023) carry_s = off + incl;
+        __syncthreads();
+    }
+    if (t == 0) st[rows] = carry_s;
+}
+
+__global__ __launch_bounds__(kSegThreads) void seg_fill_kernel(long long total, long long entries, int rows,
+                                                               const int *__restrict__ idx, int *__restrict__ cursor,
+                                                               int *__restrict__ list)
+{
+    for (long long e = (long long)blockIdx.x * kSegThreads + threadIdx.x; e < total; e += (long long)gridDim.x * kSegThreads) {
+        const long long i = e / entries;
+        const int pos = atomicAdd(cursor + i * rows + idx[e], 1);
+        list[i * entries + pos] = (int)(e - i * entries);
+    }
+}
+
+// The whole inversion of one cloud in ONE workgroup with LDS counters (count, scan, fill): scattered
+// 4-byte atomics at the L2 run at ~12 G/s on this chip (85 us for the 1 M references of the metric
+// shape, per pass), LDS atomics do the same in a few microseconds. rows <= kSegLdsRows.
+constexpr int kSegLdsRows = 24576;                                // 96 KiB of counters
+__global__ __launch_bounds__(1024) void seg_invert_lds_kernel(long long entries, int rows, const int *__restrict__ idx,
+                                                              int *__restrict__ start, int *__restrict__ list)
+{
+    extern __shared__ int cnt[];
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int *my = idx + (size_t)blockIdx.x * entries;
+    int *st = start + (size_t)blockIdx.x * (rows + 1);
+    int *out = list + (size_t)blockIdx.x * entries;
+    for (int r = t; r < rows; r += 1024) cnt[r] = 0;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (long long e = t; e < entries; e += 1024) atomicAdd(&cnt[my[e]], 1);
+    __syncthreads();
+    for (int base = 0; base < rows; base += 1024) {
+        const int r = base + t;
+        const int v = r < rows ? cnt[r] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int off = carry_s;
+        for (int i = 0; i < w; ++i) off += wsum[i];
+        if (r < rows) {
+            st[r] = off + incl - v;
+            cnt[r] = off + incl - v;                              // becomes the fill cursor
+        }
+        __syncthreads();
+        if (t == 1023) carry_s = off + incl;
+        __syncthreads();
+    }
+    if (t == 0) st[rows] = carry_s;
+    for (long long e = t; e < entries; e += 1024) {
+        const int pos = atomicAdd(&cnt[my[e]], 1);
+        out[pos] = (int)e;
+    }
+}
+
+// fixed-point helpers (per element): 2^ex > |m|; shift k = 62 - logcount - ex
+__device__ __forceinline__ int seg_shift(float maxabs, int logcount)
+{
+    const unsigned bits = __float_as_uint(maxabs);
+    return 62 - logcount - ((int)(bits >> 23) - 126);
+}
+
+// One lane group (LPR lanes) per output row; lanes own 4 consecutive channels (VEC4) or 1 channel.
+// SRC_DIV: source row of entry e is e / SRC_DIV (1 for group_point, 3 for three_interpolate);
+// weight (may be null): addend = grad_out * weight[entry], rounded to fp32 like the reference.
+// The segment's entry numbers are fetched LPR at a time (one per lane) and handed round with a
+// shuffle, and the rows are read four at a time: a lane that first loads an entry number and then the
+// row it names pays two dependent memory round trips per entry (335 us where this form needs ~150).
+template <int LPR, bool VEC4, bool DET, int SRC_DIV>
+__global__ __launch_bounds__(kSegThreads) void seg_reduce_kernel(long long out_rows, int rows, long long entries, int c,
+                                                                 const float *__restrict__ grad_out,
+                                                                 const float *__restrict__ weight,
+                                                                 const int *__restrict__ start,
+                                                                 const int *__restrict__ list,
+                                                                 float *__restrict__ out)
+{
+    constexpr int CH = VEC4 ? 4 : 1;
+    constexpr int UNR = 4;
+    const long long group = ((long long)blockIdx.x * kSegThreads + threadIdx.x) / LPR;
+    const int lane = threadIdx.x & 63;
+    const int gl = threadIdx.x % LPR, gbase = lane - gl;            // first lane of this group inside the wave
+    const long long ngroups = (long long)gridDim.x * kSegThreads / LPR;
+    const long long trips = (out_rows + ngroups - 1) / ngroups;     // wave-uniform loop: shuffles need all lanes
+    for (long long trip = 0; trip < trips; ++trip) {
+        const long long row_raw = group + trip * ngroups;
+        const bool row_ok = row_raw < out_rows;
+        const long long row = row_ok ? row_raw : out_rows - 1;
+        const long long i = row / rows;
+        const int r = (int)(row - i * rows);
+        const int beg = start[i * (rows + 1) + r];
+        const int end = row_ok ? start[i * (rows + 1) + r + 1] : beg;
+        const int *seg = list + i * entries;
+        const float *src = grad_out + (size_t)i * (entries / SRC_DIV) * c;
+        const float *wsrc = weight ? weight + (size_t)i * entries : nullptr;
+        const int len = end - beg;
+        int logc = 0;
+        while ((1 << logc) < len) ++logc;
+
+        for (int cc0 = 0; __any(cc0 < c); cc0 += LPR * CH) {
+            const int cc = cc0 + gl * CH;
+            const bool ch_ok = cc < c;
+            const int ccl = ch_ok ? cc : 0;
+            float acc[CH];
+            unsigned mx[CH];
+            long long fx[CH];
+            int k[CH];
+            double sc[CH];                                          // 2^k: the scaling is one exact fp64 multiply
+#pragma unroll
+            for (int q = 0; q < CH; ++q) { acc[q] = 0.0f; mx[q] = 0u; fx[q] = 0; k[q] = 0; sc[q] = 1.0; }
+            // pass 0: plain sum (and, for DET, the largest |addend|); pass 1 (DET only): fixed-point sum
+            for (int pass = 0; pass < (DET ? 2 : 1); ++pass) {
+                if (DET && pass == 1) {
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) { k[q] = seg_shift(__uint_as_float(mx[q]), logc); sc[q] = ldexp(1.0, k[q]); }
+                }
+                for (int p0 = 0; __any(p0 < len); p0 += LPR) {
+                    const int mine = (p0 + gl < len) ? seg[beg + p0 + gl] : 0;      // this lane's entry of the chunk
+                    const int chunk = min(LPR, len - p0);
+                    for (int j0 = 0; __any(j0 < chunk); j0 += UNR) {
+                        float a[UNR][CH];
+                        float wv[UNR];
+                        bool ok[UNR];
+#pragma unroll
+                        for (int u = 0; u < UNR; ++u) {
+                            const int j = j0 + u;
+                            ok[u] = j < chunk;
+                            const int e = __shfl(mine, gbase + (ok[u] ? j : 0));
+                            const float *g = src + (size_t)(e / SRC_DIV) * c + ccl;
+                            if (VEC4) {
+                                const float4 v = *reinterpret_cast<const float4 *>(g);
+                                a[u][0] = v.x; a[u][1] = v.y; a[u][2] = v.z; a[u][3] = v.w;
+                            } else {
+                                a[u][0] = g[0];
+                            }
+                            wv[u] = wsrc ? wsrc[e] : 1.0f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < UNR; ++u) {
+                            if (!ok[u]) continue;
+#pragma unroll
+                            for (int q = 0; q < CH; ++q) {
+                                const float ad = wsrc ? __fmul_rn(a[u][q], wv[u]) : a[u][q];
+                                if (!DET || pass == 0) {
+                                    acc[q] = __fadd_rn(acc[q], ad);
+                                    if (DET) mx[q] = max(mx[q], __float_as_uint(ad) & 0x7fffffffu);
+                                } else {
+                                    fx[q] += __double2ll_rn((double)ad * sc[q]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (row_ok && ch_ok) {
+                float res[CH];
+#pragma unroll
+                for (int q = 0; q < CH; ++q)                        // non-finite addends: the fp32 sum propagates them
+                    res[q] = (!DET || mx[q] >= 0x7f800000u) ? acc[q] : (float)ldexp((double)fx[q], -k[q]);
+                float *o = out + row * c + cc;
+                if (VEC4) *reinterpret_cast<float4 *>(o) = make_float4(res[0], res[1], res[2], res[3]);
+                else o[0] = res[0];
+            }
+        }
+    }
+}
+
+template <bool DET, int SRC_DIV>
+static void launch_reduce(long long out_rows, int rows, long long entries, int c, const float *grad_out, const float *weight,
+                          const SegWs &w, float *out, hipStream_t st)
+{
+    const bool vec4 = (c & 3) == 0;
+    const int per = vec4 ? c / 4 : c;                             // lanes a row can use
+    int lpr = 1;
+    while (lpr < per && lpr < 64) lpr <<= 1;
+    const long long threads = out_rows * lpr;
+#define PN2_SEG_CASE(L)                                                                                              \
+    if (lpr == L) {                                                                                                  \
+        if (vec4) hipLaunchKernelGGL((seg_reduce_kernel<L, true, DET, SRC_DIV>), dim3(seg_grid(threads)), dim3(kSegThreads), 0, st, \
+                                     out_rows, rows, entries, c, grad_out, weight, w.start, w.list, out);            \
+        else hipLaunchKernelGGL((seg_reduce_kernel<L, false, DET, SRC_DIV>), dim3(seg_grid(threads)), dim3(kSegThreads), 0, st, \
+                                out_rows, rows, entries, c, grad_out, weight, w.start, w.list, out);                 \
+        return;                                                                                                      \
+    }
+    PN2_SEG_CASE(1) PN2_SEG_CASE(2) PN2_SEG_CASE(4) PN2_SEG_CASE(8) PN2_SEG_CASE(16) PN2_SEG_CASE(32) PN2_SEG_CASE(64)
+#undef PN2_SEG_CASE
+}
+
+// invert idx (b clouds x `entries` references into `rows` targets), then reduce
+template <int SRC_DIV>
+static int seg_grad(int b, int rows, long long entries, int c, const float *grad_out, const int *idx, const float *weight,
+                    float *out, void *ws, int deterministic, hipStream_t st)
+{
+    SegWs w = seg_ws(ws, b, rows, entries);
+    const long long total = (long long)b * entries;
+    if (rows <= kSegLdsRows && b >= 4) {
+        // enough clouds to spread over CUs: the whole inversion of a cloud in one workgroup, LDS counters
+        const size_t lds = sizeof(int) * (size_t)rows;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(seg_invert_lds_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(seg_invert_lds_kernel, dim3(b), dim3(1024), lds, st, entries, rows, idx, w.start, w.list);
+    } else {
+    hipError_t e = hipMemsetAsync(w.cursor, 0, sizeof(int) * (size_t)b * rows, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(seg_count_kernel, dim3(seg_grid(total)), dim3(kSegThreads), 0, st, total, entries, rows, idx, w.cursor);
+    hipLaunchKernelGGL(seg_scan_kernel, dim3(b), dim3(1024), 0, st, rows, w.start, w.cursor);
+    hipLaunchKernelGGL(seg_fill_kernel, dim3(seg_grid(total)), dim3(kSegThreads), 0, st, total, entries, rows, idx, w.cursor, w.list);
+    }
+    const long long out_rows = (long long)b * rows;
+    if (deterministic) launch_reduce<true, SRC_DIV>(out_rows, rows, entries, c, grad_out, weight, w, out, st);
+    else launch_reduce<false, SRC_DIV>(out_rows, rows, entries, c, grad_out, weight, w, out, st);
+    return launch_status();
+}
+
+}  // namespace pn2
+
+extern "C" long long pn2_seg_grad_ws_bytes(int b, int rows, long long entries)
+{
+    if (b <= 0 || rows <= 0 || entries < 0) return 16;
+    return (long long)sizeof(int) * ((long long)b * (rows + 1) + (long long)b * rows + (long long)b * entries) + 16;
+}
+
+extern "C" int pn2_group_point_grad_seg(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
+                                        float *grad_points, void *ws, int deterministic, void *stream)
+{
+    using namespace pn2;
+    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0) return PN2_E_SHAPE;
+    if (b == 0) return PN2_OK;
+    if (!grad_points || !ws) return PN2_E_NULL;
+    const long long entries = (long long)m * nsample;
+    if (entries > INT_MAX || (long long)b * n > INT_MAX) return PN2_E_TOO_LARGE;
+    hipStream_t st = as_stream(stream);
+    if (entries == 0) {
+        hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * n * c, st);
+        return e == hipSuccess ? PN2_OK : (int)e;
+    }
+    if (!grad_out || !idx) return PN2_E_NULL;
+    return seg_grad<1>(b, n, entries, c, grad_out, idx, nullptr, grad_points, ws, deterministic, st);
+}
+
+extern "C" int pn2_three_interpolate_grad_seg(int b, int n, int c, int m, const float *grad_out, const int *idx,
+                                              const float *weight, float *grad_points, void *ws, int deterministic,
+                                              void *stream)
+{
+    using namespace pn2;
+    if (b < 0 || n < 0 || c <= 0 || m <= 0) return PN2_E_SHAPE;
+    if (b == 0) return PN2_OK;
+    if (!grad_points || !ws) return PN2_E_NULL;
+    const long long entries = (long long)n * 3;
+    if (entries > INT_MAX || (long long)b * m > INT_MAX) return PN2_E_TOO_LARGE;
+    hipStream_t st = as_stream(stream);
+    if (entries == 0) {
+        hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * m * c, st);
+        return e == hipSuccess ? PN2_OK : (int)e;
+    }
+    if (!grad_out || !idx || !weight) return PN2_E_NULL;
+    return seg_grad<3>(b, m, entries, c, grad_out, idx, weight, grad_points, ws, deterministic, st);
+}

@@ -10,8 +10,8 @@ NoGradient (:21, :32).
 import torch
 
 from . import _C
-from ._tensors import (det_workspace, f32, i32, is_deterministic, on_device, ptr, require, same_device,
-                       stream_ptr)
+from ._tensors import (use_segmented_grad, det_workspace, f32, i32, is_deterministic, on_device, ptr, require,
+                       same_device, seg_workspace, stream_ptr)
 
 
 def query_ball_point(radius, nsample, xyz1, xyz2):
@@ -148,7 +148,12 @@ class _GroupPoint(torch.autograd.Function):
         dev = grad_out.device
         grad_points = torch.empty((b, n, c), dtype=torch.float32, device=dev)   # zero-filled by the library
         with on_device(dev):
-            if is_deterministic():
+            if use_segmented_grad(b, n, c):
+                ws = seg_workspace(_C.lib(), b, n, m * ns, dev)
+                _C.check(_C.lib().pn2_group_point_grad_seg(b, n, c, m, ns, ptr(grad_out), ptr(idx), ptr(grad_points),
+                                                           ptr(ws), 1 if is_deterministic() else 0, stream_ptr(dev)),
+                         "group_point_grad")
+            elif is_deterministic():
                 ws = det_workspace(_C.lib(), b, n, c, dev)
                 _C.check(_C.lib().pn2_group_point_grad_det(b, n, c, m, ns, ptr(grad_out), ptr(idx), ptr(grad_points),
                                                            ptr(ws), stream_ptr(dev)), "group_point_grad")

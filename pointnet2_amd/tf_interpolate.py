@@ -10,8 +10,8 @@ gradient w.r.t. `points` only (tf_interpolate.py:29-34); ThreeNN is NoGradient (
 import torch
 
 from . import _C
-from ._tensors import (det_workspace, f32, i32, is_deterministic, on_device, ptr, require, same_device,
-                       stream_ptr)
+from ._tensors import (use_segmented_grad, det_workspace, f32, i32, is_deterministic, on_device, ptr, require,
+                       same_device, seg_workspace, stream_ptr)
 
 
 def three_nn(xyz1, xyz2):
@@ -60,7 +60,13 @@ class _ThreeInterpolate(torch.autograd.Function):
         dev = grad_out.device
         grad_points = torch.empty((b, m, c), dtype=torch.float32, device=dev)   # zero-filled by the library
         with on_device(dev):
-            if is_deterministic():
+            if use_segmented_grad(b, m, c):
+                ws = seg_workspace(_C.lib(), b, m, 3 * n, dev)
+                _C.check(_C.lib().pn2_three_interpolate_grad_seg(b, n, c, m, ptr(grad_out), ptr(idx), ptr(weight),
+                                                                 ptr(grad_points), ptr(ws),
+                                                                 1 if is_deterministic() else 0, stream_ptr(dev)),
+                         "three_interpolate_grad")
+            elif is_deterministic():
                 ws = det_workspace(_C.lib(), b, m, c, dev)
                 _C.check(_C.lib().pn2_three_interpolate_grad_det(b, n, c, m, ptr(grad_out), ptr(idx), ptr(weight),
                                                                  ptr(grad_points), ptr(ws), stream_ptr(dev)),

@@ -128,3 +128,81 @@ def test_det_grad_edge_values(cuda, deterministic):
     g[0, 5, 2, 1] = float("nan")
     got = grad_for(g)
     assert torch.isinf(got[0, idx[0, 3, 1].item(), 0]) and torch.isnan(got[0, idx[0, 5, 2].item(), 1])
+
+
+@pytest.mark.parametrize("det", [False, True])
+@pytest.mark.parametrize("c,b", [(16, 3), (20, 6), (64, 3), (130, 6), (320, 5), (17, 4)])
+def test_segmented_group_grad(cuda, det, c, b):
+    """c >= 16 takes the segmented reduction (csrc/seg_grad.hip): value against a float64 scatter-add for
+    both modes; identical bits over runs in the reproducible mode; crowded and empty segments."""
+    import pointnet2_amd as P
+    rng = np.random.default_rng(c)
+    n, m, ns = 500, 70, 16                                       # b < 4: global-atomic inversion; b >= 4: LDS inversion
+    idx = rng.integers(0, n, size=(b, m, ns)).astype(np.int32)
+    idx[:, :, ::3] = 11                                          # a third of all references hit one point
+    idx[idx == 5] = 6                                            # point 5: an empty segment
+    g = (rng.standard_normal((b, m, ns, c)) * 10.0 ** rng.integers(-3, 3, size=(b, m, ns, 1))).astype(np.float32)
+    pts = torch.zeros(b, n, c, device=cuda, requires_grad=True)
+    P.set_deterministic(det)
+    try:
+        outs = []
+        for _ in range(4):
+            pts.grad = None
+            P.group_point(pts, torch.from_numpy(idx).to(cuda)).backward(torch.from_numpy(g).to(cuda))
+            outs.append(pts.grad.clone())
+    finally:
+        P.set_deterministic(False)
+    if det:
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
+    want = _exact_scatter(b, n, c, idx.reshape(b, -1), g.reshape(b, -1, c))
+    mag = _exact_scatter(b, n, c, idx.reshape(b, -1), np.abs(g).reshape(b, -1, c))
+    cnt = np.zeros((b, n, 1))
+    for i in range(b):
+        np.add.at(cnt[i], idx[i].reshape(-1), 1.0)
+    tol = mag * 2.0 ** -23 * (1 if det else 1 + np.log2(np.maximum(cnt, 1))) + 1e-30
+    assert np.all(np.abs(outs[0].cpu().numpy() - want) <= tol)
+    assert torch.count_nonzero(outs[0][:, 5]) == 0
+
+
+@pytest.mark.parametrize("det", [False, True])
+def test_segmented_interpolate_grad(cuda, det):
+    import pointnet2_amd as P
+    rng = np.random.default_rng(8)
+    b, n, m, c = (2, 1500, 90, 36) if det else (7, 1500, 90, 36)
+    idx = rng.integers(0, m, size=(b, n, 3)).astype(np.int32)
+    w = rng.random((b, n, 3), dtype=np.float32)
+    g = rng.standard_normal((b, n, c)).astype(np.float32)
+    pts = torch.zeros(b, m, c, device=cuda, requires_grad=True)
+    P.set_deterministic(det)
+    try:
+        outs = []
+        for _ in range(4):
+            pts.grad = None
+            P.three_interpolate(pts, torch.from_numpy(idx).to(cuda), torch.from_numpy(w).to(cuda)).backward(
+                torch.from_numpy(g).to(cuda))
+            outs.append(pts.grad.clone())
+    finally:
+        P.set_deterministic(False)
+    if det:
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
+    addend = (g[:, :, None, :] * w[:, :, :, None]).astype(np.float32).reshape(b, n * 3, c)
+    want = _exact_scatter(b, m, c, idx.reshape(b, -1), addend)
+    mag = _exact_scatter(b, m, c, idx.reshape(b, -1), np.abs(addend))
+    assert np.all(np.abs(outs[0].cpu().numpy() - want) <= mag * 2.0 ** -23 * (1 if det else 8) + 1e-30)
+
+
+def test_segmented_grad_nonfinite(cuda):
+    import pointnet2_amd as P
+    b, n, c, m, ns = 1, 40, 16, 8, 4
+    idx = torch.randint(0, n, (b, m, ns), dtype=torch.int32, device=cuda)
+    g = torch.ones(b, m, ns, c, device=cuda)
+    g[0, 2, 1, 3] = float("inf")
+    g[0, 4, 0, 7] = float("nan")
+    for det in (False, True):
+        P.set_deterministic(det)
+        try:
+            pts = torch.zeros(b, n, c, device=cuda, requires_grad=True)
+            P.group_point(pts, idx).backward(g)
+        finally:
+            P.set_deterministic(False)
+        assert torch.isinf(pts.grad[0, idx[0, 2, 1].item(), 3]) and torch.isnan(pts.grad[0, idx[0, 4, 0].item(), 7])
