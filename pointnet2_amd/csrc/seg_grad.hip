@@ -32,14 +32,16 @@ static inline unsigned seg_grid(long long work, int per_block = kSegThreads)
     return (unsigned)(g > 0 ? g : 1);
 }
 
-// workspace: start int[b * (rows + 1)] | cursor int[b * rows] | list int[b * entries]
+// workspace: start int[b * (rows + 1)] | cursor int[b * rows] | sorted int[b * rows] | list int[b * entries]
+// sorted[row] != 0: the row's segment lists its entries in ascending order
 struct SegWs {
-    int *start, *cursor, *list;
+    int *start, *cursor, *sorted, *list;
 };
 static inline SegWs seg_ws(void *ws, int b, int rows, long long entries)
 {
     int *p = reinterpret_cast<int *>(ws);
-    return {p, p + (size_t)b * (rows + 1), p + (size_t)b * (rows + 1) + (size_t)b * rows};
+    int *cursor = p + (size_t)b * (rows + 1);
+    return {p, cursor, cursor + (size_t)b * rows, cursor + 2 * (size_t)b * rows};
 }
 
 __global__ __launch_bounds__(kSegThreads) void seg_count_kernel(long long total, long long entries, int rows,
@@ -97,16 +99,55 @@ __global__ __launch_bounds__(kSegThreads) void seg_fill_kernel(long long total, 
 // The whole inversion of one cloud in ONE workgroup with LDS counters (count, scan, fill): scattered
 // 4-byte atomics at the L2 run at ~12 G/s on this chip (85 us for the 1 M references of the metric
 // shape, per pass), LDS atomics do the same in a few microseconds. rows <= kSegLdsRows.
+// SORT (the list fits in LDS beside the counters): the segments are filled in LDS and every segment of
+// up to kSegSortMax entries is then sorted ascending: by one thread up to kSegSortThread entries (insertion
+// sort; the average segment has m*nsample/n ~ 8 entries), by one wave beyond (rank sort: ball queries
+// that overflow nsample return the lowest indices, so low-numbered points collect a reference from
+// almost every centroid -- segments of 100+ entries are the rule, not the exception). A sorted segment is summed in exactly the order of the reference's CPU
+// loop (tf_grouping.cpp / query_ball_point.cpp:72-85, tf_interpolate.cpp:131-153: ascending entry
+// number), so the fp32 result is bit-identical to it AND the same on every run, in a single pass.
 constexpr int kSegLdsRows = 24576;                                // 96 KiB of counters
-__global__ __launch_bounds__(1024) void seg_invert_lds_kernel(long long entries, int rows, const int *__restrict__ idx,
-                                                              int *__restrict__ start, int *__restrict__ list)
+constexpr int kSegSortThread = 32;                                // insertion sort by one thread up to here
+constexpr int kSegSortMax = 1024;                                 // rank sort by one wave up to here
+// Rank sort of one segment (distinct ints, in LDS) by a group of G lanes holding Q entries each: rank =
+// number of smaller entries is a permutation; a lane ranks its entries against the whole segment (LDS
+// reads, the same address across the group), and only then writes them back. Every lane of the wave
+// must call it (a group without work passes len = 0): the trip count is the wave's maximum.
+template <int G, int Q>
+__device__ __forceinline__ void seg_rank_sort(int *llist, int beg, int len, int gl)
 {
-    extern __shared__ int cnt[];
+    int val[Q], rank[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int a = gl + G * q;
+        val[q] = a < len ? llist[beg + a] : INT_MAX;
+        rank[q] = 0;
+    }
+    for (int j = 0; __any(j < len); ++j) {
+        const int other = j < len ? llist[beg + j] : INT_MAX;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) rank[q] += other < val[q] ? 1 : 0;
+    }
+    asm volatile("" ::: "memory");                               // all reads of the wave precede its writes
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+        if (gl + G * q < len) llist[beg + rank[q]] = val[q];
+}
+
+template <bool SORT>
+__global__ __launch_bounds__(1024) void seg_invert_lds_kernel(long long entries, int rows, const int *__restrict__ idx,
+                                                              int *__restrict__ start, int *__restrict__ sorted,
+                                                              int *__restrict__ list)
+{
+    extern __shared__ int smem_i[];
+    int *cnt = smem_i;                                            // [rows]
+    int *llist = smem_i + rows;                                   // [entries] when SORT
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int *my = idx + (size_t)blockIdx.x * entries;
     int *st = start + (size_t)blockIdx.x * (rows + 1);
+    int *flags = sorted + (size_t)blockIdx.x * rows;
     int *out = list + (size_t)blockIdx.x * entries;
     for (int r = t; r < rows; r += 1024) cnt[r] = 0;
     if (t == 0) carry_s = 0;
@@ -137,8 +178,59 @@ __global__ __launch_bounds__(1024) void seg_invert_lds_kernel(long long entries,
     if (t == 0) st[rows] = carry_s;
     for (long long e = t; e < entries; e += 1024) {
         const int pos = atomicAdd(&cnt[my[e]], 1);
-        out[pos] = (int)e;
+        if (SORT) llist[pos] = (int)e;
+        else out[pos] = (int)e;
     }
+    if (!SORT) {
+        for (int r = t; r < rows; r += 1024) flags[r] = 0;
+        return;
+    }
+    __syncthreads();                                              // cnt[r] is now the END of segment r
+    constexpr int kMid = 128, kCap = 1536;                        // 16-lane groups up to kMid entries, waves beyond
+    __shared__ int nmid, nlong;
+    __shared__ int wmid[kCap], wlong[kCap / 4];
+    if (t == 0) { nmid = 0; nlong = 0; }
+    __syncthreads();
+    for (int r = t; r < rows; r += 1024) {
+        const int end = cnt[r], beg = r ? cnt[r - 1] : 0;
+        const int len = end - beg;
+        bool done = true;
+        if (len <= kSegSortThread) {
+            for (int a = beg + 1; a < end; ++a) {
+                const int v = llist[a];
+                int p = a - 1;
+                while (p >= beg && llist[p] > v) { llist[p + 1] = llist[p]; --p; }
+                llist[p + 1] = v;
+            }
+        } else if (len <= kMid) {
+            const int slot = atomicAdd(&nmid, 1);
+            done = slot < kCap;
+            if (done) wmid[slot] = r;
+        } else if (len <= kSegSortMax) {
+            const int slot = atomicAdd(&nlong, 1);
+            done = slot < kCap / 4;
+            if (done) wlong[slot] = r;
+        } else {
+            done = false;
+        }
+        flags[r] = done;                                          // unsorted rows take the fixed-point two-pass sum
+    }
+    __syncthreads();
+    const int n_mid = min(nmid, kCap), n_long = min(nlong, kCap / 4);
+    for (int base = 0; base < n_mid; base += 64) {               // 64 groups of 16 lanes per trip
+        const int li = base + (t >> 4);
+        int beg = 0, len = 0;
+        if (li < n_mid) { const int r = wmid[li]; beg = r ? cnt[r - 1] : 0; len = cnt[r] - beg; }
+        seg_rank_sort<16, kMid / 16>(llist, beg, len, t & 15);
+    }
+    for (int base = 0; base < n_long; base += 16) {              // one wave per segment
+        const int li = base + w;
+        int beg = 0, len = 0;
+        if (li < n_long) { const int r = wlong[li]; beg = r ? cnt[r - 1] : 0; len = cnt[r] - beg; }
+        seg_rank_sort<64, kSegSortMax / 64>(llist, beg, len, lane);
+    }
+    __syncthreads();
+    for (long long e = t; e < entries; e += 1024) out[e] = llist[e];
 }
 
 // fixed-point helpers (per element): 2^ex > |m|; shift k = 62 - logcount - ex
@@ -159,6 +251,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_reduce_kernel(long long out_r
                                                                  const float *__restrict__ grad_out,
                                                                  const float *__restrict__ weight,
                                                                  const int *__restrict__ start,
+                                                                 const int *__restrict__ sorted,
                                                                  const int *__restrict__ list,
                                                                  float *__restrict__ out)
 {
@@ -183,6 +276,9 @@ __global__ __launch_bounds__(kSegThreads) void seg_reduce_kernel(long long out_r
         const int len = end - beg;
         int logc = 0;
         while ((1 << logc) < len) ++logc;
+        // a sorted segment summed in order is already reproducible (and equals the reference's CPU sum):
+        // the fixed-point second pass is only for long, unsorted segments
+        const bool two_pass = DET && !sorted[row];
 
         for (int cc0 = 0; __any(cc0 < c); cc0 += LPR * CH) {
             const int cc = cc0 + gl * CH;
@@ -196,14 +292,16 @@ __global__ __launch_bounds__(kSegThreads) void seg_reduce_kernel(long long out_r
 #pragma unroll
             for (int q = 0; q < CH; ++q) { acc[q] = 0.0f; mx[q] = 0u; fx[q] = 0; k[q] = 0; sc[q] = 1.0; }
             // pass 0: plain sum (and, for DET, the largest |addend|); pass 1 (DET only): fixed-point sum
-            for (int pass = 0; pass < (DET ? 2 : 1); ++pass) {
+            for (int pass = 0; __any(pass < (two_pass ? 2 : 1)); ++pass) {
+                const bool pass_on = pass < (two_pass ? 2 : 1);
                 if (DET && pass == 1) {
 #pragma unroll
                     for (int q = 0; q < CH; ++q) { k[q] = seg_shift(__uint_as_float(mx[q]), logc); sc[q] = ldexp(1.0, k[q]); }
                 }
-                for (int p0 = 0; __any(p0 < len); p0 += LPR) {
-                    const int mine = (p0 + gl < len) ? seg[beg + p0 + gl] : 0;      // this lane's entry of the chunk
-                    const int chunk = min(LPR, len - p0);
+                const int plen = pass_on ? len : 0;
+                for (int p0 = 0; __any(p0 < plen); p0 += LPR) {
+                    const int mine = (p0 + gl < plen) ? seg[beg + p0 + gl] : 0;     // this lane's entry of the chunk
+                    const int chunk = min(LPR, plen - p0);
                     for (int j0 = 0; __any(j0 < chunk); j0 += UNR) {
                         float a[UNR][CH];
                         float wv[UNR];
@@ -243,7 +341,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_reduce_kernel(long long out_r
                 float res[CH];
 #pragma unroll
                 for (int q = 0; q < CH; ++q)                        // non-finite addends: the fp32 sum propagates them
-                    res[q] = (!DET || mx[q] >= 0x7f800000u) ? acc[q] : (float)ldexp((double)fx[q], -k[q]);
+                    res[q] = (!two_pass || mx[q] >= 0x7f800000u) ? acc[q] : (float)ldexp((double)fx[q], -k[q]);
                 float *o = out + row * c + cc;
                 if (VEC4) *reinterpret_cast<float4 *>(o) = make_float4(res[0], res[1], res[2], res[3]);
                 else o[0] = res[0];
@@ -264,9 +362,9 @@ static void launch_reduce(long long out_rows, int rows, long long entries, int c
 #define PN2_SEG_CASE(L)                                                                                              \
     if (lpr == L) {                                                                                                  \
         if (vec4) hipLaunchKernelGGL((seg_reduce_kernel<L, true, DET, SRC_DIV>), dim3(seg_grid(threads)), dim3(kSegThreads), 0, st, \
-                                     out_rows, rows, entries, c, grad_out, weight, w.start, w.list, out);            \
+                                     out_rows, rows, entries, c, grad_out, weight, w.start, w.sorted, w.list, out);            \
         else hipLaunchKernelGGL((seg_reduce_kernel<L, false, DET, SRC_DIV>), dim3(seg_grid(threads)), dim3(kSegThreads), 0, st, \
-                                out_rows, rows, entries, c, grad_out, weight, w.start, w.list, out);                 \
+                                out_rows, rows, entries, c, grad_out, weight, w.start, w.sorted, w.list, out);                 \
         return;                                                                                                      \
     }
     PN2_SEG_CASE(1) PN2_SEG_CASE(2) PN2_SEG_CASE(4) PN2_SEG_CASE(8) PN2_SEG_CASE(16) PN2_SEG_CASE(32) PN2_SEG_CASE(64)
@@ -282,15 +380,18 @@ static int seg_grad(int b, int rows, long long entries, int c, const float *grad
     const long long total = (long long)b * entries;
     if (rows <= kSegLdsRows && b >= 4) {
         // enough clouds to spread over CUs: the whole inversion of a cloud in one workgroup, LDS counters
-        const size_t lds = sizeof(int) * (size_t)rows;
+        const size_t with_list = sizeof(int) * ((size_t)rows + (size_t)entries);
+        const bool sort = deterministic && with_list <= 144 * 1024;   // + 8 KiB static for the long-row lists
+        const size_t lds = sort ? with_list : sizeof(int) * (size_t)rows;
+        auto kern = sort ? seg_invert_lds_kernel<true> : seg_invert_lds_kernel<false>;
         if (lds > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(seg_invert_lds_kernel),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
-        hipLaunchKernelGGL(seg_invert_lds_kernel, dim3(b), dim3(1024), lds, st, entries, rows, idx, w.start, w.list);
+        hipLaunchKernelGGL(kern, dim3(b), dim3(1024), lds, st, entries, rows, idx, w.start, w.sorted, w.list);
     } else {
-    hipError_t e = hipMemsetAsync(w.cursor, 0, sizeof(int) * (size_t)b * rows, st);
+    hipError_t e = hipMemsetAsync(w.cursor, 0, 2 * sizeof(int) * (size_t)b * rows, st);   // counters and sorted flags
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(seg_count_kernel, dim3(seg_grid(total)), dim3(kSegThreads), 0, st, total, entries, rows, idx, w.cursor);
     hipLaunchKernelGGL(seg_scan_kernel, dim3(b), dim3(1024), 0, st, rows, w.start, w.cursor);
@@ -307,7 +408,7 @@ static int seg_grad(int b, int rows, long long entries, int c, const float *grad
 extern "C" long long pn2_seg_grad_ws_bytes(int b, int rows, long long entries)
 {
     if (b <= 0 || rows <= 0 || entries < 0) return 16;
-    return (long long)sizeof(int) * ((long long)b * (rows + 1) + (long long)b * rows + (long long)b * entries) + 16;
+    return (long long)sizeof(int) * ((long long)b * (rows + 1) + 2ll * b * rows + (long long)b * entries) + 16;
 }
 
 extern "C" int pn2_group_point_grad_seg(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
