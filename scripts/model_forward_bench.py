@@ -1,0 +1,107 @@
+"""End-to-end inference forward of the reference network topologies built from pointnet2_amd's modules
+(models/pointnet2_cls_ssg.py, models/pointnet2_sem_seg.py: same SA/FP levels, random weights): time per
+forward with the fused MFMA MLPs on/off, eager and as a HIP graph. Measurement aid for the callers of
+the hot path; the networks themselves are outside this repository's scope."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn as nn
+
+import pointnet2_amd.pointnet_util as U
+from pointnet2_amd import synthetic as S
+
+dev = torch.device("cuda:0")
+
+
+class ClsSSG(nn.Module):                      # models/pointnet2_cls_ssg.py:20-45
+    def __init__(self):
+        super().__init__()
+        self.sa1 = U.PointnetSAModule(0, 512, 0.2, 32, [64, 64, 128])
+        self.sa2 = U.PointnetSAModule(128, 128, 0.4, 64, [128, 128, 256])
+        self.sa3 = U.PointnetSAModule(256, None, None, None, [256, 512, 1024], group_all=True)
+        self.fc = nn.Sequential(nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.ReLU(), nn.Linear(512, 256),
+                                nn.BatchNorm1d(256), nn.ReLU(), nn.Linear(256, 40))
+
+    def forward(self, xyz):
+        x1, f1, _ = self.sa1(xyz, None)
+        x2, f2, _ = self.sa2(x1, f1)
+        _, f3, _ = self.sa3(x2, f2)
+        return self.fc(f3.reshape(xyz.shape[0], -1))
+
+
+class SemSeg(nn.Module):                      # models/pointnet2_sem_seg.py:20-50
+    def __init__(self, classes=21):
+        super().__init__()
+        self.sa1 = U.PointnetSAModule(0, 1024, 0.1, 32, [32, 32, 64])
+        self.sa2 = U.PointnetSAModule(64, 256, 0.2, 32, [64, 64, 128])
+        self.sa3 = U.PointnetSAModule(128, 64, 0.4, 32, [128, 128, 256])
+        self.sa4 = U.PointnetSAModule(256, 16, 0.8, 32, [256, 256, 512])
+        self.fp1 = U.PointnetFPModule(512 + 256, [256, 256])
+        self.fp2 = U.PointnetFPModule(256 + 128, [256, 256])
+        self.fp3 = U.PointnetFPModule(256 + 64, [256, 128])
+        self.fp4 = U.PointnetFPModule(128, [128, 128, 128])
+        self.head = nn.Sequential(nn.Conv1d(128, 128, 1), nn.BatchNorm1d(128), nn.ReLU(), nn.Conv1d(128, classes, 1))
+
+    def forward(self, xyz):
+        x1, f1, _ = self.sa1(xyz, None)
+        x2, f2, _ = self.sa2(x1, f1)
+        x3, f3, _ = self.sa3(x2, f2)
+        x4, f4, _ = self.sa4(x3, f3)
+        g3 = self.fp1(x3, x4, f3, f4)
+        g2 = self.fp2(x2, x3, f2, g3)
+        g1 = self.fp3(x1, x2, f1, g2)
+        g0 = self.fp4(xyz, x1, None, g1)
+        return self.head(g0.permute(0, 2, 1))
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def set_fused(model, flag):
+    for mod in model.modules():
+        if hasattr(mod, "fused_mlp"):
+            mod.fused_mlp = flag
+
+
+def main():
+    torch.manual_seed(0)
+    for name, model, b, n in [("pointnet2_cls_ssg B=16 N=1024", ClsSSG(), 16, 1024),
+                              ("pointnet2_sem_seg B=8 N=8192", SemSeg(), 8, 8192)]:
+        model = model.to(dev).eval()
+        xyz = torch.from_numpy(S.sphere_clouds(b, n, 1)).to(dev)
+        with torch.no_grad():
+            set_fused(model, False)
+            ref = model(xyz)
+            t_unfused = timeit(lambda: model(xyz))
+            set_fused(model, True)
+            out = model(xyz)
+            err = (out - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+            t_fused = timeit(lambda: model(xyz))
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                model(xyz)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                model(xyz)
+            t_graph = timeit(graph.replay)
+        paths = [m.last_path for m in model.modules() if hasattr(m, "last_path")]
+        print("%-32s unfused %7.3f ms | fused MLPs %7.3f ms | fused + HIP graph %7.3f ms | rel. diff %.1e | SA paths %s"
+              % (name, t_unfused, t_fused, t_graph, err, paths), flush=True)
+
+
+if __name__ == "__main__":
+    main()
