@@ -76,6 +76,14 @@ int pn2_query_ball_point(int b, int n, int m, float radius, int nsample, const f
  * dist (b,m,n) -> outi (b,m,n) i32, out (b,m,n) f32; the first k of each row are the k smallest, ascending */
 int pn2_selection_sort(int b, int n, int m, int k, const float *dist, int *outi, float *out, void *stream);
 
+/* knn_point (tf_grouping.py:48-73) in one kernel, without the (b,m,n) distance/index tensors: the distance
+ * row ((dx*dx)+(dy*dy))+(dz*dz) of a query is built in LDS, the same k swap rounds as selectionSortLauncher
+ * run on it, and only the first k (value, index) pairs are written -- identical to slicing the reference's
+ * outputs, ties included. xyz1 (b,n,3), xyz2 (b,m,3) -> val (b,m,k) f32, idx (b,m,k) i32.
+ * PN2_E_TOO_LARGE for n > 16384 or k > n (callers keep the matrix + pn2_selection_sort path). */
+int pn2_knn_point(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
+                  void *stream);
+
 /* replaces groupPointLauncher(b,n,c,m,nsample,points,idx,out)  tf_grouping.cpp:142, tf_grouping_g.cu:133-136
  * points (b,n,c), idx (b,m,nsample) -> out (b,m,nsample,c) */
 int pn2_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx, float *out,

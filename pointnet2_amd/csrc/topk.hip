@@ -66,6 +66,57 @@ __global__ __launch_bounds__(64) void selection_sort_wave_kernel(int n, int k, c
     for (int s = lane; s < n; s += 64) { out[row * n + s] = val[s]; outi[row * n + s] = ind[s]; }
 }
 
+// knn_point without the (b, m, n) tensors. The reference builds the pairwise
+// squared-distance matrix in TF (tf_grouping.py:57-65: tile, subtract, square, reduce_sum -- three
+// (b,m,n,c)/(b,m,n) tensors, ~0.5 GB each at the metric shape), runs the selection sort above on it and
+// slices the first k columns. Here a wave computes its query's distance row straight into LDS
+// (((dx*dx)+(dy*dy))+(dz*dz), d = xyz1 - xyz2, no FMA: the values the elementwise graph produces), runs
+// the SAME k swap rounds on it -- so ties come out in the reference's swap-dependent order, not in index
+// order -- and writes only the k results.
+__global__ __launch_bounds__(64) void knn_wave_kernel(int n, int m, int k, const float *__restrict__ xyz1,
+                                                      const float *__restrict__ xyz2, float *__restrict__ oval,
+                                                      int *__restrict__ oidx)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *val = reinterpret_cast<float *>(smem);
+    int *ind = reinterpret_cast<int *>(smem + sizeof(float) * (size_t)n);
+    const size_t row = blockIdx.x;                               // query number over all clouds
+    const size_t cloud = row / m;
+    const int lane = threadIdx.x;
+    const float *pts = xyz1 + cloud * n * 3;
+    const float qx = xyz2[row * 3 + 0], qy = xyz2[row * 3 + 1], qz = xyz2[row * 3 + 2];
+    for (int s = lane; s < n; s += 64) {
+        val[s] = sqdist(pts[s * 3 + 0], pts[s * 3 + 1], pts[s * 3 + 2], qx, qy, qz);
+        ind[s] = s;
+    }
+    __syncthreads();
+    const int rounds = min(k, n);
+    for (int s = 0; s < rounds; ++s) {
+        unsigned long long best = ~0ull;
+        for (int t = s + lane; t < n; t += 64) {
+            const unsigned long long key = ((unsigned long long)orderable(val[t]) << 32) | (unsigned)t;
+            best = key < best ? key : best;
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)best, o, 64);
+            const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(best >> 32), o, 64);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            best = other < best ? other : best;
+        }
+        const int mn = (int)(unsigned)best;
+        if (lane == 0 && mn != s) {
+            const float tv = val[mn]; val[mn] = val[s]; val[s] = tv;
+            const int ti = ind[mn]; ind[mn] = ind[s]; ind[s] = ti;
+        }
+        __syncthreads();
+    }
+    for (int s = lane; s < k; s += 64) {                         // k > n: the tail is the untouched row, as in the slice
+        oval[row * k + s] = s < n ? val[s] : 0.0f;
+        oidx[row * k + s] = s < n ? ind[s] : 0;
+    }
+}
+
 // fallback for very long rows: the reference's own mapping (one thread per row)
 __global__ __launch_bounds__(64) void selection_sort_serial_kernel(long long rows, int n, int k,
                                                                    const float *__restrict__ dist,
@@ -116,5 +167,27 @@ extern "C" int pn2_selection_sort(int b, int n, int m, int k, const float *dist,
         hipLaunchKernelGGL(selection_sort_serial_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, rows, n,
                            k, dist, outi, out);
     }
+    return launch_status();
+}
+
+extern "C" int pn2_knn_point(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
+                             void *stream)
+{
+    using namespace pn2;
+    if (k <= 0) return PN2_E_ARG;                       // tf_grouping.cpp:113
+    if (b < 0 || n <= 0 || m < 0) return PN2_E_SHAPE;
+    const long long rows = (long long)b * m;
+    if (rows == 0) return PN2_OK;
+    if (!xyz1 || !xyz2 || !val || !idx) return PN2_E_NULL;
+    if (rows > INT_MAX || k > n) return PN2_E_TOO_LARGE;   // k > n: tf.slice would fail in the reference as well
+    if (n > kSortMaxLdsN) return PN2_E_TOO_LARGE;           // callers keep the matrix + pn2_selection_sort path
+    const size_t lds = 8 * (size_t)n;
+    auto kern = knn_wave_kernel;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(64), lds, as_stream(stream), n, m, k, xyz1, xyz2, val, idx);
     return launch_status();
 }

@@ -184,13 +184,26 @@ def knn_point(k, xyz1, xyz2):
 
     reference: tf_grouping.py:48-73 -- a pairwise squared-distance matrix
     reduce_sum((xyz1-xyz2)**2, -1) followed by select_top_k and a slice.
-    The matrix is built with torch elementwise ops (same per-pair arithmetic:
-    differences, squares, a sum over c), the selection is the HIP selection sort.
+    For 3-D points (every use in the reference) this is ONE kernel that never materialises the matrix
+    (pn2_knn_point); other channel counts build the matrix with torch elementwise ops (same per-pair
+    arithmetic: differences, squares, a left-to-right sum over c) and run the HIP selection sort.
     """
     xyz1 = f32(xyz1.detach(), "xyz1")
     xyz2 = f32(xyz2.detach(), "xyz2")
     require(xyz1.dim() == 3 and xyz2.dim() == 3 and xyz1.shape[0] == xyz2.shape[0] and
             xyz1.shape[2] == xyz2.shape[2], "knn_point expects (b,n,c) xyz1 and (b,m,c) xyz2")
+    b, n, c = xyz1.shape
+    m = xyz2.shape[1]
+    require(int(k) > 0, "SelectionSort expects positive k")
+    if c == 3 and n <= 16384 and int(k) <= n:
+        # one kernel, no (b, m, n) tensors: the distance row lives in LDS (csrc/topk.hip, pn2_knn_point)
+        dev = same_device(xyz1, xyz2)
+        val = torch.empty((b, m, int(k)), dtype=torch.float32, device=dev)
+        idx = torch.empty((b, m, int(k)), dtype=torch.int32, device=dev)
+        with on_device(dev):
+            _C.check(_C.lib().pn2_knn_point(b, n, m, int(k), ptr(xyz1), ptr(xyz2), ptr(val), ptr(idx), stream_ptr(dev)),
+                     "knn_point")
+        return val, idx
     diff = xyz1.unsqueeze(1) - xyz2.unsqueeze(2)           # (b, m, n, c)
     sq = diff * diff
     dist = sq[..., 0].clone()

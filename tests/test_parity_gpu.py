@@ -334,6 +334,28 @@ def test_knn_point(cuda, oracle):
     assert (host(val)[:, :, 0] == 0).all()                        # each query is its own nearest neighbour
 
 
+def test_knn_point_native_ties_and_shapes(cuda, oracle):
+    """pn2_knn_point against the matrix + selection-sort definition, on clouds full of exactly tied
+    distances (duplicated points, lattices): the swap rounds decide the order among ties."""
+    import pointnet2_amd as P
+    rng = np.random.default_rng(5)
+    for gen, b, n, m, k in [(S.duplicated_clouds, 2, 500, 37, 16), (S.lattice_clouds, 2, 300, 25, 32),
+                            (S.identical_clouds, 1, 100, 7, 9), (S.sphere_clouds, 3, 2048, 50, 64),
+                            (S.uniform_clouds, 1, 5000, 20, 5), (S.dropout_clouds, 2, 400, 30, 400)]:
+        xyz1 = gen(b, n, 7)
+        pick = rng.integers(0, n, size=(b, m))
+        xyz2 = np.take_along_axis(xyz1, pick[:, :, None].repeat(3, axis=2), axis=1).copy()
+        xyz2[:, ::2] += rng.normal(0, 0.05, size=xyz2[:, ::2].shape).astype(np.float32)
+        val, idx = P.knn_point(k, dev(xyz1, cuda), dev(xyz2, cuda))
+        dx = xyz1[:, None, :, 0] - xyz2[:, :, None, 0]
+        dy = xyz1[:, None, :, 1] - xyz2[:, :, None, 1]
+        dz = xyz1[:, None, :, 2] - xyz2[:, :, None, 2]
+        d = ((dx * dx + dy * dy) + dz * dz).astype(np.float32)
+        wi, wo = oracle.select_top_k(k, d)
+        assert np.array_equal(host(idx), wi[:, :, :k]), (gen.__name__, b, n, m, k)
+        assert np.array_equal(host(val), wo[:, :, :k]), (gen.__name__, b, n, m, k)
+
+
 # ------------------------------------------------------------------ prob_sample
 def test_prob_sample_exact(cuda, oracle):
     import pointnet2_amd as P
