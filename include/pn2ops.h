@@ -80,7 +80,7 @@ int pn2_selection_sort(int b, int n, int m, int k, const float *dist, int *outi,
  * row ((dx*dx)+(dy*dy))+(dz*dz) of a query is built in LDS, the same k swap rounds as selectionSortLauncher
  * run on it, and only the first k (value, index) pairs are written -- identical to slicing the reference's
  * outputs, ties included. xyz1 (b,n,3), xyz2 (b,m,3) -> val (b,m,k) f32, idx (b,m,k) i32.
- * PN2_E_TOO_LARGE for n > 16384 or k > n (callers keep the matrix + pn2_selection_sort path). */
+ * PN2_E_TOO_LARGE for n > 14336 or k > n (callers keep the matrix + pn2_selection_sort path). */
 int pn2_knn_point(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
                   void *stream);
 

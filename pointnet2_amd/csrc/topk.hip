@@ -70,50 +70,155 @@ __global__ __launch_bounds__(64) void selection_sort_wave_kernel(int n, int k, c
 // squared-distance matrix in TF (tf_grouping.py:57-65: tile, subtract, square, reduce_sum -- three
 // (b,m,n,c)/(b,m,n) tensors, ~0.5 GB each at the metric shape), runs the selection sort above on it and
 // slices the first k columns. Here a wave computes its query's distance row straight into LDS
-// (((dx*dx)+(dy*dy))+(dz*dz), d = xyz1 - xyz2, no FMA: the values the elementwise graph produces), runs
-// the SAME k swap rounds on it -- so ties come out in the reference's swap-dependent order, not in index
-// order -- and writes only the k results.
+// (((dx*dx)+(dy*dy))+(dz*dz), d = xyz1 - xyz2, no FMA: the values the elementwise graph produces) and
+// reproduces the first k outputs of the swap rounds -- ties come out in the reference's swap-dependent
+// order, not in index order -- WITHOUT scanning the whole row k times:
+//   * only elements with value <= v_k (the k-th smallest) can ever be selected, and a swap only moves
+//     the element sitting at slot s to the slot of the selected one. So the rounds can be replayed on the
+//     candidate set C = {value <= tau} for any tau >= v_k, tracking each candidate's CURRENT slot: round s
+//     picks the candidate with the smallest (value, current slot); if another candidate sits at slot s it
+//     inherits the winner's slot. Non-candidates move around too, but nothing ever looks at them.
+//   * tau comes from two 256-bin histogram passes over the row (top 16 bits of the order-preserving key:
+//     exponent + 8 mantissa bits), i.e. v_k rounded up by < 0.4 %: |C| is k plus a handful.
+//   * |C| > kKnnCap (clouds of identical points) falls back to the literal rounds on the row.
+constexpr int kKnnCap = 1024;
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, o, 64);
+        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o, 64);
+        const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+        v = other < v ? other : v;
+    }
+    return v;
+}
+
+// the 256-bin histogram in `hist` (lane l owns bins 4l..4l+3): bin in which the cumulative count reaches
+// `want` (1-based), and the count before that bin
+__device__ __forceinline__ void knn_find_bin(const int *hist, int lane, int want, int &bin, int &before)
+{
+    const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+    const int mine = h0 + h1 + h2 + h3;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    const int excl = incl - mine;
+    const bool here = excl < want && want <= incl;               // exactly one lane (want <= total)
+    int b = 0, bef = excl;
+    if (here) {
+        if (want <= excl + h0) { b = 0; }
+        else if (want <= excl + h0 + h1) { b = 1; bef = excl + h0; }
+        else if (want <= excl + h0 + h1 + h2) { b = 2; bef = excl + h0 + h1; }
+        else { b = 3; bef = excl + h0 + h1 + h2; }
+    }
+    const unsigned long long m = __ballot(here);
+    const int src = m ? __builtin_ctzll(m) : 0;
+    bin = __shfl(4 * lane + b, src);
+    before = __shfl(bef, src);
+}
+
 __global__ __launch_bounds__(64) void knn_wave_kernel(int n, int m, int k, const float *__restrict__ xyz1,
                                                       const float *__restrict__ xyz2, float *__restrict__ oval,
                                                       int *__restrict__ oidx)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *val = reinterpret_cast<float *>(smem);
-    int *ind = reinterpret_cast<int *>(smem + sizeof(float) * (size_t)n);
+    float *val = reinterpret_cast<float *>(smem);                                  // [n]  the distance row
+    int *ind = reinterpret_cast<int *>(smem + sizeof(float) * (size_t)n);          // [n]  only for the fallback
+    int *hist = ind + n;                                                           // [256]
+    unsigned *ckey = reinterpret_cast<unsigned *>(hist + 256);                     // [kKnnCap] order-preserving value key
+    int *cpos = reinterpret_cast<int *>(ckey + kKnnCap);                           // [kKnnCap] current slot
+    int *cidx = cpos + kKnnCap;                                                    // [kKnnCap] original index
     const size_t row = blockIdx.x;                               // query number over all clouds
     const size_t cloud = row / m;
     const int lane = threadIdx.x;
     const float *pts = xyz1 + cloud * n * 3;
     const float qx = xyz2[row * 3 + 0], qy = xyz2[row * 3 + 1], qz = xyz2[row * 3 + 2];
+    for (int s = lane; s < n; s += 64) val[s] = sqdist(pts[s * 3 + 0], pts[s * 3 + 1], pts[s * 3 + 2], qx, qy, qz);
+    const int rounds = min(k, n);
+
+    // ---- tau: upper edge of the 16-bit key prefix that holds the k-th smallest value -------------------
+    for (int i = lane; i < 256; i += 64) hist[i] = 0;
+    __syncthreads();
+    for (int s = lane; s < n; s += 64) atomicAdd(&hist[orderable(val[s]) >> 24], 1);
+    __syncthreads();
+    int b1, before1;
+    knn_find_bin(hist, lane, rounds, b1, before1);
+    __syncthreads();
+    for (int i = lane; i < 256; i += 64) hist[i] = 0;
+    __syncthreads();
     for (int s = lane; s < n; s += 64) {
-        val[s] = sqdist(pts[s * 3 + 0], pts[s * 3 + 1], pts[s * 3 + 2], qx, qy, qz);
-        ind[s] = s;
+        const unsigned key = orderable(val[s]);
+        if ((int)(key >> 24) == b1) atomicAdd(&hist[(key >> 16) & 255], 1);
     }
     __syncthreads();
-    const int rounds = min(k, n);
-    for (int s = 0; s < rounds; ++s) {
-        unsigned long long best = ~0ull;
-        for (int t = s + lane; t < n; t += 64) {
-            const unsigned long long key = ((unsigned long long)orderable(val[t]) << 32) | (unsigned)t;
-            best = key < best ? key : best;
-        }
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)best, o, 64);
-            const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(best >> 32), o, 64);
-            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
-            best = other < best ? other : best;
-        }
-        const int mn = (int)(unsigned)best;
-        if (lane == 0 && mn != s) {
-            const float tv = val[mn]; val[mn] = val[s]; val[s] = tv;
-            const int ti = ind[mn]; ind[mn] = ind[s]; ind[s] = ti;
-        }
-        __syncthreads();
+    int b2, before2;
+    knn_find_bin(hist, lane, rounds - before1, b2, before2);
+    const unsigned tau = ((unsigned)b1 << 24) | ((unsigned)b2 << 16) | 0xffffu;
+
+    // ---- candidates, in ascending slot order --------------------------------------------------------------
+    int total = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int s = base + lane;
+        const unsigned key = s < n ? orderable(val[s]) : 0xffffffffu;
+        const bool in = s < n && key <= tau;
+        const unsigned long long mask = __ballot(in);
+        const int slot = total + __popcll(mask & ((1ull << lane) - 1ull));
+        if (in && slot < kKnnCap) { ckey[slot] = key; cpos[slot] = s; cidx[slot] = s; }
+        total += __popcll(mask);
     }
-    for (int s = lane; s < k; s += 64) {                         // k > n: the tail is the untouched row, as in the slice
-        oval[row * k + s] = s < n ? val[s] : 0.0f;
-        oidx[row * k + s] = s < n ? ind[s] : 0;
+    __syncthreads();
+
+    if (total <= kKnnCap) {
+        // ---- the swap rounds replayed on the candidates ----------------------------------------------------
+        for (int s = 0; s < rounds; ++s) {
+            unsigned long long best = ~0ull;
+            int bslot = 0;
+            for (int c = lane; c < total; c += 64) {
+                const unsigned long long key = ((unsigned long long)ckey[c] << 32) | (unsigned)cpos[c];
+                if (key < best) { best = key; bslot = c; }
+            }
+            const unsigned long long win = wave_min_u64(best);    // (value, current slot): unique among live candidates
+            const int q = (int)(unsigned)win;                     // the winner's current slot
+            if (best == win) {                                    // exactly one lane holds the winner
+                const int orig = cidx[bslot];
+                oval[row * k + s] = val[orig];
+                oidx[row * k + s] = orig;
+                ckey[bslot] = 0xffffffffu;                        // dead: never wins again (live keys are <= tau < this)
+                cpos[bslot] = 0x7fffffff;
+            }
+            __syncthreads();
+            if (q != s) {                                         // the element sitting at slot s moves to slot q
+                for (int c = lane; c < total; c += 64)
+                    if (cpos[c] == s && ckey[c] != 0xffffffffu) cpos[c] = q;
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---- too many ties: the literal rounds on the whole row --------------------------------------------
+        for (int s = lane; s < n; s += 64) ind[s] = s;
+        __syncthreads();
+        for (int s = 0; s < rounds; ++s) {
+            unsigned long long best = ~0ull;
+            for (int t = s + lane; t < n; t += 64) {
+                const unsigned long long key = ((unsigned long long)orderable(val[t]) << 32) | (unsigned)t;
+                best = key < best ? key : best;
+            }
+            const int mn = (int)(unsigned)wave_min_u64(best);
+            if (lane == 0 && mn != s) {
+                const float tv = val[mn]; val[mn] = val[s]; val[s] = tv;
+                const int ti = ind[mn]; ind[mn] = ind[s]; ind[s] = ti;
+            }
+            __syncthreads();
+        }
+        for (int s = lane; s < rounds; s += 64) {
+            oval[row * k + s] = val[s];
+            oidx[row * k + s] = ind[s];
+        }
     }
 }
 
@@ -180,8 +285,8 @@ extern "C" int pn2_knn_point(int b, int n, int m, int k, const float *xyz1, cons
     if (rows == 0) return PN2_OK;
     if (!xyz1 || !xyz2 || !val || !idx) return PN2_E_NULL;
     if (rows > INT_MAX || k > n) return PN2_E_TOO_LARGE;   // k > n: tf.slice would fail in the reference as well
-    if (n > kSortMaxLdsN) return PN2_E_TOO_LARGE;           // callers keep the matrix + pn2_selection_sort path
-    const size_t lds = 8 * (size_t)n;
+    if (n > kSortMaxLdsN - 2048) return PN2_E_TOO_LARGE;    // callers keep the matrix + pn2_selection_sort path
+    const size_t lds = 8 * (size_t)n + sizeof(int) * (256 + 3 * (size_t)kKnnCap);
     auto kern = knn_wave_kernel;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

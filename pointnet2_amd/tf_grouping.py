@@ -195,7 +195,7 @@ def knn_point(k, xyz1, xyz2):
     b, n, c = xyz1.shape
     m = xyz2.shape[1]
     require(int(k) > 0, "SelectionSort expects positive k")
-    if c == 3 and n <= 16384 and int(k) <= n:
+    if c == 3 and n <= 14336 and int(k) <= n:
         # one kernel, no (b, m, n) tensors: the distance row lives in LDS (csrc/topk.hip, pn2_knn_point)
         dev = same_device(xyz1, xyz2)
         val = torch.empty((b, m, int(k)), dtype=torch.float32, device=dev)

@@ -341,7 +341,9 @@ def test_knn_point_native_ties_and_shapes(cuda, oracle):
     rng = np.random.default_rng(5)
     for gen, b, n, m, k in [(S.duplicated_clouds, 2, 500, 37, 16), (S.lattice_clouds, 2, 300, 25, 32),
                             (S.identical_clouds, 1, 100, 7, 9), (S.sphere_clouds, 3, 2048, 50, 64),
-                            (S.uniform_clouds, 1, 5000, 20, 5), (S.dropout_clouds, 2, 400, 30, 400)]:
+                            (S.uniform_clouds, 1, 5000, 20, 5), (S.dropout_clouds, 2, 400, 30, 400),
+                            (S.identical_clouds, 1, 2000, 6, 12), (S.dropout_clouds, 1, 3000, 9, 100),
+                            (S.lattice_clouds, 1, 4000, 11, 70)]:
         xyz1 = gen(b, n, 7)
         pick = rng.integers(0, n, size=(b, m))
         xyz2 = np.take_along_axis(xyz1, pick[:, :, None].repeat(3, axis=2), axis=1).copy()
