@@ -265,10 +265,6 @@ static int launch_mlp(int b, int n, int m, int nsample, int cfeat, int c3, const
     return launch_status();
 }
 
-}  // namespace pn2
-
-using namespace pn2;
-
 // Which kernel runs a stack: the resident one when the input is narrow and the weights fit in LDS,
 // else the streamed one (sa_mlp_stream.hip). kind: 0 resident, 1 streamed.
 static bool mlp_choose(int cin, int c1, int c2, int c3, int nsample, int &kind, MlpConfig &rc, MlpStreamConfig &sc)
@@ -283,6 +279,8 @@ static bool mlp_choose(int cin, int c1, int c2, int c3, int nsample, int &kind, 
     }
     return false;
 }
+
+}  // namespace pn2
 
 extern "C" int pn2_sa_mlp3_config(int cin, int c1, int c2, int c3, int nsample, int *info4, long long *w_floats,
                                   long long *b_floats)

@@ -83,9 +83,11 @@ def sa_mlp_maxpool(xyz, new_xyz, points, idx, packed):
         points = f32(points.detach(), "points")
         cfeat = points.shape[2]
     require(3 + cfeat == packed.cin, "packed MLP expects %d input channels, got %d" % (packed.cin, 3 + cfeat))
-    require(ns == packed.nsample or (ns != 16 and packed.nsample != 16 and packed.kind == "streamed") or
-            (packed.kind == "resident" and _same_kernel(packed, ns)),
-            "packed for nsample=%d, called with %d" % (packed.nsample, ns))
+    # the packed layout belongs to the kernel pn2_sa_mlp3_config chose for packed.nsample; another nsample
+    # is fine as long as the library would choose the same kernel for it
+    require(ns == packed.nsample or _same_kernel(packed, ns),
+            "weights were packed for nsample=%d (%s kernel); nsample=%d needs a different layout"
+            % (packed.nsample, packed.kind, ns))
     dev = same_device(xyz, new_xyz, idx, packed.wp) if points is None else same_device(xyz, new_xyz, idx, points, packed.wp)
     out = torch.empty((b, m, packed.widths[2]), dtype=torch.float32, device=dev)
     with on_device(dev):

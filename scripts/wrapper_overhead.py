@@ -1,0 +1,52 @@
+"""Where the ~13-18 us per operator call go (host side): checks, allocation, stream lookup, the ctypes
+call itself. Development aid."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import pointnet2_amd as P
+from pointnet2_amd import _C
+from pointnet2_amd._tensors import f32, i32, on_device, ptr, stream_ptr
+
+dev = torch.device("cuda:0")
+L = _C.lib()
+b, n, m, ns = 8, 256, 64, 32
+xyz = torch.rand(b, n, 3, device=dev)
+q = xyz[:, :m].contiguous()
+idx = torch.empty(b, m, ns, dtype=torch.int32, device=dev)
+cnt = torch.empty(b, m, dtype=torch.int32, device=dev)
+
+
+def host_us(fn, iters=2000):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    return (t1 - t0) / iters * 1e6
+
+
+print("f32() x2 checks           %.2f us" % host_us(lambda: (f32(xyz, "a"), f32(q, "b"))))
+print("torch.empty x2            %.2f us" % host_us(lambda: (torch.empty((b, m, ns), dtype=torch.int32, device=dev),
+                                                              torch.empty((b, m), dtype=torch.int32, device=dev))))
+print("stream_ptr                %.2f us" % host_us(lambda: stream_ptr(dev)))
+
+
+def ctx():
+    with on_device(dev):
+        pass
+
+
+print("on_device context         %.2f us" % host_us(ctx))
+st = stream_ptr(dev)
+print("raw ctypes launch         %.2f us" % host_us(lambda: L.pn2_query_ball_point(b, n, m, 0.2, ns, xyz.data_ptr(), q.data_ptr(),
+                                                                                      idx.data_ptr(), cnt.data_ptr(), st)))
+print("data_ptr x4               %.2f us" % host_us(lambda: (xyz.data_ptr(), q.data_ptr(), idx.data_ptr(), cnt.data_ptr())))
+print("full wrapper              %.2f us" % host_us(lambda: P.query_ball_point(0.2, ns, xyz, q)))
+print("full wrapper group_point  %.2f us" % host_us(lambda: P.group_point(xyz, idx)))
+print("torch op for scale (add)  %.2f us" % host_us(lambda: xyz + 1.0))

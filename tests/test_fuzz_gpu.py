@@ -1,6 +1,8 @@
 """Seeded random-shape fuzzing of every operator against the oracle (GPU). Shapes are drawn to hit
 the tier boundaries of the kernels (FPS register/LDS/generic tiers, ball-query LDS/no-LDS paths and
 bitmap windows, group vector/scalar paths, three_nn tiles) rather than only the BASELINE shapes."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -18,10 +20,10 @@ def _dev(a, cuda):
 
 def test_fuzz_fps_ball_group(cuda, oracle):
     import pointnet2_amd as P
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(int(os.environ.get("PN2_FUZZ_SEED", "2024")))
     n_choices = [1, 2, 63, 64, 65, 127, 500, 512, 513, 1000, 1024, 1025, 2047, 3000, 4096, 4100, 8191, 8192, 8200,
                  9599, 9601, 16384, 16385]
-    for it in range(40):
+    for it in range(int(os.environ.get("PN2_FUZZ_ITERS", "40"))):
         n = int(rng.choice(n_choices))
         b = int(rng.integers(1, 4 if n > 4096 else 7))
         m = int(min(max(1, rng.integers(1, 200)), 400))
@@ -52,8 +54,8 @@ def test_fuzz_fps_ball_group(cuda, oracle):
 
 def test_fuzz_three_nn_interpolate(cuda, oracle):
     import pointnet2_amd as P
-    rng = np.random.default_rng(77)
-    for it in range(30):
+    rng = np.random.default_rng(int(os.environ.get("PN2_FUZZ_SEED", "77")))
+    for it in range(int(os.environ.get("PN2_FUZZ_ITERS", "30"))):
         b = int(rng.integers(1, 5))
         n = int(rng.choice([1, 3, 63, 64, 65, 255, 1000, 2049, 5000]))
         m = int(rng.choice([1, 2, 3, 4, 15, 16, 17, 100, 2047, 2048, 2049, 4100]))
