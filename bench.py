@@ -157,6 +157,25 @@ def one_kernel_time(fn, reps=10):
     return float(np.median([s.elapsed_time(e) for s, e in evs])) * 1e-3
 
 
+def mlp_roofline(stage):
+    """EXTRA object (not part of `value`): the MFMA-bound kernel of the hot path's consumer, the fused
+    grouped MLP + max-pool (pn2_sa_mlp3_maxpool) on the SAME batch the step just produced
+    (idx of the metric shape, widths 64-64-128 as in the reference's first SA level). Useful FLOPs only,
+    against the dense fp32 MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s)."""
+    from pointnet2_amd import sa_mlp
+    rng = np.random.default_rng(0)
+    dims = (3, 64, 64, 128)
+    layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
+               (0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32)) for i in range(3)]
+    packed = sa_mlp.PackedMLP3(layers, stage.xyz.device, NS)
+    t = one_kernel_time(lambda: sa_mlp.sa_mlp_maxpool(stage.xyz, stage.new_xyz, None, stage.idx, packed))
+    flops = 2.0 * B * M * NS * (3 * 64 + 64 * 64 + 64 * 128)
+    return {"bound": "mfma", "kernel": "sa_mlp3_maxpool 3-64-64-128 on the step's idx (fp32 MFMA)", "achieved": flops / t / 1e12,
+            "peak": 157.3, "unit": "TFLOP/s", "frac": flops / t / 1e12 / 157.3, "us": t * 1e6,
+            "note": "HIP events around the Python call (~12 us of call overhead included); rocprofv3 + "
+                    "SQ_VALU_MFMA_BUSY_CYCLES in profiles/r01"}
+
+
 def concurrent_throughput(dev, rank, path, streams, steps):
     """EXTRA figure (not `value`): the same step on `streams` independent B=32 batches in flight on
     separate HIP streams. One FPS launch occupies 32 of the 256 CUs for its whole serial chain, so
@@ -299,6 +318,10 @@ def main():
                       "algorithmic_GBps": STAGE_BYTES * B / total_k / 1e9,
                       "frac_of_hbm_peak": STAGE_BYTES * B / total_k / 1e9 / HBM_PEAK_GBS},
         }
+        try:
+            line["mlp_roofline"] = mlp_roofline(stage)
+        except Exception as e:                                   # never let the extra object break the contract line
+            line["mlp_roofline"] = {"error": repr(e)}
         if conc is not None:
             line["concurrent"] = conc
         if world == 1 and not args.no_cpu_baseline:
