@@ -77,7 +77,8 @@ class Stage:
         self.idx = torch.empty((B, M, NS), dtype=torch.int32, device=dev)
         self.cnt = torch.empty((B, M), dtype=torch.int32, device=dev)
         self.grouped = torch.empty((B, M, NS, 3), dtype=torch.float32, device=dev)
-        self.ws = torch.empty((self.lib.pn2_sample_and_group_ws_bytes(B, M),), dtype=torch.uint8, device=dev)
+        self.ws = torch.zeros((self.lib.pn2_sample_and_group_ws_bytes(B, M),), dtype=torch.uint8, device=dev)
+        self.gen = 0                                  # granule generation of the overlapped launch (see overlap_)
         self.stream = torch.cuda.current_stream(dev).cuda_stream
 
     def fps_(self):
@@ -106,9 +107,13 @@ class Stage:
                                                    self.grouped.data_ptr(), self.stream), "ball_group")
 
     def overlap_(self):
-        _C.check(self.lib.pn2_sample_and_group_xyz(B, N, M, RADIUS, NS, self.xyz.data_ptr(), self.ws.data_ptr(),
-                                                   self.fps.data_ptr(), self.new_xyz.data_ptr(), self.idx.data_ptr(),
-                                                   self.cnt.data_ptr(), self.grouped.data_ptr(), 1, self.stream),
+        # generation-tagged granules (what pointnet2_amd.sample_and_group_xyz does): ws was zeroed once at
+        # allocation, every step uses the next tag, so no per-step clear of the workspace
+        self.gen += 1
+        _C.check(self.lib.pn2_sample_and_group_xyz_gen(B, N, M, RADIUS, NS, self.xyz.data_ptr(), self.ws.data_ptr(),
+                                                       self.gen, self.fps.data_ptr(), self.new_xyz.data_ptr(),
+                                                       self.idx.data_ptr(), self.cnt.data_ptr(),
+                                                       self.grouped.data_ptr(), 1, self.stream),
                  "sample_and_group_xyz")
 
     def step_overlap(self):

@@ -188,6 +188,13 @@ int pn2_sample_and_group_xyz(int b, int n, int m, float radius, int nsample, con
                              int *fps_idx, float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz,
                              int subtract_centroid, void *stream);
 long long pn2_sample_and_group_ws_bytes(int b, int m);
+/* The same launch without the per-call clear of ws: the caller manages generations. ws must hold no granule
+ * whose tag word equals `generation` (zero ws once when it is allocated, then pass 1, 2, 3, ...: what an
+ * earlier generation left behind can never be mistaken for a published sample). One ws per stream;
+ * generation 0 is PN2_E_ARG. Saves a memset launch (~5 us) per call. */
+int pn2_sample_and_group_xyz_gen(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,
+                                 unsigned generation, int *fps_idx, float *new_xyz, int *idx, int *pts_cnt,
+                                 float *grouped_xyz, int subtract_centroid, void *stream);
 
 /* ---- host helpers ------------------------------------------------------- */
 

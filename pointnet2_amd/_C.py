@@ -53,6 +53,7 @@ _SIGNATURES = {
     "pn2_query_ball_group_xyz": [_i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "pn2_sample_and_group_xyz": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pn2_sample_and_group_ws_bytes": [_i, _i],
+    "pn2_sample_and_group_xyz_gen": [_i, _i, _i, _f, _i, _vp, _vp, ctypes.c_uint, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pn2_ball_threshold": [_f],
     "pn2_version": [],
     "pn2_debug_fps_config": [_i, _i, _i, _i, _i, _vp, _vp, _vp],

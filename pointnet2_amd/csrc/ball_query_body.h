@@ -108,12 +108,12 @@ __device__ __forceinline__ void bq_emit(size_t row, int nsample, int cnt, const 
 // index (consumer side of the R2 granule hand-off: ONE 8-byte agent-scope relaxed load per poll, the
 // tag travels with the data, no fence). The spin is bounded: a launch whose producers are not
 // resident would otherwise hang the GPU; it traps instead.
-__device__ __forceinline__ int bq_poll_sample(const unsigned long long *tagged)
+__device__ __forceinline__ int bq_poll_sample(const unsigned long long *tagged, unsigned tag = 1u)
 {
     const pn2_gu64b *g = (const pn2_gu64b *)tagged;
     for (unsigned it = 0;; ++it) {
         const unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(v >> 32) == 1u) return (int)(unsigned)v;
+        if ((unsigned)(v >> 32) == tag) return (int)(unsigned)v;
         __builtin_amdgcn_s_sleep(16);
         if (it > (1u << 23)) __builtin_trap();   // ~10 s: the longest legal chain (n = m = 8192) takes < 10 ms
     }
@@ -128,7 +128,7 @@ __device__ __forceinline__ void bq_block_body(int n, int m, int nsample, float t
                                               const unsigned long long *__restrict__ tagged,
                                               float *__restrict__ new_xyz, int *__restrict__ idx,
                                               int *__restrict__ pts_cnt, float *__restrict__ grouped, int subtract,
-                                              char *smem)
+                                              char *smem, unsigned tag = 1u)
 {
     float4 *cloud = reinterpret_cast<float4 *>(smem);                                   // [n] when LDS_CLOUD
     int *rowbuf_all = reinterpret_cast<int *>(smem + (LDS_CLOUD ? sizeof(float4) * (size_t)((n + 127) & ~127) : 0));
@@ -161,8 +161,8 @@ __device__ __forceinline__ void bq_block_body(int n, int m, int nsample, float t
         const size_t row1 = row0 + (two ? 1 : 0);
         float ax, ay, az, bx, by, bz;
         if (POLL) {
-            const int ka = bq_poll_sample(tagged + row0);
-            const int kb = bq_poll_sample(tagged + row1);
+            const int ka = bq_poll_sample(tagged + row0, tag);
+            const int kb = bq_poll_sample(tagged + row1, tag);
             const float4 pa = cloud[ka], pb = cloud[kb];          // POLL implies LDS_CLOUD
             ax = pa.x; ay = pa.y; az = pa.z; bx = pb.x; by = pb.y; bz = pb.z;
             if (lane == 0) {

@@ -130,14 +130,15 @@ __device__ __forceinline__ pn2_f2 pk_add(pn2_f2 a, pn2_f2 b)
     return r;
 }
 
-// PUBLISH: thread 0 additionally stores every selected index as an 8-byte {tag = 1, index} granule
+// PUBLISH: thread 0 additionally stores every selected index as an 8-byte {tag, index} granule
 // with ONE write-through (sc1, agent-scope relaxed atomic) store, so other workgroups of the same
 // launch can consume the samples while the chain is still running (sa_fused.hip; hand-off form R2 of
 // the CDNA guide: the data is the flag, no fences).
 template <int T, int P, bool LDSXYZ, bool PUBLISH>
 __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, const float *__restrict__ xyz,
                                              int *__restrict__ out, float *__restrict__ out_xyz,
-                                             unsigned long long *__restrict__ tagged, char *smem)
+                                             unsigned long long *__restrict__ tagged, char *smem,
+                                             unsigned tag = 1u)
 {
     constexpr int W = T / PN2_WAVE;
     constexpr int NS = T * P;                      // rank slots
@@ -190,7 +191,7 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
     sxy.x = sx; sxy.y = sy; szk.x = sz;
     if (t == 0) {
         dst[0] = 0;                                    // tf_sampling_g.cu:114-116
-        if (PUBLISH) __hip_atomic_store(gtag, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (PUBLISH) __hip_atomic_store(gtag, (unsigned long long)tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     const unsigned low0 = (unsigned)(NS - 1 - t * P);   // key low word of this thread's slot 0: larger = smaller rank
@@ -287,7 +288,7 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
         if (t == 0) {
             dst[j] = k;
             if (PUBLISH)
-                __hip_atomic_store(gtag + j, (1ull << 32) | (unsigned long long)(unsigned)k, __ATOMIC_RELAXED,
+                __hip_atomic_store(gtag + j, ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)k, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         }
     };

@@ -38,7 +38,7 @@ constexpr size_t kFusedMinLds = 82 * 1024;      // > 160 KiB / 2: one workgroup 
 
 template <int P>
 __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, int m, int Q, int nsample, float thr,
-                                                                 int qpb, const float *__restrict__ xyz,
+                                                                 int qpb, unsigned tag, const float *__restrict__ xyz,
                                                                  unsigned long long *__restrict__ tagged,
                                                                  int *__restrict__ fps_idx,
                                                                  float *__restrict__ new_xyz, int *__restrict__ idx,
@@ -48,18 +48,18 @@ __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, i
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int blk = blockIdx.x;
     if (blk < b) {
-        fps_reg_body<kFusedThreads, P, true, true>(n, m, Q, blk, xyz, fps_idx, nullptr, tagged, smem);
+        fps_reg_body<kFusedThreads, P, true, true>(n, m, Q, blk, xyz, fps_idx, nullptr, tagged, smem, tag);
     } else {
         const int id = blk - b;
         const int cloud = id % b;                // query range first, cloud second: the consumers that can
         const int q0 = (id / b) * qpb;           // start earliest are dispatched first
         bq_block_body<true, true, true>(n, m, nsample, thr, cloud, q0, min(q0 + qpb, m), xyz, nullptr, tagged,
-                                        new_xyz, idx, pts_cnt, grouped, subtract, smem);
+                                        new_xyz, idx, pts_cnt, grouped, subtract, smem, tag);
     }
 }
 
 template <int P>
-static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, const float *xyz,
+static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, unsigned tag, const float *xyz,
                         unsigned long long *ws, int *fps_idx, float *new_xyz, int *idx, int *pts_cnt,
                         float *grouped, int subtract, hipStream_t st)
 {
@@ -77,9 +77,12 @@ static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, cons
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(ws, 0, sizeof(unsigned long long) * (size_t)b * m, st);   // tags = 0: nothing published yet
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(b + nq * b), dim3(kFusedThreads), lds, st, b, n, m, Q, nsample, thr, qpb, xyz, ws,
+    if (tag == 0) {                                               // caller did not manage generations: clear, use tag 1
+        e = hipMemsetAsync(ws, 0, sizeof(unsigned long long) * (size_t)b * m, st);
+        if (e != hipSuccess) return (int)e;
+        tag = 1u;
+    }
+    hipLaunchKernelGGL(kern, dim3(b + nq * b), dim3(kFusedThreads), lds, st, b, n, m, Q, nsample, thr, qpb, tag, xyz, ws,
                        fps_idx, new_xyz, idx, pts_cnt, grouped, subtract);
     return launch_status();
 }
@@ -92,9 +95,9 @@ extern "C" long long pn2_sample_and_group_ws_bytes(int b, int m)
     return (long long)sizeof(unsigned long long) * b * m;
 }
 
-extern "C" int pn2_sample_and_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,
-                                        int *fps_idx, float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz,
-                                        int subtract_centroid, void *stream)
+static int sample_and_group_common(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws, unsigned tag,
+                                   int *fps_idx, float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz,
+                                   int subtract_centroid, void *stream)
 {
     using namespace pn2;
     if (!(radius > 0.0f) || nsample <= 0 || m <= 0) return PN2_E_ARG;
@@ -111,11 +114,32 @@ extern "C" int pn2_sample_and_group_xyz(int b, int n, int m, float radius, int n
     hipStream_t st = as_stream(stream);
     unsigned long long *w = reinterpret_cast<unsigned long long *>(ws);
     switch (P) {
-    case 1: return launch_fused<1>(b, n, m, Q, nsample, thr, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
-    case 2: return launch_fused<2>(b, n, m, Q, nsample, thr, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
-    case 4: return launch_fused<4>(b, n, m, Q, nsample, thr, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
-    case 8: return launch_fused<8>(b, n, m, Q, nsample, thr, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
-    case 16: return launch_fused<16>(b, n, m, Q, nsample, thr, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
+    case 1: return launch_fused<1>(b, n, m, Q, nsample, thr, tag, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
+    case 2: return launch_fused<2>(b, n, m, Q, nsample, thr, tag, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
+    case 4: return launch_fused<4>(b, n, m, Q, nsample, thr, tag, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
+    case 8: return launch_fused<8>(b, n, m, Q, nsample, thr, tag, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
+    case 16: return launch_fused<16>(b, n, m, Q, nsample, thr, tag, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
     default: return PN2_E_TOO_LARGE;
     }
+}
+
+extern "C" int pn2_sample_and_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,
+                                        int *fps_idx, float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz,
+                                        int subtract_centroid, void *stream)
+{
+    return sample_and_group_common(b, n, m, radius, nsample, xyz, ws, 0u, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz,
+                                   subtract_centroid, stream);
+}
+
+// Same launch without the per-call clear of `ws`: the caller manages GENERATIONS. `ws` must hold no granule
+// whose tag word equals `generation` (zero it once when it is allocated, then pass 1, 2, 3, ... -- a
+// granule left behind by an earlier generation can never be mistaken for a published sample). One
+// workspace per stream; generation 0 is not allowed.
+extern "C" int pn2_sample_and_group_xyz_gen(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,
+                                            unsigned generation, int *fps_idx, float *new_xyz, int *idx, int *pts_cnt,
+                                            float *grouped_xyz, int subtract_centroid, void *stream)
+{
+    if (generation == 0u) return PN2_E_ARG;
+    return sample_and_group_common(b, n, m, radius, nsample, xyz, ws, generation, fps_idx, new_xyz, idx, pts_cnt,
+                                   grouped_xyz, subtract_centroid, stream);
 }

@@ -68,6 +68,25 @@ def query_ball_group_xyz(radius, nsample, xyz1, xyz2, subtract_centroid=True, wa
     return idx, cnt, grouped
 
 
+# Sample-granule workspaces of the overlapped launch, one per (device, stream, size): zeroed once, then
+# every call uses the next GENERATION tag (pn2_sample_and_group_xyz_gen), so no per-call clear is needed.
+# Launches on one stream are ordered, so reusing the buffer is safe; different streams get different buffers.
+_GRANULES = {}
+
+
+def _granule_workspace(lib, dev, stream, b, m):
+    key = (dev.index, stream, b * m)
+    ent = _GRANULES.get(key)
+    if ent is None or ent[1] >= 0xFFFFFFF0:
+        if len(_GRANULES) > 64:
+            _GRANULES.clear()
+        buf = torch.zeros((lib.pn2_sample_and_group_ws_bytes(b, m),), dtype=torch.uint8, device=dev)
+        ent = [buf, 0]
+        _GRANULES[key] = ent
+    ent[1] += 1
+    return ent[0], ent[1]
+
+
 def sample_and_group_xyz(npoint, radius, nsample, xyz, subtract_centroid=True):
     """The xyz half of sample_and_group (pointnet_util.py:40-46) in ONE launch: farthest point
     sampling, gather, ball query and grouping of xyz, with the ball queries running on the idle CUs
@@ -97,12 +116,20 @@ def sample_and_group_xyz(npoint, radius, nsample, xyz, subtract_centroid=True):
     idx = torch.empty((b, m, ns), dtype=torch.int32, device=dev)
     cnt = torch.empty((b, m), dtype=torch.int32, device=dev)
     grouped = torch.empty((b, m, ns, 3), dtype=torch.float32, device=dev)
-    ws = torch.empty((lib.pn2_sample_and_group_ws_bytes(b, m),), dtype=torch.uint8, device=dev)
+    st = stream_ptr(dev)
     with on_device(dev):
-        _C.check(lib.pn2_sample_and_group_xyz(b, n, m, float(radius), ns, ptr(xyz), ptr(ws), ptr(fps_idx),
-                                              ptr(new_xyz), ptr(idx), ptr(cnt), ptr(grouped),
-                                              1 if subtract_centroid else 0, stream_ptr(dev)),
-                 "sample_and_group_xyz")
+        if torch.cuda.is_current_stream_capturing():
+            # a captured launch is replayed with the same arguments: generations cannot advance, so the
+            # workspace is cleared inside the graph instead
+            ws = torch.empty((lib.pn2_sample_and_group_ws_bytes(b, m),), dtype=torch.uint8, device=dev)
+            _C.check(lib.pn2_sample_and_group_xyz(b, n, m, float(radius), ns, ptr(xyz), ptr(ws), ptr(fps_idx),
+                                                  ptr(new_xyz), ptr(idx), ptr(cnt), ptr(grouped),
+                                                  1 if subtract_centroid else 0, st), "sample_and_group_xyz")
+        else:
+            ws, gen = _granule_workspace(lib, dev, st, b, m)
+            _C.check(lib.pn2_sample_and_group_xyz_gen(b, n, m, float(radius), ns, ptr(xyz), ptr(ws), gen, ptr(fps_idx),
+                                                      ptr(new_xyz), ptr(idx), ptr(cnt), ptr(grouped),
+                                                      1 if subtract_centroid else 0, st), "sample_and_group_xyz")
     return fps_idx, new_xyz, idx, cnt, grouped
 
 
