@@ -106,5 +106,6 @@ int main()
     CK(hipMemcpy(d_xyz, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     go<512, 8>(b, n, m, d_xyz, d_out, d_prof);
     go<256, 16>(b, n, m, d_xyz, d_out, d_prof);
+    go<1024, 4>(b, n, m, d_xyz, d_out, d_prof);
     return 0;
 }
