@@ -63,6 +63,33 @@ def test_c_abi_argument_validation_without_gpu():
     assert lib.pn2_fps_temp_floats(4, 4096) == 0 and lib.pn2_fps_temp_floats(2, 20000) == 40000
 
 
+def test_c_abi_argument_validation_of_the_extra_entry_points():
+    """The entry points without a reference counterpart validate the same way (no launch, no GPU)."""
+    from pointnet2_amd import _C
+    lib = _C.lib()
+    one = ctypes.c_void_p(16)                                       # any non-null pointer: never dereferenced
+    assert lib.pn2_knn_point(1, 8, 4, 0, None, None, None, None, None) == -3                   # k
+    assert lib.pn2_knn_point(1, 8, 4, 2, None, None, None, None, None) == -1                   # null
+    assert lib.pn2_knn_point(1, 8, 4, 9, one, one, one, one, None) == -4                       # k > n
+    assert lib.pn2_knn_point(1, 20000, 4, 2, one, one, one, one, None) == -4                   # beyond the LDS tier
+    assert lib.pn2_knn_point(0, 8, 4, 2, None, None, None, None, None) == 0                    # empty batch
+    assert lib.pn2_sample_and_group_xyz_gen(2, 1024, 64, 0.2, 32, one, one, 0, one, one, one, one, one, 1, None) == -3
+    assert lib.pn2_sample_and_group_xyz(2, 1024, 64, 0.2, 32, None, None, None, None, None, None, None, 1, None) == -1
+    assert lib.pn2_sample_and_group_xyz(200, 1024, 64, 0.2, 32, one, one, one, one, one, one, one, 1, None) == -4   # envelope
+    assert lib.pn2_group_point_grad_seg(1, 8, 4, 2, 2, None, None, None, None, 0, None) == -1
+    assert lib.pn2_group_point_grad_seg(1, 0, 4, 2, 2, None, None, one, one, 0, None) == -2
+    assert lib.pn2_three_interpolate_grad_seg(1, 8, 4, 0, None, None, None, one, one, 0, None) == -2
+    assert lib.pn2_group_point_grad_det(1, 8, 4, 2, 2, None, None, None, None, None) == -1
+    assert lib.pn2_seg_grad_ws_bytes(2, 100, 640) == 4 * (2 * 101 + 2 * 2 * 100 + 2 * 640) + 16
+    assert lib.pn2_det_grad_ws_bytes(2, 100, 8) == 16 + 8 * 2 * 100 * 8
+    assert lib.pn2_sample_and_group_ws_bytes(3, 100) == 8 * 300
+    # fused MLP: shape limits are reported, never silently mis-run
+    assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 24, 0, one, one, None, one, 64, 64, 128, one, one, one, None) == -3   # nsample
+    assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 32, 0, one, one, None, one, 512, 512, 512, one, one, one, None) == -4
+    assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 32, 4, one, one, None, one, 64, 64, 128, one, one, one, None) == -1   # points missing
+    assert lib.pn2_sa_mlp3_pack(3, 64, 64, 128, 32, 1, None, None, None, None, None, None, None, None) == -1
+
+
 def test_python_wrappers_validate_like_op_requires():
     import pointnet2_amd as P
     x = torch.zeros(2, 16, 3)
