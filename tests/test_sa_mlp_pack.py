@@ -180,3 +180,33 @@ def test_stream_pack_matches_emulated_dataflow(cin, widths, xyz_first):
     for w, b in zip(ws, bs):
         want = np.maximum(want @ w.astype(np.float64) + b, 0.0)
     assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
+
+
+def test_fold_batch_norm_equals_eval_mode_layers():
+    """sa_mlp.fold_batch_norm against torch's own conv 1x1 + BatchNorm2d (eval) on the CPU, and
+    _SharedMLP.folded_layers() end to end (three layers + ReLU)."""
+    import torch
+    from pointnet2_amd import sa_mlp
+    from pointnet2_amd.pointnet_util import _SharedMLP
+    torch.manual_seed(3)
+    mlp = _SharedMLP(7, [16, 12, 20], bn=True)
+    for mod in mlp.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.uniform_(-0.5, 0.5)
+            mod.running_var.uniform_(0.3, 2.0)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.uniform_(-0.3, 0.3)
+    mlp.eval()
+    x = torch.randn(2, 7, 5, 6)
+    with torch.no_grad():
+        want = mlp(x)
+    layers = mlp.folded_layers()
+    assert [w.shape for w, _ in layers] == [(7, 16), (16, 12), (12, 20)]
+    act = x.permute(0, 2, 3, 1).double().numpy()
+    for w, b in layers:
+        act = np.maximum(act @ w.astype(np.float64) + b.astype(np.float64), 0.0)
+    assert np.allclose(act, want.permute(0, 2, 3, 1).double().numpy(), rtol=1e-5, atol=1e-5)
+    # without batch norm the fold is the identity on (W^T, b)
+    conv = torch.nn.Conv2d(4, 6, 1)
+    w, b = sa_mlp.fold_batch_norm(conv.weight, conv.bias, None)
+    assert np.allclose(w, conv.weight.detach().numpy()[:, :, 0, 0].T) and np.allclose(b, conv.bias.detach().numpy())
