@@ -78,8 +78,9 @@ __global__ __launch_bounds__(64) void selection_sort_wave_kernel(int n, int k, c
 //     candidate set C = {value <= tau} for any tau >= v_k, tracking each candidate's CURRENT slot: round s
 //     picks the candidate with the smallest (value, current slot); if another candidate sits at slot s it
 //     inherits the winner's slot. Non-candidates move around too, but nothing ever looks at them.
-//   * tau comes from two 256-bin histogram passes over the row (top 16 bits of the order-preserving key:
-//     exponent + 8 mantissa bits), i.e. v_k rounded up by < 0.4 %: |C| is k plus a handful.
+//   * tau: for k <= 40 the k-th smallest of the 64 per-lane minima (registers only); beyond, two 256-bin
+//     histogram passes over the row (top 16 bits of the order-preserving key, v_k rounded up by < 0.4 %).
+//     Either way |C| is k plus a handful on scattered data.
 //   * |C| > kKnnCap (clouds of identical points) falls back to the literal rounds on the row.
 constexpr int kKnnCap = 1024;
 
@@ -93,6 +94,30 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
         v = other < v ? other : v;
     }
     return v;
+}
+
+// wave-wide minimum of a positive double (+inf allowed) in VALU only (DPP row operations + v_min_f64), the
+// result broadcast to every lane: the ds_bpermute butterfly this replaces cost ~1200 cycles per round
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double knn_dpp_min_step(double v)
+{
+    const int hi = __double2hiint(v), lo = __double2loint(v);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);   // no source: keep own value
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const double o = __hiloint2double(ohi, olo);
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(v), "v"(o));
+    return r;
+}
+__device__ __forceinline__ double knn_wave_min_f64(double v)
+{
+    v = knn_dpp_min_step<0xB1, 0xf>(v);    // quad_perm:[1,0,3,2]
+    v = knn_dpp_min_step<0x4E, 0xf>(v);    // quad_perm:[2,3,0,1]
+    v = knn_dpp_min_step<0x141, 0xf>(v);   // row_half_mirror
+    v = knn_dpp_min_step<0x140, 0xf>(v);   // row_mirror
+    v = knn_dpp_min_step<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
+    v = knn_dpp_min_step<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3: lane 63 holds the minimum
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 // the 256-bin histogram in `hist` (lane l owns bins 4l..4l+3): bin in which the cumulative count reaches
@@ -138,10 +163,30 @@ __global__ __launch_bounds__(64) void knn_wave_kernel(int n, int m, int k, const
     const int lane = threadIdx.x;
     const float *pts = xyz1 + cloud * n * 3;
     const float qx = xyz2[row * 3 + 0], qy = xyz2[row * 3 + 1], qz = xyz2[row * 3 + 2];
-    for (int s = lane; s < n; s += 64) val[s] = sqdist(pts[s * 3 + 0], pts[s * 3 + 1], pts[s * 3 + 2], qx, qy, qz);
+    unsigned lmin = 0xffffffffu;                                  // smallest key among this lane's elements
+    for (int s = lane; s < n; s += 64) {
+        const float d = sqdist(pts[s * 3 + 0], pts[s * 3 + 1], pts[s * 3 + 2], qx, qy, qz);
+        val[s] = d;
+        lmin = min(lmin, orderable(d));
+    }
     const int rounds = min(k, n);
 
-    // ---- tau: upper edge of the 16-bit key prefix that holds the k-th smallest value -------------------
+    // ---- tau >= v_k ---------------------------------------------------------------------------------------
+    unsigned tau;
+    if (rounds <= 40) {
+        // the `rounds`-th smallest of the 64 per-lane minima: that many DISTINCT elements are <= it, so it
+        // bounds v_k, and on scattered data it sits at global rank ~ -64 ln(1 - rounds/64) (44 for 32 of
+        // 4096). No LDS traffic at all: the histogram passes below spend ~100 k cycles per query in
+        // same-address LDS atomics (distances share a handful of exponents).
+        int rank = 0;
+        for (int j = 0; j < 64; ++j) {
+            const unsigned other = (unsigned)__builtin_amdgcn_readlane((int)lmin, j);
+            rank += (other < lmin || (other == lmin && j < lane)) ? 1 : 0;
+        }
+        const unsigned long long mask = __ballot(rank == rounds - 1);            // exactly one lane
+        tau = (unsigned)__builtin_amdgcn_readlane((int)lmin, __builtin_ctzll(mask));
+    } else {
+    // upper edge of the 16-bit key prefix that holds the k-th smallest value
     for (int i = lane; i < 256; i += 64) hist[i] = 0;
     __syncthreads();
     for (int s = lane; s < n; s += 64) atomicAdd(&hist[orderable(val[s]) >> 24], 1);
@@ -158,7 +203,8 @@ __global__ __launch_bounds__(64) void knn_wave_kernel(int n, int m, int k, const
     __syncthreads();
     int b2, before2;
     knn_find_bin(hist, lane, rounds - before1, b2, before2);
-    const unsigned tau = ((unsigned)b1 << 24) | ((unsigned)b2 << 16) | 0xffffu;
+    tau = ((unsigned)b1 << 24) | ((unsigned)b2 << 16) | 0xffffu;
+    }
 
     // ---- candidates, in ascending slot order --------------------------------------------------------------
     int total = 0;
@@ -168,33 +214,37 @@ __global__ __launch_bounds__(64) void knn_wave_kernel(int n, int m, int k, const
         const bool in = s < n && key <= tau;
         const unsigned long long mask = __ballot(in);
         const int slot = total + __popcll(mask & ((1ull << lane) - 1ull));
-        if (in && slot < kKnnCap) { ckey[slot] = key; cpos[slot] = s; cidx[slot] = s; }
+        if (in && slot < kKnnCap) { ckey[slot] = __float_as_uint(val[s] == 0.0f ? 0.0f : val[s]); cpos[slot] = s; cidx[slot] = s; }
         total += __popcll(mask);
     }
     __syncthreads();
 
     if (total <= kKnnCap) {
         // ---- the swap rounds replayed on the candidates ----------------------------------------------------
+        // keys (raw value bits : current slot) read as doubles: distances are >= +0, so the bit patterns
+        // order like the values, stay below the fp64 exponent of Inf (0x7ff00000 > 0x7f800000), and a dead
+        // candidate is +Inf -- the arg-min is a v_min_f64 chain, as in the FPS kernel
+        const double dead = __hiloint2double(0x7ff00000, 0);
         for (int s = 0; s < rounds; ++s) {
-            unsigned long long best = ~0ull;
+            double best = dead;
             int bslot = 0;
             for (int c = lane; c < total; c += 64) {
-                const unsigned long long key = ((unsigned long long)ckey[c] << 32) | (unsigned)cpos[c];
+                const double key = __hiloint2double((int)ckey[c], cpos[c]);
                 if (key < best) { best = key; bslot = c; }
             }
-            const unsigned long long win = wave_min_u64(best);    // (value, current slot): unique among live candidates
-            const int q = (int)(unsigned)win;                     // the winner's current slot
-            if (best == win) {                                    // exactly one lane holds the winner
+            const double win = knn_wave_min_f64(best);            // (value, current slot): unique among live candidates
+            const int q = __double2loint(win);                    // the winner's current slot
+            if (best == win && best < dead) {                     // exactly one lane holds the winner
                 const int orig = cidx[bslot];
                 oval[row * k + s] = val[orig];
                 oidx[row * k + s] = orig;
-                ckey[bslot] = 0xffffffffu;                        // dead: never wins again (live keys are <= tau < this)
-                cpos[bslot] = 0x7fffffff;
+                ckey[bslot] = 0x7ff00000u;                        // dead: never wins again
+                cpos[bslot] = 0;
             }
             __syncthreads();
             if (q != s) {                                         // the element sitting at slot s moves to slot q
                 for (int c = lane; c < total; c += 64)
-                    if (cpos[c] == s && ckey[c] != 0xffffffffu) cpos[c] = q;
+                    if (cpos[c] == s && ckey[c] != 0x7ff00000u) cpos[c] = q;
             }
             __syncthreads();
         }
