@@ -33,6 +33,22 @@ def test_library_exports_every_declared_symbol():
     assert "gfx950" in _C.version()
 
 
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/pn2ops.h is the drop-in boundary: it must compile as C99 (no C++-isms, no torch/HIP types)
+    and a C program must link against libpn2ops.so with nothing but the header."""
+    from pointnet2_amd import _C
+    src = tmp_path / "use.c"
+    src.write_text('#include "pn2ops.h"\n#include <stdio.h>\n'
+                   'int main(void) { printf("%s %d\\n", pn2_version(), pn2_query_ball_point(1, 8, 4, 0.0f, 4, 0, 0, 0, 0, 0)); return 0; }\n')
+    exe = tmp_path / "use"
+    libdir = os.path.dirname(_C.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+           "-L", libdir, "-lpn2ops", "-Wl,-rpath," + libdir, "-o", str(exe)]
+    subprocess.run(cmd, check=True, capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert "gfx950" in out and out.strip().endswith("-3")          # radius <= 0 is PN2_E_ARG, from plain C
+
+
 def test_library_contains_gfx950_code_object():
     from pointnet2_amd import _C
     blob = open(_C.LIB_PATH, "rb").read()
