@@ -175,6 +175,39 @@ int pn2_farthest_point_sample_gather(int b, int n, int m, const float *inp, floa
 int pn2_query_ball_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
                              int subtract_centroid, int *idx, int *pts_cnt, float *grouped_xyz, void *stream);
 
+/* pn2_query_ball_group_xyz with the kernel choice as PER-CALL arguments (no process state): kernel 0 =
+ * automatic, 1 = sweep kernel, 2 = cell-list kernel whenever it fits, 3 = cell-list kernel with 512-thread
+ * workgroups; cells_qpb = queries per workgroup of the cell-list kernel (0 = automatic). grouped_xyz may be
+ * NULL (plain query_ball_point). Used by the parity tests to force every kernel at every shape and by
+ * scripts/bq_probe.py; results are identical whatever the choice. */
+int pn2_query_ball_group_xyz_ex(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
+                                int subtract_centroid, int *idx, int *pts_cnt, float *grouped_xyz, int kernel,
+                                int cells_qpb, void *stream);
+
+/* Multi-radius form for multi-scale grouping (pointnet_sa_module_msg, utils/pointnet_util.py:175-186: one
+ * query_ball_point + group_point + centroid subtraction PER RADIUS over the same xyz / new_xyz): the cloud is
+ * staged and binned ONCE per workgroup (cells sized for the smallest radius) and queried once per radius.
+ * radii / nsamples: HOST arrays of nscales (<= 4) entries; idx / pts_cnt / grouped_xyz: HOST arrays of nscales
+ * DEVICE pointers, scale i shaped (b,m,nsamples[i]) / (b,m) / (b,m,nsamples[i],3); the arrays themselves or
+ * single entries of pts_cnt and of one of idx / grouped_xyz may be NULL. Every output is bit-identical to
+ * pn2_query_ball_group_xyz called per radius. PN2_E_TOO_LARGE for n > 8192 (call the single-radius operator). */
+int pn2_query_ball_group_xyz_msg(int b, int n, int m, int nscales, const float *radii, const int *nsamples,
+                                 const float *xyz1, const float *xyz2, int subtract_centroid, int *const *idx,
+                                 int *const *pts_cnt, float *const *grouped_xyz, void *stream);
+
+/* pn2_group_point / pn2_three_interpolate with the kernel choice per call (parity tests force every kernel,
+ * scripts/bw_probe.py times them). group: 0 automatic, 1 flat first-generation kernels, 2 row kernels,
+ * 3 row kernels with non-temporal stores; three_interpolate: 0 automatic, 1 flat, 2 row kernel. */
+int pn2_group_point_ex(int b, int n, int c, int m, int nsample, const float *points, const int *idx, float *out,
+                       int variant, void *stream);
+int pn2_three_interpolate_ex(int b, int m, int c, int n, const float *points, const int *idx, const float *weight,
+                             float *out, int variant, void *stream);
+
+/* farthest_point_sample (register-resident tier, n <= 16384) with an explicit workgroup geometry: T threads
+ * in {256, 512, 1024}, P points per thread (a power of two, T * P >= 512 * ceil(n / 512)). Every geometry
+ * returns the same indices; tests cover all of them, scripts/ time them. Stateless. */
+int pn2_farthest_point_sample_ex(int T, int P, int b, int n, int m, const float *inp, int *out, void *stream);
+
 /* The whole xyz half of sample_and_group (pointnet_util.py:40-46) in ONE launch, with the ball
  * queries overlapped under the farthest-point-sampling chain: producer workgroups (one per cloud)
  * publish each sample as they select it, consumer workgroups on the other CUs run query j as soon as

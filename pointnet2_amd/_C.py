@@ -35,6 +35,8 @@ _SIGNATURES = {
     "pn2_query_ball_point": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp],
     "pn2_selection_sort": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pn2_group_point": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "pn2_group_point_ex": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "pn2_three_interpolate_ex": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "pn2_group_point_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pn2_three_nn": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pn2_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
@@ -56,8 +58,9 @@ _SIGNATURES = {
     "pn2_sample_and_group_xyz_gen": [_i, _i, _i, _f, _i, _vp, _vp, ctypes.c_uint, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pn2_ball_threshold": [_f],
     "pn2_version": [],
-    "pn2_debug_fps_config": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
-    "pn2_debug_bq_config": [_i, _i],
+    "pn2_farthest_point_sample_ex": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "pn2_query_ball_group_xyz_ex": [_i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "pn2_query_ball_group_xyz_msg": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
 }
 _RESTYPES = {
     "pn2_fps_temp_floats": ctypes.c_longlong,
@@ -66,11 +69,10 @@ _RESTYPES = {
     "pn2_sample_and_group_ws_bytes": ctypes.c_longlong,
     "pn2_ball_threshold": ctypes.c_float,
     "pn2_version": ctypes.c_char_p,
-    "pn2_debug_bq_config": None,
 }
 
-# every symbol include/pn2ops.h declares (pn2_debug_* are tuning hooks, not part of the ABI)
-EXPORTED = sorted(k for k in _SIGNATURES if not k.startswith("pn2_debug"))
+# every symbol include/pn2ops.h declares
+EXPORTED = sorted(_SIGNATURES)
 
 _lib = None
 

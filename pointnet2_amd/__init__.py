@@ -15,7 +15,7 @@ from . import _C  # noqa: F401
 from .tf_sampling import (farthest_point_sample, farthest_point_sample_gather, gather_point,  # noqa: F401
                           prob_sample)
 from .tf_grouping import (query_ball_point, group_point, knn_point, select_top_k,  # noqa: F401
-                          query_ball_group_xyz, sample_and_group_xyz)
+                          query_ball_group_xyz, query_ball_group_xyz_msg, sample_and_group_xyz)
 from .tf_interpolate import three_nn, three_interpolate  # noqa: F401
 from ._tensors import set_deterministic, is_deterministic  # noqa: F401
 

@@ -66,21 +66,17 @@ static int launch_bq(int b, int n, int m, float thr, int nsample, const float *x
     const size_t lds = (LDS_CLOUD ? sizeof(float4) * (size_t)((n + 127) & ~127) : 0) + sizeof(int) * (size_t)nsample * kGran;
     if (lds > 160 * 1024) return PN2_E_TOO_LARGE;
     auto kern = ball_query_kernel<LDS_CLOUD, FUSE>;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(kern, dim3(gx, b), dim3(kBqThreads), lds, st, n, m, nsample, thr, qpb, xyz1, xyz2, idx,
-                       pts_cnt, grouped, subtract);
-    return launch_status();
+    if (int rc = allow_dynamic_lds(kern, lds)) return rc;
+    if (int rc = launch(kern, dim3(gx, b), dim3(kBqThreads), lds, st, n, m, nsample, thr, qpb, xyz1, xyz2, idx,
+                       pts_cnt, grouped, subtract)) return rc;
+    return PN2_OK;
 }
 
 // Cell-list kernel (ball_query_body.h, second half): the grid is built per workgroup, so a workgroup
 // takes a larger share of the queries than in the sweep kernel to amortise the binning pass.
 template <int NT, int LPQ, bool FUSE>
-__global__ __launch_bounds__(NT, NT / 256) void ball_query_cells_kernel(int n, int m, int nsample, float thr,
-                                                                      float radius, int qpb,
+__global__ __launch_bounds__(NT, NT / 256) void ball_query_cells_kernel(int b, int n, int m, int nsample, float thr,
+                                                                      float radius, int qpb, int parts,
                                                                       const float *__restrict__ xyz1,
                                                                       const float *__restrict__ xyz2,
                                                                       int *__restrict__ idx,
@@ -88,8 +84,10 @@ __global__ __launch_bounds__(NT, NT / 256) void ball_query_cells_kernel(int n, i
                                                                       float *__restrict__ grouped, int subtract)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int q0 = blockIdx.x * qpb;
-    bq_cells_block_body<NT, LPQ, FUSE, false>(n, m, nsample, thr, radius, blockIdx.y, q0, min(q0 + qpb, m), xyz1, xyz2,
+    int cloud, part;
+    decode_cloud_block(blockIdx.x, parts, b, cloud, part);
+    const int q0 = part * qpb;
+    bq_cells_block_body<NT, LPQ, FUSE, false>(n, m, nsample, thr, radius, cloud, q0, min(q0 + qpb, m), xyz1, xyz2,
                                      nullptr, nullptr, idx, pts_cnt, grouped, subtract, smem);
 }
 
@@ -98,23 +96,23 @@ static size_t bq_sweep_lds_bytes(int n, int nsample, int nthreads = kBqThreads)
     return sizeof(float4) * (size_t)((n + 127) & ~127) + sizeof(int) * (size_t)nsample * (nthreads / 64) * kBqQpw;
 }
 
-// Dispatch overrides for tests and tuning scripts (pn2_debug_bq_config): mode 0 = automatic,
-// 1 = sweep kernel only, 2 = cell-list kernel whenever it fits, 3 = same with 512-thread workgroups only.
-static int g_bq_mode = 0;
-static int g_bq_cells_qpb = 0;   // queries per workgroup of the cell-list kernel; 0 = automatic
+// Per-call dispatch options (pn2_query_ball_group_xyz_ex; the reference-shaped entry points pass {0, 0}):
+// kernel 0 = automatic, 1 = sweep kernel only, 2 = cell-list kernel whenever it fits, 3 = same with
+// 512-thread workgroups only; qpb = queries per workgroup of the cell-list kernel, 0 = automatic.
+struct BqOpts { int kernel, qpb; };
 
 // Geometry of the cell-list kernel: workgroup size and lanes per query. The query loop is branchy,
 // LDS-latency-bound code that wants 16 waves on a CU: two 512-thread workgroups when two fit in the
 // LDS (small clouds), one 1024-thread workgroup otherwise; and a wave should carry as many queries
 // as the LDS holds bitmaps for. Returns false when nothing fits (the sweep kernel is used).
 struct BqCellsGeom { int nthreads, lpq; };
-static bool bq_cells_pick(int n, int nsample, BqCellsGeom &g)
+static bool bq_cells_pick(int n, int nsample, int kernel, BqCellsGeom &g)
 {
     static const BqCellsGeom order[] = {{512, 8}, {512, 16}, {1024, 8}, {1024, 16}, {512, 8}, {512, 16}, {512, 32}};
     for (int i = 0; i < 7; ++i) {
         const BqCellsGeom &c = order[i];
-        if (g_bq_mode == 3 && c.nthreads != 512) continue;
-        const size_t cap = (i < 2 && g_bq_mode != 3) ? 80 * 1024 : 160 * 1024;   // first two: only if two workgroups fit
+        if (kernel == 3 && c.nthreads != 512) continue;
+        const size_t cap = (i < 2 && kernel != 3) ? 80 * 1024 : 160 * 1024;   // first two: only if two workgroups fit
         if (bq_cells_lds_bytes(n, nsample, c.lpq, c.nthreads) <= cap &&
             bq_sweep_lds_bytes(n, nsample, c.nthreads) <= cap) { g = c; return true; }
     }
@@ -123,20 +121,21 @@ static bool bq_cells_pick(int n, int nsample, BqCellsGeom &g)
 
 // The cell-list kernel pays a binning pass per workgroup and only prunes when the grid is fine; measured
 // on MI355X (scripts/bq_probe.py) it wins from about 2048 points per cloud and a launch that fills the GPU.
-static bool bq_use_cells(int b, int n, int m)
+static bool bq_use_cells(int b, int n, int m, int kernel)
 {
-    if (n > kBqCellsMaxPoints || n < 64 || g_bq_mode == 1) return false;
-    if (g_bq_mode >= 2) return true;
+    if (n > kBqCellsMaxPoints || n < 64 || kernel == 1) return false;
+    if (kernel >= 2) return true;
     return n >= 2048 && (long long)b * m >= 8192;
 }
 
 template <int NT, int LPQ, bool FUSE>
 static int launch_bq_cells(int b, int n, int m, float thr, float radius, int nsample, const float *xyz1,
-                           const float *xyz2, int *idx, int *pts_cnt, float *grouped, int subtract, hipStream_t st)
+                           const float *xyz2, int *idx, int *pts_cnt, float *grouped, int subtract, int opt_qpb,
+                           hipStream_t st)
 {
     constexpr int kGran = (NT / 64) * (64 / LPQ);               // queries per workgroup trip
     long long total = (long long)b * m;
-    int qpb = g_bq_cells_qpb > 0 ? g_bq_cells_qpb : (int)((total + 255) / 256);
+    int qpb = opt_qpb > 0 ? opt_qpb : (int)((total + 255) / 256);
     qpb = ((qpb + kGran - 1) / kGran) * kGran;
     if (qpb < kGran) qpb = kGran;
     if (qpb > m) qpb = ((m + kGran - 1) / kGran) * kGran;
@@ -144,24 +143,20 @@ static int launch_bq_cells(int b, int n, int m, float thr, float radius, int nsa
     const size_t a = bq_cells_lds_bytes(n, nsample, LPQ, NT), s = bq_sweep_lds_bytes(n, nsample, NT);
     const size_t lds = a > s ? a : s;                       // the fallback inside the kernel uses the sweep layout
     auto kern = ball_query_cells_kernel<NT, LPQ, FUSE>;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(kern, dim3(gx, b), dim3(NT), lds, st, n, m, nsample, thr, radius, qpb,
-                       xyz1, xyz2, idx, pts_cnt, grouped, subtract);
-    return launch_status();
+    if (int rc = allow_dynamic_lds(kern, lds)) return rc;
+    if (int rc = launch(kern, dim3((unsigned)gx * b), dim3(NT), lds, st, b, n, m, nsample, thr, radius, qpb, gx,
+                       xyz1, xyz2, idx, pts_cnt, grouped, subtract)) return rc;
+    return PN2_OK;
 }
 
 template <bool FUSE>
 static int dispatch_bq_cells(BqCellsGeom g, int b, int n, int m, float thr, float radius, int nsample,
                              const float *xyz1, const float *xyz2, int *idx, int *pts_cnt, float *grouped,
-                             int subtract, hipStream_t st)
+                             int subtract, int qpb, hipStream_t st)
 {
 #define PN2_BQ_CASE(NT, LPQ) \
     if (g.nthreads == NT && g.lpq == LPQ) \
-        return launch_bq_cells<NT, LPQ, FUSE>(b, n, m, thr, radius, nsample, xyz1, xyz2, idx, pts_cnt, grouped, subtract, st)
+        return launch_bq_cells<NT, LPQ, FUSE>(b, n, m, thr, radius, nsample, xyz1, xyz2, idx, pts_cnt, grouped, subtract, qpb, st)
     PN2_BQ_CASE(1024, 8);
     PN2_BQ_CASE(1024, 16);
     PN2_BQ_CASE(512, 8);
@@ -172,8 +167,9 @@ static int dispatch_bq_cells(BqCellsGeom g, int b, int n, int m, float thr, floa
 }
 
 static int ball_query_common(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
-                             int subtract, int *idx, int *pts_cnt, float *grouped, bool fuse, void *stream)
+                             int subtract, int *idx, int *pts_cnt, float *grouped, bool fuse, BqOpts opt, void *stream)
 {
+    if (opt.kernel < 0 || opt.kernel > 3 || opt.qpb < 0) return PN2_E_ARG;
     if (!(radius > 0.0f) || nsample <= 0) return PN2_E_ARG;   // tf_grouping.cpp:71,74
     if (b < 0 || n <= 0 || m < 0) return PN2_E_SHAPE;
     if (b == 0 || m == 0) return PN2_OK;
@@ -186,9 +182,9 @@ static int ball_query_common(int b, int n, int m, float radius, int nsample, con
     const bool lds = n <= kBqMaxLdsPoints &&
                      sizeof(float4) * (size_t)((n + 127) & ~127) + sizeof(int) * (size_t)nsample * kBqWaves * kBqQpw <= 160 * 1024;
     BqCellsGeom geom;
-    if (bq_use_cells(b, n, m) && bq_cells_pick(n, nsample, geom))
-        return fuse ? dispatch_bq_cells<true>(geom, b, n, m, thr, radius, nsample, xyz1, xyz2, idx, pts_cnt, grouped, subtract, st)
-                    : dispatch_bq_cells<false>(geom, b, n, m, thr, radius, nsample, xyz1, xyz2, idx, pts_cnt, nullptr, 0, st);
+    if (bq_use_cells(b, n, m, opt.kernel) && bq_cells_pick(n, nsample, opt.kernel, geom))
+        return fuse ? dispatch_bq_cells<true>(geom, b, n, m, thr, radius, nsample, xyz1, xyz2, idx, pts_cnt, grouped, subtract, opt.qpb, st)
+                    : dispatch_bq_cells<false>(geom, b, n, m, thr, radius, nsample, xyz1, xyz2, idx, pts_cnt, nullptr, 0, opt.qpb, st);
     if (fuse)
         return lds ? launch_bq<true, true>(b, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt, grouped, subtract, st)
                    : launch_bq<false, true>(b, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt, grouped, subtract, st);
@@ -222,7 +218,7 @@ extern "C" float pn2_ball_threshold(float radius)
 extern "C" int pn2_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1,
                                     const float *xyz2, int *idx, int *pts_cnt, void *stream)
 {
-    return pn2::ball_query_common(b, n, m, radius, nsample, xyz1, xyz2, 0, idx, pts_cnt, nullptr, false, stream);
+    return pn2::ball_query_common(b, n, m, radius, nsample, xyz1, xyz2, 0, idx, pts_cnt, nullptr, false, {0, 0}, stream);
 }
 
 extern "C" int pn2_query_ball_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz1,
@@ -230,13 +226,17 @@ extern "C" int pn2_query_ball_group_xyz(int b, int n, int m, float radius, int n
                                         float *grouped_xyz, void *stream)
 {
     return pn2::ball_query_common(b, n, m, radius, nsample, xyz1, xyz2, subtract_centroid, idx, pts_cnt,
-                                  grouped_xyz, true, stream);
+                                  grouped_xyz, true, {0, 0}, stream);
 }
 
-// Development hook (scripts/, tests): override the kernel choice (see g_bq_mode) and the cell-list
-// kernel's queries per workgroup (0 = automatic). Not part of the ABI.
-extern "C" void pn2_debug_bq_config(int mode, int qpb)
+// The same operator with the kernel choice as per-call arguments (tests force every kernel at every shape,
+// scripts/bq_probe.py tunes the dispatch): kernel 0 automatic, 1 sweep, 2 cell list, 3 cell list with
+// 512-thread workgroups; cells_qpb = queries per workgroup of the cell-list kernel (0 automatic).
+// grouped_xyz == NULL: plain query_ball_point. Stateless like everything else in the library.
+extern "C" int pn2_query_ball_group_xyz_ex(int b, int n, int m, float radius, int nsample, const float *xyz1,
+                                           const float *xyz2, int subtract_centroid, int *idx, int *pts_cnt,
+                                           float *grouped_xyz, int kernel, int cells_qpb, void *stream)
 {
-    pn2::g_bq_mode = mode;
-    pn2::g_bq_cells_qpb = qpb > 0 ? qpb : 0;
+    return pn2::ball_query_common(b, n, m, radius, nsample, xyz1, xyz2, grouped_xyz ? subtract_centroid : 0, idx, pts_cnt,
+                                  grouped_xyz, grouped_xyz != nullptr, {kernel, cells_qpb}, stream);
 }

@@ -88,7 +88,7 @@ __device__ __forceinline__ void bq_emit(size_t row, int nsample, int cnt, const 
     for (int l = lane; l < nsample; l += 64) {
         const int v = (l < cnt) ? rowbuf[l] : first;
         if (idx) idx[row * nsample + l] = v;
-        if (FUSE) {
+        if (FUSE && grouped) {
             float gx, gy, gz;
             if (LDS_CLOUD) {
                 const float4 p = cloud[v];
@@ -122,14 +122,18 @@ __device__ __forceinline__ int bq_poll_sample(const unsigned long long *tagged, 
 // One workgroup's share of the ball queries of cloud `bi`: queries [q0, q1).
 // POLL: the query points are not read from xyz2; they are the FPS samples of the same launch, taken
 // from the tagged index stream as soon as they exist (and written to new_xyz on the way).
-template <bool LDS_CLOUD, bool FUSE, bool POLL, int NT = kBqThreads>
+// STAGED: the LDS copy of the cloud already exists (multi-radius kernel: staged once, swept per radius);
+// row_stride: ints between two row buffers (0 = nsample; the multi-radius kernel passes its largest nsample
+// so that waves working on different radii never share a buffer).
+template <bool LDS_CLOUD, bool FUSE, bool POLL, int NT = kBqThreads, bool STAGED = false>
 __device__ __forceinline__ void bq_block_body(int n, int m, int nsample, float thr, int bi, int q0, int q1,
                                               const float *__restrict__ xyz1, const float *__restrict__ xyz2,
                                               const unsigned long long *__restrict__ tagged,
                                               float *__restrict__ new_xyz, int *__restrict__ idx,
                                               int *__restrict__ pts_cnt, float *__restrict__ grouped, int subtract,
-                                              char *smem, unsigned tag = 1u)
+                                              char *smem, unsigned tag = 1u, int row_stride = 0)
 {
+    if (row_stride == 0) row_stride = nsample;
     float4 *cloud = reinterpret_cast<float4 *>(smem);                                   // [n] when LDS_CLOUD
     int *rowbuf_all = reinterpret_cast<int *>(smem + (LDS_CLOUD ? sizeof(float4) * (size_t)((n + 127) & ~127) : 0));
 
@@ -137,13 +141,13 @@ __device__ __forceinline__ void bq_block_body(int n, int m, int nsample, float t
     const int lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const float *__restrict__ data = xyz1 + (size_t)bi * n * 3;
-    int *rowbuf0 = rowbuf_all + (w * kBqQpw + 0) * nsample;
-    int *rowbuf1 = rowbuf_all + (w * kBqQpw + 1) * nsample;
+    int *rowbuf0 = rowbuf_all + (w * kBqQpw + 0) * row_stride;
+    int *rowbuf1 = rowbuf_all + (w * kBqQpw + 1) * row_stride;
 
     // LDS copy of the cloud, padded to a multiple of 128 with points at +inf: a padded candidate's
     // distance is +inf (or NaN), never < thr, so the sweep needs no bounds predicate.
     const int npad = (n + 127) & ~127;
-    if (LDS_CLOUD) {
+    if (LDS_CLOUD && !STAGED) {
         for (int k = t; k < npad; k += NT) {
             if (k < n) {
                 const float *p = data + (size_t)k * 3;
@@ -484,7 +488,7 @@ __device__ __forceinline__ void bq_cells_query_loop(int n, int m, int nsample, f
                                                     float *__restrict__ new_xyz, int *__restrict__ idx,
                                                     int *__restrict__ pts_cnt, float *__restrict__ grouped,
                                                     int subtract, const float4 *sorted, const int *tab,
-                                                    char *wave_area)
+                                                    char *wave_area, size_t wave_stride = 0)
 {
     constexpr int G = 64 / LPQ;
     constexpr int CW = 64 / LPQ;                                 // 64-bit bitmap words per lane and window
@@ -493,7 +497,10 @@ __device__ __forceinline__ void bq_cells_query_loop(int n, int m, int nsample, f
     const int grp = lane / LPQ, sub = lane % LPQ;
     const int nwin = (n + 4095) / 4096;
     const int gwords = nwin * 128;                               // 32-bit words of one query's bitmap
-    unsigned *bm = reinterpret_cast<unsigned *>(wave_area + (size_t)w * bq_cells_wave_bytes(n, nsample, LPQ));
+    // wave_stride: bytes between the private areas of two waves (the multi-radius kernel passes the size its
+    // largest nsample needs, so that waves working on different radii never overlap)
+    if (wave_stride == 0) wave_stride = bq_cells_wave_bytes(n, nsample, LPQ);
+    unsigned *bm = reinterpret_cast<unsigned *>(wave_area + (size_t)w * wave_stride);
     unsigned *bmq = bm + grp * gwords;
     int *rowbuf = reinterpret_cast<int *>(bm + G * gwords) + grp * nsample;
     for (int i = lane; i < G * gwords; i += 64) bm[i] = 0u;
@@ -530,16 +537,29 @@ __device__ __forceinline__ void bq_cells_query_loop(int n, int m, int nsample, f
         const int cy0 = bq_cell(__fsub_rn(qy, reach), g.oy, g.iy, g.gy), cy1 = bq_cell(__fadd_rn(qy, reach), g.oy, g.iy, g.gy);
         const int cz0 = bq_cell(__fsub_rn(qz, reach), g.oz, g.iz, g.gz), cz1 = bq_cell(__fadd_rn(qz, reach), g.oz, g.iz, g.gz);
         const bool near_origin = fabsf(qx) <= lim && fabsf(qy) <= lim && fabsf(qz) <= lim;   // false for NaN
-        // cannot happen for a near query (cell edge > reach): kept so that a wrong range can never drop a hit
-        const bool everything = !near_origin || cy1 - cy0 > 2 || cz1 - cz0 > 2 || cy1 < cy0 || cz1 < cz0 || cx1 < cx0;
+        // Up to nine candidate runs per query. NARROW (the ball spans <= 3 cells in y and z: always the case
+        // when the grid was built for this radius): run r = the x-adjacent cells cx0..cx1 of row (cy0 + r%3,
+        // cz0 + r/3). WIDE (a radius larger than the cell edge -- the multi-radius kernel bins once, at the
+        // smallest radius): run r = the whole y-range cy0..cy1, every x, of slab cz0 + r; more candidates per
+        // run, still one contiguous piece of the sorted array each. Anything else visits the whole array --
+        // slow, never wrong (also the path of far-away and NaN queries).
+        const int sy = cy1 - cy0, sz = cz1 - cz0;                // spans - 1
+        const bool ordered = cy1 >= cy0 && cz1 >= cz0 && cx1 >= cx0;
+        const bool narrow = ordered && sy <= 2 && sz <= 2;
+        const bool wide = ordered && !narrow && sz <= 8;
+        const bool everything = !near_origin || !(narrow || wide);
         const int dx1 = cx1 - cx0 + 1;
         int rb[9], re[9];
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             const int ry = r % 3, rz = r / 3;
-            const bool rvalid = qvalid && !everything && cy0 + ry <= cy1 && cz0 + rz <= cz1;
-            const int cfirst = rvalid ? ((cz0 + rz) * g.gy + (cy0 + ry)) * g.gx + cx0 : 0;
-            const int b0 = tab[cfirst], e0 = tab[cfirst + dx1];
+            const bool rvalid = qvalid && !everything && (narrow ? (ry <= sy && rz <= sz) : (r <= sz));
+            const int nfirst = ((cz0 + rz) * g.gy + (cy0 + ry)) * g.gx + cx0;          // narrow: cells [nfirst, nfirst + dx1)
+            const int wfirst = ((cz0 + r) * g.gy + cy0) * g.gx;                         // wide: cells [wfirst, wlast)
+            const int wlast = ((cz0 + r) * g.gy + cy1) * g.gx + g.gx;
+            const int cfirst = rvalid ? (narrow ? nfirst : wfirst) : 0;
+            const int clast = rvalid ? (narrow ? nfirst + dx1 : wlast) : 0;
+            const int b0 = tab[cfirst], e0 = tab[clast];
             rb[r] = rvalid ? b0 : 0;
             re[r] = rvalid ? e0 : 0;
         }
@@ -630,7 +650,7 @@ __device__ __forceinline__ void bq_cells_query_loop(int n, int m, int nsample, f
             for (int l = sub; l < nsample; l += LPQ) {
                 const int v = (l < cnt) ? rowbuf[l] : first;
                 if (idx) idx[row * nsample + l] = v;
-                if (FUSE) {
+                if (FUSE && grouped) {
                     float gx = data[(size_t)v * 3 + 0], gy = data[(size_t)v * 3 + 1], gz = data[(size_t)v * 3 + 2];
                     if (subtract) { gx = __fsub_rn(gx, qx); gy = __fsub_rn(gy, qy); gz = __fsub_rn(gz, qz); }
                     float *o = grouped + (row * nsample + l) * 3;

@@ -162,10 +162,10 @@ static int det_prepare(void *ws, long long acc_elems, float *out, const float *g
     e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)acc_elems, st);
     if (e != hipSuccess) return (int)e;
     if (grad_elems > 0)
-        hipLaunchKernelGGL(det_absmax_kernel, dim3(det_grid(grad_elems)), dim3(kDetThreads), 0, st, grad, grad_elems, w.head);
+        if (int rc = launch(det_absmax_kernel, dim3(det_grid(grad_elems)), dim3(kDetThreads), 0, st, grad, grad_elems, w.head)) return rc;
     if (weight && weight_elems > 0)
-        hipLaunchKernelGGL(det_absmax_kernel, dim3(det_grid(weight_elems)), dim3(kDetThreads), 0, st, weight, weight_elems, w.head + 1);
-    return launch_status();
+        if (int rc = launch(det_absmax_kernel, dim3(det_grid(weight_elems)), dim3(kDetThreads), 0, st, weight, weight_elems, w.head + 1)) return rc;
+    return PN2_OK;
 }
 
 }  // namespace pn2
@@ -190,10 +190,10 @@ extern "C" int pn2_gather_point_grad_det(int b, int n, int m, const float *out_g
     if (rc || m == 0) return rc;
     DetWs w = det_ws(ws);
     const int logc = ceil_log2(m);
-    hipLaunchKernelGGL(det_gather_grad_kernel, dim3(det_grid(rows)), dim3(kDetThreads), 0, st, rows, n, m, logc, out_g, idx,
-                       w.head, w.acc, inp_g);
-    hipLaunchKernelGGL(det_convert_kernel, dim3(det_grid(accn)), dim3(kDetThreads), 0, st, accn, logc, w.head, w.acc, inp_g);
-    return launch_status();
+    if (int rc = launch(det_gather_grad_kernel, dim3(det_grid(rows)), dim3(kDetThreads), 0, st, rows, n, m, logc, out_g, idx,
+                       w.head, w.acc, inp_g)) return rc;
+    if (int rc = launch(det_convert_kernel, dim3(det_grid(accn)), dim3(kDetThreads), 0, st, accn, logc, w.head, w.acc, inp_g)) return rc;
+    return PN2_OK;
 }
 
 extern "C" int pn2_group_point_grad_det(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
@@ -210,11 +210,11 @@ extern "C" int pn2_group_point_grad_det(int b, int n, int c, int m, int nsample,
     if (rc || elems == 0) return rc;
     DetWs w = det_ws(ws);
     const int logc = ceil_log2(rpc);
-    hipLaunchKernelGGL(det_group_grad_kernel, dim3(det_grid(elems)), dim3(kDetThreads), 0, st, elems, rpc, n, c, logc,
-                       grad_out, idx, w.head, w.acc, grad_points);
-    hipLaunchKernelGGL(det_convert_kernel, dim3(det_grid(accn)), dim3(kDetThreads), 0, st, accn, logc, w.head, w.acc,
-                       grad_points);
-    return launch_status();
+    if (int rc = launch(det_group_grad_kernel, dim3(det_grid(elems)), dim3(kDetThreads), 0, st, elems, rpc, n, c, logc,
+                       grad_out, idx, w.head, w.acc, grad_points)) return rc;
+    if (int rc = launch(det_convert_kernel, dim3(det_grid(accn)), dim3(kDetThreads), 0, st, accn, logc, w.head, w.acc,
+                       grad_points)) return rc;
+    return PN2_OK;
 }
 
 extern "C" int pn2_three_interpolate_grad_det(int b, int n, int c, int m, const float *grad_out, const int *idx,
@@ -231,9 +231,9 @@ extern "C" int pn2_three_interpolate_grad_det(int b, int n, int c, int m, const 
     if (rc || elems == 0) return rc;
     DetWs w = det_ws(ws);
     const int logc = ceil_log2((long long)n * 3);
-    hipLaunchKernelGGL(det_interp_grad_kernel, dim3(det_grid(elems)), dim3(kDetThreads), 0, st, elems, m, n, c, logc, grad_out,
-                       idx, weight, w.head, w.acc, grad_points);
-    hipLaunchKernelGGL(det_convert_kernel, dim3(det_grid(accn)), dim3(kDetThreads), 0, st, accn, logc, w.head, w.acc,
-                       grad_points);
-    return launch_status();
+    if (int rc = launch(det_interp_grad_kernel, dim3(det_grid(elems)), dim3(kDetThreads), 0, st, elems, m, n, c, logc, grad_out,
+                       idx, weight, w.head, w.acc, grad_points)) return rc;
+    if (int rc = launch(det_convert_kernel, dim3(det_grid(accn)), dim3(kDetThreads), 0, st, accn, logc, w.head, w.acc,
+                       grad_points)) return rc;
+    return PN2_OK;
 }

@@ -126,13 +126,9 @@ static int launch_reg(int b, int n, int m, int Q, const float *inp, int *out, fl
 {
     const size_t lds = 256 + (LDSXYZ ? sizeof(float4) : sizeof(int)) * (size_t)T * P;
     auto kern = fps_reg_kernel<T, P, LDSXYZ>;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(kern, dim3(b), dim3(T), lds, st, n, m, Q, inp, out, oxyz);
-    return launch_status();
+    if (int rc = allow_dynamic_lds(kern, lds)) return rc;
+    if (int rc = launch(kern, dim3(b), dim3(T), lds, st, n, m, Q, inp, out, oxyz)) return rc;
+    return PN2_OK;
 }
 
 constexpr int kMaxLdsSlots = 8192;     // 256 B + 16 B per rank slot <= 160 KiB
@@ -190,8 +186,8 @@ static int fps_entry(int b, int n, int m, const float *inp, float *temp, int *ou
     hipStream_t st = as_stream(stream);
     if (n > kMaxRegPoints) {
         if (!temp) return PN2_E_NULL;
-        hipLaunchKernelGGL(fps_generic_kernel, dim3(b), dim3(1024), 0, st, n, m, inp, temp, out, out_xyz);
-        return launch_status();
+        if (int rc = launch(fps_generic_kernel, dim3(b), dim3(1024), 0, st, n, m, inp, temp, out, out_xyz)) return rc;
+        return PN2_OK;
     }
     const int Q = (n + kRefThreads - 1) / kRefThreads;
     const int ranks = kRefThreads * Q;
@@ -215,7 +211,7 @@ extern "C" int pn2_farthest_point_sample_gather(int b, int n, int m, const float
 }
 
 // tuning / test hook: run the register tier with an explicit geometry
-extern "C" int pn2_debug_fps_config(int T, int P, int b, int n, int m, const float *inp, int *out, void *stream)
+extern "C" int pn2_farthest_point_sample_ex(int T, int P, int b, int n, int m, const float *inp, int *out, void *stream)
 {
     if (m <= 0 || b <= 0 || n <= 0 || !inp || !out) return PN2_E_ARG;
     if (n > pn2::kMaxRegPoints) return PN2_E_TOO_LARGE;

@@ -58,6 +58,66 @@ __device__ __forceinline__ double wave_max_f64_lane63(double v)
     return v;
 }
 
+// The same wave arg-max in 32-bit operations (PN2_FPS_WAVE32). A key is the pair (hi = value bits, lo = low
+// word, larger lo = smaller rank). hi is a non-negative fp32, so its bit pattern orders like an unsigned
+// integer and the lexicographic max splits into
+//   1. an ALL-REDUCE of hi: four in-row butterfly steps, ONE v_max_u32 with a DPP operand each, then the
+//      xor-16 and xor-32 exchanges with gfx950's v_permlane16/32_swap (copy, swap, max);
+//   2. lo' = (hi == wave max) ? lo : 0 -- only the lanes that hold the maximum value stay in the race;
+//   3. a plain max ladder of lo' that ends in lane 63 (four in-row steps + row_bcast:15 + row_bcast:31).
+// 18 single-issue 32-bit instructions with ~10 dependent DPP hops, against six steps of
+// (2 x v_mov_b32_dpp + v_max_f64) = 18 instructions whose fp64 op has twice the latency.
+// A VGPR written by a VALU instruction may be read through DPP two wait states later at the earliest;
+// inside inline asm the compiler's hazard recogniser does not see the instructions, hence the s_nop 1.
+#ifndef PN2_FPS_WAVE32
+#define PN2_FPS_WAVE32 0
+#endif
+#ifndef PN2_FPS_LATE_STORE
+#define PN2_FPS_LATE_STORE 0
+#endif
+__device__ __forceinline__ void wave_max_key32_lane63(unsigned hi, unsigned lo, unsigned &whi, unsigned &wlo)
+{
+    unsigned m, t, l;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %[m], %[hi], %[hi] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %[m], %[m], %[m] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %[m], %[m], %[m] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %[m], %[m], %[m] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32 %[t], %[m]\n\t"
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %[t], %[m]\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32 %[m], %[m], %[t]\n\t"
+        "v_mov_b32 %[t], %[m]\n\t"
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %[t], %[m]\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32 %[m], %[m], %[t]\n\t"
+        "v_cmp_eq_u32 vcc, %[m], %[hi]\n\t"
+        "v_cndmask_b32 %[l], 0, %[lo], vcc\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %[l], %[l], %[l] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %[l], %[l], %[l] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %[l], %[l], %[l] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %[l], %[l], %[l] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %[l], %[l], %[l] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %[l], %[l], %[l] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        : [m] "=&v"(m), [t] "=&v"(t), [l] "=&v"(l)
+        : [hi] "v"(hi), [lo] "v"(lo)
+        : "vcc");
+    whi = m;
+    wlo = l;
+}
+
 // Fused gather_point: new_xyz[j] = inp[idx[j]], written once after the last round by the whole
 // workgroup (coalesced). Doing it inside the round loop costs: the extra live scalars made hipcc
 // switch the arg-max compares from SGPR-pair to VCC encodings, which serialised the selects
@@ -195,6 +255,10 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
     }
 
     const unsigned low0 = (unsigned)(NS - 1 - t * P);   // key low word of this thread's slot 0: larger = smaller rank
+    // PN2_FPS_LATE_STORE: thread 0's store of sample j sits between the winner read and the distance update
+    // (exec-mask juggling + a branch on the critical path); with the switch on it is issued one round later,
+    // right after the barrier, while the key reads are in flight.
+    int kprev = 0;
     // one round; `par` (the partial buffer parity) is a literal at both call sites so the slot
     // addresses fold to constants (scalar address arithmetic costs 4-cycle issue slots)
     auto round = [&](const int j, const int par) __attribute__((always_inline)) {
@@ -245,7 +309,11 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
         const double bestd = kd[0];
         // whole-wave key max in VALU only; lane 63 ends up with it and publishes it
         unsigned long long *slot = partial + par * W;
-        {
+        if (PN2_FPS_WAVE32) {
+            unsigned whi, wlo;
+            wave_max_key32_lane63((unsigned)__double2hiint(bestd), (unsigned)__double2loint(bestd), whi, wlo);
+            if (lane == 63) slot[w] = ((unsigned long long)whi << 32) | wlo;
+        } else {
             const double wd = wave_max_f64_lane63(bestd);
             if (lane == 63) reinterpret_cast<double *>(slot)[w] = wd;
         }
@@ -276,16 +344,29 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
         }
         int k;
         if (LDSXYZ) {
-            const float4 s = lds_rank[win];            // same address in every lane: LDS broadcast
+            typedef float pn2_f4 __attribute__((ext_vector_type(4)));
+            pn2_f4 s;                                  // same address in every lane: LDS broadcast
+            if (PN2_FPS_LATE_STORE && !PUBLISH) {
+                // issue the read, do thread 0's store of the PREVIOUS sample under its latency, then wait
+                asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(s) : "v"(win << 4) : "memory");
+                if (t == 0) dst[j - 1] = kprev;
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s) : : "memory");
+            } else {
+                const float4 q = lds_rank[win];
+                s.x = q.x; s.y = q.y; s.z = q.z; s.w = q.w;
+            }
             sx = s.x; sy = s.y; sz = s.z;
             sxy.x = s.x; sxy.y = s.y; szk.x = s.z; szk.y = s.w;
             k = __float_as_int(s.w);
         } else {
             k = lds_k[win];
+            if (PN2_FPS_LATE_STORE && !PUBLISH && t == 0) dst[j - 1] = kprev;
             sx = src[(size_t)k * 3 + 0]; sy = src[(size_t)k * 3 + 1]; sz = src[(size_t)k * 3 + 2];
             sxy.x = sx; sxy.y = sy; szk.x = sz;
         }
-        if (t == 0) {
+        if (PN2_FPS_LATE_STORE && !PUBLISH) {
+            kprev = k;                                 // stored by the NEXT round (or after the loop), see above
+        } else if (t == 0) {
             dst[j] = k;
             if (PUBLISH)
                 __hip_atomic_store(gtag + j, ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)k, __ATOMIC_RELAXED,
@@ -297,7 +378,8 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
         round(j, 1);
         round(j + 1, 0);
     }
-    if (j < m) round(j, 1);
+    if (j < m) { round(j, 1); ++j; }
+    if (PN2_FPS_LATE_STORE && !PUBLISH && t == 0 && m > 1) dst[m - 1] = kprev;
     fps_gather_epilogue<T>(m, src, dst, dxyz);
 }
 

@@ -166,6 +166,63 @@ __global__ __launch_bounds__(kThreads) void three_interpolate_v4_kernel(long lon
     }
 }
 
+// Second generation (see group.hip): grid = (parts per cloud) x (clouds) with the XCD-aware decode, the
+// (row, chunk) pair derived once per thread and advanced by constants (no integer division per element),
+// U rows' worth of idx / weight / three gathered rows in flight per lane.
+template <int U>
+__global__ __launch_bounds__(kThreads) void three_interpolate_rows_v4_kernel(int n, int m, int c4, int dr, int dl,
+                                                                             int rows_per_part, int parts, int b,
+                                                                             const float4 *__restrict__ points,
+                                                                             const int *__restrict__ idx,
+                                                                             const float *__restrict__ weight,
+                                                                             float4 *__restrict__ out)
+{
+    int cloud, part;
+    decode_cloud_block(blockIdx.x, parts, b, cloud, part);
+    const int rb = part * rows_per_part, re = min(rb + rows_per_part, n);
+    const int *__restrict__ idc = idx + (size_t)cloud * n * 3;
+    const float *__restrict__ wc = weight + (size_t)cloud * n * 3;
+    const float4 *__restrict__ src = points + (size_t)cloud * m * c4;
+    float4 *__restrict__ dst = out + (size_t)cloud * n * c4;
+    int r = rb + (int)threadIdx.x / c4, l = (int)threadIdx.x % c4;
+    while (r < re) {
+        int rr[U], ll[U], q0[U], q1[U], q2[U];
+        float w1[U], w2[U], w3[U];
+        float4 a[U], bb[U], cc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            rr[u] = r; ll[u] = l;
+            l += dl; r += dr;
+            if (l >= c4) { l -= c4; ++r; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = rr[u] < re ? rr[u] : rb;             // clamp: the loads stay in range, the store is skipped
+            const int *q = idc + (unsigned)row * 3u;
+            const float *w = wc + (unsigned)row * 3u;
+            q0[u] = q[0]; q1[u] = q[1]; q2[u] = q[2];
+            w1[u] = w[0]; w2[u] = w[1]; w3[u] = w[2];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a[u] = src[(unsigned)q0[u] * (unsigned)c4 + (unsigned)ll[u]];
+            bb[u] = src[(unsigned)q1[u] * (unsigned)c4 + (unsigned)ll[u]];
+            cc[u] = src[(unsigned)q2[u] * (unsigned)c4 + (unsigned)ll[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (rr[u] < re) {
+                float4 o;
+                o.x = interp3(a[u].x, bb[u].x, cc[u].x, w1[u], w2[u], w3[u]);
+                o.y = interp3(a[u].y, bb[u].y, cc[u].y, w1[u], w2[u], w3[u]);
+                o.z = interp3(a[u].z, bb[u].z, cc[u].z, w1[u], w2[u], w3[u]);
+                o.w = interp3(a[u].w, bb[u].w, cc[u].w, w1[u], w2[u], w3[u]);
+                dst[(unsigned)rr[u] * (unsigned)c4 + (unsigned)ll[u]] = o;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void three_interpolate_s_kernel(long long elems, int m, int n, int c,
                                                                        const float *__restrict__ points,
                                                                        const int *__restrict__ idx,
@@ -216,31 +273,59 @@ extern "C" int pn2_three_nn(int b, int n, int m, const float *xyz1, const float 
     if (b == 0 || n == 0) return PN2_OK;
     if (!xyz1 || !dist || !idx || (m > 0 && !xyz2)) return PN2_E_NULL;
     if (b > 65535) return PN2_E_TOO_LARGE;
-    hipLaunchKernelGGL(three_nn_kernel, dim3((n + kNnPoints - 1) / kNnPoints, b), dim3(kNnThreads), 0,
-                       as_stream(stream), n, m, xyz1, xyz2, dist, idx);
-    return launch_status();
+    if (int rc = launch(three_nn_kernel, dim3((n + kNnPoints - 1) / kNnPoints, b), dim3(kNnThreads), 0,
+                       as_stream(stream), n, m, xyz1, xyz2, dist, idx)) return rc;
+    return PN2_OK;
+}
+
+static int three_interpolate_entry(int b, int m, int c, int n, const float *points, const int *idx, const float *weight,
+                                   float *out, int variant, void *stream)
+{
+    using namespace pn2;
+    if (b < 0 || m <= 0 || c <= 0 || n < 0) return PN2_E_SHAPE;
+    if (variant < 0 || variant > 2) return PN2_E_ARG;
+    const long long rows = (long long)b * n;
+    if (rows == 0) return PN2_OK;
+    if (!points || !idx || !weight || !out) return PN2_E_NULL;
+    hipStream_t st = as_stream(stream);
+    if (variant != 1 && c % 4 == 0 && aligned16(points) && aligned16(out) && (long long)m * c < (1ll << 31) &&
+        (long long)n * c < (1ll << 31) && (long long)b * 4096 < INT_MAX) {
+        constexpr int U = 2;
+        const int c4 = c / 4;
+        const int rows_min = (kThreads * U * 2 + c4 - 1) / c4;
+        int parts = (4096 + b - 1) / b;
+        const int most = (n + rows_min - 1) / rows_min;
+        if (parts > most) parts = most;
+        if (parts < 1) parts = 1;
+        const int rpp = (n + parts - 1) / parts;
+        return launch((three_interpolate_rows_v4_kernel<U>), dim3((unsigned)parts * b), dim3(kThreads), 0, st, n, m, c4,
+                      kThreads / c4, kThreads % c4, rpp, parts, b, reinterpret_cast<const float4 *>(points), idx, weight,
+                      reinterpret_cast<float4 *>(out));
+    }
+    if (c % 4 == 0 && aligned16(points) && aligned16(out)) {
+        const long long chunks = rows * (c / 4);
+        if (int rc = launch(three_interpolate_v4_kernel, dim3(grid_for(chunks)), dim3(kThreads), 0, st, chunks, m, n,
+                           c / 4, reinterpret_cast<const float4 *>(points), idx, weight,
+                           reinterpret_cast<float4 *>(out))) return rc;
+    } else {
+        const long long elems = rows * c;
+        if (int rc = launch(three_interpolate_s_kernel, dim3(grid_for(elems)), dim3(kThreads), 0, st, elems, m, n, c,
+                           points, idx, weight, out)) return rc;
+    }
+    return PN2_OK;
 }
 
 extern "C" int pn2_three_interpolate(int b, int m, int c, int n, const float *points, const int *idx,
                                      const float *weight, float *out, void *stream)
 {
-    using namespace pn2;
-    if (b < 0 || m <= 0 || c <= 0 || n < 0) return PN2_E_SHAPE;
-    const long long rows = (long long)b * n;
-    if (rows == 0) return PN2_OK;
-    if (!points || !idx || !weight || !out) return PN2_E_NULL;
-    hipStream_t st = as_stream(stream);
-    if (c % 4 == 0 && aligned16(points) && aligned16(out)) {
-        const long long chunks = rows * (c / 4);
-        hipLaunchKernelGGL(three_interpolate_v4_kernel, dim3(grid_for(chunks)), dim3(kThreads), 0, st, chunks, m, n,
-                           c / 4, reinterpret_cast<const float4 *>(points), idx, weight,
-                           reinterpret_cast<float4 *>(out));
-    } else {
-        const long long elems = rows * c;
-        hipLaunchKernelGGL(three_interpolate_s_kernel, dim3(grid_for(elems)), dim3(kThreads), 0, st, elems, m, n, c,
-                           points, idx, weight, out);
-    }
-    return launch_status();
+    return three_interpolate_entry(b, m, c, n, points, idx, weight, out, 0, stream);
+}
+
+// pn2_three_interpolate with the kernel choice per call: 0 automatic, 1 flat first-generation kernels, 2 row kernel.
+extern "C" int pn2_three_interpolate_ex(int b, int m, int c, int n, const float *points, const int *idx,
+                                        const float *weight, float *out, int variant, void *stream)
+{
+    return three_interpolate_entry(b, m, c, n, points, idx, weight, out, variant, stream);
 }
 
 extern "C" int pn2_three_interpolate_grad(int b, int n, int c, int m, const float *grad_out, const int *idx,
@@ -256,7 +341,7 @@ extern "C" int pn2_three_interpolate_grad(int b, int n, int c, int m, const floa
     const long long elems = (long long)b * n * c;
     if (elems == 0) return PN2_OK;
     if (!grad_out || !idx || !weight) return PN2_E_NULL;
-    hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3(grid_for(elems)), dim3(kThreads), 0, st, elems, m, n, c,
-                       grad_out, idx, weight, grad_points);
-    return launch_status();
+    if (int rc = launch(three_interpolate_grad_kernel, dim3(grid_for(elems)), dim3(kThreads), 0, st, elems, m, n, c,
+                       grad_out, idx, weight, grad_points)) return rc;
+    return PN2_OK;
 }

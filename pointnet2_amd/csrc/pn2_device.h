@@ -9,6 +9,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <tuple>
+#include <unordered_set>
+#include <utility>
+
 #include "../../include/pn2ops.h"
 
 #define PN2_WAVE 64
@@ -71,9 +76,70 @@ __device__ __forceinline__ int mbcnt(unsigned long long mask)
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
+// Block number -> (cloud, part) for kernels that launch `parts` workgroups per cloud, all of which read
+// the same cloud (ball query: the staged points; group / interpolate: the gathered source rows). Workgroup i runs on XCD i % 8 (observed dispatch rule; used for speed only), and every XCD has
+// its own L2: with the plain map i -> (i / parts, i % parts) the workgroups of one cloud land on different
+// XCDs and each of them misses its L2 (rocprofv3, round 1: 6.7x the algorithmic read traffic). Here the
+// workgroups of a cloud share i % 8, so the first one's fetch serves the others from that XCD's L2.
+// Clouds beyond the last multiple of eight use the plain map. Bijective for every (parts, b).
+__device__ __forceinline__ void decode_cloud_block(unsigned i, int parts, int b, int &cloud, int &part)
+{
+    const unsigned full = (unsigned)(b & ~7) * (unsigned)parts;
+    if (i < full) {
+        const unsigned x = i & 7u, s = i >> 3;
+        cloud = (int)((s / (unsigned)parts) * 8u + x);
+        part = (int)(s % (unsigned)parts);
+    } else {
+        cloud = (int)(i / (unsigned)parts);
+        part = (int)(i % (unsigned)parts);
+    }
+}
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
-// launch status -> C ABI return (positive hipError_t)
-inline int launch_status() { return (int)hipGetLastError(); }
+// ---- host side: launching ---------------------------------------------------------------------
+// pn2::launch enqueues `kern` with hipLaunchKernel and returns THAT call's hipError_t as the C ABI's
+// positive return code. (hipGetLastError() after a <<<>>> launch would also report -- and clear -- a
+// stale error left behind by some earlier, unrelated runtime call of the thread.) Arguments are
+// converted to the kernel's parameter types first, like a direct call would.
+template <typename... KArgs, size_t... I>
+inline int launch_packed(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st,
+                         std::tuple<KArgs...> &vals, std::index_sequence<I...>)
+{
+    void *ptrs[] = {const_cast<void *>(static_cast<const void *>(&std::get<I>(vals)))..., nullptr};
+    return (int)hipLaunchKernel(reinterpret_cast<const void *>(kern), grid, block, ptrs, lds, st);
+}
+
+template <typename... KArgs, typename... Args>
+inline int launch(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args &&...args)
+{
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "argument count must match the kernel's parameter list");
+    std::tuple<KArgs...> vals{static_cast<KArgs>(std::forward<Args>(args))...};
+    return launch_packed(kern, grid, block, lds, st, vals, std::index_sequence_for<KArgs...>{});
+}
+
+// Kernels that ask for more than 48 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize
+// raised once. The attribute call costs microseconds, so it is made ONCE per (device, kernel) -- for the
+// whole 160 KiB of a gfx950 CU -- and remembered; this is the library's only process state, and it is
+// idempotent (every launch passes its exact size).
+template <typename K>
+inline int allow_dynamic_lds(K kern, size_t bytes)
+{
+    if (bytes <= 48 * 1024) return 0;
+    if (bytes > 160 * 1024) return PN2_E_TOO_LARGE;
+    static std::mutex mu;
+    static std::unordered_set<unsigned long long> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const unsigned long long key = (unsigned long long)reinterpret_cast<uintptr_t>(reinterpret_cast<const void *>(kern)) ^
+                                   ((unsigned long long)dev << 56);
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count(key)) return 0;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    done.insert(key);
+    return 0;
+}
 
 }  // namespace pn2

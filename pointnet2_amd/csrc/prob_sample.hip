@@ -112,12 +112,10 @@ extern "C" int pn2_prob_sample(int b, int n, int m, const float *inp_p, const fl
     if (!inp_p || !inp_r || !temp || !out) return PN2_E_NULL;
     if (b > 65535) return PN2_E_TOO_LARGE;
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(cumsum_kernel, dim3(b), dim3(kPsThreads), 0, st, n, inp_p, temp);
-    int e = launch_status();
-    if (e) return e;
+    if (int rc = launch(cumsum_kernel, dim3(b), dim3(kPsThreads), 0, st, n, inp_p, temp)) return rc;
     int base = 1;
     while (base < n) base <<= 1;
     const int gx = (m + 255) / 256 > 64 ? 64 : (m + 255) / 256;
-    hipLaunchKernelGGL(inverse_cdf_kernel, dim3(gx, b), dim3(256), 0, st, n, m, base, temp, inp_r, out);
-    return launch_status();
+    if (int rc = launch(inverse_cdf_kernel, dim3(gx, b), dim3(256), 0, st, n, m, base, temp, inp_r, out)) return rc;
+    return PN2_OK;
 }

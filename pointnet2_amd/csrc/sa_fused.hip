@@ -74,17 +74,15 @@ static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, unsi
     if (lds < kFusedMinLds) lds = kFusedMinLds;
     if (lds > 160 * 1024) return PN2_E_TOO_LARGE;
     auto kern = sa_fused_kernel<P>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    if (int rc = allow_dynamic_lds(kern, lds)) return rc;
     if (tag == 0) {                                               // caller did not manage generations: clear, use tag 1
-        e = hipMemsetAsync(ws, 0, sizeof(unsigned long long) * (size_t)b * m, st);
+        hipError_t e = hipMemsetAsync(ws, 0, sizeof(unsigned long long) * (size_t)b * m, st);
         if (e != hipSuccess) return (int)e;
         tag = 1u;
     }
-    hipLaunchKernelGGL(kern, dim3(b + nq * b), dim3(kFusedThreads), lds, st, b, n, m, Q, nsample, thr, qpb, tag, xyz, ws,
-                       fps_idx, new_xyz, idx, pts_cnt, grouped, subtract);
-    return launch_status();
+    if (int rc = launch(kern, dim3(b + nq * b), dim3(kFusedThreads), lds, st, b, n, m, Q, nsample, thr, qpb, tag, xyz, ws,
+                       fps_idx, new_xyz, idx, pts_cnt, grouped, subtract)) return rc;
+    return PN2_OK;
 }
 
 }  // namespace pn2

@@ -255,14 +255,12 @@ static int launch_mlp(int b, int n, int m, int nsample, int cfeat, int c3, const
     const long long groups = half ? (rows + 1) / 2 : rows;
     long long blocks = (groups + 3) / 4;
     long long cap = 512;                                  // persistent: every workgroup stages the weights once
-    if (const char *e = getenv("PN2_MLP_BLOCKS")) cap = atoll(e);   // tuning hook
     if (blocks > cap) blocks = cap;
     auto kern = half ? sa_mlp3_kernel<T1, T2, T3, 16> : sa_mlp3_kernel<T1, T2, T3, 32>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kMlpThreads), lds, st, n, m, nsample, cfeat, c3, rows, xyz, new_xyz,
-                       points, idx, wp, bp, out);
-    return launch_status();
+    if (int rc = allow_dynamic_lds(kern, lds)) return rc;
+    if (int rc = launch(kern, dim3((unsigned)blocks), dim3(kMlpThreads), lds, st, n, m, nsample, cfeat, c3, rows, xyz, new_xyz,
+                       points, idx, wp, bp, out)) return rc;
+    return PN2_OK;
 }
 
 // Which kernel runs a stack: the resident one when the input is narrow and the weights fit in LDS,

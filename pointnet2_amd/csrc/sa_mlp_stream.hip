@@ -252,11 +252,10 @@ static int launch_stream(const MlpStreamConfig &c, int b, int n, int m, int nsam
     const long long rows = (long long)b * m;
     long long blocks = (rows + 3) / 4;
     long long cap = 512;
-    if (const char *e = getenv("PN2_MLP_BLOCKS")) cap = atoll(e);   // tuning hook
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((sa_mlp3_stream_kernel<T1, T2, T3>), dim3((unsigned)blocks), dim3(kMlpThreads), 0, st, n, m, nsample,
-                       cfeat, c3, rows, c.ti, xyz, new_xyz, points, idx, wp, bp, out);
-    return launch_status();
+    if (int rc = launch((sa_mlp3_stream_kernel<T1, T2, T3>), dim3((unsigned)blocks), dim3(kMlpThreads), 0, st, n, m, nsample,
+                       cfeat, c3, rows, c.ti, xyz, new_xyz, points, idx, wp, bp, out)) return rc;
+    return PN2_OK;
 }
 
 int mlp_stream_launch(const MlpStreamConfig &c, int b, int n, int m, int nsample, int cfeat, int c3, const float *xyz,

@@ -351,24 +351,26 @@ __global__ __launch_bounds__(kSegThreads) void seg_reduce_kernel(long long out_r
 }
 
 template <bool DET, int SRC_DIV>
-static void launch_reduce(long long out_rows, int rows, long long entries, int c, const float *grad_out, const float *weight,
-                          const SegWs &w, float *out, hipStream_t st)
+static int launch_reduce(long long out_rows, int rows, long long entries, int c, const float *grad_out, const float *weight,
+                         const SegWs &w, float *out, hipStream_t st)
 {
-    const bool vec4 = (c & 3) == 0;
+    // 16-byte row accesses need 16-byte aligned bases (a C-ABI caller may pass a sub-allocated pointer)
+    const bool vec4 = (c & 3) == 0 && ((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
     const int per = vec4 ? c / 4 : c;                             // lanes a row can use
     int lpr = 1;
     while (lpr < per && lpr < 64) lpr <<= 1;
     const long long threads = out_rows * lpr;
 #define PN2_SEG_CASE(L)                                                                                              \
     if (lpr == L) {                                                                                                  \
-        if (vec4) hipLaunchKernelGGL((seg_reduce_kernel<L, true, DET, SRC_DIV>), dim3(seg_grid(threads)), dim3(kSegThreads), 0, st, \
-                                     out_rows, rows, entries, c, grad_out, weight, w.start, w.sorted, w.list, out);            \
-        else hipLaunchKernelGGL((seg_reduce_kernel<L, false, DET, SRC_DIV>), dim3(seg_grid(threads)), dim3(kSegThreads), 0, st, \
-                                out_rows, rows, entries, c, grad_out, weight, w.start, w.sorted, w.list, out);                 \
-        return;                                                                                                      \
+        if (vec4)                                                                                                    \
+            return launch((seg_reduce_kernel<L, true, DET, SRC_DIV>), dim3(seg_grid(threads)), dim3(kSegThreads), 0, st, \
+                          out_rows, rows, entries, c, grad_out, weight, w.start, w.sorted, w.list, out);            \
+        return launch((seg_reduce_kernel<L, false, DET, SRC_DIV>), dim3(seg_grid(threads)), dim3(kSegThreads), 0, st, \
+                      out_rows, rows, entries, c, grad_out, weight, w.start, w.sorted, w.list, out);                \
     }
     PN2_SEG_CASE(1) PN2_SEG_CASE(2) PN2_SEG_CASE(4) PN2_SEG_CASE(8) PN2_SEG_CASE(16) PN2_SEG_CASE(32) PN2_SEG_CASE(64)
 #undef PN2_SEG_CASE
+    return PN2_E_TOO_LARGE;
 }
 
 // invert idx (b clouds x `entries` references into `rows` targets), then reduce
@@ -384,23 +386,18 @@ static int seg_grad(int b, int rows, long long entries, int c, const float *grad
         const bool sort = deterministic && with_list <= 144 * 1024;   // + 8 KiB static for the long-row lists
         const size_t lds = sort ? with_list : sizeof(int) * (size_t)rows;
         auto kern = sort ? seg_invert_lds_kernel<true> : seg_invert_lds_kernel<false>;
-        if (lds > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-        }
-        hipLaunchKernelGGL(kern, dim3(b), dim3(1024), lds, st, entries, rows, idx, w.start, w.sorted, w.list);
+        if (int rc = allow_dynamic_lds(kern, lds)) return rc;
+        if (int rc = launch(kern, dim3(b), dim3(1024), lds, st, entries, rows, idx, w.start, w.sorted, w.list)) return rc;
     } else {
     hipError_t e = hipMemsetAsync(w.cursor, 0, 2 * sizeof(int) * (size_t)b * rows, st);   // counters and sorted flags
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(seg_count_kernel, dim3(seg_grid(total)), dim3(kSegThreads), 0, st, total, entries, rows, idx, w.cursor);
-    hipLaunchKernelGGL(seg_scan_kernel, dim3(b), dim3(1024), 0, st, rows, w.start, w.cursor);
-    hipLaunchKernelGGL(seg_fill_kernel, dim3(seg_grid(total)), dim3(kSegThreads), 0, st, total, entries, rows, idx, w.cursor, w.list);
+    if (int rc = launch(seg_count_kernel, dim3(seg_grid(total)), dim3(kSegThreads), 0, st, total, entries, rows, idx, w.cursor)) return rc;
+    if (int rc = launch(seg_scan_kernel, dim3(b), dim3(1024), 0, st, rows, w.start, w.cursor)) return rc;
+    if (int rc = launch(seg_fill_kernel, dim3(seg_grid(total)), dim3(kSegThreads), 0, st, total, entries, rows, idx, w.cursor, w.list)) return rc;
     }
     const long long out_rows = (long long)b * rows;
-    if (deterministic) launch_reduce<true, SRC_DIV>(out_rows, rows, entries, c, grad_out, weight, w, out, st);
-    else launch_reduce<false, SRC_DIV>(out_rows, rows, entries, c, grad_out, weight, w, out, st);
-    return launch_status();
+    return deterministic ? launch_reduce<true, SRC_DIV>(out_rows, rows, entries, c, grad_out, weight, w, out, st)
+                         : launch_reduce<false, SRC_DIV>(out_rows, rows, entries, c, grad_out, weight, w, out, st);
 }
 
 }  // namespace pn2

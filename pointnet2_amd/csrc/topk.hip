@@ -312,17 +312,13 @@ extern "C" int pn2_selection_sort(int b, int n, int m, int k, const float *dist,
     if (n <= kSortMaxLdsN) {
         const size_t lds = 8 * (size_t)n;
         auto kern = selection_sort_wave_kernel;
-        if (lds > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-        }
-        hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(64), lds, st, n, k, dist, outi, out);
+        if (int rc = allow_dynamic_lds(kern, lds)) return rc;
+        if (int rc = launch(kern, dim3((unsigned)rows), dim3(64), lds, st, n, k, dist, outi, out)) return rc;
     } else {
-        hipLaunchKernelGGL(selection_sort_serial_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, rows, n,
-                           k, dist, outi, out);
+        if (int rc = launch(selection_sort_serial_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, rows, n,
+                           k, dist, outi, out)) return rc;
     }
-    return launch_status();
+    return PN2_OK;
 }
 
 extern "C" int pn2_knn_point(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
@@ -338,11 +334,7 @@ extern "C" int pn2_knn_point(int b, int n, int m, int k, const float *xyz1, cons
     if (n > kSortMaxLdsN - 2048) return PN2_E_TOO_LARGE;    // callers keep the matrix + pn2_selection_sort path
     const size_t lds = 8 * (size_t)n + sizeof(int) * (256 + 3 * (size_t)kKnnCap);
     auto kern = knn_wave_kernel;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(64), lds, as_stream(stream), n, m, k, xyz1, xyz2, val, idx);
-    return launch_status();
+    if (int rc = allow_dynamic_lds(kern, lds)) return rc;
+    if (int rc = launch(kern, dim3((unsigned)rows), dim3(64), lds, as_stream(stream), n, m, k, xyz1, xyz2, val, idx)) return rc;
+    return PN2_OK;
 }

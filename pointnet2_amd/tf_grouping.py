@@ -14,6 +14,17 @@ from ._tensors import (use_segmented_grad, det_workspace, f32, i32, is_determini
                        same_device, seg_workspace, stream_ptr)
 
 
+# Ball-query kernel choice passed with every call (pn2_query_ball_group_xyz_ex): 0 automatic, 1 sweep,
+# 2 cell list, 3 cell list with 512-thread workgroups; second number = queries per workgroup of the
+# cell-list kernel (0 automatic). Results never depend on it; the tests force every kernel, scripts tune.
+_BQ_KERNEL = [0, 0]
+
+
+def set_ball_query_kernel(kernel=0, cells_qpb=0):
+    require(int(kernel) in (0, 1, 2, 3) and int(cells_qpb) >= 0, "kernel in 0..3, cells_qpb >= 0")
+    _BQ_KERNEL[0], _BQ_KERNEL[1] = int(kernel), int(cells_qpb)
+
+
 def query_ball_point(radius, nsample, xyz1, xyz2):
     """radius float, nsample int, xyz1 (b, ndataset, 3), xyz2 (b, npoint, 3)
     -> idx (b, npoint, nsample) i32, pts_cnt (b, npoint) i32.
@@ -34,8 +45,13 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     idx = torch.empty((b, m, ns), dtype=torch.int32, device=dev)
     cnt = torch.empty((b, m), dtype=torch.int32, device=dev)
     with on_device(dev):
-        _C.check(_C.lib().pn2_query_ball_point(b, n, m, float(radius), ns, ptr(xyz1), ptr(xyz2), ptr(idx), ptr(cnt),
-                                               stream_ptr(dev)), "query_ball_point")
+        if _BQ_KERNEL[0] or _BQ_KERNEL[1]:
+            _C.check(_C.lib().pn2_query_ball_group_xyz_ex(b, n, m, float(radius), ns, ptr(xyz1), ptr(xyz2), 0, ptr(idx),
+                                                          ptr(cnt), None, _BQ_KERNEL[0], _BQ_KERNEL[1],
+                                                          stream_ptr(dev)), "query_ball_point")
+        else:
+            _C.check(_C.lib().pn2_query_ball_point(b, n, m, float(radius), ns, ptr(xyz1), ptr(xyz2), ptr(idx),
+                                                   ptr(cnt), stream_ptr(dev)), "query_ball_point")
     return idx, cnt
 
 
@@ -62,10 +78,54 @@ def query_ball_group_xyz(radius, nsample, xyz1, xyz2, subtract_centroid=True, wa
     cnt = torch.empty((b, m), dtype=torch.int32, device=dev)
     grouped = torch.empty((b, m, ns, 3), dtype=torch.float32, device=dev)
     with on_device(dev):
-        _C.check(_C.lib().pn2_query_ball_group_xyz(b, n, m, float(radius), ns, ptr(xyz1), ptr(xyz2),
-                                                   1 if subtract_centroid else 0, ptr(idx), ptr(cnt), ptr(grouped),
-                                                   stream_ptr(dev)), "query_ball_group_xyz")
+        _C.check(_C.lib().pn2_query_ball_group_xyz_ex(b, n, m, float(radius), ns, ptr(xyz1), ptr(xyz2),
+                                                      1 if subtract_centroid else 0, ptr(idx), ptr(cnt), ptr(grouped),
+                                                      _BQ_KERNEL[0], _BQ_KERNEL[1], stream_ptr(dev)),
+                 "query_ball_group_xyz")
     return idx, cnt, grouped
+
+
+def query_ball_group_xyz_msg(radius_list, nsample_list, xyz1, xyz2, subtract_centroid=True, want_idx=True):
+    """Every radius of a multi-scale-grouping level in ONE launch: the cloud is staged and binned once
+    per workgroup and queried once per radius (pn2_query_ball_group_xyz_msg; reference loop
+    pointnet_util.py:175-186 runs query_ball_point + group_point + subtraction per radius).
+    Bit-identical to query_ball_group_xyz called per radius. Not differentiable.
+
+    -> [(idx (b,m,ns_i) i32 or None, pts_cnt (b,m) i32, grouped_xyz (b,m,ns_i,3) f32) for every scale]
+    """
+    import ctypes
+    radius_list = [float(r) for r in radius_list]
+    nsample_list = [int(k) for k in nsample_list]
+    require(len(radius_list) == len(nsample_list) and 1 <= len(radius_list), "one nsample per radius")
+    require(all(r > 0 for r in radius_list), "QueryBallPoint expects positive radius")
+    require(all(k > 0 for k in nsample_list), "QueryBallPoint expects positive nsample")
+    xyz1 = f32(xyz1.detach(), "xyz1")
+    xyz2 = f32(xyz2.detach(), "xyz2")
+    require(xyz1.dim() == 3 and xyz1.shape[2] == 3, "QueryBallPoint expects (batch_size, ndataset, 3) xyz1 shape.")
+    require(xyz2.dim() == 3 and xyz2.shape[2] == 3 and xyz2.shape[0] == xyz1.shape[0],
+            "QueryBallPoint expects (batch_size, npoint, 3) xyz2 shape.")
+    dev = same_device(xyz1, xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    ns_count = len(radius_list)
+    if ns_count > 4 or n > 8192:                                  # outside the multi-radius kernel's envelope
+        return [query_ball_group_xyz(r, k, xyz1, xyz2, subtract_centroid, want_idx)
+                for r, k in zip(radius_list, nsample_list)]
+    outs = []
+    for k in nsample_list:
+        outs.append((torch.empty((b, m, k), dtype=torch.int32, device=dev) if want_idx else None,
+                     torch.empty((b, m), dtype=torch.int32, device=dev),
+                     torch.empty((b, m, k, 3), dtype=torch.float32, device=dev)))
+    radii = (ctypes.c_float * ns_count)(*radius_list)
+    nss = (ctypes.c_int * ns_count)(*nsample_list)
+    pi = (ctypes.c_void_p * ns_count)(*[ptr(o[0]) for o in outs])
+    pc = (ctypes.c_void_p * ns_count)(*[ptr(o[1]) for o in outs])
+    pg = (ctypes.c_void_p * ns_count)(*[ptr(o[2]) for o in outs])
+    with on_device(dev):
+        _C.check(_C.lib().pn2_query_ball_group_xyz_msg(b, n, m, ns_count, radii, nss, ptr(xyz1), ptr(xyz2),
+                                                       1 if subtract_centroid else 0, pi, pc, pg, stream_ptr(dev)),
+                 "query_ball_group_xyz_msg")
+    return outs
 
 
 # Sample-granule workspaces of the overlapped launch, one per (device, stream, size): zeroed once, then

@@ -16,19 +16,20 @@ q = P.gather_point(xyz, P.farthest_point_sample(m, xyz))
 idx = torch.empty(b, m, ns, dtype=torch.int32, device=dev)
 cnt = torch.empty(b, m, dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
-cfgs = [(1, 0), (2, 0), (3, 0), (2, 128), (2, 256)]          # (mode, qpb): see pn2_debug_bq_config
+cfgs = [(1, 0), (2, 0), (3, 0), (2, 128), (2, 256)]          # (kernel, qpb): see pn2_query_ball_group_xyz_ex
 if len(sys.argv) > 1:
     cfgs = [(2, int(v)) for v in sys.argv[1:]]
 for min_n, qpb in cfgs:
-    L.pn2_debug_bq_config(min_n, qpb)
+    def go():
+        return L.pn2_query_ball_group_xyz_ex(b, n, m, r, ns, xyz.data_ptr(), q.data_ptr(), 0, idx.data_ptr(), cnt.data_ptr(),
+                                             None, min_n, qpb, None)
     for _ in range(5):
-        rc = L.pn2_query_ball_point(b, n, m, r, ns, xyz.data_ptr(), q.data_ptr(), idx.data_ptr(), cnt.data_ptr(), None)
-        assert rc == 0
+        assert go() == 0
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
-        L.pn2_query_ball_point(b, n, m, r, ns, xyz.data_ptr(), q.data_ptr(), idx.data_ptr(), cnt.data_ptr(), None)
+        go()
     e1.record()
     torch.cuda.synchronize()
     print("mode=%d qpb=%d: %.1f us/launch (back-to-back)" % (min_n, qpb, e0.elapsed_time(e1) * 1e3 / 20), flush=True)

@@ -21,14 +21,14 @@ int main(int argc, char **argv)
         for (int T : {256, 512, 1024}) {
             const int P = n / T;
             if (P < 1 || P > 32 || (T == 1024 && P > 16)) continue;
-            if (pn2_debug_fps_config(T, P, b, n, m, d_xyz, d_out, nullptr)) { printf("launch failed T=%d P=%d\n", T, P); continue; }
+            if (pn2_farthest_point_sample_ex(T, P, b, n, m, d_xyz, d_out, nullptr)) { printf("launch failed T=%d P=%d\n", T, P); continue; }
             CK(hipDeviceSynchronize());
             std::vector<int> got((size_t)b * m);
             CK(hipMemcpy(got.data(), d_out, got.size() * 4, hipMemcpyDeviceToHost));
             if (ref.empty()) ref = got;
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             CK(hipEventRecord(e0));
-            for (int r = 0; r < 5; ++r) pn2_debug_fps_config(T, P, b, n, m, d_xyz, d_out, nullptr);
+            for (int r = 0; r < 5; ++r) pn2_farthest_point_sample_ex(T, P, b, n, m, d_xyz, d_out, nullptr);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             printf("%-16s n=%5d T=%4d P=%2d : %7.1f ns/round %s\n", tag, n, T, P, ms * 1e6f / 5 / (m - 1), got == ref ? "same" : "DIFF");

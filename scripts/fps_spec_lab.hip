@@ -53,7 +53,7 @@ int main()
             if (P < 1 || P > 32 || (long long)T * P > 8192) continue;
             for (int spec = 0; spec < 2; ++spec) {
                 auto run = [&]() { return spec ? pn2_debug_fps_spec(T, P, b, n, m, d_xyz, d_out, nullptr)
-                                               : pn2_debug_fps_config(T, P, b, n, m, d_xyz, d_out, nullptr); };
+                                               : pn2_farthest_point_sample_ex(T, P, b, n, m, d_xyz, d_out, nullptr); };
                 CK(hipMemset(d_out, 0xff, (size_t)b * m * 4));
                 if (run()) { printf("n=%d T=%d P=%d spec=%d: launch refused\n", n, T, P, spec); continue; }
                 CK(hipDeviceSynchronize());

@@ -50,12 +50,12 @@ def main():
         for Pp in (4, 8, 16, 32):
             if T * Pp < N or (T == 1024 and Pp == 32):
                 continue
-            rc = _C.lib().pn2_debug_fps_config(T, Pp, B, N, M, x.data_ptr(), out.data_ptr(), st)
+            rc = _C.lib().pn2_farthest_point_sample_ex(T, Pp, B, N, M, x.data_ptr(), out.data_ptr(), st)
             if rc != 0:
                 sweep["%dx%d" % (T, Pp)] = "rc=%d" % rc
                 continue
             ok = bool((out == fps).all())
-            us = timeit(lambda: _C.lib().pn2_debug_fps_config(T, Pp, B, N, M, x.data_ptr(), out.data_ptr(), st), 5, 1)
+            us = timeit(lambda: _C.lib().pn2_farthest_point_sample_ex(T, Pp, B, N, M, x.data_ptr(), out.data_ptr(), st), 5, 1)
             sweep["%dx%d" % (T, Pp)] = {"us": us, "ns_per_iter": us * 1e3 / (M - 1), "ok": ok}
     res["fps_sweep_n4096"] = sweep
     # other shapes

@@ -1,4 +1,5 @@
-"""The cell-list ball-query kernel against the oracle (GPU). pn2_debug_bq_config forces the kernel
+"""The cell-list ball-query kernel against the oracle (GPU). tf_grouping.set_ball_query_kernel (the
+per-call kernel argument of pn2_query_ball_group_xyz_ex) forces the kernel
 choice so that both kernels are covered at every shape, including the ones the automatic dispatch would
 send the other way; the automatic choice is covered by the rest of the suite."""
 import numpy as np
@@ -12,10 +13,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture()
 def bq_mode():
-    from pointnet2_amd import _C
-    lib = _C.lib()
-    yield lambda mode, qpb=0: lib.pn2_debug_bq_config(mode, qpb)
-    lib.pn2_debug_bq_config(0, 0)
+    from pointnet2_amd import tf_grouping
+    yield lambda mode, qpb=0: tf_grouping.set_ball_query_kernel(mode, qpb)
+    tf_grouping.set_ball_query_kernel(0, 0)
 
 
 def _dev(a, cuda):

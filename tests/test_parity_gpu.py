@@ -91,7 +91,7 @@ def test_fps_all_geometries_agree(cuda, oracle):
             if T * Pp < 2048 or (T == 1024 and Pp == 32):
                 continue
             out = torch.zeros((3, 300), dtype=torch.int32, device=cuda)
-            rc = _C.lib().pn2_debug_fps_config(T, Pp, 3, 2048, 300, x.data_ptr(), out.data_ptr(),
+            rc = _C.lib().pn2_farthest_point_sample_ex(T, Pp, 3, 2048, 300, x.data_ptr(), out.data_ptr(),
                                                torch.cuda.current_stream().cuda_stream)
             assert rc == 0, (T, Pp, rc)
             assert np.array_equal(host(out), want), (T, Pp)
