@@ -4,43 +4,52 @@
 Metric (BASELINE.json): point-clouds/sec for SA(FPS+ball+group) B=32 N=4096->1024 nsample=32.
 One "step" = one pass of the hot path over one batch of synthetic clouds already resident in HBM:
 
-    fps_idx  = farthest_point_sample(1024, xyz)          (32,4096,3) f32 -> (32,1024) i32
-    new_xyz  = gather_point(xyz, fps_idx)                -> (32,1024,3) f32
-    idx, cnt = query_ball_point(0.2, 32, xyz, new_xyz)   -> (32,1024,32) i32, (32,1024) i32
-    grouped  = group_point(xyz, idx)                     -> (32,1024,32,3) f32
+    fps_idx  = farthest_point_sample(1024, xyz)          (B,4096,3) f32 -> (B,1024) i32
+    new_xyz  = gather_point(xyz, fps_idx)                -> (B,1024,3) f32
+    idx, cnt = query_ball_point(0.2, 32, xyz, new_xyz)   -> (B,1024,32) i32, (B,1024) i32
+    grouped  = group_point(xyz, idx)                     -> (B,1024,32,3) f32
 
 i.e. reference utils/pointnet_util.py:40-46, launched through the C ABI of libpn2ops.so
 (include/pn2ops.h) on torch's current HIP stream with caller-allocated outputs.
 
 --path overlap (default) is what pointnet2_amd.pointnet_util.sample_and_group launches: ONE kernel
 (pn2_sample_and_group_xyz) whose FPS workgroups publish every sample as it is selected while
-ball-query+group workgroups on the other CUs consume them, so the queries hide under the serial
-FPS chain. --path fused: TWO kernels (pn2_farthest_point_sample_gather, pn2_query_ball_group_xyz).
---path ops: the four reference-shaped operators one by one. All three produce the same outputs
-(fps_idx, new_xyz, idx, pts_cnt, grouped_xyz) and are parity-tested bit-exact against the oracle;
-`kernels` always reports the four op-level kernels.
+ball-query+group workgroups on the other CUs consume them. --path fused: TWO kernels
+(pn2_farthest_point_sample_gather, pn2_query_ball_group_xyz). --path ops: the four reference-shaped
+operators one by one. All three produce the same outputs, parity-tested bit-exact against the oracle.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
-Multi-GPU: the path shards by cloud with no data-path collective, so every rank
-processes its own B=32 batch ("weak" scaling); rank 0 prints ONE JSON line with the whole-job
-rate = N * 32 * K / max-over-ranks time.
+Multi-GPU: the path shards by cloud with no data-path collective. With --gpus N > 1 and
+no RANK in the environment this script re-launches ITSELF under torch.distributed.run (one process per
+GPU, rendezvous on 127.0.0.1); under an external torchrun it just joins. --scaling weak (default):
+every rank owns its own B=32 batch; --scaling strong: the global B=32 batch is sliced 32/N clouds per
+rank exactly as tf.slice does in the reference's tower loop (train_multi_gpu.py:185-188). Rank 0 prints
+ONE JSON line; `value` = clouds all ranks processed / max-over-ranks time of exactly K steps.
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel (farthest_point_sample, ~80 % of the step) against HBM:
-                  algorithmic bytes per launch / its HIP-event duration measured here. FPS is a
-                  serial chain of 1023 block-wide arg-max rounds, so this fraction is tiny by
-                  construction (SURVEY.md 8d "honest ceiling"); `kernels` lists every kernel of
-                  the step the same way and `stage` the whole step (851,968 B/cloud).
+  roofline     -- the kernel IN THE TIMED REGION against HBM: SURVEY 8(d)'s 851,968 algorithmic bytes
+                  per cloud x clouds per launch / the launch's average duration, HIP events on the
+                  launch stream around the K timed steps. The path is bound by the FPS chain (1023
+                  dependent block-wide arg-max rounds), so the fraction is tiny by construction; see
+                  fps_latency_model and DESIGN.md.
+  fps_latency_model -- rounds and nanoseconds per round of the FPS operator alone (the honest model).
+  kernels / stage   -- every op-level kernel of the step the same way.
+  d2           -- the same step on D2 clouds (uniform U[0,1)^3, radius 0.1: the reference harnesses'
+                  distribution).
+  sustained    -- the same step repeated for >= 1 s (not `value`; lets an external sampler see the GPU).
+  allreduce    -- N > 1: training's only exchange, the gradient mean over ranks (train_multi_gpu.py:91-126)
+                  as one flat-bucket all-reduce (sharding.allreduce_mean_) at the two model sizes.
   cpu_baseline -- the CPU oracle (oracle/pn2_oracle.c, a serial C restatement of the reference
-                  algorithms; the reference has no CPU farthest-point-sampling) timed on this
-                  host, one thread, on whole B=32 batches of the same workload for >= ~10 s.
+                  algorithms) on whole batches of the same workload, ONE thread (the reference's CPU
+                  loops are serial); cpu_baseline_all_cores -- the same code, one cloud per task on a
+                  thread pool over every logical core (SURVEY 8d "for fairness").
 """
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -50,7 +59,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from pointnet2_amd import _C, sharding, synthetic  # noqa: E402
+from pointnet2_amd import sharding, synthetic  # noqa: E402
+from pointnet2_amd.reference_configs import GRAD_BUCKET_FLOATS  # noqa: E402
 
 B, N, M, NS, RADIUS = 32, 4096, 1024, 32, 0.2
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
@@ -63,61 +73,69 @@ BYTES = {
     "group_point": M * NS * 4 + N * 12 + M * NS * 12,
 }
 STAGE_BYTES = sum(BYTES.values())   # 851,968
+TIMED_KERNEL = {"overlap": "sa_fused_kernel (pn2_sample_and_group_xyz: the whole stage in one launch)",
+                "fused": "fps_reg_kernel + ball_query_cells_kernel (two launches per step)",
+                "ops": "fps_reg_kernel, gather_point_kernel, ball_query_cells_kernel, group_point_c3_kernel"}
 
 
 class Stage:
-    """The four launches of one step, through the C ABI, with preallocated buffers."""
+    """The launches of one step, through the C ABI, with preallocated buffers."""
 
-    def __init__(self, dev, seed):
+    def __init__(self, dev, xyz_np, radius=RADIUS):
+        from pointnet2_amd import _C
+        self._C = _C
         self.dev = dev
         self.lib = _C.lib()
-        self.xyz = torch.from_numpy(synthetic.sphere_clouds(B, N, seed)).to(dev)
-        self.fps = torch.empty((B, M), dtype=torch.int32, device=dev)
-        self.new_xyz = torch.empty((B, M, 3), dtype=torch.float32, device=dev)
-        self.idx = torch.empty((B, M, NS), dtype=torch.int32, device=dev)
-        self.cnt = torch.empty((B, M), dtype=torch.int32, device=dev)
-        self.grouped = torch.empty((B, M, NS, 3), dtype=torch.float32, device=dev)
-        self.ws = torch.zeros((self.lib.pn2_sample_and_group_ws_bytes(B, M),), dtype=torch.uint8, device=dev)
+        self.radius = radius
+        self.b = xyz_np.shape[0]
+        b = self.b
+        self.xyz = torch.from_numpy(xyz_np).to(dev)
+        self.fps = torch.empty((b, M), dtype=torch.int32, device=dev)
+        self.new_xyz = torch.empty((b, M, 3), dtype=torch.float32, device=dev)
+        self.idx = torch.empty((b, M, NS), dtype=torch.int32, device=dev)
+        self.cnt = torch.empty((b, M), dtype=torch.int32, device=dev)
+        self.grouped = torch.empty((b, M, NS, 3), dtype=torch.float32, device=dev)
+        self.ws = torch.zeros((self.lib.pn2_sample_and_group_ws_bytes(b, M),), dtype=torch.uint8, device=dev)
         self.gen = 0                                  # granule generation of the overlapped launch (see overlap_)
         self.stream = torch.cuda.current_stream(dev).cuda_stream
 
     def fps_(self):
-        _C.check(self.lib.pn2_farthest_point_sample(B, N, M, self.xyz.data_ptr(), None, self.fps.data_ptr(),
-                                                    self.stream), "fps")
+        self._C.check(self.lib.pn2_farthest_point_sample(self.b, N, M, self.xyz.data_ptr(), None, self.fps.data_ptr(),
+                                                         self.stream), "fps")
 
     def gather_(self):
-        _C.check(self.lib.pn2_gather_point(B, N, M, self.xyz.data_ptr(), self.fps.data_ptr(),
-                                           self.new_xyz.data_ptr(), self.stream), "gather")
+        self._C.check(self.lib.pn2_gather_point(self.b, N, M, self.xyz.data_ptr(), self.fps.data_ptr(),
+                                                self.new_xyz.data_ptr(), self.stream), "gather")
 
     def ball_(self):
-        _C.check(self.lib.pn2_query_ball_point(B, N, M, RADIUS, NS, self.xyz.data_ptr(), self.new_xyz.data_ptr(),
-                                               self.idx.data_ptr(), self.cnt.data_ptr(), self.stream), "ball")
+        self._C.check(self.lib.pn2_query_ball_point(self.b, N, M, self.radius, NS, self.xyz.data_ptr(),
+                                                    self.new_xyz.data_ptr(), self.idx.data_ptr(), self.cnt.data_ptr(),
+                                                    self.stream), "ball")
 
     def group_(self):
-        _C.check(self.lib.pn2_group_point(B, N, 3, M, NS, self.xyz.data_ptr(), self.idx.data_ptr(),
-                                          self.grouped.data_ptr(), self.stream), "group")
+        self._C.check(self.lib.pn2_group_point(self.b, N, 3, M, NS, self.xyz.data_ptr(), self.idx.data_ptr(),
+                                               self.grouped.data_ptr(), self.stream), "group")
 
     def fps_gather_(self):
-        _C.check(self.lib.pn2_farthest_point_sample_gather(B, N, M, self.xyz.data_ptr(), None, self.fps.data_ptr(),
-                                                           self.new_xyz.data_ptr(), self.stream), "fps_gather")
+        self._C.check(self.lib.pn2_farthest_point_sample_gather(self.b, N, M, self.xyz.data_ptr(), None,
+                                                                self.fps.data_ptr(), self.new_xyz.data_ptr(),
+                                                                self.stream), "fps_gather")
 
     def ball_group_(self):
-        _C.check(self.lib.pn2_query_ball_group_xyz(B, N, M, RADIUS, NS, self.xyz.data_ptr(), self.new_xyz.data_ptr(),
-                                                   1, self.idx.data_ptr(), self.cnt.data_ptr(),
-                                                   self.grouped.data_ptr(), self.stream), "ball_group")
+        self._C.check(self.lib.pn2_query_ball_group_xyz(self.b, N, M, self.radius, NS, self.xyz.data_ptr(),
+                                                        self.new_xyz.data_ptr(), 1, self.idx.data_ptr(),
+                                                        self.cnt.data_ptr(), self.grouped.data_ptr(), self.stream),
+                      "ball_group")
 
     def overlap_(self):
         # generation-tagged granules (what pointnet2_amd.sample_and_group_xyz does): ws was zeroed once at
         # allocation, every step uses the next tag, so no per-step clear of the workspace
         self.gen += 1
-        _C.check(self.lib.pn2_sample_and_group_xyz_gen(B, N, M, RADIUS, NS, self.xyz.data_ptr(), self.ws.data_ptr(),
-                                                       self.gen, self.fps.data_ptr(), self.new_xyz.data_ptr(),
-                                                       self.idx.data_ptr(), self.cnt.data_ptr(),
-                                                       self.grouped.data_ptr(), 1, self.stream),
-                 "sample_and_group_xyz")
-
-    def step_overlap(self):
-        self.overlap_()
+        self._C.check(self.lib.pn2_sample_and_group_xyz_gen(self.b, N, M, self.radius, NS, self.xyz.data_ptr(),
+                                                            self.ws.data_ptr(), self.gen, self.fps.data_ptr(),
+                                                            self.new_xyz.data_ptr(), self.idx.data_ptr(),
+                                                            self.cnt.data_ptr(), self.grouped.data_ptr(), 1, self.stream),
+                      "sample_and_group_xyz")
 
     def step_ops(self):
         self.fps_()
@@ -129,28 +147,23 @@ class Stage:
         self.fps_gather_()
         self.ball_group_()
 
-
-def kernel_times(stage, reps=10, fused=False):
-    """Average duration of each kernel, HIP events on the launch stream (torch's current stream)."""
-    out = {}
-    table = ((("farthest_point_sample_gather", stage.fps_gather_), ("query_ball_group_xyz", stage.ball_group_))
-             if fused else
-             (("farthest_point_sample", stage.fps_), ("gather_point", stage.gather_),
-              ("query_ball_point", stage.ball_), ("group_point", stage.group_)))
-    for name, fn in table:
-        fn()
-        torch.cuda.synchronize()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for s, e in evs:
-            s.record()
-            fn()
-            e.record()
-        torch.cuda.synchronize()
-        out[name] = float(np.median([s.elapsed_time(e) for s, e in evs])) * 1e-3   # seconds
-    return out
+    def step(self, path):
+        return {"overlap": self.overlap_, "fused": self.step_fused, "ops": self.step_ops}[path]
 
 
-def one_kernel_time(fn, reps=10):
+class StubStage:
+    """CPU stand-in for the launches (tests/test_distributed.py drives the multi-process plumbing -- spawn,
+    rendezvous, barriers, max-over-ranks timing, the all-reduce leg -- on a machine without a GPU)."""
+
+    def __init__(self, b):
+        self.b = b
+
+    def step(self, path):
+        return lambda: time.sleep(2e-4)
+
+
+def event_time(fn, reps=10):
+    """Median duration of one call, HIP events on the launch stream (torch's current stream)."""
     fn()
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
@@ -159,7 +172,7 @@ def one_kernel_time(fn, reps=10):
         fn()
         e.record()
     torch.cuda.synchronize()
-    return float(np.median([s.elapsed_time(e) for s, e in evs])) * 1e-3
+    return float(np.median([s.elapsed_time(e) for s, e in evs])) * 1e-3   # seconds
 
 
 def mlp_roofline(stage):
@@ -173,12 +186,10 @@ def mlp_roofline(stage):
     layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
                (0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32)) for i in range(3)]
     packed = sa_mlp.PackedMLP3(layers, stage.xyz.device, NS)
-    t = one_kernel_time(lambda: sa_mlp.sa_mlp_maxpool(stage.xyz, stage.new_xyz, None, stage.idx, packed))
-    flops = 2.0 * B * M * NS * (3 * 64 + 64 * 64 + 64 * 128)
+    t = event_time(lambda: sa_mlp.sa_mlp_maxpool(stage.xyz, stage.new_xyz, None, stage.idx, packed))
+    flops = 2.0 * stage.b * M * NS * (3 * 64 + 64 * 64 + 64 * 128)
     return {"bound": "mfma", "kernel": "sa_mlp3_maxpool 3-64-64-128 on the step's idx (fp32 MFMA)", "achieved": flops / t / 1e12,
-            "peak": 157.3, "unit": "TFLOP/s", "frac": flops / t / 1e12 / 157.3, "us": t * 1e6,
-            "note": "HIP events around the Python call (~12 us of call overhead included); rocprofv3 + "
-                    "SQ_VALU_MFMA_BUSY_CYCLES in profiles/r01"}
+            "peak": 157.3, "unit": "TFLOP/s", "frac": flops / t / 1e12 / 157.3, "us": t * 1e6}
 
 
 def concurrent_throughput(dev, rank, path, streams, steps):
@@ -186,11 +197,10 @@ def concurrent_throughput(dev, rank, path, streams, steps):
     separate HIP streams. One FPS launch occupies 32 of the 256 CUs for its whole serial chain, so
     independent batches (prefetched SA1 inputs, concurrent requests) overlap almost perfectly."""
     ss = [torch.cuda.Stream(device=dev) for _ in range(streams)]
-    stages = []
+    fns = []
     for i, st in enumerate(ss):
         with torch.cuda.stream(st):
-            stages.append(Stage(dev, seed=2000 + 97 * rank + i))
-    fns = [{"overlap": sg.step_overlap, "fused": sg.step_fused, "ops": sg.step_ops}[path] for sg in stages]
+            fns.append(Stage(dev, synthetic.sphere_clouds(B, N, 2000 + 97 * rank + i)).step(path))
     for st, fn in zip(ss, fns):
         with torch.cuda.stream(st):
             fn()
@@ -207,6 +217,13 @@ def concurrent_throughput(dev, rank, path, streams, steps):
                     "strictly sequential steps on one stream"}
 
 
+def _oracle_stage(O, xyz, radius):
+    fps = O.farthest_point_sample(M, xyz)
+    new_xyz = O.gather_point(xyz, fps)
+    idx, _ = O.query_ball_point(radius, NS, xyz, new_xyz)
+    O.group_point(xyz, idx)
+
+
 def cpu_baseline(seed, budget_s=10.0):
     """The oracle on whole B=32 batches of the same workload, one thread. TEST INFRASTRUCTURE used
     as the reported CPU baseline only (never on the measured path)."""
@@ -215,10 +232,7 @@ def cpu_baseline(seed, budget_s=10.0):
     t0 = O.now()
     batches = 0
     while True:
-        fps = O.farthest_point_sample(M, xyz)
-        new_xyz = O.gather_point(xyz, fps)
-        idx, _ = O.query_ball_point(RADIUS, NS, xyz, new_xyz)
-        O.group_point(xyz, idx)
+        _oracle_stage(O, xyz, RADIUS)
         batches += 1
         dt = O.now() - t0
         if dt >= budget_s:
@@ -229,108 +243,238 @@ def cpu_baseline(seed, budget_s=10.0):
                       % (batches, dt, os.cpu_count() or 0)}
 
 
+def cpu_baseline_all_cores(seed, budget_s=10.0):
+    """The same oracle code with one cloud per task on a thread pool over every logical core (ctypes
+    releases the GIL for the duration of a C call): the 'OpenMP over the batch' figure of SURVEY 8(d)."""
+    import concurrent.futures as cf
+    import oracle as O
+    cores = os.cpu_count() or 1
+    clouds = max(cores, B)
+    xyz = synthetic.sphere_clouds(clouds, N, seed)
+    O.lib()
+    done = 0
+    t0 = O.now()
+    with cf.ThreadPoolExecutor(max_workers=cores) as pool:
+        while True:
+            list(pool.map(lambda i: _oracle_stage(O, xyz[i:i + 1], RADIUS), range(clouds)))
+            done += clouds
+            dt = O.now() - t0
+            if dt >= budget_s:
+                break
+    return {"value": done / dt, "unit": "clouds/s", "cores": cores, "kind": "port",
+            "sample": "%d clouds of the bench workload, one cloud per task on a %d-thread pool (every logical core) "
+                      "through oracle/pn2_oracle.c in %.1f s" % (done, cores, dt)}
+
+
+def allreduce_leg(dev, dist, reps=20):
+    """Training's only exchange (train_multi_gpu.py:91-126): the gradient mean over ranks as ONE flat-bucket
+    all-reduce (sharding.allreduce_mean_), timed at the two data-parallel models' gradient sizes."""
+    out = {}
+    world = dist.get_world_size()
+    for name, floats in GRAD_BUCKET_FLOATS.items():
+        g = torch.ones((floats,), dtype=torch.float32, device=dev)
+        for _ in range(3):
+            sharding.allreduce_mean_([g])
+        ts = []
+        for _ in range(reps):
+            dist.barrier()
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sharding.allreduce_mean_([g])
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            ts.append(sharding.max_over_ranks(time.perf_counter() - t0, dev))
+        t = float(np.median(ts))
+        nbytes = floats * 4
+        out[name] = {"floats": floats, "us": t * 1e6, "algbw_GBps": nbytes / t / 1e9,
+                     "busbw_GBps": nbytes / t / 1e9 * 2 * (world - 1) / world, "mean_ok": bool(torch.all(g == 1.0).item())}
+    out["note"] = ("one all-reduce(sum) over a flat fp32 bucket + 1/N scale per step; RCCL over xGMI with backend "
+                   "'nccl' (gloo in the CPU test). Forward SA/FP needs no collective.")
+    return out
+
+
+def respawn(args):
+    """--gpus N > 1 without a launcher: one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--path", choices=("overlap", "fused", "ops"), default="overlap")
     ap.add_argument("--streams", type=int, default=8, help="batches in flight for the extra `concurrent` figure (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-extras", action="store_true", help="only the contract line (profiling runs)")
+    ap.add_argument("--stub", action="store_true", help="CPU test mode: gloo, no kernels (tests/test_distributed.py)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(respawn(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU (no CPU path)")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    if args.stub:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm GPU (no CPU path)")
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+    sync = (lambda: None) if args.stub else torch.cuda.synchronize
     dist = None
     if world > 1 or "RANK" in os.environ:      # under torchrun the RCCL path is exercised even at N=1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    stage = Stage(dev, seed=1000 + rank)          # every rank owns its own B=32 batch (weak scaling)
-    step = {"overlap": stage.step_overlap, "fused": stage.step_fused, "ops": stage.step_ops}[args.path]
+    # sharding: weak = every rank its own B=32 batch; strong = contiguous 32/world slices of ONE global batch
+    if args.scaling == "strong":
+        lo, hi = sharding.shard_bounds(B, world, rank)
+        b_local = hi - lo
+        clouds = None if args.stub else synthetic.sphere_clouds(B, N, 1000)[lo:hi]
+    else:
+        b_local = B
+        clouds = None if args.stub else synthetic.sphere_clouds(B, N, 1000 + rank)
+    stage = StubStage(b_local) if args.stub else Stage(dev, clouds)
+    step = stage.step(args.path)
     for _ in range(max(args.warmup, 1)):
         step()
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
+    ev0 = ev1 = None
+    if not args.stub:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    if ev1 is not None:
+        ev1.record()
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     elapsed = sharding.max_over_ranks(elapsed, dev)     # whole-job time = slowest rank
+    launch_s = (ev0.elapsed_time(ev1) * 1e-3 / args.steps) if ev0 is not None else elapsed / args.steps
 
+    extras = not args.no_extras and not args.stub
+    allred = allreduce_leg(dev, dist) if (dist is not None and world > 1) else None
     conc = None
-    if args.streams > 1:
-        conc = concurrent_throughput(dev, rank, args.path, args.streams, max(args.steps, 4 * args.streams))
+    if extras and args.streams > 1 and world == 1:
+        conc = concurrent_throughput(dev, rank, args.path, args.streams, max(64, 4 * args.streams))
     if rank == 0:
-        kt = kernel_times(stage)
-        ktf = kernel_times(stage, fused=True)
-        kto = one_kernel_time(stage.overlap_)
-        dom = max(kt, key=kt.get)
-        achieved = BYTES[dom] * B / kt[dom] / 1e9
+        achieved = STAGE_BYTES * b_local / launch_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # written from rocprofv3 --pmc passes
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                traffic = json.load(open(tpath)).get({"overlap": "sample_and_group_xyz"}.get(args.path, ""))
             except Exception:
                 traffic = None
-        total_k = sum(kt.values())
         line = {
             "metric": "point-clouds/sec for SA(FPS+ball+group) B=32 N=4096→1024 nsample=32",
-            "value": world * B * args.steps / elapsed,
+            "value": world * b_local * args.steps / elapsed,
             "unit": "clouds/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "SA stage FPS+gather+ball_query+group, B=32 per GPU, N=4096->npoint=1024, "
-                                   "radius=0.2, nsample=32, xyz only (BASELINE configs: metric shape)",
-                       "clouds": "D1: unit-sphere surface x U(0.9,1.0), pc_normalize'd, seeded per rank",
+            "config": {"workload": "SA stage FPS+gather+ball_query+group, N=4096->npoint=1024, radius=0.2, nsample=32, "
+                                   "xyz only (BASELINE metric shape); %s"
+                                   % ("B=32 per GPU" if args.scaling == "weak" else
+                                      "global B=32 sliced %d clouds per GPU (train_multi_gpu.py:185-188)" % b_local),
+                       "clouds": "D1: unit-sphere surface x U(0.9,1.0), pc_normalize'd, seeded",
                        "path": args.path + {
                            "overlap": " (1 launch: FPS producers publish samples, ball-query+group consumers on the "
                                       "other CUs start query j when sample j exists; what sample_and_group launches)",
                            "fused": " (2 launches: FPS+gather, ball query+group+centroid subtract)",
                            "ops": " (4 reference-shaped operator launches)"}[args.path],
-                       "sharding": "%d independent batch shard(s), no data-path collective" % world},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "note": "FPS is a serial chain of npoint-1 block-wide arg-max rounds (%.0f ns/round); it "
-                                 "is latency bound, see DESIGN.md" % (kt["farthest_point_sample"] / (M - 1) * 1e9)},
-            "kernels": {k: {"us": v * 1e6, "algorithmic_GBps": BYTES[k] * B / v / 1e9,
-                            "frac_of_hbm_peak": BYTES[k] * B / v / 1e9 / HBM_PEAK_GBS} for k, v in kt.items()},
-            "fused_kernels": {k: {"us": v * 1e6} for k, v in ktf.items()},
-            "overlap_kernel": {"sample_and_group_xyz": {"us": kto * 1e6}},
-            "stage": {"bytes_per_cloud": STAGE_BYTES, "sum_kernel_us": total_k * 1e6,
-                      "sum_fused_kernel_us": sum(ktf.values()) * 1e6,
-                      "algorithmic_GBps": STAGE_BYTES * B / total_k / 1e9,
-                      "frac_of_hbm_peak": STAGE_BYTES * B / total_k / 1e9 / HBM_PEAK_GBS},
+                       "sharding": "%d independent batch shard(s), no data-path collective" % world,
+                       "requested_gpus": args.gpus},
+            "roofline": {"bound": "hbm", "kernel": TIMED_KERNEL[args.path], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": STAGE_BYTES * b_local,
+                         "note": "the kernel(s) of the timed region: SURVEY 8(d) bytes per cloud x clouds per launch / "
+                                 "HIP-event time per step on the launch stream. Bound by the FPS chain (latency), "
+                                 "not by HBM: see fps_latency_model"},
         }
-        try:
-            line["mlp_roofline"] = mlp_roofline(stage)
-        except Exception as e:                                   # never let the extra object break the contract line
-            line["mlp_roofline"] = {"error": repr(e)}
-        if conc is not None:
-            line["concurrent"] = conc
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(1000, args.cpu_seconds)
+        if allred is not None:
+            line["allreduce"] = allred
+        if extras:
+            kt = {"farthest_point_sample": event_time(stage.fps_), "gather_point": event_time(stage.gather_),
+                  "query_ball_point": event_time(stage.ball_), "group_point": event_time(stage.group_)}
+            ktf = {"farthest_point_sample_gather": event_time(stage.fps_gather_),
+                   "query_ball_group_xyz": event_time(stage.ball_group_)}
+            kto = event_time(stage.overlap_)
+            total_k = sum(kt.values())
+            line["fps_latency_model"] = {"rounds": M - 1, "ns_per_round": kt["farthest_point_sample"] / (M - 1) * 1e9,
+                                         "kernel_us": kt["farthest_point_sample"] * 1e6,
+                                         "share_of_step": kt["farthest_point_sample"] / launch_s,
+                                         "note": "m-1 dependent rounds of (distance update, block-wide arg-max); "
+                                                 "per-round floor analysis in DESIGN.md section 4.1"}
+            line["kernels"] = {k: {"us": v * 1e6, "algorithmic_GBps": BYTES[k] * b_local / v / 1e9,
+                                   "frac_of_hbm_peak": BYTES[k] * b_local / v / 1e9 / HBM_PEAK_GBS} for k, v in kt.items()}
+            line["fused_kernels"] = {k: {"us": v * 1e6} for k, v in ktf.items()}
+            line["overlap_kernel"] = {"sample_and_group_xyz": {"us": kto * 1e6}}
+            line["stage"] = {"bytes_per_cloud": STAGE_BYTES, "sum_kernel_us": total_k * 1e6,
+                             "sum_fused_kernel_us": sum(ktf.values()) * 1e6,
+                             "algorithmic_GBps": STAGE_BYTES * b_local / total_k / 1e9,
+                             "frac_of_hbm_peak": STAGE_BYTES * b_local / total_k / 1e9 / HBM_PEAK_GBS}
+            if world == 1:
+                try:
+                    d2 = Stage(dev, synthetic.uniform_clouds(B, N, 77), radius=0.1)
+                    t = event_time(d2.step(args.path))
+                    line["d2"] = {"clouds": "D2: uniform U[0,1)^3, radius 0.1 (query_ball_point.cpp:99-102, sem_seg L1 radius)",
+                                  "value": B / t, "unit": "clouds/s", "ms_per_step": t * 1e3,
+                                  "mean_pts_cnt": float(d2.cnt.float().mean().item())}
+                except Exception as e:
+                    line["d2"] = {"error": repr(e)}
+                try:
+                    line["mlp_roofline"] = mlp_roofline(stage)
+                except Exception as e:                               # never let an extra object break the contract line
+                    line["mlp_roofline"] = {"error": repr(e)}
+                # >= 1 s of back-to-back steps (not `value`): long enough for an external utilisation sampler
+                n_sus = max(args.steps, int(1.2 / max(launch_s, 1e-6)))
+                t0 = time.perf_counter()
+                for _ in range(n_sus):
+                    step()
+                sync()
+                dt = time.perf_counter() - t0
+                line["sustained"] = {"steps": n_sus, "seconds": dt, "value": b_local * n_sus / dt, "unit": "clouds/s"}
+            if conc is not None:
+                line["concurrent"] = conc
+            if world == 1 and not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(1000, args.cpu_seconds)
+                try:
+                    line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(1000, args.cpu_seconds)
+                except Exception as e:
+                    line["cpu_baseline_all_cores"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -214,20 +214,29 @@ int pn2_farthest_point_sample_ex(int T, int P, int b, int n, int m, const float 
  * sample j exists. Outputs are bit-identical to the separate operators:
  *   fps_idx (b,m) i32, new_xyz (b,m,3) f32, idx (b,m,nsample) i32, pts_cnt (b,m) i32,
  *   grouped_xyz (b,m,nsample,3) f32 (minus the centroid when subtract_centroid != 0).
- * ws: device scratch of pn2_sample_and_group_ws_bytes(b,m) bytes (zeroed here on `stream`).
+ * ws: device scratch of pn2_sample_and_group_ws_bytes(b,m) bytes (zeroed here on `stream`): the sample
+ * granules, the arrival-ticket counters that assign producer / consumer roles (the first b workgroups to
+ * START are the producers, so no consumer ever waits for a producer that is not running -- independent of
+ * the hardware's dispatch order), and a status word.
  * Returns PN2_E_TOO_LARGE for shapes outside the overlapped launch's envelope (b > 128, n > 8192,
  * n < 64, nsample > 256): use pn2_farthest_point_sample_gather + pn2_query_ball_group_xyz then. */
 int pn2_sample_and_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,
                              int *fps_idx, float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz,
                              int subtract_centroid, void *stream);
 long long pn2_sample_and_group_ws_bytes(int b, int m);
-/* The same launch without the per-call clear of ws: the caller manages generations. ws must hold no granule
- * whose tag word equals `generation` (zero ws once when it is allocated, then pass 1, 2, 3, ...: what an
- * earlier generation left behind can never be mistaken for a published sample). One ws per stream;
- * generation 0 is PN2_E_ARG. Saves a memset launch (~5 us) per call. */
+/* The same launch without the per-call clear of ws: the caller manages generations. Zero ws ONCE when it is
+ * allocated, then pass generation 1, 2, 3, ... -- each launch on a workspace must use the previous launch's
+ * generation + 1 (what an earlier generation left behind can never be mistaken for a published sample, and
+ * each launch resets the next one's ticket counter). One ws per stream; generation 0 is PN2_E_ARG; re-zero
+ * ws before wrapping around. Saves a memset launch (~5 us) per call. */
 int pn2_sample_and_group_xyz_gen(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,
                                  unsigned generation, int *fps_idx, float *new_xyz, int *idx, int *pts_cnt,
                                  float *grouped_xyz, int subtract_centroid, void *stream);
+/* Byte offset inside ws of the launch status word (u32): 0 ok, 1 = a consumer stopped waiting for its producer
+ * after ~10 s (cannot happen while the device makes progress; the launch's outputs are then incomplete). The
+ * library never synchronises, so a caller that wants to assert forward progress reads the word after
+ * synchronising the stream. */
+long long pn2_sample_and_group_status_offset(int b, int m);
 
 /* ---- host helpers ------------------------------------------------------- */
 

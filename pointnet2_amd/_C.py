@@ -55,6 +55,7 @@ _SIGNATURES = {
     "pn2_query_ball_group_xyz": [_i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "pn2_sample_and_group_xyz": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pn2_sample_and_group_ws_bytes": [_i, _i],
+    "pn2_sample_and_group_status_offset": [_i, _i],
     "pn2_sample_and_group_xyz_gen": [_i, _i, _i, _f, _i, _vp, _vp, ctypes.c_uint, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pn2_ball_threshold": [_f],
     "pn2_version": [],
@@ -67,6 +68,7 @@ _RESTYPES = {
     "pn2_det_grad_ws_bytes": ctypes.c_longlong,
     "pn2_seg_grad_ws_bytes": ctypes.c_longlong,
     "pn2_sample_and_group_ws_bytes": ctypes.c_longlong,
+    "pn2_sample_and_group_status_offset": ctypes.c_longlong,
     "pn2_ball_threshold": ctypes.c_float,
     "pn2_version": ctypes.c_char_p,
 }

@@ -106,8 +106,12 @@ __device__ __forceinline__ void bq_emit(size_t row, int nsample, int cnt, const 
 
 // Wait until the FPS workgroup of the same launch has published sample j of this cloud and return its
 // index (consumer side of the R2 granule hand-off: ONE 8-byte agent-scope relaxed load per poll, the
-// tag travels with the data, no fence). The spin is bounded: a launch whose producers are not
-// resident would otherwise hang the GPU; it traps instead.
+// tag travels with the data, no fence). The producers of a launch are running before any consumer polls
+// (sa_fused.hip: roles are taken by arrival ticket), so the wait always ends; the spin is nevertheless
+// bounded (~10 s; the longest legal chain, n = m = 8192, takes < 10 ms) and returns -1 instead of hanging
+// the GPU should the device ever stall a producer for that long. The caller records the failure in the
+// launch's status word and gives up its queries: an error the host can read, not a trap that would take
+// the whole HIP context down.
 __device__ __forceinline__ int bq_poll_sample(const unsigned long long *tagged, unsigned tag = 1u)
 {
     const pn2_gu64b *g = (const pn2_gu64b *)tagged;
@@ -115,7 +119,7 @@ __device__ __forceinline__ int bq_poll_sample(const unsigned long long *tagged, 
         const unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(v >> 32) == tag) return (int)(unsigned)v;
         __builtin_amdgcn_s_sleep(16);
-        if (it > (1u << 23)) __builtin_trap();   // ~10 s: the longest legal chain (n = m = 8192) takes < 10 ms
+        if (it > (1u << 23)) return -1;
     }
 }
 
@@ -131,7 +135,8 @@ __device__ __forceinline__ void bq_block_body(int n, int m, int nsample, float t
                                               const unsigned long long *__restrict__ tagged,
                                               float *__restrict__ new_xyz, int *__restrict__ idx,
                                               int *__restrict__ pts_cnt, float *__restrict__ grouped, int subtract,
-                                              char *smem, unsigned tag = 1u, int row_stride = 0)
+                                              char *smem, unsigned tag = 1u, int row_stride = 0,
+                                              unsigned *status = nullptr)
 {
     if (row_stride == 0) row_stride = nsample;
     float4 *cloud = reinterpret_cast<float4 *>(smem);                                   // [n] when LDS_CLOUD
@@ -167,6 +172,10 @@ __device__ __forceinline__ void bq_block_body(int n, int m, int nsample, float t
         if (POLL) {
             const int ka = bq_poll_sample(tagged + row0, tag);
             const int kb = bq_poll_sample(tagged + row1, tag);
+            if (ka < 0 || kb < 0) {                              // wave-uniform; see bq_poll_sample
+                if (lane == 0 && status) atomicExch(status, 1u);
+                return;
+            }
             const float4 pa = cloud[ka], pb = cloud[kb];          // POLL implies LDS_CLOUD
             ax = pa.x; ay = pa.y; az = pa.z; bx = pb.x; by = pb.y; bz = pb.z;
             if (lane == 0) {
@@ -519,7 +528,8 @@ __device__ __forceinline__ void bq_cells_query_loop(int n, int m, int nsample, f
         const size_t row = (size_t)bi * m + (qvalid ? j : q1 - 1);
         float qx, qy, qz;
         if (POLL) {
-            const int ka = bq_poll_sample(tagged + row);
+            int ka = bq_poll_sample(tagged + row);
+            if (__any(ka < 0)) return;                           // unused by the shipped launches (sweep consumers)
             qx = data[(size_t)ka * 3 + 0]; qy = data[(size_t)ka * 3 + 1]; qz = data[(size_t)ka * 3 + 2];
             if (sub == 0 && qvalid) {
                 float *o = new_xyz + row * 3;

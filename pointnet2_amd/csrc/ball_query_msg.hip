@@ -102,9 +102,12 @@ template <int NT, int LPQ>
 static int launch_msg(int b, int n, int m, int use_cells, int max_ns, const BqScales &sc, const float *xyz1,
                       const float *xyz2, int subtract, hipStream_t st)
 {
-    constexpr int kGran = (NT / 64) * (64 / LPQ);
+    // queries per workgroup trip: the cell-list loop carries 64 / LPQ queries per wave, the sweep two
+    const int kGran = (NT / 64) * (use_cells ? 64 / LPQ : kBqQpw);
     const long long total = (long long)b * m;
-    int qpb = (int)((total + 255) / 256);                      // about one workgroup per CU
+    // about one workgroup per CU when the cloud is binned (the binning pass is per workgroup); the sweep
+    // stages cheaply and wants two
+    int qpb = (int)((total + (use_cells ? 255 : 511)) / (use_cells ? 256 : 512));
     qpb = ((qpb + kGran - 1) / kGran) * kGran;
     if (qpb > m) qpb = ((m + kGran - 1) / kGran) * kGran;
     const int parts = (m + qpb - 1) / qpb;
@@ -124,11 +127,12 @@ extern "C" int pn2_query_ball_group_xyz_msg(int b, int n, int m, int nscales, co
     using namespace pn2;
     if (nscales <= 0 || nscales > kBqMaxScales || !radii || !nsamples) return PN2_E_ARG;
     if (b < 0 || n <= 0 || m < 0) return PN2_E_SHAPE;
+    for (int i = 0; i < nscales; ++i)
+        if (!(radii[i] > 0.0f) || nsamples[i] <= 0) return PN2_E_ARG;   // tf_grouping.cpp:71,74
     BqScales sc;
     sc.count = nscales;
     int max_ns = 0;
     for (int i = 0; i < nscales; ++i) {
-        if (!(radii[i] > 0.0f) || nsamples[i] <= 0) return PN2_E_ARG;   // tf_grouping.cpp:71,74
         sc.s[i] = {pn2_ball_threshold(radii[i]), radii[i], nsamples[i], idx ? idx[i] : nullptr,
                    pts_cnt ? pts_cnt[i] : nullptr, grouped_xyz ? grouped_xyz[i] : nullptr};
         if (!sc.s[i].idx && !sc.s[i].grouped) return PN2_E_NULL;

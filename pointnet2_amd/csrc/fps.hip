@@ -35,7 +35,12 @@
 // branches and a non-rank-ordered lane arg-max cost more than the skipped distances).
 // Clouds too large for the register tiers fall back to a global-memory tier
 // that keeps the running distances in the caller's `temp` buffer.
-#include "fps_body.h"
+// scripts/build_labs.sh compiles this file against scripts/fps_body_r2_experiments.h (the round body with
+// the rejected round-2 variants behind -DPN2_FPS_* switches) by overriding the header name.
+#ifndef PN2_FPS_BODY_HEADER
+#define PN2_FPS_BODY_HEADER "fps_body.h"
+#endif
+#include PN2_FPS_BODY_HEADER
 
 #include <limits.h>
 
@@ -192,8 +197,8 @@ static int fps_entry(int b, int n, int m, const float *inp, float *temp, int *ou
     const int Q = (n + kRefThreads - 1) / kRefThreads;
     const int ranks = kRefThreads * Q;
     // default geometry (measured, scripts/fps_prod_lab.hip, ns per round at n = 1024/2048/4096/8192):
-    // 256 threads with the packed distance update 276/321/405/590, 512 threads (scalar) 302/335/408/555
-    const int T = ranks <= 4096 ? 256 : 512;
+    // 256 threads with the packed distance update 273/312/402/585, 512 threads (scalar) 288/326/393/552
+    const int T = ranks <= 2048 ? 256 : 512;
     const int P = next_pow2((ranks + T - 1) / T);
     return fps_launch_config(T, P, b, n, m, inp, out, out_xyz, st);
 }

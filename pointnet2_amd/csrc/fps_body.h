@@ -27,21 +27,19 @@ __device__ __forceinline__ float vmin_f32(float a, float b)
 
 // Wave-wide max of a positive finite double (a (value:low) key, see fps_reg_kernel) WITHOUT the scalar
 // unit: per DPP step two v_mov_b32_dpp fetch the partner lane's halves and one v_max_f64 combines.
-// After the six steps lane 63 holds the wave maximum (rows 1/3 after row_bcast:15, rows 2/3 after
-// row_bcast:31). For the two broadcast steps the unwritten rows keep `old` = the lane's own value.
-template <int CTRL, int ROW_MASK>
+// After the six steps lane 63 holds the wave maximum. Every step uses row_mask 0xf with bound_ctrl: the
+// destination then needs no initial value. For the two row_bcast steps that means the rows WITHOUT a
+// source (row 0 for row_bcast:15, rows 0-1 for row_bcast:31) combine their key with 0 -- or with whatever
+// the register held -- which is harmless: lane 63's result depends only on rows 1 and 3 after step five
+// and on row 3 after step six, and those rows have sources. (The row_mask 0xa / 0xc form of round 1 had to
+// pre-load the destination with the lane's own halves: two v_mov and an s_nop more per step on the
+// serial path, 408 -> 393 ns per round at 512 x 8.)
+template <int CTRL>
 __device__ __forceinline__ double dpp_max_f64_step(double v)
 {
     const int hi = __double2hiint(v), lo = __double2loint(v);
-    int ohi, olo;
-    if (ROW_MASK == 0xf) {
-        // every lane has a valid source: the destination needs no initial value (saves two v_mov)
-        ohi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-        olo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-    } else {
-        ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-        olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
-    }
+    const int ohi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    const int olo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
     const double o = __hiloint2double(ohi, olo);
     double r;
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(v), "v"(o));
@@ -49,73 +47,13 @@ __device__ __forceinline__ double dpp_max_f64_step(double v)
 }
 __device__ __forceinline__ double wave_max_f64_lane63(double v)
 {
-    v = dpp_max_f64_step<0xB1, 0xf>(v);    // quad_perm:[1,0,3,2]
-    v = dpp_max_f64_step<0x4E, 0xf>(v);    // quad_perm:[2,3,0,1]
-    v = dpp_max_f64_step<0x141, 0xf>(v);   // row_half_mirror
-    v = dpp_max_f64_step<0x140, 0xf>(v);   // row_mirror
-    v = dpp_max_f64_step<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
-    v = dpp_max_f64_step<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
+    v = dpp_max_f64_step<0xB1>(v);    // quad_perm:[1,0,3,2]
+    v = dpp_max_f64_step<0x4E>(v);    // quad_perm:[2,3,0,1]
+    v = dpp_max_f64_step<0x141>(v);   // row_half_mirror
+    v = dpp_max_f64_step<0x140>(v);   // row_mirror
+    v = dpp_max_f64_step<0x142>(v);   // row_bcast:15: row r += row r-1 (rows 1, 3 matter)
+    v = dpp_max_f64_step<0x143>(v);   // row_bcast:31: rows 2, 3 += lane 31 (row 3 matters)
     return v;
-}
-
-// The same wave arg-max in 32-bit operations (PN2_FPS_WAVE32). A key is the pair (hi = value bits, lo = low
-// word, larger lo = smaller rank). hi is a non-negative fp32, so its bit pattern orders like an unsigned
-// integer and the lexicographic max splits into
-//   1. an ALL-REDUCE of hi: four in-row butterfly steps, ONE v_max_u32 with a DPP operand each, then the
-//      xor-16 and xor-32 exchanges with gfx950's v_permlane16/32_swap (copy, swap, max);
-//   2. lo' = (hi == wave max) ? lo : 0 -- only the lanes that hold the maximum value stay in the race;
-//   3. a plain max ladder of lo' that ends in lane 63 (four in-row steps + row_bcast:15 + row_bcast:31).
-// 18 single-issue 32-bit instructions with ~10 dependent DPP hops, against six steps of
-// (2 x v_mov_b32_dpp + v_max_f64) = 18 instructions whose fp64 op has twice the latency.
-// A VGPR written by a VALU instruction may be read through DPP two wait states later at the earliest;
-// inside inline asm the compiler's hazard recogniser does not see the instructions, hence the s_nop 1.
-#ifndef PN2_FPS_WAVE32
-#define PN2_FPS_WAVE32 0
-#endif
-#ifndef PN2_FPS_LATE_STORE
-#define PN2_FPS_LATE_STORE 0
-#endif
-__device__ __forceinline__ void wave_max_key32_lane63(unsigned hi, unsigned lo, unsigned &whi, unsigned &wlo)
-{
-    unsigned m, t, l;
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_max_u32_dpp %[m], %[hi], %[hi] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_u32_dpp %[m], %[m], %[m] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_u32_dpp %[m], %[m], %[m] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_u32_dpp %[m], %[m], %[m] row_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32 %[t], %[m]\n\t"
-        "s_nop 1\n\t"
-        "v_permlane16_swap_b32 %[t], %[m]\n\t"
-        "s_nop 1\n\t"
-        "v_max_u32 %[m], %[m], %[t]\n\t"
-        "v_mov_b32 %[t], %[m]\n\t"
-        "s_nop 1\n\t"
-        "v_permlane32_swap_b32 %[t], %[m]\n\t"
-        "s_nop 1\n\t"
-        "v_max_u32 %[m], %[m], %[t]\n\t"
-        "v_cmp_eq_u32 vcc, %[m], %[hi]\n\t"
-        "v_cndmask_b32 %[l], 0, %[lo], vcc\n\t"
-        "s_nop 1\n\t"
-        "v_max_u32_dpp %[l], %[l], %[l] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_u32_dpp %[l], %[l], %[l] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_u32_dpp %[l], %[l], %[l] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_u32_dpp %[l], %[l], %[l] row_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_u32_dpp %[l], %[l], %[l] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_u32_dpp %[l], %[l], %[l] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        : [m] "=&v"(m), [t] "=&v"(t), [l] "=&v"(l)
-        : [hi] "v"(hi), [lo] "v"(lo)
-        : "vcc");
-    whi = m;
-    wlo = l;
 }
 
 // Fused gather_point: new_xyz[j] = inp[idx[j]], written once after the last round by the whole
@@ -255,10 +193,6 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
     }
 
     const unsigned low0 = (unsigned)(NS - 1 - t * P);   // key low word of this thread's slot 0: larger = smaller rank
-    // PN2_FPS_LATE_STORE: thread 0's store of sample j sits between the winner read and the distance update
-    // (exec-mask juggling + a branch on the critical path); with the switch on it is issued one round later,
-    // right after the barrier, while the key reads are in flight.
-    int kprev = 0;
     // one round; `par` (the partial buffer parity) is a literal at both call sites so the slot
     // addresses fold to constants (scalar address arithmetic costs 4-cycle issue slots)
     auto round = [&](const int j, const int par) __attribute__((always_inline)) {
@@ -309,11 +243,7 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
         const double bestd = kd[0];
         // whole-wave key max in VALU only; lane 63 ends up with it and publishes it
         unsigned long long *slot = partial + par * W;
-        if (PN2_FPS_WAVE32) {
-            unsigned whi, wlo;
-            wave_max_key32_lane63((unsigned)__double2hiint(bestd), (unsigned)__double2loint(bestd), whi, wlo);
-            if (lane == 63) slot[w] = ((unsigned long long)whi << 32) | wlo;
-        } else {
+        {
             const double wd = wave_max_f64_lane63(bestd);
             if (lane == 63) reinterpret_cast<double *>(slot)[w] = wd;
         }
@@ -325,10 +255,10 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
         // lane i reads key i mod W (ONE LDS read per wave instead of W/2 broadcast reads) and the W
         // keys are combined across lanes with log2(W) butterfly DPP steps: every lane ends with the max
         double kq = dslot[lane & (W - 1)];
-        if (W >= 2) kq = dpp_max_f64_step<0xB1, 0xf>(kq);    // lane ^ 1
-        if (W >= 4) kq = dpp_max_f64_step<0x4E, 0xf>(kq);    // lane ^ 2
-        if (W >= 8) kq = dpp_max_f64_step<0x141, 0xf>(kq);   // other quad of the half row
-        if (W >= 16) kq = dpp_max_f64_step<0x140, 0xf>(kq);  // other half row
+        if (W >= 2) kq = dpp_max_f64_step<0xB1>(kq);    // lane ^ 1
+        if (W >= 4) kq = dpp_max_f64_step<0x4E>(kq);    // lane ^ 2
+        if (W >= 8) kq = dpp_max_f64_step<0x141>(kq);   // other quad of the half row
+        if (W >= 16) kq = dpp_max_f64_step<0x140>(kq);  // other half row
         win = (unsigned)__double2loint(kq);
         } else {
         // W <= 8: broadcast-read all keys, tournament on wave-uniform data (measured faster: 408 vs 441 ns)
@@ -344,29 +274,16 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
         }
         int k;
         if (LDSXYZ) {
-            typedef float pn2_f4 __attribute__((ext_vector_type(4)));
-            pn2_f4 s;                                  // same address in every lane: LDS broadcast
-            if (PN2_FPS_LATE_STORE && !PUBLISH) {
-                // issue the read, do thread 0's store of the PREVIOUS sample under its latency, then wait
-                asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(s) : "v"(win << 4) : "memory");
-                if (t == 0) dst[j - 1] = kprev;
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s) : : "memory");
-            } else {
-                const float4 q = lds_rank[win];
-                s.x = q.x; s.y = q.y; s.z = q.z; s.w = q.w;
-            }
+            const float4 s = lds_rank[win];            // same address in every lane: LDS broadcast
             sx = s.x; sy = s.y; sz = s.z;
             sxy.x = s.x; sxy.y = s.y; szk.x = s.z; szk.y = s.w;
             k = __float_as_int(s.w);
         } else {
             k = lds_k[win];
-            if (PN2_FPS_LATE_STORE && !PUBLISH && t == 0) dst[j - 1] = kprev;
             sx = src[(size_t)k * 3 + 0]; sy = src[(size_t)k * 3 + 1]; sz = src[(size_t)k * 3 + 2];
             sxy.x = sx; sxy.y = sy; szk.x = sz;
         }
-        if (PN2_FPS_LATE_STORE && !PUBLISH) {
-            kprev = k;                                 // stored by the NEXT round (or after the loop), see above
-        } else if (t == 0) {
+        if (t == 0) {
             dst[j] = k;
             if (PUBLISH)
                 __hip_atomic_store(gtag + j, ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)k, __ATOMIC_RELAXED,
@@ -378,8 +295,7 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
         round(j, 1);
         round(j + 1, 0);
     }
-    if (j < m) { round(j, 1); ++j; }
-    if (PN2_FPS_LATE_STORE && !PUBLISH && t == 0 && m > 1) dst[m - 1] = kprev;
+    if (j < m) round(j, 1);
     fps_gather_epilogue<T>(m, src, dst, dxyz);
 }
 

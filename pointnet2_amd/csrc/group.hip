@@ -123,6 +123,13 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 // workgroups of one cloud share an XCD (decode_cloud_block: the gathered source rows are re-read
 // nsample*m/n times and then come from that XCD's L2); a thread derives (row, chunk) ONCE and advances
 // them by adding constants; and U independent idx -> row -> store chains are in flight per lane.
+// Outputs larger than the 256 MB Infinity Cache are written with non-temporal stores (measured on MI355X,
+// scripts/bw_probe.py: (32,4096,128)->(32,1024,32,128), 608 MB by SURVEY 8(d): 171 us flat kernel, 156 us
+// row kernel, 102 us = 5.97 TB/s with nt stores; (32,512,320)->(32,128,128,320): 180 / 166 / 129 us; a
+// 144 MB output that stays in the cache prefers plain stores: 25.5 / 22.7 / 25.6 us).
+// c == 3 keeps the flat one-row-per-lane kernel: a four-rows-per-lane variant (one 16-byte index load, three
+// 16-byte stores) measured SLOWER (7.6 vs 6.6 us at the metric shape; the launch is latency bound: 18 MB
+// is 2.3 us of HBM time, less than two kernel-launch floors).
 
 typedef float pn2_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_nt(float4 *p, float4 v)      // global_store_dwordx4 ... nt
@@ -170,37 +177,6 @@ __global__ __launch_bounds__(kThreads) void group_rows_v4_kernel(int rows_per_cl
     }
 }
 
-// c == 3, rows_per_cloud % 4 == 0: a lane gathers FOUR rows (one 16-byte load of their indices, four
-// 12-byte row loads) and writes them as three 16-byte stores = 48 contiguous bytes per lane, instead of
-// one 12-byte row per lane (global_store_dwordx3 rows straddle the 16-byte sectors).
-template <bool NT>
-__global__ __launch_bounds__(kThreads) void group_rows_c3x4_kernel(int quads_per_cloud, int n, int quads_per_part,
-                                                                   int parts, int b, const float *__restrict__ points,
-                                                                   const int4 *__restrict__ idx4,
-                                                                   float4 *__restrict__ out4)
-{
-    int cloud, part;
-    decode_cloud_block(blockIdx.x, parts, b, cloud, part);
-    const int qb = part * quads_per_part, qe = min(qb + quads_per_part, quads_per_cloud);
-    const int4 *__restrict__ idc = idx4 + (size_t)cloud * quads_per_cloud;
-    const float *__restrict__ src = points + (size_t)cloud * n * 3;
-    float4 *__restrict__ dst = out4 + (size_t)cloud * quads_per_cloud * 3;
-    for (int q = qb + (int)threadIdx.x; q < qe; q += kThreads) {
-        const int4 k = idc[q];
-        const float *pa = src + (unsigned)k.x * 3u, *pb = src + (unsigned)k.y * 3u;
-        const float *pc = src + (unsigned)k.z * 3u, *pd = src + (unsigned)k.w * 3u;
-        const float a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
-        const float c0 = pc[0], c1 = pc[1], c2 = pc[2], d0 = pd[0], d1 = pd[1], d2 = pd[2];
-        float4 *o = dst + (unsigned)q * 3u;
-        const float4 v0 = make_float4(a0, a1, a2, b0), v1 = make_float4(b1, b2, c0, c1), v2 = make_float4(c2, d0, d1, d2);
-        if (NT) {
-            store_nt(o + 0, v0); store_nt(o + 1, v1); store_nt(o + 2, v2);
-        } else {
-            o[0] = v0; o[1] = v1; o[2] = v2;
-        }
-    }
-}
-
 // Parts per cloud: enough workgroups to fill the chip several times over (256 CUs x 8 resident workgroups
 // of 256 threads), but at least `min_units` units (rows / quads) per workgroup.
 static inline int parts_for(int b, int units_per_cloud, int min_units)
@@ -217,15 +193,6 @@ static int group_rows(int b, int n, int c, long long rpc, const float *points, c
 {
     const bool fits = rpc <= INT_MAX / 2 && (long long)n * c < (1ll << 31) && rpc * c < (1ll << 31) &&
                       (long long)b * 4096 < INT_MAX && true;
-    if (variant != 1 && fits && c == 3 && (rpc & 3) == 0 && aligned16(idx) && aligned16(out)) {
-        const int quads = (int)(rpc / 4);
-        const int parts = parts_for(b, quads, kThreads);
-        const int qpp = (quads + parts - 1) / parts;
-        const bool nt = variant == 3;
-        auto kern = nt ? group_rows_c3x4_kernel<true> : group_rows_c3x4_kernel<false>;
-        return launch(kern, dim3((unsigned)parts * b), dim3(kThreads), 0, st, quads, n, qpp, parts, b, points,
-                      reinterpret_cast<const int4 *>(idx), reinterpret_cast<float4 *>(out));
-    }
     if (variant != 1 && fits && c % 4 == 0 && aligned16(points) && aligned16(out)) {
         constexpr int U = 4;
         const int c4 = c / 4;
@@ -249,10 +216,6 @@ extern "C" int pn2_gather_point(int b, int n, int m, const float *inp, const int
     if (b == 0 || m == 0) return PN2_OK;
     if (!inp || !idx || !out) return PN2_E_NULL;
     const long long rows = (long long)b * m;
-    {
-        const int rc = group_rows(b, n, 3, m, inp, idx, out, 0, as_stream(stream));     // gather = group with nsample 1
-        if (rc != -1000) return rc;
-    }
     if (int rc = launch(gather_point_kernel, dim3(grid_for(rows)), dim3(kThreads), 0, as_stream(stream), rows, n, m,
                        inp, idx, out)) return rc;
     return PN2_OK;

@@ -102,10 +102,10 @@ __global__ __launch_bounds__(kNnThreads) void three_nn_kernel(int n, int m, cons
         for (int k = sub; k < cnt16; k += 16) {
             const float4 p0 = tile[k], p1 = tile[k + 4], p2 = tile[k + 8], p3 = tile[k + 12];
             // (x2-x1)..., x2 the known point (tf_interpolate.cpp:69-73)
-            const float d0 = sqdist(p0.x, p0.y, p0.z, ux, uy, uz);
-            const float d1 = sqdist(p1.x, p1.y, p1.z, ux, uy, uz);
-            const float d2 = sqdist(p2.x, p2.y, p2.z, ux, uy, uz);
-            const float d3 = sqdist(p3.x, p3.y, p3.z, ux, uy, uz);
+            const float d0 = sqdist_key(p0.x, p0.y, p0.z, ux, uy, uz);
+            const float d1 = sqdist_key(p1.x, p1.y, p1.z, ux, uy, uz);
+            const float d2 = sqdist_key(p2.x, p2.y, p2.z, ux, uy, uz);
+            const float d3 = sqdist_key(p3.x, p3.y, p3.z, ux, uy, uz);
             nn_insert(__hiloint2double(__float_as_int(d0), __float_as_int(p0.w)), b1, b2, b3);
             nn_insert(__hiloint2double(__float_as_int(d1), __float_as_int(p1.w)), b1, b2, b3);
             nn_insert(__hiloint2double(__float_as_int(d2), __float_as_int(p2.w)), b1, b2, b3);
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kThreads) void three_interpolate_v4_kernel(long lon
 // Second generation (see group.hip): grid = (parts per cloud) x (clouds) with the XCD-aware decode, the
 // (row, chunk) pair derived once per thread and advanced by constants (no integer division per element),
 // U rows' worth of idx / weight / three gathered rows in flight per lane.
-template <int U>
+template <int U, bool NT>
 __global__ __launch_bounds__(kThreads) void three_interpolate_rows_v4_kernel(int n, int m, int c4, int dr, int dl,
                                                                              int rows_per_part, int parts, int b,
                                                                              const float4 *__restrict__ points,
@@ -217,7 +217,14 @@ __global__ __launch_bounds__(kThreads) void three_interpolate_rows_v4_kernel(int
                 o.y = interp3(a[u].y, bb[u].y, cc[u].y, w1[u], w2[u], w3[u]);
                 o.z = interp3(a[u].z, bb[u].z, cc[u].z, w1[u], w2[u], w3[u]);
                 o.w = interp3(a[u].w, bb[u].w, cc[u].w, w1[u], w2[u], w3[u]);
-                dst[(unsigned)rr[u] * (unsigned)c4 + (unsigned)ll[u]] = o;
+                float4 *po = dst + ((unsigned)rr[u] * (unsigned)c4 + (unsigned)ll[u]);
+                if (NT) {
+                    typedef float pn2_v4f __attribute__((ext_vector_type(4)));
+                    pn2_v4f w = {o.x, o.y, o.z, o.w};
+                    __builtin_nontemporal_store(w, reinterpret_cast<pn2_v4f *>(po));
+                } else {
+                    *po = o;
+                }
             }
         }
     }
@@ -290,15 +297,17 @@ static int three_interpolate_entry(int b, int m, int c, int n, const float *poin
     hipStream_t st = as_stream(stream);
     if (variant != 1 && c % 4 == 0 && aligned16(points) && aligned16(out) && (long long)m * c < (1ll << 31) &&
         (long long)n * c < (1ll << 31) && (long long)b * 4096 < INT_MAX) {
-        constexpr int U = 2;
+        constexpr int U = 4;                                       // every load of a thread's share in flight at once
         const int c4 = c / 4;
-        const int rows_min = (kThreads * U * 2 + c4 - 1) / c4;
+        const int rows_min = (kThreads * U + c4 - 1) / c4;
         int parts = (4096 + b - 1) / b;
         const int most = (n + rows_min - 1) / rows_min;
         if (parts > most) parts = most;
         if (parts < 1) parts = 1;
         const int rpp = (n + parts - 1) / parts;
-        return launch((three_interpolate_rows_v4_kernel<U>), dim3((unsigned)parts * b), dim3(kThreads), 0, st, n, m, c4,
+        const bool nt = (long long)b * n * c * 4 > (192ll << 20);  // beyond the Infinity Cache: stream the output
+        auto kern = nt ? three_interpolate_rows_v4_kernel<U, true> : three_interpolate_rows_v4_kernel<U, false>;
+        return launch(kern, dim3((unsigned)parts * b), dim3(kThreads), 0, st, n, m, c4,
                       kThreads / c4, kThreads % c4, rpp, parts, b, reinterpret_cast<const float4 *>(points), idx, weight,
                       reinterpret_cast<float4 *>(out));
     }

@@ -28,6 +28,20 @@ __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, 
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
+// The same value for use as the high word of a (distance : index) ordering key read as fp64 (three_nn,
+// kNN): the last addition takes |operands| (free VOP3 source modifiers; the operands are squares, so
+// nothing changes for numbers), which clears the sign of a propagated NaN. A NaN with its sign bit set --
+// x86 produces such NaNs, and NaN coordinates propagate them -- would otherwise read as a NEGATIVE finite
+// double and win every v_min_f64; a positive NaN pattern sorts above +inf and is never admitted, like
+// `d < best` being false in the reference (tf_interpolate.cpp:74-93).
+__device__ __forceinline__ float sqdist_key(float ax, float ay, float az, float bx, float by, float bz)
+{
+    const float dx = __fsub_rn(ax, bx);
+    const float dy = __fsub_rn(ay, by);
+    const float dz = __fsub_rn(az, bz);
+    return __fadd_rn(__builtin_fabsf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy))), __builtin_fabsf(__fmul_rn(dz, dz)));
+}
+
 // ---- DPP cross-lane moves (wave64, gfx9 DPP controls) ---------------------
 // quad_perm[1,0,3,2]=0xB1  quad_perm[2,3,0,1]=0x4E  row_half_mirror=0x141  row_mirror=0x140
 template <int CTRL>

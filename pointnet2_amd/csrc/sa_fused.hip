@@ -20,11 +20,15 @@
 // launch, tag = 1. Every workgroup asks for more than half of the CU's LDS, so producers never share
 // a CU with consumers (a co-resident consumer would steal issue slots from the latency-bound chain).
 //
-// Residency: consumers spin until their producer has advanced; this is deadlock-free as long as the
-// b producer blocks are resident, which holds because workgroups are dispatched in block-index order
-// (producers first) and b <= kMaxClouds << 256 CUs. HIP does not promise that order, so the spin is
-// bounded and traps instead of hanging, and the entry point refuses shapes outside the envelope
-// (callers fall back to the two-launch path: pn2_farthest_point_sample_gather + pn2_query_ball_group_xyz).
+// Forward progress without assumptions about dispatch order: a workgroup's ROLE is not its block index but
+// its ARRIVAL TICKET (one returning atomicAdd on a per-launch counter in `ws`): the first b workgroups to
+// start running become the FPS producers (ticket = cloud), every later arrival a consumer. A consumer
+// therefore never spins before all producers are resident and running, whatever order the hardware
+// dispatches blocks in and whatever else shares the GPU; b <= 128 << 256 CUs, and every workgroup asks for
+// more than half of a CU's LDS, so a producer never shares its CU. The ticket costs ~1 us once per
+// workgroup (0.2 % of the launch). The consumers' spin is bounded all the same and REPORTS (status word
+// in `ws`, pn2_sample_and_group_status) instead of trapping; shapes outside the envelope are refused
+// (callers fall back to pn2_farthest_point_sample_gather + pn2_query_ball_group_xyz).
 #include "ball_query_body.h"
 #include "fps_body.h"
 
@@ -35,6 +39,7 @@ namespace pn2 {
 constexpr int kFusedThreads = 512;
 constexpr int kFusedMaxClouds = 128;            // producers must leave most CUs to the consumers
 constexpr size_t kFusedMinLds = 82 * 1024;      // > 160 KiB / 2: one workgroup per CU
+constexpr unsigned kFusedSlots = 64;            // ticket counters in ws, indexed by generation % 64 (power of two)
 
 template <int P>
 __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, int m, int Q, int nsample, float thr,
@@ -46,15 +51,24 @@ __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, i
                                                                  float *__restrict__ grouped, int subtract)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int blk = blockIdx.x;
+    // role by arrival ticket (header): counters live behind the b*m granules, one per generation slot
+    unsigned *ctl = reinterpret_cast<unsigned *>(tagged + (size_t)b * m);
+    unsigned *ticket_ctr = ctl + (tag & (kFusedSlots - 1));
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) {
+        s_ticket = (int)atomicAdd(ticket_ctr, 1u);
+        if (s_ticket == 0) ctl[(tag + 1u) & (kFusedSlots - 1)] = 0u;   // the next launch on this workspace starts from zero
+    }
+    __syncthreads();
+    const int blk = s_ticket;
     if (blk < b) {
         fps_reg_body<kFusedThreads, P, true, true>(n, m, Q, blk, xyz, fps_idx, nullptr, tagged, smem, tag);
     } else {
         const int id = blk - b;
-        const int cloud = id % b;                // query range first, cloud second: the consumers that can
-        const int q0 = (id / b) * qpb;           // start earliest are dispatched first
+        const int cloud = id % b;                // query range first, cloud second: the consumers that arrive
+        const int q0 = (id / b) * qpb;           // first take the queries that can start earliest
         bq_block_body<true, true, true>(n, m, nsample, thr, cloud, q0, min(q0 + qpb, m), xyz, nullptr, tagged,
-                                        new_xyz, idx, pts_cnt, grouped, subtract, smem, tag);
+                                        new_xyz, idx, pts_cnt, grouped, subtract, smem, tag, 0, ctl + kFusedSlots);
     }
 }
 
@@ -76,7 +90,7 @@ static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, unsi
     auto kern = sa_fused_kernel<P>;
     if (int rc = allow_dynamic_lds(kern, lds)) return rc;
     if (tag == 0) {                                               // caller did not manage generations: clear, use tag 1
-        hipError_t e = hipMemsetAsync(ws, 0, sizeof(unsigned long long) * (size_t)b * m, st);
+        hipError_t e = hipMemsetAsync(ws, 0, (size_t)pn2_sample_and_group_ws_bytes(b, m), st);
         if (e != hipSuccess) return (int)e;
         tag = 1u;
     }
@@ -90,7 +104,8 @@ static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, unsi
 extern "C" long long pn2_sample_and_group_ws_bytes(int b, int m)
 {
     if (b <= 0 || m <= 0) return 0;
-    return (long long)sizeof(unsigned long long) * b * m;
+    // b*m sample granules, 64 arrival-ticket counters (one per generation slot), 1 status word (+ padding)
+    return (long long)sizeof(unsigned long long) * b * m + (long long)sizeof(unsigned) * (pn2::kFusedSlots + 2);
 }
 
 static int sample_and_group_common(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws, unsigned tag,
@@ -140,4 +155,13 @@ extern "C" int pn2_sample_and_group_xyz_gen(int b, int n, int m, float radius, i
     if (generation == 0u) return PN2_E_ARG;
     return sample_and_group_common(b, n, m, radius, nsample, xyz, ws, generation, fps_idx, new_xyz, idx, pts_cnt,
                                    grouped_xyz, subtract_centroid, stream);
+}
+
+// Offset (bytes) of the launch status word inside `ws`: 0 = ok, 1 = a consumer gave up waiting for its
+// producer (the outputs of that launch are incomplete). Written by the device only in that case; a caller
+// that wants to assert forward progress reads it after synchronising the stream.
+extern "C" long long pn2_sample_and_group_status_offset(int b, int m)
+{
+    if (b <= 0 || m <= 0) return -1;
+    return (long long)sizeof(unsigned long long) * b * m + (long long)sizeof(unsigned) * pn2::kFusedSlots;
 }

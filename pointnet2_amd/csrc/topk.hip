@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64) void knn_wave_kernel(int n, int m, int k, const
     const float qx = xyz2[row * 3 + 0], qy = xyz2[row * 3 + 1], qz = xyz2[row * 3 + 2];
     unsigned lmin = 0xffffffffu;                                  // smallest key among this lane's elements
     for (int s = lane; s < n; s += 64) {
-        const float d = sqdist(pts[s * 3 + 0], pts[s * 3 + 1], pts[s * 3 + 2], qx, qy, qz);
+        const float d = sqdist_key(pts[s * 3 + 0], pts[s * 3 + 1], pts[s * 3 + 2], qx, qy, qz);   // NaN sign cleared (pn2_device.h)
         val[s] = d;
         lmin = min(lmin, orderable(d));
     }

@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from .tf_sampling import farthest_point_sample, farthest_point_sample_gather, gather_point
 from .tf_grouping import (query_ball_point, group_point, knn_point, query_ball_group_xyz,
-                          sample_and_group_xyz)
+                          query_ball_group_xyz_msg, sample_and_group_xyz)
 from .tf_interpolate import three_nn, three_interpolate
 from . import sa_mlp
 
@@ -85,6 +85,14 @@ def three_nn_weights(xyz1, xyz2):
     return idx, weight
 
 
+def _no_packing_under_capture():
+    """Packing folds the batch norms on the host (.cpu()) and uploads pageable memory: both are illegal
+    while a HIP graph is being captured. Fail with an instruction instead of corrupting the capture."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("the fused MLP weights are not packed yet (or changed): call module.prepare_fused(device) -- "
+                           "or run one eager eval forward -- before capturing a graph")
+
+
 class _SharedMLP(nn.Module):
     """Stack of tf_util.conv2d([1,1]) + BN + ReLU (tf_util.py conv2d; BN eps 1e-3 is
     tf.contrib.layers.batch_norm's default). Operates on (b, C, h, w)."""
@@ -146,8 +154,17 @@ class PointnetSAModule(nn.Module):
         """Folded + packed weights, rebuilt when a parameter or a running statistic changed."""
         stamp = tuple((t.data_ptr(), t._version) for t in list(self.mlp.parameters()) + list(self.mlp.buffers()))
         if self._pack_cache is None or self._pack_cache[0] != (stamp, device):
+            _no_packing_under_capture()
             self._pack_cache = ((stamp, device), sa_mlp.PackedMLP3(self.mlp.folded_layers(), device, self.nsample, True))
         return self._pack_cache[1]
+
+    def prepare_fused(self, device):
+        """Fold the batch norms and pack the weights for the fused kernel NOW (a host-side step with a
+        device-to-host copy and an upload): call it once after loading weights / before capturing a HIP
+        graph, so that forward() finds the cache warm."""
+        if sa_mlp.supported(self.mlp.net[0].in_channels, self.mlp.widths, self.nsample or 0):
+            self._packed(device)
+        return self
 
     def forward(self, xyz, points):
         if self._fused_ok(xyz, points):
@@ -207,19 +224,38 @@ class PointnetSAModuleMSG(nn.Module):
         stamp = (tuple((t.data_ptr(), t._version) for t in list(mlp.parameters()) + list(mlp.buffers())), device)
         hit = self._pack_cache.get(si)
         if hit is None or hit[0] != stamp:
+            _no_packing_under_capture()
             # the MSG module concatenates features FIRST (:184): xyz_first=False
             hit = (stamp, sa_mlp.PackedMLP3(mlp.folded_layers(), device, self.nsample_list[si], xyz_first=False))
             self._pack_cache[si] = hit
         return hit[1]
 
+    def prepare_fused(self, device):
+        """See PointnetSAModule.prepare_fused."""
+        cin = self.mlps[0].net[0].in_channels
+        if all(sa_mlp.supported(cin, mlp.widths, ns) for mlp, ns in zip(self.mlps, self.nsample_list)):
+            for si in range(len(self.mlps)):
+                self._packed(si, device)
+        return self
+
+    def _group_scales(self, xyz, want_idx):
+        """FPS + every radius of the level: the single overlapped launch covers FPS and the first radius
+        (:173-180), ONE multi-radius launch (one staging / binning of the cloud) the remaining radii --
+        the reference rescans the cloud once per radius (:175-186).
+        -> new_xyz, [(idx or None, grouped_xyz) per scale]"""
+        _, new_xyz, idx0, _, gx0 = sample_and_group_xyz(self.npoint, self.radius_list[0], self.nsample_list[0], xyz, True)
+        scales = [(idx0, gx0)]
+        if len(self.radius_list) > 1:
+            rest = query_ball_group_xyz_msg(self.radius_list[1:], self.nsample_list[1:], xyz, new_xyz, True, want_idx=want_idx)
+            scales += [(i, g) for i, _, g in rest]
+        return new_xyz, scales
+
     def _forward_fused(self, xyz, points):
-        """Inference: one overlapped launch for FPS + the first radius, a cell-list ball query per further
-        radius, and one fused MLP + max-pool kernel per scale; no grouped tensor is ever materialised."""
-        _, new_xyz, idx0, _, _ = sample_and_group_xyz(self.npoint, self.radius_list[0], self.nsample_list[0], xyz, True)
-        outs = []
-        for si, (radius, nsample) in enumerate(zip(self.radius_list, self.nsample_list)):
-            idx = idx0 if si == 0 else query_ball_point(radius, nsample, xyz, new_xyz)[0]
-            outs.append(sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, self._packed(si, xyz.device)))
+        """Inference: the grouping launches of _group_scales, then one fused MLP + max-pool kernel per scale;
+        no grouped tensor is ever materialised."""
+        new_xyz, scales = self._group_scales(xyz, True)
+        outs = [sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, self._packed(si, xyz.device))
+                for si, (idx, _) in enumerate(scales)]
         return new_xyz, torch.cat(outs, dim=2)
 
     def forward(self, xyz, points):
@@ -228,22 +264,15 @@ class PointnetSAModuleMSG(nn.Module):
             return self._forward_fused(xyz, points)
         self.last_path = "unfused"
         fused = not (torch.is_grad_enabled() and xyz.requires_grad)
-        first = None
+        scales = None
         if fused:
-            # FPS + the first scale's ball query/group in the single overlapped launch (:173-180);
-            # the other scales reuse new_xyz
-            _, new_xyz, idx0, _, gx0 = sample_and_group_xyz(self.npoint, self.radius_list[0],
-                                                            self.nsample_list[0], xyz, True)
-            first = (idx0, gx0)
+            new_xyz, scales = self._group_scales(xyz, points is not None)
         else:
             new_xyz = gather_point(xyz, farthest_point_sample(self.npoint, xyz))   # :173
         outs = []
         for si, (radius, nsample, mlp) in enumerate(zip(self.radius_list, self.nsample_list, self.mlps)):
-            if fused and si == 0:
-                idx, grouped_xyz = first
-            elif fused:
-                idx, _, grouped_xyz = query_ball_group_xyz(radius, nsample, xyz, new_xyz, True,
-                                                           want_idx=points is not None)
+            if fused:
+                idx, grouped_xyz = scales[si]
             else:
                 idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)       # :178
                 grouped_xyz = group_point(xyz, idx) - new_xyz.unsqueeze(2)     # :179-180

@@ -128,6 +128,31 @@ def query_ball_group_xyz_msg(radius_list, nsample_list, xyz1, xyz2, subtract_cen
     return outs
 
 
+# The single overlapped launch (csrc/sa_fused.hip) is the default of sample_and_group_xyz. It can be switched
+# off -- set_overlapped_launch(False) or PN2_OVERLAP=0 in the environment at import -- in favour of the
+# two-launch path (farthest_point_sample_gather + query_ball_group_xyz): same outputs, ~2.5 % slower at the
+# metric shape, no inter-workgroup hand-off.
+import os as _os
+_OVERLAP = [_os.environ.get("PN2_OVERLAP", "1") != "0"]
+
+
+def set_overlapped_launch(flag):
+    _OVERLAP[0] = bool(flag)
+
+
+def overlapped_launch_status(device=None):
+    """Status words of the overlapped launches' workspaces on `device` (synchronises): all zero unless a
+    consumer workgroup ever gave up waiting for its producer (pn2_sample_and_group_status_offset)."""
+    out = []
+    for (dev_index, _stream, bm), ent in _GRANULES.items():
+        if device is not None and dev_index != device.index:
+            continue
+        buf = ent[0]
+        off = buf.numel() - 8                       # status word: last but one u32 of the workspace
+        out.append(int(buf[off:off + 4].view(torch.int32).item()))
+    return out
+
+
 # Sample-granule workspaces of the overlapped launch, one per (device, stream, size): zeroed once, then
 # every call uses the next GENERATION tag (pn2_sample_and_group_xyz_gen), so no per-call clear is needed.
 # Launches on one stream are ordered, so reusing the buffer is safe; different streams get different buffers.
@@ -166,7 +191,7 @@ def sample_and_group_xyz(npoint, radius, nsample, xyz, subtract_centroid=True):
     m, ns = int(npoint), int(nsample)
     dev = xyz.device
     lib = _C.lib()
-    if b == 0 or not (b <= 128 and 64 <= n <= 8192 and ns <= 256):
+    if b == 0 or not _OVERLAP[0] or not (b <= 128 and 64 <= n <= 8192 and ns <= 256):
         from .tf_sampling import farthest_point_sample_gather
         fps_idx, new_xyz = farthest_point_sample_gather(m, xyz)
         idx, cnt, grouped = query_ball_group_xyz(radius, ns, xyz, new_xyz, subtract_centroid)

@@ -65,6 +65,8 @@ if __name__ == "__main__":
     run_msg(S.sphere_clouds, 32, 512, 128, [(0.2, 32), (0.4, 64), (0.8, 128)])       # cls_msg L2
     run_msg(S.uniform_clouds, 32, 4096, 512, [(0.1, 16), (0.2, 32), (0.4, 128)])
     run_msg(S.sphere_clouds, 32, 4096, 1024, [(0.2, 32)])
+    if len(sys.argv) > 1 and sys.argv[1] == "msg":
+        sys.exit(0)
     run(S.sphere_clouds, 32, 4096, 1024, 0.2, 32, (0, 128, 256, "0"))
     run(S.uniform_clouds, 32, 4096, 1024, 0.2, 32, (0, "0"))
     run(S.sphere_clouds, 32, 4096, 1024, 0.1, 16, (0, "0"))

@@ -11,7 +11,9 @@ for step in "$@"; do
     case $step in
     tests)     timeout 1500 python -m pytest tests -m gpu -x -q > "$OUT/tests.log" 2>&1; tail -5 "$OUT/tests.log" ;;
     tests_new) timeout 900 python -m pytest tests/test_configs_gpu.py tests/test_ball_cells_gpu.py -m gpu -q > "$OUT/tests_new.log" 2>&1; tail -15 "$OUT/tests_new.log" ;;
-    fpslab)    for f in build_lab/fps_*; do case $f in *lab*|*prof*) continue;; esac; n=$(basename $f); timeout 120 $f $n > "$OUT/$n.log" 2>&1; grep "n= 4096" "$OUT/$n.log"; done ;;
+    fpslab)    for f in build_lab/fps_*; do n=$(basename $f); case $n in *lab*|*prof*) continue;; esac; timeout 90 $f $n > "$OUT/$n.log" 2>&1; grep "n= 4096" "$OUT/$n.log"; done ;;
+    prof_bw)   (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bw" -- python $ROOT/scripts/bw_probe.py > "$OUT/prof_bw.log" 2>&1); find "$OUT/prof_bw" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_bw_probe.csv" \;; rm -rf "$OUT/prof_bw"; cut -d, -f1-8 "$OUT/kernel_stats_bw_probe.csv" | head -30 ;;
+    prof_bq)   (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bq" -- python $ROOT/scripts/bq_probe.py msg > "$OUT/prof_bq.log" 2>&1); find "$OUT/prof_bq" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_bq_msg.csv" \;; rm -rf "$OUT/prof_bq"; cut -d, -f1-8 "$OUT/kernel_stats_bq_msg.csv" | head -30 ;;
     bw)        timeout 300 python scripts/bw_probe.py > "$OUT/bw_probe.log" 2>&1; cat "$OUT/bw_probe.log" ;;
     bq)        timeout 300 python scripts/bq_probe.py > "$OUT/bq_probe.log" 2>&1; cat "$OUT/bq_probe.log" ;;
     bench)     timeout 600 python bench.py > "$OUT/bench.log" 2>&1; tail -3 "$OUT/bench.log" ;;

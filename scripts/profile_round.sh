@@ -19,9 +19,15 @@ run_pmc() {    # name, counters, command...
     find "$OUT/pmc_$name" -name "*counter_collection.csv" -exec cp {} "$OUT/pmc_$name.csv" \;
 }
 B="python $ROOT/bench.py --no-cpu-baseline --streams 0 --steps 30 --warmup 3"
+BQ="python $ROOT/bench.py --no-extras --steps 30 --warmup 3"   # only the timed kernel(s)
 run_stats ops $B --path ops
 run_stats overlap $B --path overlap
 run_stats sa_mlp python $ROOT/scripts/sa_mlp_bench.py
+run_stats bw_probe python $ROOT/scripts/bw_probe.py
+run_stats bq_msg python $ROOT/scripts/bq_probe.py msg
+run_stats config_shapes python $ROOT/scripts/config_shapes.py
+run_pmc ov_fetch FETCH_SIZE $BQ --path overlap
+run_pmc ov_write WRITE_SIZE $BQ --path overlap
 run_pmc fetch FETCH_SIZE $B --path ops
 run_pmc write WRITE_SIZE $B --path ops
 run_pmc sq "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" $B --path ops

@@ -98,7 +98,18 @@ def test_c_abi_argument_validation_of_the_extra_entry_points():
     assert lib.pn2_group_point_grad_det(1, 8, 4, 2, 2, None, None, None, None, None) == -1
     assert lib.pn2_seg_grad_ws_bytes(2, 100, 640) == 4 * (2 * 101 + 2 * 2 * 100 + 2 * 640) + 16
     assert lib.pn2_det_grad_ws_bytes(2, 100, 8) == 16 + 8 * 2 * 100 * 8
-    assert lib.pn2_sample_and_group_ws_bytes(3, 100) == 8 * 300
+    assert lib.pn2_sample_and_group_ws_bytes(3, 100) == 8 * 300 + 4 * 66        # granules + 64 ticket counters + status
+    assert lib.pn2_sample_and_group_status_offset(3, 100) == 8 * 300 + 4 * 64
+    # the per-call kernel-choice entry points validate their extra arguments too
+    assert lib.pn2_query_ball_group_xyz_ex(1, 8, 4, 0.2, 4, one, one, 0, one, one, None, 7, 0, None) == -3
+    assert lib.pn2_group_point_ex(1, 8, 4, 2, 2, one, one, one, 9, None) == -3
+    assert lib.pn2_three_interpolate_ex(1, 8, 4, 2, one, one, one, one, 5, None) == -3
+    radii = (ctypes.c_float * 2)(0.1, 0.2)
+    nss = (ctypes.c_int * 2)(4, 0)
+    assert lib.pn2_query_ball_group_xyz_msg(1, 8, 4, 2, radii, nss, one, one, 1, None, None, None, None) == -3   # nsample 0
+    assert lib.pn2_query_ball_group_xyz_msg(1, 8, 4, 5, radii, nss, one, one, 1, None, None, None, None) == -3   # > 4 scales
+    nss[1] = 4
+    assert lib.pn2_query_ball_group_xyz_msg(1, 8, 4, 2, radii, nss, one, one, 1, None, None, None, None) == -1   # no outputs
     # fused MLP: shape limits are reported, never silently mis-run
     assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 24, 0, one, one, None, one, 64, 64, 128, one, one, one, None) == -3   # nsample
     assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 32, 0, one, one, None, one, 512, 512, 512, one, one, one, None) == -4

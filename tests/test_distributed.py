@@ -81,3 +81,40 @@ def test_single_process_fallbacks():
     assert sharding.max_over_ranks(0.5) == 0.5
     g = [torch.ones(3)]
     assert sharding.allreduce_mean_(g)[0].sum() == 3
+
+
+def _run_bench(extra):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--stub", "--steps", "5", "--warmup", "1"] + extra,
+                         capture_output=True, text=True, timeout=280, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout                       # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_spawns_its_own_ranks(scaling):
+    """`python bench.py --gpus 2` with no launcher around it must itself start two ranks (the driver's
+    command line), time the steps between barriers, and report the whole-job rate: stub step on CPU/gloo."""
+    line = _run_bench(["--gpus", "2", "--scaling", scaling])
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["scaling"] == scaling
+    per_rank = 32 if scaling == "weak" else 16
+    assert abs(line["value"] - 2 * per_rank * 5 / (line["ms_per_step"] * 5e-3)) < 1e-6 * line["value"]
+    ar = line["allreduce"]                                    # the gradient-mean leg ran on both ranks
+    assert ar["sem_seg"]["floats"] == 970_000 and ar["cls_ssg"]["floats"] == 1_470_000
+    assert ar["sem_seg"]["mean_ok"] and ar["cls_ssg"]["mean_ok"] and ar["sem_seg"]["us"] > 0
+
+
+def test_bench_single_rank_stub_line():
+    line = _run_bench(["--gpus", "1"])
+    assert line["n_gpus"] == 1 and "allreduce" not in line and line["unit"] == "clouds/s"
+    for key in ("metric", "value", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line
