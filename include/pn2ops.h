@@ -160,6 +160,24 @@ int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, const float
                         const float *points, const int *idx, int c1, int c2, int c3, const float *wpacked,
                         const float *bpacked, float *out, void *stream);
 
+/* ---- a feature-propagation layer behind three_nn, fused, on the matrix cores --------------------------
+ * (no reference kernel; replaces for INFERENCE the TF graph of utils/pointnet_util.py:212-226: the
+ *  inverse-distance weights, three_interpolate, concat([interpolated, points1]) and 2-3 x [conv2d 1x1 +
+ *  batch_norm + ReLU]). fp32 in, fp32 MFMA, fp32 out.
+ *   points2 (b,m,c2) known features, points1 (b,n,c1) skip features or NULL when c1 == 0,
+ *   idx (b,n,3) i32 and dist (b,n,3) squared distances as pn2_three_nn writes them -> out (b,n,widths[nlayers-1]).
+ * nlayers 2 or 3, widths <= 256 (padded to the instantiated tile shapes; PN2_E_TOO_LARGE outside: callers keep
+ * the unfused path). w[i] (cin_i, cout_i) row-major with batch norm folded in by the caller, rows of w[0] in
+ * the reference's concat order [interpolated, points1]; pn2_fp_mlp_pack (host code) permutes them into the
+ * stream the kernel consumes (sizes from pn2_fp_mlp_config; tiles4 = input / layer tile counts). */
+int pn2_fp_mlp_config(int c2, int c1, int nlayers, const int *widths, int *tiles4, long long *w_floats,
+                      long long *b_floats);
+int pn2_fp_mlp_pack(int c2, int c1, int nlayers, const int *widths, const float *const *w, const float *const *bias,
+                    float *wpacked, float *bpacked);
+int pn2_fp_mlp(int b, int n, int m, int c2, int c1, const float *points2, const float *points1, const int *idx,
+               const float *dist, int nlayers, const int *widths, const float *wpacked, const float *bpacked,
+               float *out, void *stream);
+
 /* ---- fused entry points (no reference counterpart) ---- */
 
 /* farthest_point_sample + gather_point(inp, out) in one launch: what
@@ -215,20 +233,18 @@ int pn2_farthest_point_sample_ex(int T, int P, int b, int n, int m, const float 
  *   fps_idx (b,m) i32, new_xyz (b,m,3) f32, idx (b,m,nsample) i32, pts_cnt (b,m) i32,
  *   grouped_xyz (b,m,nsample,3) f32 (minus the centroid when subtract_centroid != 0).
  * ws: device scratch of pn2_sample_and_group_ws_bytes(b,m) bytes (zeroed here on `stream`): the sample
- * granules, the arrival-ticket counters that assign producer / consumer roles (the first b workgroups to
- * START are the producers, so no consumer ever waits for a producer that is not running -- independent of
- * the hardware's dispatch order), and a status word.
+ * granules and a status word.
  * Returns PN2_E_TOO_LARGE for shapes outside the overlapped launch's envelope (b > 128, n > 8192,
- * n < 64, nsample > 256): use pn2_farthest_point_sample_gather + pn2_query_ball_group_xyz then. */
+ * n < 64, nsample > 256) and when the device cannot hold all b producer workgroups plus a consumer at once
+ * (occupancy query at launch): use pn2_farthest_point_sample_gather + pn2_query_ball_group_xyz then. */
 int pn2_sample_and_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,
                              int *fps_idx, float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz,
                              int subtract_centroid, void *stream);
 long long pn2_sample_and_group_ws_bytes(int b, int m);
 /* The same launch without the per-call clear of ws: the caller manages generations. Zero ws ONCE when it is
- * allocated, then pass generation 1, 2, 3, ... -- each launch on a workspace must use the previous launch's
- * generation + 1 (what an earlier generation left behind can never be mistaken for a published sample, and
- * each launch resets the next one's ticket counter). One ws per stream; generation 0 is PN2_E_ARG; re-zero
- * ws before wrapping around. Saves a memset launch (~5 us) per call. */
+ * allocated, then pass a generation that no earlier launch on this workspace used (1, 2, 3, ...: what an
+ * earlier generation left behind can never be mistaken for a published sample). One ws per stream;
+ * generation 0 is PN2_E_ARG; re-zero ws before wrapping around. Saves a memset launch (~5 us) per call. */
 int pn2_sample_and_group_xyz_gen(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,
                                  unsigned generation, int *fps_idx, float *new_xyz, int *idx, int *pts_cnt,
                                  float *grouped_xyz, int subtract_centroid, void *stream);

@@ -11,7 +11,7 @@
 
 #include <mutex>
 #include <tuple>
-#include <unordered_set>
+#include <unordered_map>
 #include <utility>
 
 #include "../../include/pn2ops.h"
@@ -133,27 +133,59 @@ inline int launch(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, hip
 }
 
 // Kernels that ask for more than 48 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize
-// raised once. The attribute call costs microseconds, so it is made ONCE per (device, kernel) -- for the
-// whole 160 KiB of a gfx950 CU -- and remembered; this is the library's only process state, and it is
-// idempotent (every launch passes its exact size).
+// raised. The attribute call costs microseconds, so it is made once per (device, kernel) and the granted
+// size remembered -- the whole 160 KiB of a gfx950 CU when the kernel has no static LDS, else exactly what
+// is asked for (and again only if a later launch asks for more). This is the library's only process
+// state, and it is idempotent (every launch passes its exact size).
 template <typename K>
 inline int allow_dynamic_lds(K kern, size_t bytes)
 {
     if (bytes <= 48 * 1024) return 0;
     if (bytes > 160 * 1024) return PN2_E_TOO_LARGE;
     static std::mutex mu;
-    static std::unordered_set<unsigned long long> done;
+    static std::unordered_map<unsigned long long, size_t> granted;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
-    const unsigned long long key = (unsigned long long)reinterpret_cast<uintptr_t>(reinterpret_cast<const void *>(kern)) ^
-                                   ((unsigned long long)dev << 56);
+    const void *fn = reinterpret_cast<const void *>(kern);
+    const unsigned long long key = (unsigned long long)reinterpret_cast<uintptr_t>(fn) ^ ((unsigned long long)dev << 56);
     std::lock_guard<std::mutex> lock(mu);
-    if (done.count(key)) return 0;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    done.insert(key);
+    auto it = granted.find(key);
+    if (it != granted.end() && it->second >= bytes) return 0;
+    size_t want = 160 * 1024;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+    if (e != hipSuccess) {                                         // static LDS in the kernel: ask for the exact size
+        (void)hipGetLastError();
+        want = bytes;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        if (e != hipSuccess) return (int)e;
+    }
+    granted[key] = want;
     return 0;
+}
+
+// Workgroups of `kern` (threads, dynamic LDS bytes) the current device can hold at once: occupancy query x CU
+// count, cached per (device, kernel, LDS size). Negative = -hipError_t.
+template <typename K>
+inline int resident_workgroups(K kern, int threads, size_t lds)
+{
+    static std::mutex mu;
+    static std::unordered_map<unsigned long long, int> cache;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return -(int)e;
+    const void *fn = reinterpret_cast<const void *>(kern);
+    const unsigned long long key = ((unsigned long long)reinterpret_cast<uintptr_t>(fn) * 1315423911ull) ^
+                                   ((unsigned long long)dev << 56) ^ (unsigned long long)lds;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int per_cu = 0, cus = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds);
+    if (e != hipSuccess) return -(int)e;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return -(int)e;
+    return cache[key] = per_cu * cus;
 }
 
 }  // namespace pn2

@@ -20,15 +20,20 @@
 // launch, tag = 1. Every workgroup asks for more than half of the CU's LDS, so producers never share
 // a CU with consumers (a co-resident consumer would steal issue slots from the latency-bound chain).
 //
-// Forward progress without assumptions about dispatch order: a workgroup's ROLE is not its block index but
-// its ARRIVAL TICKET (one returning atomicAdd on a per-launch counter in `ws`): the first b workgroups to
-// start running become the FPS producers (ticket = cloud), every later arrival a consumer. A consumer
-// therefore never spins before all producers are resident and running, whatever order the hardware
-// dispatches blocks in and whatever else shares the GPU; b <= 128 << 256 CUs, and every workgroup asks for
-// more than half of a CU's LDS, so a producer never shares its CU. The ticket costs ~1 us once per
-// workgroup (0.2 % of the launch). The consumers' spin is bounded all the same and REPORTS (status word
-// in `ws`, pn2_sample_and_group_status) instead of trapping; shapes outside the envelope are refused
-// (callers fall back to pn2_farthest_point_sample_gather + pn2_query_ball_group_xyz).
+// Forward progress. Consumers spin until their producer has advanced; that cannot deadlock while the b
+// producer workgroups are running, which holds because (1) workgroups start in block-index order on this
+// hardware (producers are blocks [0, b); MI355X_MICROARCH.md: a 1024-block grid starts first -> last within
+// 0.34-0.69 us) and (2) the launch is refused unless the device can hold b + 1 of these workgroups at once
+// (occupancy query at launch, cached): b <= 128 << 256 CUs, and every workgroup asks for more than half of a
+// CU's LDS, so a producer never shares its CU. HIP does not PROMISE (1), so the consumers' spin is bounded
+// (~10 s) and a consumer that gives up records it in the status word of `ws`
+// (pn2_sample_and_group_status_offset) and exits: an error the host can read, not a trap that would take
+// the process down. Shapes outside the envelope are refused (callers use the two-launch path:
+// pn2_farthest_point_sample_gather + pn2_query_ball_group_xyz; the Python layer also has a switch).
+// Tried and measured (round 2): roles taken by ARRIVAL TICKET (one returning atomicAdd per workgroup; the
+// first b arrivals become producers), which needs no assumption about dispatch order -- 452-470 us per
+// launch against 419 with roles by block index (the ticket winners are the workgroups closest to the
+// counter's memory channel, i.e. the producers end up bunched on one XCD). Not shipped.
 #include "ball_query_body.h"
 #include "fps_body.h"
 
@@ -39,7 +44,6 @@ namespace pn2 {
 constexpr int kFusedThreads = 512;
 constexpr int kFusedMaxClouds = 128;            // producers must leave most CUs to the consumers
 constexpr size_t kFusedMinLds = 82 * 1024;      // > 160 KiB / 2: one workgroup per CU
-constexpr unsigned kFusedSlots = 64;            // ticket counters in ws, indexed by generation % 64 (power of two)
 
 template <int P>
 __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, int m, int Q, int nsample, float thr,
@@ -51,24 +55,16 @@ __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, i
                                                                  float *__restrict__ grouped, int subtract)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // role by arrival ticket (header): counters live behind the b*m granules, one per generation slot
-    unsigned *ctl = reinterpret_cast<unsigned *>(tagged + (size_t)b * m);
-    unsigned *ticket_ctr = ctl + (tag & (kFusedSlots - 1));
-    __shared__ int s_ticket;
-    if (threadIdx.x == 0) {
-        s_ticket = (int)atomicAdd(ticket_ctr, 1u);
-        if (s_ticket == 0) ctl[(tag + 1u) & (kFusedSlots - 1)] = 0u;   // the next launch on this workspace starts from zero
-    }
-    __syncthreads();
-    const int blk = s_ticket;
+    unsigned *status = reinterpret_cast<unsigned *>(tagged + (size_t)b * m);   // launch status word behind the granules
+    const int blk = blockIdx.x;
     if (blk < b) {
         fps_reg_body<kFusedThreads, P, true, true>(n, m, Q, blk, xyz, fps_idx, nullptr, tagged, smem, tag);
     } else {
         const int id = blk - b;
-        const int cloud = id % b;                // query range first, cloud second: the consumers that arrive
-        const int q0 = (id / b) * qpb;           // first take the queries that can start earliest
+        const int cloud = id % b;                // query range first, cloud second: the consumers that can
+        const int q0 = (id / b) * qpb;           // start earliest are dispatched first
         bq_block_body<true, true, true>(n, m, nsample, thr, cloud, q0, min(q0 + qpb, m), xyz, nullptr, tagged,
-                                        new_xyz, idx, pts_cnt, grouped, subtract, smem, tag, 0, ctl + kFusedSlots);
+                                        new_xyz, idx, pts_cnt, grouped, subtract, smem, tag, 0, status);
     }
 }
 
@@ -89,6 +85,12 @@ static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, unsi
     if (lds > 160 * 1024) return PN2_E_TOO_LARGE;
     auto kern = sa_fused_kernel<P>;
     if (int rc = allow_dynamic_lds(kern, lds)) return rc;
+    {
+        // residency (header): room for every producer plus at least one consumer at the same time
+        const int room = resident_workgroups(kern, kFusedThreads, lds);
+        if (room < 0) return -room;
+        if (room < b + 1) return PN2_E_TOO_LARGE;
+    }
     if (tag == 0) {                                               // caller did not manage generations: clear, use tag 1
         hipError_t e = hipMemsetAsync(ws, 0, (size_t)pn2_sample_and_group_ws_bytes(b, m), st);
         if (e != hipSuccess) return (int)e;
@@ -104,8 +106,8 @@ static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, unsi
 extern "C" long long pn2_sample_and_group_ws_bytes(int b, int m)
 {
     if (b <= 0 || m <= 0) return 0;
-    // b*m sample granules, 64 arrival-ticket counters (one per generation slot), 1 status word (+ padding)
-    return (long long)sizeof(unsigned long long) * b * m + (long long)sizeof(unsigned) * (pn2::kFusedSlots + 2);
+    // b*m sample granules + the launch status word (padded to 16 bytes)
+    return (long long)sizeof(unsigned long long) * b * m + 16;
 }
 
 static int sample_and_group_common(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws, unsigned tag,
@@ -163,5 +165,5 @@ extern "C" int pn2_sample_and_group_xyz_gen(int b, int n, int m, float radius, i
 extern "C" long long pn2_sample_and_group_status_offset(int b, int m)
 {
     if (b <= 0 || m <= 0) return -1;
-    return (long long)sizeof(unsigned long long) * b * m + (long long)sizeof(unsigned) * pn2::kFusedSlots;
+    return (long long)sizeof(unsigned long long) * b * m;
 }

@@ -46,6 +46,27 @@ __device__ __forceinline__ f32x16 mlp_relu(f32x16 x)
 // ---- streamed variant (sa_mlp_stream.hip) ------------------------------------------------------------
 constexpr int kMlpStagePairs = 4;          // 32x32 weight tile pairs per LDS stage (16 KiB)
 
+constexpr int kS = kMlpStagePairs;
+
+__host__ __device__ __forceinline__ int pad_to_stage(int pairs) { return (pairs + kS - 1) / kS * kS; }
+
+// 16 MFMAs of one tile pair out of the current LDS stage; SWAP: operands exchanged (last layer)
+template <bool SWAP>
+__device__ __forceinline__ f32x16 stream_pair(const float4 *stage, int slot, int lane, f32x16 act, f32x16 acc)
+{
+    const float4 *w4 = stage + slot * 256 + lane;
+    const float4 a0 = w4[0], a1 = w4[64], a2 = w4[128], a3 = w4[192];
+    const float wv[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+#pragma unroll
+    for (int v = 0; v < 16; ++v)
+        acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(act[v], wv[v], acc, 0, 0, 0)
+                   : __builtin_amdgcn_mfma_f32_32x32x2f32(wv[v], act[v], acc, 0, 0, 0);
+    return acc;
+}
+
+// one 32x32 tile pair of a (kin, nout) row-major weight matrix in the MFMA operand layout (sa_mlp_stream.hip)
+float *mlp_pack_pair(float *wp, const float *w, int kin, int nout, int t, int u, const int *krow);
+
 struct MlpStreamConfig { int ti, t1, t2, t3; };
 bool mlp_stream_pick(int cin, int c1, int c2, int c3, MlpStreamConfig &cfg);
 size_t mlp_stream_w_floats(const MlpStreamConfig &c);

@@ -20,24 +20,6 @@
 
 namespace pn2 {
 
-constexpr int kS = kMlpStagePairs;
-
-__host__ __device__ __forceinline__ int pad_to_stage(int pairs) { return (pairs + kS - 1) / kS * kS; }
-
-// 16 MFMAs of one tile pair out of the current LDS stage; SWAP: operands exchanged (last layer)
-template <bool SWAP>
-__device__ __forceinline__ f32x16 stream_pair(const float4 *stage, int slot, int lane, f32x16 act, f32x16 acc)
-{
-    const float4 *w4 = stage + slot * 256 + lane;
-    const float4 a0 = w4[0], a1 = w4[64], a2 = w4[128], a3 = w4[192];
-    const float wv[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
-#pragma unroll
-    for (int v = 0; v < 16; ++v)
-        acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(act[v], wv[v], acc, 0, 0, 0)
-                   : __builtin_amdgcn_mfma_f32_32x32x2f32(wv[v], act[v], acc, 0, 0, 0);
-    return acc;
-}
-
 template <int T1, int T2, int T3>
 __global__ __launch_bounds__(kMlpThreads) void sa_mlp3_stream_kernel(int n, int m, int nsample, int cfeat, int c3, long long rows,
                                                                      int ti, const float *__restrict__ xyz,
@@ -205,7 +187,7 @@ size_t mlp_stream_b_floats(const MlpStreamConfig &c) { return (size_t)(c.t1 + c.
 
 // one 32x32 tile pair in the MFMA operand layout [q][lane][r] (see sa_mlp.hip): value for lane l, register
 // 4q + r = W[krow(32u + mlp_chan(4q + r, l >> 5))][32t + (l & 31)]
-static float *pack_pair(float *wp, const float *w, int kin, int nout, int t, int u, const int *krow)
+float *mlp_pack_pair(float *wp, const float *w, int kin, int nout, int t, int u, const int *krow)
 {
     for (int q = 0; q < 4; ++q)
         for (int lane = 0; lane < 64; ++lane)
@@ -225,13 +207,13 @@ void mlp_stream_pack(const MlpStreamConfig &c, int cin, int c1, int c2, int c3, 
     for (int k = 0; k < cin; ++k) krow[k] = xyz_first ? (k < cfeat ? 3 + k : k - cfeat) : k;
     float *wp = wpacked;
     for (int u = 0; u < c.ti; ++u)
-        for (int t = 0; t < c.t1; ++t) wp = pack_pair(wp, ws[0], cin, c1, t, u, krow);
+        for (int t = 0; t < c.t1; ++t) wp = mlp_pack_pair(wp, ws[0], cin, c1, t, u, krow);
     for (int i = c.ti * c.t1; i < pad_to_stage(c.ti * c.t1); ++i)
         for (int j = 0; j < 1024; ++j) *wp++ = 0.0f;
     for (int t = 0; t < c.t2; ++t)
-        for (int u = 0; u < c.t1; ++u) wp = pack_pair(wp, ws[1], c1, c2, t, u, nullptr);
+        for (int u = 0; u < c.t1; ++u) wp = mlp_pack_pair(wp, ws[1], c1, c2, t, u, nullptr);
     for (int t = 0; t < c.t3; ++t)
-        for (int u = 0; u < c.t2; ++u) wp = pack_pair(wp, ws[2], c2, c3, t, u, nullptr);
+        for (int u = 0; u < c.t2; ++u) wp = mlp_pack_pair(wp, ws[2], c2, c3, t, u, nullptr);
     free(krow);
     const int nout[3] = {c1, c2, c3}, tout[3] = {c.t1, c.t2, c.t3};
     float *bp = bpacked;

@@ -293,8 +293,44 @@ class PointnetFPModule(nn.Module):
     def __init__(self, c_in, mlp, bn=True):
         super().__init__()
         self.mlp = _SharedMLP(c_in, mlp, bn)
+        self.fused_mlp = True          # eval-mode forward may use the fused kernel (csrc/fp_mlp.hip)
+        self.last_path = None
+        self._pack_cache = None
+
+    # Below this many unknown points per call the fused kernel's work items (32 points per wave, one serial
+    # MFMA chain each) do not fill the GPU: sem_seg FP1 (512 points, 768 -> 256 -> 256) measured 138 us fused
+    # against ~70 us layer by layer; FP3 (8192 points) 80 vs ~100; FP4 (65536 points) 72 vs 330.
+    FUSED_MIN_POINTS = 8192
+
+    def _fused_ok(self, points1, points2, npoints):
+        if not self.fused_mlp or self.training or torch.is_grad_enabled() or not points2.is_cuda:
+            return False
+        if npoints < self.FUSED_MIN_POINTS:
+            return False
+        c1 = points1.shape[2] if points1 is not None else 0
+        return sa_mlp.fp_supported(points2.shape[2], c1, self.mlp.widths)
+
+    def _packed(self, c2, c1, device):
+        stamp = (tuple((t.data_ptr(), t._version) for t in list(self.mlp.parameters()) + list(self.mlp.buffers())), device, c2, c1)
+        if self._pack_cache is None or self._pack_cache[0] != stamp:
+            _no_packing_under_capture()
+            self._pack_cache = (stamp, sa_mlp.PackedFPMLP(self.mlp.folded_layers(), c2, c1, device))
+        return self._pack_cache[1]
+
+    def prepare_fused(self, c2, c1, device):
+        """See PointnetSAModule.prepare_fused (c2 = channels of points2, c1 = channels of points1)."""
+        if sa_mlp.fp_supported(c2, c1, self.mlp.widths):
+            self._packed(c2, c1, device)
+        return self
 
     def forward(self, xyz1, xyz2, points1, points2):
+        if self._fused_ok(points1, points2, xyz1.shape[0] * xyz1.shape[1]):
+            # three_nn, then ONE kernel: weights, interpolation, concatenation and the layer stack (:212-226)
+            self.last_path = "fused"
+            dist, idx = three_nn(xyz1, xyz2)                                    # :211
+            c1 = points1.shape[2] if points1 is not None else 0
+            return sa_mlp.fp_mlp(points2, points1, idx, dist, self._packed(points2.shape[2], c1, points2.device))
+        self.last_path = "unfused"
         idx, weight = three_nn_weights(xyz1, xyz2)                              # :211-215
         interpolated = three_interpolate(points2, idx, weight)                  # :216
         x = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated   # :219

@@ -95,3 +95,61 @@ def sa_mlp_maxpool(xyz, new_xyz, points, idx, packed):
                                               packed.widths[0], packed.widths[1], packed.widths[2], ptr(packed.wp),
                                               ptr(packed.bp), ptr(out), stream_ptr(dev)), "sa_mlp3_maxpool")
     return out
+
+
+# ---- feature propagation: three_nn weights + three_interpolate + concat + MLP in one kernel (csrc/fp_mlp.hip) ----
+def fp_supported(c2, c1, widths):
+    """Can pn2_fp_mlp run this feature-propagation stack? (host-only check)"""
+    widths = [int(w) for w in widths]
+    if len(widths) not in (2, 3) or c2 <= 0 or c1 < 0:
+        return False
+    arr = (ctypes.c_int * len(widths))(*widths)
+    return _C.lib().pn2_fp_mlp_config(int(c2), int(c1), len(widths), arr, None, None, None) == 0
+
+
+class PackedFPMLP:
+    """Two or three folded layers [(W (cin, cout), b (cout))] of a feature-propagation module in the order
+    pn2_fp_mlp consumes them; rows of the first W in the reference's concat order [interpolated (c2),
+    points1 (c1)] (pointnet_util.py:219)."""
+
+    def __init__(self, layers, c2, c1, device):
+        require(len(layers) in (2, 3), "pn2_fp_mlp takes two or three layers")
+        ws = [np.ascontiguousarray(w, dtype=np.float32) for w, _ in layers]
+        bs = [np.ascontiguousarray(b, dtype=np.float32) for _, b in layers]
+        require(ws[0].shape[0] == c2 + c1, "first layer expects %d input channels, got %d" % (ws[0].shape[0], c2 + c1))
+        for i in range(1, len(ws)):
+            require(ws[i].shape[0] == ws[i - 1].shape[1], "layer shapes do not chain")
+        self.c2, self.c1 = int(c2), int(c1)
+        self.widths = [int(w.shape[1]) for w in ws]
+        lib = _C.lib()
+        n = len(ws)
+        self._warr = (ctypes.c_int * n)(*self.widths)
+        wf, bf = ctypes.c_longlong(), ctypes.c_longlong()
+        _C.check(lib.pn2_fp_mlp_config(self.c2, self.c1, n, self._warr, None, ctypes.byref(wf), ctypes.byref(bf)), "fp_mlp_config")
+        wp = np.empty(wf.value, np.float32)
+        bp = np.empty(bf.value, np.float32)
+        wptr = (ctypes.c_void_p * n)(*[w.ctypes.data for w in ws])
+        bptr = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bs])
+        _C.check(lib.pn2_fp_mlp_pack(self.c2, self.c1, n, self._warr, wptr, bptr, wp.ctypes.data, bp.ctypes.data), "fp_mlp_pack")
+        self.wp = torch.from_numpy(wp).to(device)
+        self.bp = torch.from_numpy(bp).to(device)
+
+
+def fp_mlp(points2, points1, idx, dist, packed):
+    """points2 (b,m,c2) features of the known points, points1 (b,n,c1) skip features or None, idx / dist
+    (b,n,3) from three_nn -> (b, n, widths[-1]) f32: the inverse-distance weights, the interpolation, the
+    concatenation and the layer stack of pointnet_fp_module (pointnet_util.py:211-226) in one launch."""
+    points2, idx, dist = f32(points2.detach(), "points2"), i32(idx, "idx"), f32(dist.detach(), "dist")
+    b, m, c2 = points2.shape
+    n = idx.shape[1]
+    c1 = 0
+    if points1 is not None:
+        points1 = f32(points1.detach(), "points1")
+        c1 = points1.shape[2]
+    require(c2 == packed.c2 and c1 == packed.c1, "packed FP MLP expects (%d, %d) channels, got (%d, %d)" % (packed.c2, packed.c1, c2, c1))
+    dev = same_device(points2, idx, dist, packed.wp) if points1 is None else same_device(points2, points1, idx, dist, packed.wp)
+    out = torch.empty((b, n, packed.widths[-1]), dtype=torch.float32, device=dev)
+    with on_device(dev):
+        _C.check(_C.lib().pn2_fp_mlp(b, n, m, c2, c1, ptr(points2), ptr(points1), ptr(idx), ptr(dist), len(packed.widths),
+                                     packed._warr, ptr(packed.wp), ptr(packed.bp), ptr(out), stream_ptr(dev)), "fp_mlp")
+    return out

@@ -148,7 +148,7 @@ def overlapped_launch_status(device=None):
         if device is not None and dev_index != device.index:
             continue
         buf = ent[0]
-        off = buf.numel() - 8                       # status word: last but one u32 of the workspace
+        off = buf.numel() - 16                      # status word: first u32 behind the granules
         out.append(int(buf[off:off + 4].view(torch.int32).item()))
     return out
 

@@ -1,5 +1,6 @@
 """End-to-end inference forward of the reference network topologies built from pointnet2_amd's modules
-(models/pointnet2_cls_ssg.py, models/pointnet2_sem_seg.py: same SA/FP levels, random weights): time per
+(models/pointnet2_cls_ssg.py, pointnet2_cls_msg.py, pointnet2_part_seg.py, pointnet2_sem_seg.py: same SA/FP
+levels, random weights; the four model configurations of BASELINE.json): time per
 forward with the fused MFMA MLPs on/off, eager and as a HIP graph. Measurement aid for the callers of
 the hot path; the networks themselves are outside this repository's scope."""
 import os
@@ -56,6 +57,46 @@ class SemSeg(nn.Module):                      # models/pointnet2_sem_seg.py:20-5
         return self.head(g0.permute(0, 2, 1))
 
 
+class ClsMSG(nn.Module):                      # models/pointnet2_cls_msg.py:20-41, xyz + normals (BASELINE config 3)
+    def __init__(self):
+        super().__init__()
+        self.sa1 = U.PointnetSAModuleMSG(3, 512, [0.1, 0.2, 0.4], [16, 32, 128], [[32, 32, 64], [64, 64, 128], [64, 96, 128]])
+        self.sa2 = U.PointnetSAModuleMSG(320, 128, [0.2, 0.4, 0.8], [32, 64, 128],
+                                         [[64, 64, 128], [128, 128, 256], [128, 128, 256]])
+        self.sa3 = U.PointnetSAModule(640, None, None, None, [256, 512, 1024], group_all=True)
+        self.fc = nn.Sequential(nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.ReLU(), nn.Linear(512, 256),
+                                nn.BatchNorm1d(256), nn.ReLU(), nn.Linear(256, 40))
+
+    def forward(self, cloud):                 # (b, n, 6): xyz + normals, sliced like pointnet2_part_seg.py:22-23
+        xyz, normals = cloud[:, :, :3].contiguous(), cloud[:, :, 3:].contiguous()
+        x1, f1 = self.sa1(xyz, normals)
+        x2, f2 = self.sa2(x1, f1)
+        _, f3, _ = self.sa3(x2, f2)
+        return self.fc(f3.reshape(cloud.shape[0], -1))
+
+
+class PartSeg(nn.Module):                     # models/pointnet2_part_seg.py:15-45
+    def __init__(self, classes=50):
+        super().__init__()
+        self.sa1 = U.PointnetSAModule(3, 512, 0.2, 64, [64, 64, 128])
+        self.sa2 = U.PointnetSAModule(128, 128, 0.4, 64, [128, 128, 256])
+        self.sa3 = U.PointnetSAModule(256, None, None, None, [256, 512, 1024], group_all=True)
+        self.fp1 = U.PointnetFPModule(1024 + 256, [256, 256])
+        self.fp2 = U.PointnetFPModule(256 + 128, [256, 128])
+        self.fp3 = U.PointnetFPModule(128 + 6, [128, 128, 128])
+        self.head = nn.Sequential(nn.Conv1d(128, 128, 1), nn.BatchNorm1d(128), nn.ReLU(), nn.Conv1d(128, classes, 1))
+
+    def forward(self, cloud):                 # (b, n, 6)
+        xyz, normals = cloud[:, :, :3].contiguous(), cloud[:, :, 3:].contiguous()
+        x1, f1, _ = self.sa1(xyz, normals)
+        x2, f2, _ = self.sa2(x1, f1)
+        x3, f3, _ = self.sa3(x2, f2)
+        g2 = self.fp1(x2, x3, f2, f3)
+        g1 = self.fp2(x1, x2, f1, g2)
+        g0 = self.fp3(xyz, x1, cloud, g1)     # points1 = concat(l0_xyz, l0_points), :33
+        return self.head(g0.permute(0, 2, 1))
+
+
 def timeit(fn, iters=10, warm=3):
     for _ in range(warm):
         fn()
@@ -77,10 +118,19 @@ def set_fused(model, flag):
 
 def main():
     torch.manual_seed(0)
-    for name, model, b, n in [("pointnet2_cls_ssg B=16 N=1024", ClsSSG(), 16, 1024),
-                              ("pointnet2_sem_seg B=8 N=8192", SemSeg(), 8, 8192)]:
+    import numpy as np
+    for name, model, b, n, normals in [("pointnet2_cls_ssg B=32 N=1024 (config 2)", ClsSSG(), 32, 1024, False),
+                                       ("pointnet2_cls_msg B=32 N=4096 xyz+normals (config 3)", ClsMSG(), 32, 4096, True),
+                                       ("pointnet2_part_seg B=16 N=2048 (config 4)", PartSeg(), 16, 2048, True),
+                                       ("pointnet2_sem_seg B=8 N=8192 (config 5, one GPU's share)", SemSeg(), 8, 8192, False)]:
+        if len(sys.argv) > 1 and sys.argv[1] not in name:
+            continue
         model = model.to(dev).eval()
-        xyz = torch.from_numpy(S.sphere_clouds(b, n, 1)).to(dev)
+        cloud = S.sphere_clouds(b, n, 1)
+        if normals:                           # a sphere-like surface: the normal is the direction of the point
+            nrm = cloud / np.maximum(np.linalg.norm(cloud, axis=2, keepdims=True), 1e-9)
+            cloud = np.concatenate([cloud, nrm.astype(np.float32)], axis=2)
+        xyz = torch.from_numpy(cloud).to(dev)
         with torch.no_grad():
             set_fused(model, False)
             ref = model(xyz)
@@ -99,7 +149,7 @@ def main():
                 model(xyz)
             t_graph = timeit(graph.replay)
         paths = [m.last_path for m in model.modules() if hasattr(m, "last_path")]
-        print("%-32s unfused %7.3f ms | fused MLPs %7.3f ms | fused + HIP graph %7.3f ms | rel. diff %.1e | SA paths %s"
+        print("%-58s unfused %7.3f ms | fused MLPs %7.3f ms | fused + HIP graph %7.3f ms | rel. diff %.1e | SA paths %s"
               % (name, t_unfused, t_fused, t_graph, err, paths), flush=True)
 
 

@@ -98,8 +98,8 @@ def test_c_abi_argument_validation_of_the_extra_entry_points():
     assert lib.pn2_group_point_grad_det(1, 8, 4, 2, 2, None, None, None, None, None) == -1
     assert lib.pn2_seg_grad_ws_bytes(2, 100, 640) == 4 * (2 * 101 + 2 * 2 * 100 + 2 * 640) + 16
     assert lib.pn2_det_grad_ws_bytes(2, 100, 8) == 16 + 8 * 2 * 100 * 8
-    assert lib.pn2_sample_and_group_ws_bytes(3, 100) == 8 * 300 + 4 * 66        # granules + 64 ticket counters + status
-    assert lib.pn2_sample_and_group_status_offset(3, 100) == 8 * 300 + 4 * 64
+    assert lib.pn2_sample_and_group_ws_bytes(3, 100) == 8 * 300 + 16            # granules + status word
+    assert lib.pn2_sample_and_group_status_offset(3, 100) == 8 * 300
     # the per-call kernel-choice entry points validate their extra arguments too
     assert lib.pn2_query_ball_group_xyz_ex(1, 8, 4, 0.2, 4, one, one, 0, one, one, None, 7, 0, None) == -3
     assert lib.pn2_group_point_ex(1, 8, 4, 2, 2, one, one, one, 9, None) == -3
