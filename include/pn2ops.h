@@ -143,14 +143,18 @@ int pn2_three_interpolate_grad_seg(int b, int n, int c, int m, const float *grad
  *  over nsample). fp32 in, fp32 MFMA, fp32 out.
  *   xyz (b,n,3), new_xyz (b,m,3), points (b,n,cfeat) or NULL when cfeat == 0, idx (b,m,nsample) i32
  *   -> out (b,m,c3).  Input channel order is the reference's: [relative xyz (3), features (cfeat)].
- * Two kernels behind one entry: weights resident in LDS (3 + cfeat <= 32, widths within (128,128,128);
- * nsample 16 or a multiple of 32) or streamed through LDS (up to 384 input channels, widths within
- * (128,128,256); nsample a multiple of 32). PN2_E_TOO_LARGE outside: callers keep the unfused path.
+ * Three kernels behind one entry: weights resident in LDS (3 + cfeat <= 32, widths within (128,128,128);
+ * nsample 16 or a multiple of 32), streamed through LDS (up to 384 input channels, widths within
+ * (128,128,256); nsample a multiple of 32), or the cooperative kernel for wide stacks -- (256,256,512) and the
+ * group_all level's (256,512,1024), any number of input channels, any nsample (the tail of the group is
+ * masked). idx == NULL together with new_xyz == NULL selects the group_all form (sample_and_group_all,
+ * pointnet_util.py:59-84: m = 1, nsample = n, the group is the whole cloud, no centroid subtraction).
+ * PN2_E_TOO_LARGE outside: callers keep the unfused path.
  * Weights: w_i (cin_i, cout_i) row-major = the reference's conv kernel [1,1,cin,cout] (tf_util.py:113-117)
  * with batch norm folded in by the caller; xyz_first says whether the rows of w1 are [xyz, features]
  * (pointnet_util.py:50) or [features, xyz] (:184, MSG). pn2_sa_mlp3_pack (host code) permutes them into the
  * order the kernel consumes: wpacked / bpacked of the sizes pn2_sa_mlp3_config reports (info4 = {kind:
- * 0 resident / 1 streamed, output tiles of the three layers}), uploaded by the caller. */
+ * 0 resident / 1 streamed / 2 cooperative, output tiles of the three layers}), uploaded by the caller. */
 int pn2_sa_mlp3_config(int cin, int c1, int c2, int c3, int nsample, int *info4, long long *w_floats,
                        long long *b_floats);
 int pn2_sa_mlp3_pack(int cin, int c1, int c2, int c3, int nsample, int xyz_first, const float *w1, const float *bias1,
@@ -170,13 +174,17 @@ int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, const float
  * the unfused path). w[i] (cin_i, cout_i) row-major with batch norm folded in by the caller, rows of w[0] in
  * the reference's concat order [interpolated, points1]; pn2_fp_mlp_pack (host code) permutes them into the
  * stream the kernel consumes (sizes from pn2_fp_mlp_config; tiles4 = input / layer tile counts). */
-int pn2_fp_mlp_config(int c2, int c1, int nlayers, const int *widths, int *tiles4, long long *w_floats,
+int pn2_fp_mlp_config(int c2, int c1, int nlayers, const int *widths, int kind, int *tiles4, long long *w_floats,
                       long long *b_floats);
-int pn2_fp_mlp_pack(int c2, int c1, int nlayers, const int *widths, const float *const *w, const float *const *bias,
-                    float *wpacked, float *bpacked);
+int pn2_fp_mlp_pack(int c2, int c1, int nlayers, const int *widths, int kind, const float *const *w,
+                    const float *const *bias, float *wpacked, float *bpacked);
 int pn2_fp_mlp(int b, int n, int m, int c2, int c1, const float *points2, const float *points1, const int *idx,
-               const float *dist, int nlayers, const int *widths, const float *wpacked, const float *bpacked,
+               const float *dist, int nlayers, const int *widths, int kind, const float *wpacked, const float *bpacked,
                float *out, void *stream);
+/* kind selects the kernel (and with it the packed layout): 0 = one wave per 32 points, weights streamed
+ * through LDS (many points: sem_seg FP4, 65536 points, 88 TFLOP/s); 1 = four waves share 32 points and split
+ * each layer's output tiles (few points, wide layers: a 512-point level is otherwise 16 serial MFMA chains).
+ * Same results either way; pack with the kind you launch with. */
 
 /* ---- fused entry points (no reference counterpart) ---- */
 

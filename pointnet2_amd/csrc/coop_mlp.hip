@@ -1,0 +1,366 @@
+// coop_mlp.hip -- the fused MLP kernels for WIDE layer stacks over FEW rows: the four waves of a
+// workgroup share ONE work item (32 samples) and split every layer's OUTPUT tiles between them.
+//
+// What it covers (reference call sites):
+//   * set-abstraction stacks beyond the streamed kernel's (128,128,256): sem_seg's last level
+//     pointnet_sa_module(..., mlp=[256,256,512], ...)  (models/pointnet2_sem_seg.py:31) and the group_all
+//     level mlp=[256,512,1024] of the classification / part-segmentation nets (pointnet2_cls_ssg.py:34,
+//     pointnet2_cls_msg.py:29, pointnet2_part_seg.py:28; sample_and_group_all, utils/pointnet_util.py:59-84:
+//     one group holding every point, no centroid subtraction) -- conv2d 1x1 + batch_norm + ReLU x 3 and
+//     reduce_max over the group (pointnet_util.py:117-127), any nsample (the last 32-sample part is masked);
+//   * feature-propagation layers with few unknown points (pointnet_fp_module, pointnet_util.py:199-229;
+//     sem_seg FP1-FP3, part_seg FP1-FP2: 512-8192 points, up to 1280 input channels), see fp_mlp.hip.
+// With one wave per item (sa_mlp_stream.hip, fp_mlp.hip) such a level is a handful of serial MFMA chains --
+// sem_seg FP1 is 16 items of 256 tile pairs each: 138 us with 16 waves busy on the whole GPU. Here a wave
+// computes tiles t = w, w+4, ... of every layer, so an item's chain is four times shorter and four times as
+// many SIMDs work; the hidden activations are exchanged through LDS as raw accumulator registers (a layer's
+// C/D layout IS the next layer's B-operand layout, sa_mlp.hip), one s_barrier per layer and item.
+// Every wave consumes DIFFERENT weight tile pairs, so nothing is shared through LDS: each wave streams its
+// own 4 KiB pairs from L2 straight into registers, one pair ahead of the MFMAs (the packed array is the
+// exact per-wave consumption order). Inputs are gathered by all four waves (redundant L2 reads, negligible
+// at these sizes). The last layer runs with swapped operands: a lane holds 16 samples of one channel ->
+// lane-local max-pool, or 128-byte row segments for the plain store of a feature-propagation layer.
+#include "sa_mlp_common.h"
+
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+
+namespace pn2 {
+
+constexpr int kGatherGrouped = 0, kGatherInterp = 1;
+
+__device__ __forceinline__ float coop_interp3(float p1, float p2, float p3, float w1, float w2, float w3)
+{
+    return __fadd_rn(__fadd_rn(__fmul_rn(p1, w1), __fmul_rn(p2, w2)), __fmul_rn(p3, w3));   // tf_interpolate.cpp:122
+}
+
+// Q1, Q2, Q3: output tiles PER WAVE of the three layers (layer widths 128 * Q); Q3 == 0: two layers.
+template <int GATHER, int Q1, int Q2, int Q3>
+__global__ __launch_bounds__(kMlpThreads) void coop_mlp_kernel(CoopParams p)
+{
+    constexpr int T1 = 4 * Q1, T2 = 4 * Q2, T3 = 4 * Q3;
+    constexpr bool THREE = Q3 > 0;
+    constexpr int QL = THREE ? Q3 : Q2;                                   // the last layer's tiles per wave
+    constexpr bool POOL = GATHER == kGatherGrouped;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *act1 = reinterpret_cast<float4 *>(smem);                       // [T1][4][64] float4
+    float4 *act2 = act1 + T1 * 256;                                        // [T2][4][64] (three layers only)
+    float *bias_s = reinterpret_cast<float *>(act2 + (THREE ? T2 * 256 : 0));
+    const float *b1 = bias_s, *b2 = b1 + T1 * 32, *b3 = b2 + T2 * 32;
+    const float *blast = THREE ? b3 : b2;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, s = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < (T1 + T2 + T3) * 32; i += kMlpThreads) bias_s[i] = p.bp[i];
+    __syncthreads();
+
+    // ---- this wave's weight stream: pair number 4 * k + w of the packed array, k = 0 .. per_item - 1 per item
+    const int per_item = p.ti * Q1 + T1 * Q2 + T2 * Q3;
+    const float4 *wp4 = reinterpret_cast<const float4 *>(p.wp) + (size_t)w * 256 + lane;
+    float4 nx0, nx1, nx2, nx3;                                            // the NEXT pair, in flight
+    int k = 0;                                                            // pair counter within the item
+    auto issue = [&]() __attribute__((always_inline)) {
+        const float4 *q = wp4 + (size_t)(k == per_item ? 0 : k) * 1024;  // 4 pairs * 256 float4 per step; wraps to the next item
+        nx0 = q[0]; nx1 = q[64]; nx2 = q[128]; nx3 = q[192];
+    };
+#define PN2_COOP_PAIR(SWAP, ACT, ACC)                                                                              \
+    do {                                                                                                           \
+        const float wv_[16] = {nx0.x, nx0.y, nx0.z, nx0.w, nx1.x, nx1.y, nx1.z, nx1.w,                             \
+                               nx2.x, nx2.y, nx2.z, nx2.w, nx3.x, nx3.y, nx3.z, nx3.w};                            \
+        ++k;                                                                                                       \
+        issue();                                                                                                   \
+        _Pragma("unroll") for (int v_ = 0; v_ < 16; ++v_)                                                          \
+            ACC = (SWAP) ? __builtin_amdgcn_mfma_f32_32x32x2f32((ACT)[v_], wv_[v_], ACC, 0, 0, 0)                    \
+                         : __builtin_amdgcn_mfma_f32_32x32x2f32(wv_[v_], (ACT)[v_], ACC, 0, 0, 0);                   \
+    } while (0)
+    issue();
+
+    auto act_load = [&](const float4 *act, int u) __attribute__((always_inline)) -> f32x16 {
+        const float4 *a = act + u * 256 + lane;
+        const float4 r0 = a[0], r1 = a[64], r2 = a[128], r3 = a[192];
+        f32x16 x = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+        return x;
+    };
+    auto act_store = [&](float4 *act, int t, const f32x16 &x) __attribute__((always_inline)) {
+        float4 *a = act + t * 256 + lane;
+        a[0] = make_float4(x[0], x[1], x[2], x[3]);
+        a[64] = make_float4(x[4], x[5], x[6], x[7]);
+        a[128] = make_float4(x[8], x[9], x[10], x[11]);
+        a[192] = make_float4(x[12], x[13], x[14], x[15]);
+    };
+
+    const int parts = POOL ? (p.nsample + 31) / 32 : 1;
+    // p.split: the 32-sample parts of a group are separate work units (few, large groups -- the group_all level:
+    // 32 clouds x 4 parts), merged with an integer atomic max on the pre-zeroed output (values are >= 0 after ReLU)
+    const int parts_in = p.split ? 1 : parts;
+    const long long units = POOL ? (p.split ? p.rows * parts : p.rows) : (p.rows + 31) / 32;
+    const int cin = POOL ? p.cf + 3 : p.cf + p.c1;
+
+    for (long long unit_raw = blockIdx.x; unit_raw < units; unit_raw += gridDim.x) {
+        const long long unit = p.split ? unit_raw / parts : unit_raw;       // centroid (SA) / group of 32 points (FP)
+        float best[QL];
+#pragma unroll
+        for (int g = 0; g < QL; ++g) best[g] = -INFINITY;
+        for (int part_i = 0; part_i < parts_in; ++part_i) {
+            const int part = p.split ? (int)(unit_raw % parts) : part_i;
+            k = 0;
+            // ---- per-lane gather context ----------------------------------------------------------------
+            const float *gf = nullptr, *gx = nullptr, *gc = nullptr;       // grouped: feature row, xyz row, centroid
+            const float *pa = nullptr, *pb = nullptr, *pc = nullptr, *p1 = nullptr;
+            float w1 = 0.f, w2 = 0.f, w3 = 0.f;
+            if (POOL) {
+                const long long cloud = unit / p.m;
+                const int smp = part * 32 + s;
+                int pt;
+                if (p.idx) pt = p.idx[unit * p.nsample + min(smp, p.nsample - 1)];
+                else pt = min(smp, p.n - 1);                               // group_all: the group IS the cloud
+                gf = p.feat + ((size_t)cloud * p.n + pt) * p.cf;
+                gx = p.xyz + ((size_t)cloud * p.n + pt) * 3;
+                gc = p.new_xyz ? p.new_xyz + unit * 3 : nullptr;
+            } else {
+                const long long row = min(unit * 32 + s, p.rows - 1);
+                const long long cloud = row / p.n;
+                const int *ip = p.idx + row * 3;
+                const float *dp = p.dist + row * 3;
+                // inverse-distance weights, pointnet_util.py:212-215
+                const float r1 = __fdiv_rn(1.0f, fmaxf(dp[0], 1e-10f)), r2 = __fdiv_rn(1.0f, fmaxf(dp[1], 1e-10f)),
+                            r3 = __fdiv_rn(1.0f, fmaxf(dp[2], 1e-10f));
+                const float norm = __fadd_rn(__fadd_rn(r1, r2), r3);
+                w1 = __fdiv_rn(r1, norm); w2 = __fdiv_rn(r2, norm); w3 = __fdiv_rn(r3, norm);
+                const float *base2 = p.feat + (size_t)cloud * p.m * p.cf;
+                pa = base2 + (size_t)ip[0] * p.cf; pb = base2 + (size_t)ip[1] * p.cf; pc = base2 + (size_t)ip[2] * p.cf;
+                p1 = p.skip ? p.skip + (size_t)row * p.c1 : nullptr;
+            }
+            const bool vec_a = (p.cf & 3) == 0, vec_b = vec_a && (p.c1 & 3) == 0;
+            // one 32-channel tile of layer-1 inputs: register v <- channel 32u + mlp_chan(v, h).
+            // grouped: [features (cf), xyz - centroid (3)]; interpolated: [interpolated (cf), points1 (c1)]
+            auto gather = [&](int u) __attribute__((always_inline)) -> f32x16 {
+                f32x16 x;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k0 = 32 * u + 8 * q + 4 * h;
+                    if (POOL) {
+                        if (vec_a && k0 + 3 < p.cf) {
+                            const float4 f = *reinterpret_cast<const float4 *>(gf + k0);
+                            x[4 * q] = f.x; x[4 * q + 1] = f.y; x[4 * q + 2] = f.z; x[4 * q + 3] = f.w;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int kk = k0 + r;
+                                float val = 0.0f;
+                                if (kk < p.cf) val = gf[kk];
+                                else if (kk < cin) val = gc ? __fsub_rn(gx[kk - p.cf], gc[kk - p.cf]) : gx[kk - p.cf];
+                                x[4 * q + r] = val;
+                            }
+                        }
+                    } else {
+                        if (vec_a && k0 + 3 < p.cf) {
+                            const float4 a = *reinterpret_cast<const float4 *>(pa + k0), bq = *reinterpret_cast<const float4 *>(pb + k0),
+                                         c = *reinterpret_cast<const float4 *>(pc + k0);
+                            x[4 * q] = coop_interp3(a.x, bq.x, c.x, w1, w2, w3);
+                            x[4 * q + 1] = coop_interp3(a.y, bq.y, c.y, w1, w2, w3);
+                            x[4 * q + 2] = coop_interp3(a.z, bq.z, c.z, w1, w2, w3);
+                            x[4 * q + 3] = coop_interp3(a.w, bq.w, c.w, w1, w2, w3);
+                        } else if (vec_b && k0 >= p.cf && k0 + 3 < cin) {
+                            const float4 f = *reinterpret_cast<const float4 *>(p1 + (k0 - p.cf));
+                            x[4 * q] = f.x; x[4 * q + 1] = f.y; x[4 * q + 2] = f.z; x[4 * q + 3] = f.w;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int kk = k0 + r;
+                                float val = 0.0f;
+                                if (kk < p.cf) val = coop_interp3(pa[kk], pb[kk], pc[kk], w1, w2, w3);
+                                else if (kk < cin) val = p1[kk - p.cf];
+                                x[4 * q + r] = val;
+                            }
+                        }
+                    }
+                }
+                return x;
+            };
+
+            // ---- layer 1: this wave's tiles t = 4g + w; input tiles outermost ---------------------------------
+            f32x16 a1[Q1];
+#pragma unroll
+            for (int g = 0; g < Q1; ++g) a1[g] = mlp_bias(b1, 4 * g + w, h);
+            f32x16 x = gather(0);
+            for (int u = 0; u < p.ti; ++u) {
+                f32x16 xn = x;
+                if (u + 1 < p.ti) xn = gather(u + 1);
+#pragma unroll
+                for (int g = 0; g < Q1; ++g) PN2_COOP_PAIR(false, x, a1[g]);
+                x = xn;
+            }
+#pragma unroll
+            for (int g = 0; g < Q1; ++g) act_store(act1, 4 * g + w, mlp_relu(a1[g]));
+            __syncthreads();
+
+            // ---- the last layer on `src` (TS input tiles): swapped operands; pool or store -----------------
+            auto last_layer = [&](const float4 *src, const int TS) __attribute__((always_inline)) {
+                f32x16 acc[QL];
+#pragma unroll
+                for (int g = 0; g < QL; ++g)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[g][v] = 0.0f;
+                f32x16 xa = act_load(src, 0);
+                for (int u = 0; u < TS; ++u) {
+                    f32x16 xb = xa;
+                    if (u + 1 < TS) xb = act_load(src, u + 1);
+#pragma unroll
+                    for (int g = 0; g < QL; ++g) PN2_COOP_PAIR(true, xa, acc[g]);
+                    xa = xb;
+                }
+                // register v of lane (c, hh) holds sample mlp_chan(v, hh) of the item, channel 32 (4g + w) + c
+#pragma unroll
+                for (int g = 0; g < QL; ++g) {
+                    if (POOL) {
+                        float mx = -INFINITY;
+#pragma unroll
+                        for (int v = 0; v < 16; ++v)
+                            if (part * 32 + mlp_chan(v, h) < p.nsample) mx = fmaxf(mx, acc[g][v]);   // masked tail of the group
+                        best[g] = fmaxf(best[g], mx);
+                    } else {
+                        const int ch = 32 * (4 * g + w) + s;
+                        const float bias = b3_at(blast, ch);
+                        if (ch < p.cout) {
+#pragma unroll
+                            for (int v = 0; v < 16; ++v) {
+                                const long long r = unit * 32 + mlp_chan(v, h);
+                                if (r < p.rows) p.out[r * p.cout + ch] = fmaxf(__fadd_rn(acc[g][v], bias), 0.0f);
+                            }
+                        }
+                    }
+                }
+            };
+
+            if (!THREE) {
+                last_layer(act1, T1);
+                __syncthreads();                                              // act1 is rewritten by the next item
+            } else {
+                // ---- layer 2 ---------------------------------------------------------------------------------
+                f32x16 a2[Q2];
+#pragma unroll
+                for (int g = 0; g < Q2; ++g) a2[g] = mlp_bias(b2, 4 * g + w, h);
+                f32x16 xa = act_load(act1, 0);
+                for (int u = 0; u < T1; ++u) {
+                    f32x16 xb = xa;
+                    if (u + 1 < T1) xb = act_load(act1, u + 1);
+#pragma unroll
+                    for (int g = 0; g < Q2; ++g) PN2_COOP_PAIR(false, xa, a2[g]);
+                    xa = xb;
+                }
+#pragma unroll
+                for (int g = 0; g < Q2; ++g) act_store(act2, 4 * g + w, mlp_relu(a2[g]));
+                __syncthreads();                                              // also: everyone is done reading act1
+                last_layer(act2, T2);
+                // act2 is rewritten only after the next item's first barrier: no barrier needed here
+            }
+        }
+        if (POOL) {
+#pragma unroll
+            for (int g = 0; g < QL; ++g) {
+                const int ch = 32 * (4 * g + w) + s;
+                const float mx = fmaxf(best[g], __shfl_xor(best[g], 32));
+                if (h == 0 && ch < p.cout) {
+                    const float val = fmaxf(__fadd_rn(mx, b3_at(blast, ch)), 0.0f);
+                    if (p.split) atomicMax(reinterpret_cast<int *>(p.out + unit * p.cout + ch), __float_as_int(val));
+                    else p.out[unit * p.cout + ch] = val;
+                }
+            }
+        }
+    }
+#undef PN2_COOP_PAIR
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+bool mlp_coop_pick(int cin, int nlayers, const int *widths, MlpCoopConfig &cfg)
+{
+    if (cin < 1 || (nlayers != 2 && nlayers != 3)) return false;
+    int q[3] = {0, 0, 0};
+    for (int i = 0; i < nlayers; ++i) {
+        if (widths[i] < 1 || widths[i] > 1024) return false;
+        q[i] = (widths[i] + 127) / 128;
+    }
+    // hidden activations live in LDS: 4 KiB per 32-channel tile
+    const int hidden_tiles = 4 * q[0] + (nlayers == 3 ? 4 * q[1] : 0);
+    if (hidden_tiles > 24) return false;
+    cfg = {(cin + 31) / 32, q[0], q[1], q[2]};
+    return true;
+}
+
+static long long coop_pairs(const MlpCoopConfig &c)
+{
+    return 4ll * ((long long)c.ti * c.q1 + 4ll * c.q1 * c.q2 + 4ll * c.q2 * c.q3);
+}
+size_t mlp_coop_w_floats(const MlpCoopConfig &c) { return (size_t)coop_pairs(c) * 1024; }
+size_t mlp_coop_b_floats(const MlpCoopConfig &c) { return (size_t)(4 * (c.q1 + c.q2 + c.q3)) * 32; }
+
+// krow: permutation of the first layer's weight rows (kernel channel order -> caller's row), or nullptr
+void mlp_coop_pack(const MlpCoopConfig &c, int cin, int nlayers, const int *widths, const int *krow, const float *const *ws,
+                   const float *const *bs, float *wpacked, float *bpacked)
+{
+    float *wp = wpacked;
+    const int tin[3] = {c.ti, 4 * c.q1, 4 * c.q2}, qq[3] = {c.q1, c.q2, c.q3};
+    const int kin[3] = {cin, widths[0], nlayers > 1 ? widths[1] : 0};
+    for (int L = 0; L < nlayers; ++L)
+        for (int u = 0; u < tin[L]; ++u)                       // input tiles outermost, then the wave's tile groups,
+            for (int g = 0; g < qq[L]; ++g)                    // then the four waves: pair 4k + w belongs to wave w
+                for (int wv = 0; wv < 4; ++wv)
+                    wp = mlp_pack_pair(wp, ws[L], kin[L], widths[L], 4 * g + wv, u, L == 0 ? krow : nullptr);
+    float *bp = bpacked;
+    for (int L = 0; L < 3; ++L)
+        for (int t = 0; t < 4 * qq[L]; ++t)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int v = 0; v < 16; ++v) {
+                    const int ch = 32 * t + mlp_chan(v, hh);
+                    *bp++ = (L < nlayers && ch < widths[L]) ? bs[L][ch] : 0.0f;
+                }
+}
+
+template <int GATHER, int Q1, int Q2, int Q3>
+static int launch_coop(const CoopParams &p, long long units, hipStream_t st)
+{
+    const size_t lds = sizeof(float4) * 256 * (size_t)(4 * Q1 + (Q3 > 0 ? 4 * Q2 : 0)) + sizeof(float) * 32 * (size_t)(4 * (Q1 + Q2 + Q3));
+    auto kern = coop_mlp_kernel<GATHER, Q1, Q2, Q3>;
+    if (int rc = allow_dynamic_lds(kern, lds)) return rc;
+    long long blocks = units < 512 ? units : 512;
+    return launch(kern, dim3((unsigned)blocks), dim3(kMlpThreads), lds, st, p);
+}
+
+int mlp_coop_launch(const MlpCoopConfig &c, int fp, const CoopParams &p_in, hipStream_t st)
+{
+    CoopParams p = p_in;
+    const int parts = (p.nsample + 31) / 32;
+    p.split = (!fp && parts > 1 && p.rows < 256) ? 1 : 0;          // few large groups: one work unit per 32-sample part
+    if (p.split) {
+        hipError_t e = hipMemsetAsync(p.out, 0, sizeof(float) * (size_t)p.rows * p.cout, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    const long long units = fp ? (p.rows + 31) / 32 : (p.split ? p.rows * parts : p.rows);
+#define PN2_COOP_CASE(G, A, B, C) \
+    if (fp == (G == kGatherInterp) && c.q1 == A && c.q2 == B && c.q3 == C) return launch_coop<G, A, B, C>(p, units, st)
+    PN2_COOP_CASE(kGatherGrouped, 1, 1, 2);
+    PN2_COOP_CASE(kGatherGrouped, 2, 2, 4);
+    PN2_COOP_CASE(kGatherGrouped, 2, 4, 8);
+    PN2_COOP_CASE(kGatherInterp, 1, 1, 0);
+    PN2_COOP_CASE(kGatherInterp, 2, 1, 0);
+    PN2_COOP_CASE(kGatherInterp, 2, 2, 0);
+    PN2_COOP_CASE(kGatherInterp, 1, 1, 1);
+    PN2_COOP_CASE(kGatherInterp, 2, 2, 2);
+#undef PN2_COOP_CASE
+    return PN2_E_TOO_LARGE;
+}
+
+bool mlp_coop_has_kernel(const MlpCoopConfig &c, int fp)
+{
+    static const int sa[][3] = {{1, 1, 2}, {2, 2, 4}, {2, 4, 8}};
+    static const int fpk[][3] = {{1, 1, 0}, {2, 1, 0}, {2, 2, 0}, {1, 1, 1}, {2, 2, 2}};
+    if (fp) {
+        for (const auto &k : fpk) if (c.q1 == k[0] && c.q2 == k[1] && c.q3 == k[2]) return true;
+    } else {
+        for (const auto &k : sa) if (c.q1 == k[0] && c.q2 == k[1] && c.q3 == k[2]) return true;
+    }
+    return false;
+}
+
+}  // namespace pn2

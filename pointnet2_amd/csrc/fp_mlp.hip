@@ -246,11 +246,21 @@ static int launch_fp(const FpConfig &c, long long rows, int n, int m, int c2, in
 
 }  // namespace pn2
 
-extern "C" int pn2_fp_mlp_config(int c2, int c1, int nlayers, const int *widths, int *tiles4, long long *w_floats,
+// kind: 0 = one wave per 32 points, weights streamed through LDS (this file: many points);
+//       1 = four waves per 32 points (coop_mlp.hip: few points, wide layers). Same results, different packing.
+extern "C" int pn2_fp_mlp_config(int c2, int c1, int nlayers, const int *widths, int kind, int *tiles4, long long *w_floats,
                                  long long *b_floats)
 {
     using namespace pn2;
-    if (c2 <= 0 || c1 < 0 || !widths) return PN2_E_ARG;
+    if (c2 <= 0 || c1 < 0 || !widths || (kind != 0 && kind != 1)) return PN2_E_ARG;
+    if (kind == 1) {
+        MlpCoopConfig cc;
+        if (!mlp_coop_pick(c2 + c1, nlayers, widths, cc) || !mlp_coop_has_kernel(cc, 1)) return PN2_E_TOO_LARGE;
+        if (tiles4) { tiles4[0] = cc.ti; tiles4[1] = 4 * cc.q1; tiles4[2] = 4 * cc.q2; tiles4[3] = 4 * cc.q3; }
+        if (w_floats) *w_floats = (long long)mlp_coop_w_floats(cc);
+        if (b_floats) *b_floats = (long long)mlp_coop_b_floats(cc);
+        return PN2_OK;
+    }
     FpConfig c;
     if (!fp_pick(c2 + c1, nlayers, widths, c)) return PN2_E_TOO_LARGE;
     if (tiles4) { tiles4[0] = c.ti; tiles4[1] = c.t1; tiles4[2] = c.t2; tiles4[3] = c.t3; }
@@ -260,15 +270,22 @@ extern "C" int pn2_fp_mlp_config(int c2, int c1, int nlayers, const int *widths,
 }
 
 // Host code: permute (cin_i, cout_i) row-major weights (rows of layer 1 in the reference's concat order
-// [interpolated, points1]) into the tile-pair stream the kernel consumes.
-extern "C" int pn2_fp_mlp_pack(int c2, int c1, int nlayers, const int *widths, const float *const *w,
+// [interpolated, points1]) into the tile-pair stream the chosen kernel consumes.
+extern "C" int pn2_fp_mlp_pack(int c2, int c1, int nlayers, const int *widths, int kind, const float *const *w,
                                const float *const *bias, float *wpacked, float *bpacked)
 {
     using namespace pn2;
     if (c2 <= 0 || c1 < 0 || !widths || !w || !bias || !wpacked || !bpacked) return PN2_E_NULL;
-    FpConfig c;
-    if (!fp_pick(c2 + c1, nlayers, widths, c)) return PN2_E_TOO_LARGE;
+    if (kind != 0 && kind != 1) return PN2_E_ARG;
     const int cin = c2 + c1;
+    if (kind == 1) {
+        MlpCoopConfig cc;
+        if (!mlp_coop_pick(cin, nlayers, widths, cc) || !mlp_coop_has_kernel(cc, 1)) return PN2_E_TOO_LARGE;
+        mlp_coop_pack(cc, cin, nlayers, widths, nullptr, w, bias, wpacked, bpacked);
+        return PN2_OK;
+    }
+    FpConfig c;
+    if (!fp_pick(cin, nlayers, widths, c)) return PN2_E_TOO_LARGE;
     float *wp = wpacked;
     for (int u = 0; u < c.ti; ++u)
         for (int t = 0; t < c.t1; ++t) wp = mlp_pack_pair(wp, w[0], cin, widths[0], t, u, nullptr);
@@ -291,20 +308,28 @@ extern "C" int pn2_fp_mlp_pack(int c2, int c1, int nlayers, const int *widths, c
 }
 
 extern "C" int pn2_fp_mlp(int b, int n, int m, int c2, int c1, const float *points2, const float *points1, const int *idx,
-                          const float *dist, int nlayers, const int *widths, const float *wpacked, const float *bpacked,
-                          float *out, void *stream)
+                          const float *dist, int nlayers, const int *widths, int kind, const float *wpacked,
+                          const float *bpacked, float *out, void *stream)
 {
     using namespace pn2;
     if (b < 0 || n < 0 || m <= 0 || c2 <= 0 || c1 < 0) return PN2_E_SHAPE;
     if (!widths) return PN2_E_NULL;
+    if (kind != 0 && kind != 1) return PN2_E_ARG;
     FpConfig c;
-    if (!fp_pick(c2 + c1, nlayers, widths, c)) return PN2_E_TOO_LARGE;
+    MlpCoopConfig cc;
+    if (kind == 0 ? !fp_pick(c2 + c1, nlayers, widths, c)
+                  : !(mlp_coop_pick(c2 + c1, nlayers, widths, cc) && mlp_coop_has_kernel(cc, 1))) return PN2_E_TOO_LARGE;
     const long long rows = (long long)b * n;
     if (rows == 0) return PN2_OK;
     if (!points2 || (c1 > 0 && !points1) || !idx || !dist || !wpacked || !bpacked || !out) return PN2_E_NULL;
     if ((long long)m * c2 > INT_MAX) return PN2_E_TOO_LARGE;
     const int cout = widths[nlayers - 1];
     hipStream_t st = as_stream(stream);
+    if (kind == 1) {
+        CoopParams p = {n, m, 0, c2, c1, cout, cc.ti, rows, nullptr, nullptr, points2, c1 > 0 ? points1 : nullptr, idx, dist,
+                        wpacked, bpacked, out, 0};
+        return mlp_coop_launch(cc, 1, p, st);
+    }
 #define PN2_FP_CASE(A, B, C)                                                                                           \
     if (c.t1 == A && c.t2 == B && c.t3 == C)                                                                            \
         return launch_fp<A, B, C>(c, rows, n, m, c2, c1, cout, points2, points1, idx, dist, wpacked, bpacked, out, st)

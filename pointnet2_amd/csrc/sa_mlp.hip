@@ -263,16 +263,26 @@ static int launch_mlp(int b, int n, int m, int nsample, int cfeat, int c3, const
     return PN2_OK;
 }
 
-// Which kernel runs a stack: the resident one when the input is narrow and the weights fit in LDS,
-// else the streamed one (sa_mlp_stream.hip). kind: 0 resident, 1 streamed.
-static bool mlp_choose(int cin, int c1, int c2, int c3, int nsample, int &kind, MlpConfig &rc, MlpStreamConfig &sc)
+// Which kernel runs a stack: the resident one when the input is narrow and the weights fit in LDS, the
+// streamed one (sa_mlp_stream.hip) up to widths (128,128,256), else the cooperative one (coop_mlp.hip: wide
+// stacks such as (256,256,512) and the group_all level's (256,512,1024); any nsample, masked).
+// kind: 0 resident, 1 streamed, 2 cooperative.
+static bool mlp_choose(int cin, int c1, int c2, int c3, int nsample, int &kind, MlpConfig &rc, MlpStreamConfig &sc,
+                       MlpCoopConfig &cc)
 {
-    if (cin <= 32 && mlp_pick(c1, c2, c3, rc) && sizeof(float) * (mlp_total_w(rc) + mlp_total_b(rc)) <= (size_t)kMlpMaxLds) {
+    const bool whole = nsample == 16 || (nsample > 0 && nsample % 32 == 0);
+    if (whole && cin <= 32 && mlp_pick(c1, c2, c3, rc) &&
+        sizeof(float) * (mlp_total_w(rc) + mlp_total_b(rc)) <= (size_t)kMlpMaxLds) {
         kind = 0;
         return true;
     }
-    if (nsample != 16 && mlp_stream_pick(cin, c1, c2, c3, sc)) {
+    if (whole && nsample != 16 && mlp_stream_pick(cin, c1, c2, c3, sc)) {
         kind = 1;
+        return true;
+    }
+    const int widths[3] = {c1, c2, c3};
+    if (nsample > 0 && mlp_coop_pick(cin, 3, widths, cc) && mlp_coop_has_kernel(cc, 0)) {
+        kind = 2;
         return true;
     }
     return false;
@@ -285,17 +295,20 @@ extern "C" int pn2_sa_mlp3_config(int cin, int c1, int c2, int c3, int nsample, 
 {
     using namespace pn2;
     if (cin < 3 || c1 <= 0 || c2 <= 0 || c3 <= 0) return PN2_E_ARG;
-    if (nsample != 16 && (nsample <= 0 || nsample % 32 != 0)) return PN2_E_ARG;
+    if (nsample <= 0) return PN2_E_ARG;
     int kind;
     MlpConfig rc;
     MlpStreamConfig sc;
-    if (!mlp_choose(cin, c1, c2, c3, nsample, kind, rc, sc)) return PN2_E_TOO_LARGE;
+    MlpCoopConfig cc;
+    if (!mlp_choose(cin, c1, c2, c3, nsample, kind, rc, sc, cc)) return PN2_E_TOO_LARGE;
     if (info4) {
         info4[0] = kind;
-        info4[1] = kind ? sc.t1 : rc.t1; info4[2] = kind ? sc.t2 : rc.t2; info4[3] = kind ? sc.t3 : rc.t3;
+        info4[1] = kind == 2 ? 4 * cc.q1 : kind ? sc.t1 : rc.t1;
+        info4[2] = kind == 2 ? 4 * cc.q2 : kind ? sc.t2 : rc.t2;
+        info4[3] = kind == 2 ? 4 * cc.q3 : kind ? sc.t3 : rc.t3;
     }
-    if (w_floats) *w_floats = (long long)(kind ? mlp_stream_w_floats(sc) : mlp_total_w(rc));
-    if (b_floats) *b_floats = (long long)(kind ? mlp_stream_b_floats(sc) : mlp_total_b(rc));
+    if (w_floats) *w_floats = (long long)(kind == 2 ? mlp_coop_w_floats(cc) : kind ? mlp_stream_w_floats(sc) : mlp_total_w(rc));
+    if (b_floats) *b_floats = (long long)(kind == 2 ? mlp_coop_b_floats(cc) : kind ? mlp_stream_b_floats(sc) : mlp_total_b(rc));
     return PN2_OK;
 }
 
@@ -311,11 +324,21 @@ extern "C" int pn2_sa_mlp3_pack(int cin, int c1, int c2, int c3, int nsample, in
     int kind;
     MlpConfig cfg;
     MlpStreamConfig sc;
-    if (cin < 3 || c1 <= 0 || c2 <= 0 || c3 <= 0 || !mlp_choose(cin, c1, c2, c3, nsample, kind, cfg, sc)) return PN2_E_TOO_LARGE;
+    MlpCoopConfig cc;
+    if (cin < 3 || c1 <= 0 || c2 <= 0 || c3 <= 0 || !mlp_choose(cin, c1, c2, c3, nsample, kind, cfg, sc, cc)) return PN2_E_TOO_LARGE;
     if (!w1 || !w2 || !w3 || !bias1 || !bias2 || !bias3 || !wpacked || !bpacked) return PN2_E_NULL;
     const float *ws[3] = {w1, w2, w3}, *bs[3] = {bias1, bias2, bias3};
     if (kind == 1) {
         mlp_stream_pack(sc, cin, c1, c2, c3, xyz_first, ws, bs, wpacked, bpacked);
+        return PN2_OK;
+    }
+    if (kind == 2) {
+        // kernel channel order of layer 1: [features, xyz]; caller's weight rows: [xyz, features] when xyz_first
+        const int cf = cin - 3, widths[3] = {c1, c2, c3};
+        int *krow = (int *)malloc(sizeof(int) * (size_t)cin);
+        for (int k = 0; k < cin; ++k) krow[k] = xyz_first ? (k < cf ? 3 + k : k - cf) : k;
+        mlp_coop_pack(cc, cin, 3, widths, krow, ws, bs, wpacked, bpacked);
+        free(krow);
         return PN2_OK;
     }
     const int cfeat = cin - 3;
@@ -350,15 +373,26 @@ extern "C" int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, 
 {
     using namespace pn2;
     if (b < 0 || n <= 0 || m < 0 || cfeat < 0) return PN2_E_SHAPE;
-    if (nsample != 16 && (nsample <= 0 || nsample % 32 != 0)) return PN2_E_ARG;
+    if (nsample <= 0) return PN2_E_ARG;
     if (b == 0 || m == 0) return PN2_OK;
-    if (!xyz || !new_xyz || !idx || !wpacked || !bpacked || !out || (cfeat > 0 && !points)) return PN2_E_NULL;
+    // idx == NULL and new_xyz == NULL together: the group_all level (sample_and_group_all, pointnet_util.py:59-84):
+    // m = 1, the group is the whole cloud in index order (nsample = n), no centroid subtraction
+    const bool group_all = !idx && !new_xyz;
+    if (group_all && (m != 1 || nsample != n)) return PN2_E_ARG;
+    if (!xyz || (!group_all && (!new_xyz || !idx)) || !wpacked || !bpacked || !out || (cfeat > 0 && !points)) return PN2_E_NULL;
     int kind;
     MlpConfig cfg;
     MlpStreamConfig sc;
-    if (!mlp_choose(3 + cfeat, c1, c2, c3, nsample, kind, cfg, sc)) return PN2_E_TOO_LARGE;
+    MlpCoopConfig cc;
+    if (!mlp_choose(3 + cfeat, c1, c2, c3, nsample, kind, cfg, sc, cc)) return PN2_E_TOO_LARGE;
+    if (group_all && kind != 2) return PN2_E_TOO_LARGE;           // only the cooperative kernel gathers without idx
     hipStream_t st = as_stream(stream);
     const float *pts = cfeat > 0 ? points : nullptr;
+    if (kind == 2) {
+        CoopParams p = {n, m, nsample, cfeat, 0, c3, cc.ti, (long long)b * m, xyz, new_xyz, pts, nullptr, idx, nullptr,
+                        wpacked, bpacked, out, 0};
+        return mlp_coop_launch(cc, 0, p, st);
+    }
     if (kind == 1)
         return mlp_stream_launch(sc, b, n, m, nsample, cfeat, c3, xyz, new_xyz, pts ? pts : xyz, idx, wpacked, bpacked, out, st);
 #define PN2_MLP_CASE(A, B, C) \

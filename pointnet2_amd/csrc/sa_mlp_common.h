@@ -77,4 +77,27 @@ int mlp_stream_launch(const MlpStreamConfig &c, int b, int n, int m, int nsample
                       const float *new_xyz, const float *points, const int *idx, const float *wp, const float *bp,
                       float *out, hipStream_t st);
 
+// ---- cooperative variant (coop_mlp.hip): four waves share one 32-sample item and split every layer's output
+// tiles; wide stacks over few rows (SA levels beyond (128,128,256), group_all levels, small FP levels) -------
+struct MlpCoopConfig { int ti, q1, q2, q3; };          // input tiles; output tiles PER WAVE of the layers (q3 = 0: two layers)
+struct CoopParams {
+    int n, m, nsample, cf, c1, cout, ti;              // cf: grouped feature channels (SA) / interpolated channels c2 (FP)
+    long long rows;                                   // SA: b * m centroids; FP: b * n unknown points
+    const float *xyz, *new_xyz;                       // SA (new_xyz == nullptr: group_all, no centroid)
+    const float *feat;                                // SA: points (b,n,cf); FP: points2 (b,m,cf)
+    const float *skip;                                // FP: points1 (b,n,c1) or nullptr
+    const int *idx;                                   // SA: (b,m,nsample) or nullptr (group_all); FP: (b,n,3)
+    const float *dist;                                // FP: (b,n,3)
+    const float *wp, *bp;
+    float *out;
+    int split;                                        // set by mlp_coop_launch
+};
+bool mlp_coop_pick(int cin, int nlayers, const int *widths, MlpCoopConfig &cfg);
+bool mlp_coop_has_kernel(const MlpCoopConfig &c, int fp);
+size_t mlp_coop_w_floats(const MlpCoopConfig &c);
+size_t mlp_coop_b_floats(const MlpCoopConfig &c);
+void mlp_coop_pack(const MlpCoopConfig &c, int cin, int nlayers, const int *widths, const int *krow, const float *const *ws,
+                   const float *const *bs, float *wpacked, float *bpacked);
+int mlp_coop_launch(const MlpCoopConfig &c, int fp, const CoopParams &p, hipStream_t st);
+
 }  // namespace pn2

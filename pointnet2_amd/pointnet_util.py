@@ -141,32 +141,43 @@ class PointnetSAModule(nn.Module):
 
     def _fused_ok(self, xyz, points):
         """Inference with max pooling on a layer stack pn2_sa_mlp3_maxpool covers (see sa_mlp.py)."""
-        if not self.fused_mlp or self.training or torch.is_grad_enabled() or self.group_all or self.knn:
+        if not self.fused_mlp or self.training or torch.is_grad_enabled() or self.knn:
             return False
         if self.pooling != "max" or self.mlp2 is not None or not xyz.is_cuda:
             return False
         if points is not None and not self.use_xyz:
             return False
         cin = 3 + (points.shape[2] if points is not None else 0)
+        if self.group_all:                         # only the cooperative kernel gathers a whole cloud without idx
+            return sa_mlp.supported(cin, self.mlp.widths, xyz.shape[1]) and sa_mlp.kind(cin, self.mlp.widths, xyz.shape[1]) == "cooperative"
         return sa_mlp.supported(cin, self.mlp.widths, self.nsample)
 
-    def _packed(self, device):
+    def _packed(self, device, nsample=None):
         """Folded + packed weights, rebuilt when a parameter or a running statistic changed."""
         stamp = tuple((t.data_ptr(), t._version) for t in list(self.mlp.parameters()) + list(self.mlp.buffers()))
-        if self._pack_cache is None or self._pack_cache[0] != (stamp, device):
+        nsample = nsample or self.nsample
+        if self._pack_cache is None or self._pack_cache[0] != (stamp, device, nsample):
             _no_packing_under_capture()
-            self._pack_cache = ((stamp, device), sa_mlp.PackedMLP3(self.mlp.folded_layers(), device, self.nsample, True))
+            self._pack_cache = ((stamp, device, nsample), sa_mlp.PackedMLP3(self.mlp.folded_layers(), device, nsample, True))
         return self._pack_cache[1]
 
     def prepare_fused(self, device):
         """Fold the batch norms and pack the weights for the fused kernel NOW (a host-side step with a
         device-to-host copy and an upload): call it once after loading weights / before capturing a HIP
         graph, so that forward() finds the cache warm."""
-        if sa_mlp.supported(self.mlp.net[0].in_channels, self.mlp.widths, self.nsample or 0):
+        if not self.group_all and sa_mlp.supported(self.mlp.net[0].in_channels, self.mlp.widths, self.nsample or 0):
             self._packed(device)
         return self
 
     def forward(self, xyz, points):
+        if self.group_all and self._fused_ok(xyz, points):
+            # sample_and_group_all (:59-84) + the layer stack + reduce_max in ONE kernel: new_xyz = origin, the
+            # group is the whole cloud, channels [xyz, features]
+            self.last_path = "fused"
+            b, n, _ = xyz.shape
+            new_xyz = torch.zeros((b, 1, 3), dtype=torch.float32, device=xyz.device)
+            idx = torch.arange(n, dtype=torch.int32, device=xyz.device).reshape(1, 1, n).repeat(b, 1, 1)
+            return new_xyz, sa_mlp.sa_mlp_maxpool(xyz, None, points, None, self._packed(xyz.device, n)), idx
         if self._fused_ok(xyz, points):
             # FPS + ball query in the overlapped launch, then ONE kernel from idx to the pooled features:
             # the (b, npoint, nsample, C) tensors of pointnet_util.py:44-50 and :117-127 never exist
@@ -297,39 +308,36 @@ class PointnetFPModule(nn.Module):
         self.last_path = None
         self._pack_cache = None
 
-    # Below this many unknown points per call the fused kernel's work items (32 points per wave, one serial
-    # MFMA chain each) do not fill the GPU: sem_seg FP1 (512 points, 768 -> 256 -> 256) measured 138 us fused
-    # against ~70 us layer by layer; FP3 (8192 points) 80 vs ~100; FP4 (65536 points) 72 vs 330.
-    FUSED_MIN_POINTS = 8192
-
-    def _fused_ok(self, points1, points2, npoints):
+    def _fused_kind(self, points1, points2, npoints):
+        """The fused kernel for this call (sa_mlp.fp_kind: cooperative below 16384 unknown points, streamed
+        above), or None: training, autograd, CPU tensors, or a stack no kernel covers."""
         if not self.fused_mlp or self.training or torch.is_grad_enabled() or not points2.is_cuda:
-            return False
-        if npoints < self.FUSED_MIN_POINTS:
-            return False
+            return None
         c1 = points1.shape[2] if points1 is not None else 0
-        return sa_mlp.fp_supported(points2.shape[2], c1, self.mlp.widths)
+        return sa_mlp.fp_kind(npoints, points2.shape[2], c1, self.mlp.widths)
 
-    def _packed(self, c2, c1, device):
-        stamp = (tuple((t.data_ptr(), t._version) for t in list(self.mlp.parameters()) + list(self.mlp.buffers())), device, c2, c1)
+    def _packed(self, c2, c1, kind, device):
+        stamp = (tuple((t.data_ptr(), t._version) for t in list(self.mlp.parameters()) + list(self.mlp.buffers())), device, c2, c1, kind)
         if self._pack_cache is None or self._pack_cache[0] != stamp:
             _no_packing_under_capture()
-            self._pack_cache = (stamp, sa_mlp.PackedFPMLP(self.mlp.folded_layers(), c2, c1, device))
+            self._pack_cache = (stamp, sa_mlp.PackedFPMLP(self.mlp.folded_layers(), c2, c1, device, kind))
         return self._pack_cache[1]
 
-    def prepare_fused(self, c2, c1, device):
-        """See PointnetSAModule.prepare_fused (c2 = channels of points2, c1 = channels of points1)."""
-        if sa_mlp.fp_supported(c2, c1, self.mlp.widths):
-            self._packed(c2, c1, device)
+    def prepare_fused(self, c2, c1, npoints, device):
+        """See PointnetSAModule.prepare_fused (c2 / c1 = channels of points2 / points1, npoints = b * n unknown points)."""
+        kind = sa_mlp.fp_kind(npoints, c2, c1, self.mlp.widths)
+        if kind is not None:
+            self._packed(c2, c1, kind, device)
         return self
 
     def forward(self, xyz1, xyz2, points1, points2):
-        if self._fused_ok(points1, points2, xyz1.shape[0] * xyz1.shape[1]):
+        kind = self._fused_kind(points1, points2, xyz1.shape[0] * xyz1.shape[1])
+        if kind is not None:
             # three_nn, then ONE kernel: weights, interpolation, concatenation and the layer stack (:212-226)
             self.last_path = "fused"
             dist, idx = three_nn(xyz1, xyz2)                                    # :211
             c1 = points1.shape[2] if points1 is not None else 0
-            return sa_mlp.fp_mlp(points2, points1, idx, dist, self._packed(points2.shape[2], c1, points2.device))
+            return sa_mlp.fp_mlp(points2, points1, idx, dist, self._packed(points2.shape[2], c1, kind, points2.device))
         self.last_path = "unfused"
         idx, weight = three_nn_weights(xyz1, xyz2)                              # :211-215
         interpolated = three_interpolate(points2, idx, weight)                  # :216

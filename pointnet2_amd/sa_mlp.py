@@ -28,10 +28,19 @@ def fold_batch_norm(conv_weight, conv_bias, bn=None):
 
 def supported(cin, widths, nsample):
     """Can pn2_sa_mlp3_maxpool run this layer stack? (host-only check, needs the built library)"""
-    if len(widths) != 3 or cin < 3 or not (nsample == 16 or (nsample > 0 and nsample % 32 == 0)):
+    if len(widths) != 3 or cin < 3 or nsample is None or nsample <= 0:
         return False
     return _C.lib().pn2_sa_mlp3_config(int(cin), int(widths[0]), int(widths[1]), int(widths[2]), int(nsample), None, None,
                                        None) == 0
+
+
+def kind(cin, widths, nsample):
+    """'resident' / 'streamed' / 'cooperative': the kernel pn2_sa_mlp3_config chooses, or None."""
+    info = (ctypes.c_int * 4)()
+    if len(widths) != 3 or _C.lib().pn2_sa_mlp3_config(int(cin), int(widths[0]), int(widths[1]), int(widths[2]), int(nsample), info,
+                                                        None, None) != 0:
+        return None
+    return ("resident", "streamed", "cooperative")[info[0]]
 
 
 class PackedMLP3:
@@ -53,7 +62,7 @@ class PackedMLP3:
         info = (ctypes.c_int * 4)()
         _C.check(lib.pn2_sa_mlp3_config(self.cin, *self.widths, self.nsample, info, ctypes.byref(wf), ctypes.byref(bf)),
                  "sa_mlp3_config")
-        self.kind = "streamed" if info[0] else "resident"
+        self.kind = ("resident", "streamed", "cooperative")[info[0]]
         wp = np.empty(wf.value, np.float32)
         bp = np.empty(bf.value, np.float32)
         _C.check(lib.pn2_sa_mlp3_pack(self.cin, *self.widths, self.nsample, 1 if xyz_first else 0, ws[0].ctypes.data,
@@ -69,15 +78,21 @@ def _same_kernel(packed, ns):
     info = (ctypes.c_int * 4)()
     if _C.lib().pn2_sa_mlp3_config(packed.cin, *packed.widths, int(ns), info, None, None) != 0:
         return False
-    return ("streamed" if info[0] else "resident") == packed.kind
+    return ("resident", "streamed", "cooperative")[info[0]] == packed.kind
 
 
 def sa_mlp_maxpool(xyz, new_xyz, points, idx, packed):
     """xyz (b,n,3), new_xyz (b,m,3), points (b,n,c) or None, idx (b,m,nsample) i32, packed: PackedMLP3
-    -> (b, m, c3) f32 = max over nsample of the three-layer MLP of [xyz[idx]-new_xyz, points[idx]]."""
-    xyz, new_xyz, idx = f32(xyz.detach(), "xyz"), f32(new_xyz.detach(), "new_xyz"), i32(idx, "idx")
+    -> (b, m, c3) f32 = max over nsample of the three-layer MLP of [xyz[idx]-new_xyz, points[idx]].
+    new_xyz is None and idx is None: the group_all level (sample_and_group_all, pointnet_util.py:59-84) ->
+    (b, 1, c3) = max over all n points of the MLP of [xyz, points] (no centroid)."""
+    xyz = f32(xyz.detach(), "xyz")
     b, n, _ = xyz.shape
-    m, ns = idx.shape[1], idx.shape[2]
+    if idx is None and new_xyz is None:
+        m, ns = 1, n
+    else:
+        new_xyz, idx = f32(new_xyz.detach(), "new_xyz"), i32(idx, "idx")
+        m, ns = idx.shape[1], idx.shape[2]
     cfeat = 0
     if points is not None:
         points = f32(points.detach(), "points")
@@ -88,7 +103,8 @@ def sa_mlp_maxpool(xyz, new_xyz, points, idx, packed):
     require(ns == packed.nsample or _same_kernel(packed, ns),
             "weights were packed for nsample=%d (%s kernel); nsample=%d needs a different layout"
             % (packed.nsample, packed.kind, ns))
-    dev = same_device(xyz, new_xyz, idx, packed.wp) if points is None else same_device(xyz, new_xyz, idx, points, packed.wp)
+    tensors = [t for t in (xyz, new_xyz, idx, points, packed.wp) if t is not None]
+    dev = same_device(*tensors)
     out = torch.empty((b, m, packed.widths[2]), dtype=torch.float32, device=dev)
     with on_device(dev):
         _C.check(_C.lib().pn2_sa_mlp3_maxpool(b, n, m, ns, cfeat, ptr(xyz), ptr(new_xyz), ptr(points), ptr(idx),
@@ -97,40 +113,55 @@ def sa_mlp_maxpool(xyz, new_xyz, points, idx, packed):
     return out
 
 
-# ---- feature propagation: three_nn weights + three_interpolate + concat + MLP in one kernel (csrc/fp_mlp.hip) ----
-def fp_supported(c2, c1, widths):
-    """Can pn2_fp_mlp run this feature-propagation stack? (host-only check)"""
+# ---- feature propagation: three_nn weights + three_interpolate + concat + MLP in one kernel ------------------
+# Two kernels (include/pn2ops.h, pn2_fp_mlp `kind`): 0 = one wave per 32 points with the weights streamed through
+# LDS (csrc/fp_mlp.hip; many points), 1 = four waves per 32 points (csrc/coop_mlp.hip; few points, wide layers).
+FP_COOP_MAX_POINTS = 16384        # below this many unknown points the cooperative kernel fills the GPU better
+
+
+def fp_kind(npoints, c2, c1, widths):
+    """The kernel to use for a level with `npoints` unknown points, or None when no fused kernel covers it."""
     widths = [int(w) for w in widths]
     if len(widths) not in (2, 3) or c2 <= 0 or c1 < 0:
-        return False
+        return None
     arr = (ctypes.c_int * len(widths))(*widths)
-    return _C.lib().pn2_fp_mlp_config(int(c2), int(c1), len(widths), arr, None, None, None) == 0
+    order = (1, 0) if npoints <= FP_COOP_MAX_POINTS else (0, 1)
+    for kind in order:
+        if _C.lib().pn2_fp_mlp_config(int(c2), int(c1), len(widths), arr, kind, None, None, None) == 0:
+            return kind
+    return None
+
+
+def fp_supported(c2, c1, widths, npoints=1 << 30):
+    return fp_kind(npoints, c2, c1, widths) is not None
 
 
 class PackedFPMLP:
-    """Two or three folded layers [(W (cin, cout), b (cout))] of a feature-propagation module in the order
-    pn2_fp_mlp consumes them; rows of the first W in the reference's concat order [interpolated (c2),
-    points1 (c1)] (pointnet_util.py:219)."""
+    """Two or three folded layers [(W (cin, cout), b (cout))] of a feature-propagation module in the order the
+    chosen pn2_fp_mlp kernel consumes them; rows of the first W in the reference's concat order
+    [interpolated (c2), points1 (c1)] (pointnet_util.py:219)."""
 
-    def __init__(self, layers, c2, c1, device):
+    def __init__(self, layers, c2, c1, device, kind=0):
         require(len(layers) in (2, 3), "pn2_fp_mlp takes two or three layers")
         ws = [np.ascontiguousarray(w, dtype=np.float32) for w, _ in layers]
         bs = [np.ascontiguousarray(b, dtype=np.float32) for _, b in layers]
         require(ws[0].shape[0] == c2 + c1, "first layer expects %d input channels, got %d" % (ws[0].shape[0], c2 + c1))
         for i in range(1, len(ws)):
             require(ws[i].shape[0] == ws[i - 1].shape[1], "layer shapes do not chain")
-        self.c2, self.c1 = int(c2), int(c1)
+        self.c2, self.c1, self.kind = int(c2), int(c1), int(kind)
         self.widths = [int(w.shape[1]) for w in ws]
         lib = _C.lib()
         n = len(ws)
         self._warr = (ctypes.c_int * n)(*self.widths)
         wf, bf = ctypes.c_longlong(), ctypes.c_longlong()
-        _C.check(lib.pn2_fp_mlp_config(self.c2, self.c1, n, self._warr, None, ctypes.byref(wf), ctypes.byref(bf)), "fp_mlp_config")
+        _C.check(lib.pn2_fp_mlp_config(self.c2, self.c1, n, self._warr, self.kind, None, ctypes.byref(wf), ctypes.byref(bf)),
+                 "fp_mlp_config")
         wp = np.empty(wf.value, np.float32)
         bp = np.empty(bf.value, np.float32)
         wptr = (ctypes.c_void_p * n)(*[w.ctypes.data for w in ws])
         bptr = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bs])
-        _C.check(lib.pn2_fp_mlp_pack(self.c2, self.c1, n, self._warr, wptr, bptr, wp.ctypes.data, bp.ctypes.data), "fp_mlp_pack")
+        _C.check(lib.pn2_fp_mlp_pack(self.c2, self.c1, n, self._warr, self.kind, wptr, bptr, wp.ctypes.data, bp.ctypes.data),
+                 "fp_mlp_pack")
         self.wp = torch.from_numpy(wp).to(device)
         self.bp = torch.from_numpy(bp).to(device)
 
@@ -151,5 +182,6 @@ def fp_mlp(points2, points1, idx, dist, packed):
     out = torch.empty((b, n, packed.widths[-1]), dtype=torch.float32, device=dev)
     with on_device(dev):
         _C.check(_C.lib().pn2_fp_mlp(b, n, m, c2, c1, ptr(points2), ptr(points1), ptr(idx), ptr(dist), len(packed.widths),
-                                     packed._warr, ptr(packed.wp), ptr(packed.bp), ptr(out), stream_ptr(dev)), "fp_mlp")
+                                     packed._warr, packed.kind, ptr(packed.wp), ptr(packed.bp), ptr(out), stream_ptr(dev)),
+                 "fp_mlp")
     return out

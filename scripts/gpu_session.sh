@@ -16,7 +16,7 @@ for step in "$@"; do
     prof_bq)   (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bq" -- python $ROOT/scripts/bq_probe.py msg > "$OUT/prof_bq.log" 2>&1); find "$OUT/prof_bq" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_bq_msg.csv" \;; rm -rf "$OUT/prof_bq"; cut -d, -f1-8 "$OUT/kernel_stats_bq_msg.csv" | head -30 ;;
     bw)        timeout 300 python scripts/bw_probe.py > "$OUT/bw_probe.log" 2>&1; cat "$OUT/bw_probe.log" ;;
     bq)        timeout 300 python scripts/bq_probe.py > "$OUT/bq_probe.log" 2>&1; cat "$OUT/bq_probe.log" ;;
-    tests_fp)  timeout 600 python -m pytest tests/test_fp_mlp_gpu.py tests/test_modules_gpu.py tests/test_graph_capture_gpu.py -m gpu -q > "$OUT/tests_fp.log" 2>&1; tail -15 "$OUT/tests_fp.log" ;;
+    tests_fp)  timeout 600 python -m pytest tests/test_fp_mlp_gpu.py tests/test_sa_mlp_gpu.py tests/test_modules_gpu.py tests/test_graph_capture_gpu.py -m gpu -q > "$OUT/tests_fp.log" 2>&1; tail -15 "$OUT/tests_fp.log" ;;
     models)    timeout 600 python scripts/model_forward_bench.py > "$OUT/model_forward.log" 2>&1; cat "$OUT/model_forward.log" ;;
     prof_model) (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_model" -- python $ROOT/scripts/model_forward_bench.py ${MODEL:-sem_seg} > "$OUT/prof_model.log" 2>&1); find "$OUT/prof_model" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_model_${MODEL:-sem_seg}.csv" \;; rm -rf "$OUT/prof_model"; head -30 "$OUT/kernel_stats_model_${MODEL:-sem_seg}.csv" | cut -c1-150 ;;
     bench)     timeout 600 python bench.py > "$OUT/bench.log" 2>&1; tail -3 "$OUT/bench.log" ;;

@@ -33,8 +33,9 @@ def _layers(rng, cin, widths):
     return out
 
 
+@pytest.mark.parametrize("kind", [0, 1], ids=["streamed", "cooperative"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_fp_mlp_matches_float64(cuda, oracle, case):
+def test_fp_mlp_matches_float64(cuda, oracle, case, kind):
     import pointnet2_amd as P
     from pointnet2_amd import sa_mlp
     label, b, n, m, c2, c1, widths = case
@@ -45,9 +46,14 @@ def test_fp_mlp_matches_float64(cuda, oracle, case):
     p1 = rng.standard_normal((b, n, c1)).astype(np.float32) if c1 else None
     layers = _layers(rng, c2 + c1, widths)
     assert sa_mlp.fp_supported(c2, c1, widths)
+    import ctypes
+    from pointnet2_amd import _C
+    warr = (ctypes.c_int * len(widths))(*widths)
+    if _C.lib().pn2_fp_mlp_config(c2, c1, len(widths), warr, kind, None, None, None) != 0:
+        pytest.skip("no %s kernel for this stack" % ("cooperative" if kind else "streamed"))
 
     dist, idx = P.three_nn(torch.from_numpy(unknown).to(cuda), torch.from_numpy(known).to(cuda))
-    packed = sa_mlp.PackedFPMLP(layers, c2, c1, cuda)
+    packed = sa_mlp.PackedFPMLP(layers, c2, c1, cuda, kind)
     got = sa_mlp.fp_mlp(torch.from_numpy(p2).to(cuda), torch.from_numpy(p1).to(cuda) if c1 else None, idx, dist, packed)
     got = got.cpu().numpy()
 
@@ -73,7 +79,6 @@ def test_fp_module_fused_equals_unfused(cuda):
     torch.manual_seed(0)
     b, n, m, c2, c1 = 4, 300, 70, 64, 32
     mod = PointnetFPModule(c2 + c1, [128, 64]).to(cuda)
-    mod.FUSED_MIN_POINTS = 0                                       # small test shape: force the fused kernel
     for bn in [x for x in mod.modules() if isinstance(x, torch.nn.BatchNorm2d)]:
         bn.running_mean.normal_(0, 0.2)
         bn.running_var.uniform_(0.5, 2.0)

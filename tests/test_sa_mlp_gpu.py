@@ -144,3 +144,80 @@ def test_fused_mlp_many_rows_and_repeatable(cuda, cfeat, widths, ns):
     assert all(torch.equal(outs[0], o) for o in outs[1:])
     want = _reference(xyz, new_xyz, points, idx, layers)
     assert (outs[0].double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
+# ---- cooperative kernel (csrc/coop_mlp.hip): wide stacks, any nsample, the group_all level -----------------------
+COOP_CASES = [
+    # (label, b, n, m, radius, nsample, cfeat, widths)
+    ("sem_seg SA4", 8, 64, 16, 0.8, 32, 256, (256, 256, 512)),         # models/pointnet2_sem_seg.py:31
+    ("wide, nsample 40 (masked tail)", 2, 512, 33, 0.4, 40, 61, (200, 256, 500)),
+    ("(128,128,256) at nsample 16", 3, 1024, 50, 0.3, 16, 128, (128, 128, 256)),
+    ("(128,128,256) at nsample 48", 2, 700, 41, 0.3, 48, 3, (100, 128, 256)),
+    ("xyz only, wide", 2, 600, 20, 0.5, 64, 0, (256, 256, 512)),
+]
+
+
+@pytest.mark.parametrize("case", COOP_CASES, ids=[c[0] for c in COOP_CASES])
+def test_cooperative_kernel_matches_float64(cuda, case):
+    import pointnet2_amd as P
+    from pointnet2_amd import sa_mlp
+    label, b, n, m, r, ns, cfeat, widths = case
+    rng = np.random.default_rng(len(label))
+    xyz = torch.from_numpy(S.sphere_clouds(b, n, 5)).to(cuda)
+    new_xyz = P.gather_point(xyz, P.farthest_point_sample(m, xyz))
+    idx, _ = P.query_ball_point(r, ns, xyz, new_xyz)
+    points = torch.from_numpy(rng.standard_normal((b, n, cfeat)).astype(np.float32)).to(cuda) if cfeat else None
+    dims = (3 + cfeat,) + tuple(widths)
+    layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
+               (0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32)) for i in range(3)]
+    assert sa_mlp.kind(dims[0], widths, ns) == "cooperative"
+    for xyz_first in (True, False):
+        packed = sa_mlp.PackedMLP3(layers, cuda, ns, xyz_first=xyz_first)
+        got = sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, packed)
+        ref_layers = layers
+        if not xyz_first:                                  # rows given as [features, xyz]: move them for the reference
+            w1 = np.concatenate([layers[0][0][cfeat:], layers[0][0][:cfeat]], axis=0)
+            ref_layers = [(w1, layers[0][1])] + layers[1:]
+        want = _reference(xyz, new_xyz, points, idx, ref_layers)
+        assert got.shape == (b, m, widths[2])
+        assert (got.double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item()), (label, xyz_first)
+
+
+@pytest.mark.parametrize("b,n,cfeat", [(32, 128, 256), (4, 128, 640), (3, 100, 256), (2, 33, 5)],
+                         ids=["cls_ssg L3", "cls_msg L3", "n=100 (masked)", "n=33"])
+def test_group_all_level_fused(cuda, b, n, cfeat):
+    """sample_and_group_all + [256,512,1024] + reduce_max in one kernel (pointnet2_cls_ssg.py:34, pointnet_util.py:59-84):
+    the group is the whole cloud in index order, channels [xyz, features], no centroid subtraction."""
+    from pointnet2_amd import sa_mlp
+    rng = np.random.default_rng(n)
+    widths = (256, 512, 1024)
+    xyz = torch.from_numpy(S.sphere_clouds(b, n, 6)).to(cuda)
+    points = torch.from_numpy(rng.standard_normal((b, n, cfeat)).astype(np.float32)).to(cuda)
+    dims = (3 + cfeat,) + widths
+    layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
+               (0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32)) for i in range(3)]
+    got = sa_mlp.sa_mlp_maxpool(xyz, None, points, None, sa_mlp.PackedMLP3(layers, cuda, n, xyz_first=True))
+    x = torch.cat([xyz, points], dim=2).double()
+    for w, bias in layers:
+        x = torch.relu(x @ torch.from_numpy(w).double().to(cuda) + torch.from_numpy(bias).double().to(cuda))
+    want = x.max(dim=1, keepdim=True).values
+    assert got.shape == (b, 1, 1024)
+    assert (got.double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_group_all_module_takes_the_fused_kernel(cuda):
+    import pointnet2_amd.pointnet_util as U
+    torch.manual_seed(1)
+    mod = U.PointnetSAModule(256, None, None, None, [256, 512, 1024], group_all=True).to(cuda).eval()
+    for bn in [x for x in mod.modules() if isinstance(x, torch.nn.BatchNorm2d)]:
+        bn.running_mean.normal_(0, 0.2)
+        bn.running_var.uniform_(0.5, 2.0)
+    xyz = torch.from_numpy(S.sphere_clouds(6, 128, 3)).to(cuda)
+    feats = torch.randn(6, 128, 256, device=cuda)
+    with torch.no_grad():
+        nx, out, _ = mod(xyz, feats)
+        assert mod.last_path == "fused" and out.shape == (6, 1, 1024) and torch.all(nx == 0)
+        mod.fused_mlp = False
+        _, ref, _ = mod(xyz, feats)
+        assert mod.last_path == "unfused"
+    assert (out - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())

@@ -102,8 +102,12 @@ def test_config_limits():
     assert lib.pn2_sa_mlp3_config(3, 64, 64, 128, 32, info, None, None) == 0 and info[0] == 0
     assert lib.pn2_sa_mlp3_config(67, 64, 64, 128, 32, info, None, None) == 0 and info[0] == 1    # wide input: streamed
     assert lib.pn2_sa_mlp3_config(131, 128, 128, 256, 64, info, None, None) == 0 and list(info) == [1, 4, 4, 8]
-    assert lib.pn2_sa_mlp3_config(131, 128, 128, 256, 16, info, None, None) != 0   # streamed kernel: nsample % 32
-    assert lib.pn2_sa_mlp3_config(259, 256, 256, 512, 32, info, None, None) != 0   # SA4-sized: unfused path
+    # nsample not a multiple of 32 / wide stacks: the cooperative kernel (masked tail, output tiles split over the waves)
+    assert lib.pn2_sa_mlp3_config(131, 128, 128, 256, 16, info, None, None) == 0 and list(info) == [2, 4, 4, 8]
+    assert lib.pn2_sa_mlp3_config(259, 256, 256, 512, 32, info, None, None) == 0 and list(info) == [2, 8, 8, 16]   # sem_seg SA4
+    assert lib.pn2_sa_mlp3_config(259, 256, 512, 1024, 128, info, None, None) == 0 and list(info) == [2, 8, 16, 32]  # group_all
+    assert lib.pn2_sa_mlp3_config(643, 256, 512, 1024, 100, info, None, None) == 0 and info[0] == 2                 # any nsample
+    assert lib.pn2_sa_mlp3_config(259, 512, 512, 1024, 32, info, None, None) != 0   # hidden layers beyond the LDS exchange
     assert lib.pn2_sa_mlp3_config(2, 64, 64, 128, 32, info, None, None) != 0
     assert lib.pn2_sa_mlp3_config(3, 64, 64, 128, 48, info, None, None) != 0
 
