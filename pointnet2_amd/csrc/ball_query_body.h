@@ -307,7 +307,9 @@ constexpr int kBqTabInts = kBqCellsMax + 4;                         // tab[0] = 
 __host__ __device__ __forceinline__ size_t bq_cells_wave_bytes(int n, int nsample, int lpq)
 {
     const size_t nwin = ((size_t)n + 4095) / 4096;
-    return (size_t)(64 / lpq) * (nwin * 512 + sizeof(int) * (size_t)nsample);
+    const size_t g = (size_t)(64 / lpq);
+    // per wave: G bitmaps, G row buffers (padded to 16 bytes together), G emit headers (float4)
+    return g * nwin * 512 + sizeof(int) * ((g * (size_t)nsample + 3) & ~(size_t)3) + g * 16;
 }
 __host__ __device__ __forceinline__ size_t bq_cells_lds_bytes(int n, int nsample, int lpq, int nthreads)
 {
@@ -511,7 +513,11 @@ __device__ __forceinline__ void bq_cells_query_loop(int n, int m, int nsample, f
     if (wave_stride == 0) wave_stride = bq_cells_wave_bytes(n, nsample, LPQ);
     unsigned *bm = reinterpret_cast<unsigned *>(wave_area + (size_t)w * wave_stride);
     unsigned *bmq = bm + grp * gwords;
-    int *rowbuf = reinterpret_cast<int *>(bm + G * gwords) + grp * nsample;
+    int *rowflat = reinterpret_cast<int *>(bm + G * gwords);      // the wave's G row buffers, back to back
+    int *rowbuf = rowflat + grp * nsample;
+    float4 *qhdr = reinterpret_cast<float4 *>(rowflat + ((G * nsample + 3) & ~3));   // per query: centroid + hit count (flat emit)
+    const bool pow2 = (nsample & (nsample - 1)) == 0;
+    const int lg = 31 - __builtin_clz((unsigned)nsample);
     for (int i = lane; i < G * gwords; i += 64) bm[i] = 0u;
     // |q| beyond this and q -/+ reach may round past an in-ball point: such queries visit everything
     const float lim = radius * 4096.0f;
@@ -655,7 +661,31 @@ __device__ __forceinline__ void bq_cells_query_loop(int n, int m, int nsample, f
         }
         const int cnt = min(done, nsample);
         asm volatile("" ::: "memory");
-        if (qvalid) {
+        if (pow2) {
+            // FLAT emit: the wave's G queries are consecutive rows, so their idx / grouped rows are ONE contiguous
+            // block of G * nsample entries. Lane e handles entry e: every store instruction of the wave writes
+            // 256 (idx) / 768 (grouped) contiguous bytes, whatever nsample is -- the per-query form below has
+            // each group of LPQ lanes write its own 4 * LPQ-byte piece of a different row.
+            if (sub == 0) qhdr[grp] = make_float4(qx, qy, qz, __int_as_float(cnt));
+            asm volatile("" ::: "memory");
+            const int nvalid = min(G, q1 - jb);                      // valid queries are a prefix of the wave's G
+            const size_t row0 = (size_t)bi * m + jb;
+            const int total = nvalid << lg;
+            for (int e = lane; e < total; e += 64) {
+                const int gq = e >> lg, l = e & (nsample - 1);
+                const float4 hd = qhdr[gq];
+                const int c = __float_as_int(hd.w);
+                const int v = (l < c) ? rowflat[e] : (c > 0 ? rowflat[gq << lg] : 0);   // pad with the first hit; zeros when empty
+                if (idx) idx[row0 * nsample + e] = v;
+                if (FUSE && grouped) {
+                    float gx = data[(size_t)v * 3 + 0], gy = data[(size_t)v * 3 + 1], gz = data[(size_t)v * 3 + 2];
+                    if (subtract) { gx = __fsub_rn(gx, hd.x); gy = __fsub_rn(gy, hd.y); gz = __fsub_rn(gz, hd.z); }
+                    float *o = grouped + (row0 * nsample + e) * 3;
+                    o[0] = gx; o[1] = gy; o[2] = gz;
+                }
+            }
+            if (pts_cnt && lane < nvalid) pts_cnt[row0 + lane] = __float_as_int(qhdr[lane].w);
+        } else if (qvalid) {
             const int first = cnt > 0 ? rowbuf[0] : 0;           // the first hit pads the row; zeros when empty
             for (int l = sub; l < nsample; l += LPQ) {
                 const int v = (l < cnt) ? rowbuf[l] : first;

@@ -17,6 +17,7 @@
 #include "ball_query_body.h"
 
 #include <limits.h>
+#include <math.h>
 
 namespace pn2 {
 
@@ -24,18 +25,19 @@ constexpr int kBqMaxScales = 4;
 
 struct BqScale {
     float thr, radius;
-    int nsample;
+    int nsample, lpq;                     // lanes per query of this radius' pass (as many queries per wave as the LDS holds)
     int *idx, *cnt;
     float *grouped;
 };
 struct BqScales {
     int count;
+    float bin_radius;                     // the cell list is built for this radius (see pn2_query_ball_group_xyz_msg)
     BqScale s[kBqMaxScales];
 };
 
-template <int NT, int LPQ>
+template <int NT>
 __global__ __launch_bounds__(NT, NT / 256) void ball_query_msg_kernel(int b, int n, int m, int qpb, int parts,
-                                                                    int use_cells, int max_ns, BqScales sc,
+                                                                    int use_cells, int max_ns, int wave_stride_b, BqScales sc,
                                                                     const float *__restrict__ xyz1,
                                                                     const float *__restrict__ xyz2, int subtract)
 {
@@ -49,23 +51,26 @@ __global__ __launch_bounds__(NT, NT / 256) void ball_query_msg_kernel(int b, int
     float4 *sorted = reinterpret_cast<float4 *>(smem);
     int *tab = reinterpret_cast<int *>(smem + sizeof(float4) * (size_t)n);
     char *wave_area = reinterpret_cast<char *>(tab + kBqTabInts);
-    const size_t wave_stride = bq_cells_wave_bytes(n, max_ns, LPQ);
+    const size_t wave_stride = (size_t)wave_stride_b;             // largest per-wave area over the radii
     float *misc = reinterpret_cast<float *>(wave_area + (size_t)(NT / 64) * wave_stride);
 
     bool cells = false;
     BqGrid g;
     if (use_cells) {                                             // block-uniform
-        float rmin = sc.s[0].radius;
-        for (int i = 1; i < sc.count; ++i) rmin = fminf(rmin, sc.s[i].radius);
         if (threadIdx.x == 0) tab[0] = 0;
-        cells = bq_build_grid<NT>(n, rmin * 1.001f, data, sorted, tab + 1, misc, g);
+        cells = bq_build_grid<NT>(n, sc.bin_radius * 1.001f, data, sorted, tab + 1, misc, g);
     }
     if (cells) {
         for (int i = 0; i < sc.count; ++i) {
             const BqScale &s = sc.s[i];
-            bq_cells_query_loop<NT, LPQ, true, false>(n, m, s.nsample, s.thr, s.radius, s.radius * 1.001f, cloud, q0, q1, g,
-                                                     data, xyz2, nullptr, nullptr, s.idx, s.cnt, s.grouped, subtract, sorted,
-                                                     tab, wave_area, wave_stride);
+#define PN2_MSG_LOOP(LPQ)                                                                                           \
+    bq_cells_query_loop<NT, LPQ, true, false>(n, m, s.nsample, s.thr, s.radius, s.radius * 1.001f, cloud, q0, q1, g, data, \
+                                              xyz2, nullptr, nullptr, s.idx, s.cnt, s.grouped, subtract, sorted, tab,  \
+                                              wave_area, wave_stride)
+            if (s.lpq == 8) PN2_MSG_LOOP(8);                      // block-uniform
+            else if (s.lpq == 16) PN2_MSG_LOOP(16);
+            else PN2_MSG_LOOP(32);
+#undef PN2_MSG_LOOP
         }
         return;
     }
@@ -89,33 +94,59 @@ __global__ __launch_bounds__(NT, NT / 256) void ball_query_msg_kernel(int b, int
     }
 }
 
-static size_t msg_lds_bytes(int n, int max_ns, int lpq, int nthreads)
+static size_t msg_sweep_bytes(int n, int max_ns, int nthreads)
 {
-    const size_t cells = sizeof(float4) * (size_t)n + sizeof(int) * (size_t)kBqTabInts +
-                         (size_t)(nthreads / 64) * bq_cells_wave_bytes(n, max_ns, lpq) + kBqMiscBytes;
-    const size_t sweep = sizeof(float4) * (size_t)((n + 127) & ~127) +
-                         sizeof(int) * (size_t)max_ns * (nthreads / 64) * kBqQpw;
-    return cells > sweep ? cells : sweep;
+    return sizeof(float4) * (size_t)((n + 127) & ~127) + sizeof(int) * (size_t)max_ns * (nthreads / 64) * kBqQpw;
 }
 
-template <int NT, int LPQ>
-static int launch_msg(int b, int n, int m, int use_cells, int max_ns, const BqScales &sc, const float *xyz1,
-                      const float *xyz2, int subtract, hipStream_t st)
+// Queries per workgroup: about one workgroup per CU when the cloud is binned (the binning pass is per
+// workgroup), two for the sweep; a multiple of the smallest trip (two queries per wave).
+static int msg_qpb(int b, int m, int nthreads, int use_cells)
 {
-    // queries per workgroup trip: the cell-list loop carries 64 / LPQ queries per wave, the sweep two
-    const int kGran = (NT / 64) * (use_cells ? 64 / LPQ : kBqQpw);
+    const int gran = (nthreads / 64) * kBqQpw;
     const long long total = (long long)b * m;
-    // about one workgroup per CU when the cloud is binned (the binning pass is per workgroup); the sweep
-    // stages cheaply and wants two
     int qpb = (int)((total + (use_cells ? 255 : 511)) / (use_cells ? 256 : 512));
-    qpb = ((qpb + kGran - 1) / kGran) * kGran;
-    if (qpb > m) qpb = ((m + kGran - 1) / kGran) * kGran;
+    qpb = ((qpb + gran - 1) / gran) * gran;
+    if (qpb > m) qpb = ((m + gran - 1) / gran) * gran;
+    return qpb;
+}
+
+// Lanes per query for every radius: the smallest of {8, 16, 32} (most queries per wave) that (1) fits the LDS
+// left beside the sorted cloud and the cell table, (2) does not carry more queries per workgroup trip than the
+// workgroup owns (waves * 64 / lpq <= qpb: otherwise waves idle), and (3) is at least 16 for a radius beyond
+// the binning radius (long "wide" runs). Returns the per-wave stride, 0 if nothing fits.
+static size_t msg_pick_lpq(int n, int nthreads, size_t cap, int qpb, BqScales &sc)
+{
+    const size_t fixed = sizeof(float4) * (size_t)n + sizeof(int) * (size_t)kBqTabInts + kBqMiscBytes;
+    if (fixed >= cap) return 0;
+    const size_t budget = (cap - fixed) / (size_t)(nthreads / 64);
+    size_t stride = 0;
+    for (int i = 0; i < sc.count; ++i) {
+        int lpq_min = sc.s[i].radius > sc.bin_radius * 1.01f ? 16 : 8;
+        while (lpq_min < 32 && (nthreads / 64) * (64 / lpq_min) > qpb) lpq_min *= 2;
+        int lpq = 0;
+        for (int cand : {8, 16, 32})
+            if (cand >= lpq_min && bq_cells_wave_bytes(n, sc.s[i].nsample, cand) <= budget) { lpq = cand; break; }
+        if (!lpq) return 0;
+        sc.s[i].lpq = lpq;
+        const size_t bytes = bq_cells_wave_bytes(n, sc.s[i].nsample, lpq);
+        stride = bytes > stride ? bytes : stride;
+    }
+    return stride;
+}
+
+template <int NT>
+static int launch_msg(int b, int n, int m, int use_cells, int max_ns, int qpb, size_t wave_stride, const BqScales &sc,
+                      const float *xyz1, const float *xyz2, int subtract, hipStream_t st)
+{
     const int parts = (m + qpb - 1) / qpb;
-    const size_t lds = msg_lds_bytes(n, max_ns, LPQ, NT);
-    auto kern = ball_query_msg_kernel<NT, LPQ>;
+    const size_t cells = sizeof(float4) * (size_t)n + sizeof(int) * (size_t)kBqTabInts + (size_t)(NT / 64) * wave_stride + kBqMiscBytes;
+    const size_t sweep = msg_sweep_bytes(n, max_ns, NT);
+    const size_t lds = cells > sweep ? cells : sweep;
+    auto kern = ball_query_msg_kernel<NT>;
     if (int rc = allow_dynamic_lds(kern, lds)) return rc;
-    return launch(kern, dim3((unsigned)parts * b), dim3(NT), lds, st, b, n, m, qpb, parts, use_cells, max_ns, sc, xyz1,
-                  xyz2, subtract);
+    return launch(kern, dim3((unsigned)parts * b), dim3(NT), lds, st, b, n, m, qpb, parts, use_cells, max_ns, (int)wave_stride, sc,
+                  xyz1, xyz2, subtract);
 }
 
 }  // namespace pn2
@@ -133,11 +164,23 @@ extern "C" int pn2_query_ball_group_xyz_msg(int b, int n, int m, int nscales, co
     sc.count = nscales;
     int max_ns = 0;
     for (int i = 0; i < nscales; ++i) {
-        sc.s[i] = {pn2_ball_threshold(radii[i]), radii[i], nsamples[i], idx ? idx[i] : nullptr,
+        sc.s[i] = {pn2_ball_threshold(radii[i]), radii[i], nsamples[i], 8, idx ? idx[i] : nullptr,
                    pts_cnt ? pts_cnt[i] : nullptr, grouped_xyz ? grouped_xyz[i] : nullptr};
         if (!sc.s[i].idx && !sc.s[i].grouped) return PN2_E_NULL;
         max_ns = nsamples[i] > max_ns ? nsamples[i] : max_ns;
         if ((long long)b * m * nsamples[i] * 3 > (1ll << 40)) return PN2_E_TOO_LARGE;
+    }
+    // Cell size: the SECOND smallest radius when there are three or more (else the smallest). Cells sized for
+    // the smallest radius make every larger radius walk "wide" runs (whole y-ranges of a z-slab, every x): at
+    // pointnet2_cls_msg.py:27's (0.1, 0.2, 0.4) binning at 0.2 keeps the 0.1 and 0.2 passes on <= 3 x 3 short
+    // runs and only the 0.4 pass wide (measured: 91 us binned at 0.1 with 8 lanes per query, 56 at 0.1 with 16).
+    {
+        float r1 = radii[0], r2 = INFINITY;                      // smallest, second smallest
+        for (int i = 1; i < nscales; ++i) {
+            if (radii[i] < r1) { r2 = r1; r1 = radii[i]; }
+            else if (radii[i] < r2) r2 = radii[i];
+        }
+        sc.bin_radius = (nscales >= 3) ? r2 : r1;
     }
     if (b == 0 || m == 0) return PN2_OK;
     if (!xyz1 || !xyz2) return PN2_E_NULL;
@@ -146,20 +189,16 @@ extern "C" int pn2_query_ball_group_xyz_msg(int b, int n, int m, int nscales, co
     // the binning pass is amortised over every radius of the level: worth it from mid-sized clouds on
     const int use_cells = n >= 1024 && (long long)b * m * nscales >= 8192;
     hipStream_t st = as_stream(stream);
-    // geometry: as many queries per wave as the LDS holds bitmaps and rows for (see bq_cells_pick)
-    struct Geom { int nt, lpq; size_t cap; };
-    static const Geom order[] = {{512, 8, 80 * 1024},   {512, 16, 80 * 1024},  {1024, 8, 160 * 1024}, {1024, 16, 160 * 1024},
-                                 {512, 8, 160 * 1024},  {512, 16, 160 * 1024}, {512, 32, 160 * 1024}};
+    // geometry: two 512-thread workgroups per CU when everything fits in half the LDS, else one of 1024, else one of 512
+    struct Geom { int nt; size_t cap; };
+    static const Geom order[] = {{512, 80 * 1024}, {1024, 160 * 1024}, {512, 160 * 1024}};
     for (const Geom &g : order) {
-        if (msg_lds_bytes(n, max_ns, g.lpq, g.nt) > g.cap) continue;
-#define PN2_MSG_CASE(NT, LPQ) \
-        if (g.nt == NT && g.lpq == LPQ) return launch_msg<NT, LPQ>(b, n, m, use_cells, max_ns, sc, xyz1, xyz2, subtract_centroid, st)
-        PN2_MSG_CASE(1024, 8);
-        PN2_MSG_CASE(1024, 16);
-        PN2_MSG_CASE(512, 8);
-        PN2_MSG_CASE(512, 16);
-        PN2_MSG_CASE(512, 32);
-#undef PN2_MSG_CASE
+        if (msg_sweep_bytes(n, max_ns, g.nt) > g.cap) continue;
+        const int qpb = msg_qpb(b, m, g.nt, use_cells);
+        const size_t stride = msg_pick_lpq(n, g.nt, g.cap, qpb, sc);
+        if (!stride) continue;
+        if (g.nt == 1024) return launch_msg<1024>(b, n, m, use_cells, max_ns, qpb, stride, sc, xyz1, xyz2, subtract_centroid, st);
+        return launch_msg<512>(b, n, m, use_cells, max_ns, qpb, stride, sc, xyz1, xyz2, subtract_centroid, st);
     }
     return PN2_E_TOO_LARGE;
 }

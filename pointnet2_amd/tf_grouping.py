@@ -111,11 +111,21 @@ def query_ball_group_xyz_msg(radius_list, nsample_list, xyz1, xyz2, subtract_cen
     if ns_count > 4 or n > 8192:                                  # outside the multi-radius kernel's envelope
         return [query_ball_group_xyz(r, k, xyz1, xyz2, subtract_centroid, want_idx)
                 for r, k in zip(radius_list, nsample_list)]
-    outs = []
+    # one allocation per dtype, carved into per-scale views (allocations dominate the host time of this call)
+    tot = sum(nsample_list)
+    ibuf = torch.empty((b * m * (tot + ns_count) if want_idx else b * m * ns_count,), dtype=torch.int32, device=dev)
+    gbuf = torch.empty((b * m * tot * 3,), dtype=torch.float32, device=dev)
+    outs, io, go = [], 0, 0
     for k in nsample_list:
-        outs.append((torch.empty((b, m, k), dtype=torch.int32, device=dev) if want_idx else None,
-                     torch.empty((b, m), dtype=torch.int32, device=dev),
-                     torch.empty((b, m, k, 3), dtype=torch.float32, device=dev)))
+        idx_k = None
+        if want_idx:
+            idx_k = ibuf[io:io + b * m * k].view(b, m, k)
+            io += b * m * k
+        cnt_k = ibuf[io:io + b * m].view(b, m)
+        io += b * m
+        grp_k = gbuf[go:go + b * m * k * 3].view(b, m, k, 3)
+        go += b * m * k * 3
+        outs.append((idx_k, cnt_k, grp_k))
     radii = (ctypes.c_float * ns_count)(*radius_list)
     nss = (ctypes.c_int * ns_count)(*nsample_list)
     pi = (ctypes.c_void_p * ns_count)(*[ptr(o[0]) for o in outs])

@@ -39,7 +39,8 @@ def main():
         # bench.py reads this file: HBM bytes per launch keyed by operator (the kernel that implements it
         # on the op-level path at the metric shape)
         ops = {"farthest_point_sample": "fps_reg_kernel", "gather_point": "gather_point_kernel",
-               "query_ball_point": "ball_query", "group_point": "group_point_c3_kernel",
+               "query_ball_point": "false>(int, int, int, int, float, float, int, int, float const*, float const*, int*, int*",
+               "group_point": "group_point_c3_kernel",
                "sample_and_group_xyz": "sa_fused_kernel"}
         out = {}
         for op, frag in ops.items():
