@@ -118,7 +118,10 @@ __device__ __forceinline__ int bq_poll_sample(const unsigned long long *tagged, 
     for (unsigned it = 0;; ++it) {
         const unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(v >> 32) == tag) return (int)(unsigned)v;
-        __builtin_amdgcn_s_sleep(16);
+#ifndef PN2_POLL_SLEEP
+#define PN2_POLL_SLEEP 16
+#endif
+        __builtin_amdgcn_s_sleep(PN2_POLL_SLEEP);
         if (it > (1u << 23)) return -1;
     }
 }
@@ -338,9 +341,11 @@ __device__ __forceinline__ void bq_cell_count(int *cellend, int c, bool valid, i
 // Bin the cloud (n <= kBqCellsMaxPoints). Returns false (block-uniform) when the grid would be too
 // coarse to prune or one cell holds a large share of the cloud (a sweep with its early exit is the
 // better tool for both); `sorted` has not been written in that case.
+// pos_tab (optional, n entries): point k's position in `sorted` -- the overlapped launch's consumers look the
+// query point up by its index (the FPS sample) without a trip to global memory.
 template <int NT>
 __device__ __forceinline__ bool bq_build_grid(int n, float reach, const float *__restrict__ data, float4 *sorted,
-                                              int *cellend, float *misc, BqGrid &g)
+                                              int *cellend, float *misc, BqGrid &g, unsigned short *pos_tab = nullptr)
 {
     constexpr int kBqPtsPerThread = kBqCellsMaxPoints / NT, kBqWavesT = NT / 64;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -463,7 +468,10 @@ __device__ __forceinline__ bool bq_build_grid(int n, float reach, const float *_
 #pragma unroll
     for (int i = 0; i < kBqPtsPerThread; ++i) {
         const int k = t + i * NT;
-        if (k < n) sorted[pos[i]] = make_float4(px[i], py[i], pz[i], __int_as_float(k));
+        if (k < n) {
+            sorted[pos[i]] = make_float4(px[i], py[i], pz[i], __int_as_float(k));
+            if (pos_tab) pos_tab[k] = (unsigned short)pos[i];
+        }
     }
     __syncthreads();                                             // cellend[c] is now the END of cell c
     return true;
@@ -499,7 +507,8 @@ __device__ __forceinline__ void bq_cells_query_loop(int n, int m, int nsample, f
                                                     float *__restrict__ new_xyz, int *__restrict__ idx,
                                                     int *__restrict__ pts_cnt, float *__restrict__ grouped,
                                                     int subtract, const float4 *sorted, const int *tab,
-                                                    char *wave_area, size_t wave_stride = 0)
+                                                    char *wave_area, size_t wave_stride = 0, unsigned tag = 1u,
+                                                    unsigned *status = nullptr, const unsigned short *pos_tab = nullptr)
 {
     constexpr int G = 64 / LPQ;
     constexpr int CW = 64 / LPQ;                                 // 64-bit bitmap words per lane and window
@@ -534,9 +543,13 @@ __device__ __forceinline__ void bq_cells_query_loop(int n, int m, int nsample, f
         const size_t row = (size_t)bi * m + (qvalid ? j : q1 - 1);
         float qx, qy, qz;
         if (POLL) {
-            int ka = bq_poll_sample(tagged + row);
-            if (__any(ka < 0)) return;                           // unused by the shipped launches (sweep consumers)
-            qx = data[(size_t)ka * 3 + 0]; qy = data[(size_t)ka * 3 + 1]; qz = data[(size_t)ka * 3 + 2];
+            const int ka = bq_poll_sample(tagged + row, tag);
+            if (__any(ka < 0)) {                                 // see bq_poll_sample: report, give up
+                if (lane == 0 && status) atomicExch(status, 1u);
+                return;
+            }
+            const float4 qp = sorted[pos_tab[ka]];               // POLL implies pos_tab: exact copy of xyz[ka]
+            qx = qp.x; qy = qp.y; qz = qp.z;
             if (sub == 0 && qvalid) {
                 float *o = new_xyz + row * 3;
                 o[0] = qx; o[1] = qy; o[2] = qz;
@@ -713,23 +726,27 @@ __device__ __forceinline__ void bq_cells_block_body(int n, int m, int nsample, f
                                                     const unsigned long long *__restrict__ tagged,
                                                     float *__restrict__ new_xyz, int *__restrict__ idx,
                                                     int *__restrict__ pts_cnt, float *__restrict__ grouped,
-                                                    int subtract, char *smem)
+                                                    int subtract, char *smem, unsigned tag = 1u,
+                                                    unsigned *status = nullptr)
 {
     float4 *sorted = reinterpret_cast<float4 *>(smem);
     int *tab = reinterpret_cast<int *>(smem + sizeof(float4) * (size_t)n);
     char *wave_area = reinterpret_cast<char *>(tab + kBqTabInts);
     float *misc = reinterpret_cast<float *>(wave_area + (size_t)(NT / 64) * bq_cells_wave_bytes(n, nsample, LPQ));
+    // POLL (the overlapped launch's consumers): index -> sorted position table behind the scratch (2 bytes per point)
+    unsigned short *pos_tab = POLL ? reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(misc) + kBqMiscBytes) : nullptr;
     const float *__restrict__ data = xyz1 + (size_t)bi * n * 3;
     const float reach = radius * 1.001f;
     BqGrid g;
     if (threadIdx.x == 0) tab[0] = 0;
-    if (bq_build_grid<NT>(n, reach, data, sorted, tab + 1, misc, g)) {
+    if (bq_build_grid<NT>(n, reach, data, sorted, tab + 1, misc, g, pos_tab)) {
         bq_cells_query_loop<NT, LPQ, FUSE, POLL>(n, m, nsample, thr, radius, reach, bi, q0, q1, g, data, xyz2, tagged,
-                                             new_xyz, idx, pts_cnt, grouped, subtract, sorted, tab, wave_area);
+                                             new_xyz, idx, pts_cnt, grouped, subtract, sorted, tab, wave_area, 0, tag,
+                                             status, pos_tab);
     } else {
         __syncthreads();                                         // scratch was read by everyone before it is reused
         bq_block_body<true, FUSE, POLL, NT>(n, m, nsample, thr, bi, q0, q1, xyz1, xyz2, tagged, new_xyz, idx, pts_cnt,
-                                        grouped, subtract, smem);
+                                        grouped, subtract, smem, tag, 0, status);
     }
 }
 

@@ -45,9 +45,12 @@ constexpr int kFusedThreads = 512;
 constexpr int kFusedMaxClouds = 128;            // producers must leave most CUs to the consumers
 constexpr size_t kFusedMinLds = 82 * 1024;      // > 160 KiB / 2: one workgroup per CU
 
-template <int P>
+// LPQ: lanes per query of the cell-list consumers; 0 = sweep consumers (clouds whose cell list does not fit
+// beside the position table: n > ~6000).
+template <int P, int LPQ>
 __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, int m, int Q, int nsample, float thr,
-                                                                 int qpb, unsigned tag, const float *__restrict__ xyz,
+                                                                 float radius, int qpb, unsigned tag,
+                                                                 const float *__restrict__ xyz,
                                                                  unsigned long long *__restrict__ tagged,
                                                                  int *__restrict__ fps_idx,
                                                                  float *__restrict__ new_xyz, int *__restrict__ idx,
@@ -57,19 +60,44 @@ __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, i
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned *status = reinterpret_cast<unsigned *>(tagged + (size_t)b * m);   // launch status word behind the granules
     const int blk = blockIdx.x;
+#ifndef PN2_FUSED_LAB_PUBLISH                     // lab switches (scripts/: where does the launch's time go?)
+#define PN2_FUSED_LAB_PUBLISH true
+#endif
     if (blk < b) {
-        fps_reg_body<kFusedThreads, P, true, true>(n, m, Q, blk, xyz, fps_idx, nullptr, tagged, smem, tag);
+#ifdef PN2_FUSED_LAB_TIMES
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();           // 100 MHz
+#endif
+        fps_reg_body<kFusedThreads, P, true, PN2_FUSED_LAB_PUBLISH>(n, m, Q, blk, xyz, fps_idx, nullptr, tagged, smem, tag);
+#ifdef PN2_FUSED_LAB_TIMES
+        if (blk == 0 && threadIdx.x == 0) status[1] = (unsigned)(__builtin_amdgcn_s_memrealtime() - t0);   // chain, 10 ns ticks
+#endif
     } else {
+#ifdef PN2_FUSED_LAB_NO_CONSUMERS
+        return;
+#endif
         const int id = blk - b;
         const int cloud = id % b;                // query range first, cloud second: the consumers that can
         const int q0 = (id / b) * qpb;           // start earliest are dispatched first
-        bq_block_body<true, true, true>(n, m, nsample, thr, cloud, q0, min(q0 + qpb, m), xyz, nullptr, tagged,
-                                        new_xyz, idx, pts_cnt, grouped, subtract, smem, tag, 0, status);
+        if (LPQ == 0)
+            bq_block_body<true, true, true>(n, m, nsample, thr, cloud, q0, min(q0 + qpb, m), xyz, nullptr, tagged,
+                                            new_xyz, idx, pts_cnt, grouped, subtract, smem, tag, 0, status);
+        else
+            bq_cells_block_body<kFusedThreads, (LPQ ? LPQ : 8), true, true>(n, m, nsample, thr, radius, cloud, q0,
+                                                                          min(q0 + qpb, m), xyz, nullptr, tagged, new_xyz,
+                                                                          idx, pts_cnt, grouped, subtract, smem, tag, status);
     }
 }
 
-template <int P>
-static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, unsigned tag, const float *xyz,
+// LDS of a cell-list consumer workgroup (512 threads) incl. the position table and the sweep fallback's layout
+static size_t fused_cells_lds(int n, int nsample, int lpq)
+{
+    const size_t cells = bq_cells_lds_bytes(n, nsample, lpq, kFusedThreads) + sizeof(unsigned short) * (size_t)n;
+    const size_t sweep = sizeof(float4) * (size_t)((n + 127) & ~127) + sizeof(int) * (size_t)nsample * kBqWaves * kBqQpw;
+    return cells > sweep ? cells : sweep;
+}
+
+template <int P, int LPQ>
+static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, float radius, unsigned tag, const float *xyz,
                         unsigned long long *ws, int *fps_idx, float *new_xyz, int *idx, int *pts_cnt,
                         float *grouped, int subtract, hipStream_t st)
 {
@@ -79,11 +107,12 @@ static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, unsi
     if (qpb > m) qpb = ((m + kGran - 1) / kGran) * kGran;
     const int nq = (m + qpb - 1) / qpb;
     size_t lds_f = 256 + sizeof(float4) * (size_t)kFusedThreads * P;
-    size_t lds_q = sizeof(float4) * (size_t)((n + 127) & ~127) + sizeof(int) * (size_t)nsample * kGran;
+    size_t lds_q = LPQ ? fused_cells_lds(n, nsample, LPQ)
+                       : sizeof(float4) * (size_t)((n + 127) & ~127) + sizeof(int) * (size_t)nsample * kGran;
     size_t lds = lds_f > lds_q ? lds_f : lds_q;
     if (lds < kFusedMinLds) lds = kFusedMinLds;
     if (lds > 160 * 1024) return PN2_E_TOO_LARGE;
-    auto kern = sa_fused_kernel<P>;
+    auto kern = sa_fused_kernel<P, LPQ>;
     if (int rc = allow_dynamic_lds(kern, lds)) return rc;
     {
         // residency (header): room for every producer plus at least one consumer at the same time
@@ -96,7 +125,7 @@ static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, unsi
         if (e != hipSuccess) return (int)e;
         tag = 1u;
     }
-    if (int rc = launch(kern, dim3(b + nq * b), dim3(kFusedThreads), lds, st, b, n, m, Q, nsample, thr, qpb, tag, xyz, ws,
+    if (int rc = launch(kern, dim3(b + nq * b), dim3(kFusedThreads), lds, st, b, n, m, Q, nsample, thr, radius, qpb, tag, xyz, ws,
                        fps_idx, new_xyz, idx, pts_cnt, grouped, subtract)) return rc;
     return PN2_OK;
 }
@@ -128,14 +157,21 @@ static int sample_and_group_common(int b, int n, int m, float radius, int nsampl
     const float thr = pn2_ball_threshold(radius);
     hipStream_t st = as_stream(stream);
     unsigned long long *w = reinterpret_cast<unsigned long long *>(ws);
-    switch (P) {
-    case 1: return launch_fused<1>(b, n, m, Q, nsample, thr, tag, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
-    case 2: return launch_fused<2>(b, n, m, Q, nsample, thr, tag, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
-    case 4: return launch_fused<4>(b, n, m, Q, nsample, thr, tag, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
-    case 8: return launch_fused<8>(b, n, m, Q, nsample, thr, tag, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
-    case 16: return launch_fused<16>(b, n, m, Q, nsample, thr, tag, xyz, w, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz, subtract_centroid, st);
-    default: return PN2_E_TOO_LARGE;
-    }
+    // consumers: the cell-list body with as many queries per wave as fit beside the sorted cloud, the cell table
+    // and the position table; the sweep body when nothing fits (large clouds) or the cloud is tiny
+    int lpq = 0;
+    if (n >= 1024)
+        for (int cand : {8, 16, 32})
+            if (fused_cells_lds(n, nsample, cand) <= 160 * 1024) { lpq = cand; break; }
+#define PN2_FUSED_CASE(PP, LL)                                                                                         \
+    if (P == PP && lpq == LL)                                                                                          \
+        return launch_fused<PP, LL>(b, n, m, Q, nsample, thr, radius, tag, xyz, w, fps_idx, new_xyz, idx, pts_cnt,       \
+                                    grouped_xyz, subtract_centroid, st)
+#define PN2_FUSED_P(PP) PN2_FUSED_CASE(PP, 0); PN2_FUSED_CASE(PP, 8); PN2_FUSED_CASE(PP, 16); PN2_FUSED_CASE(PP, 32)
+    PN2_FUSED_P(1); PN2_FUSED_P(2); PN2_FUSED_P(4); PN2_FUSED_P(8); PN2_FUSED_P(16);
+#undef PN2_FUSED_P
+#undef PN2_FUSED_CASE
+    return PN2_E_TOO_LARGE;
 }
 
 extern "C" int pn2_sample_and_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,

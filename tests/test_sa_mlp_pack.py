@@ -214,3 +214,121 @@ def test_fold_batch_norm_equals_eval_mode_layers():
     conv = torch.nn.Conv2d(4, 6, 1)
     w, b = sa_mlp.fold_batch_norm(conv.weight, conv.bias, None)
     assert np.allclose(w, conv.weight.detach().numpy()[:, :, 0, 0].T) and np.allclose(b, conv.bias.detach().numpy())
+
+
+# ---- packing of the round-2 kernels: feature propagation (streamed, kind 0) and cooperative (kind 1) ---------------
+def _emulate_pair(pair, act, acc, last):
+    """The 16 MFMAs of one packed 32x32 tile pair ([q][lane][r]) on activation registers act (64, 16)."""
+    pair = pair.reshape(4, 64, 4)
+    for q in range(4):
+        for r in range(4):
+            w, x = pair[q, :, r], act[:, 4 * q + r]
+            acc = _mfma(x, w, acc) if last else _mfma(w, x, acc)
+    return acc
+
+
+def _operand_tiles(x, ti):
+    """(32 samples, cin) -> ti operand tiles (64 lanes, 16 regs): register v of lane l = channel 32u + chan(v, l >> 5)."""
+    tiles = []
+    for u in range(ti):
+        t = np.zeros((64, 16))
+        for l in range(64):
+            for v in range(16):
+                k = 32 * u + _chan(v, l >> 5)
+                t[l, v] = x[l & 31, k] if k < x.shape[1] else 0.0
+        tiles.append(t)
+    return tiles
+
+
+def _unswap(acc_tiles, cout, bias_of):
+    """Last-layer accumulators (swapped operands: lane = channel, register = sample) -> (32, cout) with bias + ReLU."""
+    got = np.zeros((32, cout))
+    for t, acc in acc_tiles.items():
+        for l in range(64):
+            ch = 32 * t + (l & 31)
+            if ch < cout:
+                for v in range(16):
+                    got[_chan(v, l >> 5), ch] = max(acc[l, v] + bias_of(ch), 0.0)
+    return got
+
+
+def _b_at(bp_layer, ch):
+    t, c = ch >> 5, ch & 31
+    return bp_layer.reshape(-1, 2, 16)[t, (c >> 2) & 1, 4 * (c >> 3) + (c & 3)]
+
+
+@pytest.mark.parametrize("kind", [0, 1], ids=["streamed", "cooperative"])
+@pytest.mark.parametrize("c2,c1,widths", [(40, 8, (100, 60)), (24, 0, (128, 128, 70)), (36, 5, (130, 128))])
+def test_fp_pack_matches_emulated_dataflow(kind, c2, c1, widths):
+    """pn2_fp_mlp_pack: walk the packed stream exactly as the kernels do (fp_mlp.hip: one wave, input tiles outermost
+    in layer 1, output tiles outermost afterwards; coop_mlp.hip: pair 4k + w belongs to wave w, input tiles outermost
+    in every layer, wave w owns output tiles 4g + w) and compare with the plain layer stack."""
+    from pointnet2_amd import _C
+    lib = _C.lib()
+    rng = np.random.default_rng(c2 + kind)
+    n = len(widths)
+    warr = (ctypes.c_int * n)(*widths)
+    tiles = (ctypes.c_int * 4)()
+    wf, bf = ctypes.c_longlong(), ctypes.c_longlong()
+    rc = lib.pn2_fp_mlp_config(c2, c1, n, warr, kind, tiles, ctypes.byref(wf), ctypes.byref(bf))
+    if rc != 0:
+        pytest.skip("no kernel of this kind for the stack")
+    ti, T = tiles[0], [tiles[1], tiles[2], tiles[3]]
+    dims = (c2 + c1,) + tuple(widths)
+    ws = [rng.standard_normal((dims[i], dims[i + 1])).astype(np.float32) for i in range(n)]
+    bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) for i in range(n)]
+    wp = np.empty(wf.value, np.float32)
+    bp = np.empty(bf.value, np.float32)
+    wptr = (ctypes.c_void_p * n)(*[w.ctypes.data for w in ws])
+    bptr = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bs])
+    assert lib.pn2_fp_mlp_pack(c2, c1, n, warr, kind, wptr, bptr, wp.ctypes.data, bp.ctypes.data) == 0
+    pairs = wp.reshape(-1, 1024)
+    ob = np.cumsum([0, T[0] * 32, T[1] * 32, T[2] * 32])
+    bl = [bp[ob[i]:ob[i + 1]] for i in range(3)]
+    x = rng.standard_normal((32, c2 + c1)).astype(np.float32)
+    acts = _operand_tiles(x, ti)
+    tin = [ti, T[0], T[1]]
+    last_acc = {}
+    if kind == 0:
+        k = 0
+        for L in range(n):
+            last = L == n - 1
+            acc = {t: (np.zeros((64, 16)) if last else np.stack([bl[L].reshape(-1, 2, 16)[t, l >> 5] for l in range(64)]).astype(np.float64))
+                   for t in range(T[L])}
+            if L == 0:                                   # input tiles outermost, padded to whole stages of 4 pairs
+                for u in range(tin[L]):
+                    for t in range(T[L]):
+                        acc[t] = _emulate_pair(pairs[k], acts[u], acc[t], last)
+                        k += 1
+                k = (k + 3) // 4 * 4
+            else:
+                for t in range(T[L]):
+                    for u in range(tin[L]):
+                        acc[t] = _emulate_pair(pairs[k], acts[u], acc[t], last)
+                        k += 1
+            if last:
+                last_acc = acc
+            else:
+                acts = [np.maximum(acc[t], 0.0) for t in range(T[L])]
+    else:
+        k = 0                                           # stage counter: stage k holds pairs 4k .. 4k + 3, one per wave
+        for L in range(n):
+            last = L == n - 1
+            q = T[L] // 4
+            acc = {t: (np.zeros((64, 16)) if last else np.stack([bl[L].reshape(-1, 2, 16)[t, l >> 5] for l in range(64)]).astype(np.float64))
+                   for t in range(T[L])}
+            for u in range(tin[L]):
+                for g in range(q):
+                    for w in range(4):
+                        acc[4 * g + w] = _emulate_pair(pairs[4 * k + w], acts[u], acc[4 * g + w], last)
+                    k += 1
+            if last:
+                last_acc = acc
+            else:
+                acts = [np.maximum(acc[t], 0.0) for t in range(T[L])]
+        assert 4 * k == pairs.shape[0]
+    got = _unswap(last_acc, widths[-1], lambda ch: _b_at(bl[n - 1], ch))
+    want = x.astype(np.float64)
+    for w, b in zip(ws, bs):
+        want = np.maximum(want @ w.astype(np.float64) + b, 0.0)
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
