@@ -30,7 +30,10 @@
 // (pn2_sample_and_group_status_offset) and exits: an error the host can read, not a trap that would take
 // the process down. Shapes outside the envelope are refused (callers use the two-launch path:
 // pn2_farthest_point_sample_gather + pn2_query_ball_group_xyz; the Python layer also has a switch).
-// Tried and measured (round 2): roles taken by ARRIVAL TICKET (one returning atomicAdd per workgroup; the
+// Tried and measured (round 2), neither shipped: (1) the last 12 queries of a cloud answered by its PRODUCER workgroup
+// after the final round (candidate-parallel over the LDS mirror, bitmaps, bq_flush): correct, but 421.8-424.6 us per
+// step against 419.8 -- scripts/fused_tail_probe.py shows why: the launch ends 5-7 us after the SLOWEST of the 32
+// chains (they spread over 3.5 us), and the epilogue lengthens exactly that workgroup. (2) Roles taken by ARRIVAL TICKET (one returning atomicAdd per workgroup; the
 // first b arrivals become producers), which needs no assumption about dispatch order -- 452-470 us per
 // launch against 419 with roles by block index (the ticket winners are the workgroups closest to the
 // counter's memory channel, i.e. the producers end up bunched on one XCD). Not shipped.
@@ -44,6 +47,7 @@ namespace pn2 {
 constexpr int kFusedThreads = 512;
 constexpr int kFusedMaxClouds = 128;            // producers must leave most CUs to the consumers
 constexpr size_t kFusedMinLds = 82 * 1024;      // > 160 KiB / 2: one workgroup per CU
+
 
 // LPQ: lanes per query of the cell-list consumers; 0 = sweep consumers (clouds whose cell list does not fit
 // beside the position table: n > ~6000).
@@ -69,7 +73,15 @@ __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, i
 #endif
         fps_reg_body<kFusedThreads, P, true, PN2_FUSED_LAB_PUBLISH>(n, m, Q, blk, xyz, fps_idx, nullptr, tagged, smem, tag);
 #ifdef PN2_FUSED_LAB_TIMES
-        if (blk == 0 && threadIdx.x == 0) status[1] = (unsigned)(__builtin_amdgcn_s_memrealtime() - t0);   // chain, 10 ns ticks
+        if (threadIdx.x == 0) {
+            const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+            if (blk == 0) { status[1] = (unsigned)(t1 - t0); status[2] = (unsigned)t1; }   // chain (10 ns ticks), its absolute end
+            status[8 + 2 * blk] = (unsigned)t0;                              // the probe allocates ws with room for these
+            status[9 + 2 * blk] = (unsigned)t1;
+        }
+#endif
+#ifdef PN2_FUSED_LAB_TIMES
+        if (threadIdx.x == 0) atomicMax(status + 3, (unsigned)__builtin_amdgcn_s_memrealtime());   // last workgroup to finish
 #endif
     } else {
 #ifdef PN2_FUSED_LAB_NO_CONSUMERS
@@ -85,6 +97,9 @@ __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, i
             bq_cells_block_body<kFusedThreads, (LPQ ? LPQ : 8), true, true>(n, m, nsample, thr, radius, cloud, q0,
                                                                           min(q0 + qpb, m), xyz, nullptr, tagged, new_xyz,
                                                                           idx, pts_cnt, grouped, subtract, smem, tag, status);
+#ifdef PN2_FUSED_LAB_TIMES
+        if (threadIdx.x == 0) atomicMax(status + 3, (unsigned)__builtin_amdgcn_s_memrealtime());
+#endif
     }
 }
 
