@@ -13,24 +13,29 @@ def require(cond, msg):
         raise ValueError(msg)
 
 
-def f32(t, name):
+def _checked(t, name, dtype, dtype_name):
+    # fast path first: the messages below cost more to format than the checks do (every operator call pays them)
+    if isinstance(t, torch.Tensor) and t.dtype is dtype and t.is_cuda:
+        return t if t.is_contiguous() else t.contiguous()
     require(isinstance(t, torch.Tensor), "%s must be a torch.Tensor" % name)
-    require(t.dtype == torch.float32, "%s must be float32, got %s" % (name, t.dtype))
+    require(t.dtype == dtype, "%s must be %s, got %s" % (name, dtype_name, t.dtype))
     require(t.is_cuda, "%s must live on a ROCm device (got %s); there is no CPU path" % (name, t.device))
     return t.contiguous()
+
+
+def f32(t, name):
+    return _checked(t, name, torch.float32, "float32")
 
 
 def i32(t, name):
-    require(isinstance(t, torch.Tensor), "%s must be a torch.Tensor" % name)
-    require(t.dtype == torch.int32, "%s must be int32, got %s" % (name, t.dtype))
-    require(t.is_cuda, "%s must live on a ROCm device (got %s); there is no CPU path" % (name, t.device))
-    return t.contiguous()
+    return _checked(t, name, torch.int32, "int32")
 
 
 def same_device(*ts):
     dev = ts[0].device
     for t in ts[1:]:
-        require(t.device == dev, "all tensors must be on the same device (%s vs %s)" % (dev, t.device))
+        if t.device != dev:
+            raise ValueError("all tensors must be on the same device (%s vs %s)" % (dev, t.device))
     return dev
 
 

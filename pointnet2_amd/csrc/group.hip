@@ -129,7 +129,8 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 // 144 MB output that stays in the cache prefers plain stores: 25.5 / 22.7 / 25.6 us).
 // c == 3 keeps the flat one-row-per-lane kernel: a four-rows-per-lane variant (one 16-byte index load, three
 // 16-byte stores) measured SLOWER (7.6 vs 6.6 us at the metric shape; the launch is latency bound: 18 MB
-// is 2.3 us of HBM time, less than two kernel-launch floors).
+// is 2.3 us of HBM time, less than two kernel-launch floors). Two and four rows per lane with every index load
+// issued before the first gather: 6.3 / 6.5 us -- no change either).
 
 typedef float pn2_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_nt(float4 *p, float4 v)      // global_store_dwordx4 ... nt

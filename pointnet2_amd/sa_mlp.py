@@ -86,16 +86,16 @@ def sa_mlp_maxpool(xyz, new_xyz, points, idx, packed):
     -> (b, m, c3) f32 = max over nsample of the three-layer MLP of [xyz[idx]-new_xyz, points[idx]].
     new_xyz is None and idx is None: the group_all level (sample_and_group_all, pointnet_util.py:59-84) ->
     (b, 1, c3) = max over all n points of the MLP of [xyz, points] (no centroid)."""
-    xyz = f32(xyz.detach(), "xyz")
+    xyz = f32(xyz, "xyz")
     b, n, _ = xyz.shape
     if idx is None and new_xyz is None:
         m, ns = 1, n
     else:
-        new_xyz, idx = f32(new_xyz.detach(), "new_xyz"), i32(idx, "idx")
+        new_xyz, idx = f32(new_xyz, "new_xyz"), i32(idx, "idx")
         m, ns = idx.shape[1], idx.shape[2]
     cfeat = 0
     if points is not None:
-        points = f32(points.detach(), "points")
+        points = f32(points, "points")
         cfeat = points.shape[2]
     require(3 + cfeat == packed.cin, "packed MLP expects %d input channels, got %d" % (packed.cin, 3 + cfeat))
     # the packed layout belongs to the kernel pn2_sa_mlp3_config chose for packed.nsample; another nsample
@@ -170,12 +170,12 @@ def fp_mlp(points2, points1, idx, dist, packed):
     """points2 (b,m,c2) features of the known points, points1 (b,n,c1) skip features or None, idx / dist
     (b,n,3) from three_nn -> (b, n, widths[-1]) f32: the inverse-distance weights, the interpolation, the
     concatenation and the layer stack of pointnet_fp_module (pointnet_util.py:211-226) in one launch."""
-    points2, idx, dist = f32(points2.detach(), "points2"), i32(idx, "idx"), f32(dist.detach(), "dist")
+    points2, idx, dist = f32(points2, "points2"), i32(idx, "idx"), f32(dist, "dist")
     b, m, c2 = points2.shape
     n = idx.shape[1]
     c1 = 0
     if points1 is not None:
-        points1 = f32(points1.detach(), "points1")
+        points1 = f32(points1, "points1")
         c1 = points1.shape[2]
     require(c2 == packed.c2 and c1 == packed.c1, "packed FP MLP expects (%d, %d) channels, got (%d, %d)" % (packed.c2, packed.c1, c2, c1))
     dev = same_device(points2, idx, dist, packed.wp) if points1 is None else same_device(points2, points1, idx, dist, packed.wp)

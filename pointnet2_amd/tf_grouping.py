@@ -33,8 +33,8 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     """
     require(float(radius) > 0, "QueryBallPoint expects positive radius")
     require(int(nsample) > 0, "QueryBallPoint expects positive nsample")
-    xyz1 = f32(xyz1.detach(), "xyz1")
-    xyz2 = f32(xyz2.detach(), "xyz2")
+    xyz1 = f32(xyz1, "xyz1")
+    xyz2 = f32(xyz2, "xyz2")
     require(xyz1.dim() == 3 and xyz1.shape[2] == 3, "QueryBallPoint expects (batch_size, ndataset, 3) xyz1 shape.")
     require(xyz2.dim() == 3 and xyz2.shape[2] == 3 and xyz2.shape[0] == xyz1.shape[0],
             "QueryBallPoint expects (batch_size, npoint, 3) xyz2 shape.")
@@ -65,8 +65,8 @@ def query_ball_group_xyz(radius, nsample, xyz1, xyz2, subtract_centroid=True, wa
     """
     require(float(radius) > 0, "QueryBallPoint expects positive radius")
     require(int(nsample) > 0, "QueryBallPoint expects positive nsample")
-    xyz1 = f32(xyz1.detach(), "xyz1")
-    xyz2 = f32(xyz2.detach(), "xyz2")
+    xyz1 = f32(xyz1, "xyz1")
+    xyz2 = f32(xyz2, "xyz2")
     require(xyz1.dim() == 3 and xyz1.shape[2] == 3, "QueryBallPoint expects (batch_size, ndataset, 3) xyz1 shape.")
     require(xyz2.dim() == 3 and xyz2.shape[2] == 3 and xyz2.shape[0] == xyz1.shape[0],
             "QueryBallPoint expects (batch_size, npoint, 3) xyz2 shape.")
@@ -99,8 +99,8 @@ def query_ball_group_xyz_msg(radius_list, nsample_list, xyz1, xyz2, subtract_cen
     require(len(radius_list) == len(nsample_list) and 1 <= len(radius_list), "one nsample per radius")
     require(all(r > 0 for r in radius_list), "QueryBallPoint expects positive radius")
     require(all(k > 0 for k in nsample_list), "QueryBallPoint expects positive nsample")
-    xyz1 = f32(xyz1.detach(), "xyz1")
-    xyz2 = f32(xyz2.detach(), "xyz2")
+    xyz1 = f32(xyz1, "xyz1")
+    xyz2 = f32(xyz2, "xyz2")
     require(xyz1.dim() == 3 and xyz1.shape[2] == 3, "QueryBallPoint expects (batch_size, ndataset, 3) xyz1 shape.")
     require(xyz2.dim() == 3 and xyz2.shape[2] == 3 and xyz2.shape[0] == xyz1.shape[0],
             "QueryBallPoint expects (batch_size, npoint, 3) xyz2 shape.")
@@ -195,7 +195,7 @@ def sample_and_group_xyz(npoint, radius, nsample, xyz, subtract_centroid=True):
     require(int(npoint) > 0, "FarthestPointSample expects positive npoint")
     require(float(radius) > 0, "QueryBallPoint expects positive radius")
     require(int(nsample) > 0, "QueryBallPoint expects positive nsample")
-    xyz = f32(xyz.detach(), "xyz")
+    xyz = f32(xyz, "xyz")
     require(xyz.dim() == 3 and xyz.shape[2] == 3, "FarthestPointSample expects (batch_size,num_points,3) inp shape")
     b, n, _ = xyz.shape
     m, ns = int(npoint), int(nsample)
@@ -235,7 +235,7 @@ def select_top_k(k, dist):
     reference: tf_grouping.py:22-31, op SelectionSort tf_grouping.cpp:109-139.
     """
     require(int(k) > 0, "SelectionSort expects positive k")
-    dist = f32(dist.detach(), "dist")
+    dist = f32(dist, "dist")
     require(dist.dim() == 3, "SelectionSort expects (b,m,n) dist shape.")
     b, m, n = dist.shape
     dev = dist.device
@@ -310,8 +310,8 @@ def knn_point(k, xyz1, xyz2):
     (pn2_knn_point); other channel counts build the matrix with torch elementwise ops (same per-pair
     arithmetic: differences, squares, a left-to-right sum over c) and run the HIP selection sort.
     """
-    xyz1 = f32(xyz1.detach(), "xyz1")
-    xyz2 = f32(xyz2.detach(), "xyz2")
+    xyz1 = f32(xyz1, "xyz1")
+    xyz2 = f32(xyz2, "xyz2")
     require(xyz1.dim() == 3 and xyz2.dim() == 3 and xyz1.shape[0] == xyz2.shape[0] and
             xyz1.shape[2] == xyz2.shape[2], "knn_point expects (b,n,c) xyz1 and (b,m,c) xyz2")
     b, n, c = xyz1.shape

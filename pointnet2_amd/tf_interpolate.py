@@ -21,8 +21,8 @@ def three_nn(xyz1, xyz2):
     reference: tf_interpolate.py:8-17, op ThreeNN tf_interpolate.cpp:157-187,
     loop threenn_cpu :60-103.
     """
-    xyz1 = f32(xyz1.detach(), "xyz1")
-    xyz2 = f32(xyz2.detach(), "xyz2")
+    xyz1 = f32(xyz1, "xyz1")
+    xyz2 = f32(xyz2, "xyz2")
     require(xyz1.dim() == 3 and xyz1.shape[2] == 3, "ThreeNN expects (b,n,3) xyz1 shape")
     require(xyz2.dim() == 3 and xyz2.shape[2] == 3 and xyz2.shape[0] == xyz1.shape[0],
             "ThreeNN expects (b,m,3) xyz2 shape")
@@ -86,7 +86,7 @@ def three_interpolate(points, idx, weight):
     """
     points = f32(points, "points")
     idx = i32(idx, "idx")
-    weight = f32(weight.detach(), "weight")
+    weight = f32(weight, "weight")
     require(points.dim() == 3, "ThreeInterpolate expects (b,m,c) points shape")
     b = points.shape[0]
     require(idx.dim() == 3 and idx.shape[0] == b and idx.shape[2] == 3, "ThreeInterpolate expects (b,n,3) idx shape")
