@@ -9,6 +9,8 @@
 //   PN2_FPS_LATE_STORE   thread 0's index store moved under the winner read             409 / 405
 //   PN2_FPS_DIAG         staggered update order with the lane arg-max folded in         406 / 407
 //   PN2_FPS_PACK_512     packed update at 512 threads                                   -   / 423-467
+//   (not in this file) wave key stored by all 64 lanes, lane 63 to the slot, the rest to a scratch strip (no exec-mask
+//   juggling around the store)                                                         403 / 421   (267 vs 273 at n = 1024)
 #pragma once
 #include "../pointnet2_amd/csrc/pn2_device.h"
 
