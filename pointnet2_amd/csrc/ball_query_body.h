@@ -362,10 +362,16 @@ __device__ __forceinline__ bool bq_build_grid(int n, float reach, const float *_
         }
     }
     float lx = inf, ly = inf, lz = inf, hx = -inf, hy = -inf, hz = -inf;
+    // copies of point 0 (the reference's dropout augmentation sets up to 87.5 % of a cloud to its first point,
+    // provider.py:227-233): counted on the way, so that such a cloud leaves for the sweep BEFORE the counting sort
+    // instead of after it (the crowded-cell test below would send it there anyway, 7 us later)
+    const float p0x = data[0], p0y = data[1], p0z = data[2];
+    int dups = 0;
 #pragma unroll
     for (int i = 0; i < kBqPtsPerThread; ++i) {
         if (t + i * NT < n) {
             const float x = px[i], y = py[i], z = pz[i];
+            dups += (x == p0x && y == p0y && z == p0z) ? 1 : 0;
             if (fabsf(x) < inf) { lx = fminf(lx, x); hx = fmaxf(hx, x); }     // non-finite coordinates never hit
             if (fabsf(y) < inf) { ly = fminf(ly, y); hy = fmaxf(hy, y); }
             if (fabsf(z) < inf) { lz = fminf(lz, z); hz = fmaxf(hz, z); }
@@ -373,13 +379,26 @@ __device__ __forceinline__ bool bq_build_grid(int n, float reach, const float *_
     }
     lx = wave_minmax_lane63<false>(lx); ly = wave_minmax_lane63<false>(ly); lz = wave_minmax_lane63<false>(lz);
     hx = wave_minmax_lane63<true>(hx); hy = wave_minmax_lane63<true>(hy); hz = wave_minmax_lane63<true>(hz);
+    dups = wave_prefix_sum_incl(dups);                           // lane 63: the wave's count
     // scratch layout: float[6][16] wave partials (read back as float4: 96 scalar LDS reads per thread
-    // were a visible part of the binning time), then int[16] wave sums and int[16] wave maxima
+    // were a visible part of the binning time), then int[16] wave sums and int[16] wave maxima, int[16] copy counts
+    int *dupw = reinterpret_cast<int *>(misc + 8 * 16);
     if (lane == 63) {
         misc[0 * 16 + w] = lx; misc[1 * 16 + w] = ly; misc[2 * 16 + w] = lz;
         misc[3 * 16 + w] = hx; misc[4 * 16 + w] = hy; misc[5 * 16 + w] = hz;
+        dupw[w] = dups;
     }
     __syncthreads();
+    {
+        int total = 0;
+        const int4 *d4 = reinterpret_cast<const int4 *>(dupw);
+#pragma unroll
+        for (int v = 0; v < kBqWavesT / 4; ++v) {
+            const int4 a = d4[v];
+            total += a.x + a.y + a.z + a.w;
+        }
+        if (total > max(128, n / 16)) return false;             // block-uniform: one cell would hold all of them
+    }
     lx = ly = lz = inf;
     hx = hy = hz = -inf;
     {
