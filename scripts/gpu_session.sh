@@ -19,6 +19,8 @@ for step in "$@"; do
     tests_fp)  timeout 600 python -m pytest tests/test_fp_mlp_gpu.py tests/test_sa_mlp_gpu.py tests/test_modules_gpu.py tests/test_graph_capture_gpu.py -m gpu -q > "$OUT/tests_fp.log" 2>&1; tail -15 "$OUT/tests_fp.log" ;;
     models)    timeout 600 python scripts/model_forward_bench.py > "$OUT/model_forward.log" 2>&1; cat "$OUT/model_forward.log" ;;
     prof_model) (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_model" -- python $ROOT/scripts/model_forward_bench.py ${MODEL:-sem_seg} > "$OUT/prof_model.log" 2>&1); find "$OUT/prof_model" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_model_${MODEL:-sem_seg}.csv" \;; rm -rf "$OUT/prof_model"; head -30 "$OUT/kernel_stats_model_${MODEL:-sem_seg}.csv" | cut -c1-150 ;;
+    smoke)     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; tail -2 "$OUT/smoke.log" ;;
+    configs)   timeout 600 python scripts/config_shapes.py > "$OUT/config_shapes.json" 2> "$OUT/config_shapes.err"; tail -3 "$OUT/config_shapes.json" ;;
     bench)     timeout 600 python bench.py > "$OUT/bench.log" 2>&1; tail -3 "$OUT/bench.log" ;;
     profile)   timeout 1200 bash scripts/profile_round.sh > "$OUT/profile.log" 2>&1; tail -5 "$OUT/profile.log" ;;
     *)         echo "unknown step $step" ;;
