@@ -13,10 +13,11 @@
 // With one wave per item (sa_mlp_stream.hip, fp_mlp.hip) such a level is a handful of serial MFMA chains --
 // sem_seg FP1 is 16 items of 256 tile pairs each: 138 us with 16 waves busy on the whole GPU. Here a wave
 // computes tiles t = w, w+4, ... of every layer, so an item's chain is four times shorter and four times as
-// many SIMDs work; the hidden activations are exchanged through LDS as raw accumulator registers (a layer's
-// C/D layout IS the next layer's B-operand layout, sa_mlp.hip), one s_barrier per layer and item.
+// many SIMDs work; the hidden activations are exchanged through LDS in their three-level bf16 operand form
+// (split ONCE by the wave that produced the tile; a layer's C/D layout IS the next layer's operand slot
+// layout, sa_mlp.hip), one s_barrier per layer and item.
 // Every wave consumes DIFFERENT weight tile pairs, so nothing is shared through LDS: each wave streams its
-// own 4 KiB pairs from L2 straight into registers, one pair ahead of the MFMAs (the packed array is the
+// own 6 KiB pairs from L2 straight into registers, one pair ahead of the MFMAs (the packed array is the
 // exact per-wave consumption order). Inputs are gathered by all four waves (redundant L2 reads, negligible
 // at these sizes). The last layer runs with swapped operands: a lane holds 16 samples of one channel ->
 // lane-local max-pool, or 128-byte row segments for the plain store of a feature-propagation layer.
@@ -44,9 +45,10 @@ __global__ __launch_bounds__(kMlpThreads) void coop_mlp_kernel(CoopParams p)
     constexpr int QL = THREE ? Q3 : Q2;                                   // the last layer's tiles per wave
     constexpr bool POOL = GATHER == kGatherGrouped;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4 *act1 = reinterpret_cast<float4 *>(smem);                       // [T1][4][64] float4
-    float4 *act2 = act1 + T1 * 256;                                        // [T2][4][64] (three layers only)
-    float *bias_s = reinterpret_cast<float *>(act2 + (THREE ? T2 * 256 : 0));
+    constexpr int kTileVec = kPairWords / 4;                               // a split activation tile: [e][level][64] vectors
+    u32x4 *act1 = reinterpret_cast<u32x4 *>(smem);                         // [T1] tiles
+    u32x4 *act2 = act1 + T1 * kTileVec;                                    // [T2] tiles (three layers only)
+    float *bias_s = reinterpret_cast<float *>(act2 + (THREE ? T2 * kTileVec : 0));
     const float *b1 = bias_s, *b2 = b1 + T1 * 32, *b3 = b2 + T2 * 32;
     const float *blast = THREE ? b3 : b2;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, s = lane & 31;
@@ -56,37 +58,39 @@ __global__ __launch_bounds__(kMlpThreads) void coop_mlp_kernel(CoopParams p)
 
     // ---- this wave's weight stream: pair number 4 * k + w of the packed array, k = 0 .. per_item - 1 per item
     const int per_item = p.ti * Q1 + T1 * Q2 + T2 * Q3;
-    const float4 *wp4 = reinterpret_cast<const float4 *>(p.wp) + (size_t)w * 256 + lane;
-    float4 nx0, nx1, nx2, nx3;                                            // the NEXT pair, in flight
+    const u32x4 *wp4 = reinterpret_cast<const u32x4 *>(p.wp) + (size_t)w * kTileVec + lane;
+    u32x4 nx0, nx1, nx2, nx3, nx4, nx5;                                   // the NEXT pair, in flight: [e][level]
     int k = 0;                                                            // pair counter within the item
     auto issue = [&]() __attribute__((always_inline)) {
-        const float4 *q = wp4 + (size_t)(k == per_item ? 0 : k) * 1024;  // 4 pairs * 256 float4 per step; wraps to the next item
-        nx0 = q[0]; nx1 = q[64]; nx2 = q[128]; nx3 = q[192];
+        const u32x4 *q = wp4 + (size_t)(k == per_item ? 0 : k) * (4 * kTileVec);   // 4 pairs per step; wraps to the next item
+        nx0 = q[0]; nx1 = q[64]; nx2 = q[128]; nx3 = q[192]; nx4 = q[256]; nx5 = q[320];
     };
 #define PN2_COOP_PAIR(SWAP, ACT, ACC)                                                                              \
     do {                                                                                                           \
-        const float wv_[16] = {nx0.x, nx0.y, nx0.z, nx0.w, nx1.x, nx1.y, nx1.z, nx1.w,                             \
-                               nx2.x, nx2.y, nx2.z, nx2.w, nx3.x, nx3.y, nx3.z, nx3.w};                            \
+        const u32x4 w0_[3] = {nx0, nx1, nx2}, w1_[3] = {nx3, nx4, nx5};                                            \
         ++k;                                                                                                       \
         issue();                                                                                                   \
-        _Pragma("unroll") for (int v_ = 0; v_ < 16; ++v_)                                                          \
-            ACC = (SWAP) ? __builtin_amdgcn_mfma_f32_32x32x2f32((ACT)[v_], wv_[v_], ACC, 0, 0, 0)                    \
-                         : __builtin_amdgcn_mfma_f32_32x32x2f32(wv_[v_], (ACT)[v_], ACC, 0, 0, 0);                   \
+        ACC = mma_x6<SWAP>(w0_, (ACT).p[0], ACC);                                                                  \
+        ACC = mma_x6<SWAP>(w1_, (ACT).p[1], ACC);                                                                  \
     } while (0)
     issue();
 
-    auto act_load = [&](const float4 *act, int u) __attribute__((always_inline)) -> f32x16 {
-        const float4 *a = act + u * 256 + lane;
-        const float4 r0 = a[0], r1 = a[64], r2 = a[128], r3 = a[192];
-        f32x16 x = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+    auto act_load = [&](const u32x4 *act, int u) __attribute__((always_inline)) -> ActSplit {
+        const u32x4 *a = act + u * kTileVec + lane;
+        ActSplit x;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) x.p[e][l] = a[(e * 3 + l) * 64];
         return x;
     };
-    auto act_store = [&](float4 *act, int t, const f32x16 &x) __attribute__((always_inline)) {
-        float4 *a = act + t * 256 + lane;
-        a[0] = make_float4(x[0], x[1], x[2], x[3]);
-        a[64] = make_float4(x[4], x[5], x[6], x[7]);
-        a[128] = make_float4(x[8], x[9], x[10], x[11]);
-        a[192] = make_float4(x[12], x[13], x[14], x[15]);
+    auto act_store = [&](u32x4 *act, int t, const f32x16 &v) __attribute__((always_inline)) {
+        const ActSplit x = split_act(v);
+        u32x4 *a = act + t * kTileVec + lane;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) a[(e * 3 + l) * 64] = x.p[e][l];
     };
 
     const int parts = POOL ? (p.nsample + 31) / 32 : 1;
@@ -187,8 +191,9 @@ __global__ __launch_bounds__(kMlpThreads) void coop_mlp_kernel(CoopParams p)
             for (int u = 0; u < p.ti; ++u) {
                 f32x16 xn = x;
                 if (u + 1 < p.ti) xn = gather(u + 1);
+                const ActSplit xs = split_act(x);
 #pragma unroll
-                for (int g = 0; g < Q1; ++g) PN2_COOP_PAIR(false, x, a1[g]);
+                for (int g = 0; g < Q1; ++g) PN2_COOP_PAIR(false, xs, a1[g]);
                 x = xn;
             }
 #pragma unroll
@@ -196,15 +201,15 @@ __global__ __launch_bounds__(kMlpThreads) void coop_mlp_kernel(CoopParams p)
             __syncthreads();
 
             // ---- the last layer on `src` (TS input tiles): swapped operands; pool or store -----------------
-            auto last_layer = [&](const float4 *src, const int TS) __attribute__((always_inline)) {
+            auto last_layer = [&](const u32x4 *src, const int TS) __attribute__((always_inline)) {
                 f32x16 acc[QL];
 #pragma unroll
                 for (int g = 0; g < QL; ++g)
 #pragma unroll
                     for (int v = 0; v < 16; ++v) acc[g][v] = 0.0f;
-                f32x16 xa = act_load(src, 0);
+                ActSplit xa = act_load(src, 0);
                 for (int u = 0; u < TS; ++u) {
-                    f32x16 xb = xa;
+                    ActSplit xb = xa;
                     if (u + 1 < TS) xb = act_load(src, u + 1);
 #pragma unroll
                     for (int g = 0; g < QL; ++g) PN2_COOP_PAIR(true, xa, acc[g]);
@@ -241,9 +246,9 @@ __global__ __launch_bounds__(kMlpThreads) void coop_mlp_kernel(CoopParams p)
                 f32x16 a2[Q2];
 #pragma unroll
                 for (int g = 0; g < Q2; ++g) a2[g] = mlp_bias(b2, 4 * g + w, h);
-                f32x16 xa = act_load(act1, 0);
+                ActSplit xa = act_load(act1, 0);
                 for (int u = 0; u < T1; ++u) {
-                    f32x16 xb = xa;
+                    ActSplit xb = xa;
                     if (u + 1 < T1) xb = act_load(act1, u + 1);
 #pragma unroll
                     for (int g = 0; g < Q2; ++g) PN2_COOP_PAIR(false, xa, a2[g]);
@@ -281,7 +286,7 @@ bool mlp_coop_pick(int cin, int nlayers, const int *widths, MlpCoopConfig &cfg)
         if (widths[i] < 1 || widths[i] > 1024) return false;
         q[i] = (widths[i] + 127) / 128;
     }
-    // hidden activations live in LDS: 4 KiB per 32-channel tile
+    // hidden activations live in LDS: 6 KiB per 32-channel tile (three bf16 levels)
     const int hidden_tiles = 4 * q[0] + (nlayers == 3 ? 4 * q[1] : 0);
     if (hidden_tiles > 24) return false;
     cfg = {(cin + 31) / 32, q[0], q[1], q[2]};
@@ -292,7 +297,7 @@ static long long coop_pairs(const MlpCoopConfig &c)
 {
     return 4ll * ((long long)c.ti * c.q1 + 4ll * c.q1 * c.q2 + 4ll * c.q2 * c.q3);
 }
-size_t mlp_coop_w_floats(const MlpCoopConfig &c) { return (size_t)coop_pairs(c) * 1024; }
+size_t mlp_coop_w_floats(const MlpCoopConfig &c) { return (size_t)coop_pairs(c) * kPairWords; }
 size_t mlp_coop_b_floats(const MlpCoopConfig &c) { return (size_t)(4 * (c.q1 + c.q2 + c.q3)) * 32; }
 
 // krow: permutation of the first layer's weight rows (kernel channel order -> caller's row), or nullptr
@@ -306,7 +311,7 @@ void mlp_coop_pack(const MlpCoopConfig &c, int cin, int nlayers, const int *widt
         for (int u = 0; u < tin[L]; ++u)                       // input tiles outermost, then the wave's tile groups,
             for (int g = 0; g < qq[L]; ++g)                    // then the four waves: pair 4k + w belongs to wave w
                 for (int wv = 0; wv < 4; ++wv)
-                    wp = mlp_pack_pair(wp, ws[L], kin[L], widths[L], 4 * g + wv, u, L == 0 ? krow : nullptr);
+                    wp = mlp_pack_pair_x6(wp, ws[L], kin[L], widths[L], 4 * g + wv, u, L == 0 ? krow : nullptr);
     float *bp = bpacked;
     for (int L = 0; L < 3; ++L)
         for (int t = 0; t < 4 * qq[L]; ++t)
@@ -320,7 +325,7 @@ void mlp_coop_pack(const MlpCoopConfig &c, int cin, int nlayers, const int *widt
 template <int GATHER, int Q1, int Q2, int Q3>
 static int launch_coop(const CoopParams &p, long long units, hipStream_t st)
 {
-    const size_t lds = sizeof(float4) * 256 * (size_t)(4 * Q1 + (Q3 > 0 ? 4 * Q2 : 0)) + sizeof(float) * 32 * (size_t)(4 * (Q1 + Q2 + Q3));
+    const size_t lds = sizeof(float) * kPairWords * (size_t)(4 * Q1 + (Q3 > 0 ? 4 * Q2 : 0)) + sizeof(float) * 32 * (size_t)(4 * (Q1 + Q2 + Q3));
     auto kern = coop_mlp_kernel<GATHER, Q1, Q2, Q3>;
     if (int rc = allow_dynamic_lds(kern, lds)) return rc;
     long long blocks = units < 512 ? units : 512;

@@ -12,7 +12,8 @@
 // 32-channel tile at a time straight into the layer-1 MFMA operand registers (weighted sum in the
 // reference's order (p1*w1 + p2*w2) + p3*w3, skip-link channels appended), and runs the layer stack with
 // the machinery of the streamed-weights SA kernel (sa_mlp_stream.hip: activations chained in accumulator
-// registers, weight tile pairs streamed through a double-buffered LDS stage shared by the four waves,
+// registers between layers in their three-level bf16 operand form, weight tile pairs streamed through a
+// double-buffered LDS stage shared by the four waves,
 // the LAST layer with swapped MFMA operands so that a lane holds 16 points of one output channel). The
 // epilogue is a plain store of bias + ReLU instead of a max-pool: 128 contiguous bytes per half wave.
 // Batch norm is folded into the weights by the caller (inference), like pn2_sa_mlp3_maxpool.
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(kMlpThreads) void fp_mlp_stream_kernel(int n, int m
                                                                     float *__restrict__ out)
 {
     constexpr int TB = T1 + T2 + T3;
-    __shared__ __attribute__((aligned(16))) float4 wbuf[2][kS * 256];
+    __shared__ __attribute__((aligned(16))) u32x4 wbuf[2][kStageVec];
     __shared__ float bias_s[TB * 32];
     const float *b1 = bias_s, *b2 = b1 + T1 * 32, *b3 = b2 + T2 * 32;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, s = lane & 31;
@@ -53,18 +54,18 @@ __global__ __launch_bounds__(kMlpThreads) void fp_mlp_stream_kernel(int n, int m
     const int l1_pairs = pad_to_stage(ti * T1);
     const int stages_per_item = (l1_pairs + T2 * T1 + T3 * T2) / kS;
     int stage = 0;
-    float4 stg0, stg1, stg2, stg3;
-    static_assert(kS == 4, "the staging registers are spelled out for four pairs per stage");
+    u32x4 stg0, stg1, stg2, stg3, stg4, stg5;
+    static_assert(kStageVec == 6 * kMlpThreads, "the staging registers are spelled out for six vectors per thread");
     static_assert((T2 * T1) % kS == 0 && (T3 * T2) % kS == 0, "layers must start on stage boundaries");
 #define PN2_STREAM_ISSUE(st)                                                                                           \
     do {                                                                                                               \
-        const float4 *src_ = reinterpret_cast<const float4 *>(wstream) + (size_t)((st) % stages_per_item) * (kS * 256) + tid; \
-        stg0 = src_[0]; stg1 = src_[256]; stg2 = src_[512]; stg3 = src_[768];                                          \
+        const u32x4 *src_ = reinterpret_cast<const u32x4 *>(wstream) + (size_t)((st) % stages_per_item) * kStageVec + tid; \
+        stg0 = src_[0]; stg1 = src_[256]; stg2 = src_[512]; stg3 = src_[768]; stg4 = src_[1024]; stg5 = src_[1280];   \
     } while (0)
 #define PN2_STREAM_COMMIT(st)                                                                                          \
     do {                                                                                                               \
-        float4 *dst_ = wbuf[(st) & 1] + tid;                                                                           \
-        dst_[0] = stg0; dst_[256] = stg1; dst_[512] = stg2; dst_[768] = stg3;                                          \
+        u32x4 *dst_ = wbuf[(st) & 1] + tid;                                                                            \
+        dst_[0] = stg0; dst_[256] = stg1; dst_[512] = stg2; dst_[768] = stg3; dst_[1024] = stg4; dst_[1280] = stg5;   \
     } while (0)
 #define PN2_NEXT_STAGE()                                                                                               \
     do {                                                                                                               \
@@ -143,16 +144,18 @@ __global__ __launch_bounds__(kMlpThreads) void fp_mlp_stream_kernel(int n, int m
         for (int u = 0; u < ti; ++u) {
             f32x16 xn = x;
             if (u + 1 < ti) xn = gather(u + 1);
+            const ActSplit xs = split_act(x);
 #pragma unroll
             for (int t = 0; t < T1; ++t) {
-                h1[t] = stream_pair<false>(wbuf[stage & 1], slot, lane, x, h1[t]);
+                h1[t] = stream_pair<false>(wbuf[stage & 1], slot, lane, xs, h1[t]);
                 if (++slot == kS) { slot = 0; PN2_NEXT_STAGE(); }
             }
             x = xn;
         }
         if (slot != 0) PN2_NEXT_STAGE();
+        ActSplit s1[T1];
 #pragma unroll
-        for (int t = 0; t < T1; ++t) h1[t] = mlp_relu(h1[t]);
+        for (int t = 0; t < T1; ++t) s1[t] = split_act(mlp_relu(h1[t]));
 
         // the last layer: operands swapped -> register v of lane (c, hh) holds point mlp_chan(v, hh) of the
         // item, channel 32t + c; bias + ReLU and a plain store (128 contiguous bytes per half wave)
@@ -175,22 +178,22 @@ __global__ __launch_bounds__(kMlpThreads) void fp_mlp_stream_kernel(int n, int m
                 for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
 #pragma unroll
                 for (int u = 0; u < T1; ++u) {
-                    acc = stream_pair<true>(wbuf[stage & 1], (t * T1 + u) % kS, lane, h1[u], acc);
+                    acc = stream_pair<true>(wbuf[stage & 1], (t * T1 + u) % kS, lane, s1[u], acc);
                     if ((t * T1 + u) % kS == kS - 1) PN2_NEXT_STAGE();
                 }
                 store_tile(t, acc, b2);
             }
         } else {
-            f32x16 h2[T2];
+            ActSplit s2[T2];
 #pragma unroll
             for (int t = 0; t < T2; ++t) {
                 f32x16 acc = mlp_bias(b2, t, h);
 #pragma unroll
                 for (int u = 0; u < T1; ++u) {
-                    acc = stream_pair<false>(wbuf[stage & 1], (t * T1 + u) % kS, lane, h1[u], acc);
+                    acc = stream_pair<false>(wbuf[stage & 1], (t * T1 + u) % kS, lane, s1[u], acc);
                     if ((t * T1 + u) % kS == kS - 1) PN2_NEXT_STAGE();
                 }
-                h2[t] = mlp_relu(acc);
+                s2[t] = split_act(mlp_relu(acc));
             }
 #pragma unroll
             for (int t = 0; t < (T3 ? T3 : 1); ++t) {
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(kMlpThreads) void fp_mlp_stream_kernel(int n, int m
                 for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
 #pragma unroll
                 for (int u = 0; u < T2; ++u) {
-                    acc = stream_pair<true>(wbuf[stage & 1], (t * T2 + u) % kS, lane, h2[u], acc);
+                    acc = stream_pair<true>(wbuf[stage & 1], (t * T2 + u) % kS, lane, s2[u], acc);
                     if ((t * T2 + u) % kS == kS - 1) PN2_NEXT_STAGE();
                 }
                 store_tile(t, acc, b3);
@@ -239,7 +242,7 @@ static int launch_fp(const FpConfig &c, long long rows, int n, int m, int c2, in
 {
     const long long groups = (rows + 31) / 32;
     long long blocks = (groups + 3) / 4;
-    if (blocks > 512) blocks = 512;                               // persistent: every workgroup streams the weights
+    if (blocks > 256) blocks = 256;                               // persistent, one workgroup per CU: every workgroup streams the weights
     return launch((fp_mlp_stream_kernel<T1, T2, T3>), dim3((unsigned)blocks), dim3(kMlpThreads), 0, st, n, m, c2, c1, cout,
                   rows, c.ti, points2, points1, idx, dist, wp, bp, out);
 }
@@ -264,7 +267,7 @@ extern "C" int pn2_fp_mlp_config(int c2, int c1, int nlayers, const int *widths,
     FpConfig c;
     if (!fp_pick(c2 + c1, nlayers, widths, c)) return PN2_E_TOO_LARGE;
     if (tiles4) { tiles4[0] = c.ti; tiles4[1] = c.t1; tiles4[2] = c.t2; tiles4[3] = c.t3; }
-    if (w_floats) *w_floats = fp_pairs(c) * 1024;
+    if (w_floats) *w_floats = fp_pairs(c) * kPairWords;
     if (b_floats) *b_floats = (long long)(c.t1 + c.t2 + c.t3) * 32;
     return PN2_OK;
 }
@@ -288,13 +291,13 @@ extern "C" int pn2_fp_mlp_pack(int c2, int c1, int nlayers, const int *widths, i
     if (!fp_pick(cin, nlayers, widths, c)) return PN2_E_TOO_LARGE;
     float *wp = wpacked;
     for (int u = 0; u < c.ti; ++u)
-        for (int t = 0; t < c.t1; ++t) wp = mlp_pack_pair(wp, w[0], cin, widths[0], t, u, nullptr);
+        for (int t = 0; t < c.t1; ++t) wp = mlp_pack_pair_x6(wp, w[0], cin, widths[0], t, u, nullptr);
     for (int i = c.ti * c.t1; i < pad_to_stage(c.ti * c.t1); ++i)
-        for (int j = 0; j < 1024; ++j) *wp++ = 0.0f;
+        for (int j = 0; j < kPairWords; ++j) *wp++ = 0.0f;
     for (int t = 0; t < c.t2; ++t)
-        for (int u = 0; u < c.t1; ++u) wp = mlp_pack_pair(wp, w[1], widths[0], widths[1], t, u, nullptr);
+        for (int u = 0; u < c.t1; ++u) wp = mlp_pack_pair_x6(wp, w[1], widths[0], widths[1], t, u, nullptr);
     for (int t = 0; t < c.t3; ++t)
-        for (int u = 0; u < c.t2; ++u) wp = mlp_pack_pair(wp, w[2], widths[1], widths[2], t, u, nullptr);
+        for (int u = 0; u < c.t2; ++u) wp = mlp_pack_pair_x6(wp, w[2], widths[1], widths[2], t, u, nullptr);
     const int tout[3] = {c.t1, c.t2, c.t3};
     float *bp = bpacked;
     for (int L = 0; L < 3; ++L)

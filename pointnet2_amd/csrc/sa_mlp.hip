@@ -9,27 +9,37 @@
 // reference (and a plain PyTorch port) materialises the (b, m, nsample, C) tensor of every layer in
 // HBM: 128-640 MB per SA level in the segmentation configs. Here NOTHING between the idx tensor and
 // the (b, m, C3) result leaves the CU: rows are gathered straight into MFMA operand registers, the
-// activations of all three layers stay in accumulator registers, the max runs over lanes.
+// activations of all three layers stay in registers, the max runs over lanes.
 // Batch norm is folded into the weights by the caller (inference statistics): W' = W*s, b' = (b-mu)*s+beta.
 //
-// Arithmetic: v_mfma_f32_32x32x2_f32 -- fp32 inputs, fp32 accumulate, exact fp32 products (an fma
-// chain), 64 FLOP/clk/SIMD = the fp32 peak of the chip (157 TFLOP/s). No reduced precision.
+// Arithmetic: fp32 results on the bf16 matrix pipe. Every fp32 operand is the exact sum of three bf16 values
+// (nearest-even residuals: 8 + 8 + 8 significant bits), a product a.b is evaluated as the six bf16 x bf16 terms
+// a1b1, a1b2, a2b1, a1b3, a2b2, a3b1 (each exact in the fp32 accumulator; the three dropped terms are below 2^-24
+// relative), i.e. six v_mfma_f32_32x32x16_bf16 per 16 contraction indices where the fp32-input
+// v_mfma_f32_32x32x2_f32 needs eight at twice the cycles each: 2.7x fewer matrix-pipe cycles for the same
+// accuracy (measured against an fp64 evaluation: the same error as an fp32 fma chain, tests/test_sa_mlp_gpu.py).
+// The weights are split on the host when they are packed (three levels stored side by side, 6 bytes per weight);
+// the activations are split in registers right after each layer's ReLU: 5.5 VALU operations per value
+// (v_cvt_pk_bf16_f32, shift/mask back to fp32, subtract, twice) -- once per value and layer, amortised over the
+// layer's output width.
 //
 // Formulation. One wave owns 32 samples (one centroid at nsample = 32) and computes the TRANSPOSED
 // layer  H^T (channels x samples) = W^T (Cout x Cin) . X^T (Cin x samples):
-//   MFMA "A" operand = a 32x2 block of W^T: lane l supplies W[k][n = 32t + (l & 31)], k chosen below;
-//   MFMA "B" operand = a 2x32 block of X^T: lane l supplies X[sample = l & 31][k];
+//   MFMA "A" operand = a 32x16 block of W^T: lane l supplies W[k][n = 32t + (l & 31)] for eight k (slots j = 0..7
+//                      of lane half l >> 5), chosen below;
+//   MFMA "B" operand = a 16x32 block of X^T: lane l supplies X[sample = l & 31][k], the same eight k;
 //   C/D: lane l, register v holds H^T[channel 8(v>>2) + 4(l>>5) + (v&3)][sample l & 31].
-// The contraction index k may be visited in ANY order as long as A and B agree. Visiting, at step v of
-// input tile u, k = 32u + 8(v>>2) + (v&3) in lanes 0-31 and k + 4 in lanes 32-63 makes the B operand
-// of step v EXACTLY accumulator register v of the previous layer's tile u: the activations never move
-// between layers -- no LDS round trip, no shuffles. The weights are stored pre-permuted to match
-// (pn2_sa_mlp3_pack), in LDS, laid out so that one ds_read_b128 per lane feeds four MFMAs.
-// The LAST layer swaps the two MFMA operands (their lane maps are the same: index l & 31, k slot
-// l >> 5), which yields the untransposed H (samples x channels): a lane then holds 16 SAMPLES of one
+// The contraction index k may be visited in ANY order as long as A and B agree. Giving slot j of K16 step e
+// (e = 0, 1) of input tile u the index k = 32u + 8((8e + j) >> 2) + 4(l >> 5) + (j & 3) makes the B operand of step e
+// EXACTLY accumulator registers 8e .. 8e + 7 of the previous layer's tile u (after the split into levels): the
+// activations never move between layers -- no LDS round trip, no shuffles. The weights are stored pre-permuted to
+// match (pn2_sa_mlp3_pack), in LDS, one ds_read_b128 per lane, level and K16 step.
+// The LAST layer swaps the two MFMA operands (their lane maps are the same: index l & 31, slots by l >> 5),
+// which yields the untransposed H (samples x channels): a lane then holds 16 SAMPLES of one
 // channel, so the max-pool is 15 lane-local v_max plus one exchange with lane l ^ 32, and bias + ReLU
 // are applied once to the pooled value (x -> relu(x + b) is monotone, so max and it commute exactly).
 // Pooling across lanes instead (the first version) cost 5 cross-lane steps for each of 64 registers.
+// Eight waves (two per SIMD) share one copy of the weights in LDS.
 #include "sa_mlp_common.h"
 
 #include <stdlib.h>
@@ -37,31 +47,32 @@
 
 namespace pn2 {
 
-// One dense layer on the wave's 32 samples: out[t] = relu(bias + sum_u W^T[t][u] . in[u]), 16 MFMAs per
-// (t, u) pair. The weights of pair i + 1 are read from LDS while the MFMAs of pair i run (the compiler
-// fence keeps the prefetch where it is written; left alone, hipcc hoists EVERY weight read of the layer
-// to its top and runs out of registers). `quartets` = leading register quartets of `in` that can be
-// non-zero (4, except for a narrow first layer). MAXACC: out[t] = max(out[t], result) unless `first`.
-// LAST: operands swapped (see the header): out[t] holds raw sums H[sample][channel l & 31], no bias, no
-// ReLU, and is max-accumulated over the centroid's 32-sample groups.
+// One dense layer on the wave's 32 samples: out[t] = relu(bias + sum_u W^T[t][u] . in[u]), 12 bf16 MFMAs per
+// (t, u) pair (two K16 steps of six). The weights of step i + 1 are read from LDS while the MFMAs of step i
+// run (the compiler fence keeps the prefetch where it is written; left alone, hipcc hoists EVERY weight read
+// of the layer to its top and runs out of registers). `ksteps` = K16 steps of an input tile that can be
+// non-zero (2, except for a narrow first layer). LAST: operands swapped (see the header): out[t] holds raw
+// sums H[sample][channel l & 31], no bias, no ReLU, max-accumulated over the centroid's 32-sample groups
+// unless `first`.
 template <int TOUT, int TIN, bool LAST>
-__device__ __forceinline__ void mlp_layer(const float *wp, const float *bp, const f32x16 (&in)[TIN], f32x16 (&out)[TOUT],
-                                          int lane, int h, int quartets, bool first)
+__device__ __forceinline__ void mlp_layer(const float *wp, const float *bp, const ActSplit (&in)[TIN], f32x16 (&out)[TOUT],
+                                          int lane, int h, int ksteps, bool first)
 {
-    const float4 *w4 = reinterpret_cast<const float4 *>(wp) + lane;
-    float4 cur[4];
+    const u32x4 *w4 = reinterpret_cast<const u32x4 *>(wp) + lane;
+    u32x4 cur[3];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cur[q] = w4[q * 64];
+    for (int l = 0; l < 3; ++l) cur[l] = w4[l * 64];
     f32x16 acc;
+    constexpr int kSteps = TOUT * TIN * 2;
 #pragma unroll
-    for (int i = 0; i < TOUT * TIN; ++i) {
-        const int t = i / TIN, u = i % TIN;
-        float4 nxt[4];
-        if (i + 1 < TOUT * TIN) {
+    for (int i = 0; i < kSteps; ++i) {
+        const int pair = i >> 1, e = i & 1, t = pair / TIN, u = pair % TIN;
+        u32x4 nxt[3];
+        if (i + 1 < kSteps) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) nxt[q] = w4[(i + 1) * 256 + q * 64];
+            for (int l = 0; l < 3; ++l) nxt[l] = w4[((i + 1) * 3 + l) * 64];
         }
-        if (u == 0) {
+        if (u == 0 && e == 0) {
             if (LAST) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
@@ -70,43 +81,28 @@ __device__ __forceinline__ void mlp_layer(const float *wp, const float *bp, cons
             }
         }
         asm volatile("" ::: "memory");
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (q < quartets) {
-                if (LAST) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(in[u][4 * q + 0], cur[q].x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(in[u][4 * q + 1], cur[q].y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(in[u][4 * q + 2], cur[q].z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(in[u][4 * q + 3], cur[q].w, acc, 0, 0, 0);
-                } else {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].x, in[u][4 * q + 0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].y, in[u][4 * q + 1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].z, in[u][4 * q + 2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[q].w, in[u][4 * q + 3], acc, 0, 0, 0);
-                }
-            }
-        }
-        if (u == TIN - 1) {
+        if (e < ksteps) acc = mma_x6<LAST>(cur, in[u].p[e], acc);
+        if (u == TIN - 1 && e == 1) {
             if (!LAST) {
                 out[t] = mlp_relu(acc);
             } else if (first) {
                 out[t] = acc;
             } else {
 #pragma unroll
-                for (int v = 0; v < 16; ++v) out[t][v] = fmaxf(out[t][v], acc[v]);
+                for (int v = 0; v < 16; ++v) out[t][v] = vmax(out[t][v], acc[v]);
             }
         }
-        if (i + 1 < TOUT * TIN) {
+        if (i + 1 < kSteps) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+            for (int l = 0; l < 3; ++l) cur[l] = nxt[l];
         }
     }
 }
 
 // T1, T2, T3: output tiles (32 channels each) of the three layers; the input is one tile (Cin <= 32).
 // SPAN: samples per centroid inside one 32-sample group (32, or 16 when nsample = 16).
-template <int T1, int T2, int T3, int SPAN>
-__global__ __launch_bounds__(kMlpThreads) void sa_mlp3_kernel(int n, int m, int nsample, int cfeat, int c3, long long rows,
+template <int T1, int T2, int T3, int SPAN, int NT>
+__global__ __launch_bounds__(NT) void sa_mlp3_kernel(int n, int m, int nsample, int cfeat, int c3, long long rows,
                                                               const float *__restrict__ xyz,
                                                               const float *__restrict__ new_xyz,
                                                               const float *__restrict__ points,
@@ -126,8 +122,8 @@ __global__ __launch_bounds__(kMlpThreads) void sa_mlp3_kernel(int n, int m, int 
         const size_t bf = mlp_b_floats(T1) + mlp_b_floats(T2) + mlp_b_floats(T3);
         const float4 *src = reinterpret_cast<const float4 *>(wpacked);
         float4 *dst = reinterpret_cast<float4 *>(w1);
-        for (size_t i = threadIdx.x; i < wf / 4; i += kMlpThreads) dst[i] = src[i];
-        for (size_t i = threadIdx.x; i < bf; i += kMlpThreads) b1[i] = bpacked[i];
+        for (size_t i = threadIdx.x; i < wf / 4; i += NT) dst[i] = src[i];
+        for (size_t i = threadIdx.x; i < bf; i += NT) b1[i] = bpacked[i];
     }
     __syncthreads();
 
@@ -135,9 +131,10 @@ __global__ __launch_bounds__(kMlpThreads) void sa_mlp3_kernel(int n, int m, int 
     const int h = lane >> 5, s = lane & 31;
     const int cin = 3 + cfeat;
     const int quartets1 = (cin + 7) / 8;                 // register quartet q covers channels 8q .. 8q+7
+    const int ksteps1 = cin > 16 ? 2 : 1;                // K16 step e covers channels 16e .. 16e+15
     const int parts = SPAN == 32 ? nsample / 32 : 1;     // 32-sample groups per centroid
-    const long long wave = (long long)blockIdx.x * (kMlpThreads / 64) + (threadIdx.x >> 6);
-    const long long nwaves = (long long)gridDim.x * (kMlpThreads / 64);
+    const long long wave = (long long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * (NT / 64);
     const long long groups = SPAN == 32 ? rows : (rows + 1) / 2;
 
     // The gather is software-pipelined over the work items (a 32-sample group of a centroid): the index
@@ -187,15 +184,29 @@ __global__ __launch_bounds__(kMlpThreads) void sa_mlp3_kernel(int n, int m, int 
         const bool more = gn < groups;
         int pn = 0;
         if (more) pn = load_index(gn, partn);
-        f32x16 in0[1], h1[T1], h2[T2];
+        ActSplit s0[1], s1[T1], s2[T2];
+        {
+            f32x16 in0;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) in0[0][v] = __fsub_rn(x0[v], cen[v]);      // channels 0-2 live in registers 0-2 of lanes 0-31
+            for (int v = 0; v < 4; ++v) in0[v] = __fsub_rn(x0[v], cen[v]);      // channels 0-2 live in registers 0-2 of lanes 0-31
 #pragma unroll
-        for (int v = 4; v < 16; ++v) in0[0][v] = x0[v];
-        mlp_layer<T1, 1, false>(w1, b1, in0, h1, lane, h, quartets1, true);
-        mlp_layer<T2, T1, false>(w2, b2, h1, h2, lane, h, 4, true);
+            for (int v = 4; v < 16; ++v) in0[v] = x0[v];
+            s0[0] = split_act(in0);
+        }
+        {
+            f32x16 h1[T1];
+            mlp_layer<T1, 1, false>(w1, b1, s0, h1, lane, h, ksteps1, true);
+#pragma unroll
+            for (int t = 0; t < T1; ++t) s1[t] = split_act(h1[t]);
+        }
+        {
+            f32x16 h2[T2];
+            mlp_layer<T2, T1, false>(w2, b2, s1, h2, lane, h, 2, true);
+#pragma unroll
+            for (int t = 0; t < T2; ++t) s2[t] = split_act(h2[t]);
+        }
         if (more) x0 = load_x0(gn, pn, cen);
-        mlp_layer<T3, T2, true>(w3, b3, h2, best, lane, h, 4, part == 0);
+        mlp_layer<T3, T2, true>(w3, b3, s2, best, lane, h, 2, part == 0);
         if (!last_part) { part = partn; continue; }
         const long long row = item_row(g);
         // Pool: lane l holds channel 32t + (l & 31) for the samples 8(v >> 2) + 4(l >> 5) + (v & 3), v = 0..15
@@ -228,13 +239,56 @@ __global__ __launch_bounds__(kMlpThreads) void sa_mlp3_kernel(int n, int m, int 
     }
 }
 
+// ---- host side: bf16 levels of the weights ------------------------------------------------------------------
+static unsigned short bf16_nearest_even(float f)
+{
+    unsigned int u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);      // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+static float bf16_value(unsigned short b)
+{
+    const unsigned int u = (unsigned int)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+void mlp_split_weight(float w, unsigned short out[3])
+{
+    out[0] = bf16_nearest_even(w);
+    const float r1 = w - bf16_value(out[0]);              // exact: the residual of a nearest rounding fits in fp32
+    out[1] = bf16_nearest_even(r1);
+    const float r2 = r1 - bf16_value(out[1]);
+    out[2] = bf16_nearest_even(r2);
+}
+
+// value for K16 step e, level, lane l, slot j = level of W[krow(32u + mlp_chan(8e + j, l >> 5))][32t + (l & 31)]
+float *mlp_pack_pair_x6(float *wp, const float *w, int kin, int nout, int t, int u, const int *krow)
+{
+    unsigned short *o = reinterpret_cast<unsigned short *>(wp);
+    for (int e = 0; e < 2; ++e)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int k = 32 * u + mlp_chan(8 * e + j, lane >> 5), nn = 32 * t + (lane & 31);
+                const float val = (k < kin && nn < nout) ? w[(size_t)(krow ? krow[k] : k) * nout + nn] : 0.0f;
+                unsigned short lv[3];
+                mlp_split_weight(val, lv);
+                for (int level = 0; level < 3; ++level) o[(((e * 3 + level) * 64 + lane) * 8) + j] = lv[level];
+            }
+    return wp + kPairWords;
+}
+
 struct MlpConfig { int t1, t2, t3; };
 
 // smallest instantiated tile configuration that covers (c1, c2, c3); padded channels carry zero
 // weights and zero bias, cost MFMA time and never reach memory
 static bool mlp_pick(int c1, int c2, int c3, MlpConfig &cfg)
 {
-    static const MlpConfig kConfigs[] = {{1, 1, 2}, {2, 2, 4}, {2, 3, 4}, {4, 4, 4}};
+    static const MlpConfig kConfigs[] = {{1, 1, 2}, {2, 2, 4}, {2, 3, 4}};
     for (const MlpConfig &c : kConfigs)
         if (c1 <= 32 * c.t1 && c2 <= 32 * c.t2 && c3 <= 32 * c.t3) { cfg = c; return true; }
     return false;
@@ -253,12 +307,15 @@ static int launch_mlp(int b, int n, int m, int nsample, int cfeat, int c3, const
     const long long rows = (long long)b * m;
     const bool half = nsample == 16;
     const long long groups = half ? (rows + 1) / 2 : rows;
-    long long blocks = (groups + 3) / 4;
-    long long cap = 512;                                  // persistent: every workgroup stages the weights once
+    // eight waves share one copy of the weights (two per SIMD: one wave's operand splitting overlaps the other's
+    // MFMAs) when a wave fits in 256 registers; persistent: every workgroup stages the weights once
+    constexpr int NT = 512;
+    long long blocks = (groups + NT / 64 - 1) / (NT / 64);
+    long long cap = 256;
     if (blocks > cap) blocks = cap;
-    auto kern = half ? sa_mlp3_kernel<T1, T2, T3, 16> : sa_mlp3_kernel<T1, T2, T3, 32>;
+    auto kern = half ? sa_mlp3_kernel<T1, T2, T3, 16, NT> : sa_mlp3_kernel<T1, T2, T3, 32, NT>;
     if (int rc = allow_dynamic_lds(kern, lds)) return rc;
-    if (int rc = launch(kern, dim3((unsigned)blocks), dim3(kMlpThreads), lds, st, n, m, nsample, cfeat, c3, rows, xyz, new_xyz,
+    if (int rc = launch(kern, dim3((unsigned)blocks), dim3(NT), lds, st, n, m, nsample, cfeat, c3, rows, xyz, new_xyz,
                        points, idx, wp, bp, out)) return rc;
     return PN2_OK;
 }
@@ -346,17 +403,11 @@ extern "C" int pn2_sa_mlp3_pack(int cin, int c1, int c2, int c3, int nsample, in
     const int tin[3] = {1, cfg.t1, cfg.t2}, tout[3] = {cfg.t1, cfg.t2, cfg.t3};
     float *wp = wpacked, *bp = bpacked;
     for (int L = 0; L < 3; ++L) {
+        // kernel channel order of layer 1: [xyz, features]
+        int krow[32];
+        for (int k = 0; k < 32; ++k) krow[k] = (L == 0 && !xyz_first && k < cin) ? (k < 3 ? cfeat + k : k - 3) : k;
         for (int t = 0; t < tout[L]; ++t)
-            for (int u = 0; u < tin[L]; ++u)
-                for (int q = 0; q < 4; ++q)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int r = 0; r < 4; ++r) {
-                            const int k = 32 * u + mlp_chan(4 * q + r, lane >> 5), nn = 32 * t + (lane & 31);
-                            // kernel channel order of layer 1: [xyz, features]
-                            int row = k;
-                            if (L == 0 && !xyz_first && k < cin) row = k < 3 ? cfeat + k : k - 3;
-                            *wp++ = (k < kin[L] && nn < nout[L]) ? ws[L][(size_t)row * nout[L] + nn] : 0.0f;
-                        }
+            for (int u = 0; u < tin[L]; ++u) wp = mlp_pack_pair_x6(wp, ws[L], kin[L], nout[L], t, u, L == 0 ? krow : nullptr);
         for (int t = 0; t < tout[L]; ++t)
             for (int hh = 0; hh < 2; ++hh)
                 for (int v = 0; v < 16; ++v) {
@@ -401,7 +452,6 @@ extern "C" int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, 
     PN2_MLP_CASE(1, 1, 2);
     PN2_MLP_CASE(2, 2, 4);
     PN2_MLP_CASE(2, 3, 4);
-    PN2_MLP_CASE(4, 4, 4);
 #undef PN2_MLP_CASE
     return PN2_E_TOO_LARGE;
 }

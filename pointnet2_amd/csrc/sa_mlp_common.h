@@ -15,8 +15,8 @@ constexpr int kMlpMaxLds = 150 * 1024;
 // channel (within a 32-tile) that register v of lane-half h holds / must be fed with
 __host__ __device__ __forceinline__ int mlp_chan(int v, int h) { return 8 * (v >> 2) + 4 * h + (v & 3); }
 
-// packed sizes (floats): weights [t][u][q = 4][lane = 64][r = 4] per layer, bias [t][h = 2][v = 16]
-__host__ __device__ __forceinline__ size_t mlp_w_floats(int t_out, int t_in) { return (size_t)t_out * t_in * 1024; }
+// packed sizes (4-byte words): weights [t][u] tile pairs of kPairWords (resident kernel) per layer, bias [t][h = 2][v = 16]
+__host__ __device__ __forceinline__ size_t mlp_w_floats(int t_out, int t_in) { return (size_t)t_out * t_in * 1536; }
 __host__ __device__ __forceinline__ size_t mlp_b_floats(int t_out) { return (size_t)t_out * 32; }
 
 __device__ __forceinline__ f32x16 mlp_bias(const float *bp, int t, int h)
@@ -35,12 +35,76 @@ __device__ __forceinline__ float b3_at(const float *bp, int ch)
     return bp[(t * 2 + hh) * 16 + v];
 }
 
+// (the MLP sources are built with -fno-honor-nans: otherwise hipcc puts a canonicalising v_max x, x, x in front of
+// every fmaxf on an MFMA result -- a third of the kernel's VALU work -- while v_max_f32 returns the non-NaN
+// operand either way. Not inline asm: the MFMA -> VALU read hazard is only handled for instructions the compiler knows.)
+__device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
+
 __device__ __forceinline__ f32x16 mlp_relu(f32x16 x)
 {
 #pragma unroll
-    for (int v = 0; v < 16; ++v) x[v] = fmaxf(x[v], 0.0f);
+    for (int v = 0; v < 16; ++v) x[v] = vmax(x[v], 0.0f);
     return x;
 }
+
+// ---- fp32 products on the bf16 matrix pipe (resident kernel; see the header of sa_mlp.hip) ---------------------
+// An fp32 value is the exact sum of three bf16 values a1 + a2 + a3 (8 significant bits each, round-to-nearest
+// residuals: |a - a1 - a2 - a3| <= 2^-24 |a|). A product a.b is then a1b1 + (a1b2 + a2b1) + (a1b3 + a2b2 + a3b1)
+// up to terms of relative size 2^-24: SIX v_mfma_f32_32x32x16_bf16 (bf16 products are exact in the fp32
+// accumulator) replace EIGHT v_mfma_f32_32x32x2_f32 per 16 contraction indices, at half the cycles each.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kPairWords = 1536;          // one 32x32 tile pair: [e = 2 K16 steps][level = 3][lane = 64][4 words = 8 bf16]
+
+// the three bf16 levels of a 32-channel activation tile: p[e][level] is the MFMA operand of K16 step e
+// (slot j of lane-half h <- register 8e + j, i.e. channel mlp_chan(8e + j, h))
+struct ActSplit { u32x4 p[2][3]; };
+
+__device__ __forceinline__ unsigned int pack_bf16(float lo, float hi)
+{
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));      // v_cvt_pk_bf16_f32, nearest-even
+}
+
+__device__ __forceinline__ ActSplit split_act(const f32x16 &x)
+{
+    ActSplit s;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const float a = x[8 * e + 2 * d], b = x[8 * e + 2 * d + 1];
+            const unsigned int p1 = pack_bf16(a, b);
+            const float ra = __fsub_rn(a, __uint_as_float(p1 << 16)), rb = __fsub_rn(b, __uint_as_float(p1 & 0xffff0000u));
+            const unsigned int p2 = pack_bf16(ra, rb);
+            const float sa = __fsub_rn(ra, __uint_as_float(p2 << 16)), sb = __fsub_rn(rb, __uint_as_float(p2 & 0xffff0000u));
+            s.p[e][0][d] = p1;
+            s.p[e][1][d] = p2;
+            s.p[e][2][d] = pack_bf16(sa, sb);
+        }
+    return s;
+}
+
+// acc += sum over the 16 contraction slots of x * w, six bf16 MFMAs, small terms first. SWAP: the activations are
+// the MFMA "A" operand (last layer: untransposed result), else the weights are.
+template <bool SWAP>
+__device__ __forceinline__ f32x16 mma_x6(const u32x4 (&w)[3], const u32x4 (&x)[3], f32x16 acc)
+{
+#define PN2_MMA(WL, XL)                                                                                              \
+    acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x[XL]), __builtin_bit_cast(bf16x8, w[WL]), acc, 0, 0, 0) \
+               : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[WL]), __builtin_bit_cast(bf16x8, x[XL]), acc, 0, 0, 0)
+    PN2_MMA(0, 2); PN2_MMA(1, 1); PN2_MMA(2, 0); PN2_MMA(0, 1); PN2_MMA(1, 0); PN2_MMA(0, 0);
+#undef PN2_MMA
+    return acc;
+}
+
+// host side: the three bf16 levels of one weight
+void mlp_split_weight(float w, unsigned short out[3]);
+// one 32x32 tile pair of a (kin, nout) row-major weight matrix in the split operand layout (kPairWords words)
+float *mlp_pack_pair_x6(float *wp, const float *w, int kin, int nout, int t, int u, const int *krow);
 
 
 // ---- streamed variant (sa_mlp_stream.hip) ------------------------------------------------------------
@@ -50,22 +114,22 @@ constexpr int kS = kMlpStagePairs;
 
 __host__ __device__ __forceinline__ int pad_to_stage(int pairs) { return (pairs + kS - 1) / kS * kS; }
 
-// 16 MFMAs of one tile pair out of the current LDS stage; SWAP: operands exchanged (last layer)
+constexpr int kStreamThreads = 512;        // sa_mlp_stream.hip: eight waves share one weight stream
+constexpr int kStageVec = kS * kPairWords / 4;          // 16-byte vectors per stage
+
+// 12 MFMAs of one tile pair out of the current LDS stage (three-level bf16 operands, see split_act); SWAP:
+// operands exchanged (last layer)
 template <bool SWAP>
-__device__ __forceinline__ f32x16 stream_pair(const float4 *stage, int slot, int lane, f32x16 act, f32x16 acc)
+__device__ __forceinline__ f32x16 stream_pair(const u32x4 *stage, int slot, int lane, const ActSplit &act, f32x16 acc)
 {
-    const float4 *w4 = stage + slot * 256 + lane;
-    const float4 a0 = w4[0], a1 = w4[64], a2 = w4[128], a3 = w4[192];
-    const float wv[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
-#pragma unroll
-    for (int v = 0; v < 16; ++v)
-        acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(act[v], wv[v], acc, 0, 0, 0)
-                   : __builtin_amdgcn_mfma_f32_32x32x2f32(wv[v], act[v], acc, 0, 0, 0);
+    const u32x4 *w4 = stage + slot * (kPairWords / 4) + lane;
+    u32x4 w0[3] = {w4[0], w4[64], w4[128]};
+    asm volatile("" ::: "memory");            // keeps hipcc from hoisting the reads of later pairs up here (register budget)
+    const u32x4 w1[3] = {w4[192], w4[256], w4[320]};
+    acc = mma_x6<SWAP>(w0, act.p[0], acc);
+    acc = mma_x6<SWAP>(w1, act.p[1], acc);
     return acc;
 }
-
-// one 32x32 tile pair of a (kin, nout) row-major weight matrix in the MFMA operand layout (sa_mlp_stream.hip)
-float *mlp_pack_pair(float *wp, const float *w, int kin, int nout, int t, int u, const int *krow);
 
 struct MlpStreamConfig { int ti, t1, t2, t3; };
 bool mlp_stream_pick(int cin, int c1, int c2, int c3, MlpStreamConfig &cfg);

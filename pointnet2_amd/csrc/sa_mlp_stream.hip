@@ -3,14 +3,16 @@
 // (264 KB of fp32 weights), reference models/pointnet2_*: pointnet_sa_module(... mlp=[128,128,256] ...).
 //
 // The weights are STREAMED: the packed array is the exact sequence of 32x32 tile pairs one work item
-// (32 samples through the three layers) consumes, cut into stages of kMlpStagePairs pairs (16 KiB).
-// The four waves of a workgroup walk their items in lockstep; while they run the MFMAs of stage s out
-// of one LDS buffer, every thread holds its 64 bytes of stage s + 1 in registers (global loads issued a
-// stage earlier, i.e. ~4000 cycles of MFMA work ago), writes them to the other buffer and one
-// s_barrier flips the buffers. All workgroups stream the same bytes, so the source is the L2.
+// (32 samples through the three layers) consumes, in the three-level bf16 operand layout of sa_mlp.hip
+// (kPairWords words a pair), cut into stages of kMlpStagePairs pairs (24 KiB).
+// The eight waves of a workgroup (one workgroup per CU: ONE stream per CU) walk their items in lockstep;
+// while they run the MFMAs of stage s out of one LDS buffer, every thread holds its 48 bytes of stage
+// s + 1 in registers (global loads issued a stage earlier, i.e. ~3000 cycles of MFMA work ago), writes
+// them to the other buffer and one s_barrier flips the buffers. All workgroups stream the same bytes,
+// so the source is the L2.
 // Differences to the resident kernel, all forced by the register budget (256 VGPRs at 2 waves/SIMD):
-//   * layer 1 walks the INPUT tiles in the outer loop (only one 32-channel tile of gathered inputs is
-//     alive, all T1 output accumulators are); input channels are ordered [features, xyz] so that a
+//   * layers 1 and 2 walk the INPUT tiles in the outer loop (only one 32-channel tile of inputs is alive in
+//     its three-level form, all output accumulators are); input channels are ordered [features, xyz] so that a
 //     lane's four channels of a register quartet are one aligned 16-byte load when cfeat % 4 == 0;
 //   * the last layer's 16 registers of a tile are max-reduced right away (they hold 16 samples of one
 //     channel, see sa_mlp.hip), so the running maximum over a centroid's sample groups is T3 registers.
@@ -21,37 +23,37 @@
 namespace pn2 {
 
 template <int T1, int T2, int T3>
-__global__ __launch_bounds__(kMlpThreads) void sa_mlp3_stream_kernel(int n, int m, int nsample, int cfeat, int c3, long long rows,
-                                                                     int ti, const float *__restrict__ xyz,
-                                                                     const float *__restrict__ new_xyz,
-                                                                     const float *__restrict__ points,
-                                                                     const int *__restrict__ idx,
-                                                                     const float *__restrict__ wstream,
-                                                                     const float *__restrict__ bpacked,
-                                                                     float *__restrict__ out)
+__global__ __launch_bounds__(kStreamThreads) void sa_mlp3_stream_kernel(int n, int m, int nsample, int cfeat, int c3, long long rows,
+                                                                       int ti, const float *__restrict__ xyz,
+                                                                       const float *__restrict__ new_xyz,
+                                                                       const float *__restrict__ points,
+                                                                       const int *__restrict__ idx,
+                                                                       const float *__restrict__ wstream,
+                                                                       const float *__restrict__ bpacked,
+                                                                       float *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) float4 wbuf[2][kS * 256];
+    __shared__ __attribute__((aligned(16))) u32x4 wbuf[2][kStageVec];
     __shared__ float bias_s[(T1 + T2 + T3) * 32];
     const float *b1 = bias_s, *b2 = b1 + T1 * 32, *b3 = b2 + T2 * 32;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, s = lane & 31;
-    for (int i = tid; i < (T1 + T2 + T3) * 32; i += kMlpThreads) bias_s[i] = bpacked[i];
+    for (int i = tid; i < (T1 + T2 + T3) * 32; i += kStreamThreads) bias_s[i] = bpacked[i];
 
     const int l1_pairs = pad_to_stage(ti * T1);
     const int stages_per_item = (l1_pairs + T2 * T1 + T3 * T2) / kS;       // T2*T1 and T3*T2 are multiples of kS
     // ---- the weight stream -------------------------------------------------------------------------
     int stage = 0;                                   // running stage number (all items), uniform over the workgroup
-    float4 stg0, stg1, stg2, stg3;                   // this thread's 64 bytes of stage `stage + 1` (kS == 4)
-    static_assert(kS == 4, "the staging registers are spelled out for four pairs per stage");
-    // (macros, not lambdas over an array: hipcc kept a captured float4[4] in scratch memory)
+    u32x4 stg0, stg1, stg2;                          // this thread's 48 bytes of stage `stage + 1`
+    static_assert(kStageVec == 3 * kStreamThreads, "the staging registers are spelled out for three vectors per thread");
+    // (macros, not lambdas over an array: hipcc kept a captured array in scratch memory)
 #define PN2_STREAM_ISSUE(st)                                                                                           \
     do {                                                                                                               \
-        const float4 *src_ = reinterpret_cast<const float4 *>(wstream) + (size_t)((st) % stages_per_item) * (kS * 256) + tid; \
-        stg0 = src_[0]; stg1 = src_[256]; stg2 = src_[512]; stg3 = src_[768];                                          \
+        const u32x4 *src_ = reinterpret_cast<const u32x4 *>(wstream) + (size_t)((st) % stages_per_item) * kStageVec + tid; \
+        stg0 = src_[0]; stg1 = src_[kStreamThreads]; stg2 = src_[2 * kStreamThreads];                                  \
     } while (0)
 #define PN2_STREAM_COMMIT(st)                                                                                          \
     do {                                                                                                               \
-        float4 *dst_ = wbuf[(st) & 1] + tid;                                                                           \
-        dst_[0] = stg0; dst_[256] = stg1; dst_[512] = stg2; dst_[768] = stg3;                                          \
+        u32x4 *dst_ = wbuf[(st) & 1] + tid;                                                                            \
+        dst_[0] = stg0; dst_[kStreamThreads] = stg1; dst_[2 * kStreamThreads] = stg2;                                  \
     } while (0)
     // when the MFMAs of `stage` are issued: publish stage + 1, fetch stage + 2
 #define PN2_NEXT_STAGE()                                                                                               \
@@ -68,8 +70,8 @@ __global__ __launch_bounds__(kMlpThreads) void sa_mlp3_stream_kernel(int n, int 
 
     // ---- work items -----------------------------------------------------------------------------------
     const int parts = nsample / 32;
-    const long long wave = (long long)blockIdx.x * (kMlpThreads / 64) + (tid >> 6);
-    const long long nwaves = (long long)gridDim.x * (kMlpThreads / 64);
+    const long long wave = (long long)blockIdx.x * (kStreamThreads / 64) + (tid >> 6);
+    const long long nwaves = (long long)gridDim.x * (kStreamThreads / 64);
     const long long trips = (rows + nwaves - 1) / nwaves;                  // lockstep: every wave runs all trips
     const int cin = cfeat + 3;
     const bool vec4 = (cfeat & 3) == 0;
@@ -111,34 +113,43 @@ __global__ __launch_bounds__(kMlpThreads) void sa_mlp3_stream_kernel(int n, int 
             const int p = idx[row * nsample + part * 32 + s];
             // layer 1, input tiles outermost
             f32x16 h1[T1];
+            {
 #pragma unroll
-            for (int t = 0; t < T1; ++t) h1[t] = mlp_bias(b1, t, h);
-            f32x16 x = gather(row, p, 0);
-            int slot = 0;
-            for (int u = 0; u < ti; ++u) {
-                f32x16 xn = x;
-                if (u + 1 < ti) xn = gather(row, p, u + 1);                // one tile ahead of the MFMAs
+                for (int t = 0; t < T1; ++t) h1[t] = mlp_bias(b1, t, h);
+                f32x16 x = gather(row, p, 0);
+                int slot = 0;
+                for (int u = 0; u < ti; ++u) {
+                    f32x16 xn = x;
+                    if (u + 1 < ti) xn = gather(row, p, u + 1);            // one tile ahead of the MFMAs
+                    const ActSplit xs = split_act(x);
 #pragma unroll
-                for (int t = 0; t < T1; ++t) {
-                    h1[t] = stream_pair<false>(wbuf[stage & 1], slot, lane, x, h1[t]);
-                    if (++slot == kS) { slot = 0; PN2_NEXT_STAGE(); }
+                    for (int t = 0; t < T1; ++t) {
+                        h1[t] = stream_pair<false>(wbuf[stage & 1], slot, lane, xs, h1[t]);
+                        if (++slot == kS) { slot = 0; PN2_NEXT_STAGE(); }
+                    }
+                    x = xn;
                 }
-                x = xn;
+                if (slot != 0) PN2_NEXT_STAGE();                                // layer 1 is padded to whole stages
             }
-            if (slot != 0) PN2_NEXT_STAGE();                                    // layer 1 is padded to whole stages
+            // layer 2, input tiles outermost as well: a tile of layer-1 output is split into its bf16 levels right
+            // before its pairs run, so only ONE split input tile is alive beside the T2 accumulators
+            ActSplit s2[T2];
+            {
+                f32x16 a2[T2];
 #pragma unroll
-            for (int t = 0; t < T1; ++t) h1[t] = mlp_relu(h1[t]);
-            // layer 2
-            f32x16 h2[T2];
-#pragma unroll
-            for (int t = 0; t < T2; ++t) {
-                f32x16 acc = mlp_bias(b2, t, h);
+                for (int t = 0; t < T2; ++t) a2[t] = mlp_bias(b2, t, h);
 #pragma unroll
                 for (int u = 0; u < T1; ++u) {
-                    acc = stream_pair<false>(wbuf[stage & 1], (t * T1 + u) % kS, lane, h1[u], acc);
-                    if ((t * T1 + u) % kS == kS - 1) PN2_NEXT_STAGE();
+                    __builtin_amdgcn_sched_barrier(0);       // or hipcc splits every tile up front and spills
+                    const ActSplit su = split_act(mlp_relu(h1[u]));
+#pragma unroll
+                    for (int t = 0; t < T2; ++t) {
+                        a2[t] = stream_pair<false>(wbuf[stage & 1], (u * T2 + t) % kS, lane, su, a2[t]);
+                        if ((u * T2 + t) % kS == kS - 1) PN2_NEXT_STAGE();
+                    }
                 }
-                h2[t] = mlp_relu(acc);
+#pragma unroll
+                for (int t = 0; t < T2; ++t) s2[t] = split_act(mlp_relu(a2[t]));
             }
             // layer 3, operands swapped: a lane holds 16 samples of channel 32t + (l & 31)
 #pragma unroll
@@ -148,7 +159,7 @@ __global__ __launch_bounds__(kMlpThreads) void sa_mlp3_stream_kernel(int n, int 
                 for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
 #pragma unroll
                 for (int u = 0; u < T2; ++u) {
-                    acc = stream_pair<true>(wbuf[stage & 1], (t * T2 + u) % kS, lane, h2[u], acc);
+                    acc = stream_pair<true>(wbuf[stage & 1], (t * T2 + u) % kS, lane, s2[u], acc);
                     if ((t * T2 + u) % kS == kS - 1) PN2_NEXT_STAGE();
                 }
                 float mx = acc[0];
@@ -182,21 +193,8 @@ bool mlp_stream_pick(int cin, int c1, int c2, int c3, MlpStreamConfig &cfg)
 }
 
 static int stream_pairs(const MlpStreamConfig &c) { return pad_to_stage(c.ti * c.t1) + c.t2 * c.t1 + c.t3 * c.t2; }
-size_t mlp_stream_w_floats(const MlpStreamConfig &c) { return (size_t)stream_pairs(c) * 1024; }
+size_t mlp_stream_w_floats(const MlpStreamConfig &c) { return (size_t)stream_pairs(c) * kPairWords; }
 size_t mlp_stream_b_floats(const MlpStreamConfig &c) { return (size_t)(c.t1 + c.t2 + c.t3) * 32; }
-
-// one 32x32 tile pair in the MFMA operand layout [q][lane][r] (see sa_mlp.hip): value for lane l, register
-// 4q + r = W[krow(32u + mlp_chan(4q + r, l >> 5))][32t + (l & 31)]
-float *mlp_pack_pair(float *wp, const float *w, int kin, int nout, int t, int u, const int *krow)
-{
-    for (int q = 0; q < 4; ++q)
-        for (int lane = 0; lane < 64; ++lane)
-            for (int r = 0; r < 4; ++r) {
-                const int k = 32 * u + mlp_chan(4 * q + r, lane >> 5), nn = 32 * t + (lane & 31);
-                *wp++ = (k < kin && nn < nout) ? w[(size_t)(krow ? krow[k] : k) * nout + nn] : 0.0f;
-            }
-    return wp;
-}
 
 void mlp_stream_pack(const MlpStreamConfig &c, int cin, int c1, int c2, int c3, int xyz_first, const float *const *ws,
                      const float *const *bs, float *wpacked, float *bpacked)
@@ -207,13 +205,13 @@ void mlp_stream_pack(const MlpStreamConfig &c, int cin, int c1, int c2, int c3, 
     for (int k = 0; k < cin; ++k) krow[k] = xyz_first ? (k < cfeat ? 3 + k : k - cfeat) : k;
     float *wp = wpacked;
     for (int u = 0; u < c.ti; ++u)
-        for (int t = 0; t < c.t1; ++t) wp = mlp_pack_pair(wp, ws[0], cin, c1, t, u, krow);
+        for (int t = 0; t < c.t1; ++t) wp = mlp_pack_pair_x6(wp, ws[0], cin, c1, t, u, krow);
     for (int i = c.ti * c.t1; i < pad_to_stage(c.ti * c.t1); ++i)
-        for (int j = 0; j < 1024; ++j) *wp++ = 0.0f;
-    for (int t = 0; t < c.t2; ++t)
-        for (int u = 0; u < c.t1; ++u) wp = mlp_pack_pair(wp, ws[1], c1, c2, t, u, nullptr);
+        for (int j = 0; j < kPairWords; ++j) *wp++ = 0.0f;
+    for (int u = 0; u < c.t1; ++u)                        // layer 2 walks its input tiles outermost, like layer 1
+        for (int t = 0; t < c.t2; ++t) wp = mlp_pack_pair_x6(wp, ws[1], c1, c2, t, u, nullptr);
     for (int t = 0; t < c.t3; ++t)
-        for (int u = 0; u < c.t2; ++u) wp = mlp_pack_pair(wp, ws[2], c2, c3, t, u, nullptr);
+        for (int u = 0; u < c.t2; ++u) wp = mlp_pack_pair_x6(wp, ws[2], c2, c3, t, u, nullptr);
     free(krow);
     const int nout[3] = {c1, c2, c3}, tout[3] = {c.t1, c.t2, c.t3};
     float *bp = bpacked;
@@ -232,10 +230,10 @@ static int launch_stream(const MlpStreamConfig &c, int b, int n, int m, int nsam
                          float *out, hipStream_t st)
 {
     const long long rows = (long long)b * m;
-    long long blocks = (rows + 3) / 4;
-    long long cap = 512;
+    long long blocks = (rows + kStreamThreads / 64 - 1) / (kStreamThreads / 64);
+    long long cap = 256;                                 // one workgroup (one weight stream) per CU
     if (blocks > cap) blocks = cap;
-    if (int rc = launch((sa_mlp3_stream_kernel<T1, T2, T3>), dim3((unsigned)blocks), dim3(kMlpThreads), 0, st, n, m, nsample,
+    if (int rc = launch((sa_mlp3_stream_kernel<T1, T2, T3>), dim3((unsigned)blocks), dim3(kStreamThreads), 0, st, n, m, nsample,
                        cfeat, c3, rows, c.ti, xyz, new_xyz, points, idx, wp, bp, out)) return rc;
     return PN2_OK;
 }

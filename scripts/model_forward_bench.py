@@ -132,6 +132,10 @@ def main():
             cloud = np.concatenate([cloud, nrm.astype(np.float32)], axis=2)
         xyz = torch.from_numpy(cloud).to(dev)
         with torch.no_grad():
+            if os.environ.get("PN2_MODEL_FUSED_ONLY"):     # for rocprofv3: only the fused path's kernels in the trace
+                set_fused(model, True)
+                print("%-58s fused MLPs %7.3f ms (eager)" % (name, timeit(lambda: model(xyz), iters=20)), flush=True)
+                continue
             set_fused(model, False)
             ref = model(xyz)
             t_unfused = timeit(lambda: model(xyz))

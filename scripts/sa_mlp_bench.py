@@ -58,6 +58,10 @@ def main():
             fps_idx, new_xyz, idx, _, _ = P.sample_and_group_xyz(m, r, ns, xyz, True)
             packed = mod._packed(dev)
             t_kernel = timeit(lambda: sa_mlp.sa_mlp_maxpool(xyz, new_xyz, pts, idx, packed))
+            if os.environ.get("PN2_MLP_BENCH_KERNEL_ONLY"):        # A/B runs of library variants (PN2OPS_LIBRARY)
+                print("%-50s %-11s kernel %7.1f us = %5.1f TFLOP/s (fp32-equivalent)" % (name, packed.kind, t_kernel, flops / t_kernel / 1e6),
+                      flush=True)
+                continue
 
             def unfused_tail():
                 g = P.group_point(xyz, idx) - new_xyz[:, :, None, :]

@@ -1,13 +1,23 @@
-"""Host-side packing of the fused SA MLP (pn2_sa_mlp3_pack) against a numpy emulation of the kernel's
-MFMA data flow (CPU; no device work). The emulation hard-codes the documented operand maps of
-v_mfma_f32_32x32x2_f32 -- A: lane l holds A[i = l & 31][k = l >> 5]; B: B[k = l >> 5][j = l & 31];
-C/D: lane l, register v holds D[8(v >> 2) + 4(l >> 5) + (v & 3)][l & 31] -- so it proves that the
-permutation algebra (weights, bias, register-to-channel map, layer chaining) is right GIVEN those maps;
-the maps themselves are checked on the GPU by tests/test_sa_mlp_gpu.py."""
+"""Host-side packing of the fused MLP kernels (pn2_sa_mlp3_pack, pn2_fp_mlp_pack) against a numpy emulation of
+the kernels' MFMA data flow (CPU; no device work). The kernels compute fp32 products on the bf16 matrix pipe:
+every weight is stored as three bf16 levels w0 + w1 + w2 (exactly w), every activation is split the same way
+in registers, and six v_mfma_f32_32x32x16_bf16 per 16 contraction slots add the terms listed in _TERMS
+(csrc/sa_mlp_common.h, mma_x6). The emulation hard-codes the operand maps of that instruction -- A: lane l
+holds A[i = l & 31][k = 8 (l >> 5) + j], j = 0..7; B: B[k = 8 (l >> 5) + j][l & 31]; C/D: lane l, register v
+holds D[8(v >> 2) + 4(l >> 5) + (v & 3)][l & 31] -- and walks the packed arrays exactly as the kernels do, so
+it proves the permutation algebra (slot <-> channel map, level placement, bias, layer chaining, stream order)
+GIVEN those maps; the maps themselves and the accuracy are checked on the GPU (tests/test_sa_mlp_gpu.py).
+To make every one of the six terms visible, the emulated activations are "split" into the UNEQUAL parts
+_COEF * x instead of bf16 levels: the expected result is then the layer stack with the effective weights
+w0 (a + b + c) + w1 (a + b) + w2 a, where w0, w1, w2 come from an independent numpy bf16 split."""
 import ctypes
 
 import numpy as np
 import pytest
+
+_TERMS = [(0, 2), (1, 1), (2, 0), (0, 1), (1, 0), (0, 0)]          # (weight level, activation level)
+_COEF = (0.5, 0.3, 0.2)
+_PAIR = 1536                                                        # 4-byte words per 32x32 tile pair
 
 
 def _chan(v, h):
@@ -16,31 +26,93 @@ def _chan(v, h):
 
 _L = np.arange(64)
 _ROW = np.array([[8 * (v >> 2) + 4 * (l >> 5) + (v & 3) for v in range(16)] for l in range(64)])   # C/D row of (lane, reg)
+_K = (8 * (_L >> 5))[:, None] + np.arange(8)[None, :]                                              # k of (lane, slot)
 
 
 def _mfma(a, b, acc):
-    """One v_mfma_f32_32x32x2_f32: a, b (64,) lane operands, acc (64, 16) -> acc + A.B in the C/D map."""
-    A = np.zeros((32, 2))
-    B = np.zeros((2, 32))
-    A[_L & 31, _L >> 5] = a
-    B[_L >> 5, _L & 31] = b
+    """One v_mfma_f32_32x32x16_bf16: a, b (64 lanes, 8 slots), acc (64, 16) -> acc + A.B in the C/D map."""
+    A = np.zeros((32, 16))
+    B = np.zeros((16, 32))
+    A[(_L & 31)[:, None], _K] = a
+    B[_K, (_L & 31)[:, None]] = b
     D = A @ B
     return acc + D[_ROW, (_L & 31)[:, None]]
+
+
+def _bf16_bits_to_f64(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+
+
+def _bf16_split(w):
+    """Independent restatement of the host split: three round-to-nearest-even bf16 levels of float32 values."""
+    levels = []
+    r = np.asarray(w, np.float32)
+    for _ in range(3):
+        u = r.view(np.uint32).astype(np.uint64)
+        hi = (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+        levels.append(hi.astype(np.float64))
+        r = (r - hi).astype(np.float32)
+    return levels
+
+
+def _effective(w):
+    w0, w1, w2 = _bf16_split(w)
+    a, b, c = _COEF
+    return w0 * (a + b + c) + w1 * (a + b) + w2 * a
+
+
+def _emulate_pair(pair, act, acc, last):
+    """The 12 MFMAs of one packed tile pair ([e][level][lane][8 bf16]) on activation registers act (64, 16);
+    last: operands swapped."""
+    W = _bf16_bits_to_f64(pair.view(np.uint16).reshape(2, 3, 64, 8))
+    for e in range(2):
+        X = [c * act[:, 8 * e:8 * e + 8] for c in _COEF]
+        for wl, xl in _TERMS:
+            acc = _mfma(X[xl], W[e, wl], acc) if last else _mfma(W[e, wl], X[xl], acc)
+    return acc
+
+
+def _want(x, ws, bs):
+    want = x.astype(np.float64)
+    for w, b in zip(ws, bs):
+        want = np.maximum(want @ _effective(w) + b, 0.0)
+    return want
+
+
+def test_weight_levels_are_exact():
+    """w0 + w1 + w2 == w exactly (three nearest-even bf16 roundings cover fp32's 24 bits) and the packed levels of a
+    tile pair are the numpy split's."""
+    from pointnet2_amd import _C
+    lib = _C.lib()
+    rng = np.random.default_rng(3)
+    w = (rng.standard_normal((32, 32)) * np.exp(rng.uniform(-20, 20, (32, 32)))).astype(np.float32)
+    lv = _bf16_split(w)
+    assert np.array_equal((lv[0] + lv[1] + lv[2]).astype(np.float32), w)
+    info = (ctypes.c_int * 4)()
+    wf, bf = ctypes.c_longlong(), ctypes.c_longlong()
+    zeros = np.zeros(32, np.float32)
+    assert lib.pn2_sa_mlp3_config(32, 32, 32, 32, 32, info, ctypes.byref(wf), ctypes.byref(bf)) == 0 and info[0] == 0
+    wp, bp = np.empty(wf.value, np.float32), np.empty(bf.value, np.float32)
+    assert lib.pn2_sa_mlp3_pack(32, 32, 32, 32, 32, 1, w.ctypes.data, zeros.ctypes.data, w.ctypes.data, zeros.ctypes.data,
+                                w.ctypes.data, zeros.ctypes.data, wp.ctypes.data, bp.ctypes.data) == 0
+    pair = _bf16_bits_to_f64(wp[_PAIR:2 * _PAIR].view(np.uint16).reshape(2, 3, 64, 8))          # layer 2: no row permutation
+    for e in range(2):
+        for lane in range(64):
+            for j in range(8):
+                k, n = _chan(8 * e + j, lane >> 5), lane & 31
+                assert [pair[e, l, lane, j] for l in range(3)] == [lv[l][k, n] for l in range(3)]
 
 
 def _emulate_layer(wp, bp, t_out, t_in, acts, last=False):
     """acts: list of t_in arrays (64 lanes, 16 regs) -> list of t_out arrays, exactly as mlp_layer walks them.
     last: the kernel swaps the MFMA operands and starts from zero (bias + ReLU come after the pooling)."""
-    wp = wp.reshape(t_out, t_in, 4, 64, 4)
+    wp = wp.reshape(t_out, t_in, _PAIR)
     bp = bp.reshape(t_out, 2, 16)
     outs = []
     for t in range(t_out):
         acc = np.zeros((64, 16)) if last else np.stack([bp[t, l >> 5] for l in range(64)]).astype(np.float64)
         for u in range(t_in):
-            for q in range(4):
-                for r in range(4):
-                    w, x = wp[t, u, q, :, r], acts[u][:, 4 * q + r]
-                    acc = _mfma(x, w, acc) if last else _mfma(w, x, acc)
+            acc = _emulate_pair(wp[t, u], acts[u], acc, last)
         outs.append(acc if last else np.maximum(acc, 0.0))
     return outs
 
@@ -69,7 +141,7 @@ def test_pack_matches_emulated_dataflow(cin, widths):
         for v in range(16):
             k = _chan(v, l >> 5)
             x0[l, v] = x[l & 31, k] if k < cin else 0.0
-    sizes_w = [t1 * 1 * 1024, t2 * t1 * 1024, t3 * t2 * 1024]
+    sizes_w = [t1 * 1 * _PAIR, t2 * t1 * _PAIR, t3 * t2 * _PAIR]
     sizes_b = [t1 * 32, t2 * 32, t3 * 32]
     ow = np.cumsum([0] + sizes_w)
     ob = np.cumsum([0] + sizes_b)
@@ -89,10 +161,7 @@ def test_pack_matches_emulated_dataflow(cin, widths):
             bias = b3[t, (c >> 2) & 1, 4 * (c >> 3) + (c & 3)]
             for v in range(16):
                 got[8 * (v >> 2) + 4 * (l >> 5) + (v & 3), ch] = max(acts[t][l, v] + bias, 0.0)
-    want = x.astype(np.float64)
-    for w, b in zip(ws, bs):
-        want = np.maximum(want @ w.astype(np.float64) + b, 0.0)
-    assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
+    assert np.allclose(got, _want(x, ws, bs), rtol=1e-9, atol=1e-9)
 
 
 def test_config_limits():
@@ -115,8 +184,8 @@ def test_config_limits():
 @pytest.mark.parametrize("cin,widths,xyz_first", [(67, (64, 64, 128), True), (131, (128, 128, 256), True),
                                                    (40, (50, 64, 100), False), (323, (128, 128, 256), False)])
 def test_stream_pack_matches_emulated_dataflow(cin, widths, xyz_first):
-    """The streamed kernel's weight sequence: layer 1 input-tile-major with [features, xyz] channel order
-    and padding to whole stages, layers 2-3 output-tile-major; emulated exactly as sa_mlp_stream.hip walks it."""
+    """The streamed kernel's weight sequence: layers 1 and 2 input-tile-major (layer 1 with [features, xyz] channel
+    order and padding to whole stages), layer 3 output-tile-major; emulated exactly as sa_mlp_stream.hip walks it."""
     from pointnet2_amd import _C
     lib = _C.lib()
     rng = np.random.default_rng(cin)
@@ -133,7 +202,7 @@ def test_stream_pack_matches_emulated_dataflow(cin, widths, xyz_first):
     bp = np.empty(bf.value, np.float32)
     assert lib.pn2_sa_mlp3_pack(cin, *widths, 32, 1 if xyz_first else 0,
                                 *[a.ctypes.data for pair in zip(ws, bs) for a in pair], wp.ctypes.data, bp.ctypes.data) == 0
-    pairs = wp.reshape(-1, 4, 64, 4)
+    pairs = wp.reshape(-1, _PAIR)
     l1 = -(-ti * t1 // 4) * 4
     assert pairs.shape[0] == l1 + t2 * t1 + t3 * t2
     bias = bp.reshape(-1, 2, 16)
@@ -144,11 +213,7 @@ def test_stream_pack_matches_emulated_dataflow(cin, widths, xyz_first):
     user_in = np.concatenate([xyz, feat], axis=1) if xyz_first else kern_in
 
     def run_pair(pair, act, acc, swap=False):
-        for q in range(4):
-            for r in range(4):
-                w, x = pair[q, :, r], act[:, 4 * q + r]
-                acc = _mfma(x, w, acc) if swap else _mfma(w, x, acc)
-        return acc
+        return _emulate_pair(pair, act, acc, swap)
 
     lane_bias = lambda t0, t: np.stack([bias[t0 + t, l >> 5] for l in range(64)]).astype(np.float64)
     h1 = [lane_bias(0, t) for t in range(t1)]
@@ -161,12 +226,11 @@ def test_stream_pack_matches_emulated_dataflow(cin, widths, xyz_first):
         for t in range(t1):
             h1[t] = run_pair(pairs[u * t1 + t], x0, h1[t])
     h1 = [np.maximum(a, 0.0) for a in h1]
-    h2 = []
-    for t in range(t2):
-        acc = lane_bias(t1, t)
-        for u in range(t1):
-            acc = run_pair(pairs[l1 + t * t1 + u], h1[u], acc)
-        h2.append(np.maximum(acc, 0.0))
+    h2 = [lane_bias(t1, t) for t in range(t2)]
+    for u in range(t1):                                              # input tiles outermost
+        for t in range(t2):
+            h2[t] = run_pair(pairs[l1 + u * t2 + t], h1[u], h2[t])
+    h2 = [np.maximum(a, 0.0) for a in h2]
     got = np.zeros((32, widths[2]))
     b3 = bias[t1 + t2:]
     for t in range(t3):
@@ -180,10 +244,7 @@ def test_stream_pack_matches_emulated_dataflow(cin, widths, xyz_first):
                 bb = b3[t, (c >> 2) & 1, 4 * (c >> 3) + (c & 3)]
                 for v in range(16):
                     got[8 * (v >> 2) + 4 * (l >> 5) + (v & 3), ch] = max(acc[l, v] + bb, 0.0)
-    want = user_in.astype(np.float64)
-    for w, b in zip(ws, bs):
-        want = np.maximum(want @ w.astype(np.float64) + b, 0.0)
-    assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
+    assert np.allclose(got, _want(user_in, ws, bs), rtol=1e-9, atol=1e-9)
 
 
 def test_fold_batch_norm_equals_eval_mode_layers():
@@ -217,16 +278,6 @@ def test_fold_batch_norm_equals_eval_mode_layers():
 
 
 # ---- packing of the round-2 kernels: feature propagation (streamed, kind 0) and cooperative (kind 1) ---------------
-def _emulate_pair(pair, act, acc, last):
-    """The 16 MFMAs of one packed 32x32 tile pair ([q][lane][r]) on activation registers act (64, 16)."""
-    pair = pair.reshape(4, 64, 4)
-    for q in range(4):
-        for r in range(4):
-            w, x = pair[q, :, r], act[:, 4 * q + r]
-            acc = _mfma(x, w, acc) if last else _mfma(w, x, acc)
-    return acc
-
-
 def _operand_tiles(x, ti):
     """(32 samples, cin) -> ti operand tiles (64 lanes, 16 regs): register v of lane l = channel 32u + chan(v, l >> 5)."""
     tiles = []
@@ -282,7 +333,7 @@ def test_fp_pack_matches_emulated_dataflow(kind, c2, c1, widths):
     wptr = (ctypes.c_void_p * n)(*[w.ctypes.data for w in ws])
     bptr = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bs])
     assert lib.pn2_fp_mlp_pack(c2, c1, n, warr, kind, wptr, bptr, wp.ctypes.data, bp.ctypes.data) == 0
-    pairs = wp.reshape(-1, 1024)
+    pairs = wp.reshape(-1, _PAIR)
     ob = np.cumsum([0, T[0] * 32, T[1] * 32, T[2] * 32])
     bl = [bp[ob[i]:ob[i + 1]] for i in range(3)]
     x = rng.standard_normal((32, c2 + c1)).astype(np.float32)
@@ -328,7 +379,4 @@ def test_fp_pack_matches_emulated_dataflow(kind, c2, c1, widths):
                 acts = [np.maximum(acc[t], 0.0) for t in range(T[L])]
         assert 4 * k == pairs.shape[0]
     got = _unswap(last_acc, widths[-1], lambda ch: _b_at(bl[n - 1], ch))
-    want = x.astype(np.float64)
-    for w, b in zip(ws, bs):
-        want = np.maximum(want @ w.astype(np.float64) + b, 0.0)
-    assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
+    assert np.allclose(got, _want(x, ws, bs), rtol=1e-9, atol=1e-9)
