@@ -178,8 +178,10 @@ def event_time(fn, reps=10):
 def mlp_roofline(stage):
     """EXTRA object (not part of `value`): the MFMA-bound kernel of the hot path's consumer, the fused
     grouped MLP + max-pool (pn2_sa_mlp3_maxpool) on the SAME batch the step just produced
-    (idx of the metric shape, widths 64-64-128 as in the reference's first SA level). Useful FLOPs only,
-    against the dense fp32 MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s)."""
+    (idx of the metric shape, widths 64-64-128 as in the reference's first SA level). `achieved` counts the
+    useful fp32 FLOPs only and is set against the dense fp32 MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s);
+    the kernel evaluates every fp32 product as six bf16 MFMA terms (csrc/sa_mlp.hip), so `pipe` gives the
+    executed v_mfma_f32_32x32x16_bf16 work (156 per 32 samples) against the dense bf16 peak (2500 TFLOP/s)."""
     from pointnet2_amd import sa_mlp
     rng = np.random.default_rng(0)
     dims = (3, 64, 64, 128)
@@ -188,8 +190,11 @@ def mlp_roofline(stage):
     packed = sa_mlp.PackedMLP3(layers, stage.xyz.device, NS)
     t = event_time(lambda: sa_mlp.sa_mlp_maxpool(stage.xyz, stage.new_xyz, None, stage.idx, packed))
     flops = 2.0 * stage.b * M * NS * (3 * 64 + 64 * 64 + 64 * 128)
-    return {"bound": "mfma", "kernel": "sa_mlp3_maxpool 3-64-64-128 on the step's idx (fp32 MFMA)", "achieved": flops / t / 1e12,
-            "peak": 157.3, "unit": "TFLOP/s", "frac": flops / t / 1e12 / 157.3, "us": t * 1e6}
+    executed = 156.0 * 2 * 32 * 32 * 16 * stage.b * M * (NS // 32)
+    return {"bound": "mfma", "kernel": "sa_mlp3_maxpool 3-64-64-128 on the step's idx (fp32 results, 6 bf16 MFMA terms per product)",
+            "achieved": flops / t / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / t / 1e12 / 157.3, "us": t * 1e6,
+            "pipe": {"instruction": "v_mfma_f32_32x32x16_bf16", "executed": executed / t / 1e12, "peak": 2500.0,
+                     "unit": "TFLOP/s", "frac": executed / t / 1e12 / 2500.0}}
 
 
 def concurrent_throughput(dev, rank, path, streams, steps):

@@ -140,10 +140,11 @@ int pn2_three_interpolate_grad_seg(int b, int n, int c, int m, const float *grad
 /* ---- grouped local MLP + max-pool of a set-abstraction layer, fused, on the matrix cores ---------
  * (no reference kernel; replaces for INFERENCE the TF graph of utils/pointnet_util.py:44-50 + :117-127:
  *  group_point(xyz)-new_xyz ++ group_point(points) -> 3 x [conv2d 1x1 + batch_norm + ReLU] -> reduce_max
- *  over nsample). fp32 in, fp32 MFMA, fp32 out.
+ *  over nsample). fp32 in, fp32 out, fp32 accuracy: every product is evaluated as six
+ *  bf16 MFMA terms on three-level bf16 operands (error of an fp32 evaluation; csrc/sa_mlp.hip).
  *   xyz (b,n,3), new_xyz (b,m,3), points (b,n,cfeat) or NULL when cfeat == 0, idx (b,m,nsample) i32
  *   -> out (b,m,c3).  Input channel order is the reference's: [relative xyz (3), features (cfeat)].
- * Three kernels behind one entry: weights resident in LDS (3 + cfeat <= 32, widths within (128,128,128);
+ * Three kernels behind one entry: weights resident in LDS (3 + cfeat <= 32, widths within (64,96,128);
  * nsample 16 or a multiple of 32), streamed through LDS (up to 384 input channels, widths within
  * (128,128,256); nsample a multiple of 32), or the cooperative kernel for wide stacks -- (256,256,512) and the
  * group_all level's (256,512,1024), any number of input channels, any nsample (the tail of the group is
@@ -153,8 +154,9 @@ int pn2_three_interpolate_grad_seg(int b, int n, int c, int m, const float *grad
  * Weights: w_i (cin_i, cout_i) row-major = the reference's conv kernel [1,1,cin,cout] (tf_util.py:113-117)
  * with batch norm folded in by the caller; xyz_first says whether the rows of w1 are [xyz, features]
  * (pointnet_util.py:50) or [features, xyz] (:184, MSG). pn2_sa_mlp3_pack (host code) permutes them into the
- * order the kernel consumes: wpacked / bpacked of the sizes pn2_sa_mlp3_config reports (info4 = {kind:
- * 0 resident / 1 streamed / 2 cooperative, output tiles of the three layers}), uploaded by the caller. */
+ * order the kernel consumes and splits every weight into its three bf16 levels: wpacked / bpacked of the sizes
+ * pn2_sa_mlp3_config reports in 4-byte words (info4 = {kind: 0 resident / 1 streamed / 2 cooperative, output
+ * tiles of the three layers}; 6 bytes per padded weight), uploaded by the caller. */
 int pn2_sa_mlp3_config(int cin, int c1, int c2, int c3, int nsample, int *info4, long long *w_floats,
                        long long *b_floats);
 int pn2_sa_mlp3_pack(int cin, int c1, int c2, int c3, int nsample, int xyz_first, const float *w1, const float *bias1,
@@ -167,7 +169,7 @@ int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, const float
 /* ---- a feature-propagation layer behind three_nn, fused, on the matrix cores --------------------------
  * (no reference kernel; replaces for INFERENCE the TF graph of utils/pointnet_util.py:212-226: the
  *  inverse-distance weights, three_interpolate, concat([interpolated, points1]) and 2-3 x [conv2d 1x1 +
- *  batch_norm + ReLU]). fp32 in, fp32 MFMA, fp32 out.
+ *  batch_norm + ReLU]). fp32 in, fp32 out, fp32 accuracy (the arithmetic of pn2_sa_mlp3_maxpool).
  *   points2 (b,m,c2) known features, points1 (b,n,c1) skip features or NULL when c1 == 0,
  *   idx (b,n,3) i32 and dist (b,n,3) squared distances as pn2_three_nn writes them -> out (b,n,widths[nlayers-1]).
  * nlayers 2 or 3, widths <= 256 (padded to the instantiated tile shapes; PN2_E_TOO_LARGE outside: callers keep

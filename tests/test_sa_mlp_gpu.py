@@ -1,7 +1,8 @@
-"""pn2_sa_mlp3_maxpool (fused group + 3-layer MLP + max-pool on fp32 MFMA) against a plain PyTorch fp32
-evaluation of the same layers on the explicitly grouped tensor (GPU). Tolerance: the two differ only
-in the ORDER of fp32 accumulation (MFMA = an fma chain over k; rocBLAS tiles differently): 2e-5 relative
-to the layer's magnitude."""
+"""pn2_sa_mlp3_maxpool (fused group + 3-layer MLP + max-pool; fp32 results from six bf16 MFMA terms per product,
+csrc/sa_mlp.hip) against a float64 evaluation of the same layers on the explicitly grouped tensor (GPU).
+Tolerance: 5e-6 of the output scale -- the kernels measure 3-8e-7, the error of an fp32 evaluation of the same
+layers (scripts/mlp_accuracy.py); a missing product term (2^-16 relative each) would show as several 1e-6 --
+module-level comparisons against torch's own fp32 layers keep 2e-5 (two fp32 evaluations in different orders)."""
 import numpy as np
 import pytest
 import torch
@@ -51,7 +52,7 @@ def test_fused_mlp_matches_torch(cuda, cfeat, widths, ns):
     assert got.shape == (b, m, widths[2])
     err = (got.double() - want).abs().max().item()
     scale = want.abs().max().item()
-    assert err <= 2e-5 * max(1.0, scale), (err, scale)
+    assert err <= 5e-6 * max(1.0, scale), (err, scale)
 
 
 @pytest.mark.parametrize("cfeat,widths", [(3, (64, 64, 128)), (64, (128, 128, 256))])
@@ -72,7 +73,7 @@ def test_fused_mlp_features_first_order(cuda, cfeat, widths):
     # reference with the rows moved to [xyz, features]
     w1 = np.concatenate([layers[0][0][cfeat:], layers[0][0][:cfeat]], axis=0)
     want = _reference(xyz, new_xyz, points, idx, [(w1, layers[0][1])] + layers[1:])
-    assert (got.double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    assert (got.double() - want).abs().max().item() <= 5e-6 * max(1.0, want.abs().max().item())
 
 
 def test_fused_mlp_in_sa_module(cuda):
@@ -144,7 +145,7 @@ def test_fused_mlp_many_rows_and_repeatable(cuda, cfeat, widths, ns):
     outs = [sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, packed) for _ in range(5)]
     assert all(torch.equal(outs[0], o) for o in outs[1:])
     want = _reference(xyz, new_xyz, points, idx, layers)
-    assert (outs[0].double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    assert (outs[0].double() - want).abs().max().item() <= 5e-6 * max(1.0, want.abs().max().item())
 
 
 # ---- cooperative kernel (csrc/coop_mlp.hip): wide stacks, any nsample, the group_all level -----------------------
@@ -181,7 +182,7 @@ def test_cooperative_kernel_matches_float64(cuda, case):
             ref_layers = [(w1, layers[0][1])] + layers[1:]
         want = _reference(xyz, new_xyz, points, idx, ref_layers)
         assert got.shape == (b, m, widths[2])
-        assert (got.double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item()), (label, xyz_first)
+        assert (got.double() - want).abs().max().item() <= 5e-6 * max(1.0, want.abs().max().item()), (label, xyz_first)
 
 
 @pytest.mark.parametrize("b,n,cfeat", [(32, 128, 256), (4, 128, 640), (3, 100, 256), (2, 33, 5)],
@@ -203,7 +204,7 @@ def test_group_all_level_fused(cuda, b, n, cfeat):
         x = torch.relu(x @ torch.from_numpy(w).double().to(cuda) + torch.from_numpy(bias).double().to(cuda))
     want = x.max(dim=1, keepdim=True).values
     assert got.shape == (b, 1, 1024)
-    assert (got.double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    assert (got.double() - want).abs().max().item() <= 5e-6 * max(1.0, want.abs().max().item())
 
 
 def test_group_all_module_takes_the_fused_kernel(cuda):
