@@ -51,7 +51,8 @@ _SIGNATURES = {
     "pn2_three_interpolate_grad_seg": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pn2_sa_mlp3_config": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "pn2_sa_mlp3_pack": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "pn2_sa_mlp3_maxpool": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "pn2_sa_mlp3_maxpool": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pn2_sa_mlp3_ws_bytes": [_i, _i, _i, _i, _i, _i, _i],
     "pn2_fp_mlp_config": [_i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "pn2_fp_mlp_pack": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "pn2_fp_mlp": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
@@ -71,6 +72,7 @@ _RESTYPES = {
     "pn2_det_grad_ws_bytes": ctypes.c_longlong,
     "pn2_seg_grad_ws_bytes": ctypes.c_longlong,
     "pn2_sample_and_group_ws_bytes": ctypes.c_longlong,
+    "pn2_sa_mlp3_ws_bytes": ctypes.c_longlong,
     "pn2_sample_and_group_status_offset": ctypes.c_longlong,
     "pn2_ball_threshold": ctypes.c_float,
     "pn2_version": ctypes.c_char_p,

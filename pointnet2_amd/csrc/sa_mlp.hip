@@ -418,9 +418,23 @@ extern "C" int pn2_sa_mlp3_pack(int cin, int c1, int c2, int c3, int nsample, in
     return PN2_OK;
 }
 
+// Scratch pn2_sa_mlp3_maxpool needs for this call (0 for the resident and cooperative kernels; the streamed one keeps
+// the per-point part of layer 1 there: b * n rows of the padded first width).
+extern "C" long long pn2_sa_mlp3_ws_bytes(int b, int n, int cin, int c1, int c2, int c3, int nsample)
+{
+    using namespace pn2;
+    int kind;
+    MlpConfig rc;
+    MlpStreamConfig sc;
+    MlpCoopConfig cc;
+    if (b <= 0 || n <= 0 || cin < 3 || c1 <= 0 || c2 <= 0 || c3 <= 0 || nsample <= 0) return 0;
+    if (!mlp_choose(cin, c1, c2, c3, nsample, kind, rc, sc, cc) || kind != 1) return 0;
+    return (long long)mlp_stream_ws_bytes(sc, (long long)b * n);
+}
+
 extern "C" int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, const float *xyz, const float *new_xyz,
                                    const float *points, const int *idx, int c1, int c2, int c3, const float *wpacked,
-                                   const float *bpacked, float *out, void *stream)
+                                   const float *bpacked, float *out, void *ws, void *stream)
 {
     using namespace pn2;
     if (b < 0 || n <= 0 || m < 0 || cfeat < 0) return PN2_E_SHAPE;
@@ -445,7 +459,7 @@ extern "C" int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, 
         return mlp_coop_launch(cc, 0, p, st);
     }
     if (kind == 1)
-        return mlp_stream_launch(sc, b, n, m, nsample, cfeat, c3, xyz, new_xyz, pts ? pts : xyz, idx, wpacked, bpacked, out, st);
+        return mlp_stream_launch(sc, b, n, m, nsample, cfeat, c3, xyz, new_xyz, pts ? pts : xyz, idx, wpacked, bpacked, out, ws, st);
 #define PN2_MLP_CASE(A, B, C) \
     if (cfg.t1 == A && cfg.t2 == B && cfg.t3 == C) \
         return launch_mlp<A, B, C>(b, n, m, nsample, cfeat, c3, xyz, new_xyz, pts, idx, wpacked, bpacked, out, st)

@@ -112,7 +112,7 @@ constexpr int kMlpStagePairs = 4;          // 32x32 weight tile pairs per LDS st
 
 constexpr int kS = kMlpStagePairs;
 
-__host__ __device__ __forceinline__ int pad_to_stage(int pairs) { return (pairs + kS - 1) / kS * kS; }
+__host__ __device__ constexpr int pad_to_stage(int pairs) { return (pairs + kS - 1) / kS * kS; }
 
 constexpr int kStreamThreads = 512;        // sa_mlp_stream.hip: eight waves share one weight stream
 constexpr int kStageVec = kS * kPairWords / 4;          // 16-byte vectors per stage
@@ -131,15 +131,16 @@ __device__ __forceinline__ f32x16 stream_pair(const u32x4 *stage, int slot, int 
     return acc;
 }
 
-struct MlpStreamConfig { int ti, t1, t2, t3; };
+struct MlpStreamConfig { int ti, t1, t2, t3; };         // ti: 32-channel tiles of the grouped FEATURES (per-point layer)
 bool mlp_stream_pick(int cin, int c1, int c2, int c3, MlpStreamConfig &cfg);
 size_t mlp_stream_w_floats(const MlpStreamConfig &c);
 size_t mlp_stream_b_floats(const MlpStreamConfig &c);
+size_t mlp_stream_ws_bytes(const MlpStreamConfig &c, long long points);
 void mlp_stream_pack(const MlpStreamConfig &c, int cin, int c1, int c2, int c3, int xyz_first, const float *const *ws,
                      const float *const *bs, float *wpacked, float *bpacked);
 int mlp_stream_launch(const MlpStreamConfig &c, int b, int n, int m, int nsample, int cfeat, int c3, const float *xyz,
                       const float *new_xyz, const float *points, const int *idx, const float *wp, const float *bp,
-                      float *out, hipStream_t st);
+                      float *out, void *ws, hipStream_t st);
 
 // ---- cooperative variant (coop_mlp.hip): four waves share one 32-sample item and split every layer's output
 // tiles; wide stacks over few rows (SA levels beyond (128,128,256), group_all levels, small FP levels) -------

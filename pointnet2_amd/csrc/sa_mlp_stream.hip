@@ -1,6 +1,17 @@
 // sa_mlp_stream.hip -- the fused grouped MLP + max-pool (see sa_mlp.hip for the formulation) for layer
 // stacks whose weights do not fit in LDS: SA2/SA3-sized stacks such as 131 -> 128 -> 128 -> 256
-// (264 KB of fp32 weights), reference models/pointnet2_*: pointnet_sa_module(... mlp=[128,128,256] ...).
+// (396 KB of three-level weights), reference models/pointnet2_*: pointnet_sa_module(... mlp=[128,128,256] ...).
+//
+// The first layer is NOT evaluated per (centroid, sample) pair. Its input is [features of point j, xyz_j - c]
+// (pointnet_util.py:44-50), so   W1^T x = W1f^T f_j  +  W1x^T (xyz_j - c) :   the feature part depends on the
+// POINT only, and a point is a sample of nsample * m / n (16-64) groups. point_layer_kernel computes
+// P[j] = W1f^T f_j + b1 once per point (b*n rows instead of b*m*nsample; the 32 consecutive points of a work
+// item are contiguous rows: no gather) into a caller-provided scratch; the grouped kernel starts layer 1 from
+// the gathered P[j] (128 floats per sample where the features would be up to 384) and adds the xyz part with ONE
+// K16 step per output tile (those few weights stay in LDS for the whole launch, outside the stream). For cls_msg's second level (323 input channels) that removes 504 of 1104 MFMAs
+// per 32 samples and the splitting of 11 input tiles. (A reassociation of the layer-1 sum, within fp32 rounding.
+// The xyz part is deliberately NOT precomputed per point and per centroid: W1x^T xyz_j - W1x^T c would cancel
+// catastrophically for clouds far from the origin, the reference subtracts coordinates first.)
 //
 // The weights are STREAMED: the packed array is the exact sequence of 32x32 tile pairs one work item
 // (32 samples through the three layers) consumes, in the three-level bf16 operand layout of sa_mlp.hip
@@ -11,40 +22,21 @@
 // them to the other buffer and one s_barrier flips the buffers. All workgroups stream the same bytes,
 // so the source is the L2.
 // Differences to the resident kernel, all forced by the register budget (256 VGPRs at 2 waves/SIMD):
-//   * layers 1 and 2 walk the INPUT tiles in the outer loop (only one 32-channel tile of inputs is alive in
-//     its three-level form, all output accumulators are); input channels are ordered [features, xyz] so that a
-//     lane's four channels of a register quartet are one aligned 16-byte load when cfeat % 4 == 0;
+//   * layer 2 walks the INPUT tiles in the outer loop (only one 32-channel tile of inputs is alive in
+//     its three-level form, all output accumulators are);
 //   * the last layer's 16 registers of a tile are max-reduced right away (they hold 16 samples of one
 //     channel, see sa_mlp.hip), so the running maximum over a centroid's sample groups is T3 registers.
 #include "sa_mlp_common.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 namespace pn2 {
 
-template <int T1, int T2, int T3>
-__global__ __launch_bounds__(kStreamThreads) void sa_mlp3_stream_kernel(int n, int m, int nsample, int cfeat, int c3, long long rows,
-                                                                       int ti, const float *__restrict__ xyz,
-                                                                       const float *__restrict__ new_xyz,
-                                                                       const float *__restrict__ points,
-                                                                       const int *__restrict__ idx,
-                                                                       const float *__restrict__ wstream,
-                                                                       const float *__restrict__ bpacked,
-                                                                       float *__restrict__ out)
-{
-    __shared__ __attribute__((aligned(16))) u32x4 wbuf[2][kStageVec];
-    __shared__ float bias_s[(T1 + T2 + T3) * 32];
-    const float *b1 = bias_s, *b2 = b1 + T1 * 32, *b3 = b2 + T2 * 32;
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, s = lane & 31;
-    for (int i = tid; i < (T1 + T2 + T3) * 32; i += kStreamThreads) bias_s[i] = bpacked[i];
+constexpr int kXyzVec = 3 * 64;            // 16-byte vectors of one output tile's xyz weights: [level][lane]
 
-    const int l1_pairs = pad_to_stage(ti * T1);
-    const int stages_per_item = (l1_pairs + T2 * T1 + T3 * T2) / kS;       // T2*T1 and T3*T2 are multiples of kS
-    // ---- the weight stream -------------------------------------------------------------------------
-    int stage = 0;                                   // running stage number (all items), uniform over the workgroup
-    u32x4 stg0, stg1, stg2;                          // this thread's 48 bytes of stage `stage + 1`
-    static_assert(kStageVec == 3 * kStreamThreads, "the staging registers are spelled out for three vectors per thread");
-    // (macros, not lambdas over an array: hipcc kept a captured array in scratch memory)
+// The double-buffered weight stream shared by the two kernels below (macros, not lambdas over an array: hipcc
+// kept a captured array in scratch memory). Needs in scope: wstream, wbuf, tid, stages_per_item, stage, stg0-2.
 #define PN2_STREAM_ISSUE(st)                                                                                           \
     do {                                                                                                               \
         const u32x4 *src_ = reinterpret_cast<const u32x4 *>(wstream) + (size_t)((st) % stages_per_item) * kStageVec + tid; \
@@ -55,7 +47,7 @@ __global__ __launch_bounds__(kStreamThreads) void sa_mlp3_stream_kernel(int n, i
         u32x4 *dst_ = wbuf[(st) & 1] + tid;                                                                            \
         dst_[0] = stg0; dst_[kStreamThreads] = stg1; dst_[2 * kStreamThreads] = stg2;                                  \
     } while (0)
-    // when the MFMAs of `stage` are issued: publish stage + 1, fetch stage + 2
+// when the MFMAs of `stage` are issued: publish stage + 1, fetch stage + 2
 #define PN2_NEXT_STAGE()                                                                                               \
     do {                                                                                                               \
         PN2_STREAM_COMMIT(stage + 1);                                                                                  \
@@ -63,75 +55,155 @@ __global__ __launch_bounds__(kStreamThreads) void sa_mlp3_stream_kernel(int n, i
         ++stage;                                                                                                       \
         PN2_STREAM_ISSUE(stage + 1);                                                                                   \
     } while (0)
+static_assert(kStageVec == 3 * kStreamThreads, "the staging registers are spelled out for three vectors per thread");
+
+// P (rows, 32 * T1) = points (rows, cfeat) . W1f + b1: the feature part of layer 1, once per point. A wave owns
+// 32 consecutive rows; non-swapped operands, so lane (row s, half h) holds channels 8q + 4h .. + 3 of a tile in
+// registers 4q .. 4q + 3: one 16-byte store per quartet, the layout the grouped kernel loads back.
+template <int T1>
+__global__ __launch_bounds__(kStreamThreads) void point_layer_kernel(int cfeat, long long rows, int tif,
+                                                                    const float *__restrict__ points,
+                                                                    const float *__restrict__ wstream,
+                                                                    const float *__restrict__ bpacked, float *__restrict__ pre)
+{
+    __shared__ __attribute__((aligned(16))) u32x4 wbuf[2][kStageVec];
+    __shared__ float bias_s[T1 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, s = lane & 31;
+    for (int i = tid; i < T1 * 32; i += kStreamThreads) bias_s[i] = bpacked[i];
+    const int stages_per_item = pad_to_stage(tif * T1) / kS;
+    int stage = 0;
+    u32x4 stg0, stg1, stg2;
+    if (stages_per_item > 0) {
+        PN2_STREAM_ISSUE(0);
+        PN2_STREAM_COMMIT(0);
+    }
+    __syncthreads();
+    if (stages_per_item > 0) PN2_STREAM_ISSUE(1);
+
+    const long long groups = (rows + 31) / 32;
+    const long long wave = (long long)blockIdx.x * (kStreamThreads / 64) + (tid >> 6);
+    const long long nwaves = (long long)gridDim.x * (kStreamThreads / 64);
+    const long long trips = (groups + nwaves - 1) / nwaves;                // lockstep: every wave runs all trips
+    const bool vec4 = (cfeat & 3) == 0;
+    for (long long trip = 0; trip < trips; ++trip) {
+        const long long g = wave + trip * nwaves;
+        const long long row = min((g < groups ? g : groups - 1) * 32 + s, rows - 1);
+        const bool ok = g < groups && g * 32 + s < rows;
+        const float *pf = points + (size_t)row * cfeat;
+        auto load_tile = [&](int u) __attribute__((always_inline)) -> f32x16 {
+            f32x16 x;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k0 = 32 * u + 8 * q + 4 * h;                     // channels k0 .. k0+3 -> registers 4q .. 4q+3
+                if (vec4 && k0 + 3 < cfeat) {
+                    const float4 f = *reinterpret_cast<const float4 *>(pf + k0);
+                    x[4 * q] = f.x; x[4 * q + 1] = f.y; x[4 * q + 2] = f.z; x[4 * q + 3] = f.w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[4 * q + r] = k0 + r < cfeat ? pf[k0 + r] : 0.0f;
+                }
+            }
+            return x;
+        };
+        f32x16 acc[T1];
+#pragma unroll
+        for (int t = 0; t < T1; ++t) acc[t] = mlp_bias(bias_s, t, h);
+        if (tif > 0) {
+            f32x16 x = load_tile(0);
+            int slot = 0;
+            for (int u = 0; u < tif; ++u) {
+                f32x16 xn = x;
+                if (u + 1 < tif) xn = load_tile(u + 1);                    // one tile ahead of the MFMAs
+                const ActSplit xs = split_act(x);
+#pragma unroll
+                for (int t = 0; t < T1; ++t) {
+                    acc[t] = stream_pair<false>(wbuf[stage & 1], slot, lane, xs, acc[t]);
+                    if (++slot == kS) { slot = 0; PN2_NEXT_STAGE(); }
+                }
+                x = xn;
+            }
+            if (slot != 0) PN2_NEXT_STAGE();                                    // padded to whole stages
+        }
+        if (ok) {
+            float *dst = pre + (size_t)row * (32 * T1) + 4 * h;
+#pragma unroll
+            for (int t = 0; t < T1; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4 *>(dst + 32 * t + 8 * q) =
+                        make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+        }
+    }
+}
+
+template <int T1, int T2, int T3>
+__global__ __launch_bounds__(kStreamThreads) void sa_mlp3_stream_kernel(int n, int m, int nsample, int c3, long long rows,
+                                                                       const float *__restrict__ xyz,
+                                                                       const float *__restrict__ new_xyz,
+                                                                       const float *__restrict__ pre,
+                                                                       const int *__restrict__ idx,
+                                                                       const float *__restrict__ wstream,
+                                                                       const float *__restrict__ wxyz,
+                                                                       const float *__restrict__ bpacked,
+                                                                       float *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) u32x4 wbuf[2][kStageVec];
+    __shared__ __attribute__((aligned(16))) u32x4 wx_s[T1 * kXyzVec];     // layer 1's xyz rows: [t][level][lane]
+    __shared__ float bias_s[(T2 + T3) * 32];
+    const float *b2 = bias_s, *b3 = b2 + T2 * 32;                          // b1 went into P
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, s = lane & 31;
+    for (int i = tid; i < (T2 + T3) * 32; i += kStreamThreads) bias_s[i] = bpacked[T1 * 32 + i];
+    for (int i = tid; i < T1 * kXyzVec; i += kStreamThreads) wx_s[i] = reinterpret_cast<const u32x4 *>(wxyz)[i];
+
+    constexpr int stages_per_item = (T2 * T1 + T3 * T2) / kS;              // both products are multiples of kS
+    int stage = 0;                                   // running stage number (all items), uniform over the workgroup
+    u32x4 stg0, stg1, stg2;                          // this thread's 48 bytes of stage `stage + 1`
     PN2_STREAM_ISSUE(0);
     PN2_STREAM_COMMIT(0);
     __syncthreads();
     PN2_STREAM_ISSUE(1);
 
-    // ---- work items -----------------------------------------------------------------------------------
     const int parts = nsample / 32;
     const long long wave = (long long)blockIdx.x * (kStreamThreads / 64) + (tid >> 6);
     const long long nwaves = (long long)gridDim.x * (kStreamThreads / 64);
     const long long trips = (rows + nwaves - 1) / nwaves;                  // lockstep: every wave runs all trips
-    const int cin = cfeat + 3;
-    const bool vec4 = (cfeat & 3) == 0;
-
-    // gather one 32-channel tile of layer-1 inputs for this lane's sample: register v <- channel
-    // 32u + mlp_chan(v, h) in the order [features 0..cfeat-1, x, y, z]
-    auto gather = [&](long long row, int p, int u) __attribute__((always_inline)) -> f32x16 {
-        const long long cloud = row / m;
-        const float *pf = points + ((size_t)cloud * n + p) * cfeat;
-        const float *px = xyz + ((size_t)cloud * n + p) * 3;
-        const float *c = new_xyz + row * 3;
-        f32x16 x;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k0 = 32 * u + 8 * q + 4 * h;                         // channels k0 .. k0+3 -> registers 4q .. 4q+3
-            if (vec4 && k0 + 3 < cfeat) {
-                const float4 f = *reinterpret_cast<const float4 *>(pf + k0);
-                x[4 * q] = f.x; x[4 * q + 1] = f.y; x[4 * q + 2] = f.z; x[4 * q + 3] = f.w;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int k = k0 + r;
-                    float val = 0.0f;
-                    if (k < cfeat) val = pf[k];
-                    else if (k < cin) val = __fsub_rn(px[k - cfeat], c[k - cfeat]);
-                    x[4 * q + r] = val;
-                }
-            }
-        }
-        return x;
-    };
 
     for (long long trip = 0; trip < trips; ++trip) {
         const long long row_raw = wave + trip * nwaves;
         const bool row_ok = row_raw < rows;
         const long long row = row_ok ? row_raw : rows - 1;
+        const long long cloud = row / m;
+        const float *c = new_xyz + row * 3;
+        const float cx = c[0], cy = c[1], cz = c[2];
         float best[T3];
         for (int part = 0; part < parts; ++part) {
             const int p = idx[row * nsample + part * 32 + s];
-            // layer 1, input tiles outermost
+            // layer 1: the point's precomputed feature part + the xyz part, one K16 step per output tile
+            // (relative coordinates are channels 0-2 = registers 0-2 of lanes 0-31)
             f32x16 h1[T1];
             {
+                const float *pp = pre + ((size_t)cloud * n + p) * (32 * T1) + 4 * h;
+                const float *px = xyz + ((size_t)cloud * n + p) * 3;
+                f32x16 x;
 #pragma unroll
-                for (int t = 0; t < T1; ++t) h1[t] = mlp_bias(b1, t, h);
-                f32x16 x = gather(row, p, 0);
-                int slot = 0;
-                for (int u = 0; u < ti; ++u) {
-                    f32x16 xn = x;
-                    if (u + 1 < ti) xn = gather(row, p, u + 1);            // one tile ahead of the MFMAs
-                    const ActSplit xs = split_act(x);
+                for (int v = 0; v < 16; ++v) x[v] = 0.0f;
+                if (h == 0) { x[0] = __fsub_rn(px[0], cx); x[1] = __fsub_rn(px[1], cy); x[2] = __fsub_rn(px[2], cz); }
 #pragma unroll
-                    for (int t = 0; t < T1; ++t) {
-                        h1[t] = stream_pair<false>(wbuf[stage & 1], slot, lane, xs, h1[t]);
-                        if (++slot == kS) { slot = 0; PN2_NEXT_STAGE(); }
+                for (int t = 0; t < T1; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 f = *reinterpret_cast<const float4 *>(pp + 32 * t + 8 * q);
+                        h1[t][4 * q] = f.x; h1[t][4 * q + 1] = f.y; h1[t][4 * q + 2] = f.z; h1[t][4 * q + 3] = f.w;
                     }
-                    x = xn;
+                const ActSplit xs = split_act(x);
+#pragma unroll
+                for (int t = 0; t < T1; ++t) {
+                    const u32x4 *wx = wx_s + t * kXyzVec + lane;
+                    const u32x4 w0[3] = {wx[0], wx[64], wx[128]};
+                    h1[t] = mma_x6<false>(w0, xs.p[0], h1[t]);
                 }
-                if (slot != 0) PN2_NEXT_STAGE();                                // layer 1 is padded to whole stages
             }
-            // layer 2, input tiles outermost as well: a tile of layer-1 output is split into its bf16 levels right
+            // layer 2, input tiles outermost: a tile of layer-1 output is split into its bf16 levels right
             // before its pairs run, so only ONE split input tile is alive beside the T2 accumulators
             ActSplit s2[T2];
             {
@@ -175,10 +247,10 @@ __global__ __launch_bounds__(kStreamThreads) void sa_mlp3_stream_kernel(int n, i
             if (h == 0 && ch < c3 && row_ok) out[row * c3 + ch] = fmaxf(__fadd_rn(mx, b3_at(b3, ch)), 0.0f);
         }
     }
+}
 #undef PN2_STREAM_ISSUE
 #undef PN2_STREAM_COMMIT
 #undef PN2_NEXT_STAGE
-}
 
 bool mlp_stream_pick(int cin, int c1, int c2, int c3, MlpStreamConfig &cfg)
 {
@@ -186,33 +258,48 @@ bool mlp_stream_pick(int cin, int c1, int c2, int c3, MlpStreamConfig &cfg)
     if (cin < 3 || cin > 32 * 12) return false;
     for (const auto &sh : kShapes)
         if (c1 <= 32 * sh[0] && c2 <= 32 * sh[1] && c3 <= 32 * sh[2]) {
-            cfg = {(cin + 31) / 32, sh[0], sh[1], sh[2]};
+            cfg = {(cin - 3 + 31) / 32, sh[0], sh[1], sh[2]};          // ti: tiles of FEATURE channels (the per-point layer)
             return true;
         }
     return false;
 }
 
-static int stream_pairs(const MlpStreamConfig &c) { return pad_to_stage(c.ti * c.t1) + c.t2 * c.t1 + c.t3 * c.t2; }
-size_t mlp_stream_w_floats(const MlpStreamConfig &c) { return (size_t)stream_pairs(c) * kPairWords; }
+// packed weights: [grouped kernel's stream: layer 2, layer 3][per-point kernel's stream: feature pairs of layer 1]
+// [xyz rows of layer 1: K16 step 0 of one pair per output tile, resident in LDS]
+static int stream_main_pairs(const MlpStreamConfig &c) { return c.t2 * c.t1 + c.t3 * c.t2; }
+static int stream_point_pairs(const MlpStreamConfig &c) { return pad_to_stage(c.ti * c.t1); }
+size_t mlp_stream_w_floats(const MlpStreamConfig &c)
+{
+    return (size_t)(stream_main_pairs(c) + stream_point_pairs(c)) * kPairWords + (size_t)c.t1 * kXyzVec * 4;
+}
 size_t mlp_stream_b_floats(const MlpStreamConfig &c) { return (size_t)(c.t1 + c.t2 + c.t3) * 32; }
+size_t mlp_stream_ws_bytes(const MlpStreamConfig &c, long long points) { return sizeof(float) * (size_t)points * 32 * c.t1; }
 
 void mlp_stream_pack(const MlpStreamConfig &c, int cin, int c1, int c2, int c3, int xyz_first, const float *const *ws,
                      const float *const *bs, float *wpacked, float *bpacked)
 {
-    // kernel channel order of layer 1: [features, xyz]; caller's weight rows: [xyz, features] when xyz_first
+    // caller's rows of w1: [xyz, features] when xyz_first, else [features, xyz]
     const int cfeat = cin - 3;
-    int *krow = (int *)malloc(sizeof(int) * (size_t)cin);
-    for (int k = 0; k < cin; ++k) krow[k] = xyz_first ? (k < cfeat ? 3 + k : k - cfeat) : k;
+    int xrow[3], *frow = (int *)malloc(sizeof(int) * (size_t)(cfeat > 0 ? cfeat : 1));
+    for (int k = 0; k < 3; ++k) xrow[k] = xyz_first ? k : cfeat + k;
+    for (int k = 0; k < cfeat; ++k) frow[k] = xyz_first ? 3 + k : k;
     float *wp = wpacked;
-    for (int u = 0; u < c.ti; ++u)
-        for (int t = 0; t < c.t1; ++t) wp = mlp_pack_pair_x6(wp, ws[0], cin, c1, t, u, krow);
-    for (int i = c.ti * c.t1; i < pad_to_stage(c.ti * c.t1); ++i)
-        for (int j = 0; j < kPairWords; ++j) *wp++ = 0.0f;
-    for (int u = 0; u < c.t1; ++u)                        // layer 2 walks its input tiles outermost, like layer 1
+    for (int u = 0; u < c.t1; ++u)                        // layer 2 walks its input tiles outermost
         for (int t = 0; t < c.t2; ++t) wp = mlp_pack_pair_x6(wp, ws[1], c1, c2, t, u, nullptr);
     for (int t = 0; t < c.t3; ++t)
         for (int u = 0; u < c.t2; ++u) wp = mlp_pack_pair_x6(wp, ws[2], c2, c3, t, u, nullptr);
-    free(krow);
+    for (int u = 0; u < c.ti; ++u)                        // the per-point layer: feature tiles outermost
+        for (int t = 0; t < c.t1; ++t) wp = mlp_pack_pair_x6(wp, ws[0], cfeat, c1, t, u, frow);
+    for (int i = c.ti * c.t1; i < pad_to_stage(c.ti * c.t1); ++i)
+        for (int j = 0; j < kPairWords; ++j) *wp++ = 0.0f;
+    float *tmp = (float *)malloc(sizeof(float) * kPairWords);
+    for (int t = 0; t < c.t1; ++t) {                      // xyz rows: channels 0-2 live in K16 step 0 of input tile 0
+        mlp_pack_pair_x6(tmp, ws[0], 3, c1, t, 0, xrow);
+        memcpy(wp, tmp, sizeof(float) * kXyzVec * 4);
+        wp += kXyzVec * 4;
+    }
+    free(tmp);
+    free(frow);
     const int nout[3] = {c1, c2, c3}, tout[3] = {c.t1, c.t2, c.t3};
     float *bp = bpacked;
     for (int L = 0; L < 3; ++L)
@@ -227,26 +314,33 @@ void mlp_stream_pack(const MlpStreamConfig &c, int cin, int c1, int c2, int c3, 
 template <int T1, int T2, int T3>
 static int launch_stream(const MlpStreamConfig &c, int b, int n, int m, int nsample, int cfeat, int c3, const float *xyz,
                          const float *new_xyz, const float *points, const int *idx, const float *wp, const float *bp,
-                         float *out, hipStream_t st)
+                         float *out, float *pre, hipStream_t st)
 {
-    const long long rows = (long long)b * m;
-    long long blocks = (rows + kStreamThreads / 64 - 1) / (kStreamThreads / 64);
-    long long cap = 256;                                 // one workgroup (one weight stream) per CU
+    const long long cap = 256;                           // one workgroup (one weight stream) per CU
+    const long long npoints = (long long)b * n, groups = (npoints + 31) / 32;
+    long long blocks = (groups + kStreamThreads / 64 - 1) / (kStreamThreads / 64);
     if (blocks > cap) blocks = cap;
-    if (int rc = launch((sa_mlp3_stream_kernel<T1, T2, T3>), dim3((unsigned)blocks), dim3(kStreamThreads), 0, st, n, m, nsample,
-                       cfeat, c3, rows, c.ti, xyz, new_xyz, points, idx, wp, bp, out)) return rc;
-    return PN2_OK;
+    const float *wpoint = wp + (size_t)stream_main_pairs(c) * kPairWords;
+    const float *wxyz = wpoint + (size_t)stream_point_pairs(c) * kPairWords;
+    if (int rc = launch((point_layer_kernel<T1>), dim3((unsigned)blocks), dim3(kStreamThreads), 0, st, cfeat, npoints, c.ti, points,
+                       wpoint, bp, pre)) return rc;
+    const long long rows = (long long)b * m;
+    blocks = (rows + kStreamThreads / 64 - 1) / (kStreamThreads / 64);
+    if (blocks > cap) blocks = cap;
+    return launch((sa_mlp3_stream_kernel<T1, T2, T3>), dim3((unsigned)blocks), dim3(kStreamThreads), 0, st, n, m, nsample, c3, rows,
+                  xyz, new_xyz, (const float *)pre, idx, wp, wxyz, bp, out);
 }
 
 int mlp_stream_launch(const MlpStreamConfig &c, int b, int n, int m, int nsample, int cfeat, int c3, const float *xyz,
                       const float *new_xyz, const float *points, const int *idx, const float *wp, const float *bp,
-                      float *out, hipStream_t st)
+                      float *out, void *ws, hipStream_t st)
 {
     if (nsample <= 0 || nsample % 32 != 0) return PN2_E_ARG;
+    if (!ws) return PN2_E_NULL;
     if (c.t1 == 2 && c.t2 == 2 && c.t3 == 4)
-        return launch_stream<2, 2, 4>(c, b, n, m, nsample, cfeat, c3, xyz, new_xyz, points, idx, wp, bp, out, st);
+        return launch_stream<2, 2, 4>(c, b, n, m, nsample, cfeat, c3, xyz, new_xyz, points, idx, wp, bp, out, (float *)ws, st);
     if (c.t1 == 4 && c.t2 == 4 && c.t3 == 8)
-        return launch_stream<4, 4, 8>(c, b, n, m, nsample, cfeat, c3, xyz, new_xyz, points, idx, wp, bp, out, st);
+        return launch_stream<4, 4, 8>(c, b, n, m, nsample, cfeat, c3, xyz, new_xyz, points, idx, wp, bp, out, (float *)ws, st);
     return PN2_E_TOO_LARGE;
 }
 

@@ -111,12 +111,18 @@ def test_c_abi_argument_validation_of_the_extra_entry_points():
     nss[1] = 4
     assert lib.pn2_query_ball_group_xyz_msg(1, 8, 4, 2, radii, nss, one, one, 1, None, None, None, None) == -1   # no outputs
     # fused MLP: shape limits are reported, never silently mis-run
-    assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 0, 0, one, one, None, one, 64, 64, 128, one, one, one, None) == -3    # nsample
-    assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 24, 0, one, one, None, one, 64, 64, 128, one, one, one, None) == -4   # odd nsample: only the cooperative kernel masks, and it has no (64,64,128) form
-    assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 32, 0, one, one, None, one, 512, 512, 512, one, one, one, None) == -4
-    assert lib.pn2_sa_mlp3_maxpool(2, 64, 3, 64, 0, one, None, None, None, 256, 512, 1024, one, one, one, None) == -3  # group_all needs m = 1, nsample = n
-    assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 32, 4, one, one, None, one, 64, 64, 128, one, one, one, None) == -1   # points missing
+    assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 0, 0, one, one, None, one, 64, 64, 128, one, one, one, None, None) == -3    # nsample
+    assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 24, 0, one, one, None, one, 64, 64, 128, one, one, one, None, None) == -4   # odd nsample: only the cooperative kernel masks, and it has no (64,64,128) form
+    assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 32, 0, one, one, None, one, 512, 512, 512, one, one, one, None, None) == -4
+    assert lib.pn2_sa_mlp3_maxpool(2, 64, 3, 64, 0, one, None, None, None, 256, 512, 1024, one, one, one, None, None) == -3  # group_all needs m = 1, nsample = n
+    assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 32, 4, one, one, None, one, 64, 64, 128, one, one, one, None, None) == -1   # points missing
     assert lib.pn2_sa_mlp3_pack(3, 64, 64, 128, 32, 1, None, None, None, None, None, None, None, None) == -1
+    # scratch: only the streamed kernel needs any (the per-point part of layer 1: b * n rows of the padded first width)
+    assert lib.pn2_sa_mlp3_ws_bytes(2, 100, 3, 64, 64, 128, 32) == 0
+    assert lib.pn2_sa_mlp3_ws_bytes(2, 100, 131, 128, 128, 256, 64) == 4 * 2 * 100 * 128
+    assert lib.pn2_sa_mlp3_ws_bytes(2, 100, 67, 50, 64, 100, 32) == 4 * 2 * 100 * 64
+    assert lib.pn2_sa_mlp3_ws_bytes(2, 100, 259, 256, 256, 512, 32) == 0
+    assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 32, 64, one, one, one, one, 64, 64, 128, one, one, one, None, None) == -1  # streamed: ws missing
 
 
 def test_python_wrappers_validate_like_op_requires():

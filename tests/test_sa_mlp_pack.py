@@ -181,11 +181,44 @@ def test_config_limits():
     assert lib.pn2_sa_mlp3_config(3, 64, 64, 128, 48, info, None, None) != 0
 
 
+def _operand_tiles(x, ti):
+    """(32 samples, cin) -> ti operand tiles (64 lanes, 16 regs): register v of lane l = channel 32u + chan(v, l >> 5)."""
+    tiles = []
+    for u in range(ti):
+        t = np.zeros((64, 16))
+        for l in range(64):
+            for v in range(16):
+                k = 32 * u + _chan(v, l >> 5)
+                t[l, v] = x[l & 31, k] if k < x.shape[1] else 0.0
+        tiles.append(t)
+    return tiles
+
+
+def _unswap(acc_tiles, cout, bias_of):
+    """Last-layer accumulators (swapped operands: lane = channel, register = sample) -> (32, cout) with bias + ReLU."""
+    got = np.zeros((32, cout))
+    for t, acc in acc_tiles.items():
+        for l in range(64):
+            ch = 32 * t + (l & 31)
+            if ch < cout:
+                for v in range(16):
+                    got[_chan(v, l >> 5), ch] = max(acc[l, v] + bias_of(ch), 0.0)
+    return got
+
+
+def _b_at(bp_layer, ch):
+    t, c = ch >> 5, ch & 31
+    return bp_layer.reshape(-1, 2, 16)[t, (c >> 2) & 1, 4 * (c >> 3) + (c & 3)]
+
+
 @pytest.mark.parametrize("cin,widths,xyz_first", [(67, (64, 64, 128), True), (131, (128, 128, 256), True),
-                                                   (40, (50, 64, 100), False), (323, (128, 128, 256), False)])
+                                                   (40, (50, 64, 100), False), (323, (128, 128, 256), False),
+                                                   (3, (128, 128, 256), True)])
 def test_stream_pack_matches_emulated_dataflow(cin, widths, xyz_first):
-    """The streamed kernel's weight sequence: layers 1 and 2 input-tile-major (layer 1 with [features, xyz] channel
-    order and padding to whole stages), layer 3 output-tile-major; emulated exactly as sa_mlp_stream.hip walks it."""
+    """The streamed kernels' weight sequences, emulated exactly as sa_mlp_stream.hip walks them: the grouped kernel's
+    stream = [layer 2 input-tile-major, layer 3 output-tile-major]; behind it the per-point kernel's stream = the
+    FEATURE rows of layer 1, input-tile-major, padded to a stage; last the xyz rows of layer 1 (K16 step 0 of one
+    pair per output tile, LDS-resident). Layer 1 = P[j] (features . W1f + b1, once per point) + xyz part."""
     from pointnet2_amd import _C
     lib = _C.lib()
     rng = np.random.default_rng(cin)
@@ -197,53 +230,47 @@ def test_stream_pack_matches_emulated_dataflow(cin, widths, xyz_first):
     assert lib.pn2_sa_mlp3_config(cin, *widths, 32, info, ctypes.byref(wf), ctypes.byref(bf)) == 0
     assert info[0] == 1
     _, t1, t2, t3 = info
-    ti = (cin + 31) // 32
+    cfeat = cin - 3
+    tif = (cfeat + 31) // 32
     wp = np.empty(wf.value, np.float32)
     bp = np.empty(bf.value, np.float32)
     assert lib.pn2_sa_mlp3_pack(cin, *widths, 32, 1 if xyz_first else 0,
                                 *[a.ctypes.data for pair in zip(ws, bs) for a in pair], wp.ctypes.data, bp.ctypes.data) == 0
-    pairs = wp.reshape(-1, _PAIR)
-    l1 = -(-ti * t1 // 4) * 4
-    assert pairs.shape[0] == l1 + t2 * t1 + t3 * t2
+    pad = lambda k: -(-k // 4) * 4
+    main = t2 * t1 + t3 * t2
+    nstream = main + pad(tif * t1)
+    assert wp.size == nstream * _PAIR + t1 * (_PAIR // 2)
+    pairs = wp[:nstream * _PAIR].reshape(-1, _PAIR)
+    xyz_half = wp[nstream * _PAIR:].reshape(t1, _PAIR // 2)
     bias = bp.reshape(-1, 2, 16)
-    cfeat = cin - 3
     xyz = rng.standard_normal((32, 3))
     feat = rng.standard_normal((32, cfeat))
-    kern_in = np.concatenate([feat, xyz], axis=1)                  # the kernel's channel order
-    user_in = np.concatenate([xyz, feat], axis=1) if xyz_first else kern_in
-
-    def run_pair(pair, act, acc, swap=False):
-        return _emulate_pair(pair, act, acc, swap)
+    user_in = np.concatenate([xyz, feat], axis=1) if xyz_first else np.concatenate([feat, xyz], axis=1)
 
     lane_bias = lambda t0, t: np.stack([bias[t0 + t, l >> 5] for l in range(64)]).astype(np.float64)
+    # per-point kernel: P = features . W1f + b1 (non-swapped: lane = point, register v = channel chan(v, h))
     h1 = [lane_bias(0, t) for t in range(t1)]
-    for u in range(ti):
-        x0 = np.zeros((64, 16))
-        for l in range(64):
-            for v in range(16):
-                k = 32 * u + _chan(v, l >> 5)
-                x0[l, v] = kern_in[l & 31, k] if k < cin else 0.0
+    for u, x0 in enumerate(_operand_tiles(feat, tif)):
         for t in range(t1):
-            h1[t] = run_pair(pairs[u * t1 + t], x0, h1[t])
+            h1[t] = _emulate_pair(pairs[main + u * t1 + t], x0, h1[t], False)
+    # grouped kernel, layer 1: + xyz part, K16 step 0 of the xyz pairs only (step 1 must be all zero)
+    x0 = _operand_tiles(xyz, 1)[0]
+    for t in range(t1):
+        full = np.concatenate([xyz_half[t], np.zeros(_PAIR // 2, np.float32)])      # K16 step 1 is not even stored
+        h1[t] = _emulate_pair(full, x0, h1[t], False)
     h1 = [np.maximum(a, 0.0) for a in h1]
+    l1 = 0
     h2 = [lane_bias(t1, t) for t in range(t2)]
     for u in range(t1):                                              # input tiles outermost
         for t in range(t2):
-            h2[t] = run_pair(pairs[l1 + u * t2 + t], h1[u], h2[t])
+            h2[t] = _emulate_pair(pairs[l1 + u * t2 + t], h1[u], h2[t], False)
     h2 = [np.maximum(a, 0.0) for a in h2]
-    got = np.zeros((32, widths[2]))
-    b3 = bias[t1 + t2:]
+    b3 = bp[(t1 + t2) * 32:]
+    acc = {t: np.zeros((64, 16)) for t in range(t3)}
     for t in range(t3):
-        acc = np.zeros((64, 16))
         for u in range(t2):
-            acc = run_pair(pairs[l1 + t2 * t1 + t * t2 + u], h2[u], acc, swap=True)
-        for l in range(64):
-            ch = 32 * t + (l & 31)
-            if ch < widths[2]:
-                c = ch & 31
-                bb = b3[t, (c >> 2) & 1, 4 * (c >> 3) + (c & 3)]
-                for v in range(16):
-                    got[8 * (v >> 2) + 4 * (l >> 5) + (v & 3), ch] = max(acc[l, v] + bb, 0.0)
+            acc[t] = _emulate_pair(pairs[l1 + t2 * t1 + t * t2 + u], h2[u], acc[t], True)
+    got = _unswap(acc, widths[2], lambda ch: _b_at(b3, ch))
     assert np.allclose(got, _want(user_in, ws, bs), rtol=1e-9, atol=1e-9)
 
 
@@ -278,36 +305,6 @@ def test_fold_batch_norm_equals_eval_mode_layers():
 
 
 # ---- packing of the round-2 kernels: feature propagation (streamed, kind 0) and cooperative (kind 1) ---------------
-def _operand_tiles(x, ti):
-    """(32 samples, cin) -> ti operand tiles (64 lanes, 16 regs): register v of lane l = channel 32u + chan(v, l >> 5)."""
-    tiles = []
-    for u in range(ti):
-        t = np.zeros((64, 16))
-        for l in range(64):
-            for v in range(16):
-                k = 32 * u + _chan(v, l >> 5)
-                t[l, v] = x[l & 31, k] if k < x.shape[1] else 0.0
-        tiles.append(t)
-    return tiles
-
-
-def _unswap(acc_tiles, cout, bias_of):
-    """Last-layer accumulators (swapped operands: lane = channel, register = sample) -> (32, cout) with bias + ReLU."""
-    got = np.zeros((32, cout))
-    for t, acc in acc_tiles.items():
-        for l in range(64):
-            ch = 32 * t + (l & 31)
-            if ch < cout:
-                for v in range(16):
-                    got[_chan(v, l >> 5), ch] = max(acc[l, v] + bias_of(ch), 0.0)
-    return got
-
-
-def _b_at(bp_layer, ch):
-    t, c = ch >> 5, ch & 31
-    return bp_layer.reshape(-1, 2, 16)[t, (c >> 2) & 1, 4 * (c >> 3) + (c & 3)]
-
-
 @pytest.mark.parametrize("kind", [0, 1], ids=["streamed", "cooperative"])
 @pytest.mark.parametrize("c2,c1,widths", [(40, 8, (100, 60)), (24, 0, (128, 128, 70)), (36, 5, (130, 128))])
 def test_fp_pack_matches_emulated_dataflow(kind, c2, c1, widths):
