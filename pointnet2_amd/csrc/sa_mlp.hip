@@ -157,6 +157,15 @@ __global__ __launch_bounds__(NT) void sa_mlp3_kernel(int n, int m, int nsample, 
         const float *pf = points ? points + ((size_t)cloud * n + p) * cfeat : nullptr;
         const float *c = new_xyz + row * 3;
         f32x16 x0;
+        if (!points) {                                   // xyz only (every first SA level): three loads, no per-register tests
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { x0[v] = 0.0f; cen[v] = 0.0f; }
+            if (h == 0) {
+                x0[0] = px[0]; x0[1] = px[1]; x0[2] = px[2];
+                cen[0] = c[0]; cen[1] = c[1]; cen[2] = c[2];
+            }
+            return x0;
+        }
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int k = mlp_chan(v, h);

@@ -109,18 +109,23 @@ __global__ __launch_bounds__(kStreamThreads) void point_layer_kernel(int cfeat, 
 #pragma unroll
         for (int t = 0; t < T1; ++t) acc[t] = mlp_bias(bias_s, t, h);
         if (tif > 0) {
-            f32x16 x = load_tile(0);
+            // the NEXT tile is split into its levels in the middle of this tile's MFMAs (the barrier of the stream keeps
+            // the eight waves in step: a split at the top of the loop would idle every matrix pipe at the same time)
+            ActSplit xs = split_act(load_tile(0));
+            f32x16 xn = load_tile(tif > 1 ? 1 : 0);
             int slot = 0;
             for (int u = 0; u < tif; ++u) {
-                f32x16 xn = x;
-                if (u + 1 < tif) xn = load_tile(u + 1);                    // one tile ahead of the MFMAs
-                const ActSplit xs = split_act(x);
+                ActSplit xsn;
 #pragma unroll
                 for (int t = 0; t < T1; ++t) {
+                    if (t == T1 / 2) {
+                        xsn = split_act(xn);
+                        if (u + 2 < tif) xn = load_tile(u + 2);            // two tiles ahead of the MFMAs
+                    }
                     acc[t] = stream_pair<false>(wbuf[stage & 1], slot, lane, xs, acc[t]);
                     if (++slot == kS) { slot = 0; PN2_NEXT_STAGE(); }
                 }
-                x = xn;
+                xs = xsn;
             }
             if (slot != 0) PN2_NEXT_STAGE();                                    // padded to whole stages
         }
@@ -203,27 +208,30 @@ __global__ __launch_bounds__(kStreamThreads) void sa_mlp3_stream_kernel(int n, i
                     h1[t] = mma_x6<false>(w0, xs.p[0], h1[t]);
                 }
             }
-            // layer 2, input tiles outermost: a tile of layer-1 output is split into its bf16 levels right
-            // before its pairs run, so only ONE split input tile is alive beside the T2 accumulators
-            ActSplit s2[T2];
-            {
-                f32x16 a2[T2];
+            // layer 2, input tiles outermost: only ONE input tile is alive in its three-level form beside the T2
+            // accumulators. The level split of the NEXT tile sits in the middle of this tile's pairs: the stream's
+            // barrier keeps the eight waves in step, so a split between two tiles would idle every matrix pipe at once.
+            f32x16 a2[T2];
 #pragma unroll
-                for (int t = 0; t < T2; ++t) a2[t] = mlp_bias(b2, t, h);
+            for (int t = 0; t < T2; ++t) a2[t] = mlp_bias(b2, t, h);
+            {
+                ActSplit su = split_act(mlp_relu(h1[0]));
 #pragma unroll
                 for (int u = 0; u < T1; ++u) {
-                    __builtin_amdgcn_sched_barrier(0);       // or hipcc splits every tile up front and spills
-                    const ActSplit su = split_act(mlp_relu(h1[u]));
+                    ActSplit sn;
 #pragma unroll
                     for (int t = 0; t < T2; ++t) {
+                        if (t == T2 / 2 && u + 1 < T1) sn = split_act(mlp_relu(h1[u + 1]));
                         a2[t] = stream_pair<false>(wbuf[stage & 1], (u * T2 + t) % kS, lane, su, a2[t]);
                         if ((u * T2 + t) % kS == kS - 1) PN2_NEXT_STAGE();
                     }
+                    if (u + 1 < T1) su = sn;
                 }
-#pragma unroll
-                for (int t = 0; t < T2; ++t) s2[t] = split_act(mlp_relu(a2[t]));
             }
-            // layer 3, operands swapped: a lane holds 16 samples of channel 32t + (l & 31)
+            // layer 3, operands swapped: a lane holds 16 samples of channel 32t + (l & 31). Its first output tile
+            // walks the input tiles while the following one is still being split (same reason as above).
+            ActSplit s2[T2];
+            s2[0] = split_act(mlp_relu(a2[0]));
 #pragma unroll
             for (int t = 0; t < T3; ++t) {
                 f32x16 acc;
@@ -231,6 +239,7 @@ __global__ __launch_bounds__(kStreamThreads) void sa_mlp3_stream_kernel(int n, i
                 for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
 #pragma unroll
                 for (int u = 0; u < T2; ++u) {
+                    if (t == 0 && u + 1 < T2) s2[u + 1] = split_act(mlp_relu(a2[u + 1]));
                     acc = stream_pair<true>(wbuf[stage & 1], (t * T2 + u) % kS, lane, s2[u], acc);
                     if ((t * T2 + u) % kS == kS - 1) PN2_NEXT_STAGE();
                 }

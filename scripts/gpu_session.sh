@@ -19,7 +19,7 @@ for step in "$@"; do
     tests_fp)  timeout 600 python -m pytest tests/test_fp_mlp_gpu.py tests/test_sa_mlp_gpu.py tests/test_modules_gpu.py tests/test_graph_capture_gpu.py -m gpu -q > "$OUT/tests_fp.log" 2>&1; tail -15 "$OUT/tests_fp.log" ;;
     models)    timeout 600 python scripts/model_forward_bench.py > "$OUT/model_forward.log" 2>&1; cat "$OUT/model_forward.log" ;;
     prof_model) (cd /tmp && export TMPDIR=/tmp && PN2_MODEL_FUSED_ONLY=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_model" -- python $ROOT/scripts/model_forward_bench.py ${MODEL:-sem_seg} > "$OUT/prof_model.log" 2>&1); find "$OUT/prof_model" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_model_${MODEL:-sem_seg}.csv" \;; rm -rf "$OUT/prof_model"; head -30 "$OUT/kernel_stats_model_${MODEL:-sem_seg}.csv" | cut -c1-150 ;;
-    prof_models) for MODEL in cls_ssg cls_msg part_seg sem_seg; do (cd /tmp && export TMPDIR=/tmp && PN2_MODEL_FUSED_ONLY=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_model" -- python $ROOT/scripts/model_forward_bench.py $MODEL > "$OUT/prof_model_$MODEL.log" 2>&1); find "$OUT/prof_model" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_model_$MODEL.csv" \;; rm -rf "$OUT/prof_model"; grep fused "$OUT/prof_model_$MODEL.log"; head -14 "$OUT/kernel_stats_model_$MODEL.csv" | cut -c1-140; done ;;
+    prof_models) for MODEL in ${MODELS:-cls_ssg cls_msg part_seg sem_seg}; do (cd /tmp && export TMPDIR=/tmp && PN2_MODEL_FUSED_ONLY=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_model" -- python $ROOT/scripts/model_forward_bench.py $MODEL > "$OUT/prof_model_$MODEL.log" 2>&1); find "$OUT/prof_model" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_model_$MODEL.csv" \;; rm -rf "$OUT/prof_model"; grep fused "$OUT/prof_model_$MODEL.log"; head -14 "$OUT/kernel_stats_model_$MODEL.csv" | cut -c1-140; done ;;
     mlplab)    for f in "" $(ls build_lab/libpn2ops_*.so); do echo "--- ${f:-product}"; PN2OPS_LIBRARY=${f:+$ROOT/$f} PN2_MLP_BENCH_KERNEL_ONLY=1 timeout 200 python scripts/sa_mlp_bench.py 2>&1 | grep kernel | grep -E "${MLPLAB_FILTER:-.}"; done > "$OUT/mlplab.log" 2>&1; cat "$OUT/mlplab.log" ;;
     mlpacc)    timeout 300 python scripts/mlp_accuracy.py > "$OUT/mlp_accuracy.log" 2>&1; cat "$OUT/mlp_accuracy.log" ;;
     mlpbench)  timeout 300 python scripts/sa_mlp_bench.py --json "$OUT/sa_mlp_bench.json" > "$OUT/sa_mlp_bench.log" 2>&1; cut -c1-200 "$OUT/sa_mlp_bench.log" ;;
