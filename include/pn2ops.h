@@ -162,11 +162,12 @@ int pn2_sa_mlp3_config(int cin, int c1, int c2, int c3, int nsample, int *info4,
 int pn2_sa_mlp3_pack(int cin, int c1, int c2, int c3, int nsample, int xyz_first, const float *w1, const float *bias1,
                      const float *w2, const float *bias2, const float *w3, const float *bias3, float *wpacked,
                      float *bpacked);
-/* ws: scratch of pn2_sa_mlp3_ws_bytes(b, n, 3 + cfeat, c1, c2, c3, nsample) bytes (0 for the resident and cooperative
- * kernels: NULL is fine then). The streamed kernel evaluates the FEATURE part of layer 1 once per point into it
- * (W1^T [f_j, xyz_j - c] = W1f^T f_j + W1x^T (xyz_j - c): the first term does not depend on the centroid, and a point
- * belongs to nsample * m / n groups) and starts every sample from its point's row. */
-long long pn2_sa_mlp3_ws_bytes(int b, int n, int cin, int c1, int c2, int c3, int nsample);
+/* ws: scratch of pn2_sa_mlp3_ws_bytes(b, n, m, 3 + cfeat, c1, c2, c3, nsample) bytes (0 for the resident kernel and most
+ * cooperative shapes: NULL is fine then). The streamed kernel evaluates the FEATURE part of layer 1 once per point into
+ * it (W1^T [f_j, xyz_j - c] = W1f^T f_j + W1x^T (xyz_j - c): the first term does not depend on the centroid, and a point
+ * belongs to nsample * m / n groups) and starts every sample from its point's row. Stacks whose last layer is wider than
+ * 512 (the group_all level's 256-512-1024) keep the second layer's output there for the GEMM that runs the last layer. */
+long long pn2_sa_mlp3_ws_bytes(int b, int n, int m, int cin, int c1, int c2, int c3, int nsample);
 int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, const float *xyz, const float *new_xyz,
                         const float *points, const int *idx, int c1, int c2, int c3, const float *wpacked,
                         const float *bpacked, float *out, void *ws, void *stream);

@@ -37,11 +37,15 @@ __device__ __forceinline__ float coop_interp3(float p1, float p2, float p3, floa
 }
 
 // Q1, Q2, Q3: output tiles PER WAVE of the three layers (layer widths 128 * Q); Q3 == 0: two layers.
-template <int GATHER, int Q1, int Q2, int Q3>
+// SPLIT_OUT (two grouped layers): the second layer is a HIDDEN layer whose output tiles leave for global memory
+// in their three-level operand form, [unit][tile][e][level][lane] -- the A operand of pool_gemm_kernel below,
+// which runs the wide last layer of such a stack as a tiled GEMM.
+template <int GATHER, int Q1, int Q2, int Q3, bool SPLIT_OUT = false>
 __global__ __launch_bounds__(kMlpThreads) void coop_mlp_kernel(CoopParams p)
 {
     constexpr int T1 = 4 * Q1, T2 = 4 * Q2, T3 = 4 * Q3;
     constexpr bool THREE = Q3 > 0;
+    static_assert(!SPLIT_OUT || (Q3 == 0 && GATHER == kGatherGrouped), "split output: two grouped layers");
     constexpr int QL = THREE ? Q3 : Q2;                                   // the last layer's tiles per wave
     constexpr bool POOL = GATHER == kGatherGrouped;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(kMlpThreads) void coop_mlp_kernel(CoopParams p)
     const int parts = POOL ? (p.nsample + 31) / 32 : 1;
     // p.split: the 32-sample parts of a group are separate work units (few, large groups -- the group_all level:
     // 32 clouds x 4 parts), merged with an integer atomic max on the pre-zeroed output (values are >= 0 after ReLU)
-    const int parts_in = p.split ? 1 : parts;
+    const int parts_in = p.split ? 1 : parts;                             // SPLIT_OUT always runs with p.split
     const long long units = POOL ? (p.split ? p.rows * parts : p.rows) : (p.rows + 31) / 32;
     const int cin = POOL ? p.cf + 3 : p.cf + p.c1;
 
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(kMlpThreads) void coop_mlp_kernel(CoopParams p)
                 }
             };
 
-            if (!THREE) {
+            if (!THREE && !SPLIT_OUT) {
                 last_layer(act1, T1);
                 __syncthreads();                                              // act1 is rewritten by the next item
             } else {
@@ -254,14 +258,21 @@ __global__ __launch_bounds__(kMlpThreads) void coop_mlp_kernel(CoopParams p)
                     for (int g = 0; g < Q2; ++g) PN2_COOP_PAIR(false, xa, a2[g]);
                     xa = xb;
                 }
+                if (SPLIT_OUT) {
+                    u32x4 *dst = reinterpret_cast<u32x4 *>(p.out) + (size_t)unit_raw * T2 * kTileVec;
 #pragma unroll
-                for (int g = 0; g < Q2; ++g) act_store(act2, 4 * g + w, mlp_relu(a2[g]));
-                __syncthreads();                                              // also: everyone is done reading act1
-                last_layer(act2, T2);
-                // act2 is rewritten only after the next item's first barrier: no barrier needed here
+                    for (int g = 0; g < Q2; ++g) act_store(dst, 4 * g + w, mlp_relu(a2[g]));
+                    __syncthreads();                                          // everyone is done reading act1
+                } else {
+#pragma unroll
+                    for (int g = 0; g < Q2; ++g) act_store(act2, 4 * g + w, mlp_relu(a2[g]));
+                    __syncthreads();                                          // also: everyone is done reading act1
+                    last_layer(act2, T2);
+                    // act2 is rewritten only after the next item's first barrier: no barrier needed here
+                }
             }
         }
-        if (POOL) {
+        if (POOL && !SPLIT_OUT) {
 #pragma unroll
             for (int g = 0; g < QL; ++g) {
                 const int ch = 32 * (4 * g + w) + s;
@@ -275,6 +286,123 @@ __global__ __launch_bounds__(kMlpThreads) void coop_mlp_kernel(CoopParams p)
         }
     }
 #undef PN2_COOP_PAIR
+}
+
+// ---- the wide last layer of a (c1, c2, c3 > 512) stack as a tiled GEMM + max-pool ------------------------------
+// With one item per workgroup the cooperative kernel streams EVERY weight of the stack through every CU's vector
+// memory path for 32 rows of work (64 B/clk per CU at full MFMA rate: it is L1-bound), and the group_all level --
+// 73 % of it the 512 x 1024 last layer -- has only 128 items. Here that layer is a GEMM: a workgroup owns one group
+// (centroid / cloud) x 128 output channels; per 32-channel step of the contraction it stages the group's input tiles
+// (already in three-level operand form, written by coop_mlp_kernel<..., SPLIT_OUT>) and its slice of the weights into
+// LDS, double-buffered through registers like the streamed kernels, and every weight fragment serves four row tiles.
+// Wave w: row tile w & 3 of the current chunk of four, output tiles 2 (w >> 2) and 2 (w >> 2) + 1 of the block; swapped
+// operands (lane = channel), so the pool is lane-local + one LDS atomic max per channel on relu(x + bias) >= 0.
+constexpr int kGemmThreads = 512, kGemmColTiles = 4, kGemmRowTiles = 4;
+constexpr int kGemmStageVec = (kGemmColTiles + kGemmRowTiles) * (kPairWords / 4);   // 48 KiB per contraction step
+
+__global__ __launch_bounds__(kGemmThreads) void pool_gemm_kernel(int parts, int tk, int cout, long long groups,
+                                                                const float *__restrict__ asplit,
+                                                                const float *__restrict__ wgemm,
+                                                                const float *__restrict__ bias, float *__restrict__ out)
+{
+    constexpr int kTileVec = kPairWords / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4 *buf0 = reinterpret_cast<u32x4 *>(smem), *buf1 = buf0 + kGemmStageVec;
+    int *colmax = reinterpret_cast<int *>(buf1 + kGemmStageVec);          // [32 * kGemmColTiles]
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, s = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), rt = w & 3, cp = w >> 2;
+    const int colblocks = (cout + 32 * kGemmColTiles - 1) / (32 * kGemmColTiles);
+    static_assert(kGemmStageVec == 6 * kGemmThreads, "six staging vectors per thread: three of A, three of W");
+    // this thread's six vectors of a stage: vector i = tid + j * 512; i < 4 tiles: row tile i / kTileVec of the chunk
+    // (a tail chunk repeats the last part: harmless under max), else the weights of the contraction step
+    const int ar0 = tid / kTileVec, ao0 = tid % kTileVec;
+    const int ar1 = (tid + kGemmThreads) / kTileVec, ao1 = (tid + kGemmThreads) % kTileVec;
+    const int ar2 = (tid + 2 * kGemmThreads) / kTileVec, ao2 = (tid + 2 * kGemmThreads) % kTileVec;
+    for (long long job = blockIdx.x; job < groups * colblocks; job += gridDim.x) {
+        const long long grp = job / colblocks;
+        const int cb = (int)(job % colblocks);
+        for (int i = tid; i < 32 * kGemmColTiles; i += kGemmThreads) colmax[i] = 0;
+        const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(wgemm) + (size_t)cb * tk * (kGemmColTiles * kTileVec) + tid;
+        for (int chunk = 0; chunk < parts; chunk += kGemmRowTiles) {
+            const u32x4 *a0 = reinterpret_cast<const u32x4 *>(asplit) + (size_t)(grp * parts + min(chunk + ar0, parts - 1)) * tk * kTileVec + ao0;
+            const u32x4 *a1 = reinterpret_cast<const u32x4 *>(asplit) + (size_t)(grp * parts + min(chunk + ar1, parts - 1)) * tk * kTileVec + ao1;
+            const u32x4 *a2 = reinterpret_cast<const u32x4 *>(asplit) + (size_t)(grp * parts + min(chunk + ar2, parts - 1)) * tk * kTileVec + ao2;
+            // two stages in flight in registers (sets E / O for even / odd contraction steps): a step is ~0.8 us of MFMA
+            // work per SIMD, less than an L2 round trip under load, so one stage ahead left the loads exposed
+            u32x4 e0, e1, e2, e3, e4, e5, o0, o1, o2, o3, o4, o5;
+#define PN2_GEMM_ISSUE(u, S)                                                                                          \
+    do {                                                                                                              \
+        S##0 = a0[(size_t)(u) * kTileVec]; S##1 = a1[(size_t)(u) * kTileVec]; S##2 = a2[(size_t)(u) * kTileVec];       \
+        const u32x4 *ws_ = wsrc + (size_t)(u) * (kGemmColTiles * kTileVec);                                           \
+        S##3 = ws_[0]; S##4 = ws_[kGemmThreads]; S##5 = ws_[2 * kGemmThreads];                                        \
+    } while (0)
+#define PN2_GEMM_COMMIT(B, S)                                                                                         \
+    do {                                                                                                              \
+        u32x4 *d_ = (B) + tid;                                                                                        \
+        d_[0] = S##0; d_[kGemmThreads] = S##1; d_[2 * kGemmThreads] = S##2;                                           \
+        d_[3 * kGemmThreads] = S##3; d_[4 * kGemmThreads] = S##4; d_[5 * kGemmThreads] = S##5;                        \
+    } while (0)
+#define PN2_GEMM_STEP(cur)                                                                                            \
+    do {                                                                                                              \
+        const u32x4 *a = (cur) + rt * kTileVec + lane;                                                                \
+        const u32x4 *b0 = (cur) + (kGemmRowTiles + 2 * cp) * kTileVec + lane;                                         \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                               \
+            const u32x4 x[3] = {a[(e * 3 + 0) * 64], a[(e * 3 + 1) * 64], a[(e * 3 + 2) * 64]};                       \
+            _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                           \
+                const u32x4 *b = b0 + c * kTileVec;                                                                   \
+                const u32x4 wv[3] = {b[(e * 3 + 0) * 64], b[(e * 3 + 1) * 64], b[(e * 3 + 2) * 64]};                  \
+                acc[c] = mma_x6<true>(wv, x, acc[c]);                                                                 \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+            f32x16 acc[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[c][v] = 0.0f;
+            // (every ISSUE is unconditional, clamped to the last step: behind a branch the compiler must assume the loads
+            // may not have been issued and makes the COMMIT of the OTHER set wait for them too -- vmcnt counts in order)
+            const int last = tk - 1;
+            PN2_GEMM_ISSUE(0, e);
+            PN2_GEMM_ISSUE(min(1, last), o);
+            __syncthreads();                                   // the previous chunk's readers are done with both buffers
+            PN2_GEMM_COMMIT(buf0, e);
+            __syncthreads();
+            PN2_GEMM_ISSUE(min(2, last), e);
+            // A stage is WRITTEN to LDS before the MFMAs of the step that precedes it (its registers were loaded a whole
+            // step earlier): the barrier keeps the eight waves in step, so writes issued after the MFMAs would be 600
+            // LDS cycles in which every matrix pipe of the CU idles.
+            for (int u = 0; u < tk; u += 2) {
+                PN2_GEMM_COMMIT(buf1, o);                         // stage u + 1 (buf1's readers finished before the last barrier)
+                PN2_GEMM_STEP(buf0);                              // step u
+                __syncthreads();
+                PN2_GEMM_ISSUE(min(u + 3, last), o);
+                PN2_GEMM_COMMIT(buf0, e);                         // stage u + 2 (tk is even: 4 tiles per 128 channels)
+                PN2_GEMM_STEP(buf1);                              // step u + 1
+                __syncthreads();
+                PN2_GEMM_ISSUE(min(u + 4, last), e);
+            }
+#undef PN2_GEMM_ISSUE
+#undef PN2_GEMM_COMMIT
+#undef PN2_GEMM_STEP
+            // register v of lane (c, hh) holds row mlp_chan(v, hh) of the row tile, channel 32 (block tile) + c
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float mx = acc[c][0];
+#pragma unroll
+                for (int v = 1; v < 16; ++v) mx = fmaxf(mx, acc[c][v]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const int col = 32 * (2 * cp + c) + s, ch = 32 * kGemmColTiles * cb + col;
+                if (h == 0 && ch < cout) atomicMax(&colmax[col], __float_as_int(fmaxf(__fadd_rn(mx, bias[ch]), 0.0f)));
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 32 * kGemmColTiles; i += kGemmThreads) {
+            const int ch = 32 * kGemmColTiles * cb + i;
+            if (ch < cout) out[grp * cout + ch] = __int_as_float(colmax[i]);
+        }
+        __syncthreads();
+    }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
@@ -293,33 +421,56 @@ bool mlp_coop_pick(int cin, int nlayers, const int *widths, MlpCoopConfig &cfg)
     return true;
 }
 
+// the (.., .., > 512) grouped stacks run their last layer in pool_gemm_kernel: the packed array then holds the
+// cooperative kernel's stream of layers 1-2 followed by the last layer in GEMM order (same number of pairs)
+bool mlp_coop_gemm_last(const MlpCoopConfig &c, int fp) { return !fp && c.q3 == 8; }
+
 static long long coop_pairs(const MlpCoopConfig &c)
 {
     return 4ll * ((long long)c.ti * c.q1 + 4ll * c.q1 * c.q2 + 4ll * c.q2 * c.q3);
 }
 size_t mlp_coop_w_floats(const MlpCoopConfig &c) { return (size_t)coop_pairs(c) * kPairWords; }
+size_t mlp_coop_ws_bytes(const MlpCoopConfig &c, int fp, long long rows, int nsample)
+{
+    if (!mlp_coop_gemm_last(c, fp)) return 0;
+    return sizeof(float) * kPairWords * (size_t)rows * ((nsample + 31) / 32) * (4 * c.q2);
+}
 size_t mlp_coop_b_floats(const MlpCoopConfig &c) { return (size_t)(4 * (c.q1 + c.q2 + c.q3)) * 32; }
 
 // krow: permutation of the first layer's weight rows (kernel channel order -> caller's row), or nullptr
 void mlp_coop_pack(const MlpCoopConfig &c, int cin, int nlayers, const int *widths, const int *krow, const float *const *ws,
-                   const float *const *bs, float *wpacked, float *bpacked)
+                   const float *const *bs, float *wpacked, float *bpacked, bool krow_is_grouped)
 {
     float *wp = wpacked;
     const int tin[3] = {c.ti, 4 * c.q1, 4 * c.q2}, qq[3] = {c.q1, c.q2, c.q3};
     const int kin[3] = {cin, widths[0], nlayers > 1 ? widths[1] : 0};
-    for (int L = 0; L < nlayers; ++L)
+    const bool gemm_last = krow_is_grouped && mlp_coop_gemm_last(c, 0);
+    for (int L = 0; L < nlayers; ++L) {
+        if (L == 2 && gemm_last) {                             // [column block][contraction tile][tile of the block]
+            for (int cb = 0; cb < 4 * qq[2] / kGemmColTiles; ++cb)
+                for (int u = 0; u < tin[2]; ++u)
+                    for (int ct = 0; ct < kGemmColTiles; ++ct)
+                        wp = mlp_pack_pair_x6(wp, ws[2], kin[2], widths[2], kGemmColTiles * cb + ct, u, nullptr);
+            continue;
+        }
         for (int u = 0; u < tin[L]; ++u)                       // input tiles outermost, then the wave's tile groups,
             for (int g = 0; g < qq[L]; ++g)                    // then the four waves: pair 4k + w belongs to wave w
                 for (int wv = 0; wv < 4; ++wv)
                     wp = mlp_pack_pair_x6(wp, ws[L], kin[L], widths[L], 4 * g + wv, u, L == 0 ? krow : nullptr);
+    }
     float *bp = bpacked;
-    for (int L = 0; L < 3; ++L)
+    for (int L = 0; L < 3; ++L) {
+        if (L == 2 && gemm_last) {                             // plain channel order
+            for (int ch = 0; ch < 32 * 4 * qq[2]; ++ch) *bp++ = ch < widths[2] ? bs[2][ch] : 0.0f;
+            continue;
+        }
         for (int t = 0; t < 4 * qq[L]; ++t)
             for (int hh = 0; hh < 2; ++hh)
                 for (int v = 0; v < 16; ++v) {
                     const int ch = 32 * t + mlp_chan(v, hh);
                     *bp++ = (L < nlayers && ch < widths[L]) ? bs[L][ch] : 0.0f;
                 }
+    }
 }
 
 template <int GATHER, int Q1, int Q2, int Q3>
@@ -332,8 +483,34 @@ static int launch_coop(const CoopParams &p, long long units, hipStream_t st)
     return launch(kern, dim3((unsigned)blocks), dim3(kMlpThreads), lds, st, p);
 }
 
-int mlp_coop_launch(const MlpCoopConfig &c, int fp, const CoopParams &p_in, hipStream_t st)
+// layers 1-2 by the cooperative kernel into `ws` (three-level operand tiles), the last layer + pool as a GEMM
+static int launch_gemm_last(const MlpCoopConfig &c, const CoopParams &p_in, void *ws, hipStream_t st)
 {
+    if (!ws) return PN2_E_NULL;
+    CoopParams p = p_in;
+    const int parts = (p.nsample + 31) / 32, t2 = 4 * c.q2;
+    p.split = 1;
+    float *final_out = p.out;
+    p.out = (float *)ws;
+    {
+        auto kern = coop_mlp_kernel<kGatherGrouped, 2, 4, 0, true>;
+        const size_t lds = sizeof(float) * kPairWords * (size_t)(4 * 2) + sizeof(float) * 32 * (size_t)(4 * (2 + 4));
+        if (int rc = allow_dynamic_lds(kern, lds)) return rc;
+        const long long units = p.rows * parts;
+        if (int rc = launch(kern, dim3((unsigned)(units < 512 ? units : 512)), dim3(kMlpThreads), lds, st, p)) return rc;
+    }
+    const size_t two_layers = (size_t)kPairWords * 4 * (size_t)(c.ti * c.q1 + 4 * c.q1 * c.q2);      // words of layers 1-2
+    const float *wgemm = p.wp + two_layers, *b3 = p.bp + 32 * (size_t)(4 * (c.q1 + c.q2));
+    const size_t lds = sizeof(u32x4) * 2 * kGemmStageVec + sizeof(int) * 32 * kGemmColTiles;
+    if (int rc = allow_dynamic_lds(pool_gemm_kernel, lds)) return rc;
+    const long long jobs = p.rows * ((p.cout + 32 * kGemmColTiles - 1) / (32 * kGemmColTiles));
+    return launch(pool_gemm_kernel, dim3((unsigned)(jobs < 1024 ? jobs : 1024)), dim3(kGemmThreads), lds, st, parts, t2, p.cout,
+                  p.rows, (const float *)ws, wgemm, b3, final_out);
+}
+
+int mlp_coop_launch(const MlpCoopConfig &c, int fp, const CoopParams &p_in, hipStream_t st, void *ws)
+{
+    if (mlp_coop_gemm_last(c, fp)) return launch_gemm_last(c, p_in, ws, st);
     CoopParams p = p_in;
     const int parts = (p.nsample + 31) / 32;
     p.split = (!fp && parts > 1 && p.rows < 256) ? 1 : 0;          // few large groups: one work unit per 32-sample part
@@ -346,7 +523,6 @@ int mlp_coop_launch(const MlpCoopConfig &c, int fp, const CoopParams &p_in, hipS
     if (fp == (G == kGatherInterp) && c.q1 == A && c.q2 == B && c.q3 == C) return launch_coop<G, A, B, C>(p, units, st)
     PN2_COOP_CASE(kGatherGrouped, 1, 1, 2);
     PN2_COOP_CASE(kGatherGrouped, 2, 2, 4);
-    PN2_COOP_CASE(kGatherGrouped, 2, 4, 8);
     PN2_COOP_CASE(kGatherInterp, 1, 1, 0);
     PN2_COOP_CASE(kGatherInterp, 2, 1, 0);
     PN2_COOP_CASE(kGatherInterp, 2, 2, 0);

@@ -284,7 +284,7 @@ extern "C" int pn2_fp_mlp_pack(int c2, int c1, int nlayers, const int *widths, i
     if (kind == 1) {
         MlpCoopConfig cc;
         if (!mlp_coop_pick(cin, nlayers, widths, cc) || !mlp_coop_has_kernel(cc, 1)) return PN2_E_TOO_LARGE;
-        mlp_coop_pack(cc, cin, nlayers, widths, nullptr, w, bias, wpacked, bpacked);
+        mlp_coop_pack(cc, cin, nlayers, widths, nullptr, w, bias, wpacked, bpacked, false);
         return PN2_OK;
     }
     FpConfig c;
@@ -331,7 +331,7 @@ extern "C" int pn2_fp_mlp(int b, int n, int m, int c2, int c1, const float *poin
     if (kind == 1) {
         CoopParams p = {n, m, 0, c2, c1, cout, cc.ti, rows, nullptr, nullptr, points2, c1 > 0 ? points1 : nullptr, idx, dist,
                         wpacked, bpacked, out, 0};
-        return mlp_coop_launch(cc, 1, p, st);
+        return mlp_coop_launch(cc, 1, p, st, nullptr);
     }
 #define PN2_FP_CASE(A, B, C)                                                                                           \
     if (c.t1 == A && c.t2 == B && c.t3 == C)                                                                            \

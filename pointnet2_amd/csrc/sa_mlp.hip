@@ -403,7 +403,7 @@ extern "C" int pn2_sa_mlp3_pack(int cin, int c1, int c2, int c3, int nsample, in
         const int cf = cin - 3, widths[3] = {c1, c2, c3};
         int *krow = (int *)malloc(sizeof(int) * (size_t)cin);
         for (int k = 0; k < cin; ++k) krow[k] = xyz_first ? (k < cf ? 3 + k : k - cf) : k;
-        mlp_coop_pack(cc, cin, 3, widths, krow, ws, bs, wpacked, bpacked);
+        mlp_coop_pack(cc, cin, 3, widths, krow, ws, bs, wpacked, bpacked, true);
         free(krow);
         return PN2_OK;
     }
@@ -427,18 +427,21 @@ extern "C" int pn2_sa_mlp3_pack(int cin, int c1, int c2, int c3, int nsample, in
     return PN2_OK;
 }
 
-// Scratch pn2_sa_mlp3_maxpool needs for this call (0 for the resident and cooperative kernels; the streamed one keeps
-// the per-point part of layer 1 there: b * n rows of the padded first width).
-extern "C" long long pn2_sa_mlp3_ws_bytes(int b, int n, int cin, int c1, int c2, int c3, int nsample)
+// Scratch pn2_sa_mlp3_maxpool needs for this call: the streamed kernel keeps the per-point part of layer 1 there
+// (b * n rows of the padded first width); stacks with a last layer wider than 512 (the group_all level) keep the
+// second layer's output there, in operand form, for the GEMM that runs the last layer; 0 otherwise.
+extern "C" long long pn2_sa_mlp3_ws_bytes(int b, int n, int m, int cin, int c1, int c2, int c3, int nsample)
 {
     using namespace pn2;
     int kind;
     MlpConfig rc;
     MlpStreamConfig sc;
     MlpCoopConfig cc;
-    if (b <= 0 || n <= 0 || cin < 3 || c1 <= 0 || c2 <= 0 || c3 <= 0 || nsample <= 0) return 0;
-    if (!mlp_choose(cin, c1, c2, c3, nsample, kind, rc, sc, cc) || kind != 1) return 0;
-    return (long long)mlp_stream_ws_bytes(sc, (long long)b * n);
+    if (b <= 0 || n <= 0 || m <= 0 || cin < 3 || c1 <= 0 || c2 <= 0 || c3 <= 0 || nsample <= 0) return 0;
+    if (!mlp_choose(cin, c1, c2, c3, nsample, kind, rc, sc, cc)) return 0;
+    if (kind == 1) return (long long)mlp_stream_ws_bytes(sc, (long long)b * n);
+    if (kind == 2) return (long long)mlp_coop_ws_bytes(cc, 0, (long long)b * m, nsample);
+    return 0;
 }
 
 extern "C" int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, const float *xyz, const float *new_xyz,
@@ -465,7 +468,7 @@ extern "C" int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, 
     if (kind == 2) {
         CoopParams p = {n, m, nsample, cfeat, 0, c3, cc.ti, (long long)b * m, xyz, new_xyz, pts, nullptr, idx, nullptr,
                         wpacked, bpacked, out, 0};
-        return mlp_coop_launch(cc, 0, p, st);
+        return mlp_coop_launch(cc, 0, p, st, ws);
     }
     if (kind == 1)
         return mlp_stream_launch(sc, b, n, m, nsample, cfeat, c3, xyz, new_xyz, pts ? pts : xyz, idx, wpacked, bpacked, out, ws, st);

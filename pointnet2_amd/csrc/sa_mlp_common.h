@@ -162,7 +162,9 @@ bool mlp_coop_has_kernel(const MlpCoopConfig &c, int fp);
 size_t mlp_coop_w_floats(const MlpCoopConfig &c);
 size_t mlp_coop_b_floats(const MlpCoopConfig &c);
 void mlp_coop_pack(const MlpCoopConfig &c, int cin, int nlayers, const int *widths, const int *krow, const float *const *ws,
-                   const float *const *bs, float *wpacked, float *bpacked);
-int mlp_coop_launch(const MlpCoopConfig &c, int fp, const CoopParams &p, hipStream_t st);
+                   const float *const *bs, float *wpacked, float *bpacked, bool krow_is_grouped);
+bool mlp_coop_gemm_last(const MlpCoopConfig &c, int fp);
+size_t mlp_coop_ws_bytes(const MlpCoopConfig &c, int fp, long long rows, int nsample);
+int mlp_coop_launch(const MlpCoopConfig &c, int fp, const CoopParams &p, hipStream_t st, void *ws);
 
 }  // namespace pn2

@@ -106,9 +106,9 @@ def sa_mlp_maxpool(xyz, new_xyz, points, idx, packed):
     tensors = [t for t in (xyz, new_xyz, idx, points, packed.wp) if t is not None]
     dev = same_device(*tensors)
     out = torch.empty((b, m, packed.widths[2]), dtype=torch.float32, device=dev)
-    ws = None
-    if packed.kind == "streamed":                  # the per-point part of layer 1 lives in caller-provided scratch
-        nbytes = _C.lib().pn2_sa_mlp3_ws_bytes(b, n, packed.cin, packed.widths[0], packed.widths[1], packed.widths[2], ns)
+    ws = None                                      # scratch is the caller's (per-point layer 1 / input of the last-layer GEMM)
+    nbytes = _C.lib().pn2_sa_mlp3_ws_bytes(b, n, m, packed.cin, packed.widths[0], packed.widths[1], packed.widths[2], ns)
+    if nbytes:
         ws = torch.empty(((nbytes + 3) // 4,), dtype=torch.float32, device=dev)
     with on_device(dev):
         _C.check(_C.lib().pn2_sa_mlp3_maxpool(b, n, m, ns, cfeat, ptr(xyz), ptr(new_xyz), ptr(points), ptr(idx),

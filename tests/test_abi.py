@@ -118,10 +118,12 @@ def test_c_abi_argument_validation_of_the_extra_entry_points():
     assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 32, 4, one, one, None, one, 64, 64, 128, one, one, one, None, None) == -1   # points missing
     assert lib.pn2_sa_mlp3_pack(3, 64, 64, 128, 32, 1, None, None, None, None, None, None, None, None) == -1
     # scratch: only the streamed kernel needs any (the per-point part of layer 1: b * n rows of the padded first width)
-    assert lib.pn2_sa_mlp3_ws_bytes(2, 100, 3, 64, 64, 128, 32) == 0
-    assert lib.pn2_sa_mlp3_ws_bytes(2, 100, 131, 128, 128, 256, 64) == 4 * 2 * 100 * 128
-    assert lib.pn2_sa_mlp3_ws_bytes(2, 100, 67, 50, 64, 100, 32) == 4 * 2 * 100 * 64
-    assert lib.pn2_sa_mlp3_ws_bytes(2, 100, 259, 256, 256, 512, 32) == 0
+    assert lib.pn2_sa_mlp3_ws_bytes(2, 100, 7, 3, 64, 64, 128, 32) == 0
+    assert lib.pn2_sa_mlp3_ws_bytes(2, 100, 7, 131, 128, 128, 256, 64) == 4 * 2 * 100 * 128
+    assert lib.pn2_sa_mlp3_ws_bytes(2, 100, 7, 67, 50, 64, 100, 32) == 4 * 2 * 100 * 64
+    assert lib.pn2_sa_mlp3_ws_bytes(2, 100, 7, 259, 256, 256, 512, 32) == 0
+    # group_all (m = 1, nsample = n = 100 -> 4 parts): 16 second-layer tiles of 6 KiB per 32-row part
+    assert lib.pn2_sa_mlp3_ws_bytes(2, 100, 1, 259, 256, 512, 1024, 100) == 2 * 4 * 16 * 6144
     assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 32, 64, one, one, one, one, 64, 64, 128, one, one, one, None, None) == -1  # streamed: ws missing
 
 
