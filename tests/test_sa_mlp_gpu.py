@@ -156,6 +156,10 @@ COOP_CASES = [
     ("(128,128,256) at nsample 16", 3, 1024, 50, 0.3, 16, 128, (128, 128, 256)),
     ("(128,128,256) at nsample 48", 2, 700, 41, 0.3, 48, 3, (100, 128, 256)),
     ("xyz only, wide", 2, 600, 20, 0.5, 64, 0, (256, 256, 512)),
+    # last layer wider than 512: layers 1-2 on the cooperative kernel, the last one as a GEMM (pool_gemm_kernel);
+    # 150 samples = 5 parts = two chunks of row tiles, the second with one part and a masked tail
+    ("grouped (200,400,900), GEMM last layer, nsample 150", 2, 600, 20, 0.6, 150, 6, (200, 400, 900)),
+    ("grouped (256,512,1024), GEMM last layer, nsample 32", 3, 256, 40, 0.5, 32, 64, (256, 512, 1024)),
 ]
 
 
