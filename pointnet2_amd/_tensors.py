@@ -31,6 +31,17 @@ def i32(t, name):
     return _checked(t, name, torch.int32, "int32")
 
 
+def out_or_empty(out, shape, dtype, dev, name="out"):
+    """A caller-provided output buffer (the `out=` option of the operators: no allocation on the call path,
+    ~1.7 us per tensor saved) or a fresh one. A provided buffer must match exactly; nothing is copied."""
+    if out is None:
+        return torch.empty(shape, dtype=dtype, device=dev)
+    if not (isinstance(out, torch.Tensor) and out.dtype is dtype and tuple(out.shape) == tuple(shape) and out.device == dev
+            and out.is_contiguous()):
+        raise ValueError("%s must be a contiguous %s tensor of shape %s on %s" % (name, dtype, tuple(shape), dev))
+    return out
+
+
 def same_device(*ts):
     dev = ts[0].device
     for t in ts[1:]:

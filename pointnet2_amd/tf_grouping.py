@@ -10,7 +10,7 @@ NoGradient (:21, :32).
 import torch
 
 from . import _C
-from ._tensors import (use_segmented_grad, det_workspace, f32, i32, is_deterministic, on_device, ptr, require,
+from ._tensors import (out_or_empty, use_segmented_grad, det_workspace, f32, i32, is_deterministic, on_device, ptr, require,
                        same_device, seg_workspace, stream_ptr)
 
 
@@ -25,11 +25,12 @@ def set_ball_query_kernel(kernel=0, cells_qpb=0):
     _BQ_KERNEL[0], _BQ_KERNEL[1] = int(kernel), int(cells_qpb)
 
 
-def query_ball_point(radius, nsample, xyz1, xyz2):
+def query_ball_point(radius, nsample, xyz1, xyz2, out=None):
     """radius float, nsample int, xyz1 (b, ndataset, 3), xyz2 (b, npoint, 3)
     -> idx (b, npoint, nsample) i32, pts_cnt (b, npoint) i32.
 
     reference: tf_grouping.py:8-20, op QueryBallPoint tf_grouping.cpp:67-106.
+    out: optional preallocated (idx, pts_cnt).
     """
     require(float(radius) > 0, "QueryBallPoint expects positive radius")
     require(int(nsample) > 0, "QueryBallPoint expects positive nsample")
@@ -42,8 +43,8 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     b, n, _ = xyz1.shape
     m = xyz2.shape[1]
     ns = int(nsample)
-    idx = torch.empty((b, m, ns), dtype=torch.int32, device=dev)
-    cnt = torch.empty((b, m), dtype=torch.int32, device=dev)
+    idx = out_or_empty(out[0] if out is not None else None, (b, m, ns), torch.int32, dev, "out[0]")
+    cnt = out_or_empty(out[1] if out is not None else None, (b, m), torch.int32, dev, "out[1]")
     with on_device(dev):
         if _BQ_KERNEL[0] or _BQ_KERNEL[1]:
             _C.check(_C.lib().pn2_query_ball_group_xyz_ex(b, n, m, float(radius), ns, ptr(xyz1), ptr(xyz2), 0, ptr(idx),
@@ -247,18 +248,23 @@ def select_top_k(k, dist):
     return outi, out
 
 
+def _group_point_launch(points, idx, out=None):
+    b, n, c = points.shape
+    _, m, ns = idx.shape
+    dev = points.device
+    out = out_or_empty(out, (b, m, ns, c), torch.float32, dev)
+    with on_device(dev):
+        _C.check(_C.lib().pn2_group_point(b, n, c, m, ns, ptr(points), ptr(idx), ptr(out), stream_ptr(dev)),
+                 "group_point")
+    return out
+
+
 class _GroupPoint(torch.autograd.Function):
     @staticmethod
     def forward(ctx, points, idx):
-        b, n, c = points.shape
-        _, m, ns = idx.shape
-        dev = points.device
-        out = torch.empty((b, m, ns, c), dtype=torch.float32, device=dev)
-        with on_device(dev):
-            _C.check(_C.lib().pn2_group_point(b, n, c, m, ns, ptr(points), ptr(idx), ptr(out), stream_ptr(dev)),
-                     "group_point")
+        out = _group_point_launch(points, idx)
         ctx.save_for_backward(idx)
-        ctx.shape = (b, n, c)
+        ctx.shape = tuple(points.shape)
         return out
 
     @staticmethod
@@ -285,11 +291,12 @@ class _GroupPoint(torch.autograd.Function):
         return grad_points, None
 
 
-def group_point(points, idx):
+def group_point(points, idx, out=None):
     """points (b, ndataset, channel) f32, idx (b, npoint, nsample) i32
     -> (b, npoint, nsample, channel) f32.
 
     reference: tf_grouping.py:33-41, op GroupPoint tf_grouping.cpp:143-171.
+    out: optional preallocated result (inference: no autograd node is built for it).
     """
     points = f32(points, "points")
     idx = i32(idx, "idx")
@@ -297,6 +304,9 @@ def group_point(points, idx):
     require(idx.dim() == 3 and idx.shape[0] == points.shape[0],
             "GroupPoint expects (batch_size, npoints, nsample) idx shape")
     same_device(points, idx)
+    if out is not None:
+        require(not (points.requires_grad and torch.is_grad_enabled()), "out= is for inference: points requires grad")
+        return _group_point_launch(points, idx, out)
     return _GroupPoint.apply(points, idx)
 
 

@@ -10,13 +10,13 @@ gradient w.r.t. `points` only (tf_interpolate.py:29-34); ThreeNN is NoGradient (
 import torch
 
 from . import _C
-from ._tensors import (use_segmented_grad, det_workspace, f32, i32, is_deterministic, on_device, ptr, require,
+from ._tensors import (out_or_empty, use_segmented_grad, det_workspace, f32, i32, is_deterministic, on_device, ptr, require,
                        same_device, seg_workspace, stream_ptr)
 
 
-def three_nn(xyz1, xyz2):
+def three_nn(xyz1, xyz2, out=None):
     """xyz1 (b, n, 3) unknown, xyz2 (b, m, 3) known -> dist (b, n, 3) f32 SQUARED
-    distances ascending, idx (b, n, 3) i32.
+    distances ascending, idx (b, n, 3) i32. out: optional preallocated (dist, idx).
 
     reference: tf_interpolate.py:8-17, op ThreeNN tf_interpolate.cpp:157-187,
     loop threenn_cpu :60-103.
@@ -29,26 +29,31 @@ def three_nn(xyz1, xyz2):
     dev = same_device(xyz1, xyz2)
     b, n, _ = xyz1.shape
     m = xyz2.shape[1]
-    dist = torch.empty((b, n, 3), dtype=torch.float32, device=dev)
-    idx = torch.empty((b, n, 3), dtype=torch.int32, device=dev)
+    dist = out_or_empty(out[0] if out is not None else None, (b, n, 3), torch.float32, dev, "out[0]")
+    idx = out_or_empty(out[1] if out is not None else None, (b, n, 3), torch.int32, dev, "out[1]")
     with on_device(dev):
         _C.check(_C.lib().pn2_three_nn(b, n, m, ptr(xyz1), ptr(xyz2), ptr(dist), ptr(idx), stream_ptr(dev)),
                  "three_nn")
     return dist, idx
 
 
+def _three_interpolate_launch(points, idx, weight, out=None):
+    b, m, c = points.shape
+    n = idx.shape[1]
+    dev = points.device
+    out = out_or_empty(out, (b, n, c), torch.float32, dev)
+    with on_device(dev):
+        _C.check(_C.lib().pn2_three_interpolate(b, m, c, n, ptr(points), ptr(idx), ptr(weight), ptr(out),
+                                                stream_ptr(dev)), "three_interpolate")
+    return out
+
+
 class _ThreeInterpolate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, points, idx, weight):
-        b, m, c = points.shape
-        n = idx.shape[1]
-        dev = points.device
-        out = torch.empty((b, n, c), dtype=torch.float32, device=dev)
-        with on_device(dev):
-            _C.check(_C.lib().pn2_three_interpolate(b, m, c, n, ptr(points), ptr(idx), ptr(weight), ptr(out),
-                                                    stream_ptr(dev)), "three_interpolate")
+        out = _three_interpolate_launch(points, idx, weight)
         ctx.save_for_backward(idx, weight)
-        ctx.shape = (b, m, c)
+        ctx.shape = tuple(points.shape)
         return out
 
     @staticmethod
@@ -78,9 +83,9 @@ class _ThreeInterpolate(torch.autograd.Function):
         return grad_points, None, None
 
 
-def three_interpolate(points, idx, weight):
+def three_interpolate(points, idx, weight, out=None):
     """points (b, m, c) f32 known features, idx (b, n, 3) i32, weight (b, n, 3) f32
-    -> (b, n, c) f32.
+    -> (b, n, c) f32. out: optional preallocated result (inference: no autograd node is built for it).
 
     reference: tf_interpolate.py:19-28, op ThreeInterpolate tf_interpolate.cpp:191-222.
     """
@@ -92,4 +97,7 @@ def three_interpolate(points, idx, weight):
     require(idx.dim() == 3 and idx.shape[0] == b and idx.shape[2] == 3, "ThreeInterpolate expects (b,n,3) idx shape")
     require(weight.dim() == 3 and weight.shape == idx.shape, "ThreeInterpolate expects (b,n,3) weight shape")
     same_device(points, idx, weight)
+    if out is not None:
+        require(not (points.requires_grad and torch.is_grad_enabled()), "out= is for inference: points requires grad")
+        return _three_interpolate_launch(points, idx, weight, out)
     return _ThreeInterpolate.apply(points, idx, weight)

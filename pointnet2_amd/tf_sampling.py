@@ -11,7 +11,7 @@ ProbSample are NoGradient (:22, :57).
 import torch
 
 from . import _C
-from ._tensors import (det_workspace, f32, i32, is_deterministic, on_device, ptr, require, same_device,
+from ._tensors import (det_workspace, f32, i32, is_deterministic, on_device, out_or_empty, ptr, require, same_device,
                        stream_ptr)
 
 
@@ -35,18 +35,23 @@ def prob_sample(inp, inpr):
     return out
 
 
+def _gather_point_launch(inp, idx, out=None):
+    b, n, _ = inp.shape
+    m = idx.shape[1]
+    dev = inp.device
+    out = out_or_empty(out, (b, m, 3), torch.float32, dev)
+    with on_device(dev):
+        _C.check(_C.lib().pn2_gather_point(b, n, m, ptr(inp), ptr(idx), ptr(out), stream_ptr(dev)),
+                 "gather_point")
+    return out
+
+
 class _GatherPoint(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inp, idx):
-        b, n, _ = inp.shape
-        m = idx.shape[1]
-        dev = inp.device
-        out = torch.empty((b, m, 3), dtype=torch.float32, device=dev)
-        with on_device(dev):
-            _C.check(_C.lib().pn2_gather_point(b, n, m, ptr(inp), ptr(idx), ptr(out), stream_ptr(dev)),
-                     "gather_point")
+        out = _gather_point_launch(inp, idx)
         ctx.save_for_backward(idx)
-        ctx.n = n
+        ctx.n = inp.shape[1]
         return out
 
     @staticmethod
@@ -67,16 +72,20 @@ class _GatherPoint(torch.autograd.Function):
         return inp_g, None
 
 
-def gather_point(inp, idx):
+def gather_point(inp, idx, out=None):
     """inp (b, ndataset, 3) f32, idx (b, npoints) i32 -> (b, npoints, 3) f32.
 
     reference: tf_sampling.py:29-37, op GatherPoint tf_sampling.cpp:126-148.
+    out: optional preallocated result (inference: no autograd node is built for it).
     """
     inp = f32(inp, "inp")
     idx = i32(idx, "idx")
     require(inp.dim() == 3 and inp.shape[2] == 3, "GatherPoint expects (batch_size,num_points,3) inp shape")
     require(idx.dim() == 2 and idx.shape[0] == inp.shape[0], "GatherPoint expects (batch_size,num_result) idx shape")
     same_device(inp, idx)
+    if out is not None:
+        require(not (inp.requires_grad and torch.is_grad_enabled()), "out= is for inference: inp requires grad")
+        return _gather_point_launch(inp, idx, out)
     return _GatherPoint.apply(inp, idx)
 
 
@@ -105,11 +114,12 @@ def farthest_point_sample_gather(npoint, inp):
     return out, new_xyz
 
 
-def farthest_point_sample(npoint, inp):
+def farthest_point_sample(npoint, inp, out=None):
     """npoint int, inp (b, ndataset, 3) f32 -> (b, npoint) i32, first index 0.
 
     reference: tf_sampling.py:48-56, op FarthestPointSample tf_sampling.cpp:95-123,
     kernel tf_sampling_g.cu:105-170 (tie rule: smallest (k mod 512, k)).
+    out: optional preallocated (b, npoint) i32 result.
     """
     require(int(npoint) > 0, "FarthestPointSample expects positive npoint")
     inp = f32(inp.detach() if isinstance(inp, torch.Tensor) else inp, "inp")
@@ -118,7 +128,7 @@ def farthest_point_sample(npoint, inp):
     require(n > 0 or b == 0, "FarthestPointSample expects at least one point per cloud")
     m = int(npoint)
     dev = inp.device
-    out = torch.empty((b, m), dtype=torch.int32, device=dev)
+    out = out_or_empty(out, (b, m), torch.int32, dev)
     lib = _C.lib()
     tf = lib.pn2_fps_temp_floats(b, n)
     temp = torch.empty((tf,), dtype=torch.float32, device=dev) if tf > 0 else None   # allocate_temp, tf_sampling.cpp:115

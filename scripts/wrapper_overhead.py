@@ -49,4 +49,10 @@ print("raw ctypes launch         %.2f us" % host_us(lambda: L.pn2_query_ball_poi
 print("data_ptr x4               %.2f us" % host_us(lambda: (xyz.data_ptr(), q.data_ptr(), idx.data_ptr(), cnt.data_ptr())))
 print("full wrapper              %.2f us" % host_us(lambda: P.query_ball_point(0.2, ns, xyz, q)))
 print("full wrapper group_point  %.2f us" % host_us(lambda: P.group_point(xyz, idx)))
+g_out = torch.empty(b, m, ns, 3, device=dev)
+print("query_ball_point, out=    %.2f us" % host_us(lambda: P.query_ball_point(0.2, ns, xyz, q, out=(idx, cnt))))
+print("group_point, out=         %.2f us" % host_us(lambda: P.group_point(xyz, idx, out=g_out)))
+d3, i3 = P.three_nn(xyz, q)
+print("three_nn                  %.2f us" % host_us(lambda: P.three_nn(xyz, q)))
+print("three_nn, out=            %.2f us" % host_us(lambda: P.three_nn(xyz, q, out=(d3, i3))))
 print("torch op for scale (add)  %.2f us" % host_us(lambda: xyz + 1.0))
