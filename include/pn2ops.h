@@ -181,14 +181,19 @@ int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, const float
  * nlayers 2 or 3, widths <= 256 (padded to the instantiated tile shapes; PN2_E_TOO_LARGE outside: callers keep
  * the unfused path). w[i] (cin_i, cout_i) row-major with batch norm folded in by the caller, rows of w[0] in
  * the reference's concat order [interpolated, points1]; pn2_fp_mlp_pack (host code) permutes them into the
- * stream the kernel consumes (sizes from pn2_fp_mlp_config; tiles4 = input / layer tile counts). */
+ * streams the kernels consume (sizes from pn2_fp_mlp_config; tiles4 = skip-link / layer tile counts).
+ * The first layer is linear and so is the interpolation: W1^T [interp(points2), points1] = interp(points2 . W1a) +
+ * W1b^T points1. Q = points2 . W1a is evaluated once per KNOWN point into `ws` (pn2_fp_mlp_ws_bytes bytes, caller's),
+ * rows of Q are interpolated instead of rows of points2, and only the skip-link part of layer 1 is matrix work per
+ * unknown point. */
 int pn2_fp_mlp_config(int c2, int c1, int nlayers, const int *widths, int kind, int *tiles4, long long *w_floats,
                       long long *b_floats);
 int pn2_fp_mlp_pack(int c2, int c1, int nlayers, const int *widths, int kind, const float *const *w,
                     const float *const *bias, float *wpacked, float *bpacked);
+long long pn2_fp_mlp_ws_bytes(int b, int m, int c2, int c1, int nlayers, const int *widths, int kind);
 int pn2_fp_mlp(int b, int n, int m, int c2, int c1, const float *points2, const float *points1, const int *idx,
                const float *dist, int nlayers, const int *widths, int kind, const float *wpacked, const float *bpacked,
-               float *out, void *stream);
+               float *out, void *ws, void *stream);
 /* kind selects the kernel (and with it the packed layout): 0 = one wave per 32 points, weights streamed
  * through LDS (many points: sem_seg FP4, 65536 points, 88 TFLOP/s); 1 = four waves share 32 points and split
  * each layer's output tiles (few points, wide layers: a 512-point level is otherwise 16 serial MFMA chains).

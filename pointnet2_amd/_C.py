@@ -55,7 +55,8 @@ _SIGNATURES = {
     "pn2_sa_mlp3_ws_bytes": [_i, _i, _i, _i, _i, _i, _i, _i],
     "pn2_fp_mlp_config": [_i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "pn2_fp_mlp_pack": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],
-    "pn2_fp_mlp": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
+    "pn2_fp_mlp": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "pn2_fp_mlp_ws_bytes": [_i, _i, _i, _i, _i, _vp, _i],
     "pn2_query_ball_group_xyz": [_i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "pn2_sample_and_group_xyz": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pn2_sample_and_group_ws_bytes": [_i, _i],
@@ -73,6 +74,7 @@ _RESTYPES = {
     "pn2_seg_grad_ws_bytes": ctypes.c_longlong,
     "pn2_sample_and_group_ws_bytes": ctypes.c_longlong,
     "pn2_sa_mlp3_ws_bytes": ctypes.c_longlong,
+    "pn2_fp_mlp_ws_bytes": ctypes.c_longlong,
     "pn2_sample_and_group_status_offset": ctypes.c_longlong,
     "pn2_ball_threshold": ctypes.c_float,
     "pn2_version": ctypes.c_char_p,

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kMlpThreads) void coop_mlp_kernel(CoopParams p)
     // 32 clouds x 4 parts), merged with an integer atomic max on the pre-zeroed output (values are >= 0 after ReLU)
     const int parts_in = p.split ? 1 : parts;                             // SPLIT_OUT always runs with p.split
     const long long units = POOL ? (p.split ? p.rows * parts : p.rows) : (p.rows + 31) / 32;
-    const int cin = POOL ? p.cf + 3 : p.cf + p.c1;
+    const int cin = POOL ? p.cf + 3 : p.c1;                               // FP: layer 1's MFMA input is the skip link only
 
     for (long long unit_raw = blockIdx.x; unit_raw < units; unit_raw += gridDim.x) {
         const long long unit = p.split ? unit_raw / parts : unit_raw;       // centroid (SA) / group of 32 points (FP)
@@ -135,13 +135,14 @@ __global__ __launch_bounds__(kMlpThreads) void coop_mlp_kernel(CoopParams p)
                             r3 = __fdiv_rn(1.0f, fmaxf(dp[2], 1e-10f));
                 const float norm = __fadd_rn(__fadd_rn(r1, r2), r3);
                 w1 = __fdiv_rn(r1, norm); w2 = __fdiv_rn(r2, norm); w3 = __fdiv_rn(r3, norm);
-                const float *base2 = p.feat + (size_t)cloud * p.m * p.cf;
-                pa = base2 + (size_t)ip[0] * p.cf; pb = base2 + (size_t)ip[1] * p.cf; pc = base2 + (size_t)ip[2] * p.cf;
+                // p.feat: Q = points2 . W1a (fp_mlp.hip), one row of 32 * T1 floats per known point
+                const float *base2 = p.feat + (size_t)cloud * p.m * (32 * T1) + 4 * h;
+                pa = base2 + (size_t)ip[0] * (32 * T1); pb = base2 + (size_t)ip[1] * (32 * T1); pc = base2 + (size_t)ip[2] * (32 * T1);
                 p1 = p.skip ? p.skip + (size_t)row * p.c1 : nullptr;
             }
-            const bool vec_a = (p.cf & 3) == 0, vec_b = vec_a && (p.c1 & 3) == 0;
+            const bool vec_a = (p.cf & 3) == 0, vec_b = (p.c1 & 3) == 0;
             // one 32-channel tile of layer-1 inputs: register v <- channel 32u + mlp_chan(v, h).
-            // grouped: [features (cf), xyz - centroid (3)]; interpolated: [interpolated (cf), points1 (c1)]
+            // grouped: [features (cf), xyz - centroid (3)]; feature propagation: the skip link points1 (c1)
             auto gather = [&](int u) __attribute__((always_inline)) -> f32x16 {
                 f32x16 x;
 #pragma unroll
@@ -162,25 +163,12 @@ __global__ __launch_bounds__(kMlpThreads) void coop_mlp_kernel(CoopParams p)
                             }
                         }
                     } else {
-                        if (vec_a && k0 + 3 < p.cf) {
-                            const float4 a = *reinterpret_cast<const float4 *>(pa + k0), bq = *reinterpret_cast<const float4 *>(pb + k0),
-                                         c = *reinterpret_cast<const float4 *>(pc + k0);
-                            x[4 * q] = coop_interp3(a.x, bq.x, c.x, w1, w2, w3);
-                            x[4 * q + 1] = coop_interp3(a.y, bq.y, c.y, w1, w2, w3);
-                            x[4 * q + 2] = coop_interp3(a.z, bq.z, c.z, w1, w2, w3);
-                            x[4 * q + 3] = coop_interp3(a.w, bq.w, c.w, w1, w2, w3);
-                        } else if (vec_b && k0 >= p.cf && k0 + 3 < cin) {
-                            const float4 f = *reinterpret_cast<const float4 *>(p1 + (k0 - p.cf));
+                        if (vec_b && k0 + 3 < cin) {
+                            const float4 f = *reinterpret_cast<const float4 *>(p1 + k0);
                             x[4 * q] = f.x; x[4 * q + 1] = f.y; x[4 * q + 2] = f.z; x[4 * q + 3] = f.w;
                         } else {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int kk = k0 + r;
-                                float val = 0.0f;
-                                if (kk < p.cf) val = coop_interp3(pa[kk], pb[kk], pc[kk], w1, w2, w3);
-                                else if (kk < cin) val = p1[kk - p.cf];
-                                x[4 * q + r] = val;
-                            }
+                            for (int r = 0; r < 4; ++r) x[4 * q + r] = k0 + r < cin ? p1[k0 + r] : 0.0f;
                         }
                     }
                 }
@@ -190,8 +178,23 @@ __global__ __launch_bounds__(kMlpThreads) void coop_mlp_kernel(CoopParams p)
             // ---- layer 1: this wave's tiles t = 4g + w; input tiles outermost ---------------------------------
             f32x16 a1[Q1];
 #pragma unroll
-            for (int g = 0; g < Q1; ++g) a1[g] = mlp_bias(b1, 4 * g + w, h);
-            f32x16 x = gather(0);
+            for (int g = 0; g < Q1; ++g) {
+                a1[g] = mlp_bias(b1, 4 * g + w, h);
+                if (!POOL) {                                               // + the interpolated rows of Q, this wave's channels
+                    const int t = 4 * g + w;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 a = *reinterpret_cast<const float4 *>(pa + 32 * t + 8 * q), bq = *reinterpret_cast<const float4 *>(pb + 32 * t + 8 * q),
+                                     c = *reinterpret_cast<const float4 *>(pc + 32 * t + 8 * q);
+                        a1[g][4 * q] = __fadd_rn(a1[g][4 * q], coop_interp3(a.x, bq.x, c.x, w1, w2, w3));
+                        a1[g][4 * q + 1] = __fadd_rn(a1[g][4 * q + 1], coop_interp3(a.y, bq.y, c.y, w1, w2, w3));
+                        a1[g][4 * q + 2] = __fadd_rn(a1[g][4 * q + 2], coop_interp3(a.z, bq.z, c.z, w1, w2, w3));
+                        a1[g][4 * q + 3] = __fadd_rn(a1[g][4 * q + 3], coop_interp3(a.w, bq.w, c.w, w1, w2, w3));
+                    }
+                }
+            }
+            f32x16 x;
+            if (p.ti > 0) x = gather(0);
             for (int u = 0; u < p.ti; ++u) {
                 f32x16 xn = x;
                 if (u + 1 < p.ti) xn = gather(u + 1);
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(kGemmThreads) void pool_gemm_kernel(int parts, int 
 // ---- host side ------------------------------------------------------------------------------------------
 bool mlp_coop_pick(int cin, int nlayers, const int *widths, MlpCoopConfig &cfg)
 {
-    if (cin < 1 || (nlayers != 2 && nlayers != 3)) return false;
+    if (cin < 0 || (nlayers != 2 && nlayers != 3)) return false;          // cin == 0: an FP level without skip link
     int q[3] = {0, 0, 0};
     for (int i = 0; i < nlayers; ++i) {
         if (widths[i] < 1 || widths[i] > 1024) return false;

@@ -142,6 +142,12 @@ int mlp_stream_launch(const MlpStreamConfig &c, int b, int n, int m, int nsample
                       const float *new_xyz, const float *points, const int *idx, const float *wp, const float *bp,
                       float *out, void *ws, hipStream_t st);
 
+int point_layer_launch(int t1, int cfeat, long long rows, int tif, const float *points, const float *wstream,
+                       const float *bias, float *pre, int out_stride, int col0, hipStream_t st);
+
+int point_layer_few_rows_launch(int tiles, int cfeat, long long rows, int tif, const float *points, const float *wstream,
+                                float *pre, hipStream_t st);
+
 // ---- cooperative variant (coop_mlp.hip): four waves share one 32-sample item and split every layer's output
 // tiles; wide stacks over few rows (SA levels beyond (128,128,256), group_all levels, small FP levels) -------
 struct MlpCoopConfig { int ti, q1, q2, q3; };          // input tiles; output tiles PER WAVE of the layers (q3 = 0: two layers)

@@ -60,11 +60,14 @@ static_assert(kStageVec == 3 * kStreamThreads, "the staging registers are spelle
 // P (rows, 32 * T1) = points (rows, cfeat) . W1f + b1: the feature part of layer 1, once per point. A wave owns
 // 32 consecutive rows; non-swapped operands, so lane (row s, half h) holds channels 8q + 4h .. + 3 of a tile in
 // registers 4q .. 4q + 3: one 16-byte store per quartet, the layout the grouped kernel loads back.
+// out_stride / col0: row pitch of `pre` in floats and the first column this launch writes (a 256-wide layer is two
+// launches of the T1 = 4 instance, fp_mlp.hip).
 template <int T1>
 __global__ __launch_bounds__(kStreamThreads) void point_layer_kernel(int cfeat, long long rows, int tif,
                                                                     const float *__restrict__ points,
                                                                     const float *__restrict__ wstream,
-                                                                    const float *__restrict__ bpacked, float *__restrict__ pre)
+                                                                    const float *__restrict__ bpacked, float *__restrict__ pre,
+                                                                    int out_stride, int col0)
 {
     __shared__ __attribute__((aligned(16))) u32x4 wbuf[2][kStageVec];
     __shared__ float bias_s[T1 * 32];
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(kStreamThreads) void point_layer_kernel(int cfeat, 
             if (slot != 0) PN2_NEXT_STAGE();                                    // padded to whole stages
         }
         if (ok) {
-            float *dst = pre + (size_t)row * (32 * T1) + 4 * h;
+            float *dst = pre + (size_t)row * out_stride + col0 + 4 * h;
 #pragma unroll
             for (int t = 0; t < T1; ++t)
 #pragma unroll
@@ -138,6 +141,109 @@ __global__ __launch_bounds__(kStreamThreads) void point_layer_kernel(int cfeat, 
                     *reinterpret_cast<float4 *>(dst + 32 * t + 8 * q) =
                         make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
         }
+    }
+}
+
+// The same layer for FEW rows (feature-propagation levels with 16 ... 2048 known points, fp_mlp.hip): the streamed
+// form above walks the contraction in stages of four pairs behind a barrier, one microsecond a stage whatever the
+// row count -- 32 stages for the 1024 input channels of part_seg's first FP level, for a single work item. Here a wave
+// group owns ONE output tile of one 32-row item; its four waves take every fourth feature tile each (a split of the
+// contraction: the chain is tif / 4 pairs of 12 MFMAs), stream just those pairs from L2 into registers, two ahead,
+// and add their partial tiles through LDS at the end. items x tiles workgroups run side by side.
+// wstream: the per-point streams of fp_mlp.hip, [tile / 4][feature tile][tile % 4]; writes all `tiles` tiles.
+// VEC4: cfeat % 4 == 0. The tile loads are branch-free (clamped address + select): per-lane branches around loads make
+// hipcc wait for every load in flight at each use, the prefetched ones included.
+template <bool VEC4>
+__global__ __launch_bounds__(256) void point_layer_few_rows_kernel(int cfeat, long long rows, int tif, int tiles,
+                                                                  const float *__restrict__ points,
+                                                                  const float *__restrict__ wstream, float *__restrict__ pre)
+{
+    constexpr int kTileVec = kPairWords / 4;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, s = lane & 31;
+    __shared__ float part[3][16][64];                                      // partial tiles of waves 1-3
+    const int w = tid >> 6;
+    const long long g = blockIdx.x / tiles;
+    const int t = (int)(blockIdx.x % tiles);
+    const long long row = min(g * 32 + s, rows - 1);
+    const float *pf = points + (size_t)row * cfeat;
+    auto load_tile = [&](int u) __attribute__((always_inline)) -> f32x16 {
+        f32x16 x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k0 = 32 * u + 8 * q + 4 * h;
+            if (VEC4) {
+                const bool in = k0 < cfeat;                            // cfeat % 4 == 0: a quartet is inside or outside
+                const float4 f = *reinterpret_cast<const float4 *>(pf + (in ? k0 : 0));
+                x[4 * q] = in ? f.x : 0.0f; x[4 * q + 1] = in ? f.y : 0.0f; x[4 * q + 2] = in ? f.z : 0.0f; x[4 * q + 3] = in ? f.w : 0.0f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool in = k0 + r < cfeat;
+                    const float f = pf[in ? k0 + r : 0];
+                    x[4 * q + r] = in ? f : 0.0f;
+                }
+            }
+        }
+        return x;
+    };
+    // pair of (feature tile u, this output tile)
+    const u32x4 *wp4 = reinterpret_cast<const u32x4 *>(wstream) + ((size_t)(t / 4) * tif * 4 + (t % 4)) * kTileVec + lane;
+    const int mine = (tif - w + 3) / 4;                                    // this wave's feature tiles: w, w + 4, ...
+    const int last = max(mine - 1, 0);
+    const bool none = mine <= 0;
+    u32x4 a0, a1, a2, a3, a4, a5, b0, b1, b2, b3, b4, b5;                  // pairs u (set a / b by parity), two in flight
+#define PN2_FEW_ISSUE(u, S)                                                                                           \
+    do {                                                                                                              \
+        const u32x4 *q_ = wp4 + (size_t)min(w + 4 * (u), tif - 1) * (4 * kTileVec);                                   \
+        S##0 = q_[0]; S##1 = q_[64]; S##2 = q_[128]; S##3 = q_[192]; S##4 = q_[256]; S##5 = q_[320];                   \
+    } while (0)
+#define PN2_FEW_STEP(S, X)                                                                                            \
+    do {                                                                                                              \
+        const u32x4 w0_[3] = {S##0, S##1, S##2}, w1_[3] = {S##3, S##4, S##5};                                         \
+        const ActSplit xs_ = split_act(X);                                                                            \
+        acc = mma_x6<false>(w0_, xs_.p[0], acc);                                                                      \
+        acc = mma_x6<false>(w1_, xs_.p[1], acc);                                                                      \
+    } while (0)
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+    auto my_tile = [&](int j) __attribute__((always_inline)) -> f32x16 { return load_tile(min(w + 4 * min(j, last), tif - 1)); };
+    PN2_FEW_ISSUE(0, a);
+    PN2_FEW_ISSUE(min(1, last), b);
+    f32x16 x0 = my_tile(0), x1 = my_tile(1);
+    // straight-line double step (behind a branch hipcc makes every use wait for ALL loads in flight, the prefetch
+    // included): a surplus step (odd count, or a wave without tiles) runs on a zero tile
+    for (int u = 0; u < max(mine, 1); u += 2) {
+        if (none) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) x0[v] = 0.0f;
+        }
+        PN2_FEW_STEP(a, x0);
+        PN2_FEW_ISSUE(min(u + 2, last), a);
+        x0 = my_tile(u + 2);
+        if (u + 1 >= mine) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) x1[v] = 0.0f;
+        }
+        PN2_FEW_STEP(b, x1);
+        PN2_FEW_ISSUE(min(u + 3, last), b);
+        x1 = my_tile(u + 3);
+    }
+#undef PN2_FEW_ISSUE
+#undef PN2_FEW_STEP
+    if (w > 0) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) part[w - 1][v][lane] = acc[v];
+    }
+    __syncthreads();
+    if (w > 0) return;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = __fadd_rn(__fadd_rn(acc[v], part[0][v][lane]), __fadd_rn(part[1][v][lane], part[2][v][lane]));
+    if (g * 32 + s < rows) {
+        float *dst = pre + (size_t)row * (32 * tiles) + 32 * t + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4 *>(dst + 8 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
     }
 }
 
@@ -320,19 +426,47 @@ void mlp_stream_pack(const MlpStreamConfig &c, int cin, int c1, int c2, int c3, 
                 }
 }
 
+// pre (rows, out_stride)[:, col0 : col0 + 32 t1] = points (rows, cfeat) . W + bias; t1 = 2 or 4 output tiles
+int point_layer_launch(int t1, int cfeat, long long rows, int tif, const float *points, const float *wstream,
+                       const float *bias, float *pre, int out_stride, int col0, hipStream_t st)
+{
+    const long long groups = (rows + 31) / 32;
+    long long blocks = (groups + kStreamThreads / 64 - 1) / (kStreamThreads / 64);
+    if (blocks > 256) blocks = 256;
+    if (blocks == 0) return PN2_OK;
+    if (t1 == 2)
+        return launch((point_layer_kernel<2>), dim3((unsigned)blocks), dim3(kStreamThreads), 0, st, cfeat, rows, tif, points, wstream,
+                      bias, pre, out_stride, col0);
+    if (t1 == 4)
+        return launch((point_layer_kernel<4>), dim3((unsigned)blocks), dim3(kStreamThreads), 0, st, cfeat, rows, tif, points, wstream,
+                      bias, pre, out_stride, col0);
+    return PN2_E_ARG;
+}
+
+// the few-rows form: all `tiles` output tiles (a multiple of 4) in one launch, no bias
+int point_layer_few_rows_launch(int tiles, int cfeat, long long rows, int tif, const float *points, const float *wstream,
+                                float *pre, hipStream_t st)
+{
+    const long long blocks = (rows + 31) / 32 * tiles;
+    if (blocks == 0) return PN2_OK;
+    if ((cfeat & 3) == 0)
+        return launch(point_layer_few_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, cfeat, rows, tif, tiles, points,
+                      wstream, pre);
+    return launch(point_layer_few_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, cfeat, rows, tif, tiles, points,
+                  wstream, pre);
+}
+
 template <int T1, int T2, int T3>
 static int launch_stream(const MlpStreamConfig &c, int b, int n, int m, int nsample, int cfeat, int c3, const float *xyz,
                          const float *new_xyz, const float *points, const int *idx, const float *wp, const float *bp,
                          float *out, float *pre, hipStream_t st)
 {
     const long long cap = 256;                           // one workgroup (one weight stream) per CU
-    const long long npoints = (long long)b * n, groups = (npoints + 31) / 32;
-    long long blocks = (groups + kStreamThreads / 64 - 1) / (kStreamThreads / 64);
-    if (blocks > cap) blocks = cap;
+    const long long npoints = (long long)b * n;
+    long long blocks;
     const float *wpoint = wp + (size_t)stream_main_pairs(c) * kPairWords;
     const float *wxyz = wpoint + (size_t)stream_point_pairs(c) * kPairWords;
-    if (int rc = launch((point_layer_kernel<T1>), dim3((unsigned)blocks), dim3(kStreamThreads), 0, st, cfeat, npoints, c.ti, points,
-                       wpoint, bp, pre)) return rc;
+    if (int rc = point_layer_launch(T1, cfeat, npoints, c.ti, points, wpoint, bp, pre, 32 * T1, 0, st)) return rc;
     const long long rows = (long long)b * m;
     blocks = (rows + kStreamThreads / 64 - 1) / (kStreamThreads / 64);
     if (blocks > cap) blocks = cap;

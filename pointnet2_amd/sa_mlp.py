@@ -184,8 +184,10 @@ def fp_mlp(points2, points1, idx, dist, packed):
     require(c2 == packed.c2 and c1 == packed.c1, "packed FP MLP expects (%d, %d) channels, got (%d, %d)" % (packed.c2, packed.c1, c2, c1))
     dev = same_device(points2, idx, dist, packed.wp) if points1 is None else same_device(points2, points1, idx, dist, packed.wp)
     out = torch.empty((b, n, packed.widths[-1]), dtype=torch.float32, device=dev)
+    nbytes = _C.lib().pn2_fp_mlp_ws_bytes(b, m, c2, c1, len(packed.widths), packed._warr, packed.kind)
+    ws = torch.empty(((nbytes + 3) // 4,), dtype=torch.float32, device=dev)        # Q = points2 . W1a, one row per known point
     with on_device(dev):
         _C.check(_C.lib().pn2_fp_mlp(b, n, m, c2, c1, ptr(points2), ptr(points1), ptr(idx), ptr(dist), len(packed.widths),
-                                     packed._warr, packed.kind, ptr(packed.wp), ptr(packed.bp), ptr(out), stream_ptr(dev)),
-                 "fp_mlp")
+                                     packed._warr, packed.kind, ptr(packed.wp), ptr(packed.bp), ptr(out), ptr(ws),
+                                     stream_ptr(dev)), "fp_mlp")
     return out

@@ -308,9 +308,13 @@ def test_fold_batch_norm_equals_eval_mode_layers():
 @pytest.mark.parametrize("kind", [0, 1], ids=["streamed", "cooperative"])
 @pytest.mark.parametrize("c2,c1,widths", [(40, 8, (100, 60)), (24, 0, (128, 128, 70)), (36, 5, (130, 128))])
 def test_fp_pack_matches_emulated_dataflow(kind, c2, c1, widths):
-    """pn2_fp_mlp_pack: walk the packed stream exactly as the kernels do (fp_mlp.hip: one wave, input tiles outermost
-    in layer 1, output tiles outermost afterwards; coop_mlp.hip: pair 4k + w belongs to wave w, input tiles outermost
-    in every layer, wave w owns output tiles 4g + w) and compare with the plain layer stack."""
+    """pn2_fp_mlp_pack: walk the packed streams exactly as the kernels do and compare with the plain layer stack.
+    Layer 1 = bias + interp(points2 . W1a) + W1b^T points1: the known-feature rows of W1 go to the per-point kernel's
+    streams (one per 128 output channels, feature tiles outermost) behind the main stream, which holds the skip-link
+    rows of layer 1 and the later layers (fp_mlp.hip: one wave, input tiles outermost in layer 1 and padded to a
+    stage, output tiles outermost afterwards; coop_mlp.hip: pair 4k + w belongs to wave w, input tiles outermost in
+    every layer, wave w owns output tiles 4g + w). The interpolation is linear, so the emulation feeds the per-point
+    kernel the already interpolated features of the 32 points."""
     from pointnet2_amd import _C
     lib = _C.lib()
     rng = np.random.default_rng(c2 + kind)
@@ -322,6 +326,8 @@ def test_fp_pack_matches_emulated_dataflow(kind, c2, c1, widths):
     if rc != 0:
         pytest.skip("no kernel of this kind for the stack")
     ti, T = tiles[0], [tiles[1], tiles[2], tiles[3]]
+    assert ti == (c1 + 31) // 32
+    tif = (c2 + 31) // 32
     dims = (c2 + c1,) + tuple(widths)
     ws = [rng.standard_normal((dims[i], dims[i + 1])).astype(np.float32) for i in range(n)]
     bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) for i in range(n)]
@@ -333,16 +339,29 @@ def test_fp_pack_matches_emulated_dataflow(kind, c2, c1, widths):
     pairs = wp.reshape(-1, _PAIR)
     ob = np.cumsum([0, T[0] * 32, T[1] * 32, T[2] * 32])
     bl = [bp[ob[i]:ob[i + 1]] for i in range(3)]
+    assert bp.size == ob[3] + 128 and not bp[ob[3]:].any()            # the per-point kernel's zero bias
     x = rng.standard_normal((32, c2 + c1)).astype(np.float32)
-    acts = _operand_tiles(x, ti)
+    npoint = tif * T[0]
+    main = pairs.shape[0] - npoint
+    lane_bias = lambda L, t: np.stack([bl[L].reshape(-1, 2, 16)[t, l >> 5] for l in range(64)]).astype(np.float64)
+    # per-point kernel on the interpolated features: stream `half` holds output tiles 4 half .. 4 half + 3
+    q = {t: np.zeros((64, 16)) for t in range(T[0])}
+    for u, xt in enumerate(_operand_tiles(x[:, :c2], tif)):
+        for t in range(T[0]):
+            half = t // 4
+            q[t] = _emulate_pair(pairs[main + (half * tif + u) * 4 + t % 4], xt, q[t], False)
+    skip = _operand_tiles(x[:, c2:], ti)
     tin = [ti, T[0], T[1]]
     last_acc = {}
-    if kind == 0:
-        k = 0
-        for L in range(n):
-            last = L == n - 1
-            acc = {t: (np.zeros((64, 16)) if last else np.stack([bl[L].reshape(-1, 2, 16)[t, l >> 5] for l in range(64)]).astype(np.float64))
-                   for t in range(T[L])}
+    k = 0
+    acts = skip
+    for L in range(n):
+        last = L == n - 1
+        acc = {t: (np.zeros((64, 16)) if last else lane_bias(L, t)) for t in range(T[L])}
+        if L == 0:
+            for t in range(T[0]):
+                acc[t] = acc[t] + q[t]
+        if kind == 0:
             if L == 0:                                   # input tiles outermost, padded to whole stages of 4 pairs
                 for u in range(tin[L]):
                     for t in range(T[L]):
@@ -354,26 +373,16 @@ def test_fp_pack_matches_emulated_dataflow(kind, c2, c1, widths):
                     for u in range(tin[L]):
                         acc[t] = _emulate_pair(pairs[k], acts[u], acc[t], last)
                         k += 1
-            if last:
-                last_acc = acc
-            else:
-                acts = [np.maximum(acc[t], 0.0) for t in range(T[L])]
-    else:
-        k = 0                                           # stage counter: stage k holds pairs 4k .. 4k + 3, one per wave
-        for L in range(n):
-            last = L == n - 1
-            q = T[L] // 4
-            acc = {t: (np.zeros((64, 16)) if last else np.stack([bl[L].reshape(-1, 2, 16)[t, l >> 5] for l in range(64)]).astype(np.float64))
-                   for t in range(T[L])}
+        else:                                            # k counts steps: step k holds pairs 4k .. 4k + 3, one per wave
             for u in range(tin[L]):
-                for g in range(q):
+                for g in range(T[L] // 4):
                     for w in range(4):
                         acc[4 * g + w] = _emulate_pair(pairs[4 * k + w], acts[u], acc[4 * g + w], last)
                     k += 1
-            if last:
-                last_acc = acc
-            else:
-                acts = [np.maximum(acc[t], 0.0) for t in range(T[L])]
-        assert 4 * k == pairs.shape[0]
+        if last:
+            last_acc = acc
+        else:
+            acts = [np.maximum(acc[t], 0.0) for t in range(T[L])]
+    assert (k if kind == 0 else 4 * k) == main
     got = _unswap(last_acc, widths[-1], lambda ch: _b_at(bl[n - 1], ch))
     assert np.allclose(got, _want(x, ws, bs), rtol=1e-9, atol=1e-9)
