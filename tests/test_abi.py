@@ -125,6 +125,11 @@ def test_c_abi_argument_validation_of_the_extra_entry_points():
     # group_all (m = 1, nsample = n = 100 -> 4 parts): 16 second-layer tiles of 6 KiB per 32-row part
     assert lib.pn2_sa_mlp3_ws_bytes(2, 100, 1, 259, 256, 512, 1024, 100) == 2 * 4 * 16 * 6144
     assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 32, 64, one, one, one, one, 64, 64, 128, one, one, one, None, None) == -1  # streamed: ws missing
+    assert lib.pn2_sa_mlp3_maxpool(2, 64, 1, 64, 0, one, None, None, None, 256, 512, 1024, one, one, one, None, None) == -1   # group_all: ws missing
+    widths = (ctypes.c_int * 2)(256, 128)
+    assert lib.pn2_fp_mlp_ws_bytes(2, 7, 256, 128, 2, widths, 0) == 4 * 2 * 7 * 256       # Q: one row of the padded first width per known point
+    assert lib.pn2_fp_mlp_ws_bytes(2, 7, 256, 128, 2, widths, 1) == 4 * 2 * 7 * 256
+    assert lib.pn2_fp_mlp(2, 10, 7, 256, 128, one, one, one, one, 2, widths, 0, one, one, one, None, None) == -1       # ws missing
 
 
 def test_python_wrappers_validate_like_op_requires():
