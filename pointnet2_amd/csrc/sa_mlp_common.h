@@ -96,7 +96,11 @@ __device__ __forceinline__ f32x16 mma_x6(const u32x4 (&w)[3], const u32x4 (&x)[3
 #define PN2_MMA(WL, XL)                                                                                              \
     acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x[XL]), __builtin_bit_cast(bf16x8, w[WL]), acc, 0, 0, 0) \
                : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[WL]), __builtin_bit_cast(bf16x8, x[XL]), acc, 0, 0, 0)
+#ifdef PN2_LAB_ONE_MFMA                    /* lab builds only (scripts/build_mlp_labs.sh): what everything except the MFMAs costs */
+    PN2_MMA(0, 0);
+#else
     PN2_MMA(0, 2); PN2_MMA(1, 1); PN2_MMA(2, 0); PN2_MMA(0, 1); PN2_MMA(1, 0); PN2_MMA(0, 0);
+#endif
 #undef PN2_MMA
     return acc;
 }
