@@ -1,5 +1,6 @@
-// sa_mlp_common.h -- helpers shared by the two fused-MLP kernels (sa_mlp.hip: weights resident in LDS;
-// sa_mlp_stream.hip: weights streamed through LDS). See sa_mlp.hip for the formulation.
+// sa_mlp_common.h -- helpers shared by the fused-MLP kernels (sa_mlp.hip: weights resident in LDS; sa_mlp_stream.hip:
+// weights streamed through LDS + the per-point layers; coop_mlp.hip: four waves per item + the last-layer GEMM;
+// fp_mlp.hip: feature propagation). See sa_mlp.hip for the formulation and the arithmetic.
 #pragma once
 #include "pn2_device.h"
 
@@ -112,7 +113,7 @@ float *mlp_pack_pair_x6(float *wp, const float *w, int kin, int nout, int t, int
 
 
 // ---- streamed variant (sa_mlp_stream.hip) ------------------------------------------------------------
-constexpr int kMlpStagePairs = 4;          // 32x32 weight tile pairs per LDS stage (16 KiB)
+constexpr int kMlpStagePairs = 4;          // 32x32 weight tile pairs per LDS stage (24 KiB in three-level form)
 
 constexpr int kS = kMlpStagePairs;
 
