@@ -86,3 +86,69 @@ def test_repeatability(cuda):
             ref = cur
         else:
             assert all(torch.equal(a, bb) for a, bb in zip(ref, cur))
+
+
+def test_fuzz_fused_mlps(cuda):
+    """Random shapes through the fused MLP entry points (every kernel family: resident / streamed with its per-point
+    layer / cooperative / last-layer GEMM; FP streamed and cooperative with their projected first layer) against a
+    float64 evaluation: channel counts that are not multiples of 4 or 32, widths below a tile, nsample with a masked
+    tail, one or two known points."""
+    import pointnet2_amd as P
+    from pointnet2_amd import sa_mlp
+    rng = np.random.default_rng(int(os.environ.get("PN2_FUZZ_SEED", "31")) + 7)
+    width_sets = [(32, 32, 64), (64, 64, 128), (64, 96, 128), (128, 128, 256), (100, 120, 200), (256, 256, 512),
+                  (200, 400, 900), (17, 33, 65)]
+    done = {}
+    for trial in range(int(os.environ.get("PN2_FUZZ_TRIALS", "16"))):
+        widths = width_sets[int(rng.integers(len(width_sets)))]
+        cfeat = int(rng.choice([0, 1, 3, 6, 29, 61, 64, 130, 323]))
+        ns = int(rng.choice([16, 32, 40, 64, 96]))
+        if not sa_mlp.supported(3 + cfeat, widths, ns):
+            continue
+        b, n, m = int(rng.integers(1, 4)), int(rng.integers(ns + 8, 600)), int(rng.integers(1, 70))
+        xyz = torch.from_numpy(S.sphere_clouds(b, n, int(rng.integers(1 << 30)))).to(cuda)
+        new_xyz = P.gather_point(xyz, P.farthest_point_sample(m, xyz))
+        idx, _ = P.query_ball_point(0.5, ns, xyz, new_xyz)
+        pts = torch.from_numpy(rng.standard_normal((b, n, cfeat)).astype(np.float32)).to(cuda) if cfeat else None
+        dims = (3 + cfeat,) + tuple(widths)
+        layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
+                   (0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32)) for i in range(3)]
+        packed = sa_mlp.PackedMLP3(layers, cuda, ns)
+        done[packed.kind] = done.get(packed.kind, 0) + 1
+        got = sa_mlp.sa_mlp_maxpool(xyz, new_xyz, pts, idx, packed).double()
+        bi = torch.arange(b, device=cuda)[:, None, None]
+        x = xyz[bi, idx.long()] - new_xyz[:, :, None, :]
+        if pts is not None:
+            x = torch.cat([x, pts[bi, idx.long()]], dim=-1)
+        x = x.double()
+        for w, bias in layers:
+            x = torch.relu(x @ torch.from_numpy(w).double().to(cuda) + torch.from_numpy(bias).double().to(cuda))
+        want = x.max(dim=2).values
+        assert (got - want).abs().max().item() <= 5e-6 * max(1.0, want.abs().max().item()), (trial, widths, cfeat, ns, b, n, m, packed.kind)
+    assert len(done) >= 2, done
+    for trial in range(int(os.environ.get("PN2_FUZZ_TRIALS", "16"))):
+        nl = int(rng.choice([2, 3]))
+        widths = [int(rng.choice([16, 40, 100, 128, 130, 256])) for _ in range(nl)]
+        c2, c1 = int(rng.choice([8, 20, 128, 260])), int(rng.choice([0, 3, 5, 64, 100]))
+        b, n, m = int(rng.integers(1, 4)), int(rng.integers(3, 400)), int(rng.choice([1, 2, 3, 17, 90]))
+        unknown = torch.from_numpy(S.sphere_clouds(b, n, int(rng.integers(1 << 30)))).to(cuda)
+        known = torch.from_numpy(S.sphere_clouds(b, m, int(rng.integers(1 << 30)))).to(cuda)
+        p2 = torch.from_numpy(rng.standard_normal((b, m, c2)).astype(np.float32)).to(cuda)
+        p1 = torch.from_numpy(rng.standard_normal((b, n, c1)).astype(np.float32)).to(cuda) if c1 else None
+        dims = [c2 + c1] + widths
+        layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
+                   (0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32)) for i in range(nl)]
+        dist, idx = P.three_nn(unknown, known)
+        d = dist.double().clamp_min(1e-10)
+        w = (1.0 / d) / (1.0 / d).sum(dim=2, keepdim=True)
+        bi = torch.arange(b, device=cuda)[:, None, None]
+        act = (p2.double()[bi, idx.long()] * w[..., None]).sum(dim=2)
+        if c1:
+            act = torch.cat([act, p1.double()], dim=2)
+        for wgt, bias in layers:
+            act = torch.relu(act @ torch.from_numpy(wgt).double().to(cuda) + torch.from_numpy(bias).double().to(cuda))
+        for kind in (0, 1):
+            if sa_mlp.fp_kind(1 << 30 if kind == 0 else 1, c2, c1, widths) != kind:
+                continue
+            got = sa_mlp.fp_mlp(p2, p1, idx, dist, sa_mlp.PackedFPMLP(layers, c2, c1, cuda, kind)).double()
+            assert (got - act).abs().max().item() <= 1e-5 * max(1.0, act.abs().max().item()), (trial, kind, widths, c2, c1, b, n, m)
