@@ -22,6 +22,7 @@ B="python $ROOT/bench.py --no-cpu-baseline --streams 0 --steps 30 --warmup 3"
 BQ="python $ROOT/bench.py --no-extras --steps 30 --warmup 3"   # only the timed kernel(s)
 run_stats ops $B --path ops
 run_stats overlap $B --path overlap
+export PN2_MLP_BENCH_KERNEL_ONLY=1        # sa_mlp_bench.py: the fused kernels only (no torch layer-by-layer runs in the trace)
 run_stats sa_mlp python $ROOT/scripts/sa_mlp_bench.py
 run_stats bw_probe python $ROOT/scripts/bw_probe.py
 run_stats bq_msg python $ROOT/scripts/bq_probe.py msg
@@ -35,5 +36,7 @@ run_pmc sq2 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" 
 run_pmc mlp_fetch FETCH_SIZE python $ROOT/scripts/sa_mlp_bench.py
 run_pmc mlp_write WRITE_SIZE python $ROOT/scripts/sa_mlp_bench.py
 run_pmc mlp_sq "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" python $ROOT/scripts/sa_mlp_bench.py
+run_pmc mlp_sq2 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" python $ROOT/scripts/sa_mlp_bench.py
+run_pmc mlp_sq3 "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SALU" python $ROOT/scripts/sa_mlp_bench.py
 rm -rf "$OUT"/ops "$OUT"/overlap "$OUT"/sa_mlp "$OUT"/pmc_*/
 ls -la "$OUT"
