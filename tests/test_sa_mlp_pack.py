@@ -386,3 +386,67 @@ def test_fp_pack_matches_emulated_dataflow(kind, c2, c1, widths):
     assert (k if kind == 0 else 4 * k) == main
     got = _unswap(last_acc, widths[-1], lambda ch: _b_at(bl[n - 1], ch))
     assert np.allclose(got, _want(x, ws, bs), rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("cin,widths,xyz_first", [(259, (256, 256, 512), True), (40, (130, 200, 400), False),
+                                                   (259, (256, 512, 1024), True), (8, (200, 400, 900), False)])
+def test_coop_sa_pack_matches_emulated_dataflow(cin, widths, xyz_first):
+    """The cooperative kernel's grouped stacks (coop_mlp.hip): layers in per-wave consumption order (input tiles
+    outermost, pair 4k + w belongs to wave w, wave w owns output tiles 4g + w), layer-1 channels [features, xyz].
+    Stacks whose last layer is wider than 512 keep layers 1-2 in that order and store the last layer for
+    pool_gemm_kernel: [block of four output tiles][contraction tile][tile of the block], bias in plain channel order."""
+    from pointnet2_amd import _C
+    lib = _C.lib()
+    rng = np.random.default_rng(cin)
+    dims = (cin,) + tuple(widths)
+    ws = [rng.standard_normal((dims[i], dims[i + 1])).astype(np.float32) for i in range(3)]
+    bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) for i in range(3)]
+    info = (ctypes.c_int * 4)()
+    wf, bf = ctypes.c_longlong(), ctypes.c_longlong()
+    ns = 40                                                           # not a multiple of 32: only this kernel masks
+    assert lib.pn2_sa_mlp3_config(cin, *widths, ns, info, ctypes.byref(wf), ctypes.byref(bf)) == 0 and info[0] == 2
+    T = [info[1], info[2], info[3]]
+    ti = (cin + 31) // 32
+    wp = np.empty(wf.value, np.float32)
+    bp = np.empty(bf.value, np.float32)
+    assert lib.pn2_sa_mlp3_pack(cin, *widths, ns, 1 if xyz_first else 0,
+                                *[a.ctypes.data for pair in zip(ws, bs) for a in pair], wp.ctypes.data, bp.ctypes.data) == 0
+    pairs = wp.reshape(-1, _PAIR)
+    assert pairs.shape[0] == ti * T[0] + T[0] * T[1] + T[1] * T[2]
+    ob = np.cumsum([0, T[0] * 32, T[1] * 32, T[2] * 32])
+    bl = [bp[ob[i]:ob[i + 1]] for i in range(3)]
+    cfeat = cin - 3
+    xyz, feat = rng.standard_normal((32, 3)), rng.standard_normal((32, cfeat))
+    user_in = np.concatenate([xyz, feat], axis=1) if xyz_first else np.concatenate([feat, xyz], axis=1)
+    acts = _operand_tiles(np.concatenate([feat, xyz], axis=1), ti)   # the kernel's channel order
+    gemm_last = widths[2] > 512
+    tin = [ti, T[0], T[1]]
+    lane_bias = lambda L, t: np.stack([bl[L].reshape(-1, 2, 16)[t, l >> 5] for l in range(64)]).astype(np.float64)
+    k = 0                                                # step counter: step k holds pairs 4k .. 4k + 3, one per wave
+    last_acc = {}
+    for L in range(3):
+        last = L == 2
+        if last and gemm_last:
+            break
+        acc = {t: (np.zeros((64, 16)) if last else lane_bias(L, t)) for t in range(T[L])}
+        for u in range(tin[L]):
+            for g in range(T[L] // 4):
+                for w in range(4):
+                    acc[4 * g + w] = _emulate_pair(pairs[4 * k + w], acts[u], acc[4 * g + w], last)
+                k += 1
+        if last:
+            last_acc = acc
+        else:
+            acts = [np.maximum(acc[t], 0.0) for t in range(T[L])]
+    if gemm_last:
+        base = 4 * k
+        for t in range(T[2]):                            # pool_gemm_kernel: block cb = t / 4, tile ct = t % 4 of the block
+            acc = np.zeros((64, 16))
+            for u in range(T[1]):
+                acc = _emulate_pair(pairs[base + ((t // 4) * T[1] + u) * 4 + t % 4], acts[u], acc, True)
+            last_acc[t] = acc
+        got = _unswap(last_acc, widths[2], lambda ch: bl[2][ch])     # plain channel order
+    else:
+        assert 4 * k == pairs.shape[0]
+        got = _unswap(last_acc, widths[2], lambda ch: _b_at(bl[2], ch))
+    assert np.allclose(got, _want(user_in, ws, bs), rtol=1e-9, atol=1e-9)
