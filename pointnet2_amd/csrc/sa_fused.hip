@@ -71,7 +71,16 @@ __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, i
 #ifdef PN2_FUSED_LAB_TIMES
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();           // 100 MHz
 #endif
-        fps_reg_body<kFusedThreads, P, true, PN2_FUSED_LAB_PUBLISH>(n, m, Q, blk, xyz, fps_idx, nullptr, tagged, smem, tag);
+        // Up to 2048 rank slots the chain is shorter with FOUR waves of twice the points each (273 vs 288 ns per round
+        // at n = 1024, 312 vs 326 at 2048: a smaller block-wide arg-max; profiles/r02/fps_experiments.txt), which is what
+        // pn2_farthest_point_sample launches at these sizes: the upper four waves of a producer retire at once
+        // (a retired wave no longer counts at the workgroup's barriers).
+        if (kFusedThreads * P <= 2048) {
+            if (threadIdx.x >= kFusedThreads / 2) return;
+            fps_reg_body<kFusedThreads / 2, 2 * P, true, PN2_FUSED_LAB_PUBLISH>(n, m, Q, blk, xyz, fps_idx, nullptr, tagged, smem, tag);
+        } else {
+            fps_reg_body<kFusedThreads, P, true, PN2_FUSED_LAB_PUBLISH>(n, m, Q, blk, xyz, fps_idx, nullptr, tagged, smem, tag);
+        }
 #ifdef PN2_FUSED_LAB_TIMES
         if (threadIdx.x == 0) {
             const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
