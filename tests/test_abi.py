@@ -176,3 +176,17 @@ def test_product_never_imports_oracle():
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), f
                 assert "pn2_cpu_" not in txt, f
                 assert "libpn2_oracle" not in txt, f
+
+
+def test_out_option_buffer_validation_is_host_logic():
+    """_tensors.out_or_empty: a caller-provided result buffer must match shape, dtype, device and be contiguous;
+    without one a fresh tensor is returned (CPU tensors suffice to exercise the checks)."""
+    from pointnet2_amd._tensors import out_or_empty
+    dev = torch.device("cpu")
+    t = out_or_empty(None, (2, 3), torch.int32, dev)
+    assert t.shape == (2, 3) and t.dtype == torch.int32
+    buf = torch.empty(2, 3, dtype=torch.int32)
+    assert out_or_empty(buf, (2, 3), torch.int32, dev) is buf
+    for bad in (torch.empty(2, 4, dtype=torch.int32), torch.empty(2, 3, dtype=torch.float32), torch.empty(3, 2, dtype=torch.int32).t(), "x"):
+        with pytest.raises(ValueError, match="must be a contiguous"):
+            out_or_empty(bad, (2, 3), torch.int32, dev)
