@@ -256,7 +256,7 @@ constexpr long long kFewRows = 4096;
 static int fp_point_layer(int t1, long long known_rows, int c2, int tif, const float *points2, const float *wpoint,
                           const float *zero_bias, float *pre, hipStream_t st)
 {
-    if (known_rows <= kFewRows) return point_layer_few_rows_launch(t1, c2, known_rows, tif, points2, wpoint, pre, st);
+    if (known_rows <= kFewRows) return point_layer_few_rows_launch(t1, c2, known_rows, tif, points2, wpoint, nullptr, pre, st);
     for (int half = 0; half < t1 / 4; ++half)
         if (int rc = point_layer_launch(4, c2, known_rows, tif, points2, wpoint + (size_t)half * tif * 4 * kPairWords, zero_bias,
                                         pre, 32 * t1, 128 * half, st)) return rc;

@@ -151,7 +151,7 @@ int point_layer_launch(int t1, int cfeat, long long rows, int tif, const float *
                        const float *bias, float *pre, int out_stride, int col0, hipStream_t st);
 
 int point_layer_few_rows_launch(int tiles, int cfeat, long long rows, int tif, const float *points, const float *wstream,
-                                float *pre, hipStream_t st);
+                                const float *bias, float *pre, hipStream_t st);
 
 // ---- cooperative variant (coop_mlp.hip): four waves share one 32-sample item and split every layer's output
 // tiles; wide stacks over few rows (SA levels beyond (128,128,256), group_all levels, small FP levels) -------

@@ -150,13 +150,15 @@ __global__ __launch_bounds__(kStreamThreads) void point_layer_kernel(int cfeat, 
 // group owns ONE output tile of one 32-row item; its four waves take every fourth feature tile each (a split of the
 // contraction: the chain is tif / 4 pairs of 12 MFMAs), stream just those pairs from L2 into registers, two ahead,
 // and add their partial tiles through LDS at the end. items x tiles workgroups run side by side.
-// wstream: the per-point streams of fp_mlp.hip, [tile / 4][feature tile][tile % 4]; writes all `tiles` tiles.
+// wstream: the per-point streams of fp_mlp.hip, [tile / 4][feature tile][tile % 4]; writes all `tiles` tiles. bias: the
+// packed bias of these tiles ([tile][half][register]) or nullptr.
 // VEC4: cfeat % 4 == 0. The tile loads are branch-free (clamped address + select): per-lane branches around loads make
 // hipcc wait for every load in flight at each use, the prefetched ones included.
 template <bool VEC4>
 __global__ __launch_bounds__(256) void point_layer_few_rows_kernel(int cfeat, long long rows, int tif, int tiles,
                                                                   const float *__restrict__ points,
-                                                                  const float *__restrict__ wstream, float *__restrict__ pre)
+                                                                  const float *__restrict__ wstream,
+                                                                  const float *__restrict__ bias, float *__restrict__ pre)
 {
     constexpr int kTileVec = kPairWords / 4;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, s = lane & 31;
@@ -204,9 +206,9 @@ __global__ __launch_bounds__(256) void point_layer_few_rows_kernel(int cfeat, lo
         acc = mma_x6<false>(w0_, xs_.p[0], acc);                                                                      \
         acc = mma_x6<false>(w1_, xs_.p[1], acc);                                                                      \
     } while (0)
-    f32x16 acc;
+    f32x16 acc;                                                            // wave 0 starts from the bias (packed tile layout) if any
 #pragma unroll
-    for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+    for (int v = 0; v < 16; ++v) acc[v] = (bias && w == 0) ? bias[(t * 2 + h) * 16 + v] : 0.0f;
     auto my_tile = [&](int j) __attribute__((always_inline)) -> f32x16 { return load_tile(min(w + 4 * min(j, last), tif - 1)); };
     PN2_FEW_ISSUE(0, a);
     PN2_FEW_ISSUE(min(1, last), b);
@@ -445,15 +447,15 @@ int point_layer_launch(int t1, int cfeat, long long rows, int tif, const float *
 
 // the few-rows form: all `tiles` output tiles (a multiple of 4) in one launch, no bias
 int point_layer_few_rows_launch(int tiles, int cfeat, long long rows, int tif, const float *points, const float *wstream,
-                                float *pre, hipStream_t st)
+                                const float *bias, float *pre, hipStream_t st)
 {
     const long long blocks = (rows + 31) / 32 * tiles;
     if (blocks == 0) return PN2_OK;
     if ((cfeat & 3) == 0)
         return launch(point_layer_few_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, cfeat, rows, tif, tiles, points,
-                      wstream, pre);
+                      wstream, bias, pre);
     return launch(point_layer_few_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, cfeat, rows, tif, tiles, points,
-                  wstream, pre);
+                  wstream, bias, pre);
 }
 
 template <int T1, int T2, int T3>
@@ -466,7 +468,13 @@ static int launch_stream(const MlpStreamConfig &c, int b, int n, int m, int nsam
     long long blocks;
     const float *wpoint = wp + (size_t)stream_main_pairs(c) * kPairWords;
     const float *wxyz = wpoint + (size_t)stream_point_pairs(c) * kPairWords;
-    if (int rc = point_layer_launch(T1, cfeat, npoints, c.ti, points, wpoint, bp, pre, 32 * T1, 0, st)) return rc;
+    // few points and a 128-wide first layer (its stream [feature tile][4 tiles] is the few-rows kernel's layout too):
+    // the form without stages, see point_layer_few_rows_kernel
+    if (T1 == 4 && npoints <= 4096 && c.ti > 0) {
+        if (int rc = point_layer_few_rows_launch(4, cfeat, npoints, c.ti, points, wpoint, bp, pre, st)) return rc;
+    } else if (int rc = point_layer_launch(T1, cfeat, npoints, c.ti, points, wpoint, bp, pre, 32 * T1, 0, st)) {
+        return rc;
+    }
     const long long rows = (long long)b * m;
     blocks = (rows + kStreamThreads / 64 - 1) / (kStreamThreads / 64);
     if (blocks > cap) blocks = cap;
