@@ -249,14 +249,13 @@ static long long fp_pairs(const FpConfig &c) { return fp_main_pairs(c) + fp_poin
 // bias: [layer 1][layer 2][layer 3][128 zeros: the per-point kernel adds no bias, the interpolation weights multiply Q only]
 static long long fp_bias_floats(int t1, int t2, int t3) { return (long long)(t1 + t2 + t3) * 32 + 128; }
 
-// Q = points2 . W1a: few known points (most FP levels: 16 ... 2048) -> one wave per (item, output tile), no staging;
+// Q = points2 . W1a: few known points (most FP levels) -> one workgroup per (item, output tile), no staging;
 // many -> the streamed per-point kernel, 128 output channels per launch
-constexpr long long kFewRows = 4096;
 
 static int fp_point_layer(int t1, long long known_rows, int c2, int tif, const float *points2, const float *wpoint,
                           const float *zero_bias, float *pre, hipStream_t st)
 {
-    if (known_rows <= kFewRows) return point_layer_few_rows_launch(t1, c2, known_rows, tif, points2, wpoint, nullptr, pre, st);
+    if (point_layer_prefers_few_rows(known_rows, t1, tif)) return point_layer_few_rows_launch(t1, c2, known_rows, tif, points2, wpoint, nullptr, pre, st);
     for (int half = 0; half < t1 / 4; ++half)
         if (int rc = point_layer_launch(4, c2, known_rows, tif, points2, wpoint + (size_t)half * tif * 4 * kPairWords, zero_bias,
                                         pre, 32 * t1, 128 * half, st)) return rc;

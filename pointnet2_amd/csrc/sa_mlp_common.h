@@ -150,6 +150,7 @@ int mlp_stream_launch(const MlpStreamConfig &c, int b, int n, int m, int nsample
 int point_layer_launch(int t1, int cfeat, long long rows, int tif, const float *points, const float *wstream,
                        const float *bias, float *pre, int out_stride, int col0, hipStream_t st);
 
+bool point_layer_prefers_few_rows(long long rows, int tiles, int tif);
 int point_layer_few_rows_launch(int tiles, int cfeat, long long rows, int tif, const float *points, const float *wstream,
                                 const float *bias, float *pre, hipStream_t st);
 

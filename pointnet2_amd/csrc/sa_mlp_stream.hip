@@ -445,7 +445,11 @@ int point_layer_launch(int t1, int cfeat, long long rows, int tif, const float *
     return PN2_E_ARG;
 }
 
-// the few-rows form: all `tiles` output tiles (a multiple of 4) in one launch, no bias
+// The few-rows form re-reads a tile's weights for every 32-row item (from L2): it wins while that traffic stays small
+// -- items x tiles x feature tiles pairs of 6 KiB, bounded here at 96 MiB per launch (cls_msg level 2, 120 MiB: 30.6 us against 28.9 streamed).
+bool point_layer_prefers_few_rows(long long rows, int tiles, int tif) { return (rows + 31) / 32 * tiles * tif <= 16384; }
+
+// the few-rows form: all `tiles` output tiles (a multiple of 4) in one launch
 int point_layer_few_rows_launch(int tiles, int cfeat, long long rows, int tif, const float *points, const float *wstream,
                                 const float *bias, float *pre, hipStream_t st)
 {
@@ -470,7 +474,7 @@ static int launch_stream(const MlpStreamConfig &c, int b, int n, int m, int nsam
     const float *wxyz = wpoint + (size_t)stream_point_pairs(c) * kPairWords;
     // few points and a 128-wide first layer (its stream [feature tile][4 tiles] is the few-rows kernel's layout too):
     // the form without stages, see point_layer_few_rows_kernel
-    if (T1 == 4 && npoints <= 4096 && c.ti > 0) {
+    if (T1 == 4 && c.ti > 0 && point_layer_prefers_few_rows(npoints, 4, c.ti)) {
         if (int rc = point_layer_few_rows_launch(4, cfeat, npoints, c.ti, points, wpoint, bp, pre, st)) return rc;
     } else if (int rc = point_layer_launch(T1, cfeat, npoints, c.ti, points, wpoint, bp, pre, 32 * T1, 0, st)) {
         return rc;
