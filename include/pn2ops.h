@@ -275,6 +275,69 @@ int pn2_sample_and_group_xyz_gen(int b, int n, int m, float radius, int nsample,
  * synchronising the stream. */
 long long pn2_sample_and_group_status_offset(int b, int m);
 
+/* ---- training mode of the shared MLPs (second half) ---------------------------
+ *
+ * The reference builds every SA / FP level with is_training = True (train.py:188): each of the level's
+ * tf_util.conv2d 1x1 layers is followed by batch normalisation over ALL rows of the level
+ * (tf_util.py:512-531: batch moments, eps 1e-3, moving averages updated with bn_decay, train.py:96-104) and a
+ * ReLU; SA levels end in reduce_max over nsample (utils/pointnet_util.py:113-127), FP levels do not (:222-226).
+ * pn2_mlp_train_forward / _backward run such a stack in training mode on the matrix cores:
+ *   forward, per layer l:   z_l = h_{l-1} W_l + b_l         one MFMA GEMM launch; its prologue forms
+ *                                                           h_{l-1} = relu(a_{l-1} z_{l-1} + c_{l-1}) from the stored
+ *                                                           pre-norm tensor (layer 1: gathers the grouped rows from
+ *                                                           xyz / points / idx -- the (b,m,nsample,C) tensor never
+ *                                                           exists); its epilogue accumulates sum z, sum z^2 per
+ *                                                           channel (and, last SA layer, the per-group max / min of z
+ *                                                           with their sample numbers: BN + ReLU are monotone per
+ *                                                           channel, so the pool commutes with them)
+ *                           (a_l, c_l) from the batch moments, running statistics updated in place
+ *   backward, per layer:    dz_l = s_l dy_l - c0_l - c1_l z_l   (batch-norm backward written per channel)
+ *                           dW_l = h_{l-1}^T dz_l           MFMA, contraction over the rows
+ *                           dy_{l-1} = (dz_l W_l^T) . [h_{l-1} > 0]    MFMA GEMM; epilogue accumulates the two
+ *                                                           per-channel sums batch-norm backward needs one layer down
+ * fp32 in, fp32 out; products on the bf16 matrix pipe as six bf16 terms (see pn2_sa_mlp3_maxpool).
+ * Everything is enqueued on `stream` from ONE call per direction; no host synchronisation; all buffers the
+ * caller's. rows must be a multiple of 32; widths multiples of 4 (layer 1's input width is free when grouped).
+ */
+typedef struct pn2_group_src {     /* the rows of a grouped tensor (pointnet_util.py:44-50, :59-84): row = (cloud*m + j)*nsample + k */
+    int b, n, m, nsample;
+    int cfeat;                     /* channels of `points` (0: xyz only) */
+    int xyz_first;                 /* channel order [xyz, features] (:50, single-scale) or [features, xyz] (:184, MSG) */
+    const float *xyz;              /* (b,n,3) */
+    const float *new_xyz;          /* (b,m,3), subtracted from the grouped xyz; NULL: no centroid (group_all) */
+    const float *points;           /* (b,n,cfeat) or NULL */
+    const int *idx;                /* (b,m,nsample); NULL: sample k of the group is point k (group_all: m = 1, nsample = n) */
+} pn2_group_src;
+
+typedef struct pn2_bn_layer {
+    int cin, cout;
+    const float *weight;           /* W[k][n] = weight[k*w_stride_k + n*w_stride_n]; a torch conv kernel (cout,cin,1,1): 1, cin */
+    long long w_stride_k, w_stride_n;
+    const float *bias;             /* (cout) or NULL */
+    const float *gamma, *beta;     /* batch-norm scale / offset (cout) */
+    float *running_mean, *running_var;   /* (cout), updated in place with `momentum`; NULL: not tracked */
+    float momentum, eps;           /* torch convention: new = (1-momentum)*old + momentum*batch; momentum = 1 - bn_decay */
+    float *z;                      /* (rows, cout) pre-norm output, written by forward, read by backward */
+    float *save;                   /* (4, cout): batch mean, 1/sqrt(var+eps), a = gamma*invstd, c = beta - a*mean */
+    float *grad_weight;            /* backward: same strides as weight */
+    float *grad_gamma, *grad_beta; /* backward: (cout) */
+} pn2_bn_layer;
+
+/* pool_rows: 0 = no pooling, out is (rows, cout_L) = relu(bn(z_L)); else the group size (nsample: 16 or a multiple of
+ * 32), out (rows/pool_rows, cout_L) = max over the group; argsel (same shape, i32) receives the sample number the
+ * gradient flows to and zsel the selected pre-norm value (both needed by backward).
+ * group != NULL: layer 1 reads the grouped rows; else x is the (rows, cin_1) input. */
+long long pn2_mlp_train_ws_bytes(long long rows, int nlayers, const int *widths /* cin_1, cout_1 .. cout_L */,
+                                 int pool_rows, int backward);
+int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group,
+                          const float *x, int pool_rows, float *out, int *argsel, float *zsel, void *ws, void *stream);
+/* grad_out: shape of out. grad_x: (rows, cin_1) or NULL (plain input). grad_feat_rows: (rows, cfeat) -- the gradient
+ * of the grouped FEATURE rows, to be scattered with pn2_group_point_grad_seg -- or NULL (grouped input). The bias
+ * gradient of a layer under batch normalisation is identically zero and is not produced. */
+int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group,
+                           const float *x, int pool_rows, const float *out, const int *argsel, const float *zsel,
+                           const float *grad_out, float *grad_x, float *grad_feat_rows, void *ws, void *stream);
+
 /* ---- host helpers ------------------------------------------------------- */
 
 /* The exact fp32 threshold s* with  max(sqrtf(s),1e-20f) < radius  <=>  s < s*

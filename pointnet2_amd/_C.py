@@ -23,6 +23,7 @@ PN2_ERRORS = {
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
 _f = ctypes.c_float
+_ll = ctypes.c_longlong
 
 # name -> argtypes (all return int unless listed in _RESTYPES)
 _SIGNATURES = {
@@ -67,6 +68,9 @@ _SIGNATURES = {
     "pn2_farthest_point_sample_ex": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "pn2_query_ball_group_xyz_ex": [_i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "pn2_query_ball_group_xyz_msg": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "pn2_mlp_train_ws_bytes": [_ll, _i, _vp, _i, _i],
+    "pn2_mlp_train_forward": [_ll, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "pn2_mlp_train_backward": [_ll, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 _RESTYPES = {
     "pn2_fps_temp_floats": ctypes.c_longlong,
@@ -75,6 +79,7 @@ _RESTYPES = {
     "pn2_sample_and_group_ws_bytes": ctypes.c_longlong,
     "pn2_sa_mlp3_ws_bytes": ctypes.c_longlong,
     "pn2_fp_mlp_ws_bytes": ctypes.c_longlong,
+    "pn2_mlp_train_ws_bytes": ctypes.c_longlong,
     "pn2_sample_and_group_status_offset": ctypes.c_longlong,
     "pn2_ball_threshold": ctypes.c_float,
     "pn2_version": ctypes.c_char_p,

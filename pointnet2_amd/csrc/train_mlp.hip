@@ -1,0 +1,1068 @@
+// train_mlp.hip -- TRAINING mode of the shared MLPs of a set-abstraction / feature-propagation level on the matrix
+// cores (second half). gfx950.
+//
+// Reference: utils/pointnet_util.py:113-127 (SA: 3 x [conv2d 1x1 + batch_norm + ReLU], reduce_max over nsample),
+// :222-226 (FP: the same stack without the pool), tf_util.py:512-531 (batch moments, eps 1e-3, moving averages),
+// train.py:96-104 (bn_decay), train.py:188 (is_training = True: the reference's main mode).
+//
+// Why this is not the inference kernel with one more flag. Batch statistics couple ALL rows of a level: layer l's
+// normalisation needs the moments of z_l over every row before layer l+1 can start, and the backward pass has the
+// same coupling in the other direction (dz = s dy - c0 - c1 z with c0, c1 from two per-channel sums over all rows).
+// So a level is a SEQUENCE of passes with a per-channel reduction between them, and each pass is one GEMM over
+// the rows with everything elementwise folded into its prologue and epilogue. The pre-norm tensors z_l are the only
+// activations kept in HBM (plain row-major (rows, C) fp32, the caller's buffers); h_l = relu(a z + c), the
+// grouped input, dz, the ReLU masks and the normalised tensors never exist in memory.
+//
+// One GEMM core serves every pass (tl_gemm_kernel): a wave owns 32 rows and NS 32-column output tiles,
+//     D (32 rows x 32 cols) += A (32 rows x 16 k) . B (16 k x 32 cols)      v_mfma_f32_32x32x16_bf16
+//   A operand = the wave's rows: lane l supplies row l & 31, contraction indices 32u + 16e + 8(l >> 5) + j, j = 0..7,
+//               i.e. 32 contiguous bytes of a row-major row -- read straight from HBM (two dwordx4), transformed by
+//               the pass's prologue, split into three bf16 levels (sa_mlp_common.h: fp32 products as six bf16 terms);
+//   B operand = weights, packed ON THE DEVICE each step (they change with every optimiser step) into the same
+//               three-level operand layout, staged through LDS (all k tiles resident when they fit, else a
+//               double-buffered stream of one k tile per stage, one s_barrier per stage);
+//   C/D: lane l holds column l & 31 for the 16 rows 8(v >> 2) + 4(l >> 5) + (v & 3): per-channel work of the epilogue
+//        (bias, batch moments, max / min pool, ReLU mask of the layer below, batch-norm backward sums) is lane-local,
+//        and a row's 32 columns leave as one 128-byte store.
+// The weight gradient contracts over ROWS (tl_wgrad_kernel): both operands are read with lane = channel, slots = rows
+// (coalesced 128-byte row segments), each wave accumulates its share of the rows into a register-resident dW slab,
+// and a two-stage reduction sums the waves' slabs (fp64 in the last stage) in a fixed order: the result does not
+// depend on timing.
+#include "sa_mlp_common.h"
+
+#include <string.h>
+
+namespace pn2 {
+
+constexpr int kTlThreads = 512;          // GEMM workgroup: 8 waves, one 32-row item each per round
+constexpr int kTlWaves = kTlThreads / 64;
+constexpr int kPairVec = kPairWords / 4; // 16-byte vectors of one 32x32 weight tile pair
+constexpr int kWgThreads = 256;          // weight-gradient workgroup: 4 waves
+
+enum { A_PLAIN = 0, A_GATHER = 1, A_RELU = 2, A_DZ = 3, A_DZ_POOL = 4 };
+enum { E_STORE = 0, E_POOL = 1, E_MASK = 2, E_PLAIN = 3 };
+
+struct TlGather {
+    int n, m, nsample, cfeat, xyz_off, feat_off;
+    const float *xyz, *new_xyz, *points;
+    const int *idx;
+};
+
+struct TlGemm {
+    long long rows;
+    int K, N;                   // contraction width = pitch of A; output width = pitch of out / zprev
+    int tk;                     // 32-wide k tiles
+    int resident;               // every k tile's weights stay in LDS
+    // A operand
+    const float *A;             // A_PLAIN: x; A_RELU: z of the layer below; A_DZ / A_DZ_POOL: z of this layer
+    const float *G;             // A_DZ: dy (rows, K); A_DZ_POOL: gq (groups, K)
+    const int *argsel;          // A_DZ_POOL: (groups, K)
+    const float *p0, *p1, *p2;  // A_RELU: a, c; A_DZ*: s, c0, c1   (K floats each)
+    int group_rows;             // A_DZ_POOL
+    TlGather g;                 // A_GATHER
+    const u32x4 *wpacked;       // [slab][k tile][NS] tile pairs
+    const float *bias;          // (N) or nullptr
+    // epilogue
+    int emode;
+    float *out;                 // E_STORE / E_POOL: z (rows, N); E_MASK: dy of the layer below (rows, N); E_PLAIN: see col0
+    int out_pitch, col0, col1;  // E_PLAIN: columns [col0, col1) go to out[row * out_pitch + col - col0]
+    double *stats;              // (2, N): E_STORE / E_POOL: sum z, sum z^2; E_MASK: sum dy, sum dy * zprev
+    const float *zprev, *ea, *ec;   // E_MASK: pre-norm tensor of the layer below (rows, N) and its (a, c)
+    float *pmax, *pmin;         // E_POOL partials (rows / prow, N)
+    int *pamax, *pamin;
+    int prow;                   // 32 or 16
+};
+
+// ---- A operand: load + prologue. Register v = 8e + j of lane (row s, half hl) <-> channel 32u + 16e + 8hl + j ------------
+struct ARaw { f32x16 a, g; int4 sel[4]; };
+struct RowCtx { long long grp; int sample, pt; long long cloud; };      // of the lane's row (gather / pooled passes)
+
+template <int AMODE>
+__device__ __forceinline__ RowCtx tl_row_ctx(const TlGemm &p, long long row, bool active)
+{
+    RowCtx c = {0, 0, 0, 0};
+    if (!active) return c;
+    if (AMODE == A_GATHER) {
+        c.grp = row / p.g.nsample;
+        c.sample = (int)(row - c.grp * p.g.nsample);
+        c.cloud = c.grp / p.g.m;
+        c.pt = p.g.idx ? p.g.idx[row] : c.sample;
+    } else if (AMODE == A_DZ_POOL) {
+        c.grp = row / p.group_rows;
+        c.sample = (int)(row - c.grp * p.group_rows);
+    }
+    return c;
+}
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+template <int AMODE>
+__device__ __forceinline__ void tl_load_raw(const TlGemm &p, long long row, const RowCtx &rc, int u, int hl, bool active, ARaw &r)
+{
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { r.a[v] = 0.0f; r.g[v] = 0.0f; }
+    if (!active) return;
+    if (AMODE == A_GATHER) {
+        const TlGather &g = p.g;
+        const float *px = g.xyz + ((size_t)rc.cloud * g.n + rc.pt) * 3;
+        const float *pf = g.points ? g.points + ((size_t)rc.cloud * g.n + rc.pt) * g.cfeat : nullptr;
+        const float *pc = g.new_xyz ? g.new_xyz + rc.grp * 3 : nullptr;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 32 * u + 16 * e + 8 * hl + j;
+                float val = 0.0f;
+                const int kx = k - g.xyz_off, kf = k - g.feat_off;
+                if (kx >= 0 && kx < 3) val = pc ? __fsub_rn(px[kx], pc[kx]) : px[kx];      // pointnet_util.py:46
+                else if (kf >= 0 && kf < g.cfeat) val = pf[kf];
+                r.a[8 * e + j] = val;
+            }
+        return;
+    }
+    const float *pa = p.A + (size_t)row * p.K;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int k = 32 * u + 16 * e + 8 * hl + 4 * q;
+            if (k < p.K) {
+                const float4 t = ld4(pa + k);
+                r.a[8 * e + 4 * q] = t.x; r.a[8 * e + 4 * q + 1] = t.y; r.a[8 * e + 4 * q + 2] = t.z; r.a[8 * e + 4 * q + 3] = t.w;
+            }
+        }
+    if (AMODE == A_DZ) {
+        const float *pg = p.G + (size_t)row * p.K;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = 32 * u + 16 * e + 8 * hl + 4 * q;
+                if (k < p.K) {
+                    const float4 t = ld4(pg + k);
+                    r.g[8 * e + 4 * q] = t.x; r.g[8 * e + 4 * q + 1] = t.y; r.g[8 * e + 4 * q + 2] = t.z; r.g[8 * e + 4 * q + 3] = t.w;
+                }
+            }
+    }
+    if (AMODE == A_DZ_POOL) {
+        const float *pg = p.G + (size_t)rc.grp * p.K;
+        const int *ps = p.argsel + (size_t)rc.grp * p.K;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = 32 * u + 16 * e + 8 * hl + 4 * q;
+                int4 s4 = {-1, -1, -1, -1};
+                if (k < p.K) {
+                    const float4 t = ld4(pg + k);
+                    r.g[8 * e + 4 * q] = t.x; r.g[8 * e + 4 * q + 1] = t.y; r.g[8 * e + 4 * q + 2] = t.z; r.g[8 * e + 4 * q + 3] = t.w;
+                    s4 = *reinterpret_cast<const int4 *>(ps + k);
+                }
+                r.sel[2 * e + q] = s4;
+            }
+    }
+}
+
+// the pass's prologue on the 16 values of one k tile; lp*: the per-channel parameters in LDS (zero beyond K)
+template <int AMODE>
+__device__ __forceinline__ f32x16 tl_finish(const ARaw &r, const RowCtx &rc, int u, int hl, const float *lp0, const float *lp1,
+                                            const float *lp2)
+{
+    if (AMODE == A_PLAIN || AMODE == A_GATHER) return r.a;
+    f32x16 x;
+    const int sample = rc.sample;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int k = 32 * u + 16 * e + 8 * hl + 4 * q;
+            const float4 c0 = ld4(lp0 + k), c1 = ld4(lp1 + k);
+            const float a0[4] = {c0.x, c0.y, c0.z, c0.w}, a1[4] = {c1.x, c1.y, c1.z, c1.w};
+            if (AMODE == A_RELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int v = 8 * e + 4 * q + i;
+                    x[v] = vmax(__fadd_rn(__fmul_rn(a0[i], r.a[v]), a1[i]), 0.0f);        // h = relu(a z + c)
+                }
+            } else {
+                const float4 c2 = ld4(lp2 + k);
+                const float a2[4] = {c2.x, c2.y, c2.z, c2.w};
+                int sl[4] = {0, 0, 0, 0};
+                if (AMODE == A_DZ_POOL) {
+                    const int4 s4 = r.sel[2 * e + q];
+                    sl[0] = s4.x; sl[1] = s4.y; sl[2] = s4.z; sl[3] = s4.w;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int v = 8 * e + 4 * q + i;
+                    float dy = r.g[v];
+                    if (AMODE == A_DZ_POOL) dy = sl[i] == sample ? dy : 0.0f;             // the pool routes dy to ONE sample
+                    x[v] = __fsub_rn(__fsub_rn(__fmul_rn(a0[i], dy), a1[i]), __fmul_rn(a2[i], r.a[v]));   // s dy - c0 - c1 z
+                }
+            }
+        }
+    return x;
+}
+
+template <int NS, int AMODE>
+__global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int kpad = p.tk * 32;
+    float *lp0 = reinterpret_cast<float *>(smem), *lp1 = lp0 + kpad, *lp2 = lp1 + kpad;
+    u32x4 *wst = reinterpret_cast<u32x4 *>(lp2 + kpad);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, s = lane & 31;
+    const int slab = blockIdx.y;
+    constexpr int kStageV = NS * kPairVec;
+    constexpr int PV = (kStageV + kTlThreads - 1) / kTlThreads;
+    const u32x4 *wsrc = p.wpacked + (size_t)slab * p.tk * kStageV;
+
+    if (AMODE >= A_RELU) {
+        for (int i = tid; i < kpad; i += kTlThreads) {
+            const bool in = i < p.K;
+            lp0[i] = in ? p.p0[i] : 0.0f;
+            lp1[i] = in ? p.p1[i] : 0.0f;
+            lp2[i] = (in && AMODE >= A_DZ) ? p.p2[i] : 0.0f;
+        }
+    }
+    if (p.resident)
+        for (int i = tid; i < p.tk * kStageV; i += kTlThreads) wst[i] = wsrc[i];
+    __syncthreads();
+
+    const long long items = p.rows / 32;
+    const long long rounds = (items + kTlWaves - 1) / kTlWaves;
+    u32x4 pre[PV];
+    if (!p.resident) {
+#pragma unroll
+        for (int i = 0; i < PV; ++i) {
+            const int j = tid + i * kTlThreads;
+            if (j < kStageV) pre[i] = wsrc[j];
+        }
+    }
+    unsigned parity = 0;
+    double sd1[NS], sd2[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) { sd1[t] = 0.0; sd2[t] = 0.0; }
+
+    for (long long round = blockIdx.x; round < rounds; round += gridDim.x) {
+        const long long item = round * kTlWaves + wave;
+        const bool active = item < items;
+        const long long row0 = item * 32, row = row0 + s;
+        f32x16 acc[NS];
+#pragma unroll
+        for (int t = 0; t < NS; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] = 0.0f;
+        const RowCtx rc = tl_row_ctx<AMODE>(p, row, active);
+        ARaw raw;
+        tl_load_raw<AMODE>(p, row, rc, 0, hl, active, raw);
+        for (int u = 0; u < p.tk; ++u) {
+            const u32x4 *stage;
+            if (p.resident) {
+                stage = wst + (size_t)u * kStageV;
+            } else {
+                u32x4 *dst = wst + (parity & 1u) * kStageV;
+#pragma unroll
+                for (int i = 0; i < PV; ++i) {
+                    const int j = tid + i * kTlThreads;
+                    if (j < kStageV) dst[j] = pre[i];
+                }
+                __syncthreads();
+                const bool more = u + 1 < p.tk || round + gridDim.x < rounds;
+                if (more) {
+                    const u32x4 *nsrc = wsrc + (size_t)(u + 1 < p.tk ? u + 1 : 0) * kStageV;
+#pragma unroll
+                    for (int i = 0; i < PV; ++i) {
+                        const int j = tid + i * kTlThreads;
+                        if (j < kStageV) pre[i] = nsrc[j];
+                    }
+                }
+                stage = dst;
+                ++parity;
+            }
+            const ActSplit sp = split_act(tl_finish<AMODE>(raw, rc, u, hl, lp0, lp1, lp2));
+            if (u + 1 < p.tk) tl_load_raw<AMODE>(p, row, rc, u + 1, hl, active, raw);
+#pragma unroll
+            for (int t = 0; t < NS; ++t) acc[t] = stream_pair<true>(stage, t, lane, sp, acc[t]);
+        }
+
+        // ---- epilogue: lane = column 32(slab NS + t) + s, register v = row row0 + mlp_chan(v, hl) ----------------------
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int col = (slab * NS + t) * 32 + s;
+            const bool ok = active && col < p.N;
+            if (p.emode == E_STORE || p.emode == E_POOL) {
+                const float bias = (p.bias && col < p.N) ? p.bias[col] : 0.0f;
+                float s1 = 0.0f, s2 = 0.0f;
+                f32x16 val;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    val[v] = __fadd_rn(acc[t][v], bias);
+                    s1 = __fadd_rn(s1, val[v]);
+                    s2 = __fadd_rn(s2, __fmul_rn(val[v], val[v]));
+                }
+                if (ok) {
+                    sd1[t] += (double)s1;
+                    sd2[t] += (double)s2;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) p.out[(size_t)(row0 + mlp_chan(v, hl)) * p.N + col] = val[v];
+                }
+                if (p.emode == E_POOL) {
+                    // max / min of z over the rows of the item (two half items when a group is 16 rows), with the row
+                    // number of the FIRST extremum; the other half of the rows lives in lane l ^ 32
+                    const int halves = p.prow == 16 ? 2 : 1, span = 16 / halves;
+                    for (int hf = 0; hf < halves; ++hf) {
+                        float mx = val[hf * span], mn = mx;
+                        int ax = hf * span, an = ax;
+                        for (int v = hf * span + 1; v < (hf + 1) * span; ++v) {
+                            if (val[v] > mx) { mx = val[v]; ax = v; }
+                            if (val[v] < mn) { mn = val[v]; an = v; }
+                        }
+                        int rx = mlp_chan(ax, hl), rn = mlp_chan(an, hl);
+                        const float omx = __shfl_xor(mx, 32), omn = __shfl_xor(mn, 32);
+                        const int orx = __shfl_xor(rx, 32), orn = __shfl_xor(rn, 32);
+                        if (omx > mx || (omx == mx && orx < rx)) { mx = omx; rx = orx; }
+                        if (omn < mn || (omn == mn && orn < rn)) { mn = omn; rn = orn; }
+                        if (ok && hl == 0) {
+                            const size_t o = (size_t)(item * halves + hf) * p.N + col;
+                            p.pmax[o] = mx; p.pmin[o] = mn;
+                            p.pamax[o] = rx - hf * 16; p.pamin[o] = rn - hf * 16;
+                        }
+                    }
+                }
+            } else if (p.emode == E_MASK) {
+                const float ea = col < p.N ? p.ea[col] : 0.0f, ec = col < p.N ? p.ec[col] : 0.0f;
+                float s1 = 0.0f, s2 = 0.0f;
+                if (ok) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const size_t o = (size_t)(row0 + mlp_chan(v, hl)) * p.N + col;
+                        const float zp = p.zprev[o];
+                        const float y = __fadd_rn(__fmul_rn(ea, zp), ec);
+                        const float g = y > 0.0f ? acc[t][v] : 0.0f;                      // ReLU of the layer below
+                        p.out[o] = g;
+                        s1 = __fadd_rn(s1, g);
+                        s2 = __fadd_rn(s2, __fmul_rn(g, zp));
+                    }
+                    sd1[t] += (double)s1;
+                    sd2[t] += (double)s2;
+                }
+            } else {
+                if (active && col >= p.col0 && col < p.col1) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+                        p.out[(size_t)(row0 + mlp_chan(v, hl)) * p.out_pitch + (col - p.col0)] = acc[t][v];
+                }
+            }
+        }
+    }
+    if (p.emode != E_PLAIN && p.stats) {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int col = (slab * NS + t) * 32 + s;
+            const double d1 = sd1[t] + __shfl_xor(sd1[t], 32), d2 = sd2[t] + __shfl_xor(sd2[t], 32);
+            if (hl == 0 && col < p.N) {
+                atomicAdd(p.stats + col, d1);
+                atomicAdd(p.stats + p.N + col, d2);
+            }
+        }
+    }
+}
+
+// ---- weights -> three-level bf16 operand tiles, on the device ---------------------------------------------------------
+// value for K16 step e, level, lane l, slot j of pair (slab, u, t) = level of W[32u + 16e + 8(l >> 5) + j][32(slab NS + t) + (l & 31)]
+__global__ __launch_bounds__(256) void tl_pack_kernel(const float *__restrict__ w, long long sk, long long sn, int K, int N,
+                                                      int tk, int ns, int slabs, u32x4 *__restrict__ out)
+{
+    const long long total = (long long)slabs * tk * ns * 128;           // one thread per (pair, e, lane)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int lane = (int)(i & 63), e = (int)((i >> 6) & 1);
+        const long long pair = i >> 7;
+        const int t = (int)(pair % ns), u = (int)((pair / ns) % tk), slab = (int)(pair / ((long long)ns * tk));
+        const int n = (slab * ns + t) * 32 + (lane & 31);
+        f32x16 x;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) x[v] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 32 * u + 16 * e + 8 * (lane >> 5) + j;
+            x[j] = (k < K && n < N) ? w[k * sk + n * sn] : 0.0f;
+        }
+        const ActSplit sp = split_act(x);
+        u32x4 *o = out + pair * kPairVec + (size_t)e * 192 + lane;
+        o[0] = sp.p[0][0];
+        o[64] = sp.p[0][1];
+        o[128] = sp.p[0][2];
+    }
+}
+
+// ---- per-channel finalisation kernels (one thread per channel) -----------------------------------------------------------
+// batch moments -> (mean, invstd, a, c), running statistics (torch.nn.BatchNorm semantics: unbiased variance in the average)
+__global__ void tl_bn_finalize_kernel(const double *__restrict__ stats, int N, double count, const float *__restrict__ gamma,
+                                      const float *__restrict__ beta, float *running_mean, float *running_var,
+                                      float momentum, float eps, float *__restrict__ save)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const double mean = stats[c] / count;
+    double var = stats[N + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double a = (double)gamma[c] * invstd;
+    save[c] = (float)mean;
+    save[N + c] = (float)invstd;
+    save[2 * N + c] = (float)a;
+    save[3 * N + c] = (float)((double)beta[c] - a * mean);
+    if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+    if (running_var) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+}
+
+// (sum dy, sum dy z) -> grad_gamma, grad_beta and the coefficients of dz = s dy - c0 - c1 z
+__global__ void tl_bn_backward_finalize_kernel(const double *__restrict__ stats, int N, double count,
+                                               const float *__restrict__ gamma, const float *__restrict__ save,
+                                               float *__restrict__ grad_gamma, float *__restrict__ grad_beta,
+                                               float *__restrict__ coef)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const double mean = save[c], invstd = save[N + c];
+    const double dbeta = stats[c], dgamma = (stats[N + c] - mean * stats[c]) * invstd;
+    const double s = (double)gamma[c] * invstd;
+    const double c1 = s * dgamma * invstd / count;
+    const double c0 = s * dbeta / count - c1 * mean;
+    if (grad_gamma) grad_gamma[c] = (float)dgamma;
+    if (grad_beta) grad_beta[c] = (float)dbeta;
+    coef[c] = (float)s;
+    coef[N + c] = (float)c0;
+    coef[2 * N + c] = (float)c1;
+}
+
+// pool: partial extrema of z -> out = relu(a zsel + c), the sample the gradient flows to, zsel (a >= 0: the max, else the min)
+__global__ void tl_pool_finalize_kernel(long long groups, int N, int parts, int prow, const float *__restrict__ pmax,
+                                        const float *__restrict__ pmin, const int *__restrict__ pamax,
+                                        const int *__restrict__ pamin, const float *__restrict__ save,
+                                        float *__restrict__ out, int *__restrict__ argsel, float *__restrict__ zsel)
+{
+    const long long total = groups * N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long g = i / N;
+        const int c = (int)(i - g * N);
+        const float a = save[2 * N + c], cc = save[3 * N + c];
+        const bool up = a >= 0.0f;
+        float best = 0.0f;
+        int arg = 0;
+        for (int q = 0; q < parts; ++q) {
+            const size_t o = (size_t)(g * parts + q) * N + c;
+            const float v = up ? pmax[o] : pmin[o];
+            const int r = (up ? pamax[o] : pamin[o]) + q * prow;
+            if (q == 0 || (up ? v > best : v < best)) { best = v; arg = r; }
+        }
+        out[i] = vmax(__fadd_rn(__fmul_rn(a, best), cc), 0.0f);
+        argsel[i] = arg;
+        zsel[i] = best;
+    }
+}
+
+// pooled top layer: gq = grad_out . [out > 0]; sums of dy and dy z over all rows = over the selected entries
+__global__ __launch_bounds__(256) void tl_pool_grad_kernel(long long groups, int N, const float *__restrict__ out,
+                                                           const float *__restrict__ gout, const float *__restrict__ zsel,
+                                                           float *__restrict__ gq, double *__restrict__ stats)
+{
+    // thread (x = column within a 64-column strip, y = row lane): column sums over a strided set of groups
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ry = threadIdx.x >> 6;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < N) {
+        for (long long g = (long long)blockIdx.y * 4 + ry; g < groups; g += (long long)gridDim.y * 4) {
+            const size_t o = (size_t)g * N + c;
+            const float q = out[o] > 0.0f ? gout[o] : 0.0f;
+            gq[o] = q;
+            s1 += (double)q;
+            s2 += (double)q * (double)zsel[o];
+        }
+    }
+    __shared__ double sh[2][4][64];
+    sh[0][ry][threadIdx.x & 63] = s1;
+    sh[1][ry][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (ry == 0 && c < N) {
+        const int x = threadIdx.x & 63;
+        atomicAdd(stats + c, sh[0][0][x] + sh[0][1][x] + sh[0][2][x] + sh[0][3][x]);
+        atomicAdd(stats + N + c, sh[1][0][x] + sh[1][1][x] + sh[1][2][x] + sh[1][3][x]);
+    }
+}
+
+// unpooled top layer (FP levels): out = relu(a z + c)
+__global__ __launch_bounds__(256) void tl_apply_kernel(long long total4, int N, const float *__restrict__ z,
+                                                       const float *__restrict__ save, float *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int c = (int)((i * 4) % N);
+        const float4 zz = ld4(z + i * 4), a = ld4(save + 2 * N + c), cc = ld4(save + 3 * N + c);
+        float4 o;
+        o.x = vmax(__fadd_rn(__fmul_rn(a.x, zz.x), cc.x), 0.0f);
+        o.y = vmax(__fadd_rn(__fmul_rn(a.y, zz.y), cc.y), 0.0f);
+        o.z = vmax(__fadd_rn(__fmul_rn(a.z, zz.z), cc.z), 0.0f);
+        o.w = vmax(__fadd_rn(__fmul_rn(a.w, zz.w), cc.w), 0.0f);
+        *reinterpret_cast<float4 *>(out + i * 4) = o;
+    }
+}
+
+// unpooled top layer backward: dy = grad_out . [out > 0] (rows, N) + its two column sums
+__global__ __launch_bounds__(256) void tl_top_grad_kernel(long long rows, int N, const float *__restrict__ out,
+                                                          const float *__restrict__ gout, const float *__restrict__ z,
+                                                          float *__restrict__ dy, double *__restrict__ stats)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ry = threadIdx.x >> 6;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < N) {
+        for (long long r = (long long)blockIdx.y * 4 + ry; r < rows; r += (long long)gridDim.y * 4) {
+            const size_t o = (size_t)r * N + c;
+            const float q = out[o] > 0.0f ? gout[o] : 0.0f;
+            dy[o] = q;
+            s1 += (double)q;
+            s2 += (double)q * (double)z[o];
+        }
+    }
+    __shared__ double sh[2][4][64];
+    sh[0][ry][threadIdx.x & 63] = s1;
+    sh[1][ry][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (ry == 0 && c < N) {
+        const int x = threadIdx.x & 63;
+        atomicAdd(stats + c, sh[0][0][x] + sh[0][1][x] + sh[0][2][x] + sh[0][3][x]);
+        atomicAdd(stats + N + c, sh[1][0][x] + sh[1][1][x] + sh[1][2][x] + sh[1][3][x]);
+    }
+}
+
+// ---- weight gradient: dW (KI x NO) = h^T dz, contraction over the rows -----------------------------------------------------
+struct TlWgrad {
+    long long rows;
+    int amode;                  // A_PLAIN / A_GATHER / A_RELU: how h (rows, KI) is formed
+    int KI;
+    const float *A, *pa, *pc;
+    TlGather g;
+    int dmode;                  // A_DZ / A_DZ_POOL
+    int NO;
+    const float *Z, *G;
+    const int *argsel;
+    const float *coef;          // (3, NO): s, c0, c1
+    int group_rows;
+    float *partial;             // [slab][wave][TU*TT tiles][1024]
+    int tslabs;
+};
+
+// 16 rows (register 8e + j <-> row 16e + 8hl + j of the item) of channel `ch` of h
+__device__ __forceinline__ f32x16 wg_load_h(const TlWgrad &p, long long row0, int ch, int hl)
+{
+    f32x16 x;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) x[v] = 0.0f;
+    if (ch >= p.KI) return x;
+    if (p.amode == A_GATHER) {
+        const TlGather &g = p.g;
+        const int kx = ch - g.xyz_off, kf = ch - g.feat_off;
+        const bool isx = kx >= 0 && kx < 3, isf = kf >= 0 && kf < g.cfeat;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const long long row = row0 + 16 * (v >> 3) + 8 * hl + (v & 7);
+            const long long grp = row / g.nsample;
+            const int sample = (int)(row - grp * g.nsample);
+            const long long cloud = grp / g.m;
+            const int pt = g.idx ? g.idx[row] : sample;
+            if (isx) {
+                const float val = g.xyz[((size_t)cloud * g.n + pt) * 3 + kx];
+                x[v] = g.new_xyz ? __fsub_rn(val, g.new_xyz[grp * 3 + kx]) : val;
+            } else if (isf) {
+                x[v] = g.points[((size_t)cloud * g.n + pt) * g.cfeat + kf];
+            }
+        }
+        return x;
+    }
+    const float a = p.amode == A_RELU ? p.pa[ch] : 1.0f, c = p.amode == A_RELU ? p.pc[ch] : 0.0f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const long long row = row0 + 16 * (v >> 3) + 8 * hl + (v & 7);
+        const float z = p.A[(size_t)row * p.KI + ch];
+        x[v] = p.amode == A_RELU ? vmax(__fadd_rn(__fmul_rn(a, z), c), 0.0f) : z;
+    }
+    return x;
+}
+
+__device__ __forceinline__ f32x16 wg_load_dz(const TlWgrad &p, long long row0, int ch, int hl)
+{
+    f32x16 x;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) x[v] = 0.0f;
+    if (ch >= p.NO) return x;
+    const float s = p.coef[ch], c0 = p.coef[p.NO + ch], c1 = p.coef[2 * p.NO + ch];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const long long row = row0 + 16 * (v >> 3) + 8 * hl + (v & 7);
+        const float z = p.Z[(size_t)row * p.NO + ch];
+        float dy;
+        if (p.dmode == A_DZ_POOL) {
+            const long long grp = row / p.group_rows;
+            const int sample = (int)(row - grp * p.group_rows);
+            dy = p.argsel[(size_t)grp * p.NO + ch] == sample ? p.G[(size_t)grp * p.NO + ch] : 0.0f;
+        } else {
+            dy = p.G[(size_t)row * p.NO + ch];
+        }
+        x[v] = __fsub_rn(__fsub_rn(__fmul_rn(s, dy), c0), __fmul_rn(c1, z));
+    }
+    return x;
+}
+
+template <int TU, int TT>
+__global__ __launch_bounds__(kWgThreads) void tl_wgrad_kernel(const TlWgrad p)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, s = lane & 31;
+    const int us = blockIdx.y / p.tslabs, ts = blockIdx.y % p.tslabs;
+    const long long nw = (long long)gridDim.x * (kWgThreads / 64), wg = (long long)blockIdx.x * (kWgThreads / 64) + wave;
+    const long long items = p.rows / 32;
+    f32x16 acc[TU][TT];
+#pragma unroll
+    for (int u = 0; u < TU; ++u)
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[u][t][v] = 0.0f;
+    for (long long item = wg; item < items; item += nw) {
+        const long long row0 = item * 32;
+        ActSplit a[TU], d[TT];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) a[u] = split_act(wg_load_h(p, row0, (us * TU + u) * 32 + s, hl));
+#pragma unroll
+        for (int t = 0; t < TT; ++t) d[t] = split_act(wg_load_dz(p, row0, (ts * TT + t) * 32 + s, hl));
+#pragma unroll
+        for (int u = 0; u < TU; ++u)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                acc[u][t] = mma_x6<false>(a[u].p[0], d[t].p[0], acc[u][t]);
+                acc[u][t] = mma_x6<false>(a[u].p[1], d[t].p[1], acc[u][t]);
+            }
+    }
+    // dump: D[i = input channel mlp_chan(v, hl)][j = output channel s] of tile (u, t)
+    float4 *dst = reinterpret_cast<float4 *>(p.partial) + (((size_t)blockIdx.y * nw + wg) * (TU * TT)) * 256;
+#pragma unroll
+    for (int u = 0; u < TU; ++u)
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 o = {acc[u][t][4 * q], acc[u][t][4 * q + 1], acc[u][t][4 * q + 2], acc[u][t][4 * q + 3]};
+                dst[(size_t)(u * TT + t) * 256 + q * 64 + lane] = o;
+            }
+}
+
+// stage A of the reduction: sums of `chunk` consecutive waves' slabs (layout unchanged): in [slab][nw][E] -> out [slab][nchunks][E]
+__global__ __launch_bounds__(256) void tl_wgrad_reduce_a_kernel(const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                                long long nw, int chunk, long long nchunks, long long e4)
+{
+    const long long slab = blockIdx.z, ck = blockIdx.y;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < e4; i += (long long)gridDim.x * 256) {
+        float4 sum = {0.0f, 0.0f, 0.0f, 0.0f};
+        const long long w0 = ck * chunk, w1 = w0 + chunk < nw ? w0 + chunk : nw;
+        for (long long w = w0; w < w1; ++w) {
+            const float4 v = in[(slab * nw + w) * e4 + i];
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        out[(slab * nchunks + ck) * e4 + i] = sum;
+    }
+}
+
+// stage B: fp64 sum over the remaining partials, written with the caller's weight strides
+__global__ __launch_bounds__(256) void tl_wgrad_reduce_b_kernel(const float *__restrict__ in, long long nw, int TU, int TT,
+                                                                int tslabs, int KI, int NO, float *__restrict__ gw,
+                                                                long long sk, long long sn)
+{
+    const long long total = (long long)KI * NO;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int k = (int)(i / NO), n = (int)(i - (long long)k * NO);
+        const int u = k >> 5, kk = k & 31, t = n >> 5;
+        const int hh = (kk >> 2) & 1, v = 4 * (kk >> 3) + (kk & 3), lane = (n & 31) + 32 * hh;
+        const int us = u / TU, ul = u % TU, ts = t / TT, tl = t % TT;
+        const long long slab = (long long)us * tslabs + ts;
+        const size_t e = (size_t)TU * TT * 1024, off = (size_t)(ul * TT + tl) * 1024 + (v >> 2) * 256 + lane * 4 + (v & 3);
+        double sum = 0.0;
+        for (long long w = 0; w < nw; ++w) sum += (double)in[(slab * nw + w) * e + off];
+        gw[k * sk + n * sn] = (float)sum;
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline int tiles(int c) { return (c + 31) / 32; }
+static inline int pick_ns(int tn) { return tn >= 3 ? 4 : tn == 2 ? 2 : 1; }
+
+struct GemmShape { int K, N, tk, tn, ns, slabs, resident; size_t lds, pack_bytes; };
+
+static GemmShape gemm_shape(int K, int N)
+{
+    GemmShape g;
+    g.K = K; g.N = N;
+    g.tk = tiles(K); g.tn = tiles(N);
+    g.ns = pick_ns(g.tn);
+    g.slabs = (g.tn + g.ns - 1) / g.ns;
+    const size_t params = (size_t)3 * g.tk * 32 * sizeof(float), stage = (size_t)g.ns * kPairWords * 4;
+    g.resident = params + stage * g.tk <= (size_t)144 * 1024;
+    g.lds = params + stage * (g.resident ? g.tk : 2);
+    g.pack_bytes = (size_t)g.slabs * g.tk * g.ns * kPairWords * 4;
+    return g;
+}
+
+struct WgradShape { int TU, TT, uslabs, tslabs; long long gridx, nw, nchunks; size_t e, partial_bytes, partial2_bytes; };
+
+static WgradShape wgrad_shape(long long rows, int KI, int NO)
+{
+    WgradShape w;
+    const int tu = tiles(KI), tt = tiles(NO);
+    w.TU = tu >= 2 ? 2 : 1;
+    w.TT = tt >= 3 ? 4 : tt == 2 ? 2 : 1;
+    w.uslabs = (tu + w.TU - 1) / w.TU;
+    w.tslabs = (tt + w.TT - 1) / w.TT;
+    const long long items = rows / 32;
+    long long waves = items / 8;                                   // at least eight items per wave
+    if (waves < 4) waves = 4;
+    if (waves > 1024) waves = 1024;
+    w.gridx = (waves + 3) / 4;
+    w.nw = w.gridx * 4;
+    w.e = (size_t)w.TU * w.TT * 1024;
+    w.nchunks = w.nw > 32 ? (w.nw + 31) / 32 : 0;
+    const size_t slabs = (size_t)w.uslabs * w.tslabs;
+    w.partial_bytes = slabs * w.nw * w.e * sizeof(float);
+    w.partial2_bytes = slabs * (size_t)w.nchunks * w.e * sizeof(float);
+    return w;
+}
+
+struct TlPlan {
+    size_t pack[8];             // forward: W_l; backward: W_l^T
+    size_t stats[8];            // (2, cout_l) doubles
+    size_t coef[8];             // backward: (3, cout_l) floats
+    size_t pool;                // forward: pmax, pmin, pamax, pamin (4 arrays of parts_total x cout_L)
+    size_t gq;                  // backward, pooled: (groups, cout_L)
+    size_t ga, gb;              // backward: dy ping-pong (rows, max width)
+    size_t partial, partial2;   // backward: weight-gradient partial sums
+    size_t total;
+};
+
+static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_rows, int backward, TlPlan &pl)
+{
+    if (rows <= 0 || rows % 32 || nlayers < 1 || nlayers > 8) return false;
+    if (pool_rows && pool_rows != 16 && pool_rows % 32) return false;
+    memset(&pl, 0, sizeof(pl));
+    size_t off = 0;
+    int maxw = 0;
+    for (int l = 0; l < nlayers; ++l) {
+        const int cin = widths[l], cout = widths[l + 1];
+        if (cin <= 0 || cout <= 0 || cout % 4) return false;
+        const GemmShape g = backward ? gemm_shape(cout, cin) : gemm_shape(cin, cout);
+        pl.pack[l] = off; off = align_up(off + g.pack_bytes);
+        pl.stats[l] = off; off = align_up(off + sizeof(double) * 2 * cout);
+        if (backward) { pl.coef[l] = off; off = align_up(off + sizeof(float) * 3 * cout); }
+        if (cout > maxw) maxw = cout;
+    }
+    const int cl = widths[nlayers];
+    if (!backward) {
+        if (pool_rows) {
+            const long long parts = rows / (pool_rows == 16 ? 16 : 32);
+            pl.pool = off; off = align_up(off + (size_t)4 * parts * cl * 4);
+        }
+    } else {
+        if (pool_rows) { pl.gq = off; off = align_up(off + (size_t)(rows / pool_rows) * cl * 4); }
+        pl.ga = off; off = align_up(off + (size_t)rows * maxw * 4);
+        pl.gb = off; off = align_up(off + (size_t)rows * maxw * 4);
+        size_t p1 = 0, p2 = 0;
+        for (int l = 0; l < nlayers; ++l) {
+            const WgradShape w = wgrad_shape(rows, widths[l], widths[l + 1]);
+            if (w.partial_bytes > p1) p1 = w.partial_bytes;
+            if (w.partial2_bytes > p2) p2 = w.partial2_bytes;
+        }
+        pl.partial = off; off = align_up(off + p1);
+        pl.partial2 = off; off = align_up(off + p2);
+    }
+    pl.total = off;
+    return true;
+}
+
+static TlGather make_gather(const pn2_group_src *g)
+{
+    TlGather t;
+    t.n = g->n; t.m = g->m; t.nsample = g->nsample; t.cfeat = g->points ? g->cfeat : 0;
+    t.xyz_off = g->xyz_first ? 0 : t.cfeat;
+    t.feat_off = g->xyz_first ? 3 : 0;
+    t.xyz = g->xyz; t.new_xyz = g->new_xyz; t.points = g->points; t.idx = g->idx;
+    return t;
+}
+
+static int launch_pack(const float *w, long long sk, long long sn, const GemmShape &g, void *out, hipStream_t st)
+{
+    const long long total = (long long)g.slabs * g.tk * g.ns * 128;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    return launch(tl_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, sk, sn, g.K, g.N, g.tk, g.ns, g.slabs,
+                  reinterpret_cast<u32x4 *>(out));
+}
+
+template <int NS>
+static int launch_gemm_ns(int amode, const TlGemm &p, const GemmShape &g, dim3 grid, hipStream_t st)
+{
+#define PN2_TL_CASE(M)                                                                   \
+    case M: {                                                                            \
+        auto kern = tl_gemm_kernel<NS, M>;                                               \
+        if (int rc = allow_dynamic_lds(kern, g.lds)) return rc;                          \
+        return launch(kern, grid, dim3(kTlThreads), g.lds, st, p);                       \
+    }
+    switch (amode) {
+        PN2_TL_CASE(A_PLAIN)
+        PN2_TL_CASE(A_GATHER)
+        PN2_TL_CASE(A_RELU)
+        PN2_TL_CASE(A_DZ)
+        PN2_TL_CASE(A_DZ_POOL)
+    }
+#undef PN2_TL_CASE
+    return PN2_E_ARG;
+}
+
+static int launch_gemm(int amode, TlGemm &p, const GemmShape &g, hipStream_t st)
+{
+    p.K = g.K; p.N = g.N; p.tk = g.tk; p.resident = g.resident;
+    const long long rounds = (p.rows / 32 + kTlWaves - 1) / kTlWaves;
+    long long gx = 256 / g.slabs;                              // persistent: one 8-wave workgroup per CU over all slabs
+    if (gx < 1) gx = 1;
+    if (gx > rounds) gx = rounds;
+    const dim3 grid((unsigned)gx, (unsigned)g.slabs);
+    if (g.ns == 4) return launch_gemm_ns<4>(amode, p, g, grid, st);
+    if (g.ns == 2) return launch_gemm_ns<2>(amode, p, g, grid, st);
+    return launch_gemm_ns<1>(amode, p, g, grid, st);
+}
+
+static int launch_wgrad(TlWgrad &p, const WgradShape &w, float *partial2, const pn2_bn_layer &L, hipStream_t st)
+{
+    p.tslabs = w.tslabs;
+    const dim3 grid((unsigned)w.gridx, (unsigned)(w.uslabs * w.tslabs));
+    int rc = PN2_E_ARG;
+#define PN2_WG_CASE(U, T) if (w.TU == U && w.TT == T) rc = launch(tl_wgrad_kernel<U, T>, grid, dim3(kWgThreads), 0, st, p)
+    PN2_WG_CASE(1, 1); PN2_WG_CASE(1, 2); PN2_WG_CASE(1, 4); PN2_WG_CASE(2, 1); PN2_WG_CASE(2, 2); PN2_WG_CASE(2, 4);
+#undef PN2_WG_CASE
+    if (rc) return rc;
+    const float *src = p.partial;
+    long long nw = w.nw;
+    if (w.nchunks) {
+        const long long e4 = (long long)w.e / 4;
+        long long bx = (e4 + 255) / 256;
+        if (bx > 64) bx = 64;
+        rc = launch(tl_wgrad_reduce_a_kernel, dim3((unsigned)bx, (unsigned)w.nchunks, (unsigned)(w.uslabs * w.tslabs)), dim3(256), 0,
+                    st, reinterpret_cast<const float4 *>(p.partial), reinterpret_cast<float4 *>(partial2), w.nw, 32, w.nchunks, e4);
+        if (rc) return rc;
+        src = partial2;
+        nw = w.nchunks;
+    }
+    const long long total = (long long)p.KI * p.NO;
+    return launch(tl_wgrad_reduce_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, nw, w.TU, w.TT, w.tslabs,
+                  p.KI, p.NO, L.grad_weight, L.w_stride_k, L.w_stride_n);
+}
+
+static bool layers_ok(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group, int *widths)
+{
+    if (!layers || nlayers < 1 || nlayers > 8) return false;
+    for (int l = 0; l < nlayers; ++l) {
+        const pn2_bn_layer &L = layers[l];
+        if (L.cin <= 0 || L.cout <= 0 || L.cout % 4) return false;
+        if (l > 0 && L.cin != layers[l - 1].cout) return false;
+        if (!L.weight || !L.gamma || !L.beta || !L.z || !L.save) return false;
+        widths[l] = L.cin;
+        widths[l + 1] = L.cout;
+    }
+    if (group) {
+        if (group->b <= 0 || group->n <= 0 || group->m <= 0 || group->nsample <= 0 || !group->xyz) return false;
+        if ((long long)group->b * group->m * group->nsample != rows) return false;
+        if (layers[0].cin != 3 + (group->points ? group->cfeat : 0)) return false;
+        if (!group->idx && group->nsample != group->n) return false;
+    } else if (layers[0].cin % 4) {
+        return false;
+    }
+    return true;
+}
+
+}  // namespace pn2
+
+extern "C" long long pn2_mlp_train_ws_bytes(long long rows, int nlayers, const int *widths, int pool_rows, int backward)
+{
+    pn2::TlPlan pl;
+    if (!widths || !pn2::tl_plan(rows, nlayers, widths, pool_rows, backward, pl)) return -1;
+    return (long long)pl.total;
+}
+
+extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group,
+                                     const float *x, int pool_rows, float *out, int *argsel, float *zsel, void *ws, void *stream)
+{
+    using namespace pn2;
+    int widths[9];
+    if (!layers_ok(rows, nlayers, layers, group, widths)) return PN2_E_ARG;
+    if ((!group && !x) || !out || !ws || (pool_rows && (!argsel || !zsel))) return PN2_E_NULL;
+    if (pool_rows && (rows % pool_rows || (group && pool_rows != group->nsample))) return PN2_E_ARG;
+    TlPlan pl;
+    if (!tl_plan(rows, nlayers, widths, pool_rows, 0, pl)) return PN2_E_ARG;
+    hipStream_t st = as_stream(stream);
+    char *base = static_cast<char *>(ws);
+    // one clear for all layers' moment accumulators (they sit between the packed weights; clear each)
+    for (int l = 0; l < nlayers; ++l) {
+        const pn2_bn_layer &L = layers[l];
+        const GemmShape g = gemm_shape(L.cin, L.cout);
+        if (int rc = launch_pack(L.weight, L.w_stride_k, L.w_stride_n, g, base + pl.pack[l], st)) return rc;
+        if (hipError_t e = hipMemsetAsync(base + pl.stats[l], 0, sizeof(double) * 2 * L.cout, st)) return (int)e;
+    }
+    for (int l = 0; l < nlayers; ++l) {
+        const pn2_bn_layer &L = layers[l];
+        const GemmShape g = gemm_shape(L.cin, L.cout);
+        const bool last = l == nlayers - 1;
+        TlGemm p;
+        memset(&p, 0, sizeof(p));
+        p.rows = rows;
+        int amode;
+        if (l == 0 && group) { amode = A_GATHER; p.g = make_gather(group); }
+        else if (l == 0) { amode = A_PLAIN; p.A = x; }
+        else { amode = A_RELU; p.A = layers[l - 1].z; p.p0 = layers[l - 1].save + 2 * layers[l - 1].cout; p.p1 = layers[l - 1].save + 3 * layers[l - 1].cout; }
+        p.wpacked = reinterpret_cast<const u32x4 *>(base + pl.pack[l]);
+        p.bias = L.bias;
+        p.emode = (last && pool_rows) ? E_POOL : E_STORE;
+        p.out = L.z;
+        p.stats = reinterpret_cast<double *>(base + pl.stats[l]);
+        if (p.emode == E_POOL) {
+            const long long parts = rows / (pool_rows == 16 ? 16 : 32);
+            float *pp = reinterpret_cast<float *>(base + pl.pool);
+            p.pmax = pp; p.pmin = pp + parts * L.cout;
+            p.pamax = reinterpret_cast<int *>(pp + 2 * parts * L.cout);
+            p.pamin = reinterpret_cast<int *>(pp + 3 * parts * L.cout);
+            p.prow = pool_rows == 16 ? 16 : 32;
+        }
+        if (int rc = launch_gemm(amode, p, g, st)) return rc;
+        if (int rc = launch(tl_bn_finalize_kernel, dim3((unsigned)((L.cout + 127) / 128)), dim3(128), 0, st,
+                            reinterpret_cast<const double *>(base + pl.stats[l]), L.cout, (double)rows, L.gamma, L.beta,
+                            L.running_mean, L.running_var, L.momentum, L.eps, L.save)) return rc;
+        if (last && pool_rows) {
+            const long long groups = rows / pool_rows;
+            const int prow = pool_rows == 16 ? 16 : 32;
+            long long blocks = (groups * L.cout + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            if (int rc = launch(tl_pool_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, st, groups, L.cout, pool_rows / prow,
+                                prow, (const float *)p.pmax, (const float *)p.pmin, (const int *)p.pamax, (const int *)p.pamin,
+                                (const float *)L.save, out, argsel, zsel)) return rc;
+        } else if (last) {
+            const long long total4 = rows * L.cout / 4;
+            long long blocks = (total4 + 255) / 256;
+            if (blocks > 8192) blocks = 8192;
+            if (int rc = launch(tl_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, total4, L.cout, (const float *)L.z,
+                                (const float *)L.save, out)) return rc;
+        }
+    }
+    return PN2_OK;
+}
+
+extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group,
+                                      const float *x, int pool_rows, const float *out, const int *argsel, const float *zsel,
+                                      const float *grad_out, float *grad_x, float *grad_feat_rows, void *ws, void *stream)
+{
+    using namespace pn2;
+    int widths[9];
+    if (!layers_ok(rows, nlayers, layers, group, widths)) return PN2_E_ARG;
+    if ((!group && !x) || !out || !grad_out || !ws || (pool_rows && (!argsel || !zsel))) return PN2_E_NULL;
+    for (int l = 0; l < nlayers; ++l)
+        if (!layers[l].grad_weight || !layers[l].grad_gamma || !layers[l].grad_beta) return PN2_E_NULL;
+    TlPlan pl;
+    if (!tl_plan(rows, nlayers, widths, pool_rows, 1, pl)) return PN2_E_ARG;
+    hipStream_t st = as_stream(stream);
+    char *base = static_cast<char *>(ws);
+    const bool want_dx = group ? (grad_feat_rows && group->points && group->cfeat > 0) : grad_x != nullptr;
+    for (int l = 0; l < nlayers; ++l) {
+        const pn2_bn_layer &L = layers[l];
+        if (l > 0 || want_dx) {
+            const GemmShape g = gemm_shape(L.cout, L.cin);                // dy_{l-1} = dz_l . W_l^T
+            if (int rc = launch_pack(L.weight, L.w_stride_n, L.w_stride_k, g, base + pl.pack[l], st)) return rc;
+        }
+        if (hipError_t e = hipMemsetAsync(base + pl.stats[l], 0, sizeof(double) * 2 * L.cout, st)) return (int)e;
+    }
+    float *ga = reinterpret_cast<float *>(base + pl.ga), *gb = reinterpret_cast<float *>(base + pl.gb);
+    float *gq = reinterpret_cast<float *>(base + pl.gq);
+    const pn2_bn_layer &T = layers[nlayers - 1];
+    // top of the stack: dy_L and its two column sums
+    if (pool_rows) {
+        const long long groups = rows / pool_rows;
+        long long gy = (groups + 63) / 64;
+        if (gy > 256) gy = 256;
+        if (int rc = launch(tl_pool_grad_kernel, dim3((unsigned)((T.cout + 63) / 64), (unsigned)gy), dim3(256), 0, st, groups, T.cout, out,
+                            grad_out, zsel, gq, reinterpret_cast<double *>(base + pl.stats[nlayers - 1]))) return rc;
+    } else {
+        long long gy = (rows + 255) / 256;
+        if (gy > 512) gy = 512;
+        if (int rc = launch(tl_top_grad_kernel, dim3((unsigned)((T.cout + 63) / 64), (unsigned)gy), dim3(256), 0, st, rows, T.cout, out,
+                            grad_out, (const float *)T.z, ga, reinterpret_cast<double *>(base + pl.stats[nlayers - 1]))) return rc;
+    }
+    float *gcur = ga, *gnext = gb;                      // dy of the current layer (dense case) / of the layer below
+    for (int l = nlayers - 1; l >= 0; --l) {
+        const pn2_bn_layer &L = layers[l];
+        float *coef = reinterpret_cast<float *>(base + pl.coef[l]);
+        if (int rc = launch(tl_bn_backward_finalize_kernel, dim3((unsigned)((L.cout + 127) / 128)), dim3(128), 0, st,
+                            reinterpret_cast<const double *>(base + pl.stats[l]), L.cout, (double)rows, L.gamma,
+                            (const float *)L.save, L.grad_gamma, L.grad_beta, coef)) return rc;
+        const bool pooled_top = pool_rows && l == nlayers - 1;
+        // weight gradient
+        {
+            TlWgrad w;
+            memset(&w, 0, sizeof(w));
+            w.rows = rows;
+            w.KI = L.cin;
+            if (l == 0 && group) { w.amode = A_GATHER; w.g = make_gather(group); }
+            else if (l == 0) { w.amode = A_PLAIN; w.A = x; }
+            else { w.amode = A_RELU; w.A = layers[l - 1].z; w.pa = layers[l - 1].save + 2 * layers[l - 1].cout; w.pc = layers[l - 1].save + 3 * layers[l - 1].cout; }
+            w.dmode = pooled_top ? A_DZ_POOL : A_DZ;
+            w.NO = L.cout;
+            w.Z = L.z;
+            w.G = pooled_top ? gq : gcur;
+            w.argsel = argsel;
+            w.coef = coef;
+            w.group_rows = pool_rows;
+            w.partial = reinterpret_cast<float *>(base + pl.partial);
+            const WgradShape ws_ = wgrad_shape(rows, L.cin, L.cout);
+            if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, st)) return rc;
+        }
+        // data gradient
+        if (l > 0 || want_dx) {
+            const GemmShape g = gemm_shape(L.cout, L.cin);
+            TlGemm p;
+            memset(&p, 0, sizeof(p));
+            p.rows = rows;
+            p.A = L.z;
+            p.G = pooled_top ? gq : gcur;
+            p.argsel = argsel;
+            p.p0 = coef; p.p1 = coef + L.cout; p.p2 = coef + 2 * L.cout;
+            p.group_rows = pool_rows;
+            p.wpacked = reinterpret_cast<const u32x4 *>(base + pl.pack[l]);
+            if (l > 0) {
+                const pn2_bn_layer &D = layers[l - 1];
+                p.emode = E_MASK;
+                p.out = gnext;
+                p.zprev = D.z;
+                p.ea = D.save + 2 * D.cout;
+                p.ec = D.save + 3 * D.cout;
+                p.stats = reinterpret_cast<double *>(base + pl.stats[l - 1]);
+            } else {
+                p.emode = E_PLAIN;
+                if (group) {
+                    const TlGather gt = make_gather(group);
+                    p.out = grad_feat_rows; p.out_pitch = gt.cfeat; p.col0 = gt.feat_off; p.col1 = gt.feat_off + gt.cfeat;
+                } else {
+                    p.out = grad_x; p.out_pitch = L.cin; p.col0 = 0; p.col1 = L.cin;
+                }
+            }
+            if (int rc = launch_gemm(pooled_top ? A_DZ_POOL : A_DZ, p, g, st)) return rc;
+        }
+        float *tmp = gcur; gcur = gnext; gnext = tmp;
+    }
+    return PN2_OK;
+}

@@ -1,0 +1,258 @@
+"""Training mode of the shared MLPs (conv 1x1 + batch norm with BATCH statistics + ReLU stacks, SA levels with
+their max-pool) on the matrix cores: forward and backward, one C call per direction.
+
+Reference: utils/pointnet_util.py:113-127 (SA), :222-226 (FP), tf_util.py:512-531 (batch moments, moving
+averages), train.py:96-104 (bn_decay schedule), train.py:188 (is_training = True). Kernels and the pass structure:
+csrc/train_mlp.hip, include/pn2ops.h (pn2_mlp_train_forward / _backward); SURVEY.md section 8 row f2.
+
+What autograd sees is ONE node per level: inputs = the grouped features (or the plain rows of an FP level) and
+the level's parameters; saved for backward = the pre-norm tensors z_l (rows, C_l) and a few per-channel vectors.
+The grouped (b, m, nsample, C) tensors, the normalised / rectified activations and the ReLU masks never exist.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _C
+from ._tensors import (f32, i32, is_deterministic, on_device, ptr, require, same_device, seg_workspace, stream_ptr,
+                       use_segmented_grad)
+
+_vp, _i, _ll, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
+
+
+class GroupSrc(ctypes.Structure):          # pn2_group_src
+    _fields_ = [("b", _i), ("n", _i), ("m", _i), ("nsample", _i), ("cfeat", _i), ("xyz_first", _i),
+                ("xyz", _vp), ("new_xyz", _vp), ("points", _vp), ("idx", _vp)]
+
+
+class BnLayer(ctypes.Structure):           # pn2_bn_layer
+    _fields_ = [("cin", _i), ("cout", _i), ("weight", _vp), ("w_stride_k", _ll), ("w_stride_n", _ll), ("bias", _vp),
+                ("gamma", _vp), ("beta", _vp), ("running_mean", _vp), ("running_var", _vp), ("momentum", _f), ("eps", _f),
+                ("z", _vp), ("save", _vp), ("grad_weight", _vp), ("grad_gamma", _vp), ("grad_beta", _vp)]
+
+
+def conv_bn_pairs(net):
+    """[(conv, bn)] of an nn.Sequential of Conv (1x1) + BatchNorm + ReLU triples, or None if it is anything else."""
+    mods, out = list(net), []
+    if not mods or len(mods) % 3:
+        return None
+    for i in range(0, len(mods), 3):
+        conv, bn, relu = mods[i], mods[i + 1], mods[i + 2]
+        if not isinstance(conv, (nn.Conv2d, nn.Conv1d)) or not isinstance(bn, (nn.BatchNorm2d, nn.BatchNorm1d)) or \
+                not isinstance(relu, nn.ReLU):
+            return None
+        if any(k != 1 for k in conv.kernel_size) or conv.groups != 1:
+            return None
+        out.append((conv, bn))
+    return out
+
+
+def stack_supported(net, rows, pool_rows=0, grouped=True):
+    """Can pn2_mlp_train_forward run this stack on `rows` rows? (host-side check)"""
+    pairs = conv_bn_pairs(net)
+    if not pairs or len(pairs) > 8 or rows <= 0 or rows % 32:
+        return False
+    if pool_rows and pool_rows != 16 and pool_rows % 32:
+        return False
+    for conv, bn in pairs:
+        if conv.out_channels % 4 or bn.momentum is None or not bn.affine:
+            return False
+    if not grouped and pairs[0][0].in_channels % 4:
+        return False
+    return True
+
+
+class _Level:
+    """Non-tensor description of one call (what the autograd node needs besides its differentiable inputs)."""
+    __slots__ = ("pairs", "rows", "pool_rows", "xyz", "new_xyz", "idx", "b", "n", "m", "nsample", "xyz_first", "grouped")
+
+
+def _layer_array(level, weights, biases, gammas, betas, zs, saves, grads=None, update_running=True):
+    n = len(level.pairs)
+    arr = (BnLayer * n)()
+    for l, (conv, bn) in enumerate(level.pairs):
+        L = arr[l]
+        L.cin, L.cout = conv.in_channels, conv.out_channels
+        L.weight = ptr(weights[l])
+        L.w_stride_k, L.w_stride_n = 1, conv.in_channels          # conv kernel (cout, cin, 1[, 1]): W[k][n] = weight[n][k]
+        L.bias = ptr(biases[l])
+        L.gamma, L.beta = ptr(gammas[l]), ptr(betas[l])
+        track = update_running and bn.track_running_stats and bn.running_mean is not None
+        L.running_mean = ptr(bn.running_mean) if track else None
+        L.running_var = ptr(bn.running_var) if track else None
+        L.momentum, L.eps = float(bn.momentum), float(bn.eps)
+        L.z, L.save = ptr(zs[l]), ptr(saves[l])
+        if grads is not None:
+            L.grad_weight, L.grad_gamma, L.grad_beta = ptr(grads[l][0]), ptr(grads[l][1]), ptr(grads[l][2])
+    return arr
+
+
+def _group_struct(level, points):
+    g = GroupSrc()
+    g.b, g.n, g.m, g.nsample = level.b, level.n, level.m, level.nsample
+    g.cfeat = points.shape[2] if points is not None else 0
+    g.xyz_first = 1 if level.xyz_first else 0
+    g.xyz, g.new_xyz, g.points, g.idx = ptr(level.xyz), ptr(level.new_xyz), ptr(points), ptr(level.idx)
+    return g
+
+
+def _ws(rows, widths, pool_rows, backward, dev):
+    arr = (ctypes.c_int * len(widths))(*widths)
+    nbytes = _C.lib().pn2_mlp_train_ws_bytes(rows, len(widths) - 1, arr, pool_rows, backward)
+    require(nbytes >= 0, "pn2_mlp_train: unsupported stack (rows %% 32, widths %% 4, pool group 16 or a multiple of 32)")
+    return torch.empty(((nbytes + 7) // 8,), dtype=torch.int64, device=dev)
+
+
+class _TrainMLP(torch.autograd.Function):
+    """inputs: level, x (points (b,n,c) when grouped -- may be None -- else the (rows, cin) input), then per layer
+    conv.weight, conv.bias (or None), bn.weight, bn.bias."""
+
+    @staticmethod
+    def forward(ctx, level, x, *params):
+        n = len(level.pairs)
+        weights = [f32(params[4 * l], "weight") for l in range(n)]
+        biases = [params[4 * l + 1] for l in range(n)]
+        gammas, betas = [params[4 * l + 2] for l in range(n)], [params[4 * l + 3] for l in range(n)]
+        dev = weights[0].device
+        rows = level.rows
+        widths = [level.pairs[0][0].in_channels] + [c.out_channels for c, _ in level.pairs]
+        zs = [torch.empty((rows, w), dtype=torch.float32, device=dev) for w in widths[1:]]
+        saves = [torch.empty((4, w), dtype=torch.float32, device=dev) for w in widths[1:]]
+        cl = widths[-1]
+        if level.pool_rows:
+            groups = rows // level.pool_rows
+            out = torch.empty((groups, cl), dtype=torch.float32, device=dev)
+            argsel = torch.empty((groups, cl), dtype=torch.int32, device=dev)
+            zsel = torch.empty((groups, cl), dtype=torch.float32, device=dev)
+        else:
+            out = torch.empty((rows, cl), dtype=torch.float32, device=dev)
+            argsel = zsel = None
+        ws = _ws(rows, widths, level.pool_rows, 0, dev)
+        arr = _layer_array(level, weights, biases, gammas, betas, zs, saves)
+        grp = _group_struct(level, x) if level.grouped else None
+        with on_device(dev):
+            _C.check(_C.lib().pn2_mlp_train_forward(rows, n, arr, ctypes.byref(grp) if grp is not None else None,
+                                                    None if level.grouped else ptr(x), level.pool_rows, ptr(out), ptr(argsel),
+                                                    ptr(zsel), ptr(ws), stream_ptr(dev)), "mlp_train_forward")
+        for _, bn in level.pairs:
+            if bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+        ctx.level, ctx.widths = level, widths
+        ctx.has_x = x is not None
+        ctx.nbias = [b is not None for b in biases]
+        saved = [t for t in [x] if t is not None] + weights + [b for b in biases if b is not None] + gammas + betas + zs + saves + [out]
+        if level.pool_rows:
+            saved += [argsel, zsel]
+            ctx.mark_non_differentiable(argsel)
+        ctx.save_for_backward(*saved)
+        if level.pool_rows:
+            return out, argsel
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out, *unused):
+        level, widths = ctx.level, ctx.widths
+        n = len(level.pairs)
+        sv = list(ctx.saved_tensors)
+        x = sv.pop(0) if ctx.has_x else None
+        weights = [sv.pop(0) for _ in range(n)]
+        biases = [sv.pop(0) if has else None for has in ctx.nbias]
+        gammas = [sv.pop(0) for _ in range(n)]
+        betas = [sv.pop(0) for _ in range(n)]
+        zs = [sv.pop(0) for _ in range(n)]
+        saves = [sv.pop(0) for _ in range(n)]
+        out = sv.pop(0)
+        argsel, zsel = (sv.pop(0), sv.pop(0)) if level.pool_rows else (None, None)
+        dev = out.device
+        rows = level.rows
+        grad_out = f32(grad_out, "grad_out")
+        grads = [(torch.empty_like(weights[l]), torch.empty_like(gammas[l]), torch.empty_like(betas[l])) for l in range(n)]
+        need_x = ctx.needs_input_grad[1] and x is not None
+        grad_x = grad_rows = None
+        if need_x and level.grouped:
+            grad_rows = torch.empty((rows, x.shape[2]), dtype=torch.float32, device=dev)
+        elif need_x:
+            grad_x = torch.empty((rows, widths[0]), dtype=torch.float32, device=dev)
+        ws = _ws(rows, widths, level.pool_rows, 1, dev)
+        arr = _layer_array(level, weights, biases, gammas, betas, zs, saves, grads, update_running=False)
+        grp = _group_struct(level, x) if level.grouped else None
+        with on_device(dev):
+            _C.check(_C.lib().pn2_mlp_train_backward(rows, n, arr, ctypes.byref(grp) if grp is not None else None,
+                                                     None if level.grouped else ptr(x), level.pool_rows, ptr(out), ptr(argsel),
+                                                     ptr(zsel), ptr(grad_out), ptr(grad_x), ptr(grad_rows), ptr(ws),
+                                                     stream_ptr(dev)), "mlp_train_backward")
+            if grad_rows is not None:
+                # the grouped feature rows' gradient back onto the points: the segmented scatter of group_point's backward
+                b, npts, c = x.shape
+                m, ns = level.m, level.nsample
+                grad_x = torch.empty((b, npts, c), dtype=torch.float32, device=dev)
+                if level.idx is None:                      # group_all: row k of cloud i IS point k
+                    grad_x = grad_rows.view(b, npts, c)
+                elif use_segmented_grad(b, npts, c):
+                    sws = seg_workspace(_C.lib(), b, npts, m * ns, dev)
+                    _C.check(_C.lib().pn2_group_point_grad_seg(b, npts, c, m, ns, ptr(grad_rows), ptr(level.idx), ptr(grad_x),
+                                                               ptr(sws), 1 if is_deterministic() else 0, stream_ptr(dev)),
+                             "group_point_grad")
+                else:
+                    _C.check(_C.lib().pn2_group_point_grad(b, npts, c, m, ns, ptr(grad_rows), ptr(level.idx), ptr(grad_x),
+                                                           stream_ptr(dev)), "group_point_grad")
+        result = [None, grad_x if need_x else None]
+        for l in range(n):
+            gb = torch.zeros_like(biases[l]) if biases[l] is not None else None     # exactly zero under batch norm
+            result += [grads[l][0], gb, grads[l][1], grads[l][2]]
+        return tuple(result)
+
+
+def _params(pairs):
+    out = []
+    for conv, bn in pairs:
+        out += [conv.weight, conv.bias, bn.weight, bn.bias]
+    return out
+
+
+def sa_mlp_train(net, xyz, new_xyz, points, idx, xyz_first=True):
+    """Training-mode shared MLP + max-pool of one SA level / one MSG scale.
+    net: nn.Sequential of (Conv2d 1x1, BatchNorm2d, ReLU) triples; xyz (b,n,3); new_xyz (b,m,3) or None and idx
+    (b,m,nsample) i32 or None (both None: the group_all level); points (b,n,c) or None.
+    -> (b, m, cout) pooled features (differentiable w.r.t. points and the parameters), argsel (b, m, cout) i32."""
+    pairs = conv_bn_pairs(net)
+    require(pairs is not None, "sa_mlp_train expects Conv 1x1 + BatchNorm + ReLU triples")
+    xyz = f32(xyz, "xyz")
+    b, n, _ = xyz.shape
+    lv = _Level()
+    lv.pairs, lv.grouped, lv.xyz_first = pairs, True, bool(xyz_first)
+    lv.xyz = xyz
+    if idx is None:
+        require(new_xyz is None, "group_all takes neither idx nor new_xyz")
+        lv.new_xyz, lv.idx, lv.m, lv.nsample = None, None, 1, n
+    else:
+        lv.new_xyz, lv.idx = f32(new_xyz, "new_xyz"), i32(idx, "idx")
+        lv.m, lv.nsample = idx.shape[1], idx.shape[2]
+    lv.b, lv.n = b, n
+    lv.rows = b * lv.m * lv.nsample
+    lv.pool_rows = lv.nsample
+    if points is not None:
+        points = f32(points, "points")
+    cin = 3 + (points.shape[2] if points is not None else 0)
+    require(pairs[0][0].in_channels == cin, "the first layer expects %d channels, got %d" % (pairs[0][0].in_channels, cin))
+    require(stack_supported(net, lv.rows, lv.pool_rows, True), "unsupported stack for the fused training path")
+    same_device(xyz, pairs[0][0].weight)
+    out, argsel = _TrainMLP.apply(lv, points, *_params(pairs))
+    return out.view(b, lv.m, -1), argsel.view(b, lv.m, -1)
+
+
+def fp_mlp_train(net, x):
+    """Training-mode shared MLP of one FP level on plain rows: x (b, n, cin) -> (b, n, cout)."""
+    pairs = conv_bn_pairs(net)
+    require(pairs is not None, "fp_mlp_train expects Conv 1x1 + BatchNorm + ReLU triples")
+    x = f32(x, "x")
+    b, n, c = x.shape
+    lv = _Level()
+    lv.pairs, lv.grouped, lv.xyz_first = pairs, False, True
+    lv.xyz = lv.new_xyz = lv.idx = None
+    lv.b, lv.n, lv.m, lv.nsample = b, n, 0, 0
+    lv.rows, lv.pool_rows = b * n, 0
+    require(stack_supported(net, lv.rows, 0, False), "unsupported stack for the fused training path")
+    out = _TrainMLP.apply(lv, x.reshape(b * n, c), *_params(pairs))
+    return out.view(b, n, -1)
