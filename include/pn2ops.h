@@ -338,6 +338,12 @@ int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_layer *laye
                            const float *x, int pool_rows, const float *out, const int *argsel, const float *zsel,
                            const float *grad_out, float *grad_x, float *grad_feat_rows, void *ws, void *stream);
 
+/* diagnostics: byte offsets inside the BACKWARD workspace of the two dy buffers ((rows, max width) each; after a
+ * backward of L layers they hold dy_{L-1}, dy_{L-2}, ... alternately, starting with gb when pooled) and of the
+ * per-layer (2, cout) fp64 sums / (3, cout) fp32 coefficients */
+int pn2_mlp_train_ws_layout(long long rows, int nlayers, const int *widths, int pool_rows, long long *ga, long long *gb,
+                            long long *stats, long long *coef);
+
 /* ---- host helpers ------------------------------------------------------- */
 
 /* The exact fp32 threshold s* with  max(sqrtf(s),1e-20f) < radius  <=>  s < s*

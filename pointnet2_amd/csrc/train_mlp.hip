@@ -30,6 +30,7 @@
 // depend on timing.
 #include "sa_mlp_common.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace pn2 {
@@ -697,7 +698,17 @@ __global__ __launch_bounds__(256) void tl_wgrad_reduce_b_kernel(const float *__r
 // ---- host side -------------------------------------------------------------------------------------------------------------
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline int tiles(int c) { return (c + 31) / 32; }
-static inline int pick_ns(int tn) { return tn >= 3 ? 4 : tn == 2 ? 2 : 1; }
+static inline int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+static inline int pick_ns(int tn)
+{
+    const int cap = env_int("PN2_TL_MAX_NS", 4);          // lab switch (scripts/train_mlp_check.py); results never depend on it
+    const int ns = tn >= 3 ? 4 : tn == 2 ? 2 : 1;
+    return ns > cap ? cap : ns;
+}
 
 struct GemmShape { int K, N, tk, tn, ns, slabs, resident; size_t lds, pack_bytes; };
 
@@ -709,7 +720,7 @@ static GemmShape gemm_shape(int K, int N)
     g.ns = pick_ns(g.tn);
     g.slabs = (g.tn + g.ns - 1) / g.ns;
     const size_t params = (size_t)3 * g.tk * 32 * sizeof(float), stage = (size_t)g.ns * kPairWords * 4;
-    g.resident = params + stage * g.tk <= (size_t)144 * 1024;
+    g.resident = params + stage * g.tk <= (size_t)144 * 1024 && !env_int("PN2_TL_FORCE_STREAM", 0);
     g.lds = params + stage * (g.resident ? g.tk : 2);
     g.pack_bytes = (size_t)g.slabs * g.tk * g.ns * kPairWords * 4;
     return g;
@@ -896,6 +907,21 @@ extern "C" long long pn2_mlp_train_ws_bytes(long long rows, int nlayers, const i
     pn2::TlPlan pl;
     if (!widths || !pn2::tl_plan(rows, nlayers, widths, pool_rows, backward, pl)) return -1;
     return (long long)pl.total;
+}
+
+// byte offsets of the backward workspace's dy ping-pong buffers and per-layer sums (diagnostics: scripts/train_mlp_check.py)
+extern "C" int pn2_mlp_train_ws_layout(long long rows, int nlayers, const int *widths, int pool_rows, long long *ga, long long *gb,
+                                       long long *stats, long long *coef)
+{
+    pn2::TlPlan pl;
+    if (!widths || !pn2::tl_plan(rows, nlayers, widths, pool_rows, 1, pl)) return PN2_E_ARG;
+    if (ga) *ga = (long long)pl.ga;
+    if (gb) *gb = (long long)pl.gb;
+    for (int l = 0; l < nlayers; ++l) {
+        if (stats) stats[l] = (long long)pl.stats[l];
+        if (coef) coef[l] = (long long)pl.coef[l];
+    }
+    return PN2_OK;
 }
 
 extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group,

@@ -20,6 +20,7 @@ from .tf_grouping import (query_ball_point, group_point, knn_point, query_ball_g
                           query_ball_group_xyz_msg, sample_and_group_xyz)
 from .tf_interpolate import three_nn, three_interpolate
 from . import sa_mlp
+from . import train_mlp
 
 
 def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True, fused=None):
@@ -152,6 +153,18 @@ class PointnetSAModule(nn.Module):
             return sa_mlp.supported(cin, self.mlp.widths, xyz.shape[1]) and sa_mlp.kind(cin, self.mlp.widths, xyz.shape[1]) == "cooperative"
         return sa_mlp.supported(cin, self.mlp.widths, self.nsample)
 
+    def _train_fused_ok(self, xyz, points):
+        """Training (batch-statistics batch norm, autograd) with max pooling on a stack pn2_mlp_train_forward covers:
+        conv 1x1 + BN + ReLU triples, rows a multiple of 32, nsample 16 or a multiple of 32 (train_mlp.py)."""
+        if not self.fused_mlp or not self.training or self.pooling != "max" or self.mlp2 is not None or not xyz.is_cuda:
+            return False
+        if (torch.is_grad_enabled() and xyz.requires_grad) or (points is not None and not self.use_xyz):
+            return False
+        b, n, _ = xyz.shape
+        ns = n if self.group_all else self.nsample
+        rows = b * (1 if self.group_all else self.npoint) * ns
+        return train_mlp.stack_supported(self.mlp.net, rows, ns, True)
+
     def _packed(self, device, nsample=None):
         """Folded + packed weights, rebuilt when a parameter or a running statistic changed."""
         stamp = tuple((t.data_ptr(), t._version) for t in list(self.mlp.parameters()) + list(self.mlp.buffers()))
@@ -170,6 +183,23 @@ class PointnetSAModule(nn.Module):
         return self
 
     def forward(self, xyz, points):
+        if self._train_fused_ok(xyz, points):
+            # training: the level's geometry in the fused launches, then ONE autograd node for gather + layer stack
+            # (batch-statistics batch norm) + max-pool, forward and backward on the matrix cores (train_mlp.py)
+            self.last_path = "fused_train"
+            if self.group_all:
+                b, n, _ = xyz.shape
+                new_xyz = torch.zeros((b, 1, 3), dtype=torch.float32, device=xyz.device)
+                idx = torch.arange(n, dtype=torch.int32, device=xyz.device).reshape(1, 1, n).repeat(b, 1, 1)
+                out, _ = train_mlp.sa_mlp_train(self.mlp.net, xyz, None, points, None, True)
+                return new_xyz, out, idx
+            if self.knn:
+                _, new_xyz = farthest_point_sample_gather(self.npoint, xyz)
+                _, idx = knn_point(self.nsample, xyz, new_xyz)
+            else:
+                _, new_xyz, idx, _, _ = sample_and_group_xyz(self.npoint, self.radius, self.nsample, xyz, True)
+            out, _ = train_mlp.sa_mlp_train(self.mlp.net, xyz, new_xyz, points, idx, True)
+            return new_xyz, out, idx
         if self.group_all and self._fused_ok(xyz, points):
             # sample_and_group_all (:59-84) + the layer stack + reduce_max in ONE kernel: new_xyz = origin, the
             # group is the whole cloud, channels [xyz, features]
@@ -269,10 +299,26 @@ class PointnetSAModuleMSG(nn.Module):
                 for si, (idx, _) in enumerate(scales)]
         return new_xyz, torch.cat(outs, dim=2)
 
+    def _train_fused_ok(self, xyz, points):
+        if not self.fused_mlp or not self.training or not xyz.is_cuda or (torch.is_grad_enabled() and xyz.requires_grad):
+            return False
+        if points is not None and not self.use_xyz:
+            return False
+        rows = xyz.shape[0] * self.npoint
+        return all(train_mlp.stack_supported(mlp.net, rows * ns, ns, True) for mlp, ns in zip(self.mlps, self.nsample_list))
+
     def forward(self, xyz, points):
         if self._fused_ok(xyz, points):
             self.last_path = "fused"
             return self._forward_fused(xyz, points)
+        if self._train_fused_ok(xyz, points):
+            # training: grouping launches as in inference, then one autograd node per scale (train_mlp.py);
+            # channel order features FIRST (:184)
+            self.last_path = "fused_train"
+            new_xyz, scales = self._group_scales(xyz, True)
+            outs = [train_mlp.sa_mlp_train(mlp.net, xyz, new_xyz, points, idx, False)[0]
+                    for mlp, (idx, _) in zip(self.mlps, scales)]
+            return new_xyz, torch.cat(outs, dim=2)
         self.last_path = "unfused"
         fused = not (torch.is_grad_enabled() and xyz.requires_grad)
         scales = None
@@ -338,9 +384,14 @@ class PointnetFPModule(nn.Module):
             dist, idx = three_nn(xyz1, xyz2)                                    # :211
             c1 = points1.shape[2] if points1 is not None else 0
             return sa_mlp.fp_mlp(points2, points1, idx, dist, self._packed(points2.shape[2], c1, kind, points2.device))
-        self.last_path = "unfused"
         idx, weight = three_nn_weights(xyz1, xyz2)                              # :211-215
         interpolated = three_interpolate(points2, idx, weight)                  # :216
         x = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated   # :219
+        if self.fused_mlp and self.training and x.is_cuda and \
+                train_mlp.stack_supported(self.mlp.net, x.shape[0] * x.shape[1], 0, False):
+            # training: the layer stack with batch-statistics batch norm as one autograd node (train_mlp.py)
+            self.last_path = "fused_train"
+            return train_mlp.fp_mlp_train(self.mlp.net, x)
+        self.last_path = "unfused"
         x = self.mlp(x.permute(0, 2, 1).unsqueeze(2))                           # (b, C, 1, n)
         return x.squeeze(2).permute(0, 2, 1).contiguous()

@@ -45,6 +45,39 @@ def max_over_ranks(seconds, device=None):
     return float(t.item())
 
 
+class GradBucket:
+    """ONE persistent flat fp32 buffer that every parameter's .grad is a view of: autograd accumulates straight into
+    it, the gradient mean over ranks is a single in-place all-reduce of the buffer (RCCL over xGMI; nothing is
+    concatenated or copied back per step), and the optimiser reads the views. Replaces average_gradients
+    (train_multi_gpu.py:91-126, used :210). Call zero_() instead of optimizer.zero_grad(set_to_none=True)."""
+
+    def __init__(self, parameters):
+        self.params = [p for p in parameters if p.requires_grad]
+        if not self.params:
+            raise ValueError("GradBucket: no parameters")
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise ValueError("GradBucket: fp32 parameters on one device expected")
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero_(self):
+        self.flat.zero_()
+
+    def allreduce_mean_(self):
+        """In-place mean over ranks; a no-op without a process group. (With a group of ONE rank the collective still
+        runs -- it is how a single-GPU box exercises the RCCL path.)"""
+        if not dist.is_initialized():
+            return self.flat
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.flat.mul_(1.0 / dist.get_world_size())
+        return self.flat
+
+
 def allreduce_mean_(tensors):
     """In-place mean over ranks of a list of gradient tensors through one flat fp32 bucket
     (replaces average_gradients, train_multi_gpu.py:91-126)."""

@@ -104,6 +104,9 @@ def _ws(rows, widths, pool_rows, backward, dev):
     return torch.empty(((nbytes + 7) // 8,), dtype=torch.int64, device=dev)
 
 
+_KEEP_WS = [False, None]          # diagnostics (scripts/train_mlp_check.py): keep the last backward's workspace
+
+
 class _TrainMLP(torch.autograd.Function):
     """inputs: level, x (points (b,n,c) when grouped -- may be None -- else the (rows, cin) input), then per layer
     conv.weight, conv.bias (or None), bn.weight, bn.bias."""
@@ -175,6 +178,8 @@ class _TrainMLP(torch.autograd.Function):
         elif need_x:
             grad_x = torch.empty((rows, widths[0]), dtype=torch.float32, device=dev)
         ws = _ws(rows, widths, level.pool_rows, 1, dev)
+        if _KEEP_WS[0]:
+            _KEEP_WS[1] = (ws, rows, widths, level.pool_rows)
         arr = _layer_array(level, weights, biases, gammas, betas, zs, saves, grads, update_running=False)
         grp = _group_struct(level, x) if level.grouped else None
         with on_device(dev):

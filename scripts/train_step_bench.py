@@ -1,0 +1,142 @@
+"""Train-step harness for the reference network topologies on pointnet2_amd's modules (thin L4 harness; the models,
+optimiser and loss are torch -- outside the hot path's scope): forward + loss + backward +
+gradient mean over ranks (sharding.GradBucket: one persistent flat bucket, RCCL when a process group exists;
+reference train_multi_gpu.py:91-126, :185-211) + optimiser step, with HIP-event time per phase, for the fused training
+path (csrc/train_mlp.hip) and the layer-by-layer torch path.
+
+  python scripts/train_step_bench.py [model substring] [--steps K]
+  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 scripts/train_step_bench.py sem_seg
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from model_forward_bench import ClsMSG, ClsSSG, PartSeg, SemSeg, set_fused
+from pointnet2_amd import sharding
+from pointnet2_amd import synthetic as S
+
+
+def bn_momentum(step, batch, init=0.5, decay_step=200000.0, decay_rate=0.5, clip=0.99):
+    """torch momentum = 1 - bn_decay of the reference's schedule (train.py:96-104, get_bn_decay)."""
+    bn_mom = init * decay_rate ** ((step * batch) // decay_step)
+    return 1.0 - min(clip, 1.0 - bn_mom)
+
+
+def set_bn_momentum(model, momentum):
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+            mod.momentum = momentum
+
+
+MODELS = [("pointnet2_cls_ssg B=32 N=1024 (config 2)", ClsSSG, 32, 1024, False, "cls"),
+          ("pointnet2_cls_msg B=32 N=4096 xyz+normals (config 3)", ClsMSG, 32, 4096, True, "cls"),
+          ("pointnet2_part_seg B=16 N=2048 (config 4)", PartSeg, 16, 2048, True, "seg"),
+          ("pointnet2_sem_seg B=8 N=8192 per GPU (config 5)", SemSeg, 8, 8192, False, "seg")]
+
+
+def make_input(b, n, normals, dev, seed):
+    cloud = S.sphere_clouds(b, n, seed)
+    if normals:
+        nrm = cloud / np.maximum(np.linalg.norm(cloud, axis=2, keepdims=True), 1e-9)
+        cloud = np.concatenate([cloud, nrm.astype(np.float32)], axis=2)
+    return torch.from_numpy(cloud).to(dev)
+
+
+def run_steps(model, opt, bucket, x, labels, kind, steps, warm, batch):
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(steps)]
+    loss = None
+    for it in range(warm + steps):
+        set_bn_momentum(model, bn_momentum(it, batch))
+        rec = ev[it - warm] if it >= warm else None
+        if rec:
+            rec[0].record()
+        bucket.zero_()
+        out = model(x)
+        loss = F.cross_entropy(out, labels) if kind == "cls" else F.cross_entropy(out, labels)
+        if rec:
+            rec[1].record()
+        loss.backward()
+        if rec:
+            rec[2].record()
+        bucket.allreduce_mean_()
+        if rec:
+            rec[3].record()
+        opt.step()
+        if rec:
+            rec[4].record()
+    torch.cuda.synchronize()
+    ph = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(4)] for e in ev])
+    return ph.mean(axis=0), float(loss)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", nargs="?", default="")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--fused-only", action="store_true")
+    args = ap.parse_args()
+    distributed = "RANK" in os.environ
+    rank, world = 0, 1
+    if distributed:
+        local = int(os.environ.get("LOCAL_RANK", 0))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    results = []
+    for name, ctor, b, n, normals, kind in MODELS:
+        if args.which not in name:
+            continue
+        row = {"model": name, "world": world}
+        x = make_input(b, n, normals, dev, 1 + rank)
+        torch.manual_seed(0)
+        proto = ctor().to(dev)
+        state = {k: v.clone() for k, v in proto.state_dict().items()}
+        g = torch.Generator(device="cpu").manual_seed(5 + rank)
+        labels = (torch.randint(0, 40, (b,), generator=g) if kind == "cls" else torch.randint(0, 21, (b, n), generator=g)).to(dev)
+        grads = {}
+        for fused in ([True] if args.fused_only else [False, True]):
+            model = ctor().to(dev)
+            model.load_state_dict(state)
+            model.train()
+            set_fused(model, fused)
+            bucket = sharding.GradBucket(model.parameters())
+            opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9)
+            # one step for the gradient comparison (same weights, same batch)
+            bucket.zero_()
+            set_bn_momentum(model, bn_momentum(0, b * world))
+            loss0 = F.cross_entropy(model(x), labels)
+            loss0.backward()
+            grads[fused] = (float(loss0), bucket.flat.clone())
+            paths = [m.last_path for m in model.modules() if hasattr(m, "last_path")]
+            ph, loss = run_steps(model, opt, bucket, x, labels, kind, args.steps, args.warmup, b * world)
+            key = "fused" if fused else "layer_by_layer"
+            row[key] = {"forward_ms": round(float(ph[0]), 3), "backward_ms": round(float(ph[1]), 3),
+                        "allreduce_ms": round(float(ph[2]), 3), "optimizer_ms": round(float(ph[3]), 3),
+                        "step_ms": round(float(ph.sum()), 3), "loss": loss, "paths": paths,
+                        "grad_floats": int(bucket.flat.numel())}
+            del model, opt, bucket
+            torch.cuda.empty_cache()
+        if True in grads and False in grads:
+            (la, ga), (lb, gb) = grads[True], grads[False]
+            row["loss_rel_diff"] = abs(la - lb) / max(1e-30, abs(lb))
+            row["grad_rel_diff"] = float((ga - gb).norm() / gb.norm())
+            row["speedup"] = round(row["layer_by_layer"]["step_ms"] / row["fused"]["step_ms"], 2)
+        if rank == 0:
+            print(json.dumps(row), flush=True)
+        results.append(row)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

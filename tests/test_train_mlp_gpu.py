@@ -1,0 +1,129 @@
+"""Training mode of the shared MLPs (csrc/train_mlp.hip, pointnet2_amd/train_mlp.py) against a float64 evaluation of the
+reference graph: utils/pointnet_util.py:113-127 (SA stack + reduce_max), :222-226 (FP stack), batch-statistics batch
+norm tf_util.py:512-531. Checked: pooled output, every pre-norm tensor z_l, every parameter gradient, the gradient of
+the grouped features / plain input, the updated running mean / variance. Bound 1e-5 of each tensor's largest
+magnitude (measured 0.2-2.3e-6: the error of an fp32 evaluation).
+
+A ReLU whose argument is within fp32 rounding of zero (a few elements per million) is decided by rounding, and the
+derivative jumps there: the float64 graph is therefore evaluated on the linear piece the kernels chose (their ReLU
+decisions and pooled samples), and the decisions themselves are checked separately -- they may differ from float64's
+only at rounding level, and the pooled sample must attain the float64 maximum (scripts/train_mlp_check.py: flips,
+flip_margin, pool_gap). The module-level tests compare two fp32 evaluations (fused node vs layer-by-layer torch), which
+may sit on different pieces at such elements: outputs are compared tightly, gradients in the L2 sense."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+KERNEL_CASES = [
+    ("A xyz 32-32-64", dict(b=2, n=256, m=64, ns=32, cfeat=0, widths=[32, 32, 64])),
+    ("B c64 64-64-128", dict(b=4, n=512, m=128, ns=32, cfeat=64, widths=[64, 64, 128])),
+    ("C ns16 msg order", dict(b=2, n=256, m=64, ns=16, cfeat=3, widths=[32, 32, 64], xyz_first=False)),
+    ("D c128 128-128-256 ns64", dict(b=4, n=512, m=64, ns=64, cfeat=128, widths=[128, 128, 256])),
+    ("E group_all 256-512-1024", dict(b=4, n=128, m=1, ns=128, cfeat=256, widths=[256, 512, 1024], group_all=True)),
+    ("F plain 384-256-128", dict(b=4, n=1024, m=0, ns=0, cfeat=0, widths=[256, 128], plain_cin=384)),
+    ("G c256 256-256-512", dict(b=4, n=256, m=16, ns=32, cfeat=256, widths=[256, 256, 512])),
+    ("H 64-96-128 ns128", dict(b=2, n=512, m=64, ns=128, cfeat=0, widths=[64, 96, 128])),
+    ("I odd cin 29 feats", dict(b=2, n=256, m=32, ns=32, cfeat=29, widths=[64, 64, 128])),
+    ("J plain three layers", dict(b=2, n=2048, m=0, ns=0, cfeat=0, widths=[128, 128, 128], plain_cin=128)),
+]
+
+# the reference configurations' own level shapes (BASELINE.json configs 2 and 5)
+CONFIG_CASES = [
+    ("cfg2 cls_ssg L1", dict(b=32, n=1024, m=512, ns=32, cfeat=0, widths=[64, 64, 128])),
+    ("cfg2 cls_ssg L2", dict(b=32, n=512, m=128, ns=64, cfeat=128, widths=[128, 128, 256])),
+    ("cfg5 sem_seg SA1", dict(b=8, n=8192, m=1024, ns=32, cfeat=0, widths=[32, 32, 64])),
+    ("cfg5 sem_seg SA2", dict(b=8, n=1024, m=256, ns=32, cfeat=64, widths=[64, 64, 128])),
+    ("cfg5 sem_seg SA3", dict(b=8, n=256, m=64, ns=32, cfeat=128, widths=[128, 128, 256])),
+    ("cfg5 sem_seg FP4", dict(b=8, n=8192, m=0, ns=0, cfeat=0, widths=[128, 128, 128], plain_cin=128)),
+]
+
+
+@pytest.mark.parametrize("name,kw", KERNEL_CASES + CONFIG_CASES, ids=[c[0] for c in KERNEL_CASES + CONFIG_CASES])
+def test_train_stack_matches_float64(cuda, name, kw):
+    from scripts import train_mlp_check as T
+    worst = T.run_case(name, **kw)
+    assert worst <= TOL, "%s: worst relative error %.2e" % (name, worst)
+
+
+def _clone_module(mod):
+    import copy
+    return copy.deepcopy(mod)
+
+
+def test_sa_module_training_takes_fused_path_and_matches_layer_by_layer(cuda):
+    """PointnetSAModule.train(): the fused node vs the layer-by-layer torch path of the same module (fp32): loss,
+    parameter gradients, input-feature gradient, running statistics."""
+    import pointnet2_amd.pointnet_util as U
+    torch.manual_seed(0)
+    sa = U.PointnetSAModule(64, 128, 0.4, 32, [64, 64, 128]).to(cuda).train()
+    ref = _clone_module(sa)
+    ref.fused_mlp = False
+    xyz = torch.rand(4, 512, 3, device=cuda)
+    f0 = torch.randn(4, 512, 64, device=cuda)
+    fa, fb = f0.clone().requires_grad_(True), f0.clone().requires_grad_(True)
+    _, oa, ia = sa(xyz, fa)
+    _, ob, ib = ref(xyz, fb)
+    assert sa.last_path == "fused_train" and ref.last_path == "unfused"
+    assert torch.equal(ia, ib)
+    w = torch.randn_like(ob)
+    (oa * w).sum().backward()
+    (ob * w).sum().backward()
+    scale = lambda t: max(1e-30, float(t.abs().max()))
+    l2 = lambda a, b: float((a - b).norm() / b.norm())
+    assert float((oa - ob).abs().max()) <= 2e-5 * scale(ob)
+    assert l2(fa.grad, fb.grad) <= 2e-3
+    conv_biases = {id(mod.bias) for mod in sa.modules() if isinstance(mod, torch.nn.Conv2d)}
+    for (na, pa), (nb, pb) in zip(sa.named_parameters(), ref.named_parameters()):
+        if id(pa) in conv_biases:
+            assert float(pa.grad.abs().max()) == 0.0           # exactly zero under batch norm (torch: rounding noise)
+            continue
+        assert l2(pa.grad, pb.grad) <= 2e-3, na
+    for (na, ba), (nb, bb) in zip(sa.named_buffers(), ref.named_buffers()):
+        assert float((ba.double() - bb.double()).abs().max()) <= 1e-5 * max(1.0, scale(bb.double())), na
+
+
+def test_msg_and_fp_modules_train_fused(cuda):
+    import pointnet2_amd.pointnet_util as U
+    torch.manual_seed(1)
+    msg = U.PointnetSAModuleMSG(3, 64, [0.2, 0.4], [16, 32], [[32, 32, 64], [32, 48, 64]]).to(cuda).train()
+    fp = U.PointnetFPModule(128 + 4, [64, 64]).to(cuda).train()
+    rmsg, rfp = _clone_module(msg), _clone_module(fp)
+    rmsg.fused_mlp = rfp.fused_mlp = False
+    xyz = torch.rand(4, 256, 3, device=cuda)
+    nrm = torch.randn(4, 256, 3, device=cuda)
+    skip = torch.randn(4, 256, 4, device=cuda)
+    outs = []
+    for m_, f_ in ((msg, fp), (rmsg, rfp)):
+        n_ = nrm.clone().requires_grad_(True)
+        new_xyz, feats = m_(xyz, n_)
+        up = f_(xyz, new_xyz, skip, feats)
+        up.square().mean().backward()
+        outs.append((up, n_.grad))
+    assert msg.last_path == "fused_train" and fp.last_path == "fused_train"
+    assert rmsg.last_path == "unfused" and rfp.last_path == "unfused"
+    (ua, ga), (ub, gb) = outs
+    assert float((ua - ub).abs().max()) <= 5e-5 * float(ub.abs().max())
+    assert float((ga - gb).norm() / gb.norm()) <= 5e-3
+    for (na, pa), (nb, pb) in zip(list(msg.named_parameters()) + list(fp.named_parameters()),
+                                  list(rmsg.named_parameters()) + list(rfp.named_parameters())):
+        if pb.grad is None:
+            continue
+        s = float(pb.grad.abs().max())
+        if s < 1e-6:                                       # conv biases under batch norm: zero vs rounding noise
+            assert float(pa.grad.abs().max()) <= 1e-6
+            continue
+        assert float((pa.grad - pb.grad).norm() / pb.grad.norm()) <= 5e-3, na
+
+
+def test_training_path_refuses_unsupported_and_falls_back(cuda):
+    import pointnet2_amd.pointnet_util as U
+    sa = U.PointnetSAModule(0, 16, 0.4, 24, [32, 32, 64]).to(cuda).train()      # nsample 24: not 16 / multiple of 32
+    xyz = torch.rand(2, 128, 3, device=cuda)
+    sa(xyz, None)
+    assert sa.last_path == "unfused"
+    sa2 = U.PointnetSAModule(0, 16, 0.4, 32, [32, 32, 64], bn=False).to(cuda).train()    # no batch norm: torch path
+    sa2(xyz, None)
+    assert sa2.last_path == "unfused"
