@@ -38,7 +38,6 @@ namespace pn2 {
 constexpr int kTlThreads = 512;          // GEMM workgroup: 8 waves, one 32-row item each per round
 constexpr int kTlWaves = kTlThreads / 64;
 constexpr int kPairVec = kPairWords / 4; // 16-byte vectors of one 32x32 weight tile pair
-constexpr int kWgThreads = 256;          // weight-gradient workgroup: 4 waves
 
 enum { A_PLAIN = 0, A_GATHER = 1, A_RELU = 2, A_DZ = 3, A_DZ_POOL = 4 };
 enum { E_STORE = 0, E_POOL = 1, E_MASK = 2, E_PLAIN = 3 };
@@ -553,111 +552,172 @@ struct TlWgrad {
     const int *argsel;
     const float *coef;          // (3, NO): s, c0, c1
     int group_rows;
-    float *partial;             // [slab][wave][TU*TT tiles][1024]
-    int tslabs;
+    float *partial;             // [slab][workgroup][tus * tts tiles][1024]
+    int tus, tts, tslabs;       // tiles of h / of dz per slab; slabs along dz
 };
 
-// 16 rows (register 8e + j <-> row 16e + 8hl + j of the item) of channel `ch` of h
-__device__ __forceinline__ f32x16 wg_load_h(const TlWgrad &p, long long row0, int ch, int hl)
+// One UNIT of operand data = what one wave holds as the MFMA fragment of K16 step e of a 32-channel tile: lane (c, hl)
+// <-> channel 32 tile + c, rows 16e + 8hl + j (j = 0..7) of the 32-row block. A wave loads a unit with eight (sixteen:
+// z and dy) dword loads whose 32 lanes cover 128 contiguous bytes of a row, applies the pass's prologue, splits into
+// the three bf16 levels and writes three 16-byte fragments into the block's LDS image, from where EVERY wave of the
+// workgroup reads the fragments of the output tiles it owns: operands cross the vector memory path once per workgroup.
+struct WgRaw { float z[8], g[8]; float gq; int sel; };
+
+__device__ __forceinline__ void wg_load_unit(const TlWgrad &p, long long row0, int unit, int us, int ts, int lane, WgRaw &r)
 {
-    f32x16 x;
+    const int tile = unit >> 1, e = unit & 1, hl = lane >> 5, c = lane & 31;
+    const long long rbase = row0 + 16 * e + 8 * hl;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) x[v] = 0.0f;
-    if (ch >= p.KI) return x;
-    if (p.amode == A_GATHER) {
-        const TlGather &g = p.g;
-        const int kx = ch - g.xyz_off, kf = ch - g.feat_off;
-        const bool isx = kx >= 0 && kx < 3, isf = kf >= 0 && kf < g.cfeat;
+    for (int j = 0; j < 8; ++j) { r.z[j] = 0.0f; r.g[j] = 0.0f; }
+    r.gq = 0.0f;
+    r.sel = -1;
+    if (tile < p.tus) {                                            // h = the layer's input
+        const int ch = (us * p.tus + tile) * 32 + c;
+        if (ch >= p.KI) return;
+        if (p.amode == A_GATHER) {
+            const TlGather &g = p.g;
+            const int kx = ch - g.xyz_off, kf = ch - g.feat_off;
+            const bool isx = kx >= 0 && kx < 3, isf = kf >= 0 && kf < g.cfeat;
+            if (!isx && !isf) return;
+            const long long grp0 = rbase / g.nsample;               // the 8 rows: one group, or consecutive ones
+            const int s0 = (int)(rbase - grp0 * g.nsample);
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const long long row = row0 + 16 * (v >> 3) + 8 * hl + (v & 7);
-            const long long grp = row / g.nsample;
-            const int sample = (int)(row - grp * g.nsample);
-            const long long cloud = grp / g.m;
-            const int pt = g.idx ? g.idx[row] : sample;
-            if (isx) {
-                const float val = g.xyz[((size_t)cloud * g.n + pt) * 3 + kx];
-                x[v] = g.new_xyz ? __fsub_rn(val, g.new_xyz[grp * 3 + kx]) : val;
-            } else if (isf) {
-                x[v] = g.points[((size_t)cloud * g.n + pt) * g.cfeat + kf];
+            for (int j = 0; j < 8; ++j) {
+                const int sj = s0 + j;
+                const long long grp = grp0 + sj / g.nsample;
+                const int sample = sj % g.nsample;
+                const long long cloud = grp / g.m;
+                const int pt = g.idx ? g.idx[rbase + j] : sample;
+                if (isx) {
+                    const float val = g.xyz[((size_t)cloud * g.n + pt) * 3 + kx];
+                    r.z[j] = g.new_xyz ? __fsub_rn(val, g.new_xyz[grp * 3 + kx]) : val;
+                } else {
+                    r.z[j] = g.points[((size_t)cloud * g.n + pt) * g.cfeat + kf];
+                }
             }
+            return;
         }
-        return x;
-    }
-    const float a = p.amode == A_RELU ? p.pa[ch] : 1.0f, c = p.amode == A_RELU ? p.pc[ch] : 0.0f;
+        const float *src = p.A + (size_t)rbase * p.KI + ch;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        const long long row = row0 + 16 * (v >> 3) + 8 * hl + (v & 7);
-        const float z = p.A[(size_t)row * p.KI + ch];
-        x[v] = p.amode == A_RELU ? vmax(__fadd_rn(__fmul_rn(a, z), c), 0.0f) : z;
+        for (int j = 0; j < 8; ++j) r.z[j] = src[(size_t)j * p.KI];
+        return;
     }
-    return x;
+    const int ch = (ts * p.tts + tile - p.tus) * 32 + c;            // dz = s dy - c0 - c1 z
+    if (ch >= p.NO) return;
+    const float *src = p.Z + (size_t)rbase * p.NO + ch;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.z[j] = src[(size_t)j * p.NO];
+    if (p.dmode == A_DZ_POOL) {
+        const long long grp = rbase / p.group_rows;                // group size 16 or a multiple of 32: one group per 8 rows
+        r.gq = p.G[(size_t)grp * p.NO + ch];
+        r.sel = p.argsel[(size_t)grp * p.NO + ch] - (int)(rbase - grp * p.group_rows);
+    } else {
+        const float *sg = p.G + (size_t)rbase * p.NO + ch;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.g[j] = sg[(size_t)j * p.NO];
+    }
 }
 
-__device__ __forceinline__ f32x16 wg_load_dz(const TlWgrad &p, long long row0, int ch, int hl)
+// prologue + split of a loaded unit -> its three fragments in the block image ([tile][level][e][lane] 16-byte vectors)
+__device__ __forceinline__ void wg_store_unit(const TlWgrad &p, const WgRaw &r, int unit, int us, int ts, int lane, u32x4 *img)
 {
+    const int tile = unit >> 1, e = unit & 1, c = lane & 31;
     f32x16 x;
 #pragma unroll
     for (int v = 0; v < 16; ++v) x[v] = 0.0f;
-    if (ch >= p.NO) return x;
-    const float s = p.coef[ch], c0 = p.coef[p.NO + ch], c1 = p.coef[2 * p.NO + ch];
+    if (tile < p.tus) {
+        const int ch = (us * p.tus + tile) * 32 + c;
+        if (p.amode == A_RELU && ch < p.KI) {
+            const float a = p.pa[ch], cc = p.pc[ch];
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        const long long row = row0 + 16 * (v >> 3) + 8 * hl + (v & 7);
-        const float z = p.Z[(size_t)row * p.NO + ch];
-        float dy;
-        if (p.dmode == A_DZ_POOL) {
-            const long long grp = row / p.group_rows;
-            const int sample = (int)(row - grp * p.group_rows);
-            dy = p.argsel[(size_t)grp * p.NO + ch] == sample ? p.G[(size_t)grp * p.NO + ch] : 0.0f;
+            for (int j = 0; j < 8; ++j) x[j] = vmax(__fadd_rn(__fmul_rn(a, r.z[j]), cc), 0.0f);
         } else {
-            dy = p.G[(size_t)row * p.NO + ch];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = r.z[j];
         }
-        x[v] = __fsub_rn(__fsub_rn(__fmul_rn(s, dy), c0), __fmul_rn(c1, z));
+    } else {
+        const int ch = (ts * p.tts + tile - p.tus) * 32 + c;
+        if (ch < p.NO) {
+            const float s = p.coef[ch], c0 = p.coef[p.NO + ch], c1 = p.coef[2 * p.NO + ch];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dy = p.dmode == A_DZ_POOL ? (r.sel == j ? r.gq : 0.0f) : r.g[j];
+                x[j] = __fsub_rn(__fsub_rn(__fmul_rn(s, dy), c0), __fmul_rn(c1, r.z[j]));
+            }
+        }
     }
-    return x;
+    const ActSplit sp = split_act(x);                             // registers 0..7 -> p[0][level]
+    u32x4 *o = img + ((size_t)tile * 3 * 2 + e) * 64 + lane;
+    o[0] = sp.p[0][0];
+    o[128] = sp.p[0][1];
+    o[256] = sp.p[0][2];
 }
 
-template <int TU, int TT>
-__global__ __launch_bounds__(kWgThreads) void tl_wgrad_kernel(const TlWgrad p)
+// TPW: output tiles per wave; UPW: operand units a wave loads per 32-row block
+template <int TPW, int UPW>
+__global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, s = lane & 31;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int us = blockIdx.y / p.tslabs, ts = blockIdx.y % p.tslabs;
-    const long long nw = (long long)gridDim.x * (kWgThreads / 64), wg = (long long)blockIdx.x * (kWgThreads / 64) + wave;
-    const long long items = p.rows / 32;
-    f32x16 acc[TU][TT];
+    const int ntiles = p.tus + p.tts, nunits = 2 * ntiles, nout = p.tus * p.tts;
+    const int imgv = ntiles * 3 * 2 * 64;                           // 16-byte vectors of one block image
+    u32x4 *img0 = reinterpret_cast<u32x4 *>(smem);
+    const long long blocks = p.rows / 32;
+    f32x16 acc[TPW];
 #pragma unroll
-    for (int u = 0; u < TU; ++u)
+    for (int i = 0; i < TPW; ++i)
 #pragma unroll
-        for (int t = 0; t < TT; ++t)
+        for (int v = 0; v < 16; ++v) acc[i][v] = 0.0f;
+    WgRaw raw[UPW];
+    long long blk = blockIdx.x;
+    if (blk < blocks) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[u][t][v] = 0.0f;
-    for (long long item = wg; item < items; item += nw) {
-        const long long row0 = item * 32;
-        ActSplit a[TU], d[TT];
-#pragma unroll
-        for (int u = 0; u < TU; ++u) a[u] = split_act(wg_load_h(p, row0, (us * TU + u) * 32 + s, hl));
-#pragma unroll
-        for (int t = 0; t < TT; ++t) d[t] = split_act(wg_load_dz(p, row0, (ts * TT + t) * 32 + s, hl));
-#pragma unroll
-        for (int u = 0; u < TU; ++u)
-#pragma unroll
-            for (int t = 0; t < TT; ++t) {
-                acc[u][t] = mma_x6<false>(a[u].p[0], d[t].p[0], acc[u][t]);
-                acc[u][t] = mma_x6<false>(a[u].p[1], d[t].p[1], acc[u][t]);
-            }
+        for (int i = 0; i < UPW; ++i)
+            if (wave + 8 * i < nunits) wg_load_unit(p, blk * 32, wave + 8 * i, us, ts, lane, raw[i]);
     }
-    // dump: D[i = input channel mlp_chan(v, hl)][j = output channel s] of tile (u, t)
-    float4 *dst = reinterpret_cast<float4 *>(p.partial) + (((size_t)blockIdx.y * nw + wg) * (TU * TT)) * 256;
+    unsigned parity = 0;
+    for (; blk < blocks; blk += gridDim.x) {
+        u32x4 *img = img0 + (size_t)(parity & 1u) * imgv;
 #pragma unroll
-    for (int u = 0; u < TU; ++u)
+        for (int i = 0; i < UPW; ++i)
+            if (wave + 8 * i < nunits) wg_store_unit(p, raw[i], wave + 8 * i, us, ts, lane, img);
+        __syncthreads();
+        const long long nblk = blk + gridDim.x;
+        if (nblk < blocks) {
 #pragma unroll
-        for (int t = 0; t < TT; ++t)
+            for (int i = 0; i < UPW; ++i)
+                if (wave + 8 * i < nunits) wg_load_unit(p, nblk * 32, wave + 8 * i, us, ts, lane, raw[i]);
+        }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 o = {acc[u][t][4 * q], acc[u][t][4 * q + 1], acc[u][t][4 * q + 2], acc[u][t][4 * q + 3]};
-                dst[(size_t)(u * TT + t) * 256 + q * 64 + lane] = o;
+        for (int i = 0; i < TPW; ++i) {
+            const int q = wave + 8 * i;
+            if (q < nout) {
+                const int u = q / p.tts, t = q % p.tts;
+                const u32x4 *xa = img + (size_t)u * 384 + lane, *xb = img + (size_t)(p.tus + t) * 384 + lane;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const u32x4 a[3] = {xa[e * 64], xa[128 + e * 64], xa[256 + e * 64]};
+                    const u32x4 d[3] = {xb[e * 64], xb[128 + e * 64], xb[256 + e * 64]};
+                    acc[i] = mma_x6<false>(a, d, acc[i]);
+                }
             }
+        }
+        ++parity;
+    }
+    // dump: D[i = input channel mlp_chan(v, hl)][j = output channel lane & 31] of tile (u, t); one slab per WORKGROUP
+    float4 *dst = reinterpret_cast<float4 *>(p.partial) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * nout * 256;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int q = wave + 8 * i;
+        if (q < nout) {
+#pragma unroll
+            for (int v4 = 0; v4 < 4; ++v4) {
+                const float4 o = {acc[i][4 * v4], acc[i][4 * v4 + 1], acc[i][4 * v4 + 2], acc[i][4 * v4 + 3]};
+                dst[(size_t)q * 256 + v4 * 64 + lane] = o;
+            }
+        }
+    }
 }
 
 // stage A of the reduction: sums of `chunk` consecutive waves' slabs (layout unchanged): in [slab][nw][E] -> out [slab][nchunks][E]
@@ -726,25 +786,29 @@ static GemmShape gemm_shape(int K, int N)
     return g;
 }
 
-struct WgradShape { int TU, TT, uslabs, tslabs; long long gridx, nw, nchunks; size_t e, partial_bytes, partial2_bytes; };
+struct WgradShape { int tus, tts, uslabs, tslabs, tpw, upw; long long gridx, nw, nchunks; size_t e, lds, partial_bytes, partial2_bytes; };
 
 static WgradShape wgrad_shape(long long rows, int KI, int NO)
 {
     WgradShape w;
     const int tu = tiles(KI), tt = tiles(NO);
-    w.TU = tu >= 2 ? 2 : 1;
-    w.TT = tt >= 3 ? 4 : tt == 2 ? 2 : 1;
-    w.uslabs = (tu + w.TU - 1) / w.TU;
-    w.tslabs = (tt + w.TT - 1) / w.TT;
-    const long long items = rows / 32;
-    long long waves = items / 8;                                   // at least eight items per wave
-    if (waves < 4) waves = 4;
-    if (waves > 1024) waves = 1024;
-    w.gridx = (waves + 3) / 4;
-    w.nw = w.gridx * 4;
-    w.e = (size_t)w.TU * w.TT * 1024;
-    w.nchunks = w.nw > 32 ? (w.nw + 31) / 32 : 0;
+    w.tus = tu < 4 ? tu : 4;
+    w.tts = tt < 8 ? tt : 8;
+    w.uslabs = (tu + w.tus - 1) / w.tus;
+    w.tslabs = (tt + w.tts - 1) / w.tts;
+    const int nout = w.tus * w.tts, per = (nout + 7) / 8;
+    w.tpw = per <= 1 ? 1 : per <= 2 ? 2 : 4;
+    w.upw = (2 * (w.tus + w.tts) + 7) / 8;
     const size_t slabs = (size_t)w.uslabs * w.tslabs;
+    const long long blocks = rows / 32;
+    long long gx = 256 / (long long)slabs;                         // about one workgroup per CU over all slabs
+    if (gx < 1) gx = 1;
+    if (gx > (blocks + 3) / 4) gx = (blocks + 3) / 4;               // at least four row blocks per workgroup
+    w.gridx = gx;
+    w.nw = gx;
+    w.e = (size_t)nout * 1024;
+    w.lds = (size_t)2 * (w.tus + w.tts) * 6144;
+    w.nchunks = w.nw > 32 ? (w.nw + 31) / 32 : 0;
     w.partial_bytes = slabs * w.nw * w.e * sizeof(float);
     w.partial2_bytes = slabs * (size_t)w.nchunks * w.e * sizeof(float);
     return w;
@@ -852,14 +916,26 @@ static int launch_gemm(int amode, TlGemm &p, const GemmShape &g, hipStream_t st)
     return launch_gemm_ns<1>(amode, p, g, grid, st);
 }
 
+template <int TPW>
+static int launch_wgrad_tpw(const TlWgrad &p, const WgradShape &w, dim3 grid, hipStream_t st)
+{
+#define PN2_WG_CASE(U)                                                          \
+    if (w.upw == U) {                                                           \
+        auto kern = tl_wgrad_kernel<TPW, U>;                                    \
+        if (int rc = allow_dynamic_lds(kern, w.lds)) return rc;                 \
+        return launch(kern, grid, dim3(kTlThreads), w.lds, st, p);              \
+    }
+    PN2_WG_CASE(1) PN2_WG_CASE(2) PN2_WG_CASE(3)
+#undef PN2_WG_CASE
+    return PN2_E_ARG;
+}
+
 static int launch_wgrad(TlWgrad &p, const WgradShape &w, float *partial2, const pn2_bn_layer &L, hipStream_t st)
 {
-    p.tslabs = w.tslabs;
+    p.tus = w.tus; p.tts = w.tts; p.tslabs = w.tslabs;
     const dim3 grid((unsigned)w.gridx, (unsigned)(w.uslabs * w.tslabs));
-    int rc = PN2_E_ARG;
-#define PN2_WG_CASE(U, T) if (w.TU == U && w.TT == T) rc = launch(tl_wgrad_kernel<U, T>, grid, dim3(kWgThreads), 0, st, p)
-    PN2_WG_CASE(1, 1); PN2_WG_CASE(1, 2); PN2_WG_CASE(1, 4); PN2_WG_CASE(2, 1); PN2_WG_CASE(2, 2); PN2_WG_CASE(2, 4);
-#undef PN2_WG_CASE
+    int rc = w.tpw == 1 ? launch_wgrad_tpw<1>(p, w, grid, st) : w.tpw == 2 ? launch_wgrad_tpw<2>(p, w, grid, st)
+                                                                             : launch_wgrad_tpw<4>(p, w, grid, st);
     if (rc) return rc;
     const float *src = p.partial;
     long long nw = w.nw;
@@ -874,7 +950,7 @@ static int launch_wgrad(TlWgrad &p, const WgradShape &w, float *partial2, const 
         nw = w.nchunks;
     }
     const long long total = (long long)p.KI * p.NO;
-    return launch(tl_wgrad_reduce_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, nw, w.TU, w.TT, w.tslabs,
+    return launch(tl_wgrad_reduce_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, nw, w.tus, w.tts, w.tslabs,
                   p.KI, p.NO, L.grad_weight, L.w_stride_k, L.w_stride_n);
 }
 
