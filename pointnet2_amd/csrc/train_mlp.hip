@@ -96,8 +96,36 @@ __device__ __forceinline__ RowCtx tl_row_ctx(const TlGemm &p, long long row, boo
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
+// Buffer addressing (SRSRC): a wave-uniform 128-bit descriptor in SGPRs + ONE per-lane byte offset in a VGPR + a uniform
+// byte offset in an SGPR per instruction. A lane's eight row loads then share one address register (flat addressing
+// needs a 64-bit VGPR pair per load in flight: 100+ registers of addresses in the kernels below).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(rsrc_t r, int voff, int soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ float4 bload4(rsrc_t r, int voff, int soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+__device__ __forceinline__ int4 bload4i(rsrc_t r, int voff, int soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_int4((int)v[0], (int)v[1], (int)v[2], (int)v[3]);
+}
+__device__ __forceinline__ void bstore(float x, rsrc_t r, int voff, int soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, 0);
+}
+
 template <int AMODE>
-__device__ __forceinline__ void tl_load_raw(const TlGemm &p, long long row, const RowCtx &rc, int u, int hl, bool active, ARaw &r)
+__device__ __forceinline__ void tl_load_raw(const TlGemm &p, long long row0, long long row, const RowCtx &rc, int u, int hl,
+                                            bool active, ARaw &r)
 {
 #pragma unroll
     for (int v = 0; v < 16; ++v) { r.a[v] = 0.0f; r.g[v] = 0.0f; }
@@ -120,26 +148,29 @@ __device__ __forceinline__ void tl_load_raw(const TlGemm &p, long long row, cons
             }
         return;
     }
-    const float *pa = p.A + (size_t)row * p.K;
+    // rows of the item: descriptor at the item's first row, lane offset = its row and half, uniform offset = the k tile
+    const int s = (int)(row - row0);
+    const rsrc_t ra = make_rsrc(p.A + (size_t)row0 * p.K, 32u * (unsigned)p.K * 4u);
+    const int voff = (s * p.K + 8 * hl) * 4, soff = u * 128;
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int k = 32 * u + 16 * e + 8 * hl + 4 * q;
             if (k < p.K) {
-                const float4 t = ld4(pa + k);
+                const float4 t = bload4(ra, voff + (16 * e + 4 * q) * 4, soff);
                 r.a[8 * e + 4 * q] = t.x; r.a[8 * e + 4 * q + 1] = t.y; r.a[8 * e + 4 * q + 2] = t.z; r.a[8 * e + 4 * q + 3] = t.w;
             }
         }
     if (AMODE == A_DZ) {
-        const float *pg = p.G + (size_t)row * p.K;
+        const rsrc_t rg = make_rsrc(p.G + (size_t)row0 * p.K, 32u * (unsigned)p.K * 4u);
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int k = 32 * u + 16 * e + 8 * hl + 4 * q;
                 if (k < p.K) {
-                    const float4 t = ld4(pg + k);
+                    const float4 t = bload4(rg, voff + (16 * e + 4 * q) * 4, soff);
                     r.g[8 * e + 4 * q] = t.x; r.g[8 * e + 4 * q + 1] = t.y; r.g[8 * e + 4 * q + 2] = t.z; r.g[8 * e + 4 * q + 3] = t.w;
                 }
             }
@@ -211,7 +242,8 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
     const int kpad = p.tk * 32;
     float *lp0 = reinterpret_cast<float *>(smem), *lp1 = lp0 + kpad, *lp2 = lp1 + kpad;
     u32x4 *wst = reinterpret_cast<u32x4 *>(lp2 + kpad);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, s = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, hl = lane >> 5, s = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // wave-uniform: item bases live in SGPRs
     const int slab = blockIdx.y;
     constexpr int kStageV = NS * kPairVec;
     constexpr int PV = (kStageV + kTlThreads - 1) / kTlThreads;
@@ -244,18 +276,24 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
 #pragma unroll
     for (int t = 0; t < NS; ++t) { sd1[t] = 0.0; sd2[t] = 0.0; }
 
-    for (long long round = blockIdx.x; round < rounds; round += gridDim.x) {
-        const long long item = round * kTlWaves + wave;
-        const bool active = item < items;
-        const long long row0 = item * 32, row = row0 + s;
+    // The A operand runs one k tile ahead of the MFMAs, ACROSS rounds: the first tile of the next item is requested
+    // before this item's epilogue, so its latency hides under the stores.
+    long long round = blockIdx.x;
+    long long item = round * kTlWaves + wave, row0 = item * 32, row = row0 + s;
+    bool active = round < rounds && item < items;
+    RowCtx rc = tl_row_ctx<AMODE>(p, row, active);
+    ARaw raw;
+    if (round < rounds) tl_load_raw<AMODE>(p, row0, row, rc, 0, hl, active, raw);
+    for (; round < rounds; round += gridDim.x) {
+        const long long nround = round + gridDim.x;
+        const long long nitem = nround * kTlWaves + wave, nrow0 = nitem * 32, nrow = nrow0 + s;
+        const bool nactive = nround < rounds && nitem < items;
+        RowCtx nrc = rc;
         f32x16 acc[NS];
 #pragma unroll
         for (int t = 0; t < NS; ++t)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[t][v] = 0.0f;
-        const RowCtx rc = tl_row_ctx<AMODE>(p, row, active);
-        ARaw raw;
-        tl_load_raw<AMODE>(p, row, rc, 0, hl, active, raw);
         for (int u = 0; u < p.tk; ++u) {
             const u32x4 *stage;
             if (p.resident) {
@@ -268,7 +306,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
                     if (j < kStageV) dst[j] = pre[i];
                 }
                 __syncthreads();
-                const bool more = u + 1 < p.tk || round + gridDim.x < rounds;
+                const bool more = u + 1 < p.tk || nround < rounds;
                 if (more) {
                     const u32x4 *nsrc = wsrc + (size_t)(u + 1 < p.tk ? u + 1 : 0) * kStageV;
 #pragma unroll
@@ -281,16 +319,26 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
                 ++parity;
             }
             const ActSplit sp = split_act(tl_finish<AMODE>(raw, rc, u, hl, lp0, lp1, lp2));
-            if (u + 1 < p.tk) tl_load_raw<AMODE>(p, row, rc, u + 1, hl, active, raw);
+            if (u + 1 < p.tk) {
+                tl_load_raw<AMODE>(p, row0, row, rc, u + 1, hl, active, raw);
+            } else if (nround < rounds) {
+                nrc = tl_row_ctx<AMODE>(p, nrow, nactive);
+                tl_load_raw<AMODE>(p, nrow0, nrow, nrc, 0, hl, nactive, raw);
+            }
 #pragma unroll
             for (int t = 0; t < NS; ++t) acc[t] = stream_pair<true>(stage, t, lane, sp, acc[t]);
         }
 
         // ---- epilogue: lane = column 32(slab NS + t) + s, register v = row row0 + mlp_chan(v, hl) ----------------------
+        // buffer addressing: descriptor at the item's first row, lane offset = (4 hl) rows + its column, uniform offset = the
+        // register's row 8(v >> 2) + (v & 3)
+        const unsigned obytes = 32u * (unsigned)p.N * 4u;
+        const rsrc_t ro = make_rsrc(p.emode == E_PLAIN ? nullptr : p.out + (size_t)row0 * p.N, p.emode == E_PLAIN ? 0u : obytes);
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
             const int col = (slab * NS + t) * 32 + s;
             const bool ok = active && col < p.N;
+            const int voff = (4 * hl * p.N + col) * 4;
             if (p.emode == E_STORE || p.emode == E_POOL) {
                 const float bias = (p.bias && col < p.N) ? p.bias[col] : 0.0f;
                 float s1 = 0.0f, s2 = 0.0f;
@@ -305,7 +353,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
                     sd1[t] += (double)s1;
                     sd2[t] += (double)s2;
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) p.out[(size_t)(row0 + mlp_chan(v, hl)) * p.N + col] = val[v];
+                    for (int v = 0; v < 16; ++v) bstore(val[v], ro, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
                 }
                 if (p.emode == E_POOL) {
                     // max / min of z over the rows of the item (two half items when a group is 16 rows), with the row
@@ -334,15 +382,17 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
                 const float ea = col < p.N ? p.ea[col] : 0.0f, ec = col < p.N ? p.ec[col] : 0.0f;
                 float s1 = 0.0f, s2 = 0.0f;
                 if (ok) {
+                    const rsrc_t rz = make_rsrc(p.zprev + (size_t)row0 * p.N, obytes);
+                    f32x16 zp;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) zp[v] = bload(rz, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
 #pragma unroll
                     for (int v = 0; v < 16; ++v) {
-                        const size_t o = (size_t)(row0 + mlp_chan(v, hl)) * p.N + col;
-                        const float zp = p.zprev[o];
-                        const float y = __fadd_rn(__fmul_rn(ea, zp), ec);
+                        const float y = __fadd_rn(__fmul_rn(ea, zp[v]), ec);
                         const float g = y > 0.0f ? acc[t][v] : 0.0f;                      // ReLU of the layer below
-                        p.out[o] = g;
+                        bstore(g, ro, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
                         s1 = __fadd_rn(s1, g);
-                        s2 = __fadd_rn(s2, __fmul_rn(g, zp));
+                        s2 = __fadd_rn(s2, __fmul_rn(g, zp[v]));
                     }
                     sd1[t] += (double)s1;
                     sd2[t] += (double)s2;
@@ -355,6 +405,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
                 }
             }
         }
+        item = nitem; row0 = nrow0; row = nrow; active = nactive; rc = nrc;
     }
     if (p.emode != E_PLAIN && p.stats) {
 #pragma unroll
@@ -563,6 +614,7 @@ struct TlWgrad {
 // workgroup reads the fragments of the output tiles it owns: operands cross the vector memory path once per workgroup.
 struct WgRaw { float z[8], g[8]; float gq; int sel; };
 
+template <bool GATHER>
 __device__ __forceinline__ void wg_load_unit(const TlWgrad &p, long long row0, int unit, int us, int ts, int lane, WgRaw &r)
 {
     const int tile = unit >> 1, e = unit & 1, hl = lane >> 5, c = lane & 31;
@@ -574,47 +626,49 @@ __device__ __forceinline__ void wg_load_unit(const TlWgrad &p, long long row0, i
     if (tile < p.tus) {                                            // h = the layer's input
         const int ch = (us * p.tus + tile) * 32 + c;
         if (ch >= p.KI) return;
-        if (p.amode == A_GATHER) {
+        if (GATHER) {
             const TlGather &g = p.g;
             const int kx = ch - g.xyz_off, kf = ch - g.feat_off;
             const bool isx = kx >= 0 && kx < 3, isf = kf >= 0 && kf < g.cfeat;
             if (!isx && !isf) return;
-            const long long grp0 = rbase / g.nsample;               // the 8 rows: one group, or consecutive ones
-            const int s0 = (int)(rbase - grp0 * g.nsample);
+            const int grp0 = (int)((unsigned)rbase / (unsigned)g.nsample);   // rows < 2^31 (checked by the launcher)
+            const int s0 = (int)rbase - grp0 * g.nsample;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int sj = s0 + j;
-                const long long grp = grp0 + sj / g.nsample;
+                const int grp = grp0 + sj / g.nsample;
                 const int sample = sj % g.nsample;
-                const long long cloud = grp / g.m;
+                const int cloud = grp / g.m;
                 const int pt = g.idx ? g.idx[rbase + j] : sample;
                 if (isx) {
                     const float val = g.xyz[((size_t)cloud * g.n + pt) * 3 + kx];
-                    r.z[j] = g.new_xyz ? __fsub_rn(val, g.new_xyz[grp * 3 + kx]) : val;
+                    r.z[j] = g.new_xyz ? __fsub_rn(val, g.new_xyz[(size_t)grp * 3 + kx]) : val;
                 } else {
                     r.z[j] = g.points[((size_t)cloud * g.n + pt) * g.cfeat + kf];
                 }
             }
             return;
         }
-        const float *src = p.A + (size_t)rbase * p.KI + ch;
+        const rsrc_t rs = make_rsrc(p.A + (size_t)row0 * p.KI, 32u * (unsigned)p.KI * 4u);
+        const int voff = ((16 * e + 8 * hl) * p.KI + ch) * 4;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r.z[j] = src[(size_t)j * p.KI];
+        for (int j = 0; j < 8; ++j) r.z[j] = bload(rs, voff, j * p.KI * 4);
         return;
     }
     const int ch = (ts * p.tts + tile - p.tus) * 32 + c;            // dz = s dy - c0 - c1 z
     if (ch >= p.NO) return;
-    const float *src = p.Z + (size_t)rbase * p.NO + ch;
+    const rsrc_t rz = make_rsrc(p.Z + (size_t)row0 * p.NO, 32u * (unsigned)p.NO * 4u);
+    const int voff = ((16 * e + 8 * hl) * p.NO + ch) * 4;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r.z[j] = src[(size_t)j * p.NO];
+    for (int j = 0; j < 8; ++j) r.z[j] = bload(rz, voff, j * p.NO * 4);
     if (p.dmode == A_DZ_POOL) {
-        const long long grp = rbase / p.group_rows;                // group size 16 or a multiple of 32: one group per 8 rows
+        const int grp = (int)((unsigned)rbase / (unsigned)p.group_rows);     // group size 16 or a multiple of 32: one group per 8 rows
         r.gq = p.G[(size_t)grp * p.NO + ch];
-        r.sel = p.argsel[(size_t)grp * p.NO + ch] - (int)(rbase - grp * p.group_rows);
+        r.sel = p.argsel[(size_t)grp * p.NO + ch] - ((int)rbase - grp * p.group_rows);
     } else {
-        const float *sg = p.G + (size_t)rbase * p.NO + ch;
+        const rsrc_t rg = make_rsrc(p.G + (size_t)row0 * p.NO, 32u * (unsigned)p.NO * 4u);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r.g[j] = sg[(size_t)j * p.NO];
+        for (int j = 0; j < 8; ++j) r.g[j] = bload(rg, voff, j * p.NO * 4);
     }
 }
 
@@ -654,41 +708,38 @@ __device__ __forceinline__ void wg_store_unit(const TlWgrad &p, const WgRaw &r, 
 }
 
 // TPW: output tiles per wave; UPW: operand units a wave loads per 32-row block
-template <int TPW, int UPW>
+// Memory-bound (a few MFMAs per 40 KB of rows): what matters is bytes in flight. Every wave keeps the rows of the NEXT TWO
+// blocks in flight in registers (two raw sets, the block loop is unrolled by two), the block image in LDS is double
+// buffered, one s_barrier per block.
+template <int TPW, int UPW, bool GATHER>
 __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // uniform: scalar branches
     const int us = blockIdx.y / p.tslabs, ts = blockIdx.y % p.tslabs;
     const int ntiles = p.tus + p.tts, nunits = 2 * ntiles, nout = p.tus * p.tts;
     const int imgv = ntiles * 3 * 2 * 64;                           // 16-byte vectors of one block image
     u32x4 *img0 = reinterpret_cast<u32x4 *>(smem);
-    const long long blocks = p.rows / 32;
+    const long long blocks = p.rows / 32, step = gridDim.x;
     f32x16 acc[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[i][v] = 0.0f;
-    WgRaw raw[UPW];
-    long long blk = blockIdx.x;
-    if (blk < blocks) {
-#pragma unroll
-        for (int i = 0; i < UPW; ++i)
-            if (wave + 8 * i < nunits) wg_load_unit(p, blk * 32, wave + 8 * i, us, ts, lane, raw[i]);
-    }
-    unsigned parity = 0;
-    for (; blk < blocks; blk += gridDim.x) {
-        u32x4 *img = img0 + (size_t)(parity & 1u) * imgv;
-#pragma unroll
-        for (int i = 0; i < UPW; ++i)
-            if (wave + 8 * i < nunits) wg_store_unit(p, raw[i], wave + 8 * i, us, ts, lane, img);
-        __syncthreads();
-        const long long nblk = blk + gridDim.x;
-        if (nblk < blocks) {
+    WgRaw ra[UPW], rb[UPW];
+    auto load = [&](long long b, WgRaw (&r)[UPW]) {
+        if (b < blocks) {
 #pragma unroll
             for (int i = 0; i < UPW; ++i)
-                if (wave + 8 * i < nunits) wg_load_unit(p, nblk * 32, wave + 8 * i, us, ts, lane, raw[i]);
+                if (wave + 8 * i < nunits) wg_load_unit<GATHER>(p, b * 32, wave + 8 * i, us, ts, lane, r[i]);
         }
+    };
+    auto block = [&](long long b, WgRaw (&r)[UPW], u32x4 *img) {
+#pragma unroll
+        for (int i = 0; i < UPW; ++i)
+            if (wave + 8 * i < nunits) wg_store_unit(p, r[i], wave + 8 * i, us, ts, lane, img);
+        __syncthreads();
+        load(b + 2 * step, r);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int q = wave + 8 * i;
@@ -703,7 +754,13 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
                 }
             }
         }
-        ++parity;
+    };
+    long long blk = blockIdx.x;
+    load(blk, ra);
+    load(blk + step, rb);
+    for (; blk < blocks; blk += 2 * step) {
+        block(blk, ra, img0);
+        if (blk + step < blocks) block(blk + step, rb, img0 + imgv);      // uniform over the workgroup
     }
     // dump: D[i = input channel mlp_chan(v, hl)][j = output channel lane & 31] of tile (u, t); one slab per WORKGROUP
     float4 *dst = reinterpret_cast<float4 *>(p.partial) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * nout * 256;
@@ -801,7 +858,7 @@ static WgradShape wgrad_shape(long long rows, int KI, int NO)
     w.upw = (2 * (w.tus + w.tts) + 7) / 8;
     const size_t slabs = (size_t)w.uslabs * w.tslabs;
     const long long blocks = rows / 32;
-    long long gx = 256 / (long long)slabs;                         // about one workgroup per CU over all slabs
+    long long gx = 256 / (long long)slabs;                         // one workgroup per CU over all slabs
     if (gx < 1) gx = 1;
     if (gx > (blocks + 3) / 4) gx = (blocks + 3) / 4;               // at least four row blocks per workgroup
     w.gridx = gx;
@@ -827,7 +884,7 @@ struct TlPlan {
 
 static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_rows, int backward, TlPlan &pl)
 {
-    if (rows <= 0 || rows % 32 || nlayers < 1 || nlayers > 8) return false;
+    if (rows <= 0 || rows % 32 || rows >= (1ll << 31) || nlayers < 1 || nlayers > 8) return false;
     if (pool_rows && pool_rows != 16 && pool_rows % 32) return false;
     memset(&pl, 0, sizeof(pl));
     size_t off = 0;
@@ -921,7 +978,7 @@ static int launch_wgrad_tpw(const TlWgrad &p, const WgradShape &w, dim3 grid, hi
 {
 #define PN2_WG_CASE(U)                                                          \
     if (w.upw == U) {                                                           \
-        auto kern = tl_wgrad_kernel<TPW, U>;                                    \
+        auto kern = p.amode == A_GATHER ? tl_wgrad_kernel<TPW, U, true> : tl_wgrad_kernel<TPW, U, false>;   \
         if (int rc = allow_dynamic_lds(kern, w.lds)) return rc;                 \
         return launch(kern, grid, dim3(kTlThreads), w.lds, st, p);              \
     }
