@@ -38,6 +38,7 @@ namespace pn2 {
 constexpr int kTlThreads = 512;          // GEMM workgroup: 8 waves, one 32-row item each per round
 constexpr int kTlWaves = kTlThreads / 64;
 constexpr int kPairVec = kPairWords / 4; // 16-byte vectors of one 32x32 weight tile pair
+constexpr int kMaxParts = 256;           // rows of a per-channel partial-sum array (one per row workgroup)
 
 enum { A_PLAIN = 0, A_GATHER = 1, A_RELU = 2, A_DZ = 3, A_DZ_POOL = 4 };
 enum { E_STORE = 0, E_POOL = 1, E_MASK = 2, E_PLAIN = 3 };
@@ -71,6 +72,8 @@ struct TlGemm {
     float *pmax, *pmin;         // E_POOL partials (rows / prow, N)
     int *pamax, *pamin;
     int prow;                   // 32 or 16
+    int nt;                     // streaming (non-temporal) stores: outputs that do not fit the 256 MB Infinity Cache anyway
+    int lab;                    // lab builds of the timing study only (PN2_TL_LAB): 1 = no stores, 2 = no statistics; 0 in production
 };
 
 // ---- A operand: load + prologue. Register v = 8e + j of lane (row s, half hl) <-> channel 32u + 16e + 8hl + j ------------
@@ -118,9 +121,10 @@ __device__ __forceinline__ int4 bload4i(rsrc_t r, int voff, int soff)
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return make_int4((int)v[0], (int)v[1], (int)v[2], (int)v[3]);
 }
+template <bool NT>
 __device__ __forceinline__ void bstore(float x, rsrc_t r, int voff, int soff)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, NT ? 2 : 0);     // aux bit 1 = nt (streaming store)
 }
 
 template <int AMODE>
@@ -247,6 +251,8 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
     const int slab = blockIdx.y;
     constexpr int kStageV = NS * kPairVec;
     constexpr int PV = (kStageV + kTlThreads - 1) / kTlThreads;
+    constexpr bool PREFZ = AMODE == A_DZ && NS <= 2;              // prefetch the ReLU mask's source rows (E_MASK)
+    constexpr int DEPTH = AMODE >= A_DZ ? 1 : 2;                  // A tiles in flight ahead of the MFMAs (register budget)
     const u32x4 *wsrc = p.wpacked + (size_t)slab * p.tk * kStageV;
 
     if (AMODE >= A_RELU) {
@@ -276,71 +282,115 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
 #pragma unroll
     for (int t = 0; t < NS; ++t) { sd1[t] = 0.0; sd2[t] = 0.0; }
 
-    // The A operand runs one k tile ahead of the MFMAs, ACROSS rounds: the first tile of the next item is requested
-    // before this item's epilogue, so its latency hides under the stores.
-    long long round = blockIdx.x;
-    long long item = round * kTlWaves + wave, row0 = item * 32, row = row0 + s;
-    bool active = round < rounds && item < items;
-    RowCtx rc = tl_row_ctx<AMODE>(p, row, active);
-    ARaw raw;
-    if (round < rounds) tl_load_raw<AMODE>(p, row0, row, rc, 0, hl, active, raw);
-    for (; round < rounds; round += gridDim.x) {
-        const long long nround = round + gridDim.x;
-        const long long nitem = nround * kTlWaves + wave, nrow0 = nitem * 32, nrow = nrow0 + s;
-        const bool nactive = nround < rounds && nitem < items;
-        RowCtx nrc = rc;
-        f32x16 acc[NS];
+    // per-column parameters of the epilogue (the lane's columns never change): fetched once -- a global load inside the
+    // round loop would be waited for with vmcnt(0), which also drains the A prefetch
+    float ep0[NS], ep1[NS];
 #pragma unroll
-        for (int t = 0; t < NS; ++t)
+    for (int t = 0; t < NS; ++t) {
+        const int col = (slab * NS + t) * 32 + s;
+        ep0[t] = 0.0f; ep1[t] = 0.0f;
+        if (col < p.N) {
+            if (p.emode == E_MASK) { ep0[t] = p.ea[col]; ep1[t] = p.ec[col]; }
+            else if (p.emode != E_PLAIN && p.bias) ep0[t] = p.bias[col];
+        }
+    }
+    // The A operand is a STREAM of k tiles -- (round, u) in consumption order, across rounds -- and runs TWO tiles ahead of
+    // the MFMAs in two register slots: these passes move 0.5-1 KB per MFMA, so what they need is bytes in flight
+    // (8 KB per wave, 64 KB per CU). Gathered rows (layer 1 of an SA level) take two steps: the point index is fetched
+    // when the slot is assigned, the coordinates / features it points to one step later, so neither wait is exposed.
+    struct Slot { ARaw raw; RowCtx rc; long long round, row0, row; int u; bool active, valid, pending; };
+    auto assign = [&](Slot &sl, long long round, int u) {
+        sl.round = round; sl.u = u; sl.valid = round < rounds;
+        const long long item = round * kTlWaves + wave;
+        sl.row0 = item * 32; sl.row = sl.row0 + s;
+        sl.active = sl.valid && item < items;
+        sl.rc = tl_row_ctx<AMODE>(p, sl.row, sl.active);
+        sl.pending = sl.valid;
+    };
+    auto fetch = [&](Slot &sl) {
+        if (sl.pending) tl_load_raw<AMODE>(p, sl.row0, sl.row, sl.rc, sl.u, hl, sl.active, sl.raw);
+        sl.pending = false;
+    };
+    f32x16 acc[NS], zp[PREFZ ? NS : 1];
+    auto consume = [&](Slot &sl, Slot &other) {
+        if (AMODE == A_GATHER) fetch(other);                       // second step of the other slot's gather
+        long long nr = other.round;                               // the step consumed after this one
+        int nu = other.u;
+        bool nvalid = other.valid;
+        if (DEPTH == 1) {
+            nu = sl.u + 1; nr = sl.round;
+            if (nu >= p.tk) { nu = 0; nr += gridDim.x; }
+            nvalid = nr < rounds;
+        }
+        const u32x4 *stage;
+        if (p.resident) {
+            stage = wst + (size_t)sl.u * kStageV;
+        } else {
+            u32x4 *dst = wst + (parity & 1u) * kStageV;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[t][v] = 0.0f;
-        for (int u = 0; u < p.tk; ++u) {
-            const u32x4 *stage;
-            if (p.resident) {
-                stage = wst + (size_t)u * kStageV;
-            } else {
-                u32x4 *dst = wst + (parity & 1u) * kStageV;
+            for (int i = 0; i < PV; ++i) {
+                const int j = tid + i * kTlThreads;
+                if (j < kStageV) dst[j] = pre[i];
+            }
+            __syncthreads();
+            if (nvalid) {                                          // the next step's weights
+                const u32x4 *nsrc = wsrc + (size_t)nu * kStageV;
 #pragma unroll
                 for (int i = 0; i < PV; ++i) {
                     const int j = tid + i * kTlThreads;
-                    if (j < kStageV) dst[j] = pre[i];
+                    if (j < kStageV) pre[i] = nsrc[j];
                 }
-                __syncthreads();
-                const bool more = u + 1 < p.tk || nround < rounds;
-                if (more) {
-                    const u32x4 *nsrc = wsrc + (size_t)(u + 1 < p.tk ? u + 1 : 0) * kStageV;
-#pragma unroll
-                    for (int i = 0; i < PV; ++i) {
-                        const int j = tid + i * kTlThreads;
-                        if (j < kStageV) pre[i] = nsrc[j];
-                    }
-                }
-                stage = dst;
-                ++parity;
             }
-            const ActSplit sp = split_act(tl_finish<AMODE>(raw, rc, u, hl, lp0, lp1, lp2));
-            if (u + 1 < p.tk) {
-                tl_load_raw<AMODE>(p, row0, row, rc, u + 1, hl, active, raw);
-            } else if (nround < rounds) {
-                nrc = tl_row_ctx<AMODE>(p, nrow, nactive);
-                tl_load_raw<AMODE>(p, nrow0, nrow, nrc, 0, hl, nactive, raw);
-            }
-#pragma unroll
-            for (int t = 0; t < NS; ++t) acc[t] = stream_pair<true>(stage, t, lane, sp, acc[t]);
+            stage = dst;
+            ++parity;
         }
-
+        if (sl.u == 0) {
+#pragma unroll
+            for (int t = 0; t < NS; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[t][v] = 0.0f;
+        }
+        const ActSplit sp = split_act(tl_finish<AMODE>(sl.raw, sl.rc, sl.u, hl, lp0, lp1, lp2));
+        const bool last = sl.u + 1 == p.tk;
+        const long long erow0 = sl.row0, eitem = sl.round * kTlWaves + wave;
+        const bool eactive = sl.active;
+        if (PREFZ && last && p.emode == E_MASK && eactive) {        // the mask's source rows, under the last tile's MFMAs
+            const rsrc_t rz = make_rsrc(p.zprev + (size_t)erow0 * p.N, 32u * (unsigned)p.N * 4u);
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                const int col = (slab * NS + t) * 32 + s;
+                if (col < p.N) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+                        zp[t][v] = bload(rz, (4 * hl * p.N + col) * 4, (8 * (v >> 2) + (v & 3)) * p.N * 4);
+                }
+            }
+        }
+        {                                                          // this slot: the tile DEPTH steps ahead
+            long long r2 = nr;
+            int u2 = nu;
+            if (DEPTH == 2) {
+                u2 = nu + 1;
+                if (u2 >= p.tk) { u2 = 0; r2 += gridDim.x; }
+            }
+            if (nvalid) assign(sl, r2, u2); else sl.valid = false;
+            if ((AMODE != A_GATHER || DEPTH == 1) && sl.valid) fetch(sl);
+        }
+#pragma unroll
+        for (int t = 0; t < NS; ++t) acc[t] = stream_pair<true>(stage, t, lane, sp, acc[t]);
+        if (!last) return;
         // ---- epilogue: lane = column 32(slab NS + t) + s, register v = row row0 + mlp_chan(v, hl) ----------------------
         // buffer addressing: descriptor at the item's first row, lane offset = (4 hl) rows + its column, uniform offset = the
         // register's row 8(v >> 2) + (v & 3)
         const unsigned obytes = 32u * (unsigned)p.N * 4u;
-        const rsrc_t ro = make_rsrc(p.emode == E_PLAIN ? nullptr : p.out + (size_t)row0 * p.N, p.emode == E_PLAIN ? 0u : obytes);
+        const rsrc_t ro = make_rsrc(p.emode == E_PLAIN ? nullptr : p.out + (size_t)erow0 * p.N, p.emode == E_PLAIN ? 0u : obytes);
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
             const int col = (slab * NS + t) * 32 + s;
-            const bool ok = active && col < p.N;
+            const bool ok = eactive && col < p.N;
             const int voff = (4 * hl * p.N + col) * 4;
             if (p.emode == E_STORE || p.emode == E_POOL) {
-                const float bias = (p.bias && col < p.N) ? p.bias[col] : 0.0f;
+                const float bias = ep0[t];
                 float s1 = 0.0f, s2 = 0.0f;
                 f32x16 val;
 #pragma unroll
@@ -349,11 +399,18 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
                     s1 = __fadd_rn(s1, val[v]);
                     s2 = __fadd_rn(s2, __fmul_rn(val[v], val[v]));
                 }
-                if (ok) {
+                if (ok && !(p.lab & 2)) {
                     sd1[t] += (double)s1;
                     sd2[t] += (double)s2;
+                }
+                if (ok && !(p.lab & 1)) {
+                    if (p.nt) {
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) bstore(val[v], ro, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
+                        for (int v = 0; v < 16; ++v) bstore<true>(val[v], ro, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) bstore<false>(val[v], ro, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
+                    }
                 }
                 if (p.emode == E_POOL) {
                     // max / min of z over the rows of the item (two half items when a group is 16 rows), with the row
@@ -372,50 +429,82 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
                         if (omx > mx || (omx == mx && orx < rx)) { mx = omx; rx = orx; }
                         if (omn < mn || (omn == mn && orn < rn)) { mn = omn; rn = orn; }
                         if (ok && hl == 0) {
-                            const size_t o = (size_t)(item * halves + hf) * p.N + col;
+                            const size_t o = (size_t)(eitem * halves + hf) * p.N + col;
                             p.pmax[o] = mx; p.pmin[o] = mn;
                             p.pamax[o] = rx - hf * 16; p.pamin[o] = rn - hf * 16;
                         }
                     }
                 }
             } else if (p.emode == E_MASK) {
-                const float ea = col < p.N ? p.ea[col] : 0.0f, ec = col < p.N ? p.ec[col] : 0.0f;
+                const float ea = ep0[t], ec = ep1[t];
                 float s1 = 0.0f, s2 = 0.0f;
                 if (ok) {
-                    const rsrc_t rz = make_rsrc(p.zprev + (size_t)row0 * p.N, obytes);
-                    f32x16 zp;
+                    if (!PREFZ) {                                  // wide slabs: no registers to spare, fetched here
+                        const rsrc_t rz = make_rsrc(p.zprev + (size_t)erow0 * p.N, obytes);
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) zp[v] = bload(rz, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
+                        for (int v = 0; v < 16; ++v) zp[0][v] = bload(rz, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
+                    }
+                    const f32x16 &zz = zp[PREFZ ? t : 0];
 #pragma unroll
                     for (int v = 0; v < 16; ++v) {
-                        const float y = __fadd_rn(__fmul_rn(ea, zp[v]), ec);
+                        const float y = __fadd_rn(__fmul_rn(ea, zz[v]), ec);
                         const float g = y > 0.0f ? acc[t][v] : 0.0f;                      // ReLU of the layer below
-                        bstore(g, ro, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
+                        if (p.nt) bstore<true>(g, ro, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
+                        else bstore<false>(g, ro, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
                         s1 = __fadd_rn(s1, g);
-                        s2 = __fadd_rn(s2, __fmul_rn(g, zp[v]));
+                        s2 = __fadd_rn(s2, __fmul_rn(g, zz[v]));
                     }
                     sd1[t] += (double)s1;
                     sd2[t] += (double)s2;
                 }
             } else {
-                if (active && col >= p.col0 && col < p.col1) {
+                if (eactive && col >= p.col0 && col < p.col1) {
 #pragma unroll
                     for (int v = 0; v < 16; ++v)
-                        p.out[(size_t)(row0 + mlp_chan(v, hl)) * p.out_pitch + (col - p.col0)] = acc[t][v];
+                        p.out[(size_t)(erow0 + mlp_chan(v, hl)) * p.out_pitch + (col - p.col0)] = acc[t][v];
                 }
             }
         }
-        item = nitem; row0 = nrow0; row = nrow; active = nactive; rc = nrc;
+    };
+    Slot s0;
+    assign(s0, blockIdx.x, 0);
+    fetch(s0);
+    if (DEPTH == 2) {
+        Slot s1;
+        long long r1 = blockIdx.x;
+        int u1 = 1;
+        if (u1 >= p.tk) { u1 = 0; r1 += gridDim.x; }
+        if (s0.valid) assign(s1, r1, u1); else s1.valid = false;
+        if (s1.valid) fetch(s1);
+        while (s0.valid) {
+            consume(s0, s1);
+            if (!s1.valid) break;
+            consume(s1, s0);
+        }
+    } else {
+        while (s0.valid) consume(s0, s0);
     }
     if (p.emode != E_PLAIN && p.stats) {
+        // per-channel sums of this workgroup's rows: the eight waves' partial sums meet in LDS and leave as ONE row of the
+        // (row workgroups, 2, N) partial array -- no atomics (2048 waves adding into the same 2N addresses serialise in the
+        // L2 for ~100 us per pass), and the finalisation kernel adds the rows in a fixed order
+        __syncthreads();                                           // the weight stages are dead: reuse their LDS
+        double *red = reinterpret_cast<double *>(smem);
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
-            const int col = (slab * NS + t) * 32 + s;
             const double d1 = sd1[t] + __shfl_xor(sd1[t], 32), d2 = sd2[t] + __shfl_xor(sd2[t], 32);
-            if (hl == 0 && col < p.N) {
-                atomicAdd(p.stats + col, d1);
-                atomicAdd(p.stats + p.N + col, d2);
+            if (hl == 0) {
+                red[(wave * 2 + 0) * (NS * 32) + t * 32 + s] = d1;
+                red[(wave * 2 + 1) * (NS * 32) + t * 32 + s] = d2;
             }
+        }
+        __syncthreads();
+        if (tid < 2 * NS * 32) {
+            const int which = tid / (NS * 32), c = tid % (NS * 32), col = slab * NS * 32 + c;
+            double sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < kTlWaves; ++w) sum += red[(w * 2 + which) * (NS * 32) + c];
+            if (col < p.N) p.stats[((size_t)blockIdx.x * 2 + which) * p.N + col] = sum;
         }
     }
 }
@@ -449,14 +538,35 @@ __global__ __launch_bounds__(256) void tl_pack_kernel(const float *__restrict__ 
 
 // ---- per-channel finalisation kernels (one thread per channel) -----------------------------------------------------------
 // batch moments -> (mean, invstd, a, c), running statistics (torch.nn.BatchNorm semantics: unbiased variance in the average)
-__global__ void tl_bn_finalize_kernel(const double *__restrict__ stats, int N, double count, const float *__restrict__ gamma,
-                                      const float *__restrict__ beta, float *running_mean, float *running_var,
-                                      float momentum, float eps, float *__restrict__ save)
+// the per-channel sums arrive as `nparts` partial rows; a block of 256 threads owns 32 channels and adds the rows eight at a time
+__device__ __forceinline__ void tl_sum_parts(const double *__restrict__ stats, int nparts, int N, double &s1, double &s2)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
-    const double mean = stats[c] / count;
-    double var = stats[N + c] / count - mean * mean;
+    __shared__ double sh[2][8][32];
+    const int g = threadIdx.x >> 5, c = blockIdx.x * 32 + (threadIdx.x & 31);
+    double a = 0.0, b = 0.0;
+    if (c < N)
+        for (int q = g; q < nparts; q += 8) { a += stats[((size_t)q * 2) * N + c]; b += stats[((size_t)q * 2 + 1) * N + c]; }
+    sh[0][g][threadIdx.x & 31] = a;
+    sh[1][g][threadIdx.x & 31] = b;
+    __syncthreads();
+    s1 = 0.0; s2 = 0.0;
+    if (g == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s1 += sh[0][i][threadIdx.x & 31]; s2 += sh[1][i][threadIdx.x & 31]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void tl_bn_finalize_kernel(const double *__restrict__ stats, int nparts, int N, double count,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             float *running_mean, float *running_var, float momentum, float eps,
+                                                             float *__restrict__ save)
+{
+    double s1, s2;
+    tl_sum_parts(stats, nparts, N, s1, s2);
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    if (threadIdx.x >= 32 || c >= N) return;
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const double invstd = 1.0 / sqrt(var + (double)eps);
     const double a = (double)gamma[c] * invstd;
@@ -472,15 +582,17 @@ __global__ void tl_bn_finalize_kernel(const double *__restrict__ stats, int N, d
 }
 
 // (sum dy, sum dy z) -> grad_gamma, grad_beta and the coefficients of dz = s dy - c0 - c1 z
-__global__ void tl_bn_backward_finalize_kernel(const double *__restrict__ stats, int N, double count,
-                                               const float *__restrict__ gamma, const float *__restrict__ save,
-                                               float *__restrict__ grad_gamma, float *__restrict__ grad_beta,
-                                               float *__restrict__ coef)
+__global__ __launch_bounds__(256) void tl_bn_backward_finalize_kernel(const double *__restrict__ stats, int nparts, int N,
+                                                                      double count, const float *__restrict__ gamma,
+                                                                      const float *__restrict__ save, float *__restrict__ grad_gamma,
+                                                                      float *__restrict__ grad_beta, float *__restrict__ coef)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+    double s1, s2;
+    tl_sum_parts(stats, nparts, N, s1, s2);
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    if (threadIdx.x >= 32 || c >= N) return;
     const double mean = save[c], invstd = save[N + c];
-    const double dbeta = stats[c], dgamma = (stats[N + c] - mean * stats[c]) * invstd;
+    const double dbeta = s1, dgamma = (s2 - mean * s1) * invstd;
     const double s = (double)gamma[c] * invstd;
     const double c1 = s * dgamma * invstd / count;
     const double c0 = s * dbeta / count - c1 * mean;
@@ -541,8 +653,8 @@ __global__ __launch_bounds__(256) void tl_pool_grad_kernel(long long groups, int
     __syncthreads();
     if (ry == 0 && c < N) {
         const int x = threadIdx.x & 63;
-        atomicAdd(stats + c, sh[0][0][x] + sh[0][1][x] + sh[0][2][x] + sh[0][3][x]);
-        atomicAdd(stats + N + c, sh[1][0][x] + sh[1][1][x] + sh[1][2][x] + sh[1][3][x]);
+        stats[((size_t)blockIdx.y * 2) * N + c] = sh[0][0][x] + sh[0][1][x] + sh[0][2][x] + sh[0][3][x];
+        stats[((size_t)blockIdx.y * 2 + 1) * N + c] = sh[1][0][x] + sh[1][1][x] + sh[1][2][x] + sh[1][3][x];
     }
 }
 
@@ -585,8 +697,8 @@ __global__ __launch_bounds__(256) void tl_top_grad_kernel(long long rows, int N,
     __syncthreads();
     if (ry == 0 && c < N) {
         const int x = threadIdx.x & 63;
-        atomicAdd(stats + c, sh[0][0][x] + sh[0][1][x] + sh[0][2][x] + sh[0][3][x]);
-        atomicAdd(stats + N + c, sh[1][0][x] + sh[1][1][x] + sh[1][2][x] + sh[1][3][x]);
+        stats[((size_t)blockIdx.y * 2) * N + c] = sh[0][0][x] + sh[0][1][x] + sh[0][2][x] + sh[0][3][x];
+        stats[((size_t)blockIdx.y * 2 + 1) * N + c] = sh[1][0][x] + sh[1][1][x] + sh[1][2][x] + sh[1][3][x];
     }
 }
 
@@ -672,8 +784,27 @@ __device__ __forceinline__ void wg_load_unit(const TlWgrad &p, long long row0, i
     }
 }
 
+// the per-channel parameters of a unit's lane (its channel never changes): fetched ONCE, before the block loop -- a
+// global load inside the loop would have to be waited for with vmcnt(0), which also drains the row prefetch
+struct WgPar { float p0, p1, p2; };
+
+__device__ __forceinline__ WgPar wg_unit_params(const TlWgrad &p, int unit, int us, int ts, int lane)
+{
+    const int tile = unit >> 1, c = lane & 31;
+    WgPar w = {1.0f, 0.0f, 0.0f};
+    if (tile < p.tus) {
+        const int ch = (us * p.tus + tile) * 32 + c;
+        if (p.amode == A_RELU && ch < p.KI) { w.p0 = p.pa[ch]; w.p1 = p.pc[ch]; }
+    } else {
+        const int ch = (ts * p.tts + tile - p.tus) * 32 + c;
+        if (ch < p.NO) { w.p0 = p.coef[ch]; w.p1 = p.coef[p.NO + ch]; w.p2 = p.coef[2 * p.NO + ch]; }
+    }
+    return w;
+}
+
 // prologue + split of a loaded unit -> its three fragments in the block image ([tile][level][e][lane] 16-byte vectors)
-__device__ __forceinline__ void wg_store_unit(const TlWgrad &p, const WgRaw &r, int unit, int us, int ts, int lane, u32x4 *img)
+__device__ __forceinline__ void wg_store_unit(const TlWgrad &p, const WgRaw &r, const WgPar &w, int unit, int us, int ts, int lane,
+                                              u32x4 *img)
 {
     const int tile = unit >> 1, e = unit & 1, c = lane & 31;
     f32x16 x;
@@ -682,9 +813,8 @@ __device__ __forceinline__ void wg_store_unit(const TlWgrad &p, const WgRaw &r, 
     if (tile < p.tus) {
         const int ch = (us * p.tus + tile) * 32 + c;
         if (p.amode == A_RELU && ch < p.KI) {
-            const float a = p.pa[ch], cc = p.pc[ch];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = vmax(__fadd_rn(__fmul_rn(a, r.z[j]), cc), 0.0f);
+            for (int j = 0; j < 8; ++j) x[j] = vmax(__fadd_rn(__fmul_rn(w.p0, r.z[j]), w.p1), 0.0f);
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] = r.z[j];
@@ -692,11 +822,10 @@ __device__ __forceinline__ void wg_store_unit(const TlWgrad &p, const WgRaw &r, 
     } else {
         const int ch = (ts * p.tts + tile - p.tus) * 32 + c;
         if (ch < p.NO) {
-            const float s = p.coef[ch], c0 = p.coef[p.NO + ch], c1 = p.coef[2 * p.NO + ch];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float dy = p.dmode == A_DZ_POOL ? (r.sel == j ? r.gq : 0.0f) : r.g[j];
-                x[j] = __fsub_rn(__fsub_rn(__fmul_rn(s, dy), c0), __fmul_rn(c1, r.z[j]));
+                x[j] = __fsub_rn(__fsub_rn(__fmul_rn(w.p0, dy), w.p1), __fmul_rn(w.p2, r.z[j]));
             }
         }
     }
@@ -727,6 +856,10 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[i][v] = 0.0f;
     WgRaw ra[UPW], rb[UPW];
+    WgPar par[UPW];
+#pragma unroll
+    for (int i = 0; i < UPW; ++i)
+        if (wave + 8 * i < nunits) par[i] = wg_unit_params(p, wave + 8 * i, us, ts, lane);
     auto load = [&](long long b, WgRaw (&r)[UPW]) {
         if (b < blocks) {
 #pragma unroll
@@ -737,7 +870,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
     auto block = [&](long long b, WgRaw (&r)[UPW], u32x4 *img) {
 #pragma unroll
         for (int i = 0; i < UPW; ++i)
-            if (wave + 8 * i < nunits) wg_store_unit(p, r[i], wave + 8 * i, us, ts, lane, img);
+            if (wave + 8 * i < nunits) wg_store_unit(p, r[i], par[i], wave + 8 * i, us, ts, lane, img);
         __syncthreads();
         load(b + 2 * step, r);
 #pragma unroll
@@ -894,7 +1027,7 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
         if (cin <= 0 || cout <= 0 || cout % 4) return false;
         const GemmShape g = backward ? gemm_shape(cout, cin) : gemm_shape(cin, cout);
         pl.pack[l] = off; off = align_up(off + g.pack_bytes);
-        pl.stats[l] = off; off = align_up(off + sizeof(double) * 2 * cout);
+        pl.stats[l] = off; off = align_up(off + sizeof(double) * 2 * cout * kMaxParts);
         if (backward) { pl.coef[l] = off; off = align_up(off + sizeof(float) * 3 * cout); }
         if (cout > maxw) maxw = cout;
     }
@@ -960,14 +1093,21 @@ static int launch_gemm_ns(int amode, const TlGemm &p, const GemmShape &g, dim3 g
     return PN2_E_ARG;
 }
 
-static int launch_gemm(int amode, TlGemm &p, const GemmShape &g, hipStream_t st)
+static int launch_gemm(int amode, TlGemm &p, const GemmShape &g, hipStream_t st, int *nparts = nullptr)
 {
     p.K = g.K; p.N = g.N; p.tk = g.tk; p.resident = g.resident;
+    {
+        const int mode = env_int("PN2_TL_NT", -1);                 // lab switch: 0 never, 1 always, else by size
+        const size_t obytes = (size_t)p.rows * g.N * sizeof(float);
+        p.nt = mode == 0 ? 0 : mode == 1 ? 1 : obytes >= ((size_t)128 << 20);
+        p.lab = env_int("PN2_TL_LAB", 0);
+    }
     const long long rounds = (p.rows / 32 + kTlWaves - 1) / kTlWaves;
-    long long gx = 256 / g.slabs;                              // persistent: one 8-wave workgroup per CU over all slabs
+    long long gx = kMaxParts / g.slabs;                        // persistent: one 8-wave workgroup per CU over all slabs
     if (gx < 1) gx = 1;
     if (gx > rounds) gx = rounds;
     const dim3 grid((unsigned)gx, (unsigned)g.slabs);
+    if (nparts) *nparts = (int)gx;
     if (g.ns == 4) return launch_gemm_ns<4>(amode, p, g, grid, st);
     if (g.ns == 2) return launch_gemm_ns<2>(amode, p, g, grid, st);
     return launch_gemm_ns<1>(amode, p, g, grid, st);
@@ -1074,7 +1214,6 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
         const pn2_bn_layer &L = layers[l];
         const GemmShape g = gemm_shape(L.cin, L.cout);
         if (int rc = launch_pack(L.weight, L.w_stride_k, L.w_stride_n, g, base + pl.pack[l], st)) return rc;
-        if (hipError_t e = hipMemsetAsync(base + pl.stats[l], 0, sizeof(double) * 2 * L.cout, st)) return (int)e;
     }
     for (int l = 0; l < nlayers; ++l) {
         const pn2_bn_layer &L = layers[l];
@@ -1100,9 +1239,10 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
             p.pamin = reinterpret_cast<int *>(pp + 3 * parts * L.cout);
             p.prow = pool_rows == 16 ? 16 : 32;
         }
-        if (int rc = launch_gemm(amode, p, g, st)) return rc;
-        if (int rc = launch(tl_bn_finalize_kernel, dim3((unsigned)((L.cout + 127) / 128)), dim3(128), 0, st,
-                            reinterpret_cast<const double *>(base + pl.stats[l]), L.cout, (double)rows, L.gamma, L.beta,
+        int nparts = 0;
+        if (int rc = launch_gemm(amode, p, g, st, &nparts)) return rc;
+        if (int rc = launch(tl_bn_finalize_kernel, dim3((unsigned)((L.cout + 31) / 32)), dim3(256), 0, st,
+                            reinterpret_cast<const double *>(base + pl.stats[l]), nparts, L.cout, (double)rows, L.gamma, L.beta,
                             L.running_mean, L.running_var, L.momentum, L.eps, L.save)) return rc;
         if (last && pool_rows) {
             const long long groups = rows / pool_rows;
@@ -1144,21 +1284,23 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
             const GemmShape g = gemm_shape(L.cout, L.cin);                // dy_{l-1} = dz_l . W_l^T
             if (int rc = launch_pack(L.weight, L.w_stride_n, L.w_stride_k, g, base + pl.pack[l], st)) return rc;
         }
-        if (hipError_t e = hipMemsetAsync(base + pl.stats[l], 0, sizeof(double) * 2 * L.cout, st)) return (int)e;
     }
     float *ga = reinterpret_cast<float *>(base + pl.ga), *gb = reinterpret_cast<float *>(base + pl.gb);
     float *gq = reinterpret_cast<float *>(base + pl.gq);
     const pn2_bn_layer &T = layers[nlayers - 1];
+    int nparts[8];                                      // rows of each layer's partial-sum array
     // top of the stack: dy_L and its two column sums
     if (pool_rows) {
         const long long groups = rows / pool_rows;
         long long gy = (groups + 63) / 64;
-        if (gy > 256) gy = 256;
+        if (gy > kMaxParts) gy = kMaxParts;
+        nparts[nlayers - 1] = (int)gy;
         if (int rc = launch(tl_pool_grad_kernel, dim3((unsigned)((T.cout + 63) / 64), (unsigned)gy), dim3(256), 0, st, groups, T.cout, out,
                             grad_out, zsel, gq, reinterpret_cast<double *>(base + pl.stats[nlayers - 1]))) return rc;
     } else {
         long long gy = (rows + 255) / 256;
-        if (gy > 512) gy = 512;
+        if (gy > kMaxParts) gy = kMaxParts;
+        nparts[nlayers - 1] = (int)gy;
         if (int rc = launch(tl_top_grad_kernel, dim3((unsigned)((T.cout + 63) / 64), (unsigned)gy), dim3(256), 0, st, rows, T.cout, out,
                             grad_out, (const float *)T.z, ga, reinterpret_cast<double *>(base + pl.stats[nlayers - 1]))) return rc;
     }
@@ -1166,8 +1308,8 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
     for (int l = nlayers - 1; l >= 0; --l) {
         const pn2_bn_layer &L = layers[l];
         float *coef = reinterpret_cast<float *>(base + pl.coef[l]);
-        if (int rc = launch(tl_bn_backward_finalize_kernel, dim3((unsigned)((L.cout + 127) / 128)), dim3(128), 0, st,
-                            reinterpret_cast<const double *>(base + pl.stats[l]), L.cout, (double)rows, L.gamma,
+        if (int rc = launch(tl_bn_backward_finalize_kernel, dim3((unsigned)((L.cout + 31) / 32)), dim3(256), 0, st,
+                            reinterpret_cast<const double *>(base + pl.stats[l]), nparts[l], L.cout, (double)rows, L.gamma,
                             (const float *)L.save, L.grad_gamma, L.grad_beta, coef)) return rc;
         const bool pooled_top = pool_rows && l == nlayers - 1;
         // weight gradient
@@ -1219,7 +1361,9 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
                     p.out = grad_x; p.out_pitch = L.cin; p.col0 = 0; p.col1 = L.cin;
                 }
             }
-            if (int rc = launch_gemm(pooled_top ? A_DZ_POOL : A_DZ, p, g, st)) return rc;
+            int np = 0;
+            if (int rc = launch_gemm(pooled_top ? A_DZ_POOL : A_DZ, p, g, st, &np)) return rc;
+            if (l > 0) nparts[l - 1] = np;
         }
         float *tmp = gcur; gcur = gnext; gnext = tmp;
     }
