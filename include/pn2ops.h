@@ -329,6 +329,10 @@ typedef struct pn2_bn_layer {
  * group != NULL: layer 1 reads the grouped rows; else x is the (rows, cin_1) input. */
 long long pn2_mlp_train_ws_bytes(long long rows, int nlayers, const int *widths /* cin_1, cout_1 .. cout_L */,
                                  int pool_rows, int backward);
+/* 1: layers[L-1].z (the top layer's pre-norm tensor) is written by forward and read by backward; 0: it is neither --
+ * pooled stacks of >= 2 layers on large levels run the passes that would read z_L on the layer's INPUT instead
+ * (z_L = h W + b; csrc/train_mlp.hip, tl_top_mats_kernel), and layers[L-1].z may be NULL. */
+int pn2_mlp_train_top_stored(long long rows, int nlayers, const int *widths, int pool_rows);
 int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group,
                           const float *x, int pool_rows, float *out, int *argsel, float *zsel, void *ws, void *stream);
 /* grad_out: shape of out. grad_x: (rows, cin_1) or NULL (plain input). grad_feat_rows: (rows, cfeat) -- the gradient

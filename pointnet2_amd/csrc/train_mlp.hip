@@ -40,7 +40,7 @@ constexpr int kTlWaves = kTlThreads / 64;
 constexpr int kPairVec = kPairWords / 4; // 16-byte vectors of one 32x32 weight tile pair
 constexpr int kMaxParts = 256;           // rows of a per-channel partial-sum array (one per row workgroup)
 
-enum { A_PLAIN = 0, A_GATHER = 1, A_RELU = 2, A_DZ = 3, A_DZ_POOL = 4 };
+enum { A_PLAIN = 0, A_GATHER = 1, A_RELU = 2, A_DZ = 3, A_DZ_POOL = 4, A_FILL = 5 };
 enum { E_STORE = 0, E_POOL = 1, E_MASK = 2, E_PLAIN = 3 };
 
 struct TlGather {
@@ -59,7 +59,12 @@ struct TlGemm {
     const float *G;             // A_DZ: dy (rows, K); A_DZ_POOL: gq (groups, K)
     const int *argsel;          // A_DZ_POOL: (groups, K)
     const float *p0, *p1, *p2;  // A_RELU: a, c; A_DZ*: s, c0, c1   (K floats each)
-    int group_rows;             // A_DZ_POOL
+    int group_rows;             // A_DZ_POOL, A_FILL
+    // A_FILL (pooled top layer without its pre-norm tensor, see pn2_mlp_train_backward): k tiles [0, tk0) are the routed
+    // gradient s dy -- (argsel == sample) ? p0[k] * G[group][k] : 0, K0 channels -- and k tiles [tk0, tk) are
+    // h = relu(q0 * A2 + q1) of the layer below (K1 channels, pitch K1)
+    int tk0, K0, K1;
+    const float *A2, *q0, *q1;
     TlGather g;                 // A_GATHER
     const u32x4 *wpacked;       // [slab][k tile][NS] tile pairs
     const float *bias;          // (N) or nullptr
@@ -90,7 +95,7 @@ __device__ __forceinline__ RowCtx tl_row_ctx(const TlGemm &p, long long row, boo
         c.sample = (int)(row - c.grp * p.g.nsample);
         c.cloud = c.grp / p.g.m;
         c.pt = p.g.idx ? p.g.idx[row] : c.sample;
-    } else if (AMODE == A_DZ_POOL) {
+    } else if (AMODE == A_DZ_POOL || AMODE == A_FILL) {
         c.grp = row / p.group_rows;
         c.sample = (int)(row - c.grp * p.group_rows);
     }
@@ -152,8 +157,41 @@ __device__ __forceinline__ void tl_load_raw(const TlGemm &p, long long row0, lon
             }
         return;
     }
-    // rows of the item: descriptor at the item's first row, lane offset = its row and half, uniform offset = the k tile
     const int s = (int)(row - row0);
+    if (AMODE == A_FILL) {
+        if (u < p.tk0) {                                           // (groups, K0) routed gradient + its sample numbers
+            const float *pg = p.G + (size_t)rc.grp * p.K0;
+            const int *ps = p.argsel + (size_t)rc.grp * p.K0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int k = 32 * u + 16 * e + 8 * hl + 4 * q;
+                    int4 s4 = {-1, -1, -1, -1};
+                    if (k < p.K0) {
+                        const float4 t = ld4(pg + k);
+                        r.a[8 * e + 4 * q] = t.x; r.a[8 * e + 4 * q + 1] = t.y; r.a[8 * e + 4 * q + 2] = t.z; r.a[8 * e + 4 * q + 3] = t.w;
+                        s4 = *reinterpret_cast<const int4 *>(ps + k);
+                    }
+                    r.sel[2 * e + q] = s4;
+                }
+        } else {                                                   // rows of the layer below
+            const rsrc_t r2 = make_rsrc(p.A2 + (size_t)row0 * p.K1, 32u * (unsigned)p.K1 * 4u);
+            const int voff2 = (s * p.K1 + 8 * hl) * 4, soff2 = (u - p.tk0) * 128;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int k = 32 * (u - p.tk0) + 16 * e + 8 * hl + 4 * q;
+                    if (k < p.K1) {
+                        const float4 t = bload4(r2, voff2 + (16 * e + 4 * q) * 4, soff2);
+                        r.a[8 * e + 4 * q] = t.x; r.a[8 * e + 4 * q + 1] = t.y; r.a[8 * e + 4 * q + 2] = t.z; r.a[8 * e + 4 * q + 3] = t.w;
+                    }
+                }
+        }
+        return;
+    }
+    // rows of the item: descriptor at the item's first row, lane offset = its row and half, uniform offset = the k tile
     const rsrc_t ra = make_rsrc(p.A + (size_t)row0 * p.K, 32u * (unsigned)p.K * 4u);
     const int voff = (s * p.K + 8 * hl) * 4, soff = u * 128;
 #pragma unroll
@@ -200,12 +238,31 @@ __device__ __forceinline__ void tl_load_raw(const TlGemm &p, long long row0, lon
 
 // the pass's prologue on the 16 values of one k tile; lp*: the per-channel parameters in LDS (zero beyond K)
 template <int AMODE>
-__device__ __forceinline__ f32x16 tl_finish(const ARaw &r, const RowCtx &rc, int u, int hl, const float *lp0, const float *lp1,
-                                            const float *lp2)
+__device__ __forceinline__ f32x16 tl_finish(const ARaw &r, const RowCtx &rc, int u, int tk0, int hl, const float *lp0,
+                                            const float *lp1, const float *lp2)
 {
     if (AMODE == A_PLAIN || AMODE == A_GATHER) return r.a;
     f32x16 x;
     const int sample = rc.sample;
+    if (AMODE == A_FILL) {                                         // lp0: s (fill tiles) / a (rows of the layer below); lp1: c
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = 32 * u + 16 * e + 8 * hl + 4 * q;
+                const float4 c0 = ld4(lp0 + k), c1 = ld4(lp1 + k);
+                const float a0[4] = {c0.x, c0.y, c0.z, c0.w}, a1[4] = {c1.x, c1.y, c1.z, c1.w};
+                const int4 s4 = r.sel[2 * e + q];
+                const int sl[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int v = 8 * e + 4 * q + i;
+                    if (u < tk0) x[v] = sl[i] == sample ? __fmul_rn(a0[i], r.a[v]) : 0.0f;        // the pool routes dy to ONE sample
+                    else x[v] = vmax(__fadd_rn(__fmul_rn(a0[i], r.a[v]), a1[i]), 0.0f);
+                }
+            }
+        return x;
+    }
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -251,11 +308,18 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
     const int slab = blockIdx.y;
     constexpr int kStageV = NS * kPairVec;
     constexpr int PV = (kStageV + kTlThreads - 1) / kTlThreads;
-    constexpr bool PREFZ = AMODE == A_DZ && NS <= 2;              // prefetch the ReLU mask's source rows (E_MASK)
+    constexpr bool PREFZ = (AMODE == A_DZ || AMODE == A_FILL) && NS <= 2;              // prefetch the ReLU mask's source rows (E_MASK)
     constexpr int DEPTH = AMODE >= A_DZ ? 1 : 2;                  // A tiles in flight ahead of the MFMAs (register budget)
     const u32x4 *wsrc = p.wpacked + (size_t)slab * p.tk * kStageV;
 
-    if (AMODE >= A_RELU) {
+    if (AMODE == A_FILL) {
+        for (int i = tid; i < kpad; i += kTlThreads) {
+            const int j = i - p.tk0 * 32;
+            lp0[i] = i < p.K0 ? p.p0[i] : (j >= 0 && j < p.K1) ? p.q0[j] : 0.0f;
+            lp1[i] = (j >= 0 && j < p.K1) ? p.q1[j] : 0.0f;
+            lp2[i] = 0.0f;
+        }
+    } else if (AMODE >= A_RELU) {
         for (int i = tid; i < kpad; i += kTlThreads) {
             const bool in = i < p.K;
             lp0[i] = in ? p.p0[i] : 0.0f;
@@ -284,14 +348,15 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
 
     // per-column parameters of the epilogue (the lane's columns never change): fetched once -- a global load inside the
     // round loop would be waited for with vmcnt(0), which also drains the A prefetch
-    float ep0[NS], ep1[NS];
+    float ep0[NS], ep1[NS], ep2[NS];
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
         const int col = (slab * NS + t) * 32 + s;
-        ep0[t] = 0.0f; ep1[t] = 0.0f;
+        ep0[t] = 0.0f; ep1[t] = 0.0f; ep2[t] = 0.0f;
         if (col < p.N) {
             if (p.emode == E_MASK) { ep0[t] = p.ea[col]; ep1[t] = p.ec[col]; }
             else if (p.emode != E_PLAIN && p.bias) ep0[t] = p.bias[col];
+            if ((p.emode == E_MASK || p.emode == E_PLAIN) && p.bias) ep2[t] = p.bias[col];
         }
     }
     // The A operand is a STREAM of k tiles -- (round, u) in consumption order, across rounds -- and runs TWO tiles ahead of
@@ -350,7 +415,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[t][v] = 0.0f;
         }
-        const ActSplit sp = split_act(tl_finish<AMODE>(sl.raw, sl.rc, sl.u, hl, lp0, lp1, lp2));
+        const ActSplit sp = split_act(tl_finish<AMODE>(sl.raw, sl.rc, sl.u, p.tk0, hl, lp0, lp1, lp2));
         const bool last = sl.u + 1 == p.tk;
         const long long erow0 = sl.row0, eitem = sl.round * kTlWaves + wave;
         const bool eactive = sl.active;
@@ -403,7 +468,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
                     sd1[t] += (double)s1;
                     sd2[t] += (double)s2;
                 }
-                if (ok && !(p.lab & 1)) {
+                if (ok && !(p.lab & 1) && p.out) {
                     if (p.nt) {
 #pragma unroll
                         for (int v = 0; v < 16; ++v) bstore<true>(val[v], ro, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
@@ -448,7 +513,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
 #pragma unroll
                     for (int v = 0; v < 16; ++v) {
                         const float y = __fadd_rn(__fmul_rn(ea, zz[v]), ec);
-                        const float g = y > 0.0f ? acc[t][v] : 0.0f;                      // ReLU of the layer below
+                        const float g = y > 0.0f ? __fadd_rn(acc[t][v], ep2[t]) : 0.0f;   // ReLU of the layer below
                         if (p.nt) bstore<true>(g, ro, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
                         else bstore<false>(g, ro, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
                         s1 = __fadd_rn(s1, g);
@@ -461,7 +526,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
                 if (eactive && col >= p.col0 && col < p.col1) {
 #pragma unroll
                     for (int v = 0; v < 16; ++v)
-                        p.out[(size_t)(erow0 + mlp_chan(v, hl)) * p.out_pitch + (col - p.col0)] = acc[t][v];
+                        p.out[(size_t)(erow0 + mlp_chan(v, hl)) * p.out_pitch + (col - p.col0)] = __fadd_rn(acc[t][v], ep2[t]);
                 }
             }
         }
@@ -709,8 +774,9 @@ struct TlWgrad {
     int KI;
     const float *A, *pa, *pc;
     TlGather g;
-    int dmode;                  // A_DZ / A_DZ_POOL
-    int NO;
+    int dmode;                  // A_DZ / A_DZ_POOL / A_FILL
+    int NO;                     // A_FILL: tf * 32 + tx * 32 + 32 columns: [routed gradient (NF) | h again (KI) | ones], see below
+    int tf, NF;                 // A_FILL: tiles / channels of the routed-gradient block
     const float *Z, *G;
     const int *argsel;
     const float *coef;          // (3, NO): s, c0, c1
@@ -767,7 +833,26 @@ __device__ __forceinline__ void wg_load_unit(const TlWgrad &p, long long row0, i
         for (int j = 0; j < 8; ++j) r.z[j] = bload(rs, voff, j * p.KI * 4);
         return;
     }
-    const int ch = (ts * p.tts + tile - p.tus) * 32 + c;            // dz = s dy - c0 - c1 z
+    const int tg = ts * p.tts + tile - p.tus;                      // tile of the second operand
+    if (p.dmode == A_FILL) {
+        // second operand of the pooled top layer: [s dy routed to the pooled samples | h itself | a column of ones]
+        if (tg < p.tf) {
+            const int ch = tg * 32 + c;
+            if (ch >= p.NF) return;
+            const int grp = (int)((unsigned)rbase / (unsigned)p.group_rows);
+            r.gq = p.G[(size_t)grp * p.NF + ch];
+            r.sel = p.argsel[(size_t)grp * p.NF + ch] - ((int)rbase - grp * p.group_rows);
+        } else if (tg < p.tf + (p.KI + 31) / 32) {
+            const int ch = (tg - p.tf) * 32 + c;
+            if (ch >= p.KI) return;
+            const rsrc_t rs = make_rsrc(p.A + (size_t)row0 * p.KI, 32u * (unsigned)p.KI * 4u);
+            const int voff = ((16 * e + 8 * hl) * p.KI + ch) * 4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r.z[j] = bload(rs, voff, j * p.KI * 4);
+        }
+        return;
+    }
+    const int ch = tg * 32 + c;                                    // dz = s dy - c0 - c1 z
     if (ch >= p.NO) return;
     const rsrc_t rz = make_rsrc(p.Z + (size_t)row0 * p.NO, 32u * (unsigned)p.NO * 4u);
     const int voff = ((16 * e + 8 * hl) * p.NO + ch) * 4;
@@ -795,6 +880,15 @@ __device__ __forceinline__ WgPar wg_unit_params(const TlWgrad &p, int unit, int 
     if (tile < p.tus) {
         const int ch = (us * p.tus + tile) * 32 + c;
         if (p.amode == A_RELU && ch < p.KI) { w.p0 = p.pa[ch]; w.p1 = p.pc[ch]; }
+    } else if (p.dmode == A_FILL) {
+        const int tg = ts * p.tts + tile - p.tus;
+        if (tg < p.tf) {
+            const int ch = tg * 32 + c;
+            if (ch < p.NF) w.p0 = p.coef[ch];                      // s
+        } else {
+            const int ch = (tg - p.tf) * 32 + c;
+            if (ch < p.KI) { w.p0 = p.pa[ch]; w.p1 = p.pc[ch]; }    // h = relu(a z + c), as the first operand
+        }
     } else {
         const int ch = (ts * p.tts + tile - p.tus) * 32 + c;
         if (ch < p.NO) { w.p0 = p.coef[ch]; w.p1 = p.coef[p.NO + ch]; w.p2 = p.coef[2 * p.NO + ch]; }
@@ -818,6 +912,22 @@ __device__ __forceinline__ void wg_store_unit(const TlWgrad &p, const WgRaw &r, 
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] = r.z[j];
+        }
+    } else if (p.dmode == A_FILL) {
+        const int tg = ts * p.tts + tile - p.tus, tx = (p.KI + 31) / 32;
+        if (tg < p.tf) {
+            if (tg * 32 + c < p.NF) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = r.sel == j ? __fmul_rn(w.p0, r.gq) : 0.0f;
+            }
+        } else if (tg < p.tf + tx) {
+            if ((tg - p.tf) * 32 + c < p.KI) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = vmax(__fadd_rn(__fmul_rn(w.p0, r.z[j]), w.p1), 0.0f);
+            }
+        } else if (tg == p.tf + tx && c == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = 1.0f;                // column of ones: sum over the rows of h
         }
     } else {
         const int ch = (ts * p.tts + tile - p.tus) * 32 + c;
@@ -929,7 +1039,7 @@ __global__ __launch_bounds__(256) void tl_wgrad_reduce_a_kernel(const float4 *__
 // stage B: fp64 sum over the remaining partials, written with the caller's weight strides
 __global__ __launch_bounds__(256) void tl_wgrad_reduce_b_kernel(const float *__restrict__ in, long long nw, int TU, int TT,
                                                                 int tslabs, int KI, int NO, float *__restrict__ gw,
-                                                                long long sk, long long sn)
+                                                                long long sk, long long sn, double *__restrict__ plain)
 {
     const long long total = (long long)KI * NO;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -941,7 +1051,58 @@ __global__ __launch_bounds__(256) void tl_wgrad_reduce_b_kernel(const float *__r
         const size_t e = (size_t)TU * TT * 1024, off = (size_t)(ul * TT + tl) * 1024 + (v >> 2) * 256 + lane * 4 + (v & 3);
         double sum = 0.0;
         for (long long w = 0; w < nw; ++w) sum += (double)in[(slab * nw + w) * e + off];
-        gw[k * sk + n * sn] = (float)sum;
+        if (plain) plain[i] = sum;                                 // (KI, NO) row-major fp64, for the pooled top layer's fix-up
+        else gw[k * sk + n * sn] = (float)sum;
+    }
+}
+
+// ---- pooled top layer WITHOUT its pre-norm tensor ------------------------------------------------------------------------
+// z_L (rows, C_L) is the largest tensor of an SA level and is only ever needed in dz_L = s dy_L - c0 - c1 z_L. With
+// z_L = h W + b (h = the layer's input) both products that consume dz_L split into a part through the ROUTED gradient
+// (one entry per group and channel) and a part through h:
+//     dz_L W^T   = (s dy_L) W^T - h M - 1 r^T           M = W diag(c1) W^T  (K x K),   r = W (c0 + b c1)
+//     h^T dz_L   = h^T (s dy_L) - (h^T h) W diag(c1) - (h^T 1) (c0 + b c1)^T
+// so backward reads h (K channels) where it would read z_L (C_L = 2K channels in the reference stacks), forward never
+// writes z_L, and the extra matrix work is K / C_L of the layer's -- the passes are memory-bound, it is free.
+// tl_top_mats_kernel: the stacked fp32 weight of the data-gradient GEMM, rows [0, NFp) = W^T (c -> k), rows [NFp, NFp + K)
+// = -M, and its constant row -r. One thread per element, fp64 accumulation.
+__global__ __launch_bounds__(256) void tl_top_mats_kernel(const float *__restrict__ w, long long sk, long long sn, int K, int NF,
+                                                          int NFp, const float *__restrict__ coef, const float *__restrict__ bias,
+                                                          float *__restrict__ wp, float *__restrict__ rowc)
+{
+    const long long total = (long long)(NFp + K + 1) * K;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / K), n = (int)(i - (long long)r * K);
+        if (r < NFp) {
+            wp[i] = r < NF ? w[n * sk + r * sn] : 0.0f;
+        } else if (r < NFp + K) {
+            const int j = r - NFp;
+            double acc = 0.0;
+            for (int c = 0; c < NF; ++c) acc += (double)w[j * sk + c * sn] * (double)coef[2 * NF + c] * (double)w[n * sk + c * sn];
+            wp[i] = (float)(-acc);
+        } else {
+            double acc = 0.0;
+            for (int c = 0; c < NF; ++c)
+                acc += ((double)coef[NF + c] + (bias ? (double)bias[c] : 0.0) * (double)coef[2 * NF + c]) * (double)w[n * sk + c * sn];
+            rowc[n] = (float)(-acc);
+        }
+    }
+}
+
+// dW[k][n] = S[k][n] - c1[n] sum_j G[k][j] W[j][n] - sumh[k] (c0[n] + b[n] c1[n]); sf = [S | G | sumh ..] (K, ld) fp64
+__global__ __launch_bounds__(256) void tl_top_wgrad_fix_kernel(const double *__restrict__ sf, int ld, int K, int NF, int goff, int hoff,
+                                                               const float *__restrict__ w, long long sk, long long sn,
+                                                               const float *__restrict__ coef, const float *__restrict__ bias,
+                                                               float *__restrict__ gw)
+{
+    const long long total = (long long)K * NF;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int k = (int)(i / NF), n = (int)(i - (long long)k * NF);
+        const double *row = sf + (size_t)k * ld;
+        double acc = 0.0;
+        for (int j = 0; j < K; ++j) acc += row[goff + j] * (double)w[j * sk + n * sn];
+        const double c0 = coef[NF + n], c1 = coef[2 * NF + n], b = bias ? (double)bias[n] : 0.0;
+        gw[k * sk + n * sn] = (float)(row[n] - c1 * acc - row[hoff] * (c0 + b * c1));
     }
 }
 
@@ -1012,8 +1173,19 @@ struct TlPlan {
     size_t gq;                  // backward, pooled: (groups, cout_L)
     size_t ga, gb;              // backward: dy ping-pong (rows, max width)
     size_t partial, partial2;   // backward: weight-gradient partial sums
+    size_t topw, topsf;         // backward, pooled top layer without z_L: stacked fp32 weight + constant row; [S | G | sumh] fp64
     size_t total;
 };
+
+// Is the pooled top layer's pre-norm tensor z_L kept (small levels), or are the passes that would read it rewritten in
+// terms of the layer's input (tl_top_mats_kernel)? One rule for forward, backward and the caller's allocation.
+static bool top_stored(long long rows, int nlayers, const int *widths, int pool_rows)
+{
+    if (!pool_rows || nlayers < 2) return true;
+    if (env_int("PN2_TL_TOP_STORED", -1) >= 0) return env_int("PN2_TL_TOP_STORED", -1) != 0;      // lab switch
+    return (size_t)rows * widths[nlayers] * sizeof(float) < ((size_t)32 << 20);
+}
+static inline int top_cols(int kin, int cl) { return tiles(cl) * 32 + tiles(kin) * 32 + 32; }
 
 static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_rows, int backward, TlPlan &pl)
 {
@@ -1025,7 +1197,8 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
     for (int l = 0; l < nlayers; ++l) {
         const int cin = widths[l], cout = widths[l + 1];
         if (cin <= 0 || cout <= 0 || cout % 4) return false;
-        const GemmShape g = backward ? gemm_shape(cout, cin) : gemm_shape(cin, cout);
+        const bool ztop = backward && l == nlayers - 1 && !top_stored(rows, nlayers, widths, pool_rows);
+        const GemmShape g = ztop ? gemm_shape(tiles(cout) * 32 + cin, cin) : backward ? gemm_shape(cout, cin) : gemm_shape(cin, cout);
         pl.pack[l] = off; off = align_up(off + g.pack_bytes);
         pl.stats[l] = off; off = align_up(off + sizeof(double) * 2 * cout * kMaxParts);
         if (backward) { pl.coef[l] = off; off = align_up(off + sizeof(float) * 3 * cout); }
@@ -1042,13 +1215,20 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
         pl.ga = off; off = align_up(off + (size_t)rows * maxw * 4);
         pl.gb = off; off = align_up(off + (size_t)rows * maxw * 4);
         size_t p1 = 0, p2 = 0;
+        const bool ztop = !top_stored(rows, nlayers, widths, pool_rows);
         for (int l = 0; l < nlayers; ++l) {
-            const WgradShape w = wgrad_shape(rows, widths[l], widths[l + 1]);
+            const bool zt = ztop && l == nlayers - 1;
+            const WgradShape w = wgrad_shape(rows, widths[l], zt ? top_cols(widths[l], widths[l + 1]) : widths[l + 1]);
             if (w.partial_bytes > p1) p1 = w.partial_bytes;
             if (w.partial2_bytes > p2) p2 = w.partial2_bytes;
         }
         pl.partial = off; off = align_up(off + p1);
         pl.partial2 = off; off = align_up(off + p2);
+        if (ztop) {
+            const int kin = widths[nlayers - 1];
+            pl.topw = off; off = align_up(off + sizeof(float) * (size_t)(tiles(cl) * 32 + kin + 1) * kin);
+            pl.topsf = off; off = align_up(off + sizeof(double) * (size_t)kin * top_cols(kin, cl));
+        }
     }
     pl.total = off;
     return true;
@@ -1088,6 +1268,7 @@ static int launch_gemm_ns(int amode, const TlGemm &p, const GemmShape &g, dim3 g
         PN2_TL_CASE(A_RELU)
         PN2_TL_CASE(A_DZ)
         PN2_TL_CASE(A_DZ_POOL)
+        PN2_TL_CASE(A_FILL)
     }
 #undef PN2_TL_CASE
     return PN2_E_ARG;
@@ -1127,7 +1308,8 @@ static int launch_wgrad_tpw(const TlWgrad &p, const WgradShape &w, dim3 grid, hi
     return PN2_E_ARG;
 }
 
-static int launch_wgrad(TlWgrad &p, const WgradShape &w, float *partial2, const pn2_bn_layer &L, hipStream_t st)
+static int launch_wgrad(TlWgrad &p, const WgradShape &w, float *partial2, const pn2_bn_layer &L, hipStream_t st,
+                        double *plain = nullptr)
 {
     p.tus = w.tus; p.tts = w.tts; p.tslabs = w.tslabs;
     const dim3 grid((unsigned)w.gridx, (unsigned)(w.uslabs * w.tslabs));
@@ -1148,7 +1330,7 @@ static int launch_wgrad(TlWgrad &p, const WgradShape &w, float *partial2, const 
     }
     const long long total = (long long)p.KI * p.NO;
     return launch(tl_wgrad_reduce_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, nw, w.tus, w.tts, w.tslabs,
-                  p.KI, p.NO, L.grad_weight, L.w_stride_k, L.w_stride_n);
+                  p.KI, p.NO, L.grad_weight, L.w_stride_k, L.w_stride_n, plain);
 }
 
 static bool layers_ok(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group, int *widths)
@@ -1158,7 +1340,7 @@ static bool layers_ok(long long rows, int nlayers, const pn2_bn_layer *layers, c
         const pn2_bn_layer &L = layers[l];
         if (L.cin <= 0 || L.cout <= 0 || L.cout % 4) return false;
         if (l > 0 && L.cin != layers[l - 1].cout) return false;
-        if (!L.weight || !L.gamma || !L.beta || !L.z || !L.save) return false;
+        if (!L.weight || !L.gamma || !L.beta || !L.save) return false;
         widths[l] = L.cin;
         widths[l + 1] = L.cout;
     }
@@ -1180,6 +1362,14 @@ extern "C" long long pn2_mlp_train_ws_bytes(long long rows, int nlayers, const i
     pn2::TlPlan pl;
     if (!widths || !pn2::tl_plan(rows, nlayers, widths, pool_rows, backward, pl)) return -1;
     return (long long)pl.total;
+}
+
+// 1: the top layer's pre-norm tensor z_L is written by forward and read by backward (the caller allocates layers[L-1].z);
+// 0: it is not (pooled stacks of two or more layers on large levels: layers[L-1].z may be NULL)
+extern "C" int pn2_mlp_train_top_stored(long long rows, int nlayers, const int *widths, int pool_rows)
+{
+    if (!widths || nlayers < 1 || nlayers > 8) return 1;
+    return pn2::top_stored(rows, nlayers, widths, pool_rows) ? 1 : 0;
 }
 
 // byte offsets of the backward workspace's dy ping-pong buffers and per-layer sums (diagnostics: scripts/train_mlp_check.py)
@@ -1207,9 +1397,11 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
     if (pool_rows && (rows % pool_rows || (group && pool_rows != group->nsample))) return PN2_E_ARG;
     TlPlan pl;
     if (!tl_plan(rows, nlayers, widths, pool_rows, 0, pl)) return PN2_E_ARG;
+    const bool keep_top = top_stored(rows, nlayers, widths, pool_rows);
+    for (int l = 0; l < nlayers; ++l)
+        if (!layers[l].z && (keep_top || l < nlayers - 1)) return PN2_E_NULL;
     hipStream_t st = as_stream(stream);
     char *base = static_cast<char *>(ws);
-    // one clear for all layers' moment accumulators (they sit between the packed weights; clear each)
     for (int l = 0; l < nlayers; ++l) {
         const pn2_bn_layer &L = layers[l];
         const GemmShape g = gemm_shape(L.cin, L.cout);
@@ -1229,7 +1421,7 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
         p.wpacked = reinterpret_cast<const u32x4 *>(base + pl.pack[l]);
         p.bias = L.bias;
         p.emode = (last && pool_rows) ? E_POOL : E_STORE;
-        p.out = L.z;
+        p.out = (last && !keep_top) ? nullptr : L.z;              // the pooled top layer of a large level is never written
         p.stats = reinterpret_cast<double *>(base + pl.stats[l]);
         if (p.emode == E_POOL) {
             const long long parts = rows / (pool_rows == 16 ? 16 : 32);
@@ -1278,9 +1470,12 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
     hipStream_t st = as_stream(stream);
     char *base = static_cast<char *>(ws);
     const bool want_dx = group ? (grad_feat_rows && group->points && group->cfeat > 0) : grad_x != nullptr;
+    const bool ztop = !top_stored(rows, nlayers, widths, pool_rows);     // pooled top layer without z_L (tl_top_mats_kernel)
+    for (int l = 0; l < nlayers; ++l)
+        if (!layers[l].z && !(ztop && l == nlayers - 1)) return PN2_E_NULL;
     for (int l = 0; l < nlayers; ++l) {
         const pn2_bn_layer &L = layers[l];
-        if (l > 0 || want_dx) {
+        if ((l > 0 || want_dx) && !(ztop && l == nlayers - 1)) {
             const GemmShape g = gemm_shape(L.cout, L.cin);                // dy_{l-1} = dz_l . W_l^T
             if (int rc = launch_pack(L.weight, L.w_stride_n, L.w_stride_k, g, base + pl.pack[l], st)) return rc;
         }
@@ -1312,6 +1507,58 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
                             reinterpret_cast<const double *>(base + pl.stats[l]), nparts[l], L.cout, (double)rows, L.gamma,
                             (const float *)L.save, L.grad_gamma, L.grad_beta, coef)) return rc;
         const bool pooled_top = pool_rows && l == nlayers - 1;
+        if (pooled_top && ztop) {
+            // ---- the pooled top layer in terms of its input h = relu(a z_{l-1} + c): see tl_top_mats_kernel
+            const pn2_bn_layer &D = layers[l - 1];
+            const int K = L.cin, NF = L.cout, tf = tiles(NF), NFp = tf * 32, ld = top_cols(K, NF);
+            float *wp = reinterpret_cast<float *>(base + pl.topw), *rowc = wp + (size_t)(NFp + K) * K;
+            double *sf = reinterpret_cast<double *>(base + pl.topsf);
+            {
+                long long blocks = ((long long)(NFp + K + 1) * K + 255) / 256;
+                if (blocks > 4096) blocks = 4096;
+                if (int rc = launch(tl_top_mats_kernel, dim3((unsigned)blocks), dim3(256), 0, st, L.weight, L.w_stride_k, L.w_stride_n,
+                                    K, NF, NFp, (const float *)coef, L.bias, wp, rowc)) return rc;
+            }
+            {
+                TlWgrad w;
+                memset(&w, 0, sizeof(w));
+                w.rows = rows;
+                w.KI = K;
+                w.amode = A_RELU; w.A = D.z; w.pa = D.save + 2 * D.cout; w.pc = D.save + 3 * D.cout;
+                w.dmode = A_FILL;
+                w.NO = ld; w.tf = tf; w.NF = NF;
+                w.G = gq; w.argsel = argsel; w.coef = coef; w.group_rows = pool_rows;
+                w.partial = reinterpret_cast<float *>(base + pl.partial);
+                const WgradShape ws_ = wgrad_shape(rows, K, ld);
+                if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, st, sf)) return rc;
+                long long blocks = ((long long)K * NF + 255) / 256;
+                if (blocks > 4096) blocks = 4096;
+                if (int rc = launch(tl_top_wgrad_fix_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const double *)sf, ld, K, NF, NFp,
+                                    NFp + tiles(K) * 32, L.weight, L.w_stride_k, L.w_stride_n, (const float *)coef, L.bias,
+                                    L.grad_weight)) return rc;
+            }
+            {
+                const GemmShape g = gemm_shape(NFp + K, K);
+                if (int rc = launch_pack(wp, K, 1, g, base + pl.pack[l], st)) return rc;
+                TlGemm p;
+                memset(&p, 0, sizeof(p));
+                p.rows = rows;
+                p.tk0 = tf; p.K0 = NF; p.K1 = K;
+                p.G = gq; p.argsel = argsel; p.p0 = coef; p.group_rows = pool_rows;
+                p.A2 = D.z; p.q0 = D.save + 2 * D.cout; p.q1 = D.save + 3 * D.cout;
+                p.wpacked = reinterpret_cast<const u32x4 *>(base + pl.pack[l]);
+                p.bias = rowc;
+                p.emode = E_MASK;
+                p.out = gnext;
+                p.zprev = D.z; p.ea = D.save + 2 * D.cout; p.ec = D.save + 3 * D.cout;
+                p.stats = reinterpret_cast<double *>(base + pl.stats[l - 1]);
+                int np = 0;
+                if (int rc = launch_gemm(A_FILL, p, g, st, &np)) return rc;
+                nparts[l - 1] = np;
+            }
+            float *tmp = gcur; gcur = gnext; gnext = tmp;
+            continue;
+        }
         // weight gradient
         {
             TlWgrad w;

@@ -51,7 +51,7 @@ def conv_bn_pairs(net):
 def stack_supported(net, rows, pool_rows=0, grouped=True):
     """Can pn2_mlp_train_forward run this stack on `rows` rows? (host-side check)"""
     pairs = conv_bn_pairs(net)
-    if not pairs or len(pairs) > 8 or rows <= 0 or rows % 32:
+    if not pairs or len(pairs) > 8 or rows <= 0 or rows % 32 or rows >= 2 ** 31:
         return False
     if pool_rows and pool_rows != 16 and pool_rows % 32:
         return False
@@ -120,7 +120,11 @@ class _TrainMLP(torch.autograd.Function):
         dev = weights[0].device
         rows = level.rows
         widths = [level.pairs[0][0].in_channels] + [c.out_channels for c, _ in level.pairs]
-        zs = [torch.empty((rows, w), dtype=torch.float32, device=dev) for w in widths[1:]]
+        warr = (ctypes.c_int * len(widths))(*widths)
+        keep_top = bool(_C.lib().pn2_mlp_train_top_stored(rows, n, warr, level.pool_rows))
+        # pre-norm tensors z_l, the only activations kept; the pooled top layer's is not even written on large levels
+        zs = [torch.empty((rows, w), dtype=torch.float32, device=dev) if (keep_top or l < n - 1) else None
+              for l, w in enumerate(widths[1:])]
         saves = [torch.empty((4, w), dtype=torch.float32, device=dev) for w in widths[1:]]
         cl = widths[-1]
         if level.pool_rows:
@@ -144,7 +148,9 @@ class _TrainMLP(torch.autograd.Function):
         ctx.level, ctx.widths = level, widths
         ctx.has_x = x is not None
         ctx.nbias = [b is not None for b in biases]
-        saved = [t for t in [x] if t is not None] + weights + [b for b in biases if b is not None] + gammas + betas + zs + saves + [out]
+        ctx.nz = [z is not None for z in zs]
+        saved = [t for t in [x] if t is not None] + weights + [b for b in biases if b is not None] + gammas + betas + \
+            [z for z in zs if z is not None] + saves + [out]
         if level.pool_rows:
             saved += [argsel, zsel]
             ctx.mark_non_differentiable(argsel)
@@ -163,7 +169,7 @@ class _TrainMLP(torch.autograd.Function):
         biases = [sv.pop(0) if has else None for has in ctx.nbias]
         gammas = [sv.pop(0) for _ in range(n)]
         betas = [sv.pop(0) for _ in range(n)]
-        zs = [sv.pop(0) for _ in range(n)]
+        zs = [sv.pop(0) if has else None for has in ctx.nz]
         saves = [sv.pop(0) for _ in range(n)]
         out = sv.pop(0)
         argsel, zsel = (sv.pop(0), sv.pop(0)) if level.pool_rows else (None, None)

