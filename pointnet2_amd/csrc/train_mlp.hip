@@ -478,25 +478,39 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
                     }
                 }
                 if (p.emode == E_POOL) {
-                    // max / min of z over the rows of the item (two half items when a group is 16 rows), with the row
-                    // number of the FIRST extremum; the other half of the rows lives in lane l ^ 32
-                    const int halves = p.prow == 16 ? 2 : 1, span = 16 / halves;
-                    for (int hf = 0; hf < halves; ++hf) {
-                        float mx = val[hf * span], mn = mx;
-                        int ax = hf * span, an = ax;
-                        for (int v = hf * span + 1; v < (hf + 1) * span; ++v) {
-                            if (val[v] > mx) { mx = val[v]; ax = v; }
-                            if (val[v] < mn) { mn = val[v]; an = v; }
+                    // max / min of z over the rows of the item -- of each half item when a group is 16 rows: registers 0-7 hold
+                    // rows 0-15, registers 8-15 rows 16-31 -- with the row number of the FIRST extremum; the other half of the
+                    // rows lives in lane l ^ 32. Fully unrolled: a runtime-indexed register array would live in scratch.
+                    float mx[2], mn[2];
+                    int ax[2], an[2];
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        mx[hf] = val[8 * hf]; mn[hf] = mx[hf]; ax[hf] = 8 * hf; an[hf] = 8 * hf;
+#pragma unroll
+                        for (int v = 8 * hf + 1; v < 8 * hf + 8; ++v) {
+                            if (val[v] > mx[hf]) { mx[hf] = val[v]; ax[hf] = v; }
+                            if (val[v] < mn[hf]) { mn[hf] = val[v]; an[hf] = v; }
                         }
-                        int rx = mlp_chan(ax, hl), rn = mlp_chan(an, hl);
-                        const float omx = __shfl_xor(mx, 32), omn = __shfl_xor(mn, 32);
-                        const int orx = __shfl_xor(rx, 32), orn = __shfl_xor(rn, 32);
-                        if (omx > mx || (omx == mx && orx < rx)) { mx = omx; rx = orx; }
-                        if (omn < mn || (omn == mn && orn < rn)) { mn = omn; rn = orn; }
-                        if (ok && hl == 0) {
-                            const size_t o = (size_t)(eitem * halves + hf) * p.N + col;
-                            p.pmax[o] = mx; p.pmin[o] = mn;
-                            p.pamax[o] = rx - hf * 16; p.pamin[o] = rn - hf * 16;
+                    }
+                    if (p.prow != 16) {                            // one group: registers 8-15 come after 0-7 in row order
+                        if (mx[1] > mx[0]) { mx[0] = mx[1]; ax[0] = ax[1]; }
+                        if (mn[1] < mn[0]) { mn[0] = mn[1]; an[0] = an[1]; }
+                    }
+                    const int halves = p.prow == 16 ? 2 : 1;
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        if (hf < halves) {
+                            float bx = mx[hf], bn = mn[hf];
+                            int rx = mlp_chan(ax[hf], hl), rn = mlp_chan(an[hf], hl);
+                            const float omx = __shfl_xor(bx, 32), omn = __shfl_xor(bn, 32);
+                            const int orx = __shfl_xor(rx, 32), orn = __shfl_xor(rn, 32);
+                            if (omx > bx || (omx == bx && orx < rx)) { bx = omx; rx = orx; }
+                            if (omn < bn || (omn == bn && orn < rn)) { bn = omn; rn = orn; }
+                            if (ok && hl == 0) {
+                                const size_t o = (size_t)(eitem * halves + hf) * p.N + col;
+                                p.pmax[o] = bx; p.pmin[o] = bn;
+                                p.pamax[o] = rx - hf * 16; p.pamin[o] = rn - hf * 16;
+                            }
                         }
                     }
                 }
@@ -603,21 +617,21 @@ __global__ __launch_bounds__(256) void tl_pack_kernel(const float *__restrict__ 
 
 // ---- per-channel finalisation kernels (one thread per channel) -----------------------------------------------------------
 // batch moments -> (mean, invstd, a, c), running statistics (torch.nn.BatchNorm semantics: unbiased variance in the average)
-// the per-channel sums arrive as `nparts` partial rows; a block of 256 threads owns 32 channels and adds the rows eight at a time
+// the per-channel sums arrive as `nparts` partial rows; a block of 256 threads owns 8 channels and adds the rows 32 at a time
 __device__ __forceinline__ void tl_sum_parts(const double *__restrict__ stats, int nparts, int N, double &s1, double &s2)
 {
-    __shared__ double sh[2][8][32];
-    const int g = threadIdx.x >> 5, c = blockIdx.x * 32 + (threadIdx.x & 31);
+    __shared__ double sh[2][32][8];
+    const int g = threadIdx.x >> 3, cl = threadIdx.x & 7, c = blockIdx.x * 8 + cl;
     double a = 0.0, b = 0.0;
     if (c < N)
-        for (int q = g; q < nparts; q += 8) { a += stats[((size_t)q * 2) * N + c]; b += stats[((size_t)q * 2 + 1) * N + c]; }
-    sh[0][g][threadIdx.x & 31] = a;
-    sh[1][g][threadIdx.x & 31] = b;
+        for (int q = g; q < nparts; q += 32) { a += stats[((size_t)q * 2) * N + c]; b += stats[((size_t)q * 2 + 1) * N + c]; }
+    sh[0][g][cl] = a;
+    sh[1][g][cl] = b;
     __syncthreads();
     s1 = 0.0; s2 = 0.0;
     if (g == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { s1 += sh[0][i][threadIdx.x & 31]; s2 += sh[1][i][threadIdx.x & 31]; }
+        for (int i = 0; i < 32; ++i) { s1 += sh[0][i][cl]; s2 += sh[1][i][cl]; }
     }
 }
 
@@ -628,8 +642,8 @@ __global__ __launch_bounds__(256) void tl_bn_finalize_kernel(const double *__res
 {
     double s1, s2;
     tl_sum_parts(stats, nparts, N, s1, s2);
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-    if (threadIdx.x >= 32 || c >= N) return;
+    const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+    if (threadIdx.x >= 8 || c >= N) return;
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -654,8 +668,8 @@ __global__ __launch_bounds__(256) void tl_bn_backward_finalize_kernel(const doub
 {
     double s1, s2;
     tl_sum_parts(stats, nparts, N, s1, s2);
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-    if (threadIdx.x >= 32 || c >= N) return;
+    const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+    if (threadIdx.x >= 8 || c >= N) return;
     const double mean = save[c], invstd = save[N + c];
     const double dbeta = s1, dgamma = (s2 - mean * s1) * invstd;
     const double s = (double)gamma[c] * invstd;
@@ -777,6 +791,7 @@ struct TlWgrad {
     int dmode;                  // A_DZ / A_DZ_POOL / A_FILL
     int NO;                     // A_FILL: tf * 32 + tx * 32 + 32 columns: [routed gradient (NF) | h again (KI) | ones], see below
     int tf, NF;                 // A_FILL: tiles / channels of the routed-gradient block
+    int xshare;                 // A_FILL: every tile of h is in the slab's image, the "h again" tiles are read from there
     const float *Z, *G;
     const int *argsel;
     const float *coef;          // (3, NO): s, c0, c1
@@ -790,83 +805,95 @@ struct TlWgrad {
 // z and dy) dword loads whose 32 lanes cover 128 contiguous bytes of a row, applies the pass's prologue, splits into
 // the three bf16 levels and writes three 16-byte fragments into the block's LDS image, from where EVERY wave of the
 // workgroup reads the fragments of the output tiles it owns: operands cross the vector memory path once per workgroup.
-struct WgRaw { float z[8], g[8]; float gq; int sel; };
+struct WgRaw { float z[8], g[8]; float gq; int sel, off; };      // off: first row of the unit inside its group
+
+// BRANCH-FREE: every unit of every wave issues the same 18 buffer loads -- eight rows of a first stream, eight of a second,
+// two per-group values -- and what a unit does not need is pointed at an empty descriptor (out-of-range loads return 0
+// without touching memory). The kinds of the units of a workgroup differ (rows of h, rows of z and dy, routed gradient,
+// nothing), and a wait that is shared by paths with different numbers of loads in flight can only be vmcnt(0): with
+// branches around the loads the two-block prefetch drained at every block.
+__device__ __forceinline__ int bloadi(rsrc_t r, int voff, int soff)
+{
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+}
 
 template <bool GATHER>
-__device__ __forceinline__ void wg_load_unit(const TlWgrad &p, long long row0, int unit, int us, int ts, int lane, WgRaw &r)
+__device__ __forceinline__ void wg_load_unit(const TlWgrad &p, long long row0, int unit, int us, int ts, int lane, bool live,
+                                             WgRaw &r)
 {
     const int tile = unit >> 1, e = unit & 1, hl = lane >> 5, c = lane & 31;
-    const long long rbase = row0 + 16 * e + 8 * hl;
+    const int rin = 16 * e + 8 * hl;                               // first of the lane's eight rows inside the block
+    const int rbase = (int)row0 + rin;                             // rows < 2^31 (checked by the launcher)
+    const int kOob = (int)0xfffffff0u;                              // beyond every descriptor's num_records (<= 0x7fffffff)
+    const bool isx = tile < p.tus;
+    const int tg = ts * p.tts + tile - p.tus, tx = (p.KI + 31) / 32;
+    // ---- what this unit reads (wave-uniform choices: scalar selects, no memory operation inside a branch)
+    const float *b1 = nullptr, *b2 = nullptr, *bq = nullptr;
+    const int *bs = nullptr;
+    int pitch1 = 0, ch1 = 0, lim1 = 0, nq = 0, chq = 0, limq = 0, grows = 1;
+    bool gather = false;
+    if (!live) {                                                   // no such unit / no such block: every load out of range
+    } else if (isx) {
+        ch1 = (us * p.tus + tile) * 32 + c; lim1 = p.KI;
+        if (GATHER && p.amode == A_GATHER) gather = true; else { b1 = p.A; pitch1 = p.KI; }
+    } else if (p.dmode == A_FILL) {
+        if (tg < p.tf) { bq = p.G; bs = p.argsel; nq = p.NF; chq = tg * 32 + c; limq = p.NF; grows = p.group_rows; }
+        else if (tg < p.tf + tx && !p.xshare) { b1 = p.A; pitch1 = p.KI; ch1 = (tg - p.tf) * 32 + c; lim1 = p.KI; }
+    } else {
+        b1 = p.Z; pitch1 = p.NO; ch1 = tg * 32 + c; lim1 = p.NO;
+        if (p.dmode == A_DZ_POOL) { bq = p.G; bs = p.argsel; nq = p.NO; chq = ch1; limq = p.NO; grows = p.group_rows; }
+        else b2 = p.G;
+    }
+    // ---- descriptors and lane offsets
+    const unsigned bytes1 = 32u * (unsigned)pitch1 * 4u;
+    rsrc_t r1 = make_rsrc(b1 ? b1 + (size_t)row0 * pitch1 : nullptr, b1 ? bytes1 : 0u);
+    const rsrc_t r2 = make_rsrc(b2 ? b2 + (size_t)row0 * pitch1 : nullptr, b2 ? bytes1 : 0u);
+    int voff = (b1 && ch1 < lim1) ? (rin * pitch1 + ch1) * 4 : kOob;
+    int step = pitch1 * 4;                                         // byte distance between the lane's rows
+    int vj[8];
+    float cen_dummy = 0.0f;
+    (void)cen_dummy;
+    const int grp = (int)((unsigned)rbase / (unsigned)grows);
+    r.off = rbase - grp * grows;
+    rsrc_t rq = make_rsrc(bq, bq ? 0x7fffffffu : 0u);
+    const rsrc_t rs = make_rsrc(bs, bs ? 0x7fffffffu : 0u);
+    int voffq = (bq && chq < limq) ? (grp * nq + chq) * 4 : kOob;
+    if (GATHER) {
+        // rows of the grouped input: the point numbers of the step's 16 rows come through wave-uniform (scalar) loads --
+        // counted by lgkmcnt, they do not disturb the vector loads in flight -- and each lane then picks its half
+        const TlGather &g = p.g;
+        const int kx = ch1 - g.xyz_off, kf = ch1 - g.feat_off;
+        const bool px = gather && kx >= 0 && kx < 3, pf = gather && kf >= 0 && kf < g.cfeat;
+        const int ggrp = (int)((unsigned)rbase / (unsigned)g.nsample), s0 = rbase - ggrp * g.nsample;
+        const int cloud = ggrp / g.m;                              // group sizes are multiples of 8: one group per unit-lane
+        int pts[16];
+        const int *ip = (g.idx && live) ? g.idx + row0 + 16 * e : nullptr;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { r.z[j] = 0.0f; r.g[j] = 0.0f; }
-    r.gq = 0.0f;
-    r.sel = -1;
-    if (tile < p.tus) {                                            // h = the layer's input
-        const int ch = (us * p.tus + tile) * 32 + c;
-        if (ch >= p.KI) return;
-        if (GATHER) {
-            const TlGather &g = p.g;
-            const int kx = ch - g.xyz_off, kf = ch - g.feat_off;
-            const bool isx = kx >= 0 && kx < 3, isf = kf >= 0 && kf < g.cfeat;
-            if (!isx && !isf) return;
-            const int grp0 = (int)((unsigned)rbase / (unsigned)g.nsample);   // rows < 2^31 (checked by the launcher)
-            const int s0 = (int)rbase - grp0 * g.nsample;
+        for (int j = 0; j < 16; ++j) pts[j] = ip ? ip[j] : 0;
+        if (gather) {
+            const float *src = px ? g.xyz : g.points;
+            const int pitch = px ? 3 : g.cfeat, kk = px ? kx : kf;
+            r1 = make_rsrc(src, 0x7fffffffu);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int sj = s0 + j;
-                const int grp = grp0 + sj / g.nsample;
-                const int sample = sj % g.nsample;
-                const int cloud = grp / g.m;
-                const int pt = g.idx ? g.idx[rbase + j] : sample;
-                if (isx) {
-                    const float val = g.xyz[((size_t)cloud * g.n + pt) * 3 + kx];
-                    r.z[j] = g.new_xyz ? __fsub_rn(val, g.new_xyz[(size_t)grp * 3 + kx]) : val;
-                } else {
-                    r.z[j] = g.points[((size_t)cloud * g.n + pt) * g.cfeat + kf];
-                }
+                const int pt = g.idx ? (hl ? pts[8 + j] : pts[j]) : s0 + j;
+                vj[j] = (px || pf) ? ((cloud * g.n + pt) * pitch + kk) * 4 : kOob;
             }
-            return;
+            if (g.new_xyz) { rq = make_rsrc(g.new_xyz, 0x7fffffffu); voffq = px ? (ggrp * 3 + kx) * 4 : kOob; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vj[j] = voff == kOob ? kOob : voff + j * step;       // (no wrap: voff < 2^31)
         }
-        const rsrc_t rs = make_rsrc(p.A + (size_t)row0 * p.KI, 32u * (unsigned)p.KI * 4u);
-        const int voff = ((16 * e + 8 * hl) * p.KI + ch) * 4;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r.z[j] = bload(rs, voff, j * p.KI * 4);
-        return;
-    }
-    const int tg = ts * p.tts + tile - p.tus;                      // tile of the second operand
-    if (p.dmode == A_FILL) {
-        // second operand of the pooled top layer: [s dy routed to the pooled samples | h itself | a column of ones]
-        if (tg < p.tf) {
-            const int ch = tg * 32 + c;
-            if (ch >= p.NF) return;
-            const int grp = (int)((unsigned)rbase / (unsigned)p.group_rows);
-            r.gq = p.G[(size_t)grp * p.NF + ch];
-            r.sel = p.argsel[(size_t)grp * p.NF + ch] - ((int)rbase - grp * p.group_rows);
-        } else if (tg < p.tf + (p.KI + 31) / 32) {
-            const int ch = (tg - p.tf) * 32 + c;
-            if (ch >= p.KI) return;
-            const rsrc_t rs = make_rsrc(p.A + (size_t)row0 * p.KI, 32u * (unsigned)p.KI * 4u);
-            const int voff = ((16 * e + 8 * hl) * p.KI + ch) * 4;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) r.z[j] = bload(rs, voff, j * p.KI * 4);
-        }
-        return;
-    }
-    const int ch = tg * 32 + c;                                    // dz = s dy - c0 - c1 z
-    if (ch >= p.NO) return;
-    const rsrc_t rz = make_rsrc(p.Z + (size_t)row0 * p.NO, 32u * (unsigned)p.NO * 4u);
-    const int voff = ((16 * e + 8 * hl) * p.NO + ch) * 4;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r.z[j] = bload(rz, voff, j * p.NO * 4);
-    if (p.dmode == A_DZ_POOL) {
-        const int grp = (int)((unsigned)rbase / (unsigned)p.group_rows);     // group size 16 or a multiple of 32: one group per 8 rows
-        r.gq = p.G[(size_t)grp * p.NO + ch];
-        r.sel = p.argsel[(size_t)grp * p.NO + ch] - ((int)rbase - grp * p.group_rows);
+        for (int j = 0; j < 8; ++j) r.z[j] = bload(r1, vj[j], 0);
     } else {
-        const rsrc_t rg = make_rsrc(p.G + (size_t)row0 * p.NO, 32u * (unsigned)p.NO * 4u);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r.g[j] = bload(rg, voff, j * p.NO * 4);
+        for (int j = 0; j < 8; ++j) r.z[j] = bload(r1, voff, j * step);
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.g[j] = bload(r2, voff, j * step);
+    r.gq = bload(rq, voffq, 0);
+    r.sel = bloadi(rs, voffq, 0);
 }
 
 // the per-channel parameters of a unit's lane (its channel never changes): fetched ONCE, before the block loop -- a
@@ -901,6 +928,32 @@ __device__ __forceinline__ void wg_store_unit(const TlWgrad &p, const WgRaw &r, 
                                               u32x4 *img)
 {
     const int tile = unit >> 1, e = unit & 1, c = lane & 31;
+    u32x4 *o = img + ((size_t)tile * 3 * 2 + e) * 64 + lane;
+    if (p.dmode == A_FILL && tile >= p.tus) {
+        const int tg = ts * p.tts + tile - p.tus, tx = (p.KI + 31) / 32;
+        if (tg < p.tf) {
+            // one non-zero per lane (the pool routes dy to ONE row): split it once and drop its three bf16 levels into slot sel
+            const int rel = r.sel - r.off;                          // the pooled sample's row inside this unit, if it is here
+            const float v = (rel >= 0 && rel < 8 && tg * 32 + c < p.NF) ? __fmul_rn(w.p0, r.gq) : 0.0f;
+            const unsigned b1 = pack_bf16(v, 0.0f) & 0xffffu;
+            const float r1 = __fsub_rn(v, __uint_as_float(b1 << 16));
+            const unsigned b2 = pack_bf16(r1, 0.0f) & 0xffffu;
+            const float r2 = __fsub_rn(r1, __uint_as_float(b2 << 16));
+            const unsigned b3 = pack_bf16(r2, 0.0f) & 0xffffu;
+            const int d = rel >> 1, sh = (rel & 1) * 16;
+            u32x4 l1, l2, l3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                l1[q] = d == q ? b1 << sh : 0u;
+                l2[q] = d == q ? b2 << sh : 0u;
+                l3[q] = d == q ? b3 << sh : 0u;
+            }
+            o[0] = l1; o[128] = l2; o[256] = l3;
+            return;
+        }
+        if (tg < p.tf + tx && p.xshare) return;                     // read from the first operand's tile instead
+        if (tg >= p.tf + tx) return;                                // the column of ones is written once, before the loop
+    }
     f32x16 x;
 #pragma unroll
     for (int v = 0; v < 16; ++v) x[v] = 0.0f;
@@ -909,38 +962,32 @@ __device__ __forceinline__ void wg_store_unit(const TlWgrad &p, const WgRaw &r, 
         if (p.amode == A_RELU && ch < p.KI) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] = vmax(__fadd_rn(__fmul_rn(w.p0, r.z[j]), w.p1), 0.0f);
+        } else if (p.amode == A_GATHER) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = __fsub_rn(r.z[j], r.gq);    // pointnet_util.py:46 (gq: the centroid coordinate, 0 for features)
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] = r.z[j];
         }
     } else if (p.dmode == A_FILL) {
         const int tg = ts * p.tts + tile - p.tus, tx = (p.KI + 31) / 32;
-        if (tg < p.tf) {
-            if (tg * 32 + c < p.NF) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = r.sel == j ? __fmul_rn(w.p0, r.gq) : 0.0f;
-            }
-        } else if (tg < p.tf + tx) {
+        if (tg >= p.tf && tg < p.tf + tx) {
             if ((tg - p.tf) * 32 + c < p.KI) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x[j] = vmax(__fadd_rn(__fmul_rn(w.p0, r.z[j]), w.p1), 0.0f);
             }
-        } else if (tg == p.tf + tx && c == 0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = 1.0f;                // column of ones: sum over the rows of h
         }
     } else {
         const int ch = (ts * p.tts + tile - p.tus) * 32 + c;
         if (ch < p.NO) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float dy = p.dmode == A_DZ_POOL ? (r.sel == j ? r.gq : 0.0f) : r.g[j];
+                const float dy = p.dmode == A_DZ_POOL ? (r.sel - r.off == j ? r.gq : 0.0f) : r.g[j];
                 x[j] = __fsub_rn(__fsub_rn(__fmul_rn(w.p0, dy), w.p1), __fmul_rn(w.p2, r.z[j]));
             }
         }
     }
     const ActSplit sp = split_act(x);                             // registers 0..7 -> p[0][level]
-    u32x4 *o = img + ((size_t)tile * 3 * 2 + e) * 64 + lane;
     o[0] = sp.p[0][0];
     o[128] = sp.p[0][1];
     o[256] = sp.p[0][2];
@@ -970,12 +1017,11 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
 #pragma unroll
     for (int i = 0; i < UPW; ++i)
         if (wave + 8 * i < nunits) par[i] = wg_unit_params(p, wave + 8 * i, us, ts, lane);
-    auto load = [&](long long b, WgRaw (&r)[UPW]) {
-        if (b < blocks) {
+    auto load = [&](long long b, WgRaw (&r)[UPW]) {             // the same instruction sequence for every wave and block
+        const bool inb = b < blocks;
 #pragma unroll
-            for (int i = 0; i < UPW; ++i)
-                if (wave + 8 * i < nunits) wg_load_unit<GATHER>(p, b * 32, wave + 8 * i, us, ts, lane, r[i]);
-        }
+        for (int i = 0; i < UPW; ++i)
+            wg_load_unit<GATHER>(p, (inb ? b : 0) * 32, wave + 8 * i, us, ts, lane, inb && wave + 8 * i < nunits, r[i]);
     };
     auto block = [&](long long b, WgRaw (&r)[UPW], u32x4 *img) {
 #pragma unroll
@@ -987,8 +1033,10 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
         for (int i = 0; i < TPW; ++i) {
             const int q = wave + 8 * i;
             if (q < nout) {
-                const int u = q / p.tts, t = q % p.tts;
-                const u32x4 *xa = img + (size_t)u * 384 + lane, *xb = img + (size_t)(p.tus + t) * 384 + lane;
+                const int u = q / p.tts, t = q % p.tts, tg = ts * p.tts + t;
+                const bool shared = p.dmode == A_FILL && p.xshare && tg >= p.tf && tg < p.tf + p.tus;
+                const u32x4 *xa = img + (size_t)u * 384 + lane;
+                const u32x4 *xb = img + (size_t)(shared ? tg - p.tf : p.tus + t) * 384 + lane;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const u32x4 a[3] = {xa[e * 64], xa[128 + e * 64], xa[256 + e * 64]};
@@ -998,6 +1046,22 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
             }
         }
     };
+    if (p.dmode == A_FILL) {
+        // the column of ones (sum over the rows of h): fragment slot j of lanes with c == 0 is bf16 1.0 at level 1, constant
+        const int tx = (p.KI + 31) / 32;
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int unit = wave + 8 * i, tile = unit >> 1, e = unit & 1;
+            if (unit < nunits && tile >= p.tus && ts * p.tts + tile - p.tus == p.tf + tx) {
+                const unsigned one2 = (lane & 31) == 0 ? 0x3f803f80u : 0u;
+                const u32x4 ones = {one2, one2, one2, one2}, zero = {0u, 0u, 0u, 0u};
+                for (int b = 0; b < 2; ++b) {
+                    u32x4 *o = img0 + (size_t)b * imgv + ((size_t)tile * 3 * 2 + e) * 64 + lane;
+                    o[0] = ones; o[128] = zero; o[256] = zero;
+                }
+            }
+        }
+    }
     long long blk = blockIdx.x;
     load(blk, ra);
     load(blk + step, rb);
@@ -1433,7 +1497,7 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
         }
         int nparts = 0;
         if (int rc = launch_gemm(amode, p, g, st, &nparts)) return rc;
-        if (int rc = launch(tl_bn_finalize_kernel, dim3((unsigned)((L.cout + 31) / 32)), dim3(256), 0, st,
+        if (int rc = launch(tl_bn_finalize_kernel, dim3((unsigned)((L.cout + 7) / 8)), dim3(256), 0, st,
                             reinterpret_cast<const double *>(base + pl.stats[l]), nparts, L.cout, (double)rows, L.gamma, L.beta,
                             L.running_mean, L.running_var, L.momentum, L.eps, L.save)) return rc;
         if (last && pool_rows) {
@@ -1503,7 +1567,7 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
     for (int l = nlayers - 1; l >= 0; --l) {
         const pn2_bn_layer &L = layers[l];
         float *coef = reinterpret_cast<float *>(base + pl.coef[l]);
-        if (int rc = launch(tl_bn_backward_finalize_kernel, dim3((unsigned)((L.cout + 31) / 32)), dim3(256), 0, st,
+        if (int rc = launch(tl_bn_backward_finalize_kernel, dim3((unsigned)((L.cout + 7) / 8)), dim3(256), 0, st,
                             reinterpret_cast<const double *>(base + pl.stats[l]), nparts[l], L.cout, (double)rows, L.gamma,
                             (const float *)L.save, L.grad_gamma, L.grad_beta, coef)) return rc;
         const bool pooled_top = pool_rows && l == nlayers - 1;
@@ -1530,6 +1594,7 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
                 w.G = gq; w.argsel = argsel; w.coef = coef; w.group_rows = pool_rows;
                 w.partial = reinterpret_cast<float *>(base + pl.partial);
                 const WgradShape ws_ = wgrad_shape(rows, K, ld);
+                w.xshare = ws_.uslabs == 1;
                 if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, st, sf)) return rc;
                 long long blocks = ((long long)K * NF + 255) / 256;
                 if (blocks > 4096) blocks = 4096;
