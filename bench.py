@@ -178,10 +178,11 @@ def event_time(fn, reps=10):
 def mlp_roofline(stage):
     """EXTRA object (not part of `value`): the MFMA-bound kernel of the hot path's consumer, the fused
     grouped MLP + max-pool (pn2_sa_mlp3_maxpool) on the SAME batch the step just produced
-    (idx of the metric shape, widths 64-64-128 as in the reference's first SA level). `achieved` counts the
-    useful fp32 FLOPs only and is set against the dense fp32 MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s);
-    the kernel evaluates every fp32 product as six bf16 MFMA terms (csrc/sa_mlp.hip), so `pipe` gives the
-    executed v_mfma_f32_32x32x16_bf16 work (156 per 32 samples) against the dense bf16 peak (2500 TFLOP/s)."""
+    (idx of the metric shape, widths 64-64-128 as in the reference's first SA level). The kernel evaluates every
+    fp32 product as six bf16 MFMA terms (csrc/sa_mlp.hip): the roofline fraction is the EXECUTED
+    v_mfma_f32_32x32x16_bf16 work (156 per 32 samples) against the dense bf16 peak of MI355X_MICROARCH.md
+    (2500 TFLOP/s) -- numerator and denominator describe the same instructions. The useful fp32 FLOPs per second
+    of the layer stack are reported as a speed (`speed_fp32_equiv`), not as a fraction of anything."""
     from pointnet2_amd import sa_mlp
     rng = np.random.default_rng(0)
     dims = (3, 64, 64, 128)
@@ -192,9 +193,31 @@ def mlp_roofline(stage):
     flops = 2.0 * stage.b * M * NS * (3 * 64 + 64 * 64 + 64 * 128)
     executed = 156.0 * 2 * 32 * 32 * 16 * stage.b * M * (NS // 32)
     return {"bound": "mfma", "kernel": "sa_mlp3_maxpool 3-64-64-128 on the step's idx (fp32 results, 6 bf16 MFMA terms per product)",
-            "achieved": flops / t / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / t / 1e12 / 157.3, "us": t * 1e6,
-            "pipe": {"instruction": "v_mfma_f32_32x32x16_bf16", "executed": executed / t / 1e12, "peak": 2500.0,
-                     "unit": "TFLOP/s", "frac": executed / t / 1e12 / 2500.0}}
+            "instruction": "v_mfma_f32_32x32x16_bf16", "achieved": executed / t / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": executed / t / 1e12 / 2500.0, "us": t * 1e6,
+            "speed_fp32_equiv": {"value": flops / t / 1e12, "unit": "TFLOP/s",
+                                 "note": "useful fp32 FLOPs of the layer stack per second; a speed, not a roofline fraction"}}
+
+
+def sa_train_level(stage):
+    """EXTRA object: the TRAINING-mode shared MLP + max-pool of the same level (batch-statistics batch norm, forward and
+    backward; csrc/train_mlp.hip, SURVEY 8 row f2 second half) on the step's idx, widths 64-64-128."""
+    import torch.nn as nn
+    from pointnet2_amd import train_mlp
+    from pointnet2_amd.pointnet_util import _SharedMLP
+    net = _SharedMLP(3, [64, 64, 128], bn=True).to(stage.xyz.device).train()
+    fwd = lambda: train_mlp.sa_mlp_train(net.net, stage.xyz, stage.new_xyz, None, stage.idx, True)[0]
+    out = fwd()
+    gw = torch.ones_like(out)
+    params = list(net.parameters())
+    t_f = event_time(fwd)
+    out = fwd()
+    t_b = event_time(lambda: torch.autograd.grad(out, params, gw, retain_graph=True))
+    flops = 2.0 * stage.b * M * NS * (3 * 64 + 64 * 64 + 64 * 128)
+    return {"kernel": "pn2_mlp_train_forward / _backward 3-64-64-128 on the step's idx (batch-statistics BN + ReLU + max-pool)",
+            "forward_us": t_f * 1e6, "backward_us": t_b * 1e6,
+            "speed_fp32_equiv": {"value": 3 * flops / (t_f + t_b) / 1e12, "unit": "TFLOP/s",
+                                 "note": "forward + data gradient + weight gradient FLOPs of the layer stack per second"}}
 
 
 def concurrent_throughput(dev, rank, path, streams, steps):
@@ -272,8 +295,10 @@ def cpu_baseline_all_cores(seed, budget_s=10.0):
 
 
 def allreduce_leg(dev, dist, reps=20):
-    """Training's only exchange (train_multi_gpu.py:91-126): the gradient mean over ranks as ONE flat-bucket
-    all-reduce (sharding.allreduce_mean_), timed at the two data-parallel models' gradient sizes."""
+    """Training's only exchange (train_multi_gpu.py:91-126): the gradient mean over ranks as ONE in-place all-reduce of a
+    persistent flat bucket (sharding.GradBucket keeps every parameter's .grad as a view of it), timed at the two
+    data-parallel models' gradient sizes. Runs whenever a process group exists -- with ONE rank too: that is how a
+    single-GPU box exercises the RCCL path."""
     out = {}
     world = dist.get_world_size()
     for name, floats in GRAD_BUCKET_FLOATS.items():
@@ -384,17 +409,20 @@ def main():
     launch_s = (ev0.elapsed_time(ev1) * 1e-3 / args.steps) if ev0 is not None else elapsed / args.steps
 
     extras = not args.no_extras and not args.stub
-    allred = allreduce_leg(dev, dist) if (dist is not None and world > 1) else None
+    allred = allreduce_leg(dev, dist) if dist is not None else None
     conc = None
     if extras and args.streams > 1 and world == 1:
         conc = concurrent_throughput(dev, rank, args.path, args.streams, max(64, 4 * args.streams))
     if rank == 0:
         achieved = STAGE_BYTES * b_local / launch_s / 1e9
-        traffic = None
+        traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # written from rocprofv3 --pmc passes
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get({"overlap": "sample_and_group_xyz"}.get(args.path, ""))
+                tj = json.load(open(tpath))
+                traffic = tj.get({"overlap": "sample_and_group_xyz"}.get(args.path, ""))
+                # counters cannot be collected in a timed run: the number is the last separate --pmc pass, named here
+                traffic_source = "profiles/hbm_traffic.json @ %s (%s)" % (tj.get("commit", "?"), tj.get("pass", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE"))
             except Exception:
                 traffic = None
         line = {
@@ -423,7 +451,7 @@ def main():
                        "sharding": "%d independent batch shard(s), no data-path collective" % world,
                        "requested_gpus": args.gpus},
             "roofline": {"bound": "hbm", "kernel": TIMED_KERNEL[args.path], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": STAGE_BYTES * b_local,
                          "note": "the kernel(s) of the timed region: SURVEY 8(d) bytes per cloud x clouds per launch / "
                                  "HIP-event time per step on the launch stream. Bound by the FPS chain (latency), "
@@ -464,8 +492,13 @@ def main():
                     line["mlp_roofline"] = mlp_roofline(stage)
                 except Exception as e:                               # never let an extra object break the contract line
                     line["mlp_roofline"] = {"error": repr(e)}
-                # >= 1 s of back-to-back steps (not `value`): long enough for an external utilisation sampler
-                n_sus = max(args.steps, int(1.2 / max(launch_s, 1e-6)))
+                try:
+                    line["sa_train"] = sa_train_level(stage)
+                except Exception as e:
+                    line["sa_train"] = {"error": repr(e)}
+                # >= 5 s of back-to-back steps (not `value`), BEFORE the CPU-baseline legs: long enough for an external
+                # utilisation sampler to see the GPU busy
+                n_sus = max(args.steps, int(5.0 / max(launch_s, 1e-6)))
                 t0 = time.perf_counter()
                 for _ in range(n_sus):
                     step()

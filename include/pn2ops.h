@@ -229,7 +229,9 @@ int pn2_query_ball_group_xyz_ex(int b, int n, int m, float radius, int nsample, 
  * radii / nsamples: HOST arrays of nscales (<= 4) entries; idx / pts_cnt / grouped_xyz: HOST arrays of nscales
  * DEVICE pointers, scale i shaped (b,m,nsamples[i]) / (b,m) / (b,m,nsamples[i],3); the arrays themselves or
  * single entries of pts_cnt and of one of idx / grouped_xyz may be NULL. Every output is bit-identical to
- * pn2_query_ball_group_xyz called per radius. PN2_E_TOO_LARGE for n > 8192 (call the single-radius operator). */
+ * pn2_query_ball_group_xyz called per radius. PN2_E_TOO_LARGE -- before anything is launched -- for n > 8192 and
+ * whenever no LDS geometry fits the combination (e.g. n = 8192 with nsample >= 127 on a later radius, n = 8000 with
+ * nsample 256): call the single-radius operator per radius then, as the Python operator does. */
 int pn2_query_ball_group_xyz_msg(int b, int n, int m, int nscales, const float *radii, const int *nsamples,
                                  const float *xyz1, const float *xyz2, int subtract_centroid, int *const *idx,
                                  int *const *pts_cnt, float *const *grouped_xyz, void *stream);

@@ -107,7 +107,7 @@ __device__ __forceinline__ void bq_emit(size_t row, int nsample, int cnt, const 
 // Wait until the FPS workgroup of the same launch has published sample j of this cloud and return its
 // index (consumer side of the R2 granule hand-off: ONE 8-byte agent-scope relaxed load per poll, the
 // tag travels with the data, no fence). The producers of a launch are running before any consumer polls
-// (sa_fused.hip: roles are taken by arrival ticket), so the wait always ends; the spin is nevertheless
+// (sa_fused.hip: producers are the first b blocks, and the launch is refused unless they all fit), so the wait always ends; the spin is nevertheless
 // bounded (~10 s; the longest legal chain, n = m = 8192, takes < 10 ms) and returns -1 instead of hanging
 // the GPU should the device ever stall a producer for that long. The caller records the failure in the
 // launch's status word and gives up its queries: an error the host can read, not a trap that would take
@@ -122,7 +122,10 @@ __device__ __forceinline__ int bq_poll_sample(const unsigned long long *tagged, 
 #define PN2_POLL_SLEEP 16
 #endif
         __builtin_amdgcn_s_sleep(PN2_POLL_SLEEP);
-        if (it > (1u << 23)) return -1;
+#ifndef PN2_POLL_LIMIT
+#define PN2_POLL_LIMIT (1u << 23)          /* ~10 s; the lab build of tests/test_overlap_status_gpu.py sets 2 to force the give-up path */
+#endif
+        if (it > PN2_POLL_LIMIT) return -1;
     }
 }
 

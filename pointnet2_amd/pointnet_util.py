@@ -169,16 +169,27 @@ class PointnetSAModule(nn.Module):
         """Folded + packed weights, rebuilt when a parameter or a running statistic changed."""
         stamp = tuple((t.data_ptr(), t._version) for t in list(self.mlp.parameters()) + list(self.mlp.buffers()))
         nsample = nsample or self.nsample
-        if self._pack_cache is None or self._pack_cache[0] != (stamp, device, nsample):
+        if self._pack_cache is None or self._pack_cache[0] != (stamp, device):
+            self._pack_cache = ((stamp, device), {})            # one entry per nsample / cloud size, dropped when a weight changes
+        hit = self._pack_cache[1].get(nsample)
+        if hit is None:
             _no_packing_under_capture()
-            self._pack_cache = ((stamp, device, nsample), sa_mlp.PackedMLP3(self.mlp.folded_layers(), device, nsample, True))
-        return self._pack_cache[1]
+            if len(self._pack_cache[1]) >= 8:
+                self._pack_cache[1].clear()
+            hit = sa_mlp.PackedMLP3(self.mlp.folded_layers(), device, nsample, True)
+            self._pack_cache[1][nsample] = hit
+        return hit
 
-    def prepare_fused(self, device):
+    def prepare_fused(self, device, n=None):
         """Fold the batch norms and pack the weights for the fused kernel NOW (a host-side step with a
         device-to-host copy and an upload): call it once after loading weights / before capturing a HIP
-        graph, so that forward() finds the cache warm."""
-        if not self.group_all and sa_mlp.supported(self.mlp.net[0].in_channels, self.mlp.widths, self.nsample or 0):
+        graph, so that forward() finds the cache warm. group_all levels pack per cloud size: pass n (the number of
+        points this level will see)."""
+        cin = self.mlp.net[0].in_channels
+        if self.group_all:
+            if n and sa_mlp.supported(cin, self.mlp.widths, n) and sa_mlp.kind(cin, self.mlp.widths, n) == "cooperative":
+                self._packed(device, n)
+        elif sa_mlp.supported(cin, self.mlp.widths, self.nsample or 0):
             self._packed(device)
         return self
 
@@ -363,11 +374,15 @@ class PointnetFPModule(nn.Module):
         return sa_mlp.fp_kind(npoints, points2.shape[2], c1, self.mlp.widths)
 
     def _packed(self, c2, c1, kind, device):
-        stamp = (tuple((t.data_ptr(), t._version) for t in list(self.mlp.parameters()) + list(self.mlp.buffers())), device, c2, c1, kind)
+        stamp = (tuple((t.data_ptr(), t._version) for t in list(self.mlp.parameters()) + list(self.mlp.buffers())), device)
         if self._pack_cache is None or self._pack_cache[0] != stamp:
+            self._pack_cache = (stamp, {})                      # one entry per (c2, c1, kernel kind)
+        hit = self._pack_cache[1].get((c2, c1, kind))
+        if hit is None:
             _no_packing_under_capture()
-            self._pack_cache = (stamp, sa_mlp.PackedFPMLP(self.mlp.folded_layers(), c2, c1, device, kind))
-        return self._pack_cache[1]
+            hit = sa_mlp.PackedFPMLP(self.mlp.folded_layers(), c2, c1, device, kind)
+            self._pack_cache[1][(c2, c1, kind)] = hit
+        return hit
 
     def prepare_fused(self, c2, c1, npoints, device):
         """See PointnetSAModule.prepare_fused (c2 / c1 = channels of points2 / points1, npoints = b * n unknown points)."""

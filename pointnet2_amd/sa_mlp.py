@@ -98,6 +98,12 @@ def sa_mlp_maxpool(xyz, new_xyz, points, idx, packed):
         points = f32(points, "points")
         cfeat = points.shape[2]
     require(3 + cfeat == packed.cin, "packed MLP expects %d input channels, got %d" % (packed.cin, 3 + cfeat))
+    require(xyz.dim() == 3 and xyz.shape[2] == 3, "xyz must be (b, n, 3)")
+    if idx is not None:
+        require(new_xyz.dim() == 3 and tuple(new_xyz.shape) == (b, m, 3), "new_xyz must be (b, m, 3) with idx (b, m, nsample)")
+        require(idx.dim() == 3 and idx.shape[0] == b, "idx must be (b, m, nsample)")
+    if points is not None:
+        require(points.dim() == 3 and tuple(points.shape[:2]) == (b, n), "points must be (b, n, c) like xyz")
     # the packed layout belongs to the kernel pn2_sa_mlp3_config chose for packed.nsample; another nsample
     # is fine as long as the library would choose the same kernel for it
     require(ns == packed.nsample or _same_kernel(packed, ns),
@@ -182,6 +188,10 @@ def fp_mlp(points2, points1, idx, dist, packed):
         points1 = f32(points1, "points1")
         c1 = points1.shape[2]
     require(c2 == packed.c2 and c1 == packed.c1, "packed FP MLP expects (%d, %d) channels, got (%d, %d)" % (packed.c2, packed.c1, c2, c1))
+    require(idx.dim() == 3 and idx.shape[0] == b and idx.shape[2] == 3, "idx must be (b, n, 3) from three_nn")
+    require(tuple(dist.shape) == tuple(idx.shape), "dist must have idx's shape (b, n, 3)")
+    if points1 is not None:
+        require(points1.dim() == 3 and tuple(points1.shape[:2]) == (b, n), "points1 must be (b, n, c1)")
     dev = same_device(points2, idx, dist, packed.wp) if points1 is None else same_device(points2, points1, idx, dist, packed.wp)
     out = torch.empty((b, n, packed.widths[-1]), dtype=torch.float32, device=dev)
     nbytes = _C.lib().pn2_fp_mlp_ws_bytes(b, m, c2, c1, len(packed.widths), packed._warr, packed.kind)

@@ -74,19 +74,28 @@ class GradBucket:
         if not dist.is_initialized():
             return self.flat
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.mul_(1.0 / dist.get_world_size())
+        if dist.get_world_size() > 1:
+            self.flat.mul_(1.0 / dist.get_world_size())
         return self.flat
 
 
 def allreduce_mean_(tensors):
-    """In-place mean over ranks of a list of gradient tensors through one flat fp32 bucket
-    (replaces average_gradients, train_multi_gpu.py:91-126)."""
+    """In-place mean over ranks of a list of gradient tensors (replaces average_gradients,
+    train_multi_gpu.py:91-126). One contiguous fp32 tensor -- a GradBucket's flat buffer -- is reduced where it is;
+    several tensors go through one temporary flat bucket. A no-op without a process group; with a group of ONE rank
+    the collective still runs (a single-GPU box exercises the RCCL path that way)."""
     tensors = [t for t in tensors if t is not None]
-    if not tensors or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not tensors or not dist.is_initialized():
+        return tensors
+    world = dist.get_world_size()
+    if len(tensors) == 1 and tensors[0].dtype == torch.float32 and tensors[0].is_contiguous():
+        dist.all_reduce(tensors[0], op=dist.ReduceOp.SUM)
+        if world > 1:
+            tensors[0].mul_(1.0 / world)
         return tensors
     flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat.mul_(1.0 / dist.get_world_size())
+    flat.mul_(1.0 / world)
     off = 0
     for t in tensors:
         n = t.numel()

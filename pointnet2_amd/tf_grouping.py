@@ -133,9 +133,14 @@ def query_ball_group_xyz_msg(radius_list, nsample_list, xyz1, xyz2, subtract_cen
     pc = (ctypes.c_void_p * ns_count)(*[ptr(o[1]) for o in outs])
     pg = (ctypes.c_void_p * ns_count)(*[ptr(o[2]) for o in outs])
     with on_device(dev):
-        _C.check(_C.lib().pn2_query_ball_group_xyz_msg(b, n, m, ns_count, radii, nss, ptr(xyz1), ptr(xyz2),
-                                                       1 if subtract_centroid else 0, pi, pc, pg, stream_ptr(dev)),
-                 "query_ball_group_xyz_msg")
+        rc = _C.lib().pn2_query_ball_group_xyz_msg(b, n, m, ns_count, radii, nss, ptr(xyz1), ptr(xyz2),
+                                                   1 if subtract_centroid else 0, pi, pc, pg, stream_ptr(dev))
+    if rc == -4:
+        # PN2_E_TOO_LARGE: no LDS geometry fits this combination (e.g. n = 8192 with nsample >= 127 on a later radius);
+        # nothing has been launched -- the per-radius operator covers every shape
+        return [query_ball_group_xyz(r, k, xyz1, xyz2, subtract_centroid, want_idx)
+                for r, k in zip(radius_list, nsample_list)]
+    _C.check(rc, "query_ball_group_xyz_msg")
     return outs
 
 
@@ -164,10 +169,18 @@ def overlapped_launch_status(device=None):
     return out
 
 
+class OverlappedLaunchError(RuntimeError):
+    """A consumer workgroup of an earlier overlapped launch stopped waiting for its producer: that call's idx /
+    grouped_xyz were incomplete. Cannot happen while the device makes progress (csrc/sa_fused.hip, "Forward progress");
+    use set_overlapped_launch(False) / PN2_OVERLAP=0 to take the two-launch path."""
+
+
 # Sample-granule workspaces of the overlapped launch, one per (device, stream, size): zeroed once, then
 # every call uses the next GENERATION tag (pn2_sample_and_group_xyz_gen), so no per-call clear is needed.
 # Launches on one stream are ordered, so reusing the buffer is safe; different streams get different buffers.
+# Entry: [buffer, generation, pinned status copy, event of that copy (or None), calls]
 _GRANULES = {}
+_STATUS_EVERY = 16                                  # after the first calls, the status word is fetched every 16th call
 
 
 def _granule_workspace(lib, dev, stream, b, m):
@@ -177,10 +190,64 @@ def _granule_workspace(lib, dev, stream, b, m):
         if len(_GRANULES) > 64:
             _GRANULES.clear()
         buf = torch.zeros((lib.pn2_sample_and_group_ws_bytes(b, m),), dtype=torch.uint8, device=dev)
-        ent = [buf, 0]
+        ent = [buf, 0, torch.zeros((1,), dtype=torch.int32).pin_memory(), None, 0]
         _GRANULES[key] = ent
+    _check_status(ent, wait=False)
     ent[1] += 1
-    return ent[0], ent[1]
+    return ent
+
+
+def _status_word(ent):
+    buf = ent[0]
+    return buf[buf.numel() - 16:buf.numel() - 12].view(torch.int32)
+
+
+def _check_status(ent, wait):
+    """Look at the last fetched status word of this workspace (never blocks unless `wait`); raise if a consumer gave up."""
+    ev = ent[3]
+    if ev is None or not (wait or ev.query()):
+        return
+    if wait:
+        ev.synchronize()
+    ent[3] = None
+    if int(ent[2][0]) != 0:
+        _status_word(ent).zero_()
+        ent[2].zero_()
+        raise OverlappedLaunchError("sample_and_group_xyz: a consumer workgroup of an earlier overlapped launch gave up waiting "
+                                    "for its FPS producer; that call's idx / grouped_xyz were incomplete")
+
+
+def _fetch_status(ent):
+    """After a launch: asynchronous copy of the status word into pinned memory, on the launch's stream (no host wait);
+    the next call on this workspace -- or check_overlapped_launches() -- looks at it."""
+    ent[4] += 1
+    if ent[3] is None and (ent[4] <= 4 or ent[4] % _STATUS_EVERY == 0):
+        ent[2].copy_(_status_word(ent), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ent[3] = ev
+
+
+def check_overlapped_launches(device=None):
+    """Fetch and check the status word of every overlapped-launch workspace now (synchronises): raises
+    OverlappedLaunchError if any consumer ever gave up. The operators do the same without waiting, a few calls late."""
+    for (dev_index, _stream, _bm), ent in list(_GRANULES.items()):
+        if device is not None and dev_index != device.index:
+            continue
+        if ent[3] is None:
+            ent[2].copy_(_status_word(ent), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            ent[3] = ev
+        _check_status(ent, wait=True)
+
+
+def _two_launch_path(m, radius, ns, xyz, subtract_centroid):
+    """farthest_point_sample_gather + query_ball_group_xyz: what the overlapped launch computes, in two launches."""
+    from .tf_sampling import farthest_point_sample_gather
+    fps_idx, new_xyz = farthest_point_sample_gather(m, xyz)
+    idx, cnt, grouped = query_ball_group_xyz(radius, ns, xyz, new_xyz, subtract_centroid)
+    return fps_idx, new_xyz, idx, cnt, grouped
 
 
 def sample_and_group_xyz(npoint, radius, nsample, xyz, subtract_centroid=True):
@@ -203,10 +270,7 @@ def sample_and_group_xyz(npoint, radius, nsample, xyz, subtract_centroid=True):
     dev = xyz.device
     lib = _C.lib()
     if b == 0 or not _OVERLAP[0] or not (b <= 128 and 64 <= n <= 8192 and ns <= 256):
-        from .tf_sampling import farthest_point_sample_gather
-        fps_idx, new_xyz = farthest_point_sample_gather(m, xyz)
-        idx, cnt, grouped = query_ball_group_xyz(radius, ns, xyz, new_xyz, subtract_centroid)
-        return fps_idx, new_xyz, idx, cnt, grouped
+        return _two_launch_path(m, radius, ns, xyz, subtract_centroid)
     fps_idx = torch.empty((b, m), dtype=torch.int32, device=dev)
     new_xyz = torch.empty((b, m, 3), dtype=torch.float32, device=dev)
     idx = torch.empty((b, m, ns), dtype=torch.int32, device=dev)
@@ -218,14 +282,20 @@ def sample_and_group_xyz(npoint, radius, nsample, xyz, subtract_centroid=True):
             # a captured launch is replayed with the same arguments: generations cannot advance, so the
             # workspace is cleared inside the graph instead
             ws = torch.empty((lib.pn2_sample_and_group_ws_bytes(b, m),), dtype=torch.uint8, device=dev)
-            _C.check(lib.pn2_sample_and_group_xyz(b, n, m, float(radius), ns, ptr(xyz), ptr(ws), ptr(fps_idx),
-                                                  ptr(new_xyz), ptr(idx), ptr(cnt), ptr(grouped),
-                                                  1 if subtract_centroid else 0, st), "sample_and_group_xyz")
+            rc = lib.pn2_sample_and_group_xyz(b, n, m, float(radius), ns, ptr(xyz), ptr(ws), ptr(fps_idx), ptr(new_xyz),
+                                              ptr(idx), ptr(cnt), ptr(grouped), 1 if subtract_centroid else 0, st)
+            if rc == -4:
+                return _two_launch_path(m, radius, ns, xyz, subtract_centroid)
+            _C.check(rc, "sample_and_group_xyz")
         else:
-            ws, gen = _granule_workspace(lib, dev, st, b, m)
-            _C.check(lib.pn2_sample_and_group_xyz_gen(b, n, m, float(radius), ns, ptr(xyz), ptr(ws), gen, ptr(fps_idx),
-                                                      ptr(new_xyz), ptr(idx), ptr(cnt), ptr(grouped),
-                                                      1 if subtract_centroid else 0, st), "sample_and_group_xyz")
+            ent = _granule_workspace(lib, dev, st, b, m)          # raises if an earlier launch on it reported a give-up
+            rc = lib.pn2_sample_and_group_xyz_gen(b, n, m, float(radius), ns, ptr(xyz), ptr(ent[0]), ent[1], ptr(fps_idx),
+                                                  ptr(new_xyz), ptr(idx), ptr(cnt), ptr(grouped),
+                                                  1 if subtract_centroid else 0, st)
+            if rc == -4:                                          # PN2_E_TOO_LARGE: e.g. too few CUs to hold every producer
+                return _two_launch_path(m, radius, ns, xyz, subtract_centroid)
+            _C.check(rc, "sample_and_group_xyz")
+            _fetch_status(ent)
     return fps_idx, new_xyz, idx, cnt, grouped
 
 

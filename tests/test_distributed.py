@@ -52,6 +52,24 @@ def _worker(rank, world, port, q):
         out = sharding.allreduce_mean_(grads)
         for a, b in zip(out, want):
             assert torch.allclose(a, b, atol=1e-6)
+        # 4. GradBucket: every .grad is a view of ONE persistent flat buffer; backward accumulates into it, the mean
+        #    over ranks is one in-place all-reduce of the buffer, nothing is concatenated or copied back
+        torch.manual_seed(7)
+        net = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.ReLU(), torch.nn.Linear(4, 3))
+        bucket = sharding.GradBucket(net.parameters())
+        ptr0 = bucket.flat.data_ptr()
+        assert all(p.grad.data_ptr() >= ptr0 and p.grad.data_ptr() < ptr0 + bucket.flat.numel() * 4 for p in net.parameters())
+        x = torch.randn(6, 5, generator=torch.Generator().manual_seed(200 + rank))
+        for _ in range(2):                                     # second step: zero_() instead of zero_grad(set_to_none)
+            bucket.zero_()
+            net(x).square().sum().backward()
+            local = bucket.flat.clone()
+            bucket.allreduce_mean_()
+        assert bucket.flat.data_ptr() == ptr0 and net[0].weight.grad.data_ptr() == ptr0
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        assert torch.allclose(bucket.flat, sum(gathered) / world, atol=1e-6)
+        assert torch.allclose(net[2].bias.grad, (sum(gathered) / world)[-3:], atol=1e-6)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, "FAIL: %r" % (e,)))
@@ -116,5 +134,6 @@ def test_bench_spawns_its_own_ranks(scaling):
 def test_bench_single_rank_stub_line():
     line = _run_bench(["--gpus", "1"])
     assert line["n_gpus"] == 1 and "allreduce" not in line and line["unit"] == "clouds/s"
+    assert "traffic_source" in line["roofline"]
     for key in ("metric", "value", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in line

@@ -450,3 +450,34 @@ def test_coop_sa_pack_matches_emulated_dataflow(cin, widths, xyz_first):
         assert 4 * k == pairs.shape[0]
         got = _unswap(last_acc, widths[2], lambda ch: _b_at(bl[2], ch))
     assert np.allclose(got, _want(user_in, ws, bs), rtol=1e-9, atol=1e-9)
+
+
+def test_prepare_fused_warms_every_module_of_the_reference_configs():
+    """`prepare_fused(device)` then HIP-graph capture must not hit a cold pack cache -- every SA, SA-MSG,
+    group_all and FP module of the four reference topologies gets its weights packed ahead of time (host-only work)."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import model_forward_bench as MB
+    import pointnet2_amd.pointnet_util as U
+    dev = torch.device("cpu")
+    # (model, points seen by its group_all level, [(fp module name, c2, c1, unknown points)])
+    cases = [(MB.ClsSSG(), 128, []), (MB.ClsMSG(), 128, []),
+             (MB.PartSeg(), 128, [("fp1", 1024, 256, 16 * 128), ("fp2", 256, 128, 16 * 512), ("fp3", 128, 6, 16 * 2048)]),
+             (MB.SemSeg(), None, [("fp1", 512, 256, 8 * 64), ("fp2", 256, 128, 8 * 256), ("fp3", 256, 64, 8 * 1024),
+                                   ("fp4", 128, 0, 8 * 8192)])]
+    for model, n_all, fps in cases:
+        model.eval()
+        for name, mod in model.named_modules():
+            if isinstance(mod, U.PointnetSAModule):
+                mod.prepare_fused(dev, n=n_all if mod.group_all else None)
+                assert mod._pack_cache is not None and len(mod._pack_cache[1]) == 1, name
+            elif isinstance(mod, U.PointnetSAModuleMSG):
+                mod.prepare_fused(dev)
+                assert len(mod._pack_cache) == len(mod.mlps), name
+        for name, c2, c1, npts in fps:
+            mod = getattr(model, name)
+            mod.prepare_fused(c2, c1, npts, dev)
+            if name != "fp3" or c1 != 6:                       # part_seg FP3: 134 input channels, no fused kernel covers it
+                assert mod._pack_cache is not None and len(mod._pack_cache[1]) == 1, name
