@@ -110,8 +110,17 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void *base, unsigned bytes)
 {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+    // The descriptor's inputs go through readfirstlane: they ARE wave-uniform (kernel arguments, block and wave numbers),
+    // but hipcc cannot always prove it -- anything that met a value derived from threadIdx in a select or a phi is
+    // "divergent" to it -- and an unproven descriptor gets a waterfall loop (4 x v_readfirstlane, compare, saveexec,
+    // branch) around EVERY buffer instruction: 487 readfirstlanes per two blocks in the weight-gradient kernel.
+    const unsigned long long a = (unsigned long long)(uintptr_t)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned nb = __builtin_amdgcn_readfirstlane(bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>((uintptr_t)(((unsigned long long)hi << 32) | lo)), 0, (int)nb,
+                                             0x00020000);
 }
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }       // a value known to be wave-uniform
 __device__ __forceinline__ float bload(rsrc_t r, int voff, int soff)
 {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
@@ -801,190 +810,200 @@ struct TlWgrad {
 };
 
 // One UNIT of operand data = what one wave holds as the MFMA fragment of K16 step e of a 32-channel tile: lane (c, hl)
-// <-> channel 32 tile + c, rows 16e + 8hl + j (j = 0..7) of the 32-row block. A wave loads a unit with eight (sixteen:
-// z and dy) dword loads whose 32 lanes cover 128 contiguous bytes of a row, applies the pass's prologue, splits into
-// the three bf16 levels and writes three 16-byte fragments into the block's LDS image, from where EVERY wave of the
-// workgroup reads the fragments of the output tiles it owns: operands cross the vector memory path once per workgroup.
-struct WgRaw { float z[8], g[8]; float gq; int sel, off; };      // off: first row of the unit inside its group
+// <-> channel 32 tile + c, rows 16e + 8hl + j (j = 0..7) of the 32-row block. A wave loads a unit with dword loads whose
+// 32 lanes cover 128 contiguous bytes of a row, applies the pass's prologue, splits into the three bf16 levels and writes
+// three 16-byte fragments into the block's LDS image, from where EVERY wave of the workgroup reads the fragments of the
+// output tiles it owns: operands cross the vector memory path once per workgroup.
+//
+// Two rules shaped this code (both measured):
+//  * BRANCH-FREE loads. The units of a workgroup differ in kind (rows of h, rows of z and dy, routed gradient, nothing),
+//    and a wait shared by paths with different numbers of loads in flight can only be vmcnt(0) -- with branches around the
+//    loads the two-block prefetch drained at every block. Every unit of every wave therefore issues the same sequence of
+//    buffer loads, and what a unit does not need points at an empty descriptor (out-of-range: returns 0, no memory access).
+//  * Everything that does not depend on the block is computed ONCE per unit (WgUnit, before the block loop): these
+//    kernels issue ~2500 instructions per 32-row block and wave, and were bound by that, not by memory.
+enum { K_NONE = 0, K_H = 1, K_HGATHER = 2, K_DZ = 3, K_DZPOOL = 4, K_FILL = 5, K_ONES = 6 };
+enum { D_DZ = 0, D_DZPOOL = 1, D_TOP = 2 };                       // second-operand class of the launch (template parameter)
 
-// BRANCH-FREE: every unit of every wave issues the same 18 buffer loads -- eight rows of a first stream, eight of a second,
-// two per-group values -- and what a unit does not need is pointed at an empty descriptor (out-of-range loads return 0
-// without touching memory). The kinds of the units of a workgroup differ (rows of h, rows of z and dy, routed gradient,
-// nothing), and a wait that is shared by paths with different numbers of loads in flight can only be vmcnt(0): with
-// branches around the loads the two-block prefetch drained at every block.
+struct WgRaw { float z[8], g[8]; float gq; int sel, off; };      // off: first row of the unit inside its group
+struct WgUnit {
+    int kind;                   // uniform
+    int relu;                   // uniform: K_H rows go through relu(p0 z + p1) (else taken as they are)
+    int e, tile;                // uniform: K16 step, tile of the block image
+    const float *b1, *b2;       // uniform: row streams (nullptr: none)
+    int pitch1;                 // uniform: floats per row of the row streams
+    int voff;                   // lane: byte offset of its first row inside the block's rows (kWgOob: no such channel)
+    const float *bq;            // uniform: per-group values (routed gradient / centroid)
+    const int *bs;              // uniform: per-group sample numbers
+    int nq, chq;                // uniform pitch / lane channel (-1: none) of the per-group streams
+    // gather (layer 1 of an SA level): a lane's channel is a coordinate (kx) or a feature (kf) of the row's point; the two
+    // tensors are read through two UNIFORM descriptors, the lane that needs neither / only one reads out of range there
+    // (a per-lane descriptor would put a waterfall loop around every load)
+    const float *bgx, *bgf;     // uniform: xyz, points
+    int kx, kf, pitchf;         // lane: coordinate / feature number (-1: none); uniform: feature channels per point
+    float p0, p1, p2;           // lane: per-channel parameters of the prologue
+};
+constexpr int kWgOob = (int)0xfffffff0u;                         // beyond every descriptor's num_records (<= 0x7fffffff)
+
 __device__ __forceinline__ int bloadi(rsrc_t r, int voff, int soff)
 {
     return (int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
 }
 
-template <bool GATHER>
-__device__ __forceinline__ void wg_load_unit(const TlWgrad &p, long long row0, int unit, int us, int ts, int lane, bool live,
-                                             WgRaw &r)
+__device__ __forceinline__ WgUnit wg_plan_unit(const TlWgrad &p, int unit, int nunits, int us, int ts, int lane)
 {
-    const int tile = unit >> 1, e = unit & 1, hl = lane >> 5, c = lane & 31;
-    const int rin = 16 * e + 8 * hl;                               // first of the lane's eight rows inside the block
-    const int rbase = (int)row0 + rin;                             // rows < 2^31 (checked by the launcher)
-    const int kOob = (int)0xfffffff0u;                              // beyond every descriptor's num_records (<= 0x7fffffff)
-    const bool isx = tile < p.tus;
-    const int tg = ts * p.tts + tile - p.tus, tx = (p.KI + 31) / 32;
-    // ---- what this unit reads (wave-uniform choices: scalar selects, no memory operation inside a branch)
-    const float *b1 = nullptr, *b2 = nullptr, *bq = nullptr;
-    const int *bs = nullptr;
-    int pitch1 = 0, ch1 = 0, lim1 = 0, nq = 0, chq = 0, limq = 0, grows = 1;
-    bool gather = false;
-    if (!live) {                                                   // no such unit / no such block: every load out of range
-    } else if (isx) {
-        ch1 = (us * p.tus + tile) * 32 + c; lim1 = p.KI;
-        if (GATHER && p.amode == A_GATHER) gather = true; else { b1 = p.A; pitch1 = p.KI; }
-    } else if (p.dmode == A_FILL) {
-        if (tg < p.tf) { bq = p.G; bs = p.argsel; nq = p.NF; chq = tg * 32 + c; limq = p.NF; grows = p.group_rows; }
-        else if (tg < p.tf + tx && !p.xshare) { b1 = p.A; pitch1 = p.KI; ch1 = (tg - p.tf) * 32 + c; lim1 = p.KI; }
-    } else {
-        b1 = p.Z; pitch1 = p.NO; ch1 = tg * 32 + c; lim1 = p.NO;
-        if (p.dmode == A_DZ_POOL) { bq = p.G; bs = p.argsel; nq = p.NO; chq = ch1; limq = p.NO; grows = p.group_rows; }
-        else b2 = p.G;
-    }
-    // ---- descriptors and lane offsets
-    const unsigned bytes1 = 32u * (unsigned)pitch1 * 4u;
-    rsrc_t r1 = make_rsrc(b1 ? b1 + (size_t)row0 * pitch1 : nullptr, b1 ? bytes1 : 0u);
-    const rsrc_t r2 = make_rsrc(b2 ? b2 + (size_t)row0 * pitch1 : nullptr, b2 ? bytes1 : 0u);
-    int voff = (b1 && ch1 < lim1) ? (rin * pitch1 + ch1) * 4 : kOob;
-    int step = pitch1 * 4;                                         // byte distance between the lane's rows
-    int vj[8];
-    float cen_dummy = 0.0f;
-    (void)cen_dummy;
-    const int grp = (int)((unsigned)rbase / (unsigned)grows);
-    r.off = rbase - grp * grows;
-    rsrc_t rq = make_rsrc(bq, bq ? 0x7fffffffu : 0u);
-    const rsrc_t rs = make_rsrc(bs, bs ? 0x7fffffffu : 0u);
-    int voffq = (bq && chq < limq) ? (grp * nq + chq) * 4 : kOob;
-    if (GATHER) {
-        // rows of the grouped input: the point numbers of the step's 16 rows come through wave-uniform (scalar) loads --
-        // counted by lgkmcnt, they do not disturb the vector loads in flight -- and each lane then picks its half
-        const TlGather &g = p.g;
-        const int kx = ch1 - g.xyz_off, kf = ch1 - g.feat_off;
-        const bool px = gather && kx >= 0 && kx < 3, pf = gather && kf >= 0 && kf < g.cfeat;
-        const int ggrp = (int)((unsigned)rbase / (unsigned)g.nsample), s0 = rbase - ggrp * g.nsample;
-        const int cloud = ggrp / g.m;                              // group sizes are multiples of 8: one group per unit-lane
-        int pts[16];
-        const int *ip = (g.idx && live) ? g.idx + row0 + 16 * e : nullptr;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) pts[j] = ip ? ip[j] : 0;
-        if (gather) {
-            const float *src = px ? g.xyz : g.points;
-            const int pitch = px ? 3 : g.cfeat, kk = px ? kx : kf;
-            r1 = make_rsrc(src, 0x7fffffffu);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int pt = g.idx ? (hl ? pts[8 + j] : pts[j]) : s0 + j;
-                vj[j] = (px || pf) ? ((cloud * g.n + pt) * pitch + kk) * 4 : kOob;
-            }
-            if (g.new_xyz) { rq = make_rsrc(g.new_xyz, 0x7fffffffu); voffq = px ? (ggrp * 3 + kx) * 4 : kOob; }
+    WgUnit w;
+    const int hl = lane >> 5, c = lane & 31;
+    w.kind = K_NONE; w.relu = 0; w.e = unit & 1; w.tile = unit >> 1;
+    w.b1 = nullptr; w.b2 = nullptr; w.bq = nullptr; w.bs = nullptr; w.bgx = nullptr; w.bgf = nullptr;
+    w.pitch1 = 0; w.voff = kWgOob; w.nq = 0; w.chq = -1; w.kx = -1; w.kf = -1; w.pitchf = 0;
+    w.p0 = 1.0f; w.p1 = 0.0f; w.p2 = 0.0f;
+    if (unit >= nunits) return w;
+    const int rin = 16 * w.e + 8 * hl, tx = (p.KI + 31) / 32;
+    if (w.tile < p.tus) {                                          // the layer's input h
+        const int ch = (us * p.tus + w.tile) * 32 + c;
+        if (p.amode == A_GATHER) {
+            const TlGather &g = p.g;
+            const int kx = ch - g.xyz_off, kf = ch - g.feat_off;
+            w.kind = K_HGATHER;
+            w.bgx = g.xyz; w.bgf = g.points; w.pitchf = g.cfeat; w.bq = g.new_xyz; w.nq = 3;     // pointers: uniform choices only
+            if (ch < p.KI && kx >= 0 && kx < 3) { w.kx = kx; w.chq = g.new_xyz ? kx : -1; }
+            else if (ch < p.KI && kf >= 0 && kf < g.cfeat) w.kf = kf;
         } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) vj[j] = voff == kOob ? kOob : voff + j * step;       // (no wrap: voff < 2^31)
+            w.kind = K_H; w.b1 = p.A; w.pitch1 = p.KI; w.relu = p.amode == A_RELU;
+            if (ch < p.KI) {
+                w.voff = (rin * p.KI + ch) * 4;
+                if (p.amode == A_RELU) { w.p0 = p.pa[ch]; w.p1 = p.pc[ch]; }
+            }
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r.z[j] = bload(r1, vj[j], 0);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r.z[j] = bload(r1, voff, j * step);
+        return w;
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r.g[j] = bload(r2, voff, j * step);
-    r.gq = bload(rq, voffq, 0);
-    r.sel = bloadi(rs, voffq, 0);
-}
-
-// the per-channel parameters of a unit's lane (its channel never changes): fetched ONCE, before the block loop -- a
-// global load inside the loop would have to be waited for with vmcnt(0), which also drains the row prefetch
-struct WgPar { float p0, p1, p2; };
-
-__device__ __forceinline__ WgPar wg_unit_params(const TlWgrad &p, int unit, int us, int ts, int lane)
-{
-    const int tile = unit >> 1, c = lane & 31;
-    WgPar w = {1.0f, 0.0f, 0.0f};
-    if (tile < p.tus) {
-        const int ch = (us * p.tus + tile) * 32 + c;
-        if (p.amode == A_RELU && ch < p.KI) { w.p0 = p.pa[ch]; w.p1 = p.pc[ch]; }
-    } else if (p.dmode == A_FILL) {
-        const int tg = ts * p.tts + tile - p.tus;
+    const int tg = ts * p.tts + w.tile - p.tus;                    // tile of the second operand
+    if (p.dmode == A_FILL) {                                       // [s dy routed to the pooled samples | h itself | ones]
         if (tg < p.tf) {
             const int ch = tg * 32 + c;
-            if (ch < p.NF) w.p0 = p.coef[ch];                      // s
-        } else {
-            const int ch = (tg - p.tf) * 32 + c;
-            if (ch < p.KI) { w.p0 = p.pa[ch]; w.p1 = p.pc[ch]; }    // h = relu(a z + c), as the first operand
+            w.kind = K_FILL; w.bq = p.G; w.bs = p.argsel; w.nq = p.NF;
+            if (ch < p.NF) { w.chq = ch; w.p0 = p.coef[ch]; }
+        } else if (tg < p.tf + tx) {
+            if (!p.xshare) {
+                const int ch = (tg - p.tf) * 32 + c;
+                w.kind = K_H; w.b1 = p.A; w.pitch1 = p.KI; w.relu = 1;
+                if (ch < p.KI) { w.voff = (rin * p.KI + ch) * 4; w.p0 = p.pa[ch]; w.p1 = p.pc[ch]; }
+            }
+        } else if (tg == p.tf + tx) {
+            w.kind = K_ONES;
         }
-    } else {
-        const int ch = (ts * p.tts + tile - p.tus) * 32 + c;
-        if (ch < p.NO) { w.p0 = p.coef[ch]; w.p1 = p.coef[p.NO + ch]; w.p2 = p.coef[2 * p.NO + ch]; }
+        return w;
+    }
+    const int ch = tg * 32 + c;                                    // dz = s dy - c0 - c1 z
+    w.kind = p.dmode == A_DZ_POOL ? K_DZPOOL : K_DZ;
+    w.b1 = p.Z; w.pitch1 = p.NO;
+    if (p.dmode == A_DZ_POOL) { w.bq = p.G; w.bs = p.argsel; w.nq = p.NO; } else w.b2 = p.G;
+    if (ch < p.NO) {
+        w.voff = (rin * p.NO + ch) * 4;
+        if (p.dmode == A_DZ_POOL) w.chq = ch;
+        w.p0 = p.coef[ch]; w.p1 = p.coef[p.NO + ch]; w.p2 = p.coef[2 * p.NO + ch];
     }
     return w;
 }
 
-// prologue + split of a loaded unit -> its three fragments in the block image ([tile][level][e][lane] 16-byte vectors)
-__device__ __forceinline__ void wg_store_unit(const TlWgrad &p, const WgRaw &r, const WgPar &w, int unit, int us, int ts, int lane,
-                                              u32x4 *img)
+// the loads of one unit for the block whose first row is row0 (live = false: no such block -- everything out of range).
+// grp_u / off_u: group of the block and its first row inside it when a group is a multiple of 32 rows (uniform).
+template <bool GATHER, int DCLS>
+__device__ __forceinline__ void wg_load_unit(const TlWgrad &p, const WgUnit &w, long long row0, int grp_u, int off_u, int lane,
+                                             bool live, WgRaw &r)
 {
-    const int tile = unit >> 1, e = unit & 1, c = lane & 31;
-    u32x4 *o = img + ((size_t)tile * 3 * 2 + e) * 64 + lane;
-    if (p.dmode == A_FILL && tile >= p.tus) {
-        const int tg = ts * p.tts + tile - p.tus, tx = (p.KI + 31) / 32;
-        if (tg < p.tf) {
-            // one non-zero per lane (the pool routes dy to ONE row): split it once and drop its three bf16 levels into slot sel
-            const int rel = r.sel - r.off;                          // the pooled sample's row inside this unit, if it is here
-            const float v = (rel >= 0 && rel < 8 && tg * 32 + c < p.NF) ? __fmul_rn(w.p0, r.gq) : 0.0f;
-            const unsigned b1 = pack_bf16(v, 0.0f) & 0xffffu;
-            const float r1 = __fsub_rn(v, __uint_as_float(b1 << 16));
-            const unsigned b2 = pack_bf16(r1, 0.0f) & 0xffffu;
-            const float r2 = __fsub_rn(r1, __uint_as_float(b2 << 16));
-            const unsigned b3 = pack_bf16(r2, 0.0f) & 0xffffu;
-            const int d = rel >> 1, sh = (rel & 1) * 16;
-            u32x4 l1, l2, l3;
+    const int hl = lane >> 5, rin = 16 * w.e + 8 * hl, step = uni(w.pitch1 * 4);
+    const unsigned bytes1 = live ? 32u * (unsigned)w.pitch1 * 4u : 0u;
+    rsrc_t r1 = make_rsrc(w.b1 ? w.b1 + (size_t)row0 * w.pitch1 : nullptr, w.b1 ? bytes1 : 0u);
+    // per-group values: groups are 16 rows or a multiple of 32 (one group per block, uniform)
+    const bool g16 = p.group_rows == 16;
+    const int grp = g16 ? (((int)row0 + rin) >> 4) : grp_u;
+    r.off = g16 ? ((rin & 8)) : off_u + rin;
+    rsrc_t rq = make_rsrc(w.bq, (w.bq && live) ? 0x7fffffffu : 0u);
+    const rsrc_t rs = make_rsrc(w.bs, (w.bs && live) ? 0x7fffffffu : 0u);
+    int voffq = w.chq >= 0 ? (grp * w.nq + w.chq) * 4 : kWgOob;
+    if (GATHER) {
+        // rows of the grouped input: the point numbers of the step's 16 rows come through wave-uniform (scalar) loads --
+        // counted by lgkmcnt, they do not disturb the vector loads in flight -- and each lane then picks its half
+        const TlGather &g = p.g;
+        const bool gat = w.kind == K_HGATHER;
+        const int ggrp = (int)((unsigned)((int)row0 + rin) / (unsigned)g.nsample);      // group sizes are multiples of 8
+        const int s0 = (int)row0 + rin - ggrp * g.nsample, cloud = ggrp / g.m;
+        int pts[16];
+        const int *ip = (g.idx && live) ? g.idx + row0 + 16 * w.e : nullptr;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                l1[q] = d == q ? b1 << sh : 0u;
-                l2[q] = d == q ? b2 << sh : 0u;
-                l3[q] = d == q ? b3 << sh : 0u;
-            }
-            o[0] = l1; o[128] = l2; o[256] = l3;
-            return;
+        for (int j = 0; j < 16; ++j) pts[j] = ip ? ip[j] : 0;
+        const rsrc_t r2 = make_rsrc(w.b2 ? w.b2 + (size_t)row0 * w.pitch1 : nullptr, w.b2 ? bytes1 : 0u);
+        const rsrc_t rx = make_rsrc(w.bgx, (w.bgx && live) ? 0x7fffffffu : 0u), rf = make_rsrc(w.bgf, (w.bgf && live) ? 0x7fffffffu : 0u);
+        if (gat) voffq = w.chq >= 0 ? (ggrp * 3 + w.chq) * 4 : kWgOob;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int pt = g.idx ? (hl ? pts[8 + j] : pts[j]) : s0 + j;
+            const int vx = w.kx >= 0 ? ((cloud * g.n + pt) * 3 + w.kx) * 4 : kWgOob;
+            const int vf = w.kf >= 0 ? ((cloud * g.n + pt) * w.pitchf + w.kf) * 4 : kWgOob;
+            const int vr = w.voff == kWgOob ? kWgOob : w.voff + j * step;
+            r.z[j] = bload(gat ? rx : r1, gat ? vx : vr, 0);         // uniform choice of the descriptor
+            r.g[j] = bload(gat ? rf : r2, gat ? vf : vr, 0);
         }
-        if (tg < p.tf + tx && p.xshare) return;                     // read from the first operand's tile instead
-        if (tg >= p.tf + tx) return;                                // the column of ones is written once, before the loop
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.z[j] = bload(r1, w.voff, j * step);
+        if (DCLS == D_DZ) {
+            const rsrc_t r2 = make_rsrc(w.b2 ? w.b2 + (size_t)row0 * w.pitch1 : nullptr, w.b2 ? bytes1 : 0u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r.g[j] = bload(r2, w.voff, j * step);
+        }
+    }
+    if (DCLS != D_DZ || GATHER) {
+        r.gq = bload(rq, voffq, 0);
+        r.sel = bloadi(rs, voffq, 0);
+    }
+}
+
+// prologue + split of a loaded unit -> its three fragments in the block image ([tile][level][e][lane] 16-byte vectors)
+template <int DCLS>
+__device__ __forceinline__ void wg_store_unit(const WgUnit &w, const WgRaw &r, int lane, u32x4 *img)
+{
+    if (w.kind == K_NONE || w.kind == K_ONES) return;             // nothing / written once before the loop
+    u32x4 *o = img + ((size_t)w.tile * 3 * 2 + w.e) * 64 + lane;
+    if (DCLS == D_TOP && w.kind == K_FILL) {
+        // one non-zero per lane (the pool routes dy to ONE row): split it once and drop its three bf16 levels into slot rel
+        const int rel = r.sel - r.off;                             // the pooled sample's row inside this unit, if it is here
+        const float v = (rel >= 0 && rel < 8 && w.chq >= 0) ? __fmul_rn(w.p0, r.gq) : 0.0f;
+        const unsigned b1 = pack_bf16(v, 0.0f) & 0xffffu;
+        const float r1 = __fsub_rn(v, __uint_as_float(b1 << 16));
+        const unsigned b2 = pack_bf16(r1, 0.0f) & 0xffffu;
+        const float r2 = __fsub_rn(r1, __uint_as_float(b2 << 16));
+        const unsigned b3 = pack_bf16(r2, 0.0f) & 0xffffu;
+        const int d = rel >> 1, sh = (rel & 1) * 16;
+        u32x4 l1, l2, l3;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            l1[q] = d == q ? b1 << sh : 0u;
+            l2[q] = d == q ? b2 << sh : 0u;
+            l3[q] = d == q ? b3 << sh : 0u;
+        }
+        o[0] = l1; o[128] = l2; o[256] = l3;
+        return;
     }
     f32x16 x;
 #pragma unroll
     for (int v = 0; v < 16; ++v) x[v] = 0.0f;
-    if (tile < p.tus) {
-        const int ch = (us * p.tus + tile) * 32 + c;
-        if (p.amode == A_RELU && ch < p.KI) {
+    if (w.kind == K_H) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = vmax(__fadd_rn(__fmul_rn(w.p0, r.z[j]), w.p1), 0.0f);
-        } else if (p.amode == A_GATHER) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = __fsub_rn(r.z[j], r.gq);    // pointnet_util.py:46 (gq: the centroid coordinate, 0 for features)
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = r.z[j];
+        for (int j = 0; j < 8; ++j) {
+            const float y = vmax(__fadd_rn(__fmul_rn(w.p0, r.z[j]), w.p1), 0.0f);
+            x[j] = w.voff == kWgOob ? 0.0f : w.relu ? y : r.z[j];
         }
-    } else if (p.dmode == A_FILL) {
-        const int tg = ts * p.tts + tile - p.tus, tx = (p.KI + 31) / 32;
-        if (tg >= p.tf && tg < p.tf + tx) {
-            if ((tg - p.tf) * 32 + c < p.KI) {
+    } else if (w.kind == K_HGATHER) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = vmax(__fadd_rn(__fmul_rn(w.p0, r.z[j]), w.p1), 0.0f);
-            }
-        }
+        for (int j = 0; j < 8; ++j) x[j] = __fadd_rn(__fsub_rn(r.z[j], r.gq), r.g[j]);   // pointnet_util.py:46: coordinate - centroid (z, gq) or feature (g); the other stream read 0
     } else {
-        const int ch = (ts * p.tts + tile - p.tus) * 32 + c;
-        if (ch < p.NO) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float dy = p.dmode == A_DZ_POOL ? (r.sel - r.off == j ? r.gq : 0.0f) : r.g[j];
-                x[j] = __fsub_rn(__fsub_rn(__fmul_rn(w.p0, dy), w.p1), __fmul_rn(w.p2, r.z[j]));
-            }
+        for (int j = 0; j < 8; ++j) {
+            const float dy = DCLS == D_DZPOOL ? (r.sel - r.off == j ? r.gq : 0.0f) : r.g[j];
+            x[j] = w.voff == kWgOob ? 0.0f : __fsub_rn(__fsub_rn(__fmul_rn(w.p0, dy), w.p1), __fmul_rn(w.p2, r.z[j]));
         }
     }
     const ActSplit sp = split_act(x);                             // registers 0..7 -> p[0][level]
@@ -993,11 +1012,10 @@ __device__ __forceinline__ void wg_store_unit(const TlWgrad &p, const WgRaw &r, 
     o[256] = sp.p[0][2];
 }
 
+// Every wave keeps the rows of the NEXT TWO blocks in flight in registers (two raw sets, the block loop is unrolled by
+// two), the block image in LDS is double buffered, one s_barrier per block.
 // TPW: output tiles per wave; UPW: operand units a wave loads per 32-row block
-// Memory-bound (a few MFMAs per 40 KB of rows): what matters is bytes in flight. Every wave keeps the rows of the NEXT TWO
-// blocks in flight in registers (two raw sets, the block loop is unrolled by two), the block image in LDS is double
-// buffered, one s_barrier per block.
-template <int TPW, int UPW, bool GATHER>
+template <int TPW, int UPW, bool GATHER, int DCLS>
 __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1013,30 +1031,35 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[i][v] = 0.0f;
     WgRaw ra[UPW], rb[UPW];
-    WgPar par[UPW];
+    WgUnit un[UPW];
 #pragma unroll
-    for (int i = 0; i < UPW; ++i)
-        if (wave + 8 * i < nunits) par[i] = wg_unit_params(p, wave + 8 * i, us, ts, lane);
+    for (int i = 0; i < UPW; ++i) un[i] = wg_plan_unit(p, wave + 8 * i, nunits, us, ts, lane);
+    // output tiles of this wave: image slots of their two operands (fixed)
+    int xa_off[TPW], xb_off[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int q = wave + 8 * i, u = q < nout ? q / p.tts : 0, t = q < nout ? q % p.tts : 0, tg = ts * p.tts + t;
+        const bool shared = p.dmode == A_FILL && p.xshare && tg >= p.tf && tg < p.tf + p.tus;
+        xa_off[i] = u * 384;
+        xb_off[i] = (shared ? tg - p.tf : p.tus + t) * 384;
+    }
+    const int grows = p.group_rows > 0 ? p.group_rows : 32;
     auto load = [&](long long b, WgRaw (&r)[UPW]) {             // the same instruction sequence for every wave and block
         const bool inb = b < blocks;
+        const long long row0 = (inb ? b : 0) * 32;
+        const int grp_u = (int)((unsigned)row0 / (unsigned)grows), off_u = (int)row0 - grp_u * grows;
 #pragma unroll
-        for (int i = 0; i < UPW; ++i)
-            wg_load_unit<GATHER>(p, (inb ? b : 0) * 32, wave + 8 * i, us, ts, lane, inb && wave + 8 * i < nunits, r[i]);
+        for (int i = 0; i < UPW; ++i) wg_load_unit<GATHER, DCLS>(p, un[i], row0, grp_u, off_u, lane, inb, r[i]);
     };
     auto block = [&](long long b, WgRaw (&r)[UPW], u32x4 *img) {
 #pragma unroll
-        for (int i = 0; i < UPW; ++i)
-            if (wave + 8 * i < nunits) wg_store_unit(p, r[i], par[i], wave + 8 * i, us, ts, lane, img);
+        for (int i = 0; i < UPW; ++i) wg_store_unit<DCLS>(un[i], r[i], lane, img);
         __syncthreads();
         load(b + 2 * step, r);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int q = wave + 8 * i;
-            if (q < nout) {
-                const int u = q / p.tts, t = q % p.tts, tg = ts * p.tts + t;
-                const bool shared = p.dmode == A_FILL && p.xshare && tg >= p.tf && tg < p.tf + p.tus;
-                const u32x4 *xa = img + (size_t)u * 384 + lane;
-                const u32x4 *xb = img + (size_t)(shared ? tg - p.tf : p.tus + t) * 384 + lane;
+            if (wave + 8 * i < nout) {
+                const u32x4 *xa = img + xa_off[i] + lane, *xb = img + xb_off[i] + lane;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const u32x4 a[3] = {xa[e * 64], xa[128 + e * 64], xa[256 + e * 64]};
@@ -1046,17 +1069,15 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
             }
         }
     };
-    if (p.dmode == A_FILL) {
+    if (DCLS == D_TOP) {
         // the column of ones (sum over the rows of h): fragment slot j of lanes with c == 0 is bf16 1.0 at level 1, constant
-        const int tx = (p.KI + 31) / 32;
 #pragma unroll
         for (int i = 0; i < UPW; ++i) {
-            const int unit = wave + 8 * i, tile = unit >> 1, e = unit & 1;
-            if (unit < nunits && tile >= p.tus && ts * p.tts + tile - p.tus == p.tf + tx) {
+            if (un[i].kind == K_ONES) {
                 const unsigned one2 = (lane & 31) == 0 ? 0x3f803f80u : 0u;
                 const u32x4 ones = {one2, one2, one2, one2}, zero = {0u, 0u, 0u, 0u};
                 for (int b = 0; b < 2; ++b) {
-                    u32x4 *o = img0 + (size_t)b * imgv + ((size_t)tile * 3 * 2 + e) * 64 + lane;
+                    u32x4 *o = img0 + (size_t)b * imgv + ((size_t)un[i].tile * 3 * 2 + un[i].e) * 64 + lane;
                     o[0] = ones; o[128] = zero; o[256] = zero;
                 }
             }
@@ -1358,18 +1379,29 @@ static int launch_gemm(int amode, TlGemm &p, const GemmShape &g, hipStream_t st,
     return launch_gemm_ns<1>(amode, p, g, grid, st);
 }
 
-template <int TPW>
-static int launch_wgrad_tpw(const TlWgrad &p, const WgradShape &w, dim3 grid, hipStream_t st)
+template <int TPW, bool GATHER, int DCLS>
+static int launch_wgrad_kern(const TlWgrad &p, const WgradShape &w, dim3 grid, hipStream_t st)
 {
 #define PN2_WG_CASE(U)                                                          \
     if (w.upw == U) {                                                           \
-        auto kern = p.amode == A_GATHER ? tl_wgrad_kernel<TPW, U, true> : tl_wgrad_kernel<TPW, U, false>;   \
+        auto kern = tl_wgrad_kernel<TPW, U, GATHER, DCLS>;                      \
         if (int rc = allow_dynamic_lds(kern, w.lds)) return rc;                 \
         return launch(kern, grid, dim3(kTlThreads), w.lds, st, p);              \
     }
     PN2_WG_CASE(1) PN2_WG_CASE(2) PN2_WG_CASE(3)
 #undef PN2_WG_CASE
     return PN2_E_ARG;
+}
+
+template <int TPW>
+static int launch_wgrad_tpw(const TlWgrad &p, const WgradShape &w, dim3 grid, hipStream_t st)
+{
+    if (p.dmode == A_FILL) return launch_wgrad_kern<TPW, false, D_TOP>(p, w, grid, st);
+    if (p.amode == A_GATHER)
+        return p.dmode == A_DZ_POOL ? launch_wgrad_kern<TPW, true, D_DZPOOL>(p, w, grid, st)
+                                    : launch_wgrad_kern<TPW, true, D_DZ>(p, w, grid, st);
+    return p.dmode == A_DZ_POOL ? launch_wgrad_kern<TPW, false, D_DZPOOL>(p, w, grid, st)
+                                : launch_wgrad_kern<TPW, false, D_DZ>(p, w, grid, st);
 }
 
 static int launch_wgrad(TlWgrad &p, const WgradShape &w, float *partial2, const pn2_bn_layer &L, hipStream_t st,
