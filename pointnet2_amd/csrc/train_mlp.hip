@@ -599,25 +599,28 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
 
 // ---- weights -> three-level bf16 operand tiles, on the device ---------------------------------------------------------
 // value for K16 step e, level, lane l, slot j of pair (slab, u, t) = level of W[32u + 16e + 8(l >> 5) + j][32(slab NS + t) + (l & 31)]
-__global__ __launch_bounds__(256) void tl_pack_kernel(const float *__restrict__ w, long long sk, long long sn, int K, int N,
-                                                      int tk, int ns, int slabs, u32x4 *__restrict__ out)
+struct TlPackJob { const float *w; long long sk, sn; int K, N, tk, ns, slabs; u32x4 *out; };
+struct TlPackJobs { TlPackJob j[8]; };                            // one launch packs every layer of a level (blockIdx.y = layer)
+
+__global__ __launch_bounds__(256) void tl_pack_kernel(const TlPackJobs jobs)
 {
-    const long long total = (long long)slabs * tk * ns * 128;           // one thread per (pair, e, lane)
+    const TlPackJob &q = jobs.j[blockIdx.y];
+    const long long total = (long long)q.slabs * q.tk * q.ns * 128;     // one thread per (pair, e, lane)
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int lane = (int)(i & 63), e = (int)((i >> 6) & 1);
         const long long pair = i >> 7;
-        const int t = (int)(pair % ns), u = (int)((pair / ns) % tk), slab = (int)(pair / ((long long)ns * tk));
-        const int n = (slab * ns + t) * 32 + (lane & 31);
+        const int t = (int)(pair % q.ns), u = (int)((pair / q.ns) % q.tk), slab = (int)(pair / ((long long)q.ns * q.tk));
+        const int n = (slab * q.ns + t) * 32 + (lane & 31);
         f32x16 x;
 #pragma unroll
         for (int v = 0; v < 16; ++v) x[v] = 0.0f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 32 * u + 16 * e + 8 * (lane >> 5) + j;
-            x[j] = (k < K && n < N) ? w[k * sk + n * sn] : 0.0f;
+            x[j] = (k < q.K && n < q.N) ? q.w[k * q.sk + n * q.sn] : 0.0f;
         }
         const ActSplit sp = split_act(x);
-        u32x4 *o = out + pair * kPairVec + (size_t)e * 192 + lane;
+        u32x4 *o = q.out + pair * kPairVec + (size_t)e * 192 + lane;
         o[0] = sp.p[0][0];
         o[64] = sp.p[0][1];
         o[128] = sp.p[0][2];
@@ -1208,13 +1211,20 @@ static inline int pick_ns(int tn)
 
 struct GemmShape { int K, N, tk, tn, ns, slabs, resident; size_t lds, pack_bytes; };
 
-static GemmShape gemm_shape(int K, int N)
+static GemmShape gemm_shape(long long rows, int K, int N)
 {
     GemmShape g;
     g.K = K; g.N = N;
     g.tk = tiles(K); g.tn = tiles(N);
     g.ns = pick_ns(g.tn);
     g.slabs = (g.tn + g.ns - 1) / g.ns;
+    // few rows (group_all, the deep levels of the segmentation nets): a workgroup covers 256 rows of one column slab, so
+    // narrower slabs are what spreads the pass over the chip -- the rows are re-read per slab, which is nothing here
+    const long long rounds = (rows / 32 + kTlWaves - 1) / kTlWaves;
+    while (g.ns > 1 && rounds * g.slabs < 128) {
+        g.ns /= 2;
+        g.slabs = (g.tn + g.ns - 1) / g.ns;
+    }
     const size_t params = (size_t)3 * g.tk * 32 * sizeof(float), stage = (size_t)g.ns * kPairWords * 4;
     g.resident = params + stage * g.tk <= (size_t)144 * 1024 && !env_int("PN2_TL_FORCE_STREAM", 0);
     g.lds = params + stage * (g.resident ? g.tk : 2);
@@ -1228,8 +1238,12 @@ static WgradShape wgrad_shape(long long rows, int KI, int NO)
 {
     WgradShape w;
     const int tu = tiles(KI), tt = tiles(NO);
-    w.tus = tu < 4 ? tu : 4;
-    w.tts = tt < 8 ? tt : 8;
+    w.tus = tu < 4 ? tu : 4;                                        // (five input tiles in one slab -- the 131 channels of the second
+    w.tts = tt < 8 ? tt : 8;                                        // SA levels -- measured slower: three units per wave spill)
+    // few rows: more, smaller slabs spread the pass over the chip (each slab re-reads the rows, which is nothing here)
+    while ((long long)((tu + w.tus - 1) / w.tus) * ((tt + w.tts - 1) / w.tts) * ((rows / 32 + 3) / 4) < 64 && (w.tus > 1 || w.tts > 1)) {
+        if (w.tts >= w.tus && w.tts > 1) w.tts = (w.tts + 1) / 2; else w.tus = (w.tus + 1) / 2;
+    }
     w.uslabs = (tu + w.tus - 1) / w.tus;
     w.tslabs = (tt + w.tts - 1) / w.tts;
     const int nout = w.tus * w.tts, per = (nout + 7) / 8;
@@ -1283,7 +1297,7 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
         const int cin = widths[l], cout = widths[l + 1];
         if (cin <= 0 || cout <= 0 || cout % 4) return false;
         const bool ztop = backward && l == nlayers - 1 && !top_stored(rows, nlayers, widths, pool_rows);
-        const GemmShape g = ztop ? gemm_shape(tiles(cout) * 32 + cin, cin) : backward ? gemm_shape(cout, cin) : gemm_shape(cin, cout);
+        const GemmShape g = ztop ? gemm_shape(rows, tiles(cout) * 32 + cin, cin) : backward ? gemm_shape(rows, cout, cin) : gemm_shape(rows, cin, cout);
         pl.pack[l] = off; off = align_up(off + g.pack_bytes);
         pl.stats[l] = off; off = align_up(off + sizeof(double) * 2 * cout * kMaxParts);
         if (backward) { pl.coef[l] = off; off = align_up(off + sizeof(float) * 3 * cout); }
@@ -1329,13 +1343,33 @@ static TlGather make_gather(const pn2_group_src *g)
     return t;
 }
 
+static void add_pack_job(TlPackJobs &jobs, int &n, const float *w, long long sk, long long sn, const GemmShape &g, void *out)
+{
+    TlPackJob &q = jobs.j[n++];
+    q.w = w; q.sk = sk; q.sn = sn; q.K = g.K; q.N = g.N; q.tk = g.tk; q.ns = g.ns; q.slabs = g.slabs;
+    q.out = reinterpret_cast<u32x4 *>(out);
+}
+
+static int launch_pack_jobs(const TlPackJobs &jobs, int n, hipStream_t st)
+{
+    if (n == 0) return PN2_OK;
+    long long most = 0;
+    for (int i = 0; i < n; ++i) {
+        const long long total = (long long)jobs.j[i].slabs * jobs.j[i].tk * jobs.j[i].ns * 128;
+        if (total > most) most = total;
+    }
+    long long blocks = (most + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    return launch(tl_pack_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, st, jobs);
+}
+
 static int launch_pack(const float *w, long long sk, long long sn, const GemmShape &g, void *out, hipStream_t st)
 {
-    const long long total = (long long)g.slabs * g.tk * g.ns * 128;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    return launch(tl_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, sk, sn, g.K, g.N, g.tk, g.ns, g.slabs,
-                  reinterpret_cast<u32x4 *>(out));
+    TlPackJobs jobs;
+    memset(&jobs, 0, sizeof(jobs));
+    int n = 0;
+    add_pack_job(jobs, n, w, sk, sn, g, out);
+    return launch_pack_jobs(jobs, n, st);
 }
 
 template <int NS>
@@ -1498,14 +1532,19 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
         if (!layers[l].z && (keep_top || l < nlayers - 1)) return PN2_E_NULL;
     hipStream_t st = as_stream(stream);
     char *base = static_cast<char *>(ws);
-    for (int l = 0; l < nlayers; ++l) {
-        const pn2_bn_layer &L = layers[l];
-        const GemmShape g = gemm_shape(L.cin, L.cout);
-        if (int rc = launch_pack(L.weight, L.w_stride_k, L.w_stride_n, g, base + pl.pack[l], st)) return rc;
+    {
+        TlPackJobs jobs;                                          // every layer's weights -> operand tiles, one launch
+        memset(&jobs, 0, sizeof(jobs));
+        int nj = 0;
+        for (int l = 0; l < nlayers; ++l) {
+            const pn2_bn_layer &L = layers[l];
+            add_pack_job(jobs, nj, L.weight, L.w_stride_k, L.w_stride_n, gemm_shape(rows, L.cin, L.cout), base + pl.pack[l]);
+        }
+        if (int rc = launch_pack_jobs(jobs, nj, st)) return rc;
     }
     for (int l = 0; l < nlayers; ++l) {
         const pn2_bn_layer &L = layers[l];
-        const GemmShape g = gemm_shape(L.cin, L.cout);
+        const GemmShape g = gemm_shape(rows, L.cin, L.cout);
         const bool last = l == nlayers - 1;
         TlGemm p;
         memset(&p, 0, sizeof(p));
@@ -1569,12 +1608,24 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
     const bool ztop = !top_stored(rows, nlayers, widths, pool_rows);     // pooled top layer without z_L (tl_top_mats_kernel)
     for (int l = 0; l < nlayers; ++l)
         if (!layers[l].z && !(ztop && l == nlayers - 1)) return PN2_E_NULL;
-    for (int l = 0; l < nlayers; ++l) {
-        const pn2_bn_layer &L = layers[l];
-        if ((l > 0 || want_dx) && !(ztop && l == nlayers - 1)) {
-            const GemmShape g = gemm_shape(L.cout, L.cin);                // dy_{l-1} = dz_l . W_l^T
-            if (int rc = launch_pack(L.weight, L.w_stride_n, L.w_stride_k, g, base + pl.pack[l], st)) return rc;
+    {
+        TlPackJobs jobs;                                          // W_l^T of every data-gradient GEMM, one launch
+        memset(&jobs, 0, sizeof(jobs));
+        int nj = 0;
+        for (int l = 0; l < nlayers; ++l) {
+            const pn2_bn_layer &L = layers[l];
+            if ((l > 0 || want_dx) && !(ztop && l == nlayers - 1)) {      // dy_{l-1} = dz_l . W_l^T
+                if (l == 0 && group) {
+                    // layer 1 of a grouped level: only the FEATURE rows of W_1 (the grouped xyz takes no gradient here)
+                    const TlGather gt = make_gather(group);
+                    add_pack_job(jobs, nj, L.weight + gt.feat_off * L.w_stride_k, L.w_stride_n, L.w_stride_k,
+                                 gemm_shape(rows, L.cout, gt.cfeat), base + pl.pack[l]);
+                } else {
+                    add_pack_job(jobs, nj, L.weight, L.w_stride_n, L.w_stride_k, gemm_shape(rows, L.cout, L.cin), base + pl.pack[l]);
+                }
+            }
         }
+        if (int rc = launch_pack_jobs(jobs, nj, st)) return rc;
     }
     float *ga = reinterpret_cast<float *>(base + pl.ga), *gb = reinterpret_cast<float *>(base + pl.gb);
     float *gq = reinterpret_cast<float *>(base + pl.gq);
@@ -1635,7 +1686,7 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
                                     L.grad_weight)) return rc;
             }
             {
-                const GemmShape g = gemm_shape(NFp + K, K);
+                const GemmShape g = gemm_shape(rows, NFp + K, K);
                 if (int rc = launch_pack(wp, K, 1, g, base + pl.pack[l], st)) return rc;
                 TlGemm p;
                 memset(&p, 0, sizeof(p));
@@ -1678,7 +1729,7 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
         }
         // data gradient
         if (l > 0 || want_dx) {
-            const GemmShape g = gemm_shape(L.cout, L.cin);
+            const GemmShape g = (l == 0 && group) ? gemm_shape(rows, L.cout, make_gather(group).cfeat) : gemm_shape(rows, L.cout, L.cin);
             TlGemm p;
             memset(&p, 0, sizeof(p));
             p.rows = rows;
@@ -1700,7 +1751,7 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
                 p.emode = E_PLAIN;
                 if (group) {
                     const TlGather gt = make_gather(group);
-                    p.out = grad_feat_rows; p.out_pitch = gt.cfeat; p.col0 = gt.feat_off; p.col1 = gt.feat_off + gt.cfeat;
+                    p.out = grad_feat_rows; p.out_pitch = gt.cfeat; p.col0 = 0; p.col1 = gt.cfeat;
                 } else {
                     p.out = grad_x; p.out_pitch = L.cin; p.col0 = 0; p.col1 = L.cin;
                 }

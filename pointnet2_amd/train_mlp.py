@@ -142,9 +142,9 @@ class _TrainMLP(torch.autograd.Function):
             _C.check(_C.lib().pn2_mlp_train_forward(rows, n, arr, ctypes.byref(grp) if grp is not None else None,
                                                     None if level.grouped else ptr(x), level.pool_rows, ptr(out), ptr(argsel),
                                                     ptr(zsel), ptr(ws), stream_ptr(dev)), "mlp_train_forward")
-        for _, bn in level.pairs:
-            if bn.track_running_stats and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
+        nbt = [bn.num_batches_tracked for _, bn in level.pairs if bn.track_running_stats and bn.num_batches_tracked is not None]
+        if nbt:
+            torch._foreach_add_(nbt, 1)                        # one launch for the level's counters
         ctx.level, ctx.widths = level, widths
         ctx.has_x = x is not None
         ctx.nbias = [b is not None for b in biases]
@@ -209,8 +209,12 @@ class _TrainMLP(torch.autograd.Function):
                     _C.check(_C.lib().pn2_group_point_grad(b, npts, c, m, ns, ptr(grad_rows), ptr(level.idx), ptr(grad_x),
                                                            stream_ptr(dev)), "group_point_grad")
         result = [None, grad_x if need_x else None]
+        # the conv bias gradients: exactly zero under batch norm (one zero buffer, one fill launch, a view per layer)
+        zero = torch.zeros((sum(widths[1:]),), dtype=torch.float32, device=dev)
+        off = 0
         for l in range(n):
-            gb = torch.zeros_like(biases[l]) if biases[l] is not None else None     # exactly zero under batch norm
+            gb = zero[off:off + widths[l + 1]] if biases[l] is not None else None
+            off += widths[l + 1]
             result += [grads[l][0], gb, grads[l][1], grads[l][2]]
         return tuple(result)
 

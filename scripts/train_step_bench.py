@@ -77,12 +77,44 @@ def run_steps(model, opt, bucket, x, labels, kind, steps, warm, batch):
     return ph.mean(axis=0), float(loss)
 
 
+def graph_step(model, opt, bucket, x, labels, steps):
+    """forward + loss + backward + SGD step of the fused path captured in one HIP graph (static input buffers); replay time.
+    Everything on the path is capturable: no host synchronisation, no pageable copies, scratch from torch's allocator."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                         # warm-up on a side stream, as torch.cuda.graph requires
+        for _ in range(3):
+            bucket.zero_()
+            F.cross_entropy(model(x), labels).backward()
+            opt.step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        bucket.zero_()
+        loss = F.cross_entropy(model(x), labels)
+        loss.backward()
+        opt.step()
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return {"step_ms": round(e0.elapsed_time(e1) / steps, 3), "loss": float(loss)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("which", nargs="?", default="")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--fused-only", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="additionally capture forward + loss + backward + optimiser step of the fused path in ONE HIP graph "
+                         "and time its replay (a level's step is ~40 small launches: eager runs are launch-bound on small levels)")
     args = ap.parse_args()
     distributed = "RANK" in os.environ
     rank, world = 0, 1
@@ -124,6 +156,8 @@ def main():
                         "allreduce_ms": round(float(ph[2]), 3), "optimizer_ms": round(float(ph[3]), 3),
                         "step_ms": round(float(ph.sum()), 3), "loss": loss, "paths": paths,
                         "grad_floats": int(bucket.flat.numel())}
+            if fused and args.graph and not distributed:
+                row["fused_graph"] = graph_step(model, opt, bucket, x, labels, args.steps)
             del model, opt, bucket
             torch.cuda.empty_cache()
         if True in grads and False in grads:

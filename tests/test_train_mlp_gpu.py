@@ -127,3 +127,37 @@ def test_training_path_refuses_unsupported_and_falls_back(cuda):
     sa2 = U.PointnetSAModule(0, 16, 0.4, 32, [32, 32, 64], bn=False).to(cuda).train()    # no batch norm: torch path
     sa2(xyz, None)
     assert sa2.last_path == "unfused"
+
+
+def test_fused_training_step_is_graph_capturable(cuda):
+    """forward + backward of a fused SA level inside ONE HIP graph (no host synchronisation, no pageable copies on the path):
+    the replay on new data equals the eager evaluation of the same data."""
+    import pointnet2_amd.pointnet_util as U
+    torch.manual_seed(3)
+    sa = U.PointnetSAModule(16, 64, 0.4, 32, [32, 32, 64]).to(cuda).train()
+    xyz = torch.rand(4, 256, 3, device=cuda)
+    feats = torch.randn(4, 256, 16, device=cuda, requires_grad=True)
+    w = torch.randn(4, 64, 64, device=cuda)
+    params = list(sa.parameters())
+
+    def step():
+        _, out, _ = sa(xyz, feats)
+        return out, torch.autograd.grad((out * w).sum(), params + [feats])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out_g, grads_g = step()
+    assert sa.last_path == "fused_train"
+    xyz.copy_(torch.rand(4, 256, 3, device=cuda))
+    with torch.no_grad():
+        feats.copy_(torch.randn(4, 256, 16, device=cuda))
+    g.replay()
+    torch.cuda.synchronize()
+    out_e, grads_e = step()
+    assert torch.equal(out_g, out_e)
+    for a, b in zip(grads_g, grads_e):
+        assert float((a - b).abs().max()) <= 1e-6 * max(1e-30, float(b.abs().max()))
