@@ -277,6 +277,22 @@ int pn2_sample_and_group_xyz_gen(int b, int n, int m, float radius, int nsample,
  * synchronising the stream. */
 long long pn2_sample_and_group_status_offset(int b, int m);
 
+/* ---- one call per level (inference) ---------------------------------------------------------------------
+ * pn2_sa_level = pointnet_sa_module (utils/pointnet_util.py:87-154) for max pooling and three layers: the overlapped
+ * sample-and-group launch (or, outside its envelope, pn2_farthest_point_sample_gather + pn2_query_ball_group_xyz) followed
+ * by pn2_sa_mlp3_maxpool, enqueued by ONE call. ws_sample: pn2_sample_and_group_ws_bytes(b, m) bytes, handled as in
+ * pn2_sample_and_group_xyz_gen (generation > 0: zeroed once by the caller, a fresh generation per call) or cleared here
+ * (generation = 0); fps_temp: pn2_fps_temp_floats(b, n) floats or NULL when that is 0; ws_mlp: pn2_sa_mlp3_ws_bytes(...)
+ * bytes or NULL when that is 0; wpacked / bpacked from pn2_sa_mlp3_pack. Outputs as the two operators' (all required).
+ * pn2_fp_level = pointnet_fp_module (:199-229): pn2_three_nn followed by pn2_fp_mlp (dist / idx are outputs too). */
+int pn2_sa_level(int b, int n, int m, float radius, int nsample, int cfeat, const float *xyz, const float *points,
+                 void *ws_sample, unsigned generation, float *fps_temp, int c1, int c2, int c3, const float *wpacked,
+                 const float *bpacked, int *fps_idx, float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz, float *out,
+                 void *ws_mlp, void *stream);
+int pn2_fp_level(int b, int n, int m, int c2, int c1, const float *xyz1, const float *xyz2, const float *points2,
+                 const float *points1, int nlayers, const int *widths, int kind, const float *wpacked, const float *bpacked,
+                 float *dist, int *idx, float *out, void *ws, void *stream);
+
 /* ---- training mode of the shared MLPs (second half) ---------------------------
  *
  * The reference builds every SA / FP level with is_training = True (train.py:188): each of the level's

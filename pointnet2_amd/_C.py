@@ -68,6 +68,9 @@ _SIGNATURES = {
     "pn2_farthest_point_sample_ex": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "pn2_query_ball_group_xyz_ex": [_i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "pn2_query_ball_group_xyz_msg": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "pn2_sa_level": [_i, _i, _i, _f, _i, _i, _vp, _vp, _vp, ctypes.c_uint, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                     _vp],
+    "pn2_fp_level": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pn2_mlp_train_ws_bytes": [_ll, _i, _vp, _i, _i],
     "pn2_mlp_train_top_stored": [_ll, _i, _vp, _i],
     "pn2_mlp_train_ws_layout": [_ll, _i, _vp, _i, _vp, _vp, _vp, _vp],

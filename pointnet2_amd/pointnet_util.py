@@ -137,8 +137,17 @@ class PointnetSAModule(nn.Module):
         c = self.mlp.c_out * (2 if pooling == "max_and_avg" else 1)
         self.mlp2 = _SharedMLP(c, mlp2, bn) if mlp2 else None
         self.fused_mlp = True          # eval-mode forward may use the fused MFMA kernel (sa_mlp.py)
+        self.reuse_buffers = False     # eval: keep the level's result / scratch tensors and overwrite them on the next call
         self.last_path = None
         self._pack_cache = None
+        self._lvl_buffers = None
+
+    def _level_buffers(self):
+        if not self.reuse_buffers:
+            return None
+        if self._lvl_buffers is None:
+            self._lvl_buffers = sa_mlp.LevelBuffers()
+        return self._lvl_buffers
 
     def _fused_ok(self, xyz, points):
         """Inference with max pooling on a layer stack pn2_sa_mlp3_maxpool covers (see sa_mlp.py)."""
@@ -220,11 +229,12 @@ class PointnetSAModule(nn.Module):
             idx = torch.arange(n, dtype=torch.int32, device=xyz.device).reshape(1, 1, n).repeat(b, 1, 1)
             return new_xyz, sa_mlp.sa_mlp_maxpool(xyz, None, points, None, self._packed(xyz.device, n)), idx
         if self._fused_ok(xyz, points):
-            # FPS + ball query in the overlapped launch, then ONE kernel from idx to the pooled features:
-            # the (b, npoint, nsample, C) tensors of pointnet_util.py:44-50 and :117-127 never exist
-            fps_idx, new_xyz, idx, _, _ = sample_and_group_xyz(self.npoint, self.radius, self.nsample, xyz, True)
+            # ONE C call (csrc/levels.hip): FPS + ball query in the overlapped launch, then one kernel from idx to the
+            # pooled features: the (b, npoint, nsample, C) tensors of pointnet_util.py:44-50 and :117-127 never exist
             self.last_path = "fused"
-            return new_xyz, sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, self._packed(xyz.device)), idx
+            new_xyz, out, idx, _, _, _ = sa_mlp.sa_level(self.npoint, self.radius, self.nsample, xyz, points,
+                                                          self._packed(xyz.device), self._level_buffers())
+            return new_xyz, out, idx
         self.last_path = "unfused"
         if self.group_all:
             new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, self.use_xyz)
@@ -362,8 +372,10 @@ class PointnetFPModule(nn.Module):
         super().__init__()
         self.mlp = _SharedMLP(c_in, mlp, bn)
         self.fused_mlp = True          # eval-mode forward may use the fused kernel (csrc/fp_mlp.hip)
+        self.reuse_buffers = False     # eval: keep the level's result / scratch tensors and overwrite them on the next call
         self.last_path = None
         self._pack_cache = None
+        self._lvl_buffers = None
 
     def _fused_kind(self, points1, points2, npoints):
         """The fused kernel for this call (sa_mlp.fp_kind: cooperative below 16384 unknown points, streamed
@@ -394,11 +406,14 @@ class PointnetFPModule(nn.Module):
     def forward(self, xyz1, xyz2, points1, points2):
         kind = self._fused_kind(points1, points2, xyz1.shape[0] * xyz1.shape[1])
         if kind is not None:
-            # three_nn, then ONE kernel: weights, interpolation, concatenation and the layer stack (:212-226)
+            # ONE C call (csrc/levels.hip): three_nn, then one kernel for weights, interpolation, concatenation and the
+            # layer stack (:211-226)
             self.last_path = "fused"
-            dist, idx = three_nn(xyz1, xyz2)                                    # :211
             c1 = points1.shape[2] if points1 is not None else 0
-            return sa_mlp.fp_mlp(points2, points1, idx, dist, self._packed(points2.shape[2], c1, kind, points2.device))
+            if self.reuse_buffers and self._lvl_buffers is None:
+                self._lvl_buffers = sa_mlp.LevelBuffers()
+            return sa_mlp.fp_level(xyz1, xyz2, points1, points2, self._packed(points2.shape[2], c1, kind, points2.device),
+                                   self._lvl_buffers if self.reuse_buffers else None)
         idx, weight = three_nn_weights(xyz1, xyz2)                              # :211-215
         interpolated = three_interpolate(points2, idx, weight)                  # :216
         x = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated   # :219

@@ -201,3 +201,97 @@ def fp_mlp(points2, points1, idx, dist, packed):
                                      packed._warr, packed.kind, ptr(packed.wp), ptr(packed.bp), ptr(out), ptr(ws),
                                      stream_ptr(dev)), "fp_mlp")
     return out
+
+
+# ---- one C call per level (inference): csrc/levels.hip ---------------------------------------------------------------------
+class LevelBuffers:
+    """Result and scratch tensors of a level call, kept by the CALLER (a module with `reuse_buffers = True`) and handed
+    back on every call of the same shape: the level is then one C call and no allocation. The results are overwritten by
+    the next call -- for inference loops that consume a level's outputs before calling it again."""
+    __slots__ = ("key", "t")
+
+    def __init__(self):
+        self.key, self.t = None, None
+
+
+def sa_level(npoint, radius, nsample, xyz, points, packed, buffers=None):
+    """pointnet_sa_module (max pooling, three layers) in ONE call: xyz (b,n,3), points (b,n,c) or None, packed: PackedMLP3
+    -> new_xyz (b,m,3), pooled features (b,m,c3), idx (b,m,nsample), fps_idx (b,m), pts_cnt (b,m), grouped_xyz (b,m,ns,3)."""
+    from . import tf_grouping as G
+    xyz = f32(xyz, "xyz")
+    require(xyz.dim() == 3 and xyz.shape[2] == 3, "xyz must be (b, n, 3)")
+    b, n, _ = xyz.shape
+    m, ns = int(npoint), int(nsample)
+    require(m > 0 and ns > 0 and float(radius) > 0, "npoint, nsample and radius must be positive")
+    cfeat = 0
+    if points is not None:
+        points = f32(points, "points")
+        require(points.dim() == 3 and tuple(points.shape[:2]) == (b, n), "points must be (b, n, c) like xyz")
+        cfeat = points.shape[2]
+    require(3 + cfeat == packed.cin, "packed MLP expects %d input channels, got %d" % (packed.cin, 3 + cfeat))
+    require(ns == packed.nsample or _same_kernel(packed, ns), "weights were packed for another kernel (nsample %d)" % packed.nsample)
+    dev = same_device(xyz, packed.wp) if points is None else same_device(xyz, points, packed.wp)
+    lib = _C.lib()
+    key = (b, n, m, ns, cfeat, packed.widths, dev)
+    if buffers is not None and buffers.key == key:
+        fps_idx, new_xyz, idx, cnt, grouped, out, ws, temp = buffers.t
+    else:
+        fps_idx = torch.empty((b, m), dtype=torch.int32, device=dev)
+        new_xyz = torch.empty((b, m, 3), dtype=torch.float32, device=dev)
+        idx = torch.empty((b, m, ns), dtype=torch.int32, device=dev)
+        cnt = torch.empty((b, m), dtype=torch.int32, device=dev)
+        grouped = torch.empty((b, m, ns, 3), dtype=torch.float32, device=dev)
+        out = torch.empty((b, m, packed.widths[2]), dtype=torch.float32, device=dev)
+        nbytes = lib.pn2_sa_mlp3_ws_bytes(b, n, m, packed.cin, packed.widths[0], packed.widths[1], packed.widths[2], ns)
+        ws = torch.empty(((nbytes + 3) // 4,), dtype=torch.float32, device=dev) if nbytes else None
+        tf = lib.pn2_fps_temp_floats(b, n)
+        temp = torch.empty((tf,), dtype=torch.float32, device=dev) if tf > 0 else None
+        if buffers is not None:
+            buffers.key, buffers.t = key, (fps_idx, new_xyz, idx, cnt, grouped, out, ws, temp)
+    st = stream_ptr(dev)
+    with on_device(dev):
+        if torch.cuda.is_current_stream_capturing() or not G._OVERLAP[0]:
+            wss = torch.empty((lib.pn2_sample_and_group_ws_bytes(b, m),), dtype=torch.uint8, device=dev)
+            ent, gen = None, 0
+            wsp = ptr(wss)
+        else:
+            ent = G._granule_workspace(lib, dev, st, b, m)         # raises if an earlier launch on it reported a give-up
+            gen, wsp = ent[1], ptr(ent[0])
+        _C.check(lib.pn2_sa_level(b, n, m, float(radius), ns, cfeat, ptr(xyz), ptr(points), wsp, gen, ptr(temp),
+                                  packed.widths[0], packed.widths[1], packed.widths[2], ptr(packed.wp), ptr(packed.bp),
+                                  ptr(fps_idx), ptr(new_xyz), ptr(idx), ptr(cnt), ptr(grouped), ptr(out), ptr(ws), st), "sa_level")
+        if ent is not None:
+            G._fetch_status(ent)
+    return new_xyz, out, idx, fps_idx, cnt, grouped
+
+
+def fp_level(xyz1, xyz2, points1, points2, packed, buffers=None):
+    """pointnet_fp_module in ONE call: three_nn + (weights, interpolation, concat, layer stack) -> (b, n, cout)."""
+    xyz1, xyz2, points2 = f32(xyz1, "xyz1"), f32(xyz2, "xyz2"), f32(points2, "points2")
+    b, n, _ = xyz1.shape
+    m, c2 = points2.shape[1], points2.shape[2]
+    require(xyz1.dim() == 3 and xyz1.shape[2] == 3 and tuple(xyz2.shape) == (b, m, 3), "xyz1 (b,n,3), xyz2 (b,m,3) expected")
+    c1 = 0
+    if points1 is not None:
+        points1 = f32(points1, "points1")
+        require(points1.dim() == 3 and tuple(points1.shape[:2]) == (b, n), "points1 must be (b, n, c1)")
+        c1 = points1.shape[2]
+    require(c2 == packed.c2 and c1 == packed.c1, "packed FP MLP expects (%d, %d) channels, got (%d, %d)" % (packed.c2, packed.c1, c2, c1))
+    dev = same_device(xyz1, xyz2, points2, packed.wp)
+    lib = _C.lib()
+    key = (b, n, m, c2, c1, tuple(packed.widths), packed.kind, dev)
+    if buffers is not None and buffers.key == key:
+        dist, idx, out, ws = buffers.t
+    else:
+        dist = torch.empty((b, n, 3), dtype=torch.float32, device=dev)
+        idx = torch.empty((b, n, 3), dtype=torch.int32, device=dev)
+        out = torch.empty((b, n, packed.widths[-1]), dtype=torch.float32, device=dev)
+        nbytes = lib.pn2_fp_mlp_ws_bytes(b, m, c2, c1, len(packed.widths), packed._warr, packed.kind)
+        ws = torch.empty(((nbytes + 3) // 4,), dtype=torch.float32, device=dev)
+        if buffers is not None:
+            buffers.key, buffers.t = key, (dist, idx, out, ws)
+    with on_device(dev):
+        _C.check(lib.pn2_fp_level(b, n, m, c2, c1, ptr(xyz1), ptr(xyz2), ptr(points2), ptr(points1), len(packed.widths),
+                                  packed._warr, packed.kind, ptr(packed.wp), ptr(packed.bp), ptr(dist), ptr(idx), ptr(out), ptr(ws),
+                                  stream_ptr(dev)), "fp_level")
+    return out

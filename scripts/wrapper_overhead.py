@@ -56,3 +56,23 @@ d3, i3 = P.three_nn(xyz, q)
 print("three_nn                  %.2f us" % host_us(lambda: P.three_nn(xyz, q)))
 print("three_nn, out=            %.2f us" % host_us(lambda: P.three_nn(xyz, q, out=(d3, i3))))
 print("torch op for scale (add)  %.2f us" % host_us(lambda: xyz + 1.0))
+
+# ---- one call per level (csrc/levels.hip): host time of an eager SA / FP level of the inference path
+import numpy as np
+from pointnet2_amd import sa_mlp
+import pointnet2_amd.pointnet_util as U
+
+torch.manual_seed(0)
+sa = U.PointnetSAModule(64, 64, 0.4, 32, [64, 64, 128]).to(dev).eval()
+fp = U.PointnetFPModule(128 + 64, [128, 128]).to(dev).eval()
+xyz8 = torch.rand(8, 256, 3, device=dev)
+feat = torch.randn(8, 256, 64, device=dev)
+with torch.no_grad():
+    nx, nf, _ = sa(xyz8, feat)
+    fp(xyz8, nx, feat, nf)
+    print("SA level, eager module    %.2f us" % host_us(lambda: sa(xyz8, feat)))
+    print("FP level, eager module    %.2f us" % host_us(lambda: fp(xyz8, nx, feat, nf)))
+    sa.reuse_buffers = fp.reuse_buffers = True
+    sa(xyz8, feat); fp(xyz8, nx, feat, nf)
+    print("SA level, reuse_buffers   %.2f us" % host_us(lambda: sa(xyz8, feat)))
+    print("FP level, reuse_buffers   %.2f us" % host_us(lambda: fp(xyz8, nx, feat, nf)))

@@ -78,3 +78,35 @@ def test_sample_and_group_paths_agree_with_grad(cuda):
         assert torch.equal(u, v.detach())
     b[1].sum().backward()
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
+def test_level_entry_points_equal_the_operator_sequence(cuda):
+    """pn2_sa_level / pn2_fp_level (one C call per level, csrc/levels.hip) return exactly what the operator sequence
+    they compose returns; with reuse_buffers the same tensors are handed back."""
+    import pointnet2_amd.pointnet_util as U
+    from pointnet2_amd import sa_mlp
+    from pointnet2_amd.tf_grouping import sample_and_group_xyz
+    from pointnet2_amd.tf_interpolate import three_nn
+    torch.manual_seed(0)
+    sa = U.PointnetSAModule(32, 128, 0.3, 32, [64, 64, 128]).to(cuda).eval()
+    fp = U.PointnetFPModule(128 + 32, [128, 64]).to(cuda).eval()
+    xyz = torch.rand(4, 1024, 3, device=cuda)
+    feat = torch.randn(4, 1024, 32, device=cuda)
+    with torch.no_grad():
+        new_xyz, pooled, idx = sa(xyz, feat)
+        assert sa.last_path == "fused"
+        _, nx, ix, _, _ = sample_and_group_xyz(128, 0.3, 32, xyz, True)
+        want = sa_mlp.sa_mlp_maxpool(xyz, nx, feat, ix, sa._packed(cuda))
+        assert torch.equal(new_xyz, nx) and torch.equal(idx, ix) and torch.equal(pooled, want)
+        up = fp(xyz, new_xyz, feat, pooled)
+        assert fp.last_path == "fused"
+        d, i3 = three_nn(xyz, new_xyz)
+        want_up = sa_mlp.fp_mlp(pooled, feat, i3, d, fp._packed(128, 32, sa_mlp.fp_kind(4 * 1024, 128, 32, [128, 64]), cuda))
+        assert torch.equal(up, want_up)
+        sa.reuse_buffers = fp.reuse_buffers = True
+        a1 = sa(xyz, feat)
+        a2 = sa(xyz, feat)
+        assert a1[1].data_ptr() == a2[1].data_ptr() and torch.equal(a2[1], want)
+        u1 = fp(xyz, new_xyz, feat, pooled)
+        u2 = fp(xyz, new_xyz, feat, pooled)
+        assert u1.data_ptr() == u2.data_ptr() and torch.equal(u2, want_up)
