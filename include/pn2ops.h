@@ -346,19 +346,27 @@ typedef struct pn2_bn_layer {
  * gradient flows to and zsel the selected pre-norm value (both needed by backward).
  * group != NULL: layer 1 reads the grouped rows; else x is the (rows, cin_1) input. */
 long long pn2_mlp_train_ws_bytes(long long rows, int nlayers, const int *widths /* cin_1, cout_1 .. cout_L */,
-                                 int pool_rows, int backward);
+                                 int pool_rows, int backward,
+                                 const int *group_dims /* grouped input: {b, n, m, nsample, cfeat, idx != NULL}; else NULL */);
+/* 1: layer 1 of this grouped level is evaluated once per POINT -- z_1 = (points W1f)[idx] + (xyz - c) W1x + b, the
+ * feature term being a GEMM over the b n points instead of the b m nsample rows (csrc/train_mlp.hip, tl_l1_forward_kernel)
+ * -- and backward then produces the gradient of `points` itself (grad_points) instead of the per-row grad_feat_rows. */
+int pn2_mlp_train_layer1_per_point(int nlayers, const int *widths, const int *group_dims);
 /* 1: layers[L-1].z (the top layer's pre-norm tensor) is written by forward and read by backward; 0: it is neither --
  * pooled stacks of >= 2 layers on large levels run the passes that would read z_L on the layer's INPUT instead
  * (z_L = h W + b; csrc/train_mlp.hip, tl_top_mats_kernel), and layers[L-1].z may be NULL. */
 int pn2_mlp_train_top_stored(long long rows, int nlayers, const int *widths, int pool_rows);
 int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group,
                           const float *x, int pool_rows, float *out, int *argsel, float *zsel, void *ws, void *stream);
-/* grad_out: shape of out. grad_x: (rows, cin_1) or NULL (plain input). grad_feat_rows: (rows, cfeat) -- the gradient
- * of the grouped FEATURE rows, to be scattered with pn2_group_point_grad_seg -- or NULL (grouped input). The bias
- * gradient of a layer under batch normalisation is identically zero and is not produced. */
+/* grad_out: shape of out. grad_x: (rows, cin_1) or NULL (plain input). Grouped input: grad_feat_rows (rows, cfeat) -- the
+ * gradient of the grouped FEATURE rows, to be scattered with pn2_group_point_grad_seg -- or, when
+ * pn2_mlp_train_layer1_per_point() says so, grad_points (b, n, cfeat), the gradient of `points` itself (the scatter runs
+ * inside, `reproducible` selects its sorted-segment mode); NULL: not wanted. The bias gradient of a layer under batch
+ * normalisation is identically zero and is not produced. */
 int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group,
                            const float *x, int pool_rows, const float *out, const int *argsel, const float *zsel,
-                           const float *grad_out, float *grad_x, float *grad_feat_rows, void *ws, void *stream);
+                           const float *grad_out, float *grad_x, float *grad_feat_rows, float *grad_points, int reproducible,
+                           void *ws, void *stream);
 
 /* diagnostics: byte offsets inside the BACKWARD workspace of the two dy buffers ((rows, max width) each; after a
  * backward of L layers they hold dy_{L-1}, dy_{L-2}, ... alternately, starting with gb when pooled) and of the

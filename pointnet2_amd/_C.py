@@ -71,11 +71,12 @@ _SIGNATURES = {
     "pn2_sa_level": [_i, _i, _i, _f, _i, _i, _vp, _vp, _vp, ctypes.c_uint, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                      _vp],
     "pn2_fp_level": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "pn2_mlp_train_ws_bytes": [_ll, _i, _vp, _i, _i],
+    "pn2_mlp_train_ws_bytes": [_ll, _i, _vp, _i, _i, _vp],
+    "pn2_mlp_train_layer1_per_point": [_i, _vp, _vp],
     "pn2_mlp_train_top_stored": [_ll, _i, _vp, _i],
     "pn2_mlp_train_ws_layout": [_ll, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "pn2_mlp_train_forward": [_ll, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
-    "pn2_mlp_train_backward": [_ll, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pn2_mlp_train_backward": [_ll, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
 }
 _RESTYPES = {
     "pn2_fps_temp_floats": ctypes.c_longlong,

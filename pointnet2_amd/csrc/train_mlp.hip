@@ -1194,6 +1194,145 @@ __global__ __launch_bounds__(256) void tl_top_wgrad_fix_kernel(const double *__r
     }
 }
 
+// ---- layer 1 of a grouped level ONCE PER POINT -----------------------------------------------------------------------------
+// Layer 1 reads [xyz_j - c, f_j] (utils/pointnet_util.py:44-50): z_1 = W1f^T f_j + W1x^T (xyz_j - c) + b. The feature term
+// depends on the POINT only, and a point is a sample of nsample m / n (16-64) groups: P = points . W1f is one GEMM over the
+// b n points (the generic kernel, plain rows), and the pass over the b m nsample rows only gathers a row of P (cout_1 floats
+// where the features were up to 320) and adds the three coordinate terms -- no matrix pipe needed for K = 3. Backward:
+//     dW1x = (xyz - c)^T dz_1 and dz_1 itself      one pass over the rows (tl_l1_dz_kernel; dz_1 overwrites dy_1)
+//     S    = scatter-add of dz_1 onto the points   pn2_group_point_grad_seg (the level's ordinary segmented reduction)
+//     dW1f = points^T S,   dPoints = S W1f^T       two GEMMs over the b n points
+// instead of a weight-gradient and a data-gradient GEMM over all rows with the gathered 131-323 channel input, and a
+// segmented reduction of a (rows, cfeat) tensor. (The inference kernels do the same: csrc/sa_mlp_stream.hip.)
+struct TlL1 {
+    long long rows;
+    int n, m, nsample, C;                   // points per cloud, groups per cloud, rows per group, cout_1
+    const float *xyz, *new_xyz;             // (b,n,3), (b,m,3) or nullptr
+    const int *idx;                         // (rows)
+    const float *P;                         // forward: (b n, C)
+    const float *wx;                        // forward: W1x, 3 rows of the weight: wx[k * skx + col * sn]
+    long long skx, sn;
+    const float *bias;                      // forward: (C) or nullptr
+    float *z;                               // forward: out (rows, C);  backward: z_1 (rows, C)
+    double *stats;                          // forward: (workgroups, 2, C) partial sums
+    float *g;                               // backward: dy_1 in, dz_1 out (rows, C)
+    const float *coef;                      // backward: (3, C): s, c0, c1
+    float *part;                            // backward: (workgroups, 3, C) partial dW1x
+};
+
+// thread <-> (row lane, 4 columns): a block of 256 threads covers 256 / (C / 4) rows at a time, columns fixed per thread
+__global__ __launch_bounds__(256) void tl_l1_forward_kernel(const TlL1 p)
+{
+    const int qpr = p.C / 4, q = threadIdx.x % qpr, rl = threadIdx.x / qpr, rpb = 256 / qpr, col = 4 * q;
+    float4 w0, w1, w2, b4 = {0.f, 0.f, 0.f, 0.f};
+    {
+        const float *w = p.wx + (size_t)col * p.sn;
+        w0 = make_float4(w[0], w[p.sn], w[2 * p.sn], w[3 * p.sn]);
+        w1 = make_float4(w[p.skx], w[p.skx + p.sn], w[p.skx + 2 * p.sn], w[p.skx + 3 * p.sn]);
+        w2 = make_float4(w[2 * p.skx], w[2 * p.skx + p.sn], w[2 * p.skx + 2 * p.sn], w[2 * p.skx + 3 * p.sn]);
+        if (p.bias) b4 = ld4(p.bias + col);
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long long row = (long long)blockIdx.x * rpb + rl; row < p.rows; row += (long long)gridDim.x * rpb) {
+        const int grp = (int)(row / p.nsample), cloud = grp / p.m, pt = p.idx[row];
+        const float *px = p.xyz + ((size_t)cloud * p.n + pt) * 3;
+        float x0 = px[0], x1 = px[1], x2 = px[2];
+        if (p.new_xyz) {
+            const float *pc = p.new_xyz + (size_t)grp * 3;
+            x0 = __fsub_rn(x0, pc[0]); x1 = __fsub_rn(x1, pc[1]); x2 = __fsub_rn(x2, pc[2]);      // pointnet_util.py:46
+        }
+        const float4 pp = ld4(p.P + ((size_t)cloud * p.n + pt) * p.C + col);
+        float z[4] = {pp.x + b4.x, pp.y + b4.y, pp.z + b4.z, pp.w + b4.w};
+        const float a0[4] = {w0.x, w0.y, w0.z, w0.w}, a1[4] = {w1.x, w1.y, w1.z, w1.w}, a2[4] = {w2.x, w2.y, w2.z, w2.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            z[i] = fmaf(x0, a0[i], z[i]);
+            z[i] = fmaf(x1, a1[i], z[i]);
+            z[i] = fmaf(x2, a2[i], z[i]);
+            s1[i] += z[i];
+            s2[i] = fmaf(z[i], z[i], s2[i]);
+        }
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f zo = {z[0], z[1], z[2], z[3]};
+        __builtin_nontemporal_store(zo, reinterpret_cast<v4f *>(p.z + (size_t)row * p.C + col));
+    }
+    __shared__ double red[2][256][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[0][threadIdx.x][i] = (double)s1[i]; red[1][threadIdx.x][i] = (double)s2[i]; }
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double a = 0.0, b = 0.0;
+            for (int r = 0; r < rpb; ++r) { a += red[0][r * qpr + q][i]; b += red[1][r * qpr + q][i]; }
+            p.stats[((size_t)blockIdx.x * 2) * p.C + col + i] = a;
+            p.stats[((size_t)blockIdx.x * 2 + 1) * p.C + col + i] = b;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void tl_l1_dz_kernel(const TlL1 p)
+{
+    const int qpr = p.C / 4, q = threadIdx.x % qpr, rl = threadIdx.x / qpr, rpb = 256 / qpr, col = 4 * q;
+    const float4 s4 = ld4(p.coef + col), c04 = ld4(p.coef + p.C + col), c14 = ld4(p.coef + 2 * p.C + col);
+    const float s[4] = {s4.x, s4.y, s4.z, s4.w}, c0[4] = {c04.x, c04.y, c04.z, c04.w}, c1[4] = {c14.x, c14.y, c14.z, c14.w};
+    float acc[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (long long row = (long long)blockIdx.x * rpb + rl; row < p.rows; row += (long long)gridDim.x * rpb) {
+        const int grp = (int)(row / p.nsample), cloud = grp / p.m, pt = p.idx[row];
+        const float *px = p.xyz + ((size_t)cloud * p.n + pt) * 3;
+        float x[3] = {px[0], px[1], px[2]};
+        if (p.new_xyz) {
+            const float *pc = p.new_xyz + (size_t)grp * 3;
+            x[0] = __fsub_rn(x[0], pc[0]); x[1] = __fsub_rn(x[1], pc[1]); x[2] = __fsub_rn(x[2], pc[2]);
+        }
+        const size_t o = (size_t)row * p.C + col;
+        const float4 g4 = ld4(p.g + o), z4 = ld4(p.z + o);
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w};
+        float dz[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dz[i] = __fsub_rn(__fsub_rn(__fmul_rn(s[i], gg[i]), c0[i]), __fmul_rn(c1[i], zz[i]));      // s dy - c0 - c1 z
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[k][i] = fmaf(x[k], dz[i], acc[k][i]);
+        }
+        *reinterpret_cast<float4 *>(p.g + o) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+    }
+    __shared__ float red[3][256][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[k][threadIdx.x][i] = acc[k][i];
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double a = 0.0;
+                for (int r = 0; r < rpb; ++r) a += (double)red[k][r * qpr + q][i];
+                p.part[((size_t)blockIdx.x * 3 + k) * p.C + col + i] = (float)a;
+            }
+    }
+}
+
+// dW1x[k][col] = sum over the workgroups' partials (fp64), written to rows [xyz_off, xyz_off + 3) of grad_weight
+__global__ void tl_l1_wx_reduce_kernel(const float *__restrict__ part, int nparts, int C, float *__restrict__ gw, long long sk,
+                                       long long sn)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * C) return;
+    const int k = i / C, col = i - k * C;
+    double a = 0.0;
+    for (int q = 0; q < nparts; ++q) a += (double)part[((size_t)q * 3 + k) * C + col];
+    gw[k * sk + col * sn] = (float)a;
+}
+
+__global__ void tl_identity_coef_kernel(int C, float *__restrict__ coef)       // dz = 1 * g - 0 - 0 * z
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * C) coef[i] = i < C ? 1.0f : 0.0f;
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline int tiles(int c) { return (c + 31) / 32; }
@@ -1234,12 +1373,19 @@ static GemmShape gemm_shape(long long rows, int K, int N)
 
 struct WgradShape { int tus, tts, uslabs, tslabs, tpw, upw; long long gridx, nw, nchunks; size_t e, lds, partial_bytes, partial2_bytes; };
 
-static WgradShape wgrad_shape(long long rows, int KI, int NO)
+static WgradShape wgrad_shape(long long rows, int KI, int NO, bool gather = false)
 {
     WgradShape w;
     const int tu = tiles(KI), tt = tiles(NO);
-    w.tus = tu < 4 ? tu : 4;                                        // (five input tiles in one slab -- the 131 channels of the second
-    w.tts = tt < 8 ? tt : 8;                                        // SA levels -- measured slower: three units per wave spill)
+    w.tus = tu < 4 ? tu : 4;
+    w.tts = tt < 8 ? tt : 8;
+    if (gather && tu > 4 && tu <= 6) {
+        // layer 1 of an SA level with features (131 / 134 input channels = five tiles): the grouped input is gathered from
+        // an L2-resident tensor and cheap to read again, dz is not -- so ALL input tiles sit in one slab and dz is cut into
+        // slabs of two tiles, each read once (with the 4 + 8 shape dz crossed HBM twice). Two units and two tiles per wave.
+        w.tus = tu;
+        w.tts = tt < 2 ? tt : 2;
+    }
     // few rows: more, smaller slabs spread the pass over the chip (each slab re-reads the rows, which is nothing here)
     while ((long long)((tu + w.tus - 1) / w.tus) * ((tt + w.tts - 1) / w.tts) * ((rows / 32 + 3) / 4) < 64 && (w.tus > 1 || w.tts > 1)) {
         if (w.tts >= w.tus && w.tts > 1) w.tts = (w.tts + 1) / 2; else w.tus = (w.tus + 1) / 2;
@@ -1273,6 +1419,8 @@ struct TlPlan {
     size_t ga, gb;              // backward: dy ping-pong (rows, max width)
     size_t partial, partial2;   // backward: weight-gradient partial sums
     size_t topw, topsf;         // backward, pooled top layer without z_L: stacked fp32 weight + constant row; [S | G | sumh] fp64
+    size_t l1p;                 // layer 1 per point: forward P (b n, cout_1); backward S (b n, cout_1)
+    size_t l1seg, l1part, l1coef;   // backward: scratch of the segmented reduction, dW1x partials (256, 3, cout_1), identity coefficients
     size_t total;
 };
 
@@ -1286,7 +1434,21 @@ static bool top_stored(long long rows, int nlayers, const int *widths, int pool_
 }
 static inline int top_cols(int kin, int cl) { return tiles(cl) * 32 + tiles(kin) * 32 + 32; }
 
-static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_rows, int backward, TlPlan &pl)
+// group dims as the C ABI passes them to the workspace query: b, n, m, nsample, cfeat, has_idx
+struct GroupDims { int b, n, m, nsample, cfeat, has_idx; };
+
+// Is layer 1 of this grouped level evaluated once per POINT (tl_l1_forward_kernel)? One rule for forward, backward, the
+// workspace sizes and the caller's allocation of the feature gradient.
+static bool l1_per_point(int nlayers, const int *widths, const GroupDims *g)
+{
+    if (!g || !g->has_idx || nlayers < 2 || env_int("PN2_TL_L1_PER_POINT", 1) == 0) return false;
+    const int c1 = widths[1];
+    if (g->cfeat < 8 || g->cfeat % 4 || ((long long)g->b * g->n) % 32 || c1 % 4 || c1 / 4 > 256 || 256 % (c1 / 4)) return false;
+    return widths[0] == 3 + g->cfeat;
+}
+
+static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_rows, int backward, TlPlan &pl,
+                    const GroupDims *gd = nullptr)
 {
     if (rows <= 0 || rows % 32 || rows >= (1ll << 31) || nlayers < 1 || nlayers > 8) return false;
     if (pool_rows && pool_rows != 16 && pool_rows % 32) return false;
@@ -1298,7 +1460,13 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
         if (cin <= 0 || cout <= 0 || cout % 4) return false;
         const bool ztop = backward && l == nlayers - 1 && !top_stored(rows, nlayers, widths, pool_rows);
         const GemmShape g = ztop ? gemm_shape(rows, tiles(cout) * 32 + cin, cin) : backward ? gemm_shape(rows, cout, cin) : gemm_shape(rows, cin, cout);
-        pl.pack[l] = off; off = align_up(off + g.pack_bytes);
+        size_t pb = g.pack_bytes;
+        if (l == 0 && l1_per_point(nlayers, widths, gd)) {           // the per-point GEMMs' operand tiles instead
+            const long long bn = (long long)gd->b * gd->n;
+            const GemmShape gp = backward ? gemm_shape(bn, cout, gd->cfeat) : gemm_shape(bn, gd->cfeat, cout);
+            if (gp.pack_bytes > pb) pb = gp.pack_bytes;
+        }
+        pl.pack[l] = off; off = align_up(off + pb);
         pl.stats[l] = off; off = align_up(off + sizeof(double) * 2 * cout * kMaxParts);
         if (backward) { pl.coef[l] = off; off = align_up(off + sizeof(float) * 3 * cout); }
         if (cout > maxw) maxw = cout;
@@ -1317,7 +1485,14 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
         const bool ztop = !top_stored(rows, nlayers, widths, pool_rows);
         for (int l = 0; l < nlayers; ++l) {
             const bool zt = ztop && l == nlayers - 1;
-            const WgradShape w = wgrad_shape(rows, widths[l], zt ? top_cols(widths[l], widths[l + 1]) : widths[l + 1]);
+            for (int gat = 0; gat < (l == 0 ? 2 : 1); ++gat) {      // layer 1 may be a gathered input (other slab shape)
+                const WgradShape w = wgrad_shape(rows, widths[l], zt ? top_cols(widths[l], widths[l + 1]) : widths[l + 1], gat != 0);
+                if (w.partial_bytes > p1) p1 = w.partial_bytes;
+                if (w.partial2_bytes > p2) p2 = w.partial2_bytes;
+            }
+        }
+        if (l1_per_point(nlayers, widths, gd)) {                  // dW1f = points^T S over the b n points
+            const WgradShape w = wgrad_shape((long long)gd->b * gd->n, gd->cfeat, widths[1]);
             if (w.partial_bytes > p1) p1 = w.partial_bytes;
             if (w.partial2_bytes > p2) p2 = w.partial2_bytes;
         }
@@ -1329,8 +1504,23 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
             pl.topsf = off; off = align_up(off + sizeof(double) * (size_t)kin * top_cols(kin, cl));
         }
     }
+    if (l1_per_point(nlayers, widths, gd)) {
+        const long long bn = (long long)gd->b * gd->n;
+        pl.l1p = off; off = align_up(off + (size_t)bn * widths[1] * 4);
+        if (backward) {
+            pl.l1seg = off; off = align_up(off + (size_t)pn2_seg_grad_ws_bytes(gd->b, gd->n, (long long)gd->m * gd->nsample));
+            pl.l1part = off; off = align_up(off + (size_t)kMaxParts * 3 * widths[1] * 4);
+            pl.l1coef = off; off = align_up(off + (size_t)3 * widths[1] * 4);
+        }
+    }
     pl.total = off;
     return true;
+}
+
+static GroupDims group_dims(const pn2_group_src *g)
+{
+    GroupDims d = {g->b, g->n, g->m, g->nsample, g->points ? g->cfeat : 0, g->idx ? 1 : 0};
+    return d;
 }
 
 static TlGather make_gather(const pn2_group_src *g)
@@ -1487,11 +1677,23 @@ static bool layers_ok(long long rows, int nlayers, const pn2_bn_layer *layers, c
 
 }  // namespace pn2
 
-extern "C" long long pn2_mlp_train_ws_bytes(long long rows, int nlayers, const int *widths, int pool_rows, int backward)
+extern "C" long long pn2_mlp_train_ws_bytes(long long rows, int nlayers, const int *widths, int pool_rows, int backward,
+                                            const int *group_dims)
 {
     pn2::TlPlan pl;
-    if (!widths || !pn2::tl_plan(rows, nlayers, widths, pool_rows, backward, pl)) return -1;
+    pn2::GroupDims gd;
+    if (group_dims) gd = {group_dims[0], group_dims[1], group_dims[2], group_dims[3], group_dims[4], group_dims[5]};
+    if (!widths || !pn2::tl_plan(rows, nlayers, widths, pool_rows, backward, pl, group_dims ? &gd : nullptr)) return -1;
     return (long long)pl.total;
+}
+
+// 1: layer 1 of this grouped level runs once per point; backward then writes the gradient of `points` itself
+// (grad_points (b, n, cfeat)) instead of the per-row gradient grad_feat_rows
+extern "C" int pn2_mlp_train_layer1_per_point(int nlayers, const int *widths, const int *group_dims)
+{
+    if (!widths || !group_dims || nlayers < 1 || nlayers > 8) return 0;
+    const pn2::GroupDims gd = {group_dims[0], group_dims[1], group_dims[2], group_dims[3], group_dims[4], group_dims[5]};
+    return pn2::l1_per_point(nlayers, widths, &gd) ? 1 : 0;
 }
 
 // 1: the top layer's pre-norm tensor z_L is written by forward and read by backward (the caller allocates layers[L-1].z);
@@ -1526,7 +1728,10 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
     if ((!group && !x) || !out || !ws || (pool_rows && (!argsel || !zsel))) return PN2_E_NULL;
     if (pool_rows && (rows % pool_rows || (group && pool_rows != group->nsample))) return PN2_E_ARG;
     TlPlan pl;
-    if (!tl_plan(rows, nlayers, widths, pool_rows, 0, pl)) return PN2_E_ARG;
+    GroupDims gd;
+    if (group) gd = group_dims(group);
+    if (!tl_plan(rows, nlayers, widths, pool_rows, 0, pl, group ? &gd : nullptr)) return PN2_E_ARG;
+    const bool per_point = group && l1_per_point(nlayers, widths, &gd);
     const bool keep_top = top_stored(rows, nlayers, widths, pool_rows);
     for (int l = 0; l < nlayers; ++l)
         if (!layers[l].z && (keep_top || l < nlayers - 1)) return PN2_E_NULL;
@@ -1538,7 +1743,13 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
         int nj = 0;
         for (int l = 0; l < nlayers; ++l) {
             const pn2_bn_layer &L = layers[l];
-            add_pack_job(jobs, nj, L.weight, L.w_stride_k, L.w_stride_n, gemm_shape(rows, L.cin, L.cout), base + pl.pack[l]);
+            if (l == 0 && per_point) {                            // only the feature rows of W_1: P = points . W1f
+                const TlGather gt = make_gather(group);
+                add_pack_job(jobs, nj, L.weight + gt.feat_off * L.w_stride_k, L.w_stride_k, L.w_stride_n,
+                             gemm_shape((long long)gd.b * gd.n, gt.cfeat, L.cout), base + pl.pack[l]);
+            } else {
+                add_pack_job(jobs, nj, L.weight, L.w_stride_k, L.w_stride_n, gemm_shape(rows, L.cin, L.cout), base + pl.pack[l]);
+            }
         }
         if (int rc = launch_pack_jobs(jobs, nj, st)) return rc;
     }
@@ -1546,6 +1757,38 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
         const pn2_bn_layer &L = layers[l];
         const GemmShape g = gemm_shape(rows, L.cin, L.cout);
         const bool last = l == nlayers - 1;
+        if (l == 0 && per_point) {
+            // layer 1 once per point (tl_l1_forward_kernel): P = points . W1f over the b n points, then one pass over the rows
+            const TlGather gt = make_gather(group);
+            const long long bn = (long long)gd.b * gd.n;
+            float *P = reinterpret_cast<float *>(base + pl.l1p);
+            {
+                const GemmShape gp = gemm_shape(bn, gt.cfeat, L.cout);
+                TlGemm q;
+                memset(&q, 0, sizeof(q));
+                q.rows = bn;
+                q.A = group->points;
+                q.wpacked = reinterpret_cast<const u32x4 *>(base + pl.pack[l]);
+                q.emode = E_STORE;
+                q.out = P;
+                if (int rc = launch_gemm(A_PLAIN, q, gp, st)) return rc;
+            }
+            TlL1 q;
+            memset(&q, 0, sizeof(q));
+            q.rows = rows; q.n = gd.n; q.m = gd.m; q.nsample = gd.nsample; q.C = L.cout;
+            q.xyz = group->xyz; q.new_xyz = group->new_xyz; q.idx = group->idx; q.P = P;
+            q.wx = L.weight + gt.xyz_off * L.w_stride_k; q.skx = L.w_stride_k; q.sn = L.w_stride_n;
+            q.bias = L.bias; q.z = L.z;
+            q.stats = reinterpret_cast<double *>(base + pl.stats[l]);
+            const int rpb = 256 / (L.cout / 4);
+            long long blocks = (rows + rpb - 1) / rpb;
+            if (blocks > kMaxParts) blocks = kMaxParts;
+            if (int rc = launch(tl_l1_forward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, q)) return rc;
+            if (int rc = launch(tl_bn_finalize_kernel, dim3((unsigned)((L.cout + 7) / 8)), dim3(256), 0, st,
+                                reinterpret_cast<const double *>(base + pl.stats[l]), (int)blocks, L.cout, (double)rows, L.gamma,
+                                L.beta, L.running_mean, L.running_var, L.momentum, L.eps, L.save)) return rc;
+            continue;
+        }
         TlGemm p;
         memset(&p, 0, sizeof(p));
         p.rows = rows;
@@ -1592,7 +1835,8 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
 
 extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group,
                                       const float *x, int pool_rows, const float *out, const int *argsel, const float *zsel,
-                                      const float *grad_out, float *grad_x, float *grad_feat_rows, void *ws, void *stream)
+                                      const float *grad_out, float *grad_x, float *grad_feat_rows, float *grad_points,
+                                      int reproducible, void *ws, void *stream)
 {
     using namespace pn2;
     int widths[9];
@@ -1601,10 +1845,13 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
     for (int l = 0; l < nlayers; ++l)
         if (!layers[l].grad_weight || !layers[l].grad_gamma || !layers[l].grad_beta) return PN2_E_NULL;
     TlPlan pl;
-    if (!tl_plan(rows, nlayers, widths, pool_rows, 1, pl)) return PN2_E_ARG;
+    GroupDims gd;
+    if (group) gd = group_dims(group);
+    if (!tl_plan(rows, nlayers, widths, pool_rows, 1, pl, group ? &gd : nullptr)) return PN2_E_ARG;
     hipStream_t st = as_stream(stream);
     char *base = static_cast<char *>(ws);
-    const bool want_dx = group ? (grad_feat_rows && group->points && group->cfeat > 0) : grad_x != nullptr;
+    const bool per_point = group && l1_per_point(nlayers, widths, &gd);
+    const bool want_dx = group ? ((per_point ? grad_points : grad_feat_rows) && group->points && group->cfeat > 0) : grad_x != nullptr;
     const bool ztop = !top_stored(rows, nlayers, widths, pool_rows);     // pooled top layer without z_L (tl_top_mats_kernel)
     for (int l = 0; l < nlayers; ++l)
         if (!layers[l].z && !(ztop && l == nlayers - 1)) return PN2_E_NULL;
@@ -1616,10 +1863,11 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
             const pn2_bn_layer &L = layers[l];
             if ((l > 0 || want_dx) && !(ztop && l == nlayers - 1)) {      // dy_{l-1} = dz_l . W_l^T
                 if (l == 0 && group) {
-                    // layer 1 of a grouped level: only the FEATURE rows of W_1 (the grouped xyz takes no gradient here)
+                    // layer 1 of a grouped level: only the FEATURE rows of W_1 (the grouped xyz takes no gradient here);
+                    // per point: the same tiles, for the GEMM over the b n points
                     const TlGather gt = make_gather(group);
                     add_pack_job(jobs, nj, L.weight + gt.feat_off * L.w_stride_k, L.w_stride_n, L.w_stride_k,
-                                 gemm_shape(rows, L.cout, gt.cfeat), base + pl.pack[l]);
+                                 gemm_shape(per_point ? (long long)gd.b * gd.n : rows, L.cout, gt.cfeat), base + pl.pack[l]);
                 } else {
                     add_pack_job(jobs, nj, L.weight, L.w_stride_n, L.w_stride_k, gemm_shape(rows, L.cout, L.cin), base + pl.pack[l]);
                 }
@@ -1707,6 +1955,51 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
             float *tmp = gcur; gcur = gnext; gnext = tmp;
             continue;
         }
+        if (l == 0 && per_point) {
+            // ---- layer 1 once per point (see tl_l1_forward_kernel): dz_1 and dW1x in one pass over the rows, the scatter of
+            // dz_1 onto the points, then two GEMMs over the b n points
+            const TlGather gt = make_gather(group);
+            const long long bn = (long long)gd.b * gd.n;
+            float *S = reinterpret_cast<float *>(base + pl.l1p), *part = reinterpret_cast<float *>(base + pl.l1part);
+            float *ident = reinterpret_cast<float *>(base + pl.l1coef);
+            TlL1 q;
+            memset(&q, 0, sizeof(q));
+            q.rows = rows; q.n = gd.n; q.m = gd.m; q.nsample = gd.nsample; q.C = L.cout;
+            q.xyz = group->xyz; q.new_xyz = group->new_xyz; q.idx = group->idx;
+            q.z = L.z; q.g = gcur; q.coef = coef; q.part = part;
+            const int rpb = 256 / (L.cout / 4);
+            long long blocks = (rows + rpb - 1) / rpb;
+            if (blocks > kMaxParts) blocks = kMaxParts;
+            if (int rc = launch(tl_l1_dz_kernel, dim3((unsigned)blocks), dim3(256), 0, st, q)) return rc;
+            if (int rc = launch(tl_l1_wx_reduce_kernel, dim3((unsigned)((3 * L.cout + 127) / 128)), dim3(128), 0, st, (const float *)part,
+                                (int)blocks, L.cout, L.grad_weight + gt.xyz_off * L.w_stride_k, L.w_stride_k, L.w_stride_n)) return rc;
+            if (int rc = pn2_group_point_grad_seg(gd.b, gd.n, L.cout, gd.m, gd.nsample, gcur, group->idx, S, base + pl.l1seg,
+                                                  reproducible, stream)) return rc;
+            if (int rc = launch(tl_identity_coef_kernel, dim3((unsigned)((3 * L.cout + 127) / 128)), dim3(128), 0, st, L.cout, ident)) return rc;
+            {
+                TlWgrad w;                                        // dW1f = points^T S
+                memset(&w, 0, sizeof(w));
+                w.rows = bn; w.KI = gt.cfeat; w.amode = A_PLAIN; w.A = group->points;
+                w.dmode = A_DZ; w.NO = L.cout; w.Z = S; w.G = S; w.coef = ident;
+                w.partial = reinterpret_cast<float *>(base + pl.partial);
+                pn2_bn_layer Lf = L;
+                Lf.grad_weight = L.grad_weight + gt.feat_off * L.w_stride_k;
+                const WgradShape ws_ = wgrad_shape(bn, gt.cfeat, L.cout);
+                if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), Lf, st)) return rc;
+            }
+            if (want_dx) {                                        // dPoints = S W1f^T
+                const GemmShape g = gemm_shape(bn, L.cout, gt.cfeat);
+                TlGemm p;
+                memset(&p, 0, sizeof(p));
+                p.rows = bn;
+                p.A = S;
+                p.wpacked = reinterpret_cast<const u32x4 *>(base + pl.pack[l]);
+                p.emode = E_PLAIN;
+                p.out = grad_points; p.out_pitch = gt.cfeat; p.col0 = 0; p.col1 = gt.cfeat;
+                if (int rc = launch_gemm(A_PLAIN, p, g, st)) return rc;
+            }
+            break;
+        }
         // weight gradient
         {
             TlWgrad w;
@@ -1724,7 +2017,7 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
             w.coef = coef;
             w.group_rows = pool_rows;
             w.partial = reinterpret_cast<float *>(base + pl.partial);
-            const WgradShape ws_ = wgrad_shape(rows, L.cin, L.cout);
+            const WgradShape ws_ = wgrad_shape(rows, L.cin, L.cout, w.amode == A_GATHER);
             if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, st)) return rc;
         }
         // data gradient

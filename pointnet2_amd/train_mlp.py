@@ -97,9 +97,17 @@ def _group_struct(level, points):
     return g
 
 
-def _ws(rows, widths, pool_rows, backward, dev):
+def _group_dims(level, points):
+    """{b, n, m, nsample, cfeat, idx != NULL} of a grouped level for the workspace / per-point queries, or None."""
+    if not level.grouped:
+        return None
+    return (ctypes.c_int * 6)(level.b, level.n, level.m, level.nsample, points.shape[2] if points is not None else 0,
+                              1 if level.idx is not None else 0)
+
+
+def _ws(rows, widths, pool_rows, backward, dev, gdims=None):
     arr = (ctypes.c_int * len(widths))(*widths)
-    nbytes = _C.lib().pn2_mlp_train_ws_bytes(rows, len(widths) - 1, arr, pool_rows, backward)
+    nbytes = _C.lib().pn2_mlp_train_ws_bytes(rows, len(widths) - 1, arr, pool_rows, backward, gdims)
     require(nbytes >= 0, "pn2_mlp_train: unsupported stack (rows %% 32, widths %% 4, pool group 16 or a multiple of 32)")
     return torch.empty(((nbytes + 7) // 8,), dtype=torch.int64, device=dev)
 
@@ -135,7 +143,7 @@ class _TrainMLP(torch.autograd.Function):
         else:
             out = torch.empty((rows, cl), dtype=torch.float32, device=dev)
             argsel = zsel = None
-        ws = _ws(rows, widths, level.pool_rows, 0, dev)
+        ws = _ws(rows, widths, level.pool_rows, 0, dev, _group_dims(level, x))
         arr = _layer_array(level, weights, biases, gammas, betas, zs, saves)
         grp = _group_struct(level, x) if level.grouped else None
         with on_device(dev):
@@ -178,12 +186,17 @@ class _TrainMLP(torch.autograd.Function):
         grad_out = f32(grad_out, "grad_out")
         grads = [(torch.empty_like(weights[l]), torch.empty_like(gammas[l]), torch.empty_like(betas[l])) for l in range(n)]
         need_x = ctx.needs_input_grad[1] and x is not None
-        grad_x = grad_rows = None
-        if need_x and level.grouped:
+        grad_x = grad_rows = grad_pts = None
+        gdims = _group_dims(level, x)
+        warr = (ctypes.c_int * len(widths))(*widths)
+        per_point = level.grouped and bool(_C.lib().pn2_mlp_train_layer1_per_point(n, warr, gdims))
+        if need_x and level.grouped and per_point:
+            grad_pts = torch.empty(tuple(x.shape), dtype=torch.float32, device=dev)      # written by the library itself
+        elif need_x and level.grouped:
             grad_rows = torch.empty((rows, x.shape[2]), dtype=torch.float32, device=dev)
         elif need_x:
             grad_x = torch.empty((rows, widths[0]), dtype=torch.float32, device=dev)
-        ws = _ws(rows, widths, level.pool_rows, 1, dev)
+        ws = _ws(rows, widths, level.pool_rows, 1, dev, gdims)
         if _KEEP_WS[0]:
             _KEEP_WS[1] = (ws, rows, widths, level.pool_rows)
         arr = _layer_array(level, weights, biases, gammas, betas, zs, saves, grads, update_running=False)
@@ -191,8 +204,11 @@ class _TrainMLP(torch.autograd.Function):
         with on_device(dev):
             _C.check(_C.lib().pn2_mlp_train_backward(rows, n, arr, ctypes.byref(grp) if grp is not None else None,
                                                      None if level.grouped else ptr(x), level.pool_rows, ptr(out), ptr(argsel),
-                                                     ptr(zsel), ptr(grad_out), ptr(grad_x), ptr(grad_rows), ptr(ws),
-                                                     stream_ptr(dev)), "mlp_train_backward")
+                                                     ptr(zsel), ptr(grad_out), ptr(grad_x), ptr(grad_rows), ptr(grad_pts),
+                                                     1 if is_deterministic() else 0, ptr(ws), stream_ptr(dev)),
+                     "mlp_train_backward")
+            if grad_pts is not None:
+                grad_x = grad_pts
             if grad_rows is not None:
                 # the grouped feature rows' gradient back onto the points: the segmented scatter of group_point's backward
                 b, npts, c = x.shape

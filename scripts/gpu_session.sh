@@ -27,6 +27,24 @@ for step in "$@"; do
     smoke)     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; tail -2 "$OUT/smoke.log" ;;
     configs)   timeout 600 python scripts/config_shapes.py > "$OUT/config_shapes.json" 2> "$OUT/config_shapes.err"; tail -3 "$OUT/config_shapes.json" ;;
     bench)     timeout 600 python bench.py > "$OUT/bench.log" 2>&1; tail -3 "$OUT/bench.log" ;;
+    trainbench) timeout 400 python scripts/train_mlp_bench.py 2> "$OUT/train_mlp_bench.err" | grep "^{" > "$OUT/train_mlp_bench.jsonl"; python - "$OUT/train_mlp_bench.jsonl" <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    r = json.loads(l)
+    print("%-58s fused %7.1f + %7.1f us | layer by layer %7.1f + %7.1f us | x%.2f" % (r["level"][:58], r["fused"]["forward_us"], r["fused"]["backward_us"], r["layer_by_layer"]["forward_us"], r["layer_by_layer"]["backward_us"], r["speedup_step"]))
+PY
+    ;;
+    trainstep) timeout 900 python scripts/train_step_bench.py --steps 8 2> "$OUT/train_step.err" | grep "^{" > "$OUT/train_step.jsonl"; python - "$OUT/train_step.jsonl" <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    r = json.loads(l)
+    f, u = r["fused"], r["layer_by_layer"]
+    print("%-50s layer by layer %6.2f + %6.2f = %6.2f ms | fused %6.2f + %6.2f = %6.2f ms | x%.2f" % (r["model"][:50], u["forward_ms"], u["backward_ms"], u["step_ms"], f["forward_ms"], f["backward_ms"], f["step_ms"], r["speedup"]))
+PY
+    ;;
+    trainrccl) timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 scripts/train_step_bench.py sem_seg --steps 8 --fused-only 2> "$OUT/train_rccl.err" | grep "^{" > "$OUT/train_step_rccl.jsonl"; cat "$OUT/train_step_rccl.jsonl" | cut -c1-400
+               timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --steps 20 --no-extras 2> "$OUT/bench_rccl.err" | grep "^{" > "$OUT/bench_rccl.json"; python -c "import json,sys; print(json.load(open(sys.argv[1]))['allreduce'])" "$OUT/bench_rccl.json" ;;
+    traincheck) PN2_TL_TOP_STORED=0 timeout 300 python scripts/train_mlp_check.py > "$OUT/train_check_zfree.log" 2>&1; tail -1 "$OUT/train_check_zfree.log"; timeout 300 python scripts/train_mlp_check.py > "$OUT/train_check.log" 2>&1; tail -1 "$OUT/train_check.log" ;;
     profile)   timeout 1200 bash scripts/profile_round.sh > "$OUT/profile.log" 2>&1; tail -5 "$OUT/profile.log" ;;
     *)         echo "unknown step $step" ;;
     esac

@@ -227,6 +227,7 @@ if __name__ == "__main__":
         ("F plain 384-256-128", dict(b=4, n=1024, m=0, ns=0, cfeat=0, widths=[256, 128], plain_cin=384)),
         ("G c256 256-256-512", dict(b=4, n=256, m=16, ns=32, cfeat=256, widths=[256, 256, 512])),
         ("H 64-96-128 ns128", dict(b=2, n=512, m=64, ns=128, cfeat=0, widths=[64, 96, 128])),
+        ("K msg order c32 ns64", dict(b=4, n=256, m=32, ns=64, cfeat=32, widths=[64, 64, 128], xyz_first=False)),
     ]
     only = [a for a in sys.argv[1:] if not a.startswith("--")]
     repeat = max([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--repeat=")] + [1])
