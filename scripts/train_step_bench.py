@@ -80,6 +80,9 @@ def run_steps(model, opt, bucket, x, labels, kind, steps, warm, batch):
 def graph_step(model, opt, bucket, x, labels, steps):
     """forward + loss + backward + SGD step of the fused path captured in one HIP graph (static input buffers); replay time.
     Everything on the path is capturable: no host synchronisation, no pageable copies, scratch from torch's allocator."""
+    import gc
+    gc.collect()                                          # AccumulateGrad nodes of earlier (default-stream) backwards must be gone:
+    torch.cuda.synchronize()                              # a node kept alive would tie the capture to the default stream
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):                         # warm-up on a side stream, as torch.cuda.graph requires
@@ -89,7 +92,7 @@ def graph_step(model, opt, bucket, x, labels, steps):
             opt.step()
     torch.cuda.current_stream().wait_stream(side)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, stream=side):
         bucket.zero_()
         loss = F.cross_entropy(model(x), labels)
         loss.backward()
@@ -149,6 +152,7 @@ def main():
             loss0 = F.cross_entropy(model(x), labels)
             loss0.backward()
             grads[fused] = (float(loss0), bucket.flat.clone())
+            del loss0                                      # no reference to an old autograd graph may survive into a capture
             paths = [m.last_path for m in model.modules() if hasattr(m, "last_path")]
             ph, loss = run_steps(model, opt, bucket, x, labels, kind, args.steps, args.warmup, b * world)
             key = "fused" if fused else "layer_by_layer"
