@@ -1165,14 +1165,27 @@ __global__ __launch_bounds__(256) void tl_top_mats_kernel(const float *__restric
             wp[i] = r < NF ? w[n * sk + r * sn] : 0.0f;
         } else if (r < NFp + K) {
             const int j = r - NFp;
-            double acc = 0.0;
-            for (int c = 0; c < NF; ++c) acc += (double)w[j * sk + c * sn] * (double)coef[2 * NF + c] * (double)w[n * sk + c * sn];
-            wp[i] = (float)(-acc);
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};                  // four chains: the loop is load latency, not arithmetic
+            int c = 0;
+            for (; c + 4 <= NF; c += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc[u] += (double)w[j * sk + (c + u) * sn] * (double)coef[2 * NF + c + u] * (double)w[n * sk + (c + u) * sn];
+            }
+            for (; c < NF; ++c) acc[0] += (double)w[j * sk + c * sn] * (double)coef[2 * NF + c] * (double)w[n * sk + c * sn];
+            wp[i] = (float)(-((acc[0] + acc[1]) + (acc[2] + acc[3])));
         } else {
-            double acc = 0.0;
-            for (int c = 0; c < NF; ++c)
-                acc += ((double)coef[NF + c] + (bias ? (double)bias[c] : 0.0) * (double)coef[2 * NF + c]) * (double)w[n * sk + c * sn];
-            rowc[n] = (float)(-acc);
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            int c = 0;
+            for (; c + 4 <= NF; c += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc[u] += ((double)coef[NF + c + u] + (bias ? (double)bias[c + u] : 0.0) * (double)coef[2 * NF + c + u]) *
+                              (double)w[n * sk + (c + u) * sn];
+            }
+            for (; c < NF; ++c)
+                acc[0] += ((double)coef[NF + c] + (bias ? (double)bias[c] : 0.0) * (double)coef[2 * NF + c]) * (double)w[n * sk + c * sn];
+            rowc[n] = (float)(-((acc[0] + acc[1]) + (acc[2] + acc[3])));
         }
     }
 }
@@ -1187,8 +1200,14 @@ __global__ __launch_bounds__(256) void tl_top_wgrad_fix_kernel(const double *__r
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int k = (int)(i / NF), n = (int)(i - (long long)k * NF);
         const double *row = sf + (size_t)k * ld;
-        double acc = 0.0;
-        for (int j = 0; j < K; ++j) acc += row[goff + j] * (double)w[j * sk + n * sn];
+        double a4[4] = {0.0, 0.0, 0.0, 0.0};
+        int j = 0;
+        for (; j + 4 <= K; j += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a4[u] += row[goff + j + u] * (double)w[(j + u) * sk + n * sn];
+        }
+        for (; j < K; ++j) a4[0] += row[goff + j] * (double)w[j * sk + n * sn];
+        const double acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         const double c0 = coef[NF + n], c1 = coef[2 * NF + n], b = bias ? (double)bias[n] : 0.0;
         gw[k * sk + n * sn] = (float)(row[n] - c1 * acc - row[hoff] * (c0 + b * c1));
     }
@@ -1220,43 +1239,90 @@ struct TlL1 {
     float *part;                            // backward: (workgroups, 3, C) partial dW1x
 };
 
-// thread <-> (row lane, 4 columns): a block of 256 threads covers 256 / (C / 4) rows at a time, columns fixed per thread
-__global__ __launch_bounds__(256) void tl_l1_forward_kernel(const TlL1 p)
+// thread <-> (row lane, 4 columns): a block of kL1Threads covers kL1Threads / (C / 4) rows at a time, columns fixed per
+// thread, and every thread keeps kL1U rows in flight (all loads of a batch are issued before the first is used: the
+// point number -> coordinates / row of P chain is two dependent latencies, one row at a time ran at 1-2 TB/s).
+// P == nullptr: a level WITHOUT features (the first level of every network): z_1 = b + (xyz - c) W1 on the vector units,
+// three multiply-adds per output -- the generic gathered GEMM spent a matrix-core pass on a contraction of three.
+constexpr int kL1Threads = 512, kL1U = 4;
+
+struct L1Rows {                                   // the batch's rows: number, point, group (clamped to a valid row when !ok)
+    unsigned row[kL1U];
+    size_t pt[kL1U];                              // cloud * n + point
+    unsigned grp[kL1U];
+    bool ok[kL1U];
+};
+
+__device__ __forceinline__ L1Rows l1_rows(const TlL1 &p, unsigned base, unsigned stride, unsigned rows)
 {
-    const int qpr = p.C / 4, q = threadIdx.x % qpr, rl = threadIdx.x / qpr, rpb = 256 / qpr, col = 4 * q;
-    float4 w0, w1, w2, b4 = {0.f, 0.f, 0.f, 0.f};
+    L1Rows r;
+#pragma unroll
+    for (int u = 0; u < kL1U; ++u) {
+        const unsigned rr = base + (unsigned)u * stride;
+        r.ok[u] = rr < rows;
+        r.row[u] = r.ok[u] ? rr : base;
+        r.grp[u] = r.row[u] / (unsigned)p.nsample;
+    }
+#pragma unroll
+    for (int u = 0; u < kL1U; ++u) r.pt[u] = (size_t)(r.grp[u] / (unsigned)p.m) * p.n + p.idx[r.row[u]];
+    return r;
+}
+
+__device__ __forceinline__ void l1_coords(const TlL1 &p, const L1Rows &r, float (&x)[kL1U][3])
+{
+#pragma unroll
+    for (int u = 0; u < kL1U; ++u) {
+        const float *px = p.xyz + r.pt[u] * 3;
+        x[u][0] = px[0]; x[u][1] = px[1]; x[u][2] = px[2];
+    }
+    if (p.new_xyz) {
+#pragma unroll
+        for (int u = 0; u < kL1U; ++u) {
+            const float *pc = p.new_xyz + (size_t)r.grp[u] * 3;
+            const float c0 = pc[0], c1 = pc[1], c2 = pc[2];
+            x[u][0] = __fsub_rn(x[u][0], c0); x[u][1] = __fsub_rn(x[u][1], c1); x[u][2] = __fsub_rn(x[u][2], c2);   // pointnet_util.py:46
+        }
+    }
+}
+
+__global__ __launch_bounds__(kL1Threads) void tl_l1_forward_kernel(const TlL1 p)
+{
+    const int qpr = p.C / 4, q = threadIdx.x % qpr, rl = threadIdx.x / qpr, rpb = kL1Threads / qpr, col = 4 * q;
+    float a0[4], a1[4], a2[4], b4[4] = {0.f, 0.f, 0.f, 0.f};
     {
         const float *w = p.wx + (size_t)col * p.sn;
-        w0 = make_float4(w[0], w[p.sn], w[2 * p.sn], w[3 * p.sn]);
-        w1 = make_float4(w[p.skx], w[p.skx + p.sn], w[p.skx + 2 * p.sn], w[p.skx + 3 * p.sn]);
-        w2 = make_float4(w[2 * p.skx], w[2 * p.skx + p.sn], w[2 * p.skx + 2 * p.sn], w[2 * p.skx + 3 * p.sn]);
-        if (p.bias) b4 = ld4(p.bias + col);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a0[i] = w[i * p.sn]; a1[i] = w[p.skx + i * p.sn]; a2[i] = w[2 * p.skx + i * p.sn]; }
+        if (p.bias) { const float4 b = ld4(p.bias + col); b4[0] = b.x; b4[1] = b.y; b4[2] = b.z; b4[3] = b.w; }
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    for (long long row = (long long)blockIdx.x * rpb + rl; row < p.rows; row += (long long)gridDim.x * rpb) {
-        const int grp = (int)(row / p.nsample), cloud = grp / p.m, pt = p.idx[row];
-        const float *px = p.xyz + ((size_t)cloud * p.n + pt) * 3;
-        float x0 = px[0], x1 = px[1], x2 = px[2];
-        if (p.new_xyz) {
-            const float *pc = p.new_xyz + (size_t)grp * 3;
-            x0 = __fsub_rn(x0, pc[0]); x1 = __fsub_rn(x1, pc[1]); x2 = __fsub_rn(x2, pc[2]);      // pointnet_util.py:46
-        }
-        const float4 pp = ld4(p.P + ((size_t)cloud * p.n + pt) * p.C + col);
-        float z[4] = {pp.x + b4.x, pp.y + b4.y, pp.z + b4.z, pp.w + b4.w};
-        const float a0[4] = {w0.x, w0.y, w0.z, w0.w}, a1[4] = {w1.x, w1.y, w1.z, w1.w}, a2[4] = {w2.x, w2.y, w2.z, w2.w};
+    const unsigned rows = (unsigned)p.rows, stride = gridDim.x * (unsigned)rpb;
+    for (unsigned base = blockIdx.x * (unsigned)rpb + rl; base < rows; base += kL1U * stride) {
+        const L1Rows r = l1_rows(p, base, stride, rows);
+        float x[kL1U][3];
+        float4 pp[kL1U];
+        l1_coords(p, r, x);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            z[i] = fmaf(x0, a0[i], z[i]);
-            z[i] = fmaf(x1, a1[i], z[i]);
-            z[i] = fmaf(x2, a2[i], z[i]);
-            s1[i] += z[i];
-            s2[i] = fmaf(z[i], z[i], s2[i]);
+        for (int u = 0; u < kL1U; ++u) pp[u] = p.P ? ld4(p.P + r.pt[u] * p.C + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < kL1U; ++u) {
+            float z[4] = {pp[u].x + b4[0], pp[u].y + b4[1], pp[u].z + b4[2], pp[u].w + b4[3]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                z[i] = fmaf(x[u][0], a0[i], z[i]);
+                z[i] = fmaf(x[u][1], a1[i], z[i]);
+                z[i] = fmaf(x[u][2], a2[i], z[i]);
+            }
+            if (r.ok[u]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { s1[i] += z[i]; s2[i] = fmaf(z[i], z[i], s2[i]); }
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f zo = {z[0], z[1], z[2], z[3]};
+                __builtin_nontemporal_store(zo, reinterpret_cast<v4f *>(p.z + (size_t)r.row[u] * p.C + col));
+            }
         }
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f zo = {z[0], z[1], z[2], z[3]};
-        __builtin_nontemporal_store(zo, reinterpret_cast<v4f *>(p.z + (size_t)row * p.C + col));
     }
-    __shared__ double red[2][256][4];
+    __shared__ double red[2][kL1Threads][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { red[0][threadIdx.x][i] = (double)s1[i]; red[1][threadIdx.x][i] = (double)s2[i]; }
     __syncthreads();
@@ -1264,40 +1330,51 @@ __global__ __launch_bounds__(256) void tl_l1_forward_kernel(const TlL1 p)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             double a = 0.0, b = 0.0;
-            for (int r = 0; r < rpb; ++r) { a += red[0][r * qpr + q][i]; b += red[1][r * qpr + q][i]; }
+            for (int k = 0; k < rpb; ++k) { a += red[0][k * qpr + q][i]; b += red[1][k * qpr + q][i]; }
             p.stats[((size_t)blockIdx.x * 2) * p.C + col + i] = a;
             p.stats[((size_t)blockIdx.x * 2 + 1) * p.C + col + i] = b;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void tl_l1_dz_kernel(const TlL1 p)
+// dz_1 = s dy_1 - c0 - c1 z_1 and the coordinate rows of the weight gradient, dW1x = (xyz - c)^T dz_1, in one pass over the
+// rows. STORE: dz_1 overwrites dy_1 (the per-point path scatters it onto the points next); a level without features needs
+// only dW1x = its whole first-layer weight gradient.
+template <bool STORE>
+__global__ __launch_bounds__(kL1Threads) void tl_l1_dz_kernel(const TlL1 p)
 {
-    const int qpr = p.C / 4, q = threadIdx.x % qpr, rl = threadIdx.x / qpr, rpb = 256 / qpr, col = 4 * q;
+    const int qpr = p.C / 4, q = threadIdx.x % qpr, rl = threadIdx.x / qpr, rpb = kL1Threads / qpr, col = 4 * q;
     const float4 s4 = ld4(p.coef + col), c04 = ld4(p.coef + p.C + col), c14 = ld4(p.coef + 2 * p.C + col);
     const float s[4] = {s4.x, s4.y, s4.z, s4.w}, c0[4] = {c04.x, c04.y, c04.z, c04.w}, c1[4] = {c14.x, c14.y, c14.z, c14.w};
     float acc[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    for (long long row = (long long)blockIdx.x * rpb + rl; row < p.rows; row += (long long)gridDim.x * rpb) {
-        const int grp = (int)(row / p.nsample), cloud = grp / p.m, pt = p.idx[row];
-        const float *px = p.xyz + ((size_t)cloud * p.n + pt) * 3;
-        float x[3] = {px[0], px[1], px[2]};
-        if (p.new_xyz) {
-            const float *pc = p.new_xyz + (size_t)grp * 3;
-            x[0] = __fsub_rn(x[0], pc[0]); x[1] = __fsub_rn(x[1], pc[1]); x[2] = __fsub_rn(x[2], pc[2]);
-        }
-        const size_t o = (size_t)row * p.C + col;
-        const float4 g4 = ld4(p.g + o), z4 = ld4(p.z + o);
-        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w};
-        float dz[4];
+    const unsigned rows = (unsigned)p.rows, stride = gridDim.x * (unsigned)rpb;
+    for (unsigned base = blockIdx.x * (unsigned)rpb + rl; base < rows; base += kL1U * stride) {
+        const L1Rows r = l1_rows(p, base, stride, rows);
+        float x[kL1U][3];
+        float4 g4[kL1U], z4[kL1U];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            dz[i] = __fsub_rn(__fsub_rn(__fmul_rn(s[i], gg[i]), c0[i]), __fmul_rn(c1[i], zz[i]));      // s dy - c0 - c1 z
-#pragma unroll
-            for (int k = 0; k < 3; ++k) acc[k][i] = fmaf(x[k], dz[i], acc[k][i]);
+        for (int u = 0; u < kL1U; ++u) {
+            const size_t o = (size_t)r.row[u] * p.C + col;
+            g4[u] = ld4(p.g + o);
+            z4[u] = ld4(p.z + o);
         }
-        *reinterpret_cast<float4 *>(p.g + o) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+        l1_coords(p, r, x);
+#pragma unroll
+        for (int u = 0; u < kL1U; ++u) {
+            const float gg[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w}, zz[4] = {z4[u].x, z4[u].y, z4[u].z, z4[u].w};
+            float dz[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dz[i] = __fsub_rn(__fsub_rn(__fmul_rn(s[i], gg[i]), c0[i]), __fmul_rn(c1[i], zz[i]));      // s dy - c0 - c1 z
+                const float dv = r.ok[u] ? dz[i] : 0.0f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc[k][i] = fmaf(x[u][k], dv, acc[k][i]);
+            }
+            if (STORE && r.ok[u])
+                *reinterpret_cast<float4 *>(p.g + (size_t)r.row[u] * p.C + col) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+        }
     }
-    __shared__ float red[3][256][4];
+    __shared__ float red[3][kL1Threads][4];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -1309,22 +1386,31 @@ __global__ __launch_bounds__(256) void tl_l1_dz_kernel(const TlL1 p)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 double a = 0.0;
-                for (int r = 0; r < rpb; ++r) a += (double)red[k][r * qpr + q][i];
+                for (int j = 0; j < rpb; ++j) a += (double)red[k][j * qpr + q][i];
                 p.part[((size_t)blockIdx.x * 3 + k) * p.C + col + i] = (float)a;
             }
     }
 }
 
-// dW1x[k][col] = sum over the workgroups' partials (fp64), written to rows [xyz_off, xyz_off + 3) of grad_weight
-__global__ void tl_l1_wx_reduce_kernel(const float *__restrict__ part, int nparts, int C, float *__restrict__ gw, long long sk,
-                                       long long sn)
+// dW1x[k][col] = sum over the workgroups' partials (fp64), written to rows [xyz_off, xyz_off + 3) of grad_weight.
+// A block of 256 threads owns 8 of the 3 C sums and adds the partial rows 32 at a time (a thread per sum walking all
+// 256 rows was 60 us of dependent L2 latencies).
+__global__ __launch_bounds__(256) void tl_l1_wx_reduce_kernel(const float *__restrict__ part, int nparts, int C, float *__restrict__ gw,
+                                                              long long sk, long long sn)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 3 * C) return;
-    const int k = i / C, col = i - k * C;
+    __shared__ double sh[32][8];
+    const int g = threadIdx.x >> 3, cl = threadIdx.x & 7, i = blockIdx.x * 8 + cl;
     double a = 0.0;
-    for (int q = 0; q < nparts; ++q) a += (double)part[((size_t)q * 3 + k) * C + col];
-    gw[k * sk + col * sn] = (float)a;
+    if (i < 3 * C)
+        for (int q = g; q < nparts; q += 32) a += (double)part[(size_t)q * 3 * C + i];
+    sh[g][cl] = a;
+    __syncthreads();
+    if (g != 0 || i >= 3 * C) return;
+    double sum = 0.0;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) sum += sh[r][cl];
+    const int k = i / C, col = i - k * C;
+    gw[k * sk + col * sn] = (float)sum;
 }
 
 __global__ void tl_identity_coef_kernel(int C, float *__restrict__ coef)       // dz = 1 * g - 0 - 0 * z
@@ -1447,6 +1533,15 @@ static bool l1_per_point(int nlayers, const int *widths, const GroupDims *g)
     return widths[0] == 3 + g->cfeat;
 }
 
+// Is this a grouped level WITHOUT features whose first layer (a contraction of the three coordinates) runs on the vector
+// units (tl_l1_forward_kernel with P == nullptr, tl_l1_dz_kernel<false>)? The first level of every reference network.
+static bool l1_coords_only(int nlayers, const int *widths, const GroupDims *g)
+{
+    if (!g || !g->has_idx || g->cfeat != 0 || widths[0] != 3 || nlayers < 2 || env_int("PN2_TL_L1_COORDS", 1) == 0) return false;
+    const int c1 = widths[1];
+    return c1 % 4 == 0 && c1 / 4 <= kL1Threads && kL1Threads % (c1 / 4) == 0;
+}
+
 static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_rows, int backward, TlPlan &pl,
                     const GroupDims *gd = nullptr)
 {
@@ -1512,6 +1607,8 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
             pl.l1part = off; off = align_up(off + (size_t)kMaxParts * 3 * widths[1] * 4);
             pl.l1coef = off; off = align_up(off + (size_t)3 * widths[1] * 4);
         }
+    } else if (backward && l1_coords_only(nlayers, widths, gd)) {
+        pl.l1part = off; off = align_up(off + (size_t)kMaxParts * 3 * widths[1] * 4);
     }
     pl.total = off;
     return true;
@@ -1719,6 +1816,46 @@ extern "C" int pn2_mlp_train_ws_layout(long long rows, int nlayers, const int *w
     return PN2_OK;
 }
 
+namespace pn2 {
+// layer 1 on the vector units: the pass over the rows (P: the per-point products, or nullptr for a level without features)
+static int launch_l1_forward(long long rows, const GroupDims &gd, const pn2_group_src *group, const pn2_bn_layer &L, const float *P,
+                             double *stats, hipStream_t st, int *nparts)
+{
+    const TlGather gt = make_gather(group);
+    TlL1 q;
+    memset(&q, 0, sizeof(q));
+    q.rows = rows; q.n = gd.n; q.m = gd.m; q.nsample = gd.nsample; q.C = L.cout;
+    q.xyz = group->xyz; q.new_xyz = group->new_xyz; q.idx = group->idx; q.P = P;
+    q.wx = L.weight + gt.xyz_off * L.w_stride_k; q.skx = L.w_stride_k; q.sn = L.w_stride_n;
+    q.bias = L.bias; q.z = L.z;
+    q.stats = stats;
+    const int rpb = kL1Threads / (L.cout / 4);
+    long long blocks = (rows + (long long)rpb * kL1U - 1) / ((long long)rpb * kL1U);
+    if (blocks > kMaxParts) blocks = kMaxParts;
+    *nparts = (int)blocks;
+    return launch(tl_l1_forward_kernel, dim3((unsigned)blocks), dim3(kL1Threads), 0, st, q);
+}
+
+// dz_1 (in place when `store`) and dW1x -> rows [xyz_off, xyz_off + 3) of the layer's weight gradient
+static int launch_l1_dz(long long rows, const GroupDims &gd, const pn2_group_src *group, const pn2_bn_layer &L, float *dy,
+                        const float *coef, float *part, bool store, hipStream_t st)
+{
+    const TlGather gt = make_gather(group);
+    TlL1 q;
+    memset(&q, 0, sizeof(q));
+    q.rows = rows; q.n = gd.n; q.m = gd.m; q.nsample = gd.nsample; q.C = L.cout;
+    q.xyz = group->xyz; q.new_xyz = group->new_xyz; q.idx = group->idx;
+    q.z = L.z; q.g = dy; q.coef = coef; q.part = part;
+    const int rpb = kL1Threads / (L.cout / 4);
+    long long blocks = (rows + (long long)rpb * kL1U - 1) / ((long long)rpb * kL1U);
+    if (blocks > kMaxParts) blocks = kMaxParts;
+    if (int rc = store ? launch(tl_l1_dz_kernel<true>, dim3((unsigned)blocks), dim3(kL1Threads), 0, st, q)
+                       : launch(tl_l1_dz_kernel<false>, dim3((unsigned)blocks), dim3(kL1Threads), 0, st, q)) return rc;
+    return launch(tl_l1_wx_reduce_kernel, dim3((unsigned)((3 * L.cout + 7) / 8)), dim3(256), 0, st, (const float *)part, (int)blocks,
+                  L.cout, L.grad_weight + gt.xyz_off * L.w_stride_k, L.w_stride_k, L.w_stride_n);
+}
+}  // namespace pn2
+
 extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group,
                                      const float *x, int pool_rows, float *out, int *argsel, float *zsel, void *ws, void *stream)
 {
@@ -1732,6 +1869,7 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
     if (group) gd = group_dims(group);
     if (!tl_plan(rows, nlayers, widths, pool_rows, 0, pl, group ? &gd : nullptr)) return PN2_E_ARG;
     const bool per_point = group && l1_per_point(nlayers, widths, &gd);
+    const bool coords_only = group && l1_coords_only(nlayers, widths, &gd);
     const bool keep_top = top_stored(rows, nlayers, widths, pool_rows);
     for (int l = 0; l < nlayers; ++l)
         if (!layers[l].z && (keep_top || l < nlayers - 1)) return PN2_E_NULL;
@@ -1743,6 +1881,7 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
         int nj = 0;
         for (int l = 0; l < nlayers; ++l) {
             const pn2_bn_layer &L = layers[l];
+            if (l == 0 && coords_only) continue;                 // no matrix-core pass at all
             if (l == 0 && per_point) {                            // only the feature rows of W_1: P = points . W1f
                 const TlGather gt = make_gather(group);
                 add_pack_job(jobs, nj, L.weight + gt.feat_off * L.w_stride_k, L.w_stride_k, L.w_stride_n,
@@ -1773,19 +1912,19 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
                 q.out = P;
                 if (int rc = launch_gemm(A_PLAIN, q, gp, st)) return rc;
             }
-            TlL1 q;
-            memset(&q, 0, sizeof(q));
-            q.rows = rows; q.n = gd.n; q.m = gd.m; q.nsample = gd.nsample; q.C = L.cout;
-            q.xyz = group->xyz; q.new_xyz = group->new_xyz; q.idx = group->idx; q.P = P;
-            q.wx = L.weight + gt.xyz_off * L.w_stride_k; q.skx = L.w_stride_k; q.sn = L.w_stride_n;
-            q.bias = L.bias; q.z = L.z;
-            q.stats = reinterpret_cast<double *>(base + pl.stats[l]);
-            const int rpb = 256 / (L.cout / 4);
-            long long blocks = (rows + rpb - 1) / rpb;
-            if (blocks > kMaxParts) blocks = kMaxParts;
-            if (int rc = launch(tl_l1_forward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, q)) return rc;
+            int np = 0;
+            if (int rc = launch_l1_forward(rows, gd, group, L, P, reinterpret_cast<double *>(base + pl.stats[l]), st, &np)) return rc;
             if (int rc = launch(tl_bn_finalize_kernel, dim3((unsigned)((L.cout + 7) / 8)), dim3(256), 0, st,
-                                reinterpret_cast<const double *>(base + pl.stats[l]), (int)blocks, L.cout, (double)rows, L.gamma,
+                                reinterpret_cast<const double *>(base + pl.stats[l]), np, L.cout, (double)rows, L.gamma,
+                                L.beta, L.running_mean, L.running_var, L.momentum, L.eps, L.save)) return rc;
+            continue;
+        }
+        if (l == 0 && coords_only) {
+            // a level without features: z_1 = b + (xyz - c) W1 in one pass on the vector units (tl_l1_forward_kernel, no P)
+            int np = 0;
+            if (int rc = launch_l1_forward(rows, gd, group, L, nullptr, reinterpret_cast<double *>(base + pl.stats[l]), st, &np)) return rc;
+            if (int rc = launch(tl_bn_finalize_kernel, dim3((unsigned)((L.cout + 7) / 8)), dim3(256), 0, st,
+                                reinterpret_cast<const double *>(base + pl.stats[l]), np, L.cout, (double)rows, L.gamma,
                                 L.beta, L.running_mean, L.running_var, L.momentum, L.eps, L.save)) return rc;
             continue;
         }
@@ -1851,6 +1990,7 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
     hipStream_t st = as_stream(stream);
     char *base = static_cast<char *>(ws);
     const bool per_point = group && l1_per_point(nlayers, widths, &gd);
+    const bool coords_only = group && l1_coords_only(nlayers, widths, &gd);
     const bool want_dx = group ? ((per_point ? grad_points : grad_feat_rows) && group->points && group->cfeat > 0) : grad_x != nullptr;
     const bool ztop = !top_stored(rows, nlayers, widths, pool_rows);     // pooled top layer without z_L (tl_top_mats_kernel)
     for (int l = 0; l < nlayers; ++l)
@@ -1955,6 +2095,11 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
             float *tmp = gcur; gcur = gnext; gnext = tmp;
             continue;
         }
+        if (l == 0 && coords_only) {
+            // ---- a level without features: the first layer's weight gradient is dW1x, one pass over dy_1 and z_1
+            if (int rc = launch_l1_dz(rows, gd, group, L, gcur, coef, reinterpret_cast<float *>(base + pl.l1part), false, st)) return rc;
+            break;
+        }
         if (l == 0 && per_point) {
             // ---- layer 1 once per point (see tl_l1_forward_kernel): dz_1 and dW1x in one pass over the rows, the scatter of
             // dz_1 onto the points, then two GEMMs over the b n points
@@ -1962,17 +2107,7 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
             const long long bn = (long long)gd.b * gd.n;
             float *S = reinterpret_cast<float *>(base + pl.l1p), *part = reinterpret_cast<float *>(base + pl.l1part);
             float *ident = reinterpret_cast<float *>(base + pl.l1coef);
-            TlL1 q;
-            memset(&q, 0, sizeof(q));
-            q.rows = rows; q.n = gd.n; q.m = gd.m; q.nsample = gd.nsample; q.C = L.cout;
-            q.xyz = group->xyz; q.new_xyz = group->new_xyz; q.idx = group->idx;
-            q.z = L.z; q.g = gcur; q.coef = coef; q.part = part;
-            const int rpb = 256 / (L.cout / 4);
-            long long blocks = (rows + rpb - 1) / rpb;
-            if (blocks > kMaxParts) blocks = kMaxParts;
-            if (int rc = launch(tl_l1_dz_kernel, dim3((unsigned)blocks), dim3(256), 0, st, q)) return rc;
-            if (int rc = launch(tl_l1_wx_reduce_kernel, dim3((unsigned)((3 * L.cout + 127) / 128)), dim3(128), 0, st, (const float *)part,
-                                (int)blocks, L.cout, L.grad_weight + gt.xyz_off * L.w_stride_k, L.w_stride_k, L.w_stride_n)) return rc;
+            if (int rc = launch_l1_dz(rows, gd, group, L, gcur, coef, part, true, st)) return rc;
             if (int rc = pn2_group_point_grad_seg(gd.b, gd.n, L.cout, gd.m, gd.nsample, gcur, group->idx, S, base + pl.l1seg,
                                                   reproducible, stream)) return rc;
             if (int rc = launch(tl_identity_coef_kernel, dim3((unsigned)((3 * L.cout + 127) / 128)), dim3(128), 0, st, L.cout, ident)) return rc;

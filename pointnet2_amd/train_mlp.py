@@ -58,9 +58,7 @@ def stack_supported(net, rows, pool_rows=0, grouped=True):
     for conv, bn in pairs:
         if conv.out_channels % 4 or bn.momentum is None or not bn.affine:
             return False
-    if not grouped and pairs[0][0].in_channels % 4:
-        return False
-    return True
+    return True                    # plain rows of a width that is no multiple of 4 are zero-padded by fp_mlp_train
 
 
 class _Level:
@@ -73,9 +71,10 @@ def _layer_array(level, weights, biases, gammas, betas, zs, saves, grads=None, u
     arr = (BnLayer * n)()
     for l, (conv, bn) in enumerate(level.pairs):
         L = arr[l]
-        L.cin, L.cout = conv.in_channels, conv.out_channels
+        cin = weights[l].shape[1]                                  # conv.in_channels, or its zero-padded width (fp_mlp_train)
+        L.cin, L.cout = cin, conv.out_channels
         L.weight = ptr(weights[l])
-        L.w_stride_k, L.w_stride_n = 1, conv.in_channels          # conv kernel (cout, cin, 1[, 1]): W[k][n] = weight[n][k]
+        L.w_stride_k, L.w_stride_n = 1, cin                        # conv kernel (cout, cin, 1[, 1]): W[k][n] = weight[n][k]
         L.bias = ptr(biases[l])
         L.gamma, L.beta = ptr(gammas[l]), ptr(betas[l])
         track = update_running and bn.track_running_stats and bn.running_mean is not None
@@ -127,7 +126,7 @@ class _TrainMLP(torch.autograd.Function):
         gammas, betas = [params[4 * l + 2] for l in range(n)], [params[4 * l + 3] for l in range(n)]
         dev = weights[0].device
         rows = level.rows
-        widths = [level.pairs[0][0].in_channels] + [c.out_channels for c, _ in level.pairs]
+        widths = [weights[0].shape[1]] + [c.out_channels for c, _ in level.pairs]
         warr = (ctypes.c_int * len(widths))(*widths)
         keep_top = bool(_C.lib().pn2_mlp_train_top_stored(rows, n, warr, level.pool_rows))
         # pre-norm tensors z_l, the only activations kept; the pooled top layer's is not even written on large levels
@@ -285,5 +284,15 @@ def fp_mlp_train(net, x):
     lv.b, lv.n, lv.m, lv.nsample = b, n, 0, 0
     lv.rows, lv.pool_rows = b * n, 0
     require(stack_supported(net, lv.rows, 0, False), "unsupported stack for the fused training path")
-    out = _TrainMLP.apply(lv, x.reshape(b * n, c), *_params(pairs))
+    require(pairs[0][0].in_channels == c, "the first layer expects %d channels, got %d" % (pairs[0][0].in_channels, c))
+    params = _params(pairs)
+    x = x.reshape(b * n, c)
+    if c % 4:
+        # the kernels read rows 16 bytes at a time: zero columns up to a multiple of 4 on the input and on the first
+        # layer's weight (autograd slices both gradients back); part_seg's last level has 128 + 6 channels
+        pad = 4 - c % 4
+        x = torch.nn.functional.pad(x, (0, pad))
+        w = params[0]
+        params[0] = torch.nn.functional.pad(w, (0, 0) * (w.dim() - 2) + (0, pad))
+    out = _TrainMLP.apply(lv, x, *params)
     return out.view(b, n, -1)

@@ -33,11 +33,13 @@ run_stats overlap $B --path overlap
 run_shapes bw_probe python $ROOT/scripts/bw_probe.py
 run_shapes config_shapes python $ROOT/scripts/config_shapes.py
 export PN2_TRAIN_BENCH_KERNEL_ONLY=1
-run_shapes train_levels python $ROOT/scripts/train_mlp_bench.py
-run_stats train_metric python $ROOT/scripts/train_mlp_bench.py metric
+# one kernel-stats pass per training LEVEL (a step is ~30 different kernels, so a level is a process, not a run of launches)
+for lv in "metric" "cls_ssg SA1" "cls_ssg SA2" "cls_msg SA1" "cls_msg SA2" "sem_seg SA1" "sem_seg SA2" "sem_seg SA4" "group_all" "FP sem_seg" "FP part_seg"; do
+    run_stats "train_$(echo $lv | tr ' ' '_')" python $ROOT/scripts/train_mlp_bench.py "$lv"
+done
 run_pmc ov_fetch FETCH_SIZE $BQ --path overlap
 run_pmc ov_write WRITE_SIZE $BQ --path overlap
 run_pmc train_fetch FETCH_SIZE python $ROOT/scripts/train_mlp_bench.py metric
 run_pmc train_write WRITE_SIZE python $ROOT/scripts/train_mlp_bench.py metric
-rm -rf "$OUT"/ops "$OUT"/overlap "$OUT"/bw_probe "$OUT"/config_shapes "$OUT"/train_levels "$OUT"/train_metric "$OUT"/pmc_*/
+rm -rf "$OUT"/ops "$OUT"/overlap "$OUT"/bw_probe "$OUT"/config_shapes "$OUT"/train_*/ "$OUT"/pmc_*/
 ls -la "$OUT"

@@ -29,6 +29,7 @@ KERNEL_CASES = [
     ("I odd cin 29 feats", dict(b=2, n=256, m=32, ns=32, cfeat=29, widths=[64, 64, 128])),
     ("J plain three layers", dict(b=2, n=2048, m=0, ns=0, cfeat=0, widths=[128, 128, 128], plain_cin=128)),
     ("K msg order c32 ns64", dict(b=4, n=256, m=32, ns=64, cfeat=32, widths=[64, 64, 128], xyz_first=False)),
+    ("L plain cin 134 (part_seg FP3: zero-padded to 136)", dict(b=2, n=2048, m=0, ns=0, cfeat=0, widths=[128, 128], plain_cin=134)),
 ]
 
 # the reference configurations' own level shapes (BASELINE.json configs 2 and 5)
