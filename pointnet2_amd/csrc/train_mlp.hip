@@ -1194,7 +1194,7 @@ __global__ __launch_bounds__(256) void tl_top_mats_kernel(const float *__restric
 __global__ __launch_bounds__(256) void tl_top_wgrad_fix_kernel(const double *__restrict__ sf, int ld, int K, int NF, int goff, int hoff,
                                                                const float *__restrict__ w, long long sk, long long sn,
                                                                const float *__restrict__ coef, const float *__restrict__ bias,
-                                                               float *__restrict__ gw)
+                                                               float *__restrict__ gw, const double *__restrict__ S)
 {
     const long long total = (long long)K * NF;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -1209,7 +1209,130 @@ __global__ __launch_bounds__(256) void tl_top_wgrad_fix_kernel(const double *__r
         for (; j < K; ++j) a4[0] += row[goff + j] * (double)w[j * sk + n * sn];
         const double acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         const double c0 = coef[NF + n], c1 = coef[2 * NF + n], b = bias ? (double)bias[n] : 0.0;
-        gw[k * sk + n * sn] = (float)(row[n] - c1 * acc - row[hoff] * (c0 + b * c1));
+        gw[k * sk + n * sn] = (float)((S ? S[i] : row[n]) - c1 * acc - row[hoff] * (c0 + b * c1));      // S: (K, NF) of tl_top_s_kernel
+    }
+}
+
+// ---- the ROUTED part of that weight gradient on the vector units ----------------------------------------------------------
+// S = h^T (s dy_L), and dy_L has one non-zero per group and channel (the pooled sample):
+//     S[k][c] = sum over the groups g of   h[row(g, argsel[g][c])][k] * s_c gq[g][c]
+// -- C_L K multiply-adds per GROUP instead of per row. As tiles of the dense kernel (tl_wgrad_kernel, K_FILL units) the
+// routed gradient was 2/3 of its operand tiles and matrix-core work (312 us at the metric shape, instruction-bound).
+// A workgroup of eight waves stages the h rows of GB groups in LDS (relu(a z + c) applied on the way in; the next
+// batch's rows are in flight in registers meanwhile); a wave owns 64 channels x KC inputs of S in registers, a lane = a
+// channel: it reads the KC values of ITS pooled sample's row (ds_read_b128) and scales them. One (K, C_L) partial per
+// workgroup, summed in fp64 afterwards (tl_wgrad_reduce_a_kernel + tl_top_s_reduce_kernel).
+struct TlTopS {
+    long long groups;
+    int ns, K, NF, GB, ld;                  // rows per group, input / output channels, groups per batch, LDS row pitch (floats)
+    const float *z, *pa, *pc;               // z_{L-1} (rows, K) and the coefficients of h = relu(pa z + pc)
+    const float *gq;                        // (groups, NF) routed gradient
+    const int *argsel;                      // (groups, NF) pooled sample of the group
+    const float *coef;                      // s (NF)
+    float *partial;                         // (gridDim.x, K, NF)
+};
+constexpr int kTopSThreads = 512, kTopSGroups = 8;
+
+template <int KC, int NLD>
+__global__ __launch_bounds__(kTopSThreads, (KC <= 16 && NLD <= 4) ? 4 : 2) void tl_top_s_kernel(const TlTopS p)
+{
+    extern __shared__ __attribute__((aligned(16))) float tops_lds[];
+    float *coefs = tops_lds, *tile = tops_lds + 2 * p.K;            // [pa | pc], then GB x ns rows of ld floats
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kchunks = p.K / KC, nitems = ((p.NF + 63) / 64) * kchunks, item = blockIdx.y * 8 + wave;
+    const bool work = item < nitems;
+    const int cc = work ? item / kchunks : 0, kc = work ? item - cc * kchunks : 0, c = cc * 64 + lane;
+    const bool cok = work && c < p.NF;
+    const float sc = cok ? p.coef[c] : 0.0f;
+    for (int i = threadIdx.x; i < p.K; i += kTopSThreads) { coefs[i] = p.pa[i]; coefs[p.K + i] = p.pc[i]; }
+    float acc[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) acc[k] = 0.0f;
+    const int k4row = p.K / 4;
+    const long long nb = (p.groups + p.GB - 1) / p.GB;
+    float4 raw[NLD];
+    int an[kTopSGroups];
+    float vn[kTopSGroups];
+    auto fetch = [&](long long batch) {                          // rows of a batch are one contiguous range of z
+        const long long g0 = batch * p.GB;
+        const int ng = batch < nb ? (int)(p.groups - g0 < p.GB ? p.groups - g0 : p.GB) : 0;
+        const int total4 = ng * p.ns * k4row;
+        const float *src = p.z + (size_t)g0 * p.ns * p.K;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = threadIdx.x + i * kTopSThreads;
+            raw[i] = e < total4 ? ld4(src + (size_t)e * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int gi = 0; gi < kTopSGroups; ++gi) {
+            const bool ok = cok && gi < ng;
+            const size_t o = (size_t)(g0 + gi) * p.NF + c;
+            an[gi] = ok ? p.argsel[o] : 0;
+            vn[gi] = ok ? __fmul_rn(sc, p.gq[o]) : 0.0f;
+        }
+    };
+    fetch(blockIdx.x);
+    __syncthreads();                                               // coefs
+    for (long long batch = blockIdx.x; batch < nb; batch += gridDim.x) {
+        const int total4 = p.GB * p.ns * k4row;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = threadIdx.x + i * kTopSThreads;
+            if (e < total4) {
+                const int row = e / k4row, k = (e - row * k4row) * 4;
+                const float4 a = *reinterpret_cast<const float4 *>(coefs + k), b = *reinterpret_cast<const float4 *>(coefs + p.K + k);
+                float4 h;
+                h.x = vmax(__fadd_rn(__fmul_rn(a.x, raw[i].x), b.x), 0.0f);
+                h.y = vmax(__fadd_rn(__fmul_rn(a.y, raw[i].y), b.y), 0.0f);
+                h.z = vmax(__fadd_rn(__fmul_rn(a.z, raw[i].z), b.z), 0.0f);
+                h.w = vmax(__fadd_rn(__fmul_rn(a.w, raw[i].w), b.w), 0.0f);
+                *reinterpret_cast<float4 *>(tile + (size_t)row * p.ld + k) = h;
+            }
+        }
+        int ac[kTopSGroups];
+        float vc[kTopSGroups];
+#pragma unroll
+        for (int gi = 0; gi < kTopSGroups; ++gi) { ac[gi] = an[gi]; vc[gi] = vn[gi]; }
+        __syncthreads();
+        fetch(batch + gridDim.x);                                  // in flight under the multiply-adds
+        if (work) {
+#pragma unroll
+            for (int gi = 0; gi < kTopSGroups; ++gi) {
+                if (gi < p.GB) {
+                    const float *hr = tile + (size_t)(gi * p.ns + ac[gi]) * p.ld + kc * KC;
+#pragma unroll
+                    for (int k4 = 0; k4 < KC / 4; ++k4) {
+                        const float4 h = *reinterpret_cast<const float4 *>(hr + 4 * k4);
+                        acc[4 * k4] = fmaf(vc[gi], h.x, acc[4 * k4]);
+                        acc[4 * k4 + 1] = fmaf(vc[gi], h.y, acc[4 * k4 + 1]);
+                        acc[4 * k4 + 2] = fmaf(vc[gi], h.z, acc[4 * k4 + 2]);
+                        acc[4 * k4 + 3] = fmaf(vc[gi], h.w, acc[4 * k4 + 3]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (cok) {
+        float *dst = p.partial + ((size_t)blockIdx.x * p.K + (size_t)kc * KC) * p.NF + c;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) dst[(size_t)k * p.NF] = acc[k];
+    }
+}
+
+// S (K, NF) fp64 = sum of `nparts` fp32 partials
+__global__ __launch_bounds__(256) void tl_top_s_reduce_kernel(const float *__restrict__ in, int nparts, long long total,
+                                                              double *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        int q = 0;
+        for (; q + 4 <= nparts; q += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += (double)in[(size_t)(q + u) * total + i];
+        }
+        for (; q < nparts; ++q) a[0] += (double)in[(size_t)q * total + i];
+        out[i] = (a[0] + a[1]) + (a[2] + a[3]);
     }
 }
 
@@ -1296,8 +1419,11 @@ __global__ __launch_bounds__(kL1Threads) void tl_l1_forward_kernel(const TlL1 p)
         if (p.bias) { const float4 b = ld4(p.bias + col); b4[0] = b.x; b4[1] = b.y; b4[2] = b.z; b4[3] = b.w; }
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    const unsigned rows = (unsigned)p.rows, stride = gridDim.x * (unsigned)rpb;
-    for (unsigned base = blockIdx.x * (unsigned)rpb + rl; base < rows; base += kL1U * stride) {
+    // a workgroup walks ONE contiguous range of rows, a batch = kL1U consecutive slices of rpb rows (whole 32 KB runs of z)
+    const unsigned rows = (unsigned)p.rows, stride = (unsigned)rpb, span = kL1U * stride;
+    const unsigned chunk = (rows + gridDim.x * span - 1) / (gridDim.x * span) * span;
+    const unsigned first = blockIdx.x * chunk, stop = first + chunk < rows ? first + chunk : rows;
+    for (unsigned base = first + rl; base < stop; base += span) {
         const L1Rows r = l1_rows(p, base, stride, rows);
         float x[kL1U][3];
         float4 pp[kL1U];
@@ -1347,8 +1473,11 @@ __global__ __launch_bounds__(kL1Threads) void tl_l1_dz_kernel(const TlL1 p)
     const float4 s4 = ld4(p.coef + col), c04 = ld4(p.coef + p.C + col), c14 = ld4(p.coef + 2 * p.C + col);
     const float s[4] = {s4.x, s4.y, s4.z, s4.w}, c0[4] = {c04.x, c04.y, c04.z, c04.w}, c1[4] = {c14.x, c14.y, c14.z, c14.w};
     float acc[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    const unsigned rows = (unsigned)p.rows, stride = gridDim.x * (unsigned)rpb;
-    for (unsigned base = blockIdx.x * (unsigned)rpb + rl; base < rows; base += kL1U * stride) {
+    // a workgroup walks ONE contiguous range of rows, a batch = kL1U consecutive slices of rpb rows (whole 32 KB runs of z)
+    const unsigned rows = (unsigned)p.rows, stride = (unsigned)rpb, span = kL1U * stride;
+    const unsigned chunk = (rows + gridDim.x * span - 1) / (gridDim.x * span) * span;
+    const unsigned first = blockIdx.x * chunk, stop = first + chunk < rows ? first + chunk : rows;
+    for (unsigned base = first + rl; base < stop; base += span) {
         const L1Rows r = l1_rows(p, base, stride, rows);
         float x[kL1U][3];
         float4 g4[kL1U], z4[kL1U];
@@ -1505,6 +1634,7 @@ struct TlPlan {
     size_t ga, gb;              // backward: dy ping-pong (rows, max width)
     size_t partial, partial2;   // backward: weight-gradient partial sums
     size_t topw, topsf;         // backward, pooled top layer without z_L: stacked fp32 weight + constant row; [S | G | sumh] fp64
+    size_t tops_part, tops_part2, tops64;   // ... its routed part on the vector units: partials (two stages), S (K, C_L) fp64
     size_t l1p;                 // layer 1 per point: forward P (b n, cout_1); backward S (b n, cout_1)
     size_t l1seg, l1part, l1coef;   // backward: scratch of the segmented reduction, dW1x partials (256, 3, cout_1), identity coefficients
     size_t total;
@@ -1531,6 +1661,52 @@ static bool l1_per_point(int nlayers, const int *widths, const GroupDims *g)
     const int c1 = widths[1];
     if (g->cfeat < 8 || g->cfeat % 4 || ((long long)g->b * g->n) % 32 || c1 % 4 || c1 / 4 > 256 || 256 % (c1 / 4)) return false;
     return widths[0] == 3 + g->cfeat;
+}
+
+// launch shape of tl_top_s_kernel (ok = false: the dense kernel takes the routed gradient as operand tiles)
+struct TopSShape { bool ok; int GB, KC, NLD, ld, gridx, gridy, nchunks; size_t lds, part_bytes, part2_bytes; };
+
+static TopSShape top_s_shape(long long rows, int pool_rows, int K, int NF)
+{
+    TopSShape t;
+    memset(&t, 0, sizeof(t));
+    if (!pool_rows || K % 4) return t;
+    {
+        // measured (scripts/lab_ab.sh PN2_TL_TOP_SPARSE): 3-12 % of a level's backward from 0.26 M rows x 128 inputs up,
+        // nothing or a few microseconds lost below (sem_seg's levels) -- there the extra launches cost what the tiles saved
+        const int mode = env_int("PN2_TL_TOP_SPARSE", -1);        // lab switch: 0 never, 1 whenever the shape allows
+        if (mode == 0 || (mode < 0 && rows * K < (1ll << 24))) return t;
+    }
+    const long long per_group = (long long)pool_rows * K;           // floats of one group's input rows
+    if (per_group > 16384) return t;                               // eight 16-byte loads per thread at most
+    t.ld = K + 4;                                                  // rows 16 bytes apart in the banks
+    const size_t group_lds = (size_t)pool_rows * t.ld * 4;
+    int gb = (int)(8192 / per_group);                              // four loads per thread when a group allows (registers: two
+    if (gb < 1) gb = 1;                                            // workgroups per CU), eight for the largest groups
+    if (gb > kTopSGroups) gb = kTopSGroups;
+    while (gb > 1 && (size_t)gb * group_lds > ((size_t)64 << 10)) --gb;
+    t.GB = gb;
+    t.lds = (size_t)2 * K * 4 + (size_t)gb * group_lds;
+    if (t.lds > ((size_t)144 << 10)) return t;
+    const int per_thread = (int)((gb * per_group / 4 + kTopSThreads - 1) / kTopSThreads);
+    t.NLD = per_thread <= 1 ? 1 : per_thread <= 2 ? 2 : per_thread <= 4 ? 4 : 8;
+    const int nchunk = (NF + 63) / 64;
+    t.KC = 4;
+    for (int kc = 64; kc >= 4; kc /= 2)                            // the widest strip of inputs that still gives eight waves work
+        if (K % kc == 0 && nchunk * (K / kc) >= 6) { t.KC = kc; break; }
+    const int items = nchunk * (K / t.KC);
+    t.gridy = (items + 7) / 8;
+    const long long groups = rows / pool_rows, nb = (groups + gb - 1) / gb;
+    long long gx = ((long long)32 << 20) / ((long long)K * NF * 4);  // at most 32 MB of partial sums ...
+    if (gx < 128) gx = 128;                                        // ... but half the chip at least
+    if (gx > 512) gx = 512;
+    if (gx > nb) gx = nb;
+    t.gridx = (int)gx;
+    t.nchunks = gx > 32 ? (int)((gx + 31) / 32) : 0;
+    t.part_bytes = (size_t)gx * K * NF * 4;
+    t.part2_bytes = (size_t)t.nchunks * K * NF * 4;
+    t.ok = true;
+    return t;
 }
 
 // Is this a grouped level WITHOUT features whose first layer (a contraction of the three coordinates) runs on the vector
@@ -1585,6 +1761,11 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
                 if (w.partial_bytes > p1) p1 = w.partial_bytes;
                 if (w.partial2_bytes > p2) p2 = w.partial2_bytes;
             }
+            if (zt) {                                              // without the routed tiles (tl_top_s_kernel takes them)
+                const WgradShape w = wgrad_shape(rows, widths[l], top_cols(widths[l], 0));
+                if (w.partial_bytes > p1) p1 = w.partial_bytes;
+                if (w.partial2_bytes > p2) p2 = w.partial2_bytes;
+            }
         }
         if (l1_per_point(nlayers, widths, gd)) {                  // dW1f = points^T S over the b n points
             const WgradShape w = wgrad_shape((long long)gd->b * gd->n, gd->cfeat, widths[1]);
@@ -1597,6 +1778,12 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
             const int kin = widths[nlayers - 1];
             pl.topw = off; off = align_up(off + sizeof(float) * (size_t)(tiles(cl) * 32 + kin + 1) * kin);
             pl.topsf = off; off = align_up(off + sizeof(double) * (size_t)kin * top_cols(kin, cl));
+            const TopSShape ts = top_s_shape(rows, pool_rows, kin, cl);
+            if (ts.ok) {
+                pl.tops_part = off; off = align_up(off + ts.part_bytes);
+                pl.tops_part2 = off; off = align_up(off + ts.part2_bytes);
+                pl.tops64 = off; off = align_up(off + sizeof(double) * (size_t)kin * cl);
+            }
         }
     }
     if (l1_per_point(nlayers, widths, gd)) {
@@ -1748,6 +1935,47 @@ static int launch_wgrad(TlWgrad &p, const WgradShape &w, float *partial2, const 
     const long long total = (long long)p.KI * p.NO;
     return launch(tl_wgrad_reduce_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, nw, w.tus, w.tts, w.tslabs,
                   p.KI, p.NO, L.grad_weight, L.w_stride_k, L.w_stride_n, plain);
+}
+
+template <int KC>
+static int launch_top_s_kc(const TlTopS &p, const TopSShape &t, hipStream_t st)
+{
+    const dim3 grid((unsigned)t.gridx, (unsigned)t.gridy);
+#define PN2_TS_CASE(N)                                                              \
+    if (t.NLD == N) {                                                               \
+        auto kern = tl_top_s_kernel<KC, N>;                                         \
+        if (int rc = allow_dynamic_lds(kern, t.lds)) return rc;                     \
+        return launch(kern, grid, dim3(kTopSThreads), t.lds, st, p);                \
+    }
+    PN2_TS_CASE(1) PN2_TS_CASE(2) PN2_TS_CASE(4) PN2_TS_CASE(8)
+#undef PN2_TS_CASE
+    return PN2_E_ARG;
+}
+
+// S (K, NF) fp64 = h^T (s dy_L) through the pooled samples (tl_top_s_kernel + the two reduction stages)
+static int launch_top_s(TlTopS &p, const TopSShape &t, float *part2, double *s64, hipStream_t st)
+{
+    p.GB = t.GB; p.ld = t.ld;
+    int rc = t.KC == 64 ? launch_top_s_kc<64>(p, t, st) : t.KC == 32 ? launch_top_s_kc<32>(p, t, st)
+           : t.KC == 16 ? launch_top_s_kc<16>(p, t, st) : t.KC == 8 ? launch_top_s_kc<8>(p, t, st) : launch_top_s_kc<4>(p, t, st);
+    if (rc) return rc;
+    const long long total = (long long)p.K * p.NF;
+    const float *src = p.partial;
+    int nparts = t.gridx;
+    if (t.nchunks) {
+        const long long e4 = total / 4;
+        long long bx = (e4 + 255) / 256;
+        if (bx > 64) bx = 64;
+        rc = launch(tl_wgrad_reduce_a_kernel, dim3((unsigned)bx, (unsigned)t.nchunks, 1u), dim3(256), 0, st,
+                    reinterpret_cast<const float4 *>(p.partial), reinterpret_cast<float4 *>(part2), (long long)t.gridx, 32,
+                    (long long)t.nchunks, e4);
+        if (rc) return rc;
+        src = part2;
+        nparts = t.nchunks;
+    }
+    long long blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    return launch(tl_top_s_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, nparts, total, s64);
 }
 
 static bool layers_ok(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group, int *widths)
@@ -2055,23 +2283,37 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
                                     K, NF, NFp, (const float *)coef, L.bias, wp, rowc)) return rc;
             }
             {
+                // weight gradient: the routed part S on the vector units (tl_top_s_kernel) when its shape allows, the Gram
+                // matrix h^T h and the column sums of h from the dense kernel, combined by tl_top_wgrad_fix_kernel
+                const TopSShape ts = top_s_shape(rows, pool_rows, K, NF);
+                double *s64 = ts.ok ? reinterpret_cast<double *>(base + pl.tops64) : nullptr;
+                if (ts.ok) {
+                    TlTopS q;
+                    memset(&q, 0, sizeof(q));
+                    q.groups = rows / pool_rows; q.ns = pool_rows; q.K = K; q.NF = NF;
+                    q.z = D.z; q.pa = D.save + 2 * D.cout; q.pc = D.save + 3 * D.cout;
+                    q.gq = gq; q.argsel = argsel; q.coef = coef;
+                    q.partial = reinterpret_cast<float *>(base + pl.tops_part);
+                    if (int rc = launch_top_s(q, ts, reinterpret_cast<float *>(base + pl.tops_part2), s64, st)) return rc;
+                }
+                const int tfw = ts.ok ? 0 : tf, ldw = ts.ok ? top_cols(K, 0) : ld;       // operand tiles of the dense kernel
                 TlWgrad w;
                 memset(&w, 0, sizeof(w));
                 w.rows = rows;
                 w.KI = K;
                 w.amode = A_RELU; w.A = D.z; w.pa = D.save + 2 * D.cout; w.pc = D.save + 3 * D.cout;
                 w.dmode = A_FILL;
-                w.NO = ld; w.tf = tf; w.NF = NF;
+                w.NO = ldw; w.tf = tfw; w.NF = ts.ok ? 0 : NF;
                 w.G = gq; w.argsel = argsel; w.coef = coef; w.group_rows = pool_rows;
                 w.partial = reinterpret_cast<float *>(base + pl.partial);
-                const WgradShape ws_ = wgrad_shape(rows, K, ld);
+                const WgradShape ws_ = wgrad_shape(rows, K, ldw);
                 w.xshare = ws_.uslabs == 1;
                 if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, st, sf)) return rc;
                 long long blocks = ((long long)K * NF + 255) / 256;
                 if (blocks > 4096) blocks = 4096;
-                if (int rc = launch(tl_top_wgrad_fix_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const double *)sf, ld, K, NF, NFp,
-                                    NFp + tiles(K) * 32, L.weight, L.w_stride_k, L.w_stride_n, (const float *)coef, L.bias,
-                                    L.grad_weight)) return rc;
+                if (int rc = launch(tl_top_wgrad_fix_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const double *)sf, ldw, K, NF,
+                                    tfw * 32, tfw * 32 + tiles(K) * 32, L.weight, L.w_stride_k, L.w_stride_n, (const float *)coef,
+                                    L.bias, L.grad_weight, (const double *)s64)) return rc;
             }
             {
                 const GemmShape g = gemm_shape(rows, NFp + K, K);

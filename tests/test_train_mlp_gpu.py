@@ -50,6 +50,18 @@ def test_train_stack_matches_float64(cuda, name, kw):
     assert worst <= TOL, "%s: worst relative error %.2e" % (name, worst)
 
 
+# the pooled top layer without its pre-norm tensor, its routed gradient on the vector units (tl_top_s_kernel): the size
+# rules switch both on for big levels only, so the small shapes force them -- one case per (inputs per wave, loads per
+# thread) variant of the kernel, plus group_all's shape, which falls back to the dense tiles (128 x 512 inputs per group)
+@pytest.mark.parametrize("name,kw", [c for c in KERNEL_CASES if c[0][0] in "ABCDEGHK"], ids=[c[0] for c in KERNEL_CASES if c[0][0] in "ABCDEGHK"])
+def test_routed_top_gradient_variants(cuda, monkeypatch, name, kw):
+    from scripts import train_mlp_check as T
+    monkeypatch.setenv("PN2_TL_TOP_STORED", "0")
+    monkeypatch.setenv("PN2_TL_TOP_SPARSE", "1")
+    worst = T.run_case(name, **kw)
+    assert worst <= TOL, "%s: worst relative error %.2e" % (name, worst)
+
+
 def _clone_module(mod):
     import copy
     return copy.deepcopy(mod)
