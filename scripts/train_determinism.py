@@ -1,0 +1,80 @@
+"""Is the fused training path bit-reproducible call to call? Runs fuzz cases of tests/test_train_fuzz_gpu.py twice in one
+process (fresh modules, same seeded inputs) and compares every saved tensor and every gradient bit for bit.
+usage: python scripts/train_determinism.py [seed ...]"""
+import importlib.util
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pointnet2_amd import train_mlp  # noqa: E402
+from pointnet2_amd.pointnet_util import _SharedMLP  # noqa: E402
+
+spec = importlib.util.spec_from_file_location("fz", os.path.join(ROOT, "tests", "test_train_fuzz_gpu.py"))
+fz = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(fz)
+dev = torch.device("cuda:0")
+
+
+def run(seed, kw):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    plain, group_all = kw.get("plain_cin", 0), kw.get("group_all", False)
+    b, n, m, ns, cfeat, widths = kw["b"], kw["n"], kw["m"], kw["ns"], kw["cfeat"], kw["widths"]
+    cin = plain if plain else 3 + cfeat
+    torch.manual_seed(seed)
+    net = _SharedMLP(cin, widths, bn=True).to(dev).train()
+    if plain:
+        x = torch.randn((b, n, cin), generator=g).to(dev).requires_grad_(True)
+        out = train_mlp.fp_mlp_train(net.net, x)
+        leaf = x
+    else:
+        xyz = torch.rand((b, n, 3), generator=g).to(dev)
+        pts = torch.randn((b, n, cfeat), generator=g).to(dev).requires_grad_(True) if cfeat else None
+        if group_all:
+            new_xyz = idx = None
+        else:
+            new_xyz = xyz[:, :m].contiguous()
+            idx = torch.randint(0, n, (b, m, ns), generator=g, dtype=torch.int32).to(dev)
+            idx[:, :, ns // 2:] = idx[:, :, :1]
+        out, _ = train_mlp.sa_mlp_train(net.net, xyz, new_xyz, pts, idx, kw.get("xyz_first", True))
+        leaf = pts
+    node = out.grad_fn
+    while node is not None and type(node).__name__ != "_TrainMLPBackward":
+        node = node.next_functions[0][0]
+    saved = [t.clone() for t in node.saved_tensors]
+    gw = torch.randn(out.shape, generator=g).to(dev)
+    (out * gw).sum().backward()
+    grads = [p.grad.clone() for p in net.parameters()] + ([leaf.grad.clone()] if leaf is not None else [])
+    torch.cuda.synchronize()
+    return [out.detach().clone()] + saved, grads
+
+
+def main():
+    seeds = [int(a) for a in sys.argv[1:]] or [182, 11, 270, 293, 448, 551, 0, 1, 2, 3]
+    for seed in seeds:
+        kw, env = fz._case(seed)
+        for k in ("PN2_TL_TOP_STORED", "PN2_TL_TOP_SPARSE", "PN2_TL_L1_PER_POINT", "PN2_TL_L1_COORDS", "PN2_TL_FORCE_STREAM"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        runs = []
+        for rep in range(3):
+            junk = torch.full((64 << 20,), float(rep + 1) * 1e30, device=dev)       # dirty the allocator's free blocks
+            del junk
+            runs.append(run(seed, kw))
+        report = []
+        for rep in (1, 2):
+            for kind, a_list, b_list in (("saved", runs[0][0], runs[rep][0]), ("grad", runs[0][1], runs[rep][1])):
+                for i, (a, b2) in enumerate(zip(a_list, b_list)):
+                    if a.dtype.is_floating_point:
+                        d = float((a.double() - b2.double()).abs().max())
+                        if d != 0.0:
+                            report.append("%s[%d] shape %s maxdiff %.3e (scale %.3e)" % (kind, i, tuple(a.shape), d, float(a.abs().max())))
+                    elif not torch.equal(a, b2):
+                        report.append("%s[%d] ints differ" % (kind, i))
+        print("seed %d %s %s: %s" % (seed, kw, env, "bit-identical x3" if not report else "; ".join(sorted(set(report)))), flush=True)
+
+
+if __name__ == "__main__":
+    main()
