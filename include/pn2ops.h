@@ -339,6 +339,8 @@ typedef struct pn2_bn_layer {
     float *save;                   /* (4, cout): batch mean, 1/sqrt(var+eps), a = gamma*invstd, c = beta - a*mean */
     float *grad_weight;            /* backward: same strides as weight */
     float *grad_gamma, *grad_beta; /* backward: (cout) */
+    int grad_accumulate;           /* backward: 0 = the three gradients are written, 1 = ADDED to what the buffers hold (one fp32
+                                      add per element, as a framework's own accumulation into .grad would do) */
 } pn2_bn_layer;
 
 /* pool_rows: 0 = no pooling, out is (rows, cout_L) = relu(bn(z_L)); else the group size (nsample: 16 or a multiple of

@@ -676,7 +676,7 @@ __global__ __launch_bounds__(256) void tl_bn_finalize_kernel(const double *__res
 __global__ __launch_bounds__(256) void tl_bn_backward_finalize_kernel(const double *__restrict__ stats, int nparts, int N,
                                                                       double count, const float *__restrict__ gamma,
                                                                       const float *__restrict__ save, float *__restrict__ grad_gamma,
-                                                                      float *__restrict__ grad_beta, float *__restrict__ coef)
+                                                                      float *__restrict__ grad_beta, float *__restrict__ coef, int accumulate)
 {
     double s1, s2;
     tl_sum_parts(stats, nparts, N, s1, s2);
@@ -687,8 +687,8 @@ __global__ __launch_bounds__(256) void tl_bn_backward_finalize_kernel(const doub
     const double s = (double)gamma[c] * invstd;
     const double c1 = s * dgamma * invstd / count;
     const double c0 = s * dbeta / count - c1 * mean;
-    if (grad_gamma) grad_gamma[c] = (float)dgamma;
-    if (grad_beta) grad_beta[c] = (float)dbeta;
+    if (grad_gamma) grad_gamma[c] = accumulate ? __fadd_rn(grad_gamma[c], (float)dgamma) : (float)dgamma;
+    if (grad_beta) grad_beta[c] = accumulate ? __fadd_rn(grad_beta[c], (float)dbeta) : (float)dbeta;
     coef[c] = (float)s;
     coef[N + c] = (float)c0;
     coef[2 * N + c] = (float)c1;
@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(256) void tl_wgrad_reduce_a_kernel(const float4 *__
 // stage B: fp64 sum over the remaining partials, written with the caller's weight strides
 __global__ __launch_bounds__(256) void tl_wgrad_reduce_b_kernel(const float *__restrict__ in, long long nw, int TU, int TT,
                                                                 int tslabs, int KI, int NO, float *__restrict__ gw,
-                                                                long long sk, long long sn, double *__restrict__ plain)
+                                                                long long sk, long long sn, double *__restrict__ plain, int accumulate)
 {
     const long long total = (long long)KI * NO;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -1140,7 +1140,7 @@ __global__ __launch_bounds__(256) void tl_wgrad_reduce_b_kernel(const float *__r
         double sum = 0.0;
         for (long long w = 0; w < nw; ++w) sum += (double)in[(slab * nw + w) * e + off];
         if (plain) plain[i] = sum;                                 // (KI, NO) row-major fp64, for the pooled top layer's fix-up
-        else gw[k * sk + n * sn] = (float)sum;
+        else gw[k * sk + n * sn] = accumulate ? __fadd_rn(gw[k * sk + n * sn], (float)sum) : (float)sum;
     }
 }
 
@@ -1194,7 +1194,7 @@ __global__ __launch_bounds__(256) void tl_top_mats_kernel(const float *__restric
 __global__ __launch_bounds__(256) void tl_top_wgrad_fix_kernel(const double *__restrict__ sf, int ld, int K, int NF, int goff, int hoff,
                                                                const float *__restrict__ w, long long sk, long long sn,
                                                                const float *__restrict__ coef, const float *__restrict__ bias,
-                                                               float *__restrict__ gw, const double *__restrict__ S)
+                                                               float *__restrict__ gw, const double *__restrict__ S, int accumulate)
 {
     const long long total = (long long)K * NF;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -1209,7 +1209,8 @@ __global__ __launch_bounds__(256) void tl_top_wgrad_fix_kernel(const double *__r
         for (; j < K; ++j) a4[0] += row[goff + j] * (double)w[j * sk + n * sn];
         const double acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         const double c0 = coef[NF + n], c1 = coef[2 * NF + n], b = bias ? (double)bias[n] : 0.0;
-        gw[k * sk + n * sn] = (float)((S ? S[i] : row[n]) - c1 * acc - row[hoff] * (c0 + b * c1));      // S: (K, NF) of tl_top_s_kernel
+        const float gv = (float)((S ? S[i] : row[n]) - c1 * acc - row[hoff] * (c0 + b * c1));
+        gw[k * sk + n * sn] = accumulate ? __fadd_rn(gw[k * sk + n * sn], gv) : gv;      // S: (K, NF) of tl_top_s_kernel
     }
 }
 
@@ -1525,7 +1526,7 @@ __global__ __launch_bounds__(kL1Threads) void tl_l1_dz_kernel(const TlL1 p)
 // A block of 256 threads owns 8 of the 3 C sums and adds the partial rows 32 at a time (a thread per sum walking all
 // 256 rows was 60 us of dependent L2 latencies).
 __global__ __launch_bounds__(256) void tl_l1_wx_reduce_kernel(const float *__restrict__ part, int nparts, int C, float *__restrict__ gw,
-                                                              long long sk, long long sn)
+                                                              long long sk, long long sn, int accumulate)
 {
     __shared__ double sh[32][8];
     const int g = threadIdx.x >> 3, cl = threadIdx.x & 7, i = blockIdx.x * 8 + cl;
@@ -1539,7 +1540,7 @@ __global__ __launch_bounds__(256) void tl_l1_wx_reduce_kernel(const float *__res
 #pragma unroll
     for (int r = 0; r < 32; ++r) sum += sh[r][cl];
     const int k = i / C, col = i - k * C;
-    gw[k * sk + col * sn] = (float)sum;
+    gw[k * sk + col * sn] = accumulate ? __fadd_rn(gw[k * sk + col * sn], (float)sum) : (float)sum;
 }
 
 __global__ void tl_identity_coef_kernel(int C, float *__restrict__ coef)       // dz = 1 * g - 0 - 0 * z
@@ -1934,7 +1935,7 @@ static int launch_wgrad(TlWgrad &p, const WgradShape &w, float *partial2, const 
     }
     const long long total = (long long)p.KI * p.NO;
     return launch(tl_wgrad_reduce_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, nw, w.tus, w.tts, w.tslabs,
-                  p.KI, p.NO, L.grad_weight, L.w_stride_k, L.w_stride_n, plain);
+                  p.KI, p.NO, L.grad_weight, L.w_stride_k, L.w_stride_n, plain, L.grad_accumulate);
 }
 
 template <int KC>
@@ -2080,7 +2081,7 @@ static int launch_l1_dz(long long rows, const GroupDims &gd, const pn2_group_src
     if (int rc = store ? launch(tl_l1_dz_kernel<true>, dim3((unsigned)blocks), dim3(kL1Threads), 0, st, q)
                        : launch(tl_l1_dz_kernel<false>, dim3((unsigned)blocks), dim3(kL1Threads), 0, st, q)) return rc;
     return launch(tl_l1_wx_reduce_kernel, dim3((unsigned)((3 * L.cout + 7) / 8)), dim3(256), 0, st, (const float *)part, (int)blocks,
-                  L.cout, L.grad_weight + gt.xyz_off * L.w_stride_k, L.w_stride_k, L.w_stride_n);
+                  L.cout, L.grad_weight + gt.xyz_off * L.w_stride_k, L.w_stride_k, L.w_stride_n, L.grad_accumulate);
 }
 }  // namespace pn2
 
@@ -2268,7 +2269,7 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
         float *coef = reinterpret_cast<float *>(base + pl.coef[l]);
         if (int rc = launch(tl_bn_backward_finalize_kernel, dim3((unsigned)((L.cout + 7) / 8)), dim3(256), 0, st,
                             reinterpret_cast<const double *>(base + pl.stats[l]), nparts[l], L.cout, (double)rows, L.gamma,
-                            (const float *)L.save, L.grad_gamma, L.grad_beta, coef)) return rc;
+                            (const float *)L.save, L.grad_gamma, L.grad_beta, coef, L.grad_accumulate)) return rc;
         const bool pooled_top = pool_rows && l == nlayers - 1;
         if (pooled_top && ztop) {
             // ---- the pooled top layer in terms of its input h = relu(a z_{l-1} + c): see tl_top_mats_kernel
@@ -2313,7 +2314,7 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
                 if (blocks > 4096) blocks = 4096;
                 if (int rc = launch(tl_top_wgrad_fix_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const double *)sf, ldw, K, NF,
                                     tfw * 32, tfw * 32 + tiles(K) * 32, L.weight, L.w_stride_k, L.w_stride_n, (const float *)coef,
-                                    L.bias, L.grad_weight, (const double *)s64)) return rc;
+                                    L.bias, L.grad_weight, (const double *)s64, L.grad_accumulate)) return rc;
             }
             {
                 const GemmShape g = gemm_shape(rows, NFp + K, K);

@@ -39,7 +39,8 @@ import json, sys
 for l in open(sys.argv[1]):
     r = json.loads(l)
     f, u = r["fused"], r["layer_by_layer"]
-    print("%-50s layer by layer %6.2f + %6.2f = %6.2f ms | fused %6.2f + %6.2f = %6.2f ms | x%.2f" % (r["model"][:50], u["forward_ms"], u["backward_ms"], u["step_ms"], f["forward_ms"], f["backward_ms"], f["step_ms"], r["speedup"]))
+    d = r.get("fused_direct", f)
+    print("%-50s layer by layer %6.2f + %6.2f = %6.2f ms | fused %6.2f + %6.2f = %6.2f ms x%.2f | gradients added in the kernels %6.2f ms x%.2f" % (r["model"][:50], u["forward_ms"], u["backward_ms"], u["step_ms"], f["forward_ms"], f["backward_ms"], f["step_ms"], r["speedup"], d["step_ms"], r.get("speedup_direct", 0.0)))
 PY
     ;;
     trainrccl) timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 scripts/train_step_bench.py sem_seg --steps 8 --fused-only 2> "$OUT/train_rccl.err" | grep "^{" > "$OUT/train_step_rccl.jsonl"; cat "$OUT/train_step_rccl.jsonl" | cut -c1-400

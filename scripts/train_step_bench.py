@@ -20,7 +20,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from model_forward_bench import ClsMSG, ClsSSG, PartSeg, SemSeg, set_fused
-from pointnet2_amd import sharding
+from pointnet2_amd import sharding, train_mlp
 from pointnet2_amd import synthetic as S
 
 
@@ -139,7 +139,11 @@ def main():
         g = torch.Generator(device="cpu").manual_seed(5 + rank)
         labels = (torch.randint(0, 40, (b,), generator=g) if kind == "cls" else torch.randint(0, 21, (b, n), generator=g)).to(dev)
         grads = {}
-        for fused in ([True] if args.fused_only else [False, True]):
+        # three variants: the layer-by-layer path, the fused nodes, and the fused nodes adding their parameter gradients
+        # straight into the bucket's views (train_mlp.set_accumulate_into_grad: no `grad += new` launches by autograd)
+        variants = [("layer_by_layer", False, False), ("fused", True, False), ("fused_direct", True, True)]
+        for key, fused, direct in (variants[1:] if args.fused_only else variants):
+            train_mlp.set_accumulate_into_grad(direct)
             model = ctor().to(dev)
             model.load_state_dict(state)
             model.train()
@@ -151,24 +155,27 @@ def main():
             set_bn_momentum(model, bn_momentum(0, b * world))
             loss0 = F.cross_entropy(model(x), labels)
             loss0.backward()
-            grads[fused] = (float(loss0), bucket.flat.clone())
+            grads[key] = (float(loss0), bucket.flat.clone())
             del loss0                                      # no reference to an old autograd graph may survive into a capture
             paths = [m.last_path for m in model.modules() if hasattr(m, "last_path")]
             ph, loss = run_steps(model, opt, bucket, x, labels, kind, args.steps, args.warmup, b * world)
-            key = "fused" if fused else "layer_by_layer"
             row[key] = {"forward_ms": round(float(ph[0]), 3), "backward_ms": round(float(ph[1]), 3),
                         "allreduce_ms": round(float(ph[2]), 3), "optimizer_ms": round(float(ph[3]), 3),
                         "step_ms": round(float(ph.sum()), 3), "loss": loss, "paths": paths,
                         "grad_floats": int(bucket.flat.numel())}
-            if fused and args.graph and not distributed:
+            if key == "fused" and args.graph and not distributed:
                 row["fused_graph"] = graph_step(model, opt, bucket, x, labels, args.steps)
             del model, opt, bucket
             torch.cuda.empty_cache()
-        if True in grads and False in grads:
-            (la, ga), (lb, gb) = grads[True], grads[False]
+        train_mlp.set_accumulate_into_grad(False)
+        if "fused" in grads and "layer_by_layer" in grads:
+            (la, ga), (lb, gb) = grads["fused"], grads["layer_by_layer"]
             row["loss_rel_diff"] = abs(la - lb) / max(1e-30, abs(lb))
             row["grad_rel_diff"] = float((ga - gb).norm() / gb.norm())
             row["speedup"] = round(row["layer_by_layer"]["step_ms"] / row["fused"]["step_ms"], 2)
+            row["speedup_direct"] = round(row["layer_by_layer"]["step_ms"] / row["fused_direct"]["step_ms"], 2)
+        if "fused" in grads and "fused_direct" in grads:
+            row["direct_grad_rel_diff"] = float((grads["fused_direct"][1] - grads["fused"][1]).norm() / grads["fused"][1].norm())
         if rank == 0:
             print(json.dumps(row), flush=True)
         results.append(row)

@@ -175,3 +175,33 @@ def test_fused_training_step_is_graph_capturable(cuda):
     assert torch.equal(out_g, out_e)
     for a, b in zip(grads_g, grads_e):
         assert float((a - b).abs().max()) <= 1e-6 * max(1e-30, float(b.abs().max()))
+
+
+def test_parameter_gradients_added_into_existing_grads(cuda):
+    """train_mlp.set_accumulate_into_grad: with `.grad` tensors in place (a gradient bucket's views) the backward kernels add
+    into them and autograd receives no parameter gradient; same numbers as the default path, twice in a row (accumulation)."""
+    import pointnet2_amd.pointnet_util as U
+    from pointnet2_amd import train_mlp
+    from pointnet2_amd.sharding import GradBucket
+    torch.manual_seed(3)
+    sa = U.PointnetSAModule(64, 128, 0.4, 32, [64, 64, 128]).to(cuda).train()
+    ref = _clone_module(sa)
+    xyz = torch.rand(4, 512, 3, device=cuda)
+    feats = torch.randn(4, 512, 64, device=cuda)
+    gw = torch.randn(4, 128, 128, device=cuda)
+    try:
+        bucket = GradBucket(sa.parameters())
+        bucket.zero_()
+        views = [p.grad.data_ptr() for p in sa.parameters()]
+        train_mlp.set_accumulate_into_grad(True)
+        for _ in range(2):                                      # two micro-batches into the same bucket
+            (sa(xyz, feats)[1] * gw).sum().backward()
+        assert sa.last_path == "fused_train"
+        assert [p.grad.data_ptr() for p in sa.parameters()] == views, "the .grad views were replaced"
+    finally:
+        train_mlp.set_accumulate_into_grad(False)
+    for _ in range(2):
+        (ref(xyz, feats)[1] * gw).sum().backward()
+    for (name, p), q in zip(sa.named_parameters(), ref.parameters()):
+        scale = float(q.grad.abs().max())
+        assert float((p.grad - q.grad).abs().max()) <= 1e-6 * max(scale, 1e-30), name
