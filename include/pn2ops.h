@@ -347,6 +347,14 @@ typedef struct pn2_bn_layer {
  * 32), out (rows/pool_rows, cout_L) = max over the group; argsel (same shape, i32) receives the sample number the
  * gradient flows to and zsel the selected pre-norm value (both needed by backward).
  * group != NULL: layer 1 reads the grouped rows; else x is the (rows, cin_1) input. */
+/* Organisation of the passes (csrc/train_mlp.hip) is chosen by size rules -- results never depend on it -- which these
+ * environment variables override for A/B timing and for the tests that force every variant (read at each call):
+ *   PN2_TL_TOP_STORED=0|1     keep / do not keep the pooled top layer's pre-norm tensor (default: kept below 32 MB)
+ *   PN2_TL_TOP_SPARSE=0|1     routed part of that layer's weight gradient on the vector units (default: from 2^24 row x inputs)
+ *   PN2_TL_L1_PER_POINT=0     never evaluate layer 1 once per point
+ *   PN2_TL_L1_COORDS=0        never run a feature-less level's layer 1 on the vector units
+ *   PN2_TL_FORCE_STREAM=1     weights streamed through LDS even where they would stay resident
+ *   PN2_TL_MAX_NS=1|2|4       cap on 32-column output tiles per wave;  PN2_TL_NT=0|1  non-temporal stores never / always */
 long long pn2_mlp_train_ws_bytes(long long rows, int nlayers, const int *widths /* cin_1, cout_1 .. cout_L */,
                                  int pool_rows, int backward,
                                  const int *group_dims /* grouped input: {b, n, m, nsample, cfeat, idx != NULL}; else NULL */);
