@@ -335,8 +335,8 @@ typedef struct pn2_bn_layer {
     const float *gamma, *beta;     /* batch-norm scale / offset (cout) */
     float *running_mean, *running_var;   /* (cout), updated in place with `momentum`; NULL: not tracked */
     float momentum, eps;           /* torch convention: new = (1-momentum)*old + momentum*batch; momentum = 1 - bn_decay */
-    float *z;                      /* (rows, cout) pre-norm output, written by forward, read by backward */
-    float *save;                   /* (4, cout): batch mean, 1/sqrt(var+eps), a = gamma*invstd, c = beta - a*mean */
+    float *z;                      /* (rows, cout) pre-norm tensor h W (WITHOUT the bias, which batch norm cancels), written by forward, read by backward */
+    float *save;                   /* (4, cout): batch mean of z (= the layer's batch mean - bias), 1/sqrt(var+eps), a = gamma*invstd, c = beta - a*mean */
     float *grad_weight;            /* backward: same strides as weight */
     float *grad_gamma, *grad_beta; /* backward: (cout) */
     int grad_accumulate;           /* backward: 0 = the three gradients are written, 1 = ADDED to what the buffers hold (one fp32

@@ -650,7 +650,7 @@ __device__ __forceinline__ void tl_sum_parts(const double *__restrict__ stats, i
 __global__ __launch_bounds__(256) void tl_bn_finalize_kernel(const double *__restrict__ stats, int nparts, int N, double count,
                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
                                                              float *running_mean, float *running_var, float momentum, float eps,
-                                                             float *__restrict__ save)
+                                                             float *__restrict__ save, const float *__restrict__ bias)
 {
     double s1, s2;
     tl_sum_parts(stats, nparts, N, s1, s2);
@@ -665,7 +665,8 @@ __global__ __launch_bounds__(256) void tl_bn_finalize_kernel(const double *__res
     save[N + c] = (float)invstd;
     save[2 * N + c] = (float)a;
     save[3 * N + c] = (float)((double)beta[c] - a * mean);
-    if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+    // the stored pre-norm tensor is h W WITHOUT the conv bias (see pn2_mlp_train_forward): the layer's batch mean is mean + b
+    if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * (mean + (bias ? (double)bias[c] : 0.0)));
     if (running_var) {
         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
         running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
@@ -2056,7 +2057,7 @@ static int launch_l1_forward(long long rows, const GroupDims &gd, const pn2_grou
     q.rows = rows; q.n = gd.n; q.m = gd.m; q.nsample = gd.nsample; q.C = L.cout;
     q.xyz = group->xyz; q.new_xyz = group->new_xyz; q.idx = group->idx; q.P = P;
     q.wx = L.weight + gt.xyz_off * L.w_stride_k; q.skx = L.w_stride_k; q.sn = L.w_stride_n;
-    q.bias = L.bias; q.z = L.z;
+    q.bias = nullptr; q.z = L.z;                  // no conv bias in the stored tensor (pn2_mlp_train_forward)
     q.stats = stats;
     const int rpb = kL1Threads / (L.cout / 4);
     long long blocks = (rows + (long long)rpb * kL1U - 1) / ((long long)rpb * kL1U);
@@ -2121,6 +2122,10 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
         }
         if (int rc = launch_pack_jobs(jobs, nj, st)) return rc;
     }
+    // The conv bias is NOT added to the pre-norm tensors: batch normalisation removes any per-channel constant, so
+    // z_l := h W_l gives the same output, the same gradients (the bias gradient is zero) and the same batch variance; only
+    // the batch MEAN that enters the running average is mean(z_l) + b_l (tl_bn_finalize_kernel). It is more than a saved
+    // add: the folded form a z + c loses accuracy with |mean| / std of a channel, and a bias is pure mean.
     for (int l = 0; l < nlayers; ++l) {
         const pn2_bn_layer &L = layers[l];
         const GemmShape g = gemm_shape(rows, L.cin, L.cout);
@@ -2145,7 +2150,7 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
             if (int rc = launch_l1_forward(rows, gd, group, L, P, reinterpret_cast<double *>(base + pl.stats[l]), st, &np)) return rc;
             if (int rc = launch(tl_bn_finalize_kernel, dim3((unsigned)((L.cout + 7) / 8)), dim3(256), 0, st,
                                 reinterpret_cast<const double *>(base + pl.stats[l]), np, L.cout, (double)rows, L.gamma,
-                                L.beta, L.running_mean, L.running_var, L.momentum, L.eps, L.save)) return rc;
+                                L.beta, L.running_mean, L.running_var, L.momentum, L.eps, L.save, L.bias)) return rc;
             continue;
         }
         if (l == 0 && coords_only) {
@@ -2154,7 +2159,7 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
             if (int rc = launch_l1_forward(rows, gd, group, L, nullptr, reinterpret_cast<double *>(base + pl.stats[l]), st, &np)) return rc;
             if (int rc = launch(tl_bn_finalize_kernel, dim3((unsigned)((L.cout + 7) / 8)), dim3(256), 0, st,
                                 reinterpret_cast<const double *>(base + pl.stats[l]), np, L.cout, (double)rows, L.gamma,
-                                L.beta, L.running_mean, L.running_var, L.momentum, L.eps, L.save)) return rc;
+                                L.beta, L.running_mean, L.running_var, L.momentum, L.eps, L.save, L.bias)) return rc;
             continue;
         }
         TlGemm p;
@@ -2165,7 +2170,7 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
         else if (l == 0) { amode = A_PLAIN; p.A = x; }
         else { amode = A_RELU; p.A = layers[l - 1].z; p.p0 = layers[l - 1].save + 2 * layers[l - 1].cout; p.p1 = layers[l - 1].save + 3 * layers[l - 1].cout; }
         p.wpacked = reinterpret_cast<const u32x4 *>(base + pl.pack[l]);
-        p.bias = L.bias;
+        p.bias = nullptr;                                        // see the comment above the loop
         p.emode = (last && pool_rows) ? E_POOL : E_STORE;
         p.out = (last && !keep_top) ? nullptr : L.z;              // the pooled top layer of a large level is never written
         p.stats = reinterpret_cast<double *>(base + pl.stats[l]);
@@ -2181,7 +2186,7 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
         if (int rc = launch_gemm(amode, p, g, st, &nparts)) return rc;
         if (int rc = launch(tl_bn_finalize_kernel, dim3((unsigned)((L.cout + 7) / 8)), dim3(256), 0, st,
                             reinterpret_cast<const double *>(base + pl.stats[l]), nparts, L.cout, (double)rows, L.gamma, L.beta,
-                            L.running_mean, L.running_var, L.momentum, L.eps, L.save)) return rc;
+                            L.running_mean, L.running_var, L.momentum, L.eps, L.save, L.bias)) return rc;
         if (last && pool_rows) {
             const long long groups = rows / pool_rows;
             const int prow = pool_rows == 16 ? 16 : 32;
@@ -2281,7 +2286,7 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
                 long long blocks = ((long long)(NFp + K + 1) * K + 255) / 256;
                 if (blocks > 4096) blocks = 4096;
                 if (int rc = launch(tl_top_mats_kernel, dim3((unsigned)blocks), dim3(256), 0, st, L.weight, L.w_stride_k, L.w_stride_n,
-                                    K, NF, NFp, (const float *)coef, L.bias, wp, rowc)) return rc;
+                                    K, NF, NFp, (const float *)coef, (const float *)nullptr, wp, rowc)) return rc;    // z_L = h W: no bias term
             }
             {
                 // weight gradient: the routed part S on the vector units (tl_top_s_kernel) when its shape allows, the Gram
@@ -2314,7 +2319,7 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
                 if (blocks > 4096) blocks = 4096;
                 if (int rc = launch(tl_top_wgrad_fix_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const double *)sf, ldw, K, NF,
                                     tfw * 32, tfw * 32 + tiles(K) * 32, L.weight, L.w_stride_k, L.w_stride_n, (const float *)coef,
-                                    L.bias, L.grad_weight, (const double *)s64, L.grad_accumulate)) return rc;
+                                    (const float *)nullptr, L.grad_weight, (const double *)s64, L.grad_accumulate)) return rc;
             }
             {
                 const GemmShape g = gemm_shape(rows, NFp + K, K);

@@ -157,7 +157,7 @@ def run_case(name, b, n, m, ns, cfeat, widths, xyz_first=True, group_all=False, 
             "pool_gap": diag["pool_gap"]}
     for l in range(nl):
         if zsaved[l] is not None:
-            errs["z%d" % (l + 1)] = rel(zsaved[l], zs64[l])
+            errs["z%d" % (l + 1)] = rel(zsaved[l], zs64[l] - params64[l][1].detach())      # stored without the conv bias
     (want * gw.double()).sum().backward()
     (out.reshape(want.shape) * gw).sum().backward(retain_graph=True)
     torch.cuda.synchronize()
