@@ -41,5 +41,10 @@ run_pmc ov_fetch FETCH_SIZE $BQ --path overlap
 run_pmc ov_write WRITE_SIZE $BQ --path overlap
 run_pmc train_fetch FETCH_SIZE python $ROOT/scripts/train_mlp_bench.py metric
 run_pmc train_write WRITE_SIZE python $ROOT/scripts/train_mlp_bench.py metric
+# instruction mix of the training kernels at the metric shape (two more separate counter passes)
+if [ -z "${PN2_PROFILE_SKIP_SQ:-}" ]; then
+run_pmc train_sq "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" python $ROOT/scripts/train_mlp_bench.py metric
+run_pmc train_sq2 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY" python $ROOT/scripts/train_mlp_bench.py metric
+fi
 rm -rf "$OUT"/ops "$OUT"/overlap "$OUT"/bw_probe "$OUT"/config_shapes "$OUT"/train_*/ "$OUT"/pmc_*/
 ls -la "$OUT"
