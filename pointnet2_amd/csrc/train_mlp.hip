@@ -464,14 +464,13 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
             const bool ok = eactive && col < p.N;
             const int voff = (4 * hl * p.N + col) * 4;
             if (p.emode == E_STORE || p.emode == E_POOL) {
-                const float bias = ep0[t];
+                // (no bias: the pre-norm tensors are stored without it, pn2_mlp_train_forward; ep0 is 0 in these modes)
                 float s1 = 0.0f, s2 = 0.0f;
-                f32x16 val;
+                const f32x16 &val = acc[t];
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
-                    val[v] = __fadd_rn(acc[t][v], bias);
                     s1 = __fadd_rn(s1, val[v]);
-                    s2 = __fadd_rn(s2, __fmul_rn(val[v], val[v]));
+                    s2 = fmaf(val[v], val[v], s2);
                 }
                 if (ok && !(p.lab & 2)) {
                     sd1[t] += (double)s1;
@@ -540,7 +539,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
                         if (p.nt) bstore<true>(g, ro, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
                         else bstore<false>(g, ro, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
                         s1 = __fadd_rn(s1, g);
-                        s2 = __fadd_rn(s2, __fmul_rn(g, zz[v]));
+                        s2 = fmaf(g, zz[v], s2);
                     }
                     sd1[t] += (double)s1;
                     sd2[t] += (double)s2;
