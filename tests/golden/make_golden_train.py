@@ -1,0 +1,128 @@
+"""Generates tests/golden/train_fp64.npz: known-answer vectors for the TRAINING entry points (pn2_mlp_train_forward /
+pn2_mlp_train_backward): a float64 numpy evaluation (oracle/train_stack.py) of the reference's graph piece --
+utils/pointnet_util.py:44-50, :113-127 (SA level), :222-226 (FP level), batch statistics tf_util.py:512-531 -- on
+geometry produced by the oracle (farthest_point_sample, gather_point, query_ball_point). CPU only:
+
+    python tests/golden/make_golden_train.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import oracle as O  # noqa: E402
+from oracle import train_stack as T  # noqa: E402
+from pointnet2_amd import synthetic as S  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+MOMENTUM, EPS = 0.1, 1e-3
+
+
+def make_layers(rng, cin, widths):
+    layers = []
+    for w in widths:
+        layers.append({"W": (rng.standard_normal((cin, w)) / np.sqrt(cin)).astype(np.float32),
+                       "b": np.zeros(w, np.float32),                       # tf_util.py:174-175: biases start at 0 (and stay there under BN)
+                       "gamma": (0.5 + rng.random(w)).astype(np.float32) * np.where(rng.random(w) < 0.15, -1, 1).astype(np.float32),
+                       "beta": (0.2 * rng.standard_normal(w)).astype(np.float32),
+                       "running_mean": rng.standard_normal(w).astype(np.float32),
+                       "running_var": (0.5 + rng.random(w)).astype(np.float32)})
+        cin = w
+    return layers
+
+
+def margin(cache):
+    """How far the case is from a decision an fp32 evaluation could take differently: the smallest |y| of any ReLU input and
+    the smallest gap between a group's pooled value and its runner-up (distinct values), both relative to the layer's
+    scale. An fp32 evaluation of these stacks is within ~1e-6 of the scale (tests/test_train_fuzz_gpu.py), so a case with
+    margin >= 5e-6 has the same piecewise-linear piece in fp32 and in float64, and its gradients are comparable."""
+    m = np.inf
+    for C in cache["layers"]:
+        y = C["y"]
+        m = min(m, float(np.abs(y).min() / np.abs(y).max()))
+    if cache["pool"]:
+        h = cache["h_out"]
+        g = h.reshape(-1, cache["pool"], h.shape[1])
+        top = g.max(axis=1)
+        second = np.where(g < top[:, None, :], g, -np.inf).max(axis=1)
+        gap = np.where(top > 0, top - second, np.inf)
+        m = min(m, float(gap.min() / np.abs(h).max()))
+    return m
+
+
+def pack(prefix, d, arrays):
+    for k, v in arrays.items():
+        d["%s/%s" % (prefix, k)] = v
+
+
+def sa_case(d, name, rng, b, n, m, radius, ns, cfeat, widths, seed, xyz_first=True):
+    xyz = S.sphere_clouds(b, n, seed)
+    new_xyz = O.gather_point(xyz, O.farthest_point_sample(m, xyz))
+    idx, _ = O.query_ball_point(radius, ns, xyz, new_xyz)
+    pts = rng.standard_normal((b, n, cfeat)).astype(np.float32) if cfeat else None
+    rows = T.group_rows(xyz, new_xyz, pts, idx, xyz_first)
+    for attempt in range(200):                                  # weights re-drawn until no decision is at rounding level
+        layers = make_layers(rng, 3 + cfeat, widths)
+        out, cache = T.forward(rows, layers, ns, MOMENTUM, EPS)
+        if margin(cache) >= 5e-6:
+            break
+    else:
+        raise RuntimeError("no well-separated case found")
+    print("%-14s margin %.1e after %d draw(s)" % (name, margin(cache), attempt + 1))
+    gw = rng.standard_normal(out.shape).astype(np.float32)
+    grad_rows, grads = T.backward(gw, layers, cache)
+    arrays = {"xyz": xyz, "new_xyz": new_xyz, "idx": idx.astype(np.int32), "grad_out": gw, "out": out,
+              "meta": np.array([b, n, m, ns, cfeat, int(xyz_first), len(widths)] + list(widths), np.int64)}
+    if cfeat:
+        arrays["points"] = pts
+        arrays["grad_points"] = T.scatter_feature_grad(grad_rows, idx, n, cfeat, xyz_first)
+    for l, (L, C, G) in enumerate(zip(layers, cache["layers"], grads)):
+        for k in ("W", "b", "gamma", "beta", "running_mean", "running_var"):
+            arrays["l%d_%s" % (l, k)] = L[k]
+        arrays["l%d_new_running_mean" % l] = C["running_mean"]
+        arrays["l%d_new_running_var" % l] = C["running_var"]
+        for k in ("dW", "dgamma", "dbeta"):
+            arrays["l%d_%s" % (l, k)] = G[k]
+    pack(name, d, arrays)
+
+
+def fp_case(d, name, rng, b, n, cin, widths):
+    x = rng.standard_normal((b, n, cin)).astype(np.float32)
+    for attempt in range(200):
+        layers = make_layers(rng, cin, widths)
+        out, cache = T.forward(x.reshape(b * n, cin), layers, 0, MOMENTUM, EPS)
+        if margin(cache) >= 5e-6:
+            break
+    else:
+        raise RuntimeError("no well-separated case found")
+    print("%-14s margin %.1e after %d draw(s)" % (name, margin(cache), attempt + 1))
+    gw = rng.standard_normal(out.shape).astype(np.float32)
+    grad_rows, grads = T.backward(gw, layers, cache)
+    arrays = {"x": x, "grad_out": gw, "out": out, "grad_x": grad_rows.reshape(b, n, cin),
+              "meta": np.array([b, n, 0, 0, cin, 1, len(widths)] + list(widths), np.int64)}
+    for l, (L, C, G) in enumerate(zip(layers, cache["layers"], grads)):
+        for k in ("W", "b", "gamma", "beta", "running_mean", "running_var"):
+            arrays["l%d_%s" % (l, k)] = L[k]
+        arrays["l%d_new_running_mean" % l] = C["running_mean"]
+        arrays["l%d_new_running_var" % l] = C["running_var"]
+        for k in ("dW", "dgamma", "dbeta"):
+            arrays["l%d_%s" % (l, k)] = G[k]
+    pack(name, d, arrays)
+
+
+def main():
+    rng = np.random.default_rng(20260921)
+    d = {}
+    sa_case(d, "sa_xyz", rng, 2, 256, 32, 0.4, 32, 0, [32, 32, 64], 11)                      # first level of a network: no features
+    sa_case(d, "sa_feat", rng, 2, 256, 32, 0.4, 32, 16, [32, 32, 64], 12)                    # features: layer 1 once per point
+    sa_case(d, "sa_msg_order", rng, 2, 128, 16, 0.5, 16, 3, [16, 32], 13, xyz_first=False)   # MSG channel order, 16 samples, normals
+    fp_case(d, "fp_plain", rng, 2, 128, 40, [32, 32])                                        # feature-propagation stack on plain rows
+    path = os.path.join(OUT, "train_fp64.npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, "%.1f kB" % (os.path.getsize(path) / 1e3), "arrays:", len(d))
+
+
+if __name__ == "__main__":
+    main()
