@@ -304,14 +304,14 @@ def allreduce_leg(dev, dist, reps=20):
     for name, floats in GRAD_BUCKET_FLOATS.items():
         g = torch.ones((floats,), dtype=torch.float32, device=dev)
         for _ in range(3):
-            sharding.allreduce_mean_([g])
+            sharding.allreduce_mean_([g], force_collective=True)
         ts = []
         for _ in range(reps):
             dist.barrier()
             if dev.type == "cuda":
                 torch.cuda.synchronize()
             t0 = time.perf_counter()
-            sharding.allreduce_mean_([g])
+            sharding.allreduce_mean_([g], force_collective=True)
             if dev.type == "cuda":
                 torch.cuda.synchronize()
             ts.append(sharding.max_over_ranks(time.perf_counter() - t0, dev))

@@ -282,7 +282,7 @@ long long pn2_sample_and_group_status_offset(int b, int m);
  * sample-and-group launch (or, outside its envelope, pn2_farthest_point_sample_gather + pn2_query_ball_group_xyz) followed
  * by pn2_sa_mlp3_maxpool, enqueued by ONE call. ws_sample: pn2_sample_and_group_ws_bytes(b, m) bytes, handled as in
  * pn2_sample_and_group_xyz_gen (generation > 0: zeroed once by the caller, a fresh generation per call) or cleared here
- * (generation = 0); fps_temp: pn2_fps_temp_floats(b, n) floats or NULL when that is 0; ws_mlp: pn2_sa_mlp3_ws_bytes(...)
+ * (generation = 0); NULL: never the overlapped launch, always the two-launch path; fps_temp: pn2_fps_temp_floats(b, n) floats or NULL when that is 0; ws_mlp: pn2_sa_mlp3_ws_bytes(...)
  * bytes or NULL when that is 0; wpacked / bpacked from pn2_sa_mlp3_pack. Outputs as the two operators' (all required).
  * pn2_fp_level = pointnet_fp_module (:199-229): pn2_three_nn followed by pn2_fp_mlp (dist / idx are outputs too). */
 int pn2_sa_level(int b, int n, int m, float radius, int nsample, int cfeat, const float *xyz, const float *points,
@@ -341,20 +341,30 @@ typedef struct pn2_bn_layer {
     float *grad_gamma, *grad_beta; /* backward: (cout) */
     int grad_accumulate;           /* backward: 0 = the three gradients are written, 1 = ADDED to what the buffers hold (one fp32
                                       add per element, as a framework's own accumulation into .grad would do) */
+    int running_var_biased;        /* which batch variance enters running_var: 0 = the UNBIASED one, var * N / (N - 1)
+                                      (torch.nn.BatchNorm); 1 = the biased one (tf.contrib.layers.batch_norm as the reference
+                                      calls it, tf_util.py:512-531: the moving variance receives tf.nn.moments' variance) */
 } pn2_bn_layer;
 
 /* pool_rows: 0 = no pooling, out is (rows, cout_L) = relu(bn(z_L)); else the group size (nsample: 16 or a multiple of
  * 32), out (rows/pool_rows, cout_L) = max over the group; argsel (same shape, i32) receives the sample number the
  * gradient flows to and zsel the selected pre-norm value (both needed by backward).
  * group != NULL: layer 1 reads the grouped rows; else x is the (rows, cin_1) input. */
-/* Organisation of the passes (csrc/train_mlp.hip) is chosen by size rules -- results never depend on it -- which these
- * environment variables override for A/B timing and for the tests that force every variant (read at each call):
- *   PN2_TL_TOP_STORED=0|1     keep / do not keep the pooled top layer's pre-norm tensor (default: kept below 32 MB)
- *   PN2_TL_TOP_SPARSE=0|1     routed part of that layer's weight gradient on the vector units (default: from 2^24 row x inputs)
- *   PN2_TL_L1_PER_POINT=0     never evaluate layer 1 once per point
- *   PN2_TL_L1_COORDS=0        never run a feature-less level's layer 1 on the vector units
- *   PN2_TL_FORCE_STREAM=1     weights streamed through LDS even where they would stay resident
- *   PN2_TL_MAX_NS=1|2|4       cap on 32-column output tiles per wave;  PN2_TL_NT=0|1  non-temporal stores never / always */
+/* Organisation of the passes (csrc/train_mlp.hip) is chosen by size rules -- results never depend on it. The *_ex entry
+ * points take the rules' overrides as a per-call argument (A/B timing, and the tests that force every variant); the
+ * library reads no environment variable and keeps no mode. A zeroed struct (or opts == NULL) = every rule automatic. */
+enum { PN2_OPT_AUTO = 0, PN2_OPT_OFF = 1, PN2_OPT_ON = 2 };
+typedef struct pn2_train_opts {
+    int top_stored;                /* keep the pooled top layer's pre-norm tensor z_L (AUTO: kept below 32 MB) */
+    int top_sparse;                /* routed part of that layer's weight gradient on the vector units (AUTO: from 2^24 row x inputs) */
+    int l1_per_point;              /* layer 1 of a grouped level with features once per point (OFF: never) */
+    int l1_coords;                 /* layer 1 of a feature-less level on the vector units (OFF: never) */
+    int force_stream;              /* ON: weights streamed through LDS even where they would stay resident */
+    int max_ns;                    /* cap on 32-column output tiles per wave: 0 (= 4), 1, 2, 4 */
+    int nt;                        /* non-temporal stores: AUTO by size (outputs >= 128 MB), OFF never, ON always */
+    int fuse_wgrad;                /* weight gradient of a layer inside its data-gradient pass (one pass over the layer's
+                                      activations instead of two; AUTO: wherever the slab fits the registers), OFF: never */
+} pn2_train_opts;
 long long pn2_mlp_train_ws_bytes(long long rows, int nlayers, const int *widths /* cin_1, cout_1 .. cout_L */,
                                  int pool_rows, int backward,
                                  const int *group_dims /* grouped input: {b, n, m, nsample, cfeat, idx != NULL}; else NULL */);
@@ -377,6 +387,18 @@ int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_layer *laye
                            const float *x, int pool_rows, const float *out, const int *argsel, const float *zsel,
                            const float *grad_out, float *grad_x, float *grad_feat_rows, float *grad_points, int reproducible,
                            void *ws, void *stream);
+/* the same five entry points with the organisation overrides (the plain ones pass NULL) */
+long long pn2_mlp_train_ws_bytes_ex(long long rows, int nlayers, const int *widths, int pool_rows, int backward,
+                                    const int *group_dims, const pn2_train_opts *opts);
+int pn2_mlp_train_layer1_per_point_ex(int nlayers, const int *widths, const int *group_dims, const pn2_train_opts *opts);
+int pn2_mlp_train_top_stored_ex(long long rows, int nlayers, const int *widths, int pool_rows, const pn2_train_opts *opts);
+int pn2_mlp_train_forward_ex(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group,
+                             const float *x, int pool_rows, float *out, int *argsel, float *zsel, void *ws,
+                             const pn2_train_opts *opts, void *stream);
+int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group,
+                              const float *x, int pool_rows, const float *out, const int *argsel, const float *zsel,
+                              const float *grad_out, float *grad_x, float *grad_feat_rows, float *grad_points,
+                              int reproducible, void *ws, const pn2_train_opts *opts, void *stream);
 
 /* diagnostics: byte offsets inside the BACKWARD workspace of the two dy buffers ((rows, max width) each; after a
  * backward of L layers they hold dy_{L-1}, dy_{L-2}, ... alternately, starting with gb when pooled) and of the

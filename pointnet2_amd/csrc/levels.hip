@@ -14,10 +14,13 @@ extern "C" int pn2_sa_level(int b, int n, int m, float radius, int nsample, int 
 {
     // FPS + gather + ball query + grouping of xyz: the overlapped launch, or -- outside its envelope / on a device that
     // cannot hold every producer at once -- the two-launch path (bit-identical results)
-    int rc = generation ? pn2_sample_and_group_xyz_gen(b, n, m, radius, nsample, xyz, ws_sample, generation, fps_idx, new_xyz, idx,
-                                                       pts_cnt, grouped_xyz, 1, stream)
-                        : pn2_sample_and_group_xyz(b, n, m, radius, nsample, xyz, ws_sample, fps_idx, new_xyz, idx, pts_cnt,
-                                                   grouped_xyz, 1, stream);
+    // ws_sample == NULL: the caller does not want the overlapped launch (tf_grouping.set_overlapped_launch(False), the switch
+    // OverlappedLaunchError points at) -- straight to the two-launch path
+    int rc = !ws_sample ? PN2_E_TOO_LARGE
+             : generation ? pn2_sample_and_group_xyz_gen(b, n, m, radius, nsample, xyz, ws_sample, generation, fps_idx, new_xyz, idx,
+                                                         pts_cnt, grouped_xyz, 1, stream)
+                          : pn2_sample_and_group_xyz(b, n, m, radius, nsample, xyz, ws_sample, fps_idx, new_xyz, idx, pts_cnt,
+                                                     grouped_xyz, 1, stream);
     if (rc == PN2_E_TOO_LARGE) {
         rc = pn2_farthest_point_sample_gather(b, n, m, xyz, fps_temp, fps_idx, new_xyz, stream);
         if (rc) return rc;

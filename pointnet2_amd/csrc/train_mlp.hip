@@ -649,7 +649,7 @@ __device__ __forceinline__ void tl_sum_parts(const double *__restrict__ stats, i
 __global__ __launch_bounds__(256) void tl_bn_finalize_kernel(const double *__restrict__ stats, int nparts, int N, double count,
                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
                                                              float *running_mean, float *running_var, float momentum, float eps,
-                                                             float *__restrict__ save, const float *__restrict__ bias)
+                                                             float *__restrict__ save, const float *__restrict__ bias, int var_biased)
 {
     double s1, s2;
     tl_sum_parts(stats, nparts, N, s1, s2);
@@ -667,8 +667,9 @@ __global__ __launch_bounds__(256) void tl_bn_finalize_kernel(const double *__res
     // the stored pre-norm tensor is h W WITHOUT the conv bias (see pn2_mlp_train_forward): the layer's batch mean is mean + b
     if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * (mean + (bias ? (double)bias[c] : 0.0)));
     if (running_var) {
-        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+        // torch.nn.BatchNorm averages the UNBIASED batch variance, tf.contrib.layers.batch_norm (tf_util.py:512-531) the biased one
+        const double bv = (var_biased || count <= 1.0) ? var : var * count / (count - 1.0);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * bv);
     }
 }
 
@@ -1552,26 +1553,41 @@ __global__ void tl_identity_coef_kernel(int C, float *__restrict__ coef)       /
 // ---- host side -------------------------------------------------------------------------------------------------------------
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline int tiles(int c) { return (c + 31) / 32; }
-static inline int env_int(const char *name, int dflt)
+// The organisation overrides of a call (include/pn2ops.h: pn2_train_opts; NULL = every rule automatic). They travel as an
+// argument through every rule below: the library reads no environment variable and keeps no mode.
+typedef pn2_train_opts Opts;
+static inline Opts opts_of(const pn2_train_opts *o)
 {
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
+    Opts d;
+    memset(&d, 0, sizeof(d));
+    return o ? *o : d;
 }
-static inline int pick_ns(int tn)
+static inline int pick_ns(int tn, const Opts &o)
 {
-    const int cap = env_int("PN2_TL_MAX_NS", 4);          // lab switch (scripts/train_mlp_check.py); results never depend on it
+    const int cap = (o.max_ns == 1 || o.max_ns == 2) ? o.max_ns : 4;      // results never depend on it
     const int ns = tn >= 3 ? 4 : tn == 2 ? 2 : 1;
     return ns > cap ? cap : ns;
+}
+// CUs of the current device (partition modes expose fewer than 256); 256 when there is no device (host-side queries)
+static inline int device_cus()
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0) {
+        (void)hipGetLastError();
+        return 256;
+    }
+    return cus > 256 ? 256 : cus;
 }
 
 struct GemmShape { int K, N, tk, tn, ns, slabs, resident; size_t lds, pack_bytes; };
 
-static GemmShape gemm_shape(long long rows, int K, int N)
+static GemmShape gemm_shape(long long rows, int K, int N, const Opts &o)
 {
     GemmShape g;
     g.K = K; g.N = N;
     g.tk = tiles(K); g.tn = tiles(N);
-    g.ns = pick_ns(g.tn);
+    g.ns = pick_ns(g.tn, o);
     g.slabs = (g.tn + g.ns - 1) / g.ns;
     // few rows (group_all, the deep levels of the segmentation nets): a workgroup covers 256 rows of one column slab, so
     // narrower slabs are what spreads the pass over the chip -- the rows are re-read per slab, which is nothing here
@@ -1581,7 +1597,7 @@ static GemmShape gemm_shape(long long rows, int K, int N)
         g.slabs = (g.tn + g.ns - 1) / g.ns;
     }
     const size_t params = (size_t)3 * g.tk * 32 * sizeof(float), stage = (size_t)g.ns * kPairWords * 4;
-    g.resident = params + stage * g.tk <= (size_t)144 * 1024 && !env_int("PN2_TL_FORCE_STREAM", 0);
+    g.resident = params + stage * g.tk <= (size_t)144 * 1024 && o.force_stream != PN2_OPT_ON;
     g.lds = params + stage * (g.resident ? g.tk : 2);
     g.pack_bytes = (size_t)g.slabs * g.tk * g.ns * kPairWords * 4;
     return g;
@@ -1589,7 +1605,7 @@ static GemmShape gemm_shape(long long rows, int K, int N)
 
 struct WgradShape { int tus, tts, uslabs, tslabs, tpw, upw; long long gridx, nw, nchunks; size_t e, lds, partial_bytes, partial2_bytes; };
 
-static WgradShape wgrad_shape(long long rows, int KI, int NO, bool gather = false)
+static WgradShape wgrad_shape(long long rows, int KI, int NO, bool gather = false, int cus = 256)
 {
     WgradShape w;
     const int tu = tiles(KI), tt = tiles(NO);
@@ -1613,7 +1629,7 @@ static WgradShape wgrad_shape(long long rows, int KI, int NO, bool gather = fals
     w.upw = (2 * (w.tus + w.tts) + 7) / 8;
     const size_t slabs = (size_t)w.uslabs * w.tslabs;
     const long long blocks = rows / 32;
-    long long gx = 256 / (long long)slabs;                         // one workgroup per CU over all slabs
+    long long gx = cus / (long long)slabs;                         // one workgroup per CU over all slabs
     if (gx < 1) gx = 1;
     if (gx > (blocks + 3) / 4) gx = (blocks + 3) / 4;               // at least four row blocks per workgroup
     w.gridx = gx;
@@ -1643,10 +1659,10 @@ struct TlPlan {
 
 // Is the pooled top layer's pre-norm tensor z_L kept (small levels), or are the passes that would read it rewritten in
 // terms of the layer's input (tl_top_mats_kernel)? One rule for forward, backward and the caller's allocation.
-static bool top_stored(long long rows, int nlayers, const int *widths, int pool_rows)
+static bool top_stored(long long rows, int nlayers, const int *widths, int pool_rows, const Opts &o)
 {
     if (!pool_rows || nlayers < 2) return true;
-    if (env_int("PN2_TL_TOP_STORED", -1) >= 0) return env_int("PN2_TL_TOP_STORED", -1) != 0;      // lab switch
+    if (o.top_stored != PN2_OPT_AUTO) return o.top_stored == PN2_OPT_ON;
     return (size_t)rows * widths[nlayers] * sizeof(float) < ((size_t)32 << 20);
 }
 static inline int top_cols(int kin, int cl) { return tiles(cl) * 32 + tiles(kin) * 32 + 32; }
@@ -1656,9 +1672,9 @@ struct GroupDims { int b, n, m, nsample, cfeat, has_idx; };
 
 // Is layer 1 of this grouped level evaluated once per POINT (tl_l1_forward_kernel)? One rule for forward, backward, the
 // workspace sizes and the caller's allocation of the feature gradient.
-static bool l1_per_point(int nlayers, const int *widths, const GroupDims *g)
+static bool l1_per_point(int nlayers, const int *widths, const GroupDims *g, const Opts &o)
 {
-    if (!g || !g->has_idx || nlayers < 2 || env_int("PN2_TL_L1_PER_POINT", 1) == 0) return false;
+    if (!g || !g->has_idx || nlayers < 2 || o.l1_per_point == PN2_OPT_OFF) return false;
     const int c1 = widths[1];
     if (g->cfeat < 8 || g->cfeat % 4 || ((long long)g->b * g->n) % 32 || c1 % 4 || c1 / 4 > 256 || 256 % (c1 / 4)) return false;
     return widths[0] == 3 + g->cfeat;
@@ -1667,7 +1683,7 @@ static bool l1_per_point(int nlayers, const int *widths, const GroupDims *g)
 // launch shape of tl_top_s_kernel (ok = false: the dense kernel takes the routed gradient as operand tiles)
 struct TopSShape { bool ok; int GB, KC, NLD, ld, gridx, gridy, nchunks; size_t lds, part_bytes, part2_bytes; };
 
-static TopSShape top_s_shape(long long rows, int pool_rows, int K, int NF)
+static TopSShape top_s_shape(long long rows, int pool_rows, int K, int NF, const Opts &o)
 {
     TopSShape t;
     memset(&t, 0, sizeof(t));
@@ -1675,8 +1691,7 @@ static TopSShape top_s_shape(long long rows, int pool_rows, int K, int NF)
     {
         // measured (scripts/lab_ab.sh PN2_TL_TOP_SPARSE): 3-12 % of a level's backward from 0.26 M rows x 128 inputs up,
         // nothing or a few microseconds lost below (sem_seg's levels) -- there the extra launches cost what the tiles saved
-        const int mode = env_int("PN2_TL_TOP_SPARSE", -1);        // lab switch: 0 never, 1 whenever the shape allows
-        if (mode == 0 || (mode < 0 && rows * K < (1ll << 24))) return t;
+        if (o.top_sparse == PN2_OPT_OFF || (o.top_sparse == PN2_OPT_AUTO && rows * K < (1ll << 24))) return t;
     }
     const long long per_group = (long long)pool_rows * K;           // floats of one group's input rows
     if (per_group > 16384) return t;                               // eight 16-byte loads per thread at most
@@ -1712,15 +1727,15 @@ static TopSShape top_s_shape(long long rows, int pool_rows, int K, int NF)
 
 // Is this a grouped level WITHOUT features whose first layer (a contraction of the three coordinates) runs on the vector
 // units (tl_l1_forward_kernel with P == nullptr, tl_l1_dz_kernel<false>)? The first level of every reference network.
-static bool l1_coords_only(int nlayers, const int *widths, const GroupDims *g)
+static bool l1_coords_only(int nlayers, const int *widths, const GroupDims *g, const Opts &o)
 {
-    if (!g || !g->has_idx || g->cfeat != 0 || widths[0] != 3 || nlayers < 2 || env_int("PN2_TL_L1_COORDS", 1) == 0) return false;
+    if (!g || !g->has_idx || g->cfeat != 0 || widths[0] != 3 || nlayers < 2 || o.l1_coords == PN2_OPT_OFF) return false;
     const int c1 = widths[1];
     return c1 % 4 == 0 && c1 / 4 <= kL1Threads && kL1Threads % (c1 / 4) == 0;
 }
 
 static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_rows, int backward, TlPlan &pl,
-                    const GroupDims *gd = nullptr)
+                    const GroupDims *gd, const Opts &o)
 {
     if (rows <= 0 || rows % 32 || rows >= (1ll << 31) || nlayers < 1 || nlayers > 8) return false;
     if (pool_rows && pool_rows != 16 && pool_rows % 32) return false;
@@ -1730,12 +1745,12 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
     for (int l = 0; l < nlayers; ++l) {
         const int cin = widths[l], cout = widths[l + 1];
         if (cin <= 0 || cout <= 0 || cout % 4) return false;
-        const bool ztop = backward && l == nlayers - 1 && !top_stored(rows, nlayers, widths, pool_rows);
-        const GemmShape g = ztop ? gemm_shape(rows, tiles(cout) * 32 + cin, cin) : backward ? gemm_shape(rows, cout, cin) : gemm_shape(rows, cin, cout);
+        const bool ztop = backward && l == nlayers - 1 && !top_stored(rows, nlayers, widths, pool_rows, o);
+        const GemmShape g = ztop ? gemm_shape(rows, tiles(cout) * 32 + cin, cin, o) : backward ? gemm_shape(rows, cout, cin, o) : gemm_shape(rows, cin, cout, o);
         size_t pb = g.pack_bytes;
-        if (l == 0 && l1_per_point(nlayers, widths, gd)) {           // the per-point GEMMs' operand tiles instead
+        if (l == 0 && l1_per_point(nlayers, widths, gd, o)) {           // the per-point GEMMs' operand tiles instead
             const long long bn = (long long)gd->b * gd->n;
-            const GemmShape gp = backward ? gemm_shape(bn, cout, gd->cfeat) : gemm_shape(bn, gd->cfeat, cout);
+            const GemmShape gp = backward ? gemm_shape(bn, cout, gd->cfeat, o) : gemm_shape(bn, gd->cfeat, cout, o);
             if (gp.pack_bytes > pb) pb = gp.pack_bytes;
         }
         pl.pack[l] = off; off = align_up(off + pb);
@@ -1754,7 +1769,7 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
         pl.ga = off; off = align_up(off + (size_t)rows * maxw * 4);
         pl.gb = off; off = align_up(off + (size_t)rows * maxw * 4);
         size_t p1 = 0, p2 = 0;
-        const bool ztop = !top_stored(rows, nlayers, widths, pool_rows);
+        const bool ztop = !top_stored(rows, nlayers, widths, pool_rows, o);
         for (int l = 0; l < nlayers; ++l) {
             const bool zt = ztop && l == nlayers - 1;
             for (int gat = 0; gat < (l == 0 ? 2 : 1); ++gat) {      // layer 1 may be a gathered input (other slab shape)
@@ -1768,7 +1783,7 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
                 if (w.partial2_bytes > p2) p2 = w.partial2_bytes;
             }
         }
-        if (l1_per_point(nlayers, widths, gd)) {                  // dW1f = points^T S over the b n points
+        if (l1_per_point(nlayers, widths, gd, o)) {                  // dW1f = points^T S over the b n points
             const WgradShape w = wgrad_shape((long long)gd->b * gd->n, gd->cfeat, widths[1]);
             if (w.partial_bytes > p1) p1 = w.partial_bytes;
             if (w.partial2_bytes > p2) p2 = w.partial2_bytes;
@@ -1779,7 +1794,7 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
             const int kin = widths[nlayers - 1];
             pl.topw = off; off = align_up(off + sizeof(float) * (size_t)(tiles(cl) * 32 + kin + 1) * kin);
             pl.topsf = off; off = align_up(off + sizeof(double) * (size_t)kin * top_cols(kin, cl));
-            const TopSShape ts = top_s_shape(rows, pool_rows, kin, cl);
+            const TopSShape ts = top_s_shape(rows, pool_rows, kin, cl, o);
             if (ts.ok) {
                 pl.tops_part = off; off = align_up(off + ts.part_bytes);
                 pl.tops_part2 = off; off = align_up(off + ts.part2_bytes);
@@ -1787,7 +1802,7 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
             }
         }
     }
-    if (l1_per_point(nlayers, widths, gd)) {
+    if (l1_per_point(nlayers, widths, gd, o)) {
         const long long bn = (long long)gd->b * gd->n;
         pl.l1p = off; off = align_up(off + (size_t)bn * widths[1] * 4);
         if (backward) {
@@ -1795,7 +1810,7 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
             pl.l1part = off; off = align_up(off + (size_t)kMaxParts * 3 * widths[1] * 4);
             pl.l1coef = off; off = align_up(off + (size_t)3 * widths[1] * 4);
         }
-    } else if (backward && l1_coords_only(nlayers, widths, gd)) {
+    } else if (backward && l1_coords_only(nlayers, widths, gd, o)) {
         pl.l1part = off; off = align_up(off + (size_t)kMaxParts * 3 * widths[1] * 4);
     }
     pl.total = off;
@@ -1868,14 +1883,17 @@ static int launch_gemm_ns(int amode, const TlGemm &p, const GemmShape &g, dim3 g
     return PN2_E_ARG;
 }
 
-static int launch_gemm(int amode, TlGemm &p, const GemmShape &g, hipStream_t st, int *nparts = nullptr)
+static int launch_gemm(int amode, TlGemm &p, const GemmShape &g, hipStream_t st, const Opts &o, int *nparts = nullptr)
 {
     p.K = g.K; p.N = g.N; p.tk = g.tk; p.resident = g.resident;
     {
-        const int mode = env_int("PN2_TL_NT", -1);                 // lab switch: 0 never, 1 always, else by size
         const size_t obytes = (size_t)p.rows * g.N * sizeof(float);
-        p.nt = mode == 0 ? 0 : mode == 1 ? 1 : obytes >= ((size_t)128 << 20);
-        p.lab = env_int("PN2_TL_LAB", 0);
+        p.nt = o.nt == PN2_OPT_OFF ? 0 : o.nt == PN2_OPT_ON ? 1 : obytes >= ((size_t)128 << 20);
+#ifdef PN2_TL_LAB_BUILD            /* timing-study builds only (scripts/build_mlp_labs.sh): 1 = no stores, 2 = no statistics */
+        p.lab = getenv("PN2_TL_LAB") ? atoi(getenv("PN2_TL_LAB")) : 0;
+#else
+        p.lab = 0;
+#endif
     }
     const long long rounds = (p.rows / 32 + kTlWaves - 1) / kTlWaves;
     long long gx = kMaxParts / g.slabs;                        // persistent: one 8-wave workgroup per CU over all slabs
@@ -2003,31 +2021,44 @@ static bool layers_ok(long long rows, int nlayers, const pn2_bn_layer *layers, c
 
 }  // namespace pn2
 
-extern "C" long long pn2_mlp_train_ws_bytes(long long rows, int nlayers, const int *widths, int pool_rows, int backward,
-                                            const int *group_dims)
+extern "C" long long pn2_mlp_train_ws_bytes_ex(long long rows, int nlayers, const int *widths, int pool_rows, int backward,
+                                               const int *group_dims, const pn2_train_opts *opts)
 {
     pn2::TlPlan pl;
     pn2::GroupDims gd;
     if (group_dims) gd = {group_dims[0], group_dims[1], group_dims[2], group_dims[3], group_dims[4], group_dims[5]};
-    if (!widths || !pn2::tl_plan(rows, nlayers, widths, pool_rows, backward, pl, group_dims ? &gd : nullptr)) return -1;
+    if (!widths || !pn2::tl_plan(rows, nlayers, widths, pool_rows, backward, pl, group_dims ? &gd : nullptr, pn2::opts_of(opts))) return -1;
     return (long long)pl.total;
+}
+extern "C" long long pn2_mlp_train_ws_bytes(long long rows, int nlayers, const int *widths, int pool_rows, int backward,
+                                            const int *group_dims)
+{
+    return pn2_mlp_train_ws_bytes_ex(rows, nlayers, widths, pool_rows, backward, group_dims, nullptr);
 }
 
 // 1: layer 1 of this grouped level runs once per point; backward then writes the gradient of `points` itself
 // (grad_points (b, n, cfeat)) instead of the per-row gradient grad_feat_rows
-extern "C" int pn2_mlp_train_layer1_per_point(int nlayers, const int *widths, const int *group_dims)
+extern "C" int pn2_mlp_train_layer1_per_point_ex(int nlayers, const int *widths, const int *group_dims, const pn2_train_opts *opts)
 {
     if (!widths || !group_dims || nlayers < 1 || nlayers > 8) return 0;
     const pn2::GroupDims gd = {group_dims[0], group_dims[1], group_dims[2], group_dims[3], group_dims[4], group_dims[5]};
-    return pn2::l1_per_point(nlayers, widths, &gd) ? 1 : 0;
+    return pn2::l1_per_point(nlayers, widths, &gd, pn2::opts_of(opts)) ? 1 : 0;
+}
+extern "C" int pn2_mlp_train_layer1_per_point(int nlayers, const int *widths, const int *group_dims)
+{
+    return pn2_mlp_train_layer1_per_point_ex(nlayers, widths, group_dims, nullptr);
 }
 
 // 1: the top layer's pre-norm tensor z_L is written by forward and read by backward (the caller allocates layers[L-1].z);
 // 0: it is not (pooled stacks of two or more layers on large levels: layers[L-1].z may be NULL)
-extern "C" int pn2_mlp_train_top_stored(long long rows, int nlayers, const int *widths, int pool_rows)
+extern "C" int pn2_mlp_train_top_stored_ex(long long rows, int nlayers, const int *widths, int pool_rows, const pn2_train_opts *opts)
 {
     if (!widths || nlayers < 1 || nlayers > 8) return 1;
-    return pn2::top_stored(rows, nlayers, widths, pool_rows) ? 1 : 0;
+    return pn2::top_stored(rows, nlayers, widths, pool_rows, pn2::opts_of(opts)) ? 1 : 0;
+}
+extern "C" int pn2_mlp_train_top_stored(long long rows, int nlayers, const int *widths, int pool_rows)
+{
+    return pn2_mlp_train_top_stored_ex(rows, nlayers, widths, pool_rows, nullptr);
 }
 
 // byte offsets of the backward workspace's dy ping-pong buffers and per-layer sums (diagnostics: scripts/train_mlp_check.py)
@@ -2035,7 +2066,7 @@ extern "C" int pn2_mlp_train_ws_layout(long long rows, int nlayers, const int *w
                                        long long *stats, long long *coef)
 {
     pn2::TlPlan pl;
-    if (!widths || !pn2::tl_plan(rows, nlayers, widths, pool_rows, 1, pl)) return PN2_E_ARG;
+    if (!widths || !pn2::tl_plan(rows, nlayers, widths, pool_rows, 1, pl, nullptr, pn2::opts_of(nullptr))) return PN2_E_ARG;
     if (ga) *ga = (long long)pl.ga;
     if (gb) *gb = (long long)pl.gb;
     for (int l = 0; l < nlayers; ++l) {
@@ -2088,7 +2119,15 @@ static int launch_l1_dz(long long rows, const GroupDims &gd, const pn2_group_src
 extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group,
                                      const float *x, int pool_rows, float *out, int *argsel, float *zsel, void *ws, void *stream)
 {
+    return pn2_mlp_train_forward_ex(rows, nlayers, layers, group, x, pool_rows, out, argsel, zsel, ws, nullptr, stream);
+}
+
+extern "C" int pn2_mlp_train_forward_ex(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group,
+                                        const float *x, int pool_rows, float *out, int *argsel, float *zsel, void *ws,
+                                        const pn2_train_opts *opts, void *stream)
+{
     using namespace pn2;
+    const Opts o = opts_of(opts);
     int widths[9];
     if (!layers_ok(rows, nlayers, layers, group, widths)) return PN2_E_ARG;
     if ((!group && !x) || !out || !ws || (pool_rows && (!argsel || !zsel))) return PN2_E_NULL;
@@ -2096,10 +2135,10 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
     TlPlan pl;
     GroupDims gd;
     if (group) gd = group_dims(group);
-    if (!tl_plan(rows, nlayers, widths, pool_rows, 0, pl, group ? &gd : nullptr)) return PN2_E_ARG;
-    const bool per_point = group && l1_per_point(nlayers, widths, &gd);
-    const bool coords_only = group && l1_coords_only(nlayers, widths, &gd);
-    const bool keep_top = top_stored(rows, nlayers, widths, pool_rows);
+    if (!tl_plan(rows, nlayers, widths, pool_rows, 0, pl, group ? &gd : nullptr, o)) return PN2_E_ARG;
+    const bool per_point = group && l1_per_point(nlayers, widths, &gd, o);
+    const bool coords_only = group && l1_coords_only(nlayers, widths, &gd, o);
+    const bool keep_top = top_stored(rows, nlayers, widths, pool_rows, o);
     for (int l = 0; l < nlayers; ++l)
         if (!layers[l].z && (keep_top || l < nlayers - 1)) return PN2_E_NULL;
     hipStream_t st = as_stream(stream);
@@ -2114,9 +2153,9 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
             if (l == 0 && per_point) {                            // only the feature rows of W_1: P = points . W1f
                 const TlGather gt = make_gather(group);
                 add_pack_job(jobs, nj, L.weight + gt.feat_off * L.w_stride_k, L.w_stride_k, L.w_stride_n,
-                             gemm_shape((long long)gd.b * gd.n, gt.cfeat, L.cout), base + pl.pack[l]);
+                             gemm_shape((long long)gd.b * gd.n, gt.cfeat, L.cout, o), base + pl.pack[l]);
             } else {
-                add_pack_job(jobs, nj, L.weight, L.w_stride_k, L.w_stride_n, gemm_shape(rows, L.cin, L.cout), base + pl.pack[l]);
+                add_pack_job(jobs, nj, L.weight, L.w_stride_k, L.w_stride_n, gemm_shape(rows, L.cin, L.cout, o), base + pl.pack[l]);
             }
         }
         if (int rc = launch_pack_jobs(jobs, nj, st)) return rc;
@@ -2127,7 +2166,7 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
     // add: the folded form a z + c loses accuracy with |mean| / std of a channel, and a bias is pure mean.
     for (int l = 0; l < nlayers; ++l) {
         const pn2_bn_layer &L = layers[l];
-        const GemmShape g = gemm_shape(rows, L.cin, L.cout);
+        const GemmShape g = gemm_shape(rows, L.cin, L.cout, o);
         const bool last = l == nlayers - 1;
         if (l == 0 && per_point) {
             // layer 1 once per point (tl_l1_forward_kernel): P = points . W1f over the b n points, then one pass over the rows
@@ -2135,7 +2174,7 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
             const long long bn = (long long)gd.b * gd.n;
             float *P = reinterpret_cast<float *>(base + pl.l1p);
             {
-                const GemmShape gp = gemm_shape(bn, gt.cfeat, L.cout);
+                const GemmShape gp = gemm_shape(bn, gt.cfeat, L.cout, o);
                 TlGemm q;
                 memset(&q, 0, sizeof(q));
                 q.rows = bn;
@@ -2143,13 +2182,13 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
                 q.wpacked = reinterpret_cast<const u32x4 *>(base + pl.pack[l]);
                 q.emode = E_STORE;
                 q.out = P;
-                if (int rc = launch_gemm(A_PLAIN, q, gp, st)) return rc;
+                if (int rc = launch_gemm(A_PLAIN, q, gp, st, o)) return rc;
             }
             int np = 0;
             if (int rc = launch_l1_forward(rows, gd, group, L, P, reinterpret_cast<double *>(base + pl.stats[l]), st, &np)) return rc;
             if (int rc = launch(tl_bn_finalize_kernel, dim3((unsigned)((L.cout + 7) / 8)), dim3(256), 0, st,
                                 reinterpret_cast<const double *>(base + pl.stats[l]), np, L.cout, (double)rows, L.gamma,
-                                L.beta, L.running_mean, L.running_var, L.momentum, L.eps, L.save, L.bias)) return rc;
+                                L.beta, L.running_mean, L.running_var, L.momentum, L.eps, L.save, L.bias, L.running_var_biased)) return rc;
             continue;
         }
         if (l == 0 && coords_only) {
@@ -2158,7 +2197,7 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
             if (int rc = launch_l1_forward(rows, gd, group, L, nullptr, reinterpret_cast<double *>(base + pl.stats[l]), st, &np)) return rc;
             if (int rc = launch(tl_bn_finalize_kernel, dim3((unsigned)((L.cout + 7) / 8)), dim3(256), 0, st,
                                 reinterpret_cast<const double *>(base + pl.stats[l]), np, L.cout, (double)rows, L.gamma,
-                                L.beta, L.running_mean, L.running_var, L.momentum, L.eps, L.save, L.bias)) return rc;
+                                L.beta, L.running_mean, L.running_var, L.momentum, L.eps, L.save, L.bias, L.running_var_biased)) return rc;
             continue;
         }
         TlGemm p;
@@ -2182,10 +2221,10 @@ extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_l
             p.prow = pool_rows == 16 ? 16 : 32;
         }
         int nparts = 0;
-        if (int rc = launch_gemm(amode, p, g, st, &nparts)) return rc;
+        if (int rc = launch_gemm(amode, p, g, st, o, &nparts)) return rc;
         if (int rc = launch(tl_bn_finalize_kernel, dim3((unsigned)((L.cout + 7) / 8)), dim3(256), 0, st,
                             reinterpret_cast<const double *>(base + pl.stats[l]), nparts, L.cout, (double)rows, L.gamma, L.beta,
-                            L.running_mean, L.running_var, L.momentum, L.eps, L.save, L.bias)) return rc;
+                            L.running_mean, L.running_var, L.momentum, L.eps, L.save, L.bias, L.running_var_biased)) return rc;
         if (last && pool_rows) {
             const long long groups = rows / pool_rows;
             const int prow = pool_rows == 16 ? 16 : 32;
@@ -2210,7 +2249,18 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
                                       const float *grad_out, float *grad_x, float *grad_feat_rows, float *grad_points,
                                       int reproducible, void *ws, void *stream)
 {
+    return pn2_mlp_train_backward_ex(rows, nlayers, layers, group, x, pool_rows, out, argsel, zsel, grad_out, grad_x, grad_feat_rows,
+                                     grad_points, reproducible, ws, nullptr, stream);
+}
+
+extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group,
+                                         const float *x, int pool_rows, const float *out, const int *argsel, const float *zsel,
+                                         const float *grad_out, float *grad_x, float *grad_feat_rows, float *grad_points,
+                                         int reproducible, void *ws, const pn2_train_opts *opts, void *stream)
+{
     using namespace pn2;
+    const Opts o = opts_of(opts);
+    const int cus = device_cus();
     int widths[9];
     if (!layers_ok(rows, nlayers, layers, group, widths)) return PN2_E_ARG;
     if ((!group && !x) || !out || !grad_out || !ws || (pool_rows && (!argsel || !zsel))) return PN2_E_NULL;
@@ -2219,13 +2269,13 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
     TlPlan pl;
     GroupDims gd;
     if (group) gd = group_dims(group);
-    if (!tl_plan(rows, nlayers, widths, pool_rows, 1, pl, group ? &gd : nullptr)) return PN2_E_ARG;
+    if (!tl_plan(rows, nlayers, widths, pool_rows, 1, pl, group ? &gd : nullptr, o)) return PN2_E_ARG;
     hipStream_t st = as_stream(stream);
     char *base = static_cast<char *>(ws);
-    const bool per_point = group && l1_per_point(nlayers, widths, &gd);
-    const bool coords_only = group && l1_coords_only(nlayers, widths, &gd);
+    const bool per_point = group && l1_per_point(nlayers, widths, &gd, o);
+    const bool coords_only = group && l1_coords_only(nlayers, widths, &gd, o);
     const bool want_dx = group ? ((per_point ? grad_points : grad_feat_rows) && group->points && group->cfeat > 0) : grad_x != nullptr;
-    const bool ztop = !top_stored(rows, nlayers, widths, pool_rows);     // pooled top layer without z_L (tl_top_mats_kernel)
+    const bool ztop = !top_stored(rows, nlayers, widths, pool_rows, o);     // pooled top layer without z_L (tl_top_mats_kernel)
     for (int l = 0; l < nlayers; ++l)
         if (!layers[l].z && !(ztop && l == nlayers - 1)) return PN2_E_NULL;
     {
@@ -2240,9 +2290,9 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
                     // per point: the same tiles, for the GEMM over the b n points
                     const TlGather gt = make_gather(group);
                     add_pack_job(jobs, nj, L.weight + gt.feat_off * L.w_stride_k, L.w_stride_n, L.w_stride_k,
-                                 gemm_shape(per_point ? (long long)gd.b * gd.n : rows, L.cout, gt.cfeat), base + pl.pack[l]);
+                                 gemm_shape(per_point ? (long long)gd.b * gd.n : rows, L.cout, gt.cfeat, o), base + pl.pack[l]);
                 } else {
-                    add_pack_job(jobs, nj, L.weight, L.w_stride_n, L.w_stride_k, gemm_shape(rows, L.cout, L.cin), base + pl.pack[l]);
+                    add_pack_job(jobs, nj, L.weight, L.w_stride_n, L.w_stride_k, gemm_shape(rows, L.cout, L.cin, o), base + pl.pack[l]);
                 }
             }
         }
@@ -2290,7 +2340,7 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
             {
                 // weight gradient: the routed part S on the vector units (tl_top_s_kernel) when its shape allows, the Gram
                 // matrix h^T h and the column sums of h from the dense kernel, combined by tl_top_wgrad_fix_kernel
-                const TopSShape ts = top_s_shape(rows, pool_rows, K, NF);
+                const TopSShape ts = top_s_shape(rows, pool_rows, K, NF, o);
                 double *s64 = ts.ok ? reinterpret_cast<double *>(base + pl.tops64) : nullptr;
                 if (ts.ok) {
                     TlTopS q;
@@ -2311,7 +2361,7 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
                 w.NO = ldw; w.tf = tfw; w.NF = ts.ok ? 0 : NF;
                 w.G = gq; w.argsel = argsel; w.coef = coef; w.group_rows = pool_rows;
                 w.partial = reinterpret_cast<float *>(base + pl.partial);
-                const WgradShape ws_ = wgrad_shape(rows, K, ldw);
+                const WgradShape ws_ = wgrad_shape(rows, K, ldw, false, cus);
                 w.xshare = ws_.uslabs == 1;
                 if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, st, sf)) return rc;
                 long long blocks = ((long long)K * NF + 255) / 256;
@@ -2321,7 +2371,7 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
                                     (const float *)nullptr, L.grad_weight, (const double *)s64, L.grad_accumulate)) return rc;
             }
             {
-                const GemmShape g = gemm_shape(rows, NFp + K, K);
+                const GemmShape g = gemm_shape(rows, NFp + K, K, o);
                 if (int rc = launch_pack(wp, K, 1, g, base + pl.pack[l], st)) return rc;
                 TlGemm p;
                 memset(&p, 0, sizeof(p));
@@ -2336,7 +2386,7 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
                 p.zprev = D.z; p.ea = D.save + 2 * D.cout; p.ec = D.save + 3 * D.cout;
                 p.stats = reinterpret_cast<double *>(base + pl.stats[l - 1]);
                 int np = 0;
-                if (int rc = launch_gemm(A_FILL, p, g, st, &np)) return rc;
+                if (int rc = launch_gemm(A_FILL, p, g, st, o, &np)) return rc;
                 nparts[l - 1] = np;
             }
             float *tmp = gcur; gcur = gnext; gnext = tmp;
@@ -2366,11 +2416,11 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
                 w.partial = reinterpret_cast<float *>(base + pl.partial);
                 pn2_bn_layer Lf = L;
                 Lf.grad_weight = L.grad_weight + gt.feat_off * L.w_stride_k;
-                const WgradShape ws_ = wgrad_shape(bn, gt.cfeat, L.cout);
+                const WgradShape ws_ = wgrad_shape(bn, gt.cfeat, L.cout, false, cus);
                 if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), Lf, st)) return rc;
             }
             if (want_dx) {                                        // dPoints = S W1f^T
-                const GemmShape g = gemm_shape(bn, L.cout, gt.cfeat);
+                const GemmShape g = gemm_shape(bn, L.cout, gt.cfeat, o);
                 TlGemm p;
                 memset(&p, 0, sizeof(p));
                 p.rows = bn;
@@ -2378,7 +2428,7 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
                 p.wpacked = reinterpret_cast<const u32x4 *>(base + pl.pack[l]);
                 p.emode = E_PLAIN;
                 p.out = grad_points; p.out_pitch = gt.cfeat; p.col0 = 0; p.col1 = gt.cfeat;
-                if (int rc = launch_gemm(A_PLAIN, p, g, st)) return rc;
+                if (int rc = launch_gemm(A_PLAIN, p, g, st, o)) return rc;
             }
             break;
         }
@@ -2399,12 +2449,12 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
             w.coef = coef;
             w.group_rows = pool_rows;
             w.partial = reinterpret_cast<float *>(base + pl.partial);
-            const WgradShape ws_ = wgrad_shape(rows, L.cin, L.cout, w.amode == A_GATHER);
+            const WgradShape ws_ = wgrad_shape(rows, L.cin, L.cout, w.amode == A_GATHER, cus);
             if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, st)) return rc;
         }
         // data gradient
         if (l > 0 || want_dx) {
-            const GemmShape g = (l == 0 && group) ? gemm_shape(rows, L.cout, make_gather(group).cfeat) : gemm_shape(rows, L.cout, L.cin);
+            const GemmShape g = (l == 0 && group) ? gemm_shape(rows, L.cout, make_gather(group).cfeat, o) : gemm_shape(rows, L.cout, L.cin, o);
             TlGemm p;
             memset(&p, 0, sizeof(p));
             p.rows = rows;
@@ -2432,7 +2482,7 @@ extern "C" int pn2_mlp_train_backward(long long rows, int nlayers, const pn2_bn_
                 }
             }
             int np = 0;
-            if (int rc = launch_gemm(pooled_top ? A_DZ_POOL : A_DZ, p, g, st, &np)) return rc;
+            if (int rc = launch_gemm(pooled_top ? A_DZ_POOL : A_DZ, p, g, st, o, &np)) return rc;
             if (l > 0) nparts[l - 1] = np;
         }
         float *tmp = gcur; gcur = gnext; gnext = tmp;

@@ -86,6 +86,18 @@ def three_nn_weights(xyz1, xyz2):
     return idx, weight
 
 
+def use_tf_moving_variance(model, flag=True):
+    """Make every batch norm of `model` feed the BIASED batch variance to its running variance in the fused training path,
+    as tf.contrib.layers.batch_norm does in the reference (tf_util.py:512-531: tf.nn.moments' variance goes straight
+    into the moving average; torch.nn.BatchNorm averages the unbiased one, var * N / (N - 1) -- a relative difference of
+    1 / N, 2.4e-4 on a 4,096-row level). pn2_bn_layer.running_var_biased. The layer-by-layer torch path keeps torch's
+    convention."""
+    for mod in model.modules():
+        if isinstance(mod, (nn.BatchNorm1d, nn.BatchNorm2d)):
+            mod.running_var_biased = bool(flag)
+    return model
+
+
 def _no_packing_under_capture():
     """Packing folds the batch norms on the host (.cpu()) and uploads pageable memory: both are illegal
     while a HIP graph is being captured. Fail with an instruction instead of corrupting the capture."""

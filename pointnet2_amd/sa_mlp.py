@@ -223,6 +223,7 @@ def sa_level(npoint, radius, nsample, xyz, points, packed, buffers=None):
     b, n, _ = xyz.shape
     m, ns = int(npoint), int(nsample)
     require(m > 0 and ns > 0 and float(radius) > 0, "npoint, nsample and radius must be positive")
+    require(b > 0, "sa_level: empty batch")                # (PointnetSAModule sends b == 0 through the operator path)
     cfeat = 0
     if points is not None:
         points = f32(points, "points")
@@ -250,7 +251,11 @@ def sa_level(npoint, radius, nsample, xyz, points, packed, buffers=None):
             buffers.key, buffers.t = key, (fps_idx, new_xyz, idx, cnt, grouped, out, ws, temp)
     st = stream_ptr(dev)
     with on_device(dev):
-        if torch.cuda.is_current_stream_capturing() or not G._OVERLAP[0]:
+        if not G._OVERLAP[0]:
+            # set_overlapped_launch(False) / PN2_OVERLAP=0 (what OverlappedLaunchError tells the user to do): no workspace ->
+            # pn2_sa_level takes the two-launch path, no sa_fused_kernel is launched
+            ent, gen, wsp = None, 0, None
+        elif torch.cuda.is_current_stream_capturing():
             wss = torch.empty((lib.pn2_sample_and_group_ws_bytes(b, m),), dtype=torch.uint8, device=dev)
             ent, gen = None, 0
             wsp = ptr(wss)

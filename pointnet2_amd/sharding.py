@@ -68,10 +68,11 @@ class GradBucket:
     def zero_(self):
         self.flat.zero_()
 
-    def allreduce_mean_(self):
-        """In-place mean over ranks; a no-op without a process group. (With a group of ONE rank the collective still
-        runs -- it is how a single-GPU box exercises the RCCL path.)"""
-        if not dist.is_initialized():
+    def allreduce_mean_(self, force_collective=False):
+        """In-place mean over ranks; a no-op without a process group or with ONE rank (a single-GPU training loop pays
+        nothing). force_collective: run the collective also at world size 1 -- how bench.py and tests/test_rccl_gpu.py
+        exercise the RCCL path on a single-GPU box."""
+        if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
             return self.flat
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         if dist.get_world_size() > 1:
@@ -79,13 +80,13 @@ class GradBucket:
         return self.flat
 
 
-def allreduce_mean_(tensors):
+def allreduce_mean_(tensors, force_collective=False):
     """In-place mean over ranks of a list of gradient tensors (replaces average_gradients,
     train_multi_gpu.py:91-126). One contiguous fp32 tensor -- a GradBucket's flat buffer -- is reduced where it is;
-    several tensors go through one temporary flat bucket. A no-op without a process group; with a group of ONE rank
-    the collective still runs (a single-GPU box exercises the RCCL path that way)."""
+    several tensors go through one temporary flat bucket. A no-op without a process group or with ONE rank, unless
+    force_collective (bench.py / tests/test_rccl_gpu.py exercise the RCCL path on a single-GPU box that way)."""
     tensors = [t for t in tensors if t is not None]
-    if not tensors or not dist.is_initialized():
+    if not tensors or not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
         return tensors
     world = dist.get_world_size()
     if len(tensors) == 1 and tensors[0].dtype == torch.float32 and tensors[0].is_contiguous():

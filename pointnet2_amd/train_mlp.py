@@ -9,14 +9,15 @@ What autograd sees is ONE node per level: inputs = the grouped features (or the 
 the level's parameters; saved for backward = the pre-norm tensors z_l (rows, C_l) and a few per-channel vectors.
 The grouped (b, m, nsample, C) tensors, the normalised / rectified activations and the ReLU masks never exist.
 """
+import contextlib
 import ctypes
 
 import torch
 import torch.nn as nn
 
 from . import _C
-from ._tensors import (f32, i32, is_deterministic, on_device, ptr, require, same_device, seg_workspace, stream_ptr,
-                       use_segmented_grad)
+from ._tensors import (det_workspace, f32, i32, is_deterministic, on_device, ptr, require, same_device, seg_workspace,
+                       stream_ptr, use_segmented_grad)
 
 _vp, _i, _ll, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
 
@@ -29,7 +30,64 @@ class GroupSrc(ctypes.Structure):          # pn2_group_src
 class BnLayer(ctypes.Structure):           # pn2_bn_layer
     _fields_ = [("cin", _i), ("cout", _i), ("weight", _vp), ("w_stride_k", _ll), ("w_stride_n", _ll), ("bias", _vp),
                 ("gamma", _vp), ("beta", _vp), ("running_mean", _vp), ("running_var", _vp), ("momentum", _f), ("eps", _f),
-                ("z", _vp), ("save", _vp), ("grad_weight", _vp), ("grad_gamma", _vp), ("grad_beta", _vp), ("grad_accumulate", _i)]
+                ("z", _vp), ("save", _vp), ("grad_weight", _vp), ("grad_gamma", _vp), ("grad_beta", _vp), ("grad_accumulate", _i),
+                ("running_var_biased", _i)]
+
+
+class TrainOpts(ctypes.Structure):         # pn2_train_opts: 0 = automatic, 1 = off, 2 = on
+    _fields_ = [("top_stored", _i), ("top_sparse", _i), ("l1_per_point", _i), ("l1_coords", _i), ("force_stream", _i),
+                ("max_ns", _i), ("nt", _i), ("fuse_wgrad", _i)]
+
+
+_OPT_NAMES = tuple(name for name, _ in TrainOpts._fields_)
+_OPTS = {}                         # overrides in force (empty: every rule automatic -> the library gets NULL)
+
+
+def _opts_from(saved):
+    """A dict of overrides -> the `const pn2_train_opts *` argument (a ctypes reference that keeps its struct alive), or None."""
+    if not saved:
+        return None
+    o = TrainOpts()
+    for k, v in saved.items():
+        setattr(o, k, (v or 0) if k == "max_ns" else (0 if v is None else 2 if v else 1))
+    return ctypes.byref(o)
+
+
+def _opts():
+    """The overrides in force. The SAME ones must reach the workspace query, the organisation queries, forward and backward
+    of one node: backward re-reads what forward ran under (ctx.opts)."""
+    return _opts_from(_OPTS)
+
+
+def parse_options(text):
+    """'top_stored=0,fuse_wgrad=1,max_ns=2' -> the keyword arguments of options() (the A/B scripts take such a string from
+    their command line / PN2_TRAIN_OPTS; the package itself never reads the environment)."""
+    kw = {}
+    for item in (text or "").replace(" ", "").split(","):
+        if not item:
+            continue
+        k, _, v = item.partition("=")
+        require(k in _OPT_NAMES and v.lstrip("-").isdigit(), "bad training option %r" % item)
+        kw[k] = int(v) if k == "max_ns" else (None if int(v) < 0 else bool(int(v)))
+    return kw
+
+
+@contextlib.contextmanager
+def options(**kw):
+    """Force the organisation of the training passes inside the block (tests that cover every variant, A/B timing):
+    top_stored / top_sparse / l1_per_point / l1_coords / force_stream / nt / fuse_wgrad = True | False | None (automatic),
+    max_ns = 1 | 2 | 4. Results never depend on them. They travel to the library as a per-call argument
+    (pn2_mlp_train_*_ex); the library itself reads no environment variable. A node's backward runs under the options its
+    forward ran under."""
+    for k in kw:
+        require(k in _OPT_NAMES, "unknown training option %r (known: %s)" % (k, ", ".join(_OPT_NAMES)))
+    old = dict(_OPTS)
+    _OPTS.update(kw)
+    try:
+        yield
+    finally:
+        _OPTS.clear()
+        _OPTS.update(old)
 
 
 def conv_bn_pairs(net):
@@ -58,6 +116,12 @@ def stack_supported(net, rows, pool_rows=0, grouped=True):
     for conv, bn in pairs:
         if conv.out_channels % 4 or bn.momentum is None or not bn.affine:
             return False
+        # a batch norm frozen with bn.eval() inside a model in train() (fine-tuning) normalises with its RUNNING statistics
+        # and must not update them: that is not this path (batch statistics), the layer-by-layer path handles it
+        if not bn.training or not conv.training:
+            return False
+        if any(t is not None and t.dtype != torch.float32 for t in (conv.weight, conv.bias, bn.weight, bn.bias)):
+            return False
     return True                    # plain rows of a width that is no multiple of 4 are zero-padded by fp_mlp_train
 
 
@@ -82,6 +146,10 @@ def _layer_array(level, weights, biases, gammas, betas, zs, saves, grads=None, u
         L.running_var = ptr(bn.running_var) if track else None
         L.momentum, L.eps = float(bn.momentum), float(bn.eps)
         L.z, L.save = ptr(zs[l]), ptr(saves[l])
+        # tf.contrib.layers.batch_norm feeds the BIASED batch variance to the moving variance (tf_util.py:512-531), torch the
+        # unbiased one: a batch-norm module marked with `running_var_biased = True` (pointnet_util.use_tf_moving_variance)
+        # follows the reference
+        L.running_var_biased = 1 if getattr(bn, "running_var_biased", False) else 0
         if grads is not None:
             L.grad_weight, L.grad_gamma, L.grad_beta = ptr(grads[l][0]), ptr(grads[l][1]), ptr(grads[l][2])
     return arr
@@ -104,9 +172,9 @@ def _group_dims(level, points):
                               1 if level.idx is not None else 0)
 
 
-def _ws(rows, widths, pool_rows, backward, dev, gdims=None):
+def _ws(rows, widths, pool_rows, backward, dev, gdims=None, opts=None):
     arr = (ctypes.c_int * len(widths))(*widths)
-    nbytes = _C.lib().pn2_mlp_train_ws_bytes(rows, len(widths) - 1, arr, pool_rows, backward, gdims)
+    nbytes = _C.lib().pn2_mlp_train_ws_bytes_ex(rows, len(widths) - 1, arr, pool_rows, backward, gdims, opts)
     require(nbytes >= 0, "pn2_mlp_train: unsupported stack (rows %% 32, widths %% 4, pool group 16 or a multiple of 32)")
     return torch.empty(((nbytes + 7) // 8,), dtype=torch.int64, device=dev)
 
@@ -120,8 +188,22 @@ def set_accumulate_into_grad(flag):
     or a second micro-batch), the backward kernels add their results into them (pn2_bn_layer.grad_accumulate) and the
     autograd node returns no gradient for those parameters -- instead of autograd launching one `grad += new` per
     parameter afterwards (46 launches = 0.2 ms of a pointnet2_cls_ssg step). Same arithmetic: one fp32 add per element.
-    Off by default because parameter hooks (DistributedDataParallel's) do not see gradients that bypass autograd."""
+    Off by default because parameter hooks (DistributedDataParallel's) do not see gradients that bypass autograd.
+    Only for `loss.backward()`: under `torch.autograd.grad(...)` `.grad` must not be touched, and a node cannot tell the
+    two apart -- so do not call autograd.grad on these levels while the mode is on (it would receive None for the
+    parameters and find them added to `.grad`). Prefer the scoped form, `with accumulate_into_grad(): loss.backward()`."""
     _ACCUMULATE[0] = bool(flag)
+
+
+@contextlib.contextmanager
+def accumulate_into_grad(flag=True):
+    """set_accumulate_into_grad for the duration of a block (around `loss.backward()`)."""
+    old = _ACCUMULATE[0]
+    _ACCUMULATE[0] = bool(flag)
+    try:
+        yield
+    finally:
+        _ACCUMULATE[0] = old
 
 
 def _grad_slot(param, like):
@@ -148,7 +230,8 @@ class _TrainMLP(torch.autograd.Function):
         rows = level.rows
         widths = [weights[0].shape[1]] + [c.out_channels for c, _ in level.pairs]
         warr = (ctypes.c_int * len(widths))(*widths)
-        keep_top = bool(_C.lib().pn2_mlp_train_top_stored(rows, n, warr, level.pool_rows))
+        opts = _opts()
+        keep_top = bool(_C.lib().pn2_mlp_train_top_stored_ex(rows, n, warr, level.pool_rows, opts))
         # pre-norm tensors z_l, the only activations kept; the pooled top layer's is not even written on large levels
         zs = [torch.empty((rows, w), dtype=torch.float32, device=dev) if (keep_top or l < n - 1) else None
               for l, w in enumerate(widths[1:])]
@@ -162,17 +245,18 @@ class _TrainMLP(torch.autograd.Function):
         else:
             out = torch.empty((rows, cl), dtype=torch.float32, device=dev)
             argsel = zsel = None
-        ws = _ws(rows, widths, level.pool_rows, 0, dev, _group_dims(level, x))
+        ws = _ws(rows, widths, level.pool_rows, 0, dev, _group_dims(level, x), opts)
         arr = _layer_array(level, weights, biases, gammas, betas, zs, saves)
         grp = _group_struct(level, x) if level.grouped else None
         with on_device(dev):
-            _C.check(_C.lib().pn2_mlp_train_forward(rows, n, arr, ctypes.byref(grp) if grp is not None else None,
-                                                    None if level.grouped else ptr(x), level.pool_rows, ptr(out), ptr(argsel),
-                                                    ptr(zsel), ptr(ws), stream_ptr(dev)), "mlp_train_forward")
+            _C.check(_C.lib().pn2_mlp_train_forward_ex(rows, n, arr, ctypes.byref(grp) if grp is not None else None,
+                                                       None if level.grouped else ptr(x), level.pool_rows, ptr(out), ptr(argsel),
+                                                       ptr(zsel), ptr(ws), opts, stream_ptr(dev)), "mlp_train_forward")
         nbt = [bn.num_batches_tracked for _, bn in level.pairs if bn.track_running_stats and bn.num_batches_tracked is not None]
         if nbt:
             torch._foreach_add_(nbt, 1)                        # one launch for the level's counters
         ctx.level, ctx.widths = level, widths
+        ctx.opts = dict(_OPTS)                              # backward must see the organisation forward ran under
         ctx.has_x = x is not None
         ctx.nbias = [b is not None for b in biases]
         ctx.nz = [z is not None for z in zs]
@@ -214,14 +298,15 @@ class _TrainMLP(torch.autograd.Function):
         grad_x = grad_rows = grad_pts = None
         gdims = _group_dims(level, x)
         warr = (ctypes.c_int * len(widths))(*widths)
-        per_point = level.grouped and bool(_C.lib().pn2_mlp_train_layer1_per_point(n, warr, gdims))
+        opts = _opts_from(ctx.opts)
+        per_point = level.grouped and bool(_C.lib().pn2_mlp_train_layer1_per_point_ex(n, warr, gdims, opts))
         if need_x and level.grouped and per_point:
             grad_pts = torch.empty(tuple(x.shape), dtype=torch.float32, device=dev)      # written by the library itself
         elif need_x and level.grouped:
             grad_rows = torch.empty((rows, x.shape[2]), dtype=torch.float32, device=dev)
         elif need_x:
             grad_x = torch.empty((rows, widths[0]), dtype=torch.float32, device=dev)
-        ws = _ws(rows, widths, level.pool_rows, 1, dev, gdims)
+        ws = _ws(rows, widths, level.pool_rows, 1, dev, gdims, opts)
         if _KEEP_WS[0]:
             _KEEP_WS[1] = (ws, rows, widths, level.pool_rows)
         arr = _layer_array(level, weights, biases, gammas, betas, zs, saves, grads, update_running=False)
@@ -229,10 +314,10 @@ class _TrainMLP(torch.autograd.Function):
             arr[l].grad_accumulate = 1 if direct[l] else 0
         grp = _group_struct(level, x) if level.grouped else None
         with on_device(dev):
-            _C.check(_C.lib().pn2_mlp_train_backward(rows, n, arr, ctypes.byref(grp) if grp is not None else None,
-                                                     None if level.grouped else ptr(x), level.pool_rows, ptr(out), ptr(argsel),
-                                                     ptr(zsel), ptr(grad_out), ptr(grad_x), ptr(grad_rows), ptr(grad_pts),
-                                                     1 if is_deterministic() else 0, ptr(ws), stream_ptr(dev)),
+            _C.check(_C.lib().pn2_mlp_train_backward_ex(rows, n, arr, ctypes.byref(grp) if grp is not None else None,
+                                                        None if level.grouped else ptr(x), level.pool_rows, ptr(out), ptr(argsel),
+                                                        ptr(zsel), ptr(grad_out), ptr(grad_x), ptr(grad_rows), ptr(grad_pts),
+                                                        1 if is_deterministic() else 0, ptr(ws), opts, stream_ptr(dev)),
                      "mlp_train_backward")
             if grad_pts is not None:
                 grad_x = grad_pts
@@ -248,6 +333,10 @@ class _TrainMLP(torch.autograd.Function):
                     _C.check(_C.lib().pn2_group_point_grad_seg(b, npts, c, m, ns, ptr(grad_rows), ptr(level.idx), ptr(grad_x),
                                                                ptr(sws), 1 if is_deterministic() else 0, stream_ptr(dev)),
                              "group_point_grad")
+                elif is_deterministic():                   # few channels on a small batch: the fixed-point scatter, as group_point's backward
+                    dws = det_workspace(_C.lib(), b, npts, c, dev)
+                    _C.check(_C.lib().pn2_group_point_grad_det(b, npts, c, m, ns, ptr(grad_rows), ptr(level.idx), ptr(grad_x),
+                                                               ptr(dws), stream_ptr(dev)), "group_point_grad")
                 else:
                     _C.check(_C.lib().pn2_group_point_grad(b, npts, c, m, ns, ptr(grad_rows), ptr(level.idx), ptr(grad_x),
                                                            stream_ptr(dev)), "group_point_grad")
@@ -282,6 +371,7 @@ def sa_mlp_train(net, xyz, new_xyz, points, idx, xyz_first=True):
     pairs = conv_bn_pairs(net)
     require(pairs is not None, "sa_mlp_train expects Conv 1x1 + BatchNorm + ReLU triples")
     xyz = f32(xyz, "xyz")
+    require(xyz.dim() == 3 and xyz.shape[2] == 3, "xyz must be (b, n, 3), got %s" % (tuple(xyz.shape),))
     b, n, _ = xyz.shape
     lv = _Level()
     lv.pairs, lv.grouped, lv.xyz_first = pairs, True, bool(xyz_first)
@@ -290,13 +380,22 @@ def sa_mlp_train(net, xyz, new_xyz, points, idx, xyz_first=True):
         require(new_xyz is None, "group_all takes neither idx nor new_xyz")
         lv.new_xyz, lv.idx, lv.m, lv.nsample = None, None, 1, n
     else:
+        # the kernels index xyz / points through idx and new_xyz through the group number: a mismatch reads out of bounds
+        require(new_xyz is not None, "idx without new_xyz")
         lv.new_xyz, lv.idx = f32(new_xyz, "new_xyz"), i32(idx, "idx")
+        require(idx.dim() == 3 and idx.shape[0] == b, "idx must be (b, m, nsample) with b = %d, got %s" % (b, tuple(idx.shape)))
+        require(tuple(new_xyz.shape) == (b, idx.shape[1], 3),
+                "new_xyz must be (b, m, 3) = %s, got %s" % ((b, idx.shape[1], 3), tuple(new_xyz.shape)))
+        same_device(xyz, lv.new_xyz, lv.idx)
         lv.m, lv.nsample = idx.shape[1], idx.shape[2]
     lv.b, lv.n = b, n
     lv.rows = b * lv.m * lv.nsample
     lv.pool_rows = lv.nsample
     if points is not None:
         points = f32(points, "points")
+        require(points.dim() == 3 and tuple(points.shape[:2]) == (b, n),
+                "points must be (b, n, c) with (b, n) = %s, got %s" % ((b, n), tuple(points.shape)))
+        same_device(xyz, points)
     cin = 3 + (points.shape[2] if points is not None else 0)
     require(pairs[0][0].in_channels == cin, "the first layer expects %d channels, got %d" % (pairs[0][0].in_channels, cin))
     require(stack_supported(net, lv.rows, lv.pool_rows, True), "unsupported stack for the fused training path")
@@ -310,7 +409,9 @@ def fp_mlp_train(net, x):
     pairs = conv_bn_pairs(net)
     require(pairs is not None, "fp_mlp_train expects Conv 1x1 + BatchNorm + ReLU triples")
     x = f32(x, "x")
+    require(x.dim() == 3, "x must be (b, n, cin), got %s" % (tuple(x.shape),))
     b, n, c = x.shape
+    same_device(x, pairs[0][0].weight)
     lv = _Level()
     lv.pairs, lv.grouped, lv.xyz_first = pairs, False, True
     lv.xyz = lv.new_xyz = lv.idx = None

@@ -45,7 +45,16 @@ PY
     ;;
     trainrccl) timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 scripts/train_step_bench.py sem_seg --steps 8 --fused-only 2> "$OUT/train_rccl.err" | grep "^{" > "$OUT/train_step_rccl.jsonl"; cat "$OUT/train_step_rccl.jsonl" | cut -c1-400
                timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --steps 20 --no-extras 2> "$OUT/bench_rccl.err" | grep "^{" > "$OUT/bench_rccl.json"; python -c "import json,sys; print(json.load(open(sys.argv[1]))['allreduce'])" "$OUT/bench_rccl.json" ;;
-    traincheck) PN2_TL_TOP_STORED=0 timeout 300 python scripts/train_mlp_check.py > "$OUT/train_check_zfree.log" 2>&1; tail -1 "$OUT/train_check_zfree.log"; timeout 300 python scripts/train_mlp_check.py > "$OUT/train_check.log" 2>&1; tail -1 "$OUT/train_check.log" ;;
+    traincheck) PN2_TRAIN_OPTS=top_stored=0 timeout 300 python scripts/train_mlp_check.py > "$OUT/train_check_zfree.log" 2>&1; tail -1 "$OUT/train_check_zfree.log"; timeout 300 python scripts/train_mlp_check.py > "$OUT/train_check.log" 2>&1; tail -1 "$OUT/train_check.log" ;;
+    traintests) timeout 1500 python -m pytest tests/test_train_mlp_gpu.py tests/test_train_golden_gpu.py tests/test_train_fuzz_gpu.py tests/test_whole_model_fp64_gpu.py tests/test_overlap_status_gpu.py tests/test_modules_gpu.py -m gpu -q > "$OUT/traintests.log" 2>&1; tail -25 "$OUT/traintests.log" ;;
+    wholemodel) timeout 900 python scripts/whole_model_fp64.py --top 2> "$OUT/whole_model_fp64.err" | grep "^{" > "$OUT/whole_model_fp64.jsonl"; python - "$OUT/whole_model_fp64.jsonl" <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    r = json.loads(l)
+    print("%-52s grad L2 err vs float64: layer by layer %.2e  fused %.2e  (fused vs layer by layer %.2e)" % (r["model"][:52], r["layer_by_layer"]["grad_l2_err"], r["fused"]["grad_l2_err"], r["fused_vs_layer_by_layer_l2"]))
+PY
+    ;;
+    fuzzsurvey) timeout ${FUZZ_TIMEOUT:-900} python scripts/train_fuzz_survey.py ${FUZZ_CASES:-600} > "$OUT/train_fuzz_survey.txt" 2> "$OUT/train_fuzz_survey.err"; tail -5 "$OUT/train_fuzz_survey.txt" ;;
     profile)   timeout 1200 bash scripts/profile_round.sh > "$OUT/profile.log" 2>&1; tail -5 "$OUT/profile.log" ;;
     *)         echo "unknown step $step" ;;
     esac

@@ -14,7 +14,7 @@ from scripts import train_mlp_check as T  # noqa: E402
 spec = importlib.util.spec_from_file_location("fz", os.path.join(ROOT, "tests", "test_train_fuzz_gpu.py"))
 fz = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(fz)
-KEYS = ("PN2_TL_TOP_STORED", "PN2_TL_TOP_SPARSE", "PN2_TL_L1_PER_POINT", "PN2_TL_L1_COORDS", "PN2_TL_FORCE_STREAM")
+from pointnet2_amd import train_mlp  # noqa: E402
 
 
 def main():
@@ -22,11 +22,8 @@ def main():
     over, ratios = 0, []
     for seed in range(n):
         kw, env = fz._case(seed)
-        for k in KEYS:
-            os.environ.pop(k, None)
-        os.environ.update(env)
         buf = io.StringIO()
-        with contextlib.redirect_stdout(buf):
+        with contextlib.redirect_stdout(buf), train_mlp.options(**env):
             worst = T.run_case("fuzz %d" % seed, seed=seed, fp32_baseline=True, **kw)
         base = T.run_case.baseline
         ratios.append(worst / max(base, 1e-9))

@@ -1,6 +1,8 @@
 """Training-mode shared MLP of single SA / FP levels: fused node (csrc/train_mlp.hip) vs the layer-by-layer torch
 path of the same module (group_point + concat + conv/BN/ReLU stack + max, autograd), forward and backward, HIP-event
-times. PN2_TRAIN_BENCH_KERNEL_ONLY=1: only the fused path (for rocprofv3 traces). Writes JSON lines."""
+times. PN2_TRAIN_BENCH_KERNEL_ONLY=1: only the fused path (for rocprofv3 traces). PN2_TRAIN_OPTS="fuse_wgrad=0,top_stored=1":
+organisation overrides for A/B runs (train_mlp.options; read HERE, by the script -- the library has no environment switches).
+Writes JSON lines."""
 import json
 import os
 import sys
@@ -106,4 +108,5 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    with train_mlp.options(**train_mlp.parse_options(os.environ.get("PN2_TRAIN_OPTS", ""))):
+        main()

@@ -246,11 +246,13 @@ if __name__ == "__main__":
     only = [a for a in sys.argv[1:] if not a.startswith("--")]
     repeat = max([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--repeat=")] + [1])
     bad = 0
+    forced = train_mlp.parse_options(os.environ.get("PN2_TRAIN_OPTS", ""))      # e.g. "top_stored=0,fuse_wgrad=0"
     for name, kw in cases * repeat:
         if only and not any(name.startswith(o) for o in only):
             continue
         try:
-            w = run_case(name, **kw)
+            with train_mlp.options(**forced):
+                w = run_case(name, **kw)
             bad += w > 2e-5
         except Exception as exc:
             import traceback

@@ -52,9 +52,10 @@ def main():
             if s > 0 and float((a - r).abs().max()) > 1e-5 * s:
                 bad[nm] = bad.get(nm, 0) + 1
     torch.cuda.synchronize()
-    print("stress %s x%d env(MAX_NS=%s FORCE_STREAM=%s): forward deviations %d, backward deviations %s"
-          % (which, reps, os.environ.get("PN2_TL_MAX_NS"), os.environ.get("PN2_TL_FORCE_STREAM"), fwd_bad, bad or "none"), flush=True)
+    print("stress %s x%d opts(%s): forward deviations %d, backward deviations %s"
+          % (which, reps, os.environ.get("PN2_TRAIN_OPTS", ""), fwd_bad, bad or "none"), flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    with train_mlp.options(**train_mlp.parse_options(os.environ.get("PN2_TRAIN_OPTS", ""))):
+        main()

@@ -57,7 +57,7 @@ def pack(prefix, d, arrays):
         d["%s/%s" % (prefix, k)] = v
 
 
-def sa_case(d, name, rng, b, n, m, radius, ns, cfeat, widths, seed, xyz_first=True):
+def sa_case(d, name, rng, b, n, m, radius, ns, cfeat, widths, seed, xyz_first=True, unbiased=True):
     xyz = S.sphere_clouds(b, n, seed)
     new_xyz = O.gather_point(xyz, O.farthest_point_sample(m, xyz))
     idx, _ = O.query_ball_point(radius, ns, xyz, new_xyz)
@@ -65,7 +65,7 @@ def sa_case(d, name, rng, b, n, m, radius, ns, cfeat, widths, seed, xyz_first=Tr
     rows = T.group_rows(xyz, new_xyz, pts, idx, xyz_first)
     for attempt in range(200):                                  # weights re-drawn until no decision is at rounding level
         layers = make_layers(rng, 3 + cfeat, widths)
-        out, cache = T.forward(rows, layers, ns, MOMENTUM, EPS)
+        out, cache = T.forward(rows, layers, ns, MOMENTUM, EPS, unbiased_running_var=unbiased)
         if margin(cache) >= 5e-6:
             break
     else:
@@ -74,6 +74,7 @@ def sa_case(d, name, rng, b, n, m, radius, ns, cfeat, widths, seed, xyz_first=Tr
     gw = rng.standard_normal(out.shape).astype(np.float32)
     grad_rows, grads = T.backward(gw, layers, cache)
     arrays = {"xyz": xyz, "new_xyz": new_xyz, "idx": idx.astype(np.int32), "grad_out": gw, "out": out,
+              "running_var_biased": np.array(0 if unbiased else 1, np.int64),
               "meta": np.array([b, n, m, ns, cfeat, int(xyz_first), len(widths)] + list(widths), np.int64)}
     if cfeat:
         arrays["points"] = pts
@@ -119,6 +120,9 @@ def main():
     sa_case(d, "sa_feat", rng, 2, 256, 32, 0.4, 32, 16, [32, 32, 64], 12)                    # features: layer 1 once per point
     sa_case(d, "sa_msg_order", rng, 2, 128, 16, 0.5, 16, 3, [16, 32], 13, xyz_first=False)   # MSG channel order, 16 samples, normals
     fp_case(d, "fp_plain", rng, 2, 128, 40, [32, 32])                                        # feature-propagation stack on plain rows
+    # the reference's own moving-variance convention: tf.contrib.layers.batch_norm averages the BIASED batch variance
+    # (tf_util.py:512-531); a small level so that the factor N / (N - 1) = 1 + 2e-3 is far above the tolerance
+    sa_case(d, "sa_tf_var", rng, 2, 64, 8, 0.6, 32, 8, [16, 32], 14, unbiased=False)
     path = os.path.join(OUT, "train_fp64.npz")
     np.savez_compressed(path, **d)
     print("wrote", path, "%.1f kB" % (os.path.getsize(path) / 1e3), "arrays:", len(d))

@@ -63,3 +63,28 @@ def test_msg_falls_back_when_no_lds_geometry_fits(cuda, oracle):
     for (idx, cnt, g), r, k in zip(outs, (0.1, 0.2, 0.4), (16, 32, 128)):
         oi, oc = oracle.query_ball_point(r, k, xyz, xyz[:, :256])
         assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(cnt.cpu().numpy(), oc)
+
+
+def test_fused_sa_level_honours_the_overlap_switch(cuda, monkeypatch):
+    """with set_overlapped_launch(False) the eval SA level (ONE C call, pn2_sa_level) must not run
+    the overlapped launch either. It gets no granule workspace at all -- the overlapped kernel cannot run without one --
+    and the results are those of the default path."""
+    import pointnet2_amd.pointnet_util as U
+    import pointnet2_amd.tf_grouping as G
+    torch.manual_seed(0)
+    sa = U.PointnetSAModule(0, 128, 0.2, 32, [32, 32, 64]).to(cuda).eval()
+    xyz = torch.rand(4, 1024, 3, device=cuda)
+    with torch.no_grad():
+        new_a, out_a, idx_a = sa(xyz, None)
+        assert sa.last_path == "fused"
+
+        def no_workspace(*a, **k):
+            raise AssertionError("the overlapped launch's workspace was requested with the switch off")
+        monkeypatch.setattr(G, "_granule_workspace", no_workspace)
+        G.set_overlapped_launch(False)
+        try:
+            new_b, out_b, idx_b = sa(xyz, None)
+        finally:
+            G.set_overlapped_launch(True)
+    assert sa.last_path == "fused"
+    assert torch.equal(new_a, new_b) and torch.equal(idx_a, idx_b) and torch.equal(out_a, out_b)

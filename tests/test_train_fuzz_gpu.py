@@ -18,17 +18,19 @@ def _case(seed):
     kind = rng.choice(["group", "group", "group", "plain", "group_all"])
     nl = rng.choice([1, 2, 2, 3, 3, 4])
     widths = [rng.choice(WIDTHS) for _ in range(nl)]
-    env = {}
+    env = {}                                                # train_mlp.options(**env): per-call pn2_train_opts
     if rng.random() < 0.4:
-        env["PN2_TL_TOP_STORED"] = "0"                      # pooled top layer without z_L wherever the stack allows it
+        env["top_stored"] = False                           # pooled top layer without z_L wherever the stack allows it
         if rng.random() < 0.7:
-            env["PN2_TL_TOP_SPARSE"] = "1"                  # ... and its routed weight gradient on the vector units
+            env["top_sparse"] = True                        # ... and its routed weight gradient on the vector units
     if rng.random() < 0.2:
-        env["PN2_TL_L1_PER_POINT"] = "0"
+        env["l1_per_point"] = False
     if rng.random() < 0.2:
-        env["PN2_TL_L1_COORDS"] = "0"
+        env["l1_coords"] = False
     if rng.random() < 0.2:
-        env["PN2_TL_FORCE_STREAM"] = "1"                    # weights streamed through LDS instead of resident
+        env["force_stream"] = True                          # weights streamed through LDS instead of resident
+    if rng.random() < 0.25:
+        env["fuse_wgrad"] = False                           # weight gradients as separate passes
     if kind == "plain":
         b, n = rng.choice([(1, 32), (2, 48), (3, 64), (2, 1024), (5, 32)])
         kw = dict(b=b, n=n, m=0, ns=0, cfeat=0, widths=widths, plain_cin=rng.choice([4, 6, 30, 64, 134, 200]))
@@ -47,12 +49,12 @@ def _case(seed):
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PN2_FUZZ_CASES", "40"))))      # more for a soak run
-def test_random_level_shapes_match_float64(cuda, monkeypatch, seed):
+def test_random_level_shapes_match_float64(cuda, seed):
+    from pointnet2_amd import train_mlp
     from scripts import train_mlp_check as T
     kw, env = _case(seed)
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    worst = T.run_case("fuzz %d %s %s" % (seed, kw, env), seed=seed, fp32_baseline=True, **kw)
+    with train_mlp.options(**env):
+        worst = T.run_case("fuzz %d %s %s" % (seed, kw, env), seed=seed, fp32_baseline=True, **kw)
     # Bound: 1e-5 of each tensor's scale, as for the reference networks' shapes -- or twice the error torch's own fp32
     # evaluation of the same graph makes against the same float64 results, where a stack amplifies rounding. Over 600
     # cases (scripts/train_fuzz_survey.py) no case exceeds 1e-5 and the fused path's worst error is 0.42x torch's in the

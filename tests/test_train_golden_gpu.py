@@ -40,7 +40,7 @@ def build_net(c, cin, widths, dev):
     return net
 
 
-@pytest.mark.parametrize("name", ["sa_xyz", "sa_feat", "sa_msg_order", "fp_plain"])
+@pytest.mark.parametrize("name", ["sa_xyz", "sa_feat", "sa_msg_order", "fp_plain", "sa_tf_var"])
 def test_fused_training_level_matches_known_answers(cuda, name):
     from pointnet2_amd import train_mlp
     c = load(name)
@@ -48,6 +48,9 @@ def test_fused_training_level_matches_known_answers(cuda, name):
     widths = [int(v) for v in c["meta"][7:7 + nl]]
     if name.startswith("sa"):
         net = build_net(c, 3 + cfeat, widths, cuda)
+        if int(c.get("running_var_biased", 0)):                 # sa_tf_var: tf.contrib's moving variance (pn2_bn_layer.running_var_biased)
+            from pointnet2_amd.pointnet_util import use_tf_moving_variance
+            use_tf_moving_variance(net)
         xyz = torch.from_numpy(c["xyz"]).to(cuda)
         new_xyz = torch.from_numpy(c["new_xyz"]).to(cuda)
         idx = torch.from_numpy(c["idx"]).to(cuda)

@@ -91,3 +91,46 @@ def test_there_is_no_cpu_path():
     idx = torch.zeros(2, 8, 32, dtype=torch.int32)
     with pytest.raises((ValueError, RuntimeError, _C.Pn2LibraryMissing if hasattr(_C, "Pn2LibraryMissing") else RuntimeError)):
         train_mlp.sa_mlp_train(net.net, xyz, xyz[:, :8].contiguous(), pts, idx, True)
+
+
+def test_organisation_overrides_are_a_per_call_argument(monkeypatch):
+    """the organisation switches travel as pn2_train_opts through the *_ex entry points; the
+    library reads no environment variable (a stray PN2_TL_* in a user's shell changes nothing)."""
+    L = _C.lib()
+    w = _ints(3, 64, 64, 128)
+    big = 32 * 1024 * 32
+    assert L.pn2_mlp_train_top_stored_ex(big, 3, w, 32, None) == 0
+    with train_mlp.options(top_stored=True):
+        assert L.pn2_mlp_train_top_stored_ex(big, 3, w, 32, train_mlp._opts()) == 1
+        kept = L.pn2_mlp_train_ws_bytes_ex(big, 3, w, 32, 1, None, train_mlp._opts())
+    assert train_mlp._opts() is None                                          # the block's overrides are gone
+    assert kept != L.pn2_mlp_train_ws_bytes(big, 3, w, 32, 1, None)           # another plan (z_L kept: no Gram / routed scratch)
+    wf = _ints(131, 128, 128, 256)
+    gd = _ints(32, 512, 128, 64, 128, 1)
+    with train_mlp.options(l1_per_point=False):
+        assert L.pn2_mlp_train_layer1_per_point_ex(3, wf, gd, train_mlp._opts()) == 0
+    assert L.pn2_mlp_train_layer1_per_point_ex(3, wf, gd, None) == 1
+    for name in ("PN2_TL_TOP_STORED", "PN2_TL_L1_PER_POINT", "PN2_TL_LAB"):   # the round-3 environment switches: dead
+        monkeypatch.setenv(name, "1" if name != "PN2_TL_L1_PER_POINT" else "0")
+    assert L.pn2_mlp_train_top_stored(big, 3, w, 32) == 0
+    assert L.pn2_mlp_train_layer1_per_point(3, wf, gd) == 1
+    import subprocess
+    lib_path = _C.LIB_PATH
+    strings = subprocess.run(["strings", lib_path], capture_output=True, text=True).stdout
+    assert "PN2_TL_" not in strings, "the product library still names an environment switch"
+    assert train_mlp.parse_options("top_stored=0, fuse_wgrad=1,max_ns=2,nt=-1") == {"top_stored": False, "fuse_wgrad": True, "max_ns": 2, "nt": None}
+    with pytest.raises(ValueError):
+        train_mlp.parse_options("no_such_option=1")
+    with pytest.raises(ValueError):
+        with train_mlp.options(no_such_option=True):
+            pass
+
+
+def test_frozen_batch_norm_is_not_a_fused_stack():
+    net = _SharedMLP(6, [32, 32], bn=True).train()
+    assert train_mlp.stack_supported(net.net, 1024, 32, True)
+    net.net[1].eval()                                                         # fine-tuning with frozen statistics
+    assert not train_mlp.stack_supported(net.net, 1024, 32, True)
+    net.train()
+    net.net[0].half()
+    assert not train_mlp.stack_supported(net.net, 1024, 32, True)             # non-fp32 parameters: fall back, do not raise

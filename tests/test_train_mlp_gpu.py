@@ -40,6 +40,25 @@ CONFIG_CASES = [
     ("cfg5 sem_seg SA2", dict(b=8, n=1024, m=256, ns=32, cfeat=64, widths=[64, 64, 128])),
     ("cfg5 sem_seg SA3", dict(b=8, n=256, m=64, ns=32, cfeat=128, widths=[128, 128, 256])),
     ("cfg5 sem_seg FP4", dict(b=8, n=8192, m=0, ns=0, cfeat=0, widths=[128, 128, 128], plain_cin=128)),
+    # configs 3 and 4 and the rest of 5: every training level shape of the four networks
+    ("cfg2 cls_ssg L3 group_all", dict(b=32, n=128, m=1, ns=128, cfeat=256, widths=[256, 512, 1024], group_all=True)),
+    ("cfg3 cls_msg L1 s1", dict(b=32, n=4096, m=512, ns=16, cfeat=3, widths=[32, 32, 64], xyz_first=False)),
+    ("cfg3 cls_msg L1 s2", dict(b=32, n=4096, m=512, ns=32, cfeat=3, widths=[64, 64, 128], xyz_first=False)),
+    ("cfg3 cls_msg L1 s3", dict(b=32, n=4096, m=512, ns=128, cfeat=3, widths=[64, 96, 128], xyz_first=False)),
+    ("cfg3 cls_msg L2 s1", dict(b=32, n=512, m=128, ns=32, cfeat=320, widths=[64, 64, 128], xyz_first=False)),
+    ("cfg3 cls_msg L2 s2", dict(b=32, n=512, m=128, ns=64, cfeat=320, widths=[128, 128, 256], xyz_first=False)),
+    ("cfg3 cls_msg L2 s3", dict(b=32, n=512, m=128, ns=128, cfeat=320, widths=[128, 128, 256], xyz_first=False)),
+    ("cfg3 cls_msg L3 group_all", dict(b=32, n=128, m=1, ns=128, cfeat=640, widths=[256, 512, 1024], group_all=True)),
+    ("cfg4 part_seg SA1", dict(b=16, n=2048, m=512, ns=64, cfeat=3, widths=[64, 64, 128])),
+    ("cfg4 part_seg SA2", dict(b=16, n=512, m=128, ns=64, cfeat=128, widths=[128, 128, 256])),
+    ("cfg4 part_seg SA3 group_all", dict(b=16, n=128, m=1, ns=128, cfeat=256, widths=[256, 512, 1024], group_all=True)),
+    ("cfg4 part_seg FP1", dict(b=16, n=128, m=0, ns=0, cfeat=0, widths=[256, 256], plain_cin=1280)),
+    ("cfg4 part_seg FP2", dict(b=16, n=512, m=0, ns=0, cfeat=0, widths=[256, 128], plain_cin=384)),
+    ("cfg4 part_seg FP3", dict(b=16, n=2048, m=0, ns=0, cfeat=0, widths=[128, 128, 128], plain_cin=134)),
+    ("cfg5 sem_seg SA4", dict(b=8, n=64, m=16, ns=32, cfeat=256, widths=[256, 256, 512])),
+    ("cfg5 sem_seg FP1", dict(b=8, n=64, m=0, ns=0, cfeat=0, widths=[256, 256], plain_cin=768)),
+    ("cfg5 sem_seg FP2", dict(b=8, n=256, m=0, ns=0, cfeat=0, widths=[256, 256], plain_cin=384)),
+    ("cfg5 sem_seg FP3", dict(b=8, n=1024, m=0, ns=0, cfeat=0, widths=[256, 128], plain_cin=320)),
 ]
 
 
@@ -54,11 +73,11 @@ def test_train_stack_matches_float64(cuda, name, kw):
 # rules switch both on for big levels only, so the small shapes force them -- one case per (inputs per wave, loads per
 # thread) variant of the kernel, plus group_all's shape, which falls back to the dense tiles (128 x 512 inputs per group)
 @pytest.mark.parametrize("name,kw", [c for c in KERNEL_CASES if c[0][0] in "ABCDEGHK"], ids=[c[0] for c in KERNEL_CASES if c[0][0] in "ABCDEGHK"])
-def test_routed_top_gradient_variants(cuda, monkeypatch, name, kw):
+def test_routed_top_gradient_variants(cuda, name, kw):
+    from pointnet2_amd import train_mlp
     from scripts import train_mlp_check as T
-    monkeypatch.setenv("PN2_TL_TOP_STORED", "0")
-    monkeypatch.setenv("PN2_TL_TOP_SPARSE", "1")
-    worst = T.run_case(name, **kw)
+    with train_mlp.options(top_stored=False, top_sparse=True):
+        worst = T.run_case(name, **kw)
     assert worst <= TOL, "%s: worst relative error %.2e" % (name, worst)
 
 
@@ -205,3 +224,79 @@ def test_parameter_gradients_added_into_existing_grads(cuda):
     for (name, p), q in zip(sa.named_parameters(), ref.parameters()):
         scale = float(q.grad.abs().max())
         assert float((p.grad - q.grad).abs().max()) <= 1e-6 * max(scale, 1e-30), name
+
+
+def test_frozen_batch_norm_takes_the_layer_by_layer_path(cuda):
+    """bn.eval() inside a model in train() (fine-tuning) normalises with the RUNNING statistics and
+    must leave them alone -- not the fused path's semantics (batch statistics), so the module falls back."""
+    import pointnet2_amd.pointnet_util as U
+    torch.manual_seed(5)
+    sa = U.PointnetSAModule(16, 64, 0.4, 32, [32, 32, 64]).to(cuda).train()
+    for mod in sa.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.eval()
+            mod.running_mean.normal_()
+            mod.running_var.uniform_(0.5, 1.5)
+    before = {k: v.clone() for k, v in sa.state_dict().items()}
+    xyz = torch.rand(4, 256, 3, device=cuda)
+    feats = torch.randn(4, 256, 16, device=cuda)
+    sa(xyz, feats)
+    assert sa.last_path == "unfused"
+    for k, v in sa.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    fp = U.PointnetFPModule(32 + 4, [32, 32]).to(cuda).train()
+    fp.mlp.net[1].eval()
+    fp(xyz, xyz[:, :64].contiguous(), torch.randn(4, 256, 4, device=cuda), torch.randn(4, 64, 32, device=cuda))
+    assert fp.last_path == "unfused"
+
+
+def test_training_node_validates_shapes(cuda):
+    """a mismatch between xyz / new_xyz / idx / points would read out of bounds on the device."""
+    from pointnet2_amd import train_mlp
+    from pointnet2_amd.pointnet_util import _SharedMLP
+    net = _SharedMLP(3 + 8, [32, 32], bn=True).to(cuda).train()
+    xyz = torch.rand(2, 128, 3, device=cuda)
+    new_xyz = xyz[:, :16].contiguous()
+    idx = torch.randint(0, 128, (2, 16, 32), dtype=torch.int32, device=cuda)
+    pts = torch.randn(2, 128, 8, device=cuda)
+    train_mlp.sa_mlp_train(net.net, xyz, new_xyz, pts, idx)                                 # the consistent call
+    with pytest.raises(ValueError):
+        train_mlp.sa_mlp_train(net.net, xyz, new_xyz[:, :8].contiguous(), pts, idx)         # new_xyz (b, 8, 3) vs idx (b, 16, ns)
+    with pytest.raises(ValueError):
+        train_mlp.sa_mlp_train(net.net, xyz, new_xyz, pts, idx[:1].contiguous())            # idx batch 1 vs xyz batch 2
+    with pytest.raises(ValueError):
+        train_mlp.sa_mlp_train(net.net, xyz, new_xyz, pts[:, :64].contiguous(), idx)        # points (b, 64, c) vs xyz (b, 128, 3)
+    with pytest.raises(ValueError):
+        train_mlp.sa_mlp_train(net.net, xyz[:, :, :2].contiguous(), new_xyz, pts, idx)      # xyz not (b, n, 3)
+    fp = _SharedMLP(16, [32], bn=True).to(cuda).train()
+    with pytest.raises(ValueError):
+        train_mlp.fp_mlp_train(fp.net, torch.randn(64, 16, device=cuda))                    # rank 2
+
+
+def test_few_channel_scatter_is_reproducible_in_deterministic_mode(cuda):
+    """ADVICE round 3 (low): 3 feature channels on a small batch take neither the per-point path nor the segmented scatter;
+    in deterministic mode the point gradient must then come from the fixed-point scatter, bit-identical run to run."""
+    from pointnet2_amd import train_mlp
+    from pointnet2_amd._tensors import set_deterministic, use_segmented_grad
+    from pointnet2_amd.pointnet_util import _SharedMLP
+    torch.manual_seed(2)
+    b, n, m, ns, c = 2, 32768, 64, 32, 3
+    assert not use_segmented_grad(b, n, c)
+    net = _SharedMLP(3 + c, [32, 32], bn=True).to(cuda).train()
+    xyz = torch.rand(b, n, 3, device=cuda)
+    new_xyz = xyz[:, :m].contiguous()
+    idx = torch.randint(0, 64, (b, m, ns), dtype=torch.int32, device=cuda)                  # heavy collisions on few points
+    pts = torch.randn(b, n, c, device=cuda, requires_grad=True)
+    gw = torch.randn(b, m, 32, device=cuda)
+    set_deterministic(True)
+    try:
+        grads = []
+        for _ in range(3):
+            out, _ = train_mlp.sa_mlp_train(net.net, xyz, new_xyz, pts, idx)
+            grads.append(torch.autograd.grad((out * gw).sum(), pts)[0])
+    finally:
+        set_deterministic(False)
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+    out, _ = train_mlp.sa_mlp_train(net.net, xyz, new_xyz, pts, idx)
+    g_atomic = torch.autograd.grad((out * gw).sum(), pts)[0]
+    assert float((g_atomic - grads[0]).abs().max()) <= 1e-5 * float(grads[0].abs().max())
