@@ -65,8 +65,12 @@ CONFIG_CASES = [
 @pytest.mark.parametrize("name,kw", KERNEL_CASES + CONFIG_CASES, ids=[c[0] for c in KERNEL_CASES + CONFIG_CASES])
 def test_train_stack_matches_float64(cuda, name, kw):
     from scripts import train_mlp_check as T
-    worst = T.run_case(name, **kw)
-    assert worst <= TOL, "%s: worst relative error %.2e" % (name, worst)
+    worst = T.run_case(name, fp32_baseline=True, **kw)
+    # 1e-5 of each tensor's scale -- or, on the levels with millions of rows, twice the error torch's own fp32 evaluation of the
+    # same graph makes against the same float64 results: a per-channel sum over 2 M rows of fp32 gradients (cls_msg SA1 scale 3:
+    # dbeta 1.5e-5) carries the rounding of its 2 M terms whoever adds them. The rule of tests/test_train_fuzz_gpu.py.
+    bound = max(TOL, 2.0 * T.run_case.baseline)
+    assert worst <= bound, "%s: worst relative error %.2e (torch fp32: %.2e)" % (name, worst, T.run_case.baseline)
 
 
 # the pooled top layer without its pre-norm tensor, its routed gradient on the vector units (tl_top_s_kernel): the size
