@@ -30,7 +30,9 @@
 // depend on timing.
 #include "sa_mlp_common.h"
 
+#include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 namespace pn2 {
@@ -811,6 +813,20 @@ struct TlWgrad {
     int group_rows;
     float *partial;             // [slab][workgroup][tus * tts tiles][1024]
     int tus, tts, tslabs;       // tiles of h / of dz per slab; slabs along dz
+    // ---- the layer's DATA gradient in the same pass (template flag DY; one slab only): dy_{l-1} = (second operand) . Wt,
+    // contraction over the k tiles the block image already holds, see "One pass per layer" below
+    const u32x4 *dy_w;          // packed operand tiles [k tile][dy_nt] of Wt (tl_pack_kernel, ns = dy_nt, one slab)
+    int dy_tk, dy_nt;           // k tiles (32 channels) of the contraction / 32-column tiles of the output
+    int dy_tf;                  // D_TOP with shared h tiles: k tiles >= dy_tf are image tiles (u - dy_tf), the others tus + u
+    int dy_cols, dy_pitch;      // output columns / floats per row of dy_out and dy_zprev
+    float *dy_out;              // (rows, dy_pitch)
+    const float *dy_zprev, *dy_ea, *dy_ec;   // ReLU mask of the layer below: its pre-norm tensor and (a, c); nullptr: plain store
+    const float *dy_bias;       // constant row added to every output row (D_TOP: -r) or nullptr
+    double *dy_stats;           // (gridDim.x, 2, dy_pitch): sum dy, sum dy * zprev of this workgroup's rows, or nullptr
+    int dy_nt_store;            // streaming stores
+    int single;                 // ONE block image in LDS (two barriers per block) instead of two
+    int dy_acopy;               // the dense second-operand units also write their fragments in the data gradient's own layout
+    unsigned long long *timing; // lab builds (PN2_WG_TIMING): per-wave cycle counts of the block loop's phases, workgroup 0
 };
 
 // One UNIT of operand data = what one wave holds as the MFMA fragment of K16 step e of a 32-channel tile: lane (c, hl)
@@ -965,12 +981,36 @@ __device__ __forceinline__ void wg_load_unit(const TlWgrad &p, const WgUnit &w, 
     }
 }
 
+// Position of lane's 16-byte fragment inside a (tile, level, e) row of the block image. Plain lane order serves the weight
+// gradient (every reader takes lane's own fragment); the data gradient fused into the pass reads the image TRANSPOSED --
+// lane = row, eight 2-byte reads from eight channels' fragments -- and in plain order the 64 lanes of such a read hit
+// four banks (rows 8 apart are 128-byte multiples apart). The XOR spreads the eight (e, row half, channel half) classes
+// over the eight 16-byte bank groups; it permutes fragments inside aligned groups of eight, so the 16-byte accesses
+// stay conflict-free.
+__device__ __forceinline__ int wg_swz(int lane, int e) { return lane ^ (((lane >> 3) & 1) | (((lane >> 5) & 1) << 1) | (e << 2)); }
+
 // prologue + split of a loaded unit -> its three fragments in the block image ([tile][level][e][lane] 16-byte vectors)
+// zr != nullptr (data gradient in the same pass): the RAW rows of the first operand (the pre-norm tensor of the layer below)
+// also go to LDS as fp32 [row][channel], pitch zpitch floats -- the data gradient's epilogue needs them for the ReLU mask
+// and the batch-norm backward sums, and a global load there, however close in L2, could only return after every older
+// prefetch load (in-order return counting): it cost the two-block prefetch
+//
+// imgA != nullptr: a dense second-operand unit (dz) also leaves its three levels in the layout the DATA gradient's MFMA reads
+// as its A operand -- lane = row, eight consecutive channels per 16-byte fragment: [tile][level][K16 step q][row + 32 g] --
+// as 2-byte stores (each lane holds ONE channel of eight rows; the transposition has to happen somewhere, and here it is
+// spread over the eight producer waves instead of eight 2-byte reads per fragment in the two consumer waves). The 16-byte
+// slot index is XOR-ed with (g | hl << 1 | q << 2): without it the 64 lanes of one store hit four banks.
 template <int DCLS>
-__device__ __forceinline__ void wg_store_unit(const WgUnit &w, const WgRaw &r, int lane, u32x4 *img)
+__device__ __forceinline__ void wg_store_unit(const WgUnit &w, const WgRaw &r, int lane, u32x4 *img, float *zr = nullptr, int zpitch = 0,
+                                              u32x4 *imgA = nullptr, int tus = 0)
 {
     if (w.kind == K_NONE || w.kind == K_ONES) return;             // nothing / written once before the loop
-    u32x4 *o = img + ((size_t)w.tile * 3 * 2 + w.e) * 64 + lane;
+    if (zr && w.kind == K_H && w.relu && w.tile * 32 + 32 <= zpitch) {
+        float *zo = zr + (16 * w.e + 8 * (lane >> 5)) * zpitch + w.tile * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zo[j * zpitch] = r.z[j];
+    }
+    u32x4 *o = img + ((size_t)w.tile * 3 * 2 + w.e) * 64 + wg_swz(lane, w.e);
     if (DCLS == D_TOP && w.kind == K_FILL) {
         // one non-zero per lane (the pool routes dy to ONE row): split it once and drop its three bf16 levels into slot rel
         const int rel = r.sel - r.off;                             // the pooled sample's row inside this unit, if it is here
@@ -1014,12 +1054,36 @@ __device__ __forceinline__ void wg_store_unit(const WgUnit &w, const WgRaw &r, i
     o[0] = sp.p[0][0];
     o[128] = sp.p[0][1];
     o[256] = sp.p[0][2];
+    if (imgA && (w.kind == K_DZ || w.kind == K_DZPOOL)) {
+        const int c = lane & 31, hl = lane >> 5, q = c >> 4, g = (c >> 3) & 1, sg = g | (hl << 1) | (q << 2);
+        char *ba = reinterpret_cast<char *>(imgA) + ((size_t)(w.tile - tus) * 6 + q) * 1024 + (16 * w.e + 8 * hl + 32 * g) * 16 + (c & 7) * 2;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                char *pa = ba + (((2 * d + half) ^ sg) << 4);
+#pragma unroll
+                for (int lv = 0; lv < 3; ++lv)
+                    *reinterpret_cast<unsigned short *>(pa + lv * 2048) = (unsigned short)(half ? sp.p[0][lv][d] >> 16 : sp.p[0][lv][d] & 0xffffu);
+            }
+    }
 }
 
 // Every wave keeps the rows of the NEXT TWO blocks in flight in registers (two raw sets, the block loop is unrolled by
 // two), the block image in LDS is double buffered, one s_barrier per block.
 // TPW: output tiles per wave; UPW: operand units a wave loads per 32-row block
-template <int TPW, int UPW, bool GATHER, int DCLS>
+//
+// One pass per layer (DY): the weight gradient dW_l = h^T dz and the data gradient dy_{l-1} = (dz W_l^T) . [h > 0] consume
+// the SAME two tiles of a row block -- dz_l from (dy_l, z_l) and h_{l-1} from z_{l-1} -- so as two kernels the layer's
+// activations crossed HBM twice per direction. With DY the block image serves both: the waves that own no (or the fewest)
+// dW tiles take one 32-column tile of dy_{l-1} each. Its A operand is the image read TRANSPOSED (lane = row: eight
+// ds_read_u16 per 16-byte fragment instead of one ds_read_b128, no vector instruction but four packs -- the operand was
+// formed, split and stored once, by the unit loads), its B operand the packed W^T, LDS-resident for the whole launch;
+// the epilogue is the data-gradient GEMM's (mask of the layer below from its pre-norm tensor, the batch-norm backward
+// sums, 128-byte row stores). The dy waves run their own copy of the block loop (template ROLE): vector-memory returns
+// are counted in order, and a wait shared with waves that issue no mask loads / stores between two prefetches could
+// only be the smaller count, i.e. the dy waves would wait for half of the prefetch they just issued.
+template <int TPW, int UPW, bool GATHER, int DCLS, bool DY>
 __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1028,6 +1092,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
     const int ntiles = p.tus + p.tts, nunits = 2 * ntiles, nout = p.tus * p.tts;
     const int imgv = ntiles * 3 * 2 * 64;                           // 16-byte vectors of one block image
     u32x4 *img0 = reinterpret_cast<u32x4 *>(smem);
+    u32x4 *img1 = (DY && p.single) ? img0 : img0 + imgv;
     const long long blocks = p.rows / 32, step = gridDim.x;
     f32x16 acc[TPW];
 #pragma unroll
@@ -1036,6 +1101,8 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
         for (int v = 0; v < 16; ++v) acc[i][v] = 0.0f;
     WgRaw ra[UPW], rb[UPW];
     WgUnit un[UPW];
+    // (measured: taking the unit loads away from the waves that produce the data gradient -- the block's critical path --
+    // made the pass slower, 286 -> 306 us at the metric shape: the other waves' second unit costs more than it frees)
 #pragma unroll
     for (int i = 0; i < UPW; ++i) un[i] = wg_plan_unit(p, wave + 8 * i, nunits, us, ts, lane);
     // output tiles of this wave: image slots of their two operands (fixed)
@@ -1047,31 +1114,162 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
         xa_off[i] = u * 384;
         xb_off[i] = (shared ? tg - p.tf : p.tus + t) * 384;
     }
+    const int sw0 = wg_swz(lane, 0), sw1 = 64 + wg_swz(lane, 1);     // lane's fragment of K16 step 0 / 1 inside a (tile, level)
     const int grows = p.group_rows > 0 ? p.group_rows : 32;
-    auto load = [&](long long b, WgRaw (&r)[UPW]) {             // the same instruction sequence for every wave and block
+    // ---- data-gradient role: the LAST dy_nt waves take one output tile each (they own the fewest dW tiles)
+    const int dyt = DY ? uni(7 - wave < p.dy_nt ? 7 - wave : -1) : -1;
+    const u32x4 *wl = img0 + (size_t)((DY && p.single) ? 1 : 2) * imgv;      // packed W^T, resident
+    const int zpitch = p.tus * 32 + 2;                             // raw rows of the layer below: 8 rows apart = 16 banks apart
+    float *zr0 = DY ? reinterpret_cast<float *>(const_cast<u32x4 *>(wl) + (size_t)p.dy_tk * p.dy_nt * kPairVec) : nullptr;
+    float *zr1 = (DY && !p.single) ? zr0 + 32 * zpitch : zr0;
+    u32x4 *ia0 = (DY && p.dy_acopy) ? reinterpret_cast<u32x4 *>(zr0 + (size_t)(p.single ? 1 : 2) * 32 * zpitch) : nullptr;
+    u32x4 *ia1 = (DY && p.dy_acopy && !p.single) ? ia0 + (size_t)p.dy_tk * 384 : ia0;
+    double sd1 = 0.0, sd2 = 0.0;
+    // transposed reads: lane = row r of the block = fragment slot (e_r, half hl_r, j_r) of the image; its eight values of a
+    // K16 step are slots of eight channels' fragments: byte address = tile * 6144 + level * 2048 + 256 * (K16 step) + tb + 16 (j ^ sg)
+    int tb = 0, sg16 = 0, sa0 = 0, sa1 = 0;
+    if (DY) {
+        const int r = lane & 31, g = lane >> 5, er = r >> 4, hr = (r >> 3) & 1, jr = r & 7;
+        tb = er * 1024 + (8 * g + 32 * hr) * 16 + jr * 2;
+        sg16 = (g | (hr << 1) | (er << 2)) << 4;
+        sa0 = lane ^ (g | (hr << 1));                              // lane's fragment of K16 step 0 / 1 in the A-layout copy
+        sa1 = 64 + (lane ^ (g | (hr << 1) | 4));
+    }
+    float dy_ea = 0.0f, dy_ec = 0.0f, dy_b = 0.0f;
+    if (DY && dyt >= 0) {
+        const int col = dyt * 32 + (lane & 31);
+        dy_ec = 1.0f;                                              // no mask: y = 0 * z + 1 > 0
+        if (col < p.dy_cols) {
+            if (p.dy_zprev) { dy_ea = p.dy_ea[col]; dy_ec = p.dy_ec[col]; }
+            if (p.dy_bias) dy_b = p.dy_bias[col];
+        }
+    }
+    if (DY) {
+        u32x4 *wdst = const_cast<u32x4 *>(wl);
+        const int nv = p.dy_tk * p.dy_nt * kPairVec;
+        for (int i = threadIdx.x; i < nv; i += kTlThreads) wdst[i] = p.dy_w[i];
+        // the raw rows are only written when the first operand goes through a ReLU (a masked pass); an unmasked pass reads them
+        // too (times zero): defined values
+        const int nz = (p.single ? 1 : 2) * 32 * zpitch;
+        for (int i = threadIdx.x; i < nz; i += kTlThreads) zr0[i] = 0.0f;
+    }
+    auto load = [&](long long b, WgRaw (&r)[UPW]) __attribute__((always_inline)) {   // the same instruction sequence for every wave and block
         const bool inb = b < blocks;
         const long long row0 = (inb ? b : 0) * 32;
         const int grp_u = (int)((unsigned)row0 / (unsigned)grows), off_u = (int)row0 - grp_u * grows;
 #pragma unroll
         for (int i = 0; i < UPW; ++i) wg_load_unit<GATHER, DCLS>(p, un[i], row0, grp_u, off_u, lane, inb, r[i]);
     };
-    auto block = [&](long long b, WgRaw (&r)[UPW], u32x4 *img) {
-#pragma unroll
-        for (int i = 0; i < UPW; ++i) wg_store_unit<DCLS>(un[i], r[i], lane, img);
-        __syncthreads();
-        load(b + 2 * step, r);
+    auto tiles_of_wave = [&](const u32x4 *img) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             if (wave + 8 * i < nout) {
-                const u32x4 *xa = img + xa_off[i] + lane, *xb = img + xb_off[i] + lane;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const u32x4 a[3] = {xa[e * 64], xa[128 + e * 64], xa[256 + e * 64]};
-                    const u32x4 d[3] = {xb[e * 64], xb[128 + e * 64], xb[256 + e * 64]};
+                const u32x4 *xa = img + xa_off[i], *xb = img + xb_off[i];
+                {
+                    const u32x4 a[3] = {xa[sw0], xa[128 + sw0], xa[256 + sw0]};
+                    const u32x4 d[3] = {xb[sw0], xb[128 + sw0], xb[256 + sw0]};
+                    acc[i] = mma_x6<false>(a, d, acc[i]);
+                }
+                {
+                    const u32x4 a[3] = {xa[sw1], xa[128 + sw1], xa[256 + sw1]};
+                    const u32x4 d[3] = {xb[sw1], xb[128 + sw1], xb[256 + sw1]};
                     acc[i] = mma_x6<false>(a, d, acc[i]);
                 }
             }
         }
+    };
+    // ROLE = 1: this wave also produces tile dyt of the data gradient
+#ifdef PN2_WG_TIMING
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define PN2_TICK(K) { const unsigned long long tnow = __builtin_readcyclecounter(); tph[K] += tnow - tlast; tlast = tnow; }
+#else
+#define PN2_TICK(K)
+#endif
+    auto block = [&](long long b, WgRaw (&r)[UPW], u32x4 *img, float *zr, u32x4 *imgA, auto role) __attribute__((always_inline)) {
+        constexpr bool ROLE = decltype(role)::value;
+        PN2_TICK(5)
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) wg_store_unit<DCLS>(un[i], r[i], lane, img, zr, zpitch, imgA, p.tus);
+        PN2_TICK(0)
+        __syncthreads();
+        PN2_TICK(1)
+        const int hl = lane >> 5, col = dyt * 32 + (lane & 31);
+        const int voff = (ROLE && col < p.dy_cols) ? (4 * hl * p.dy_pitch + col) * 4 : kWgOob;
+        const int rstep = uni(p.dy_pitch * 4);
+        load(b + 2 * step, r);
+        tiles_of_wave(img);
+        PN2_TICK(2)
+        if (ROLE) {
+            f32x16 d;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) d[v] = 0.0f;
+            const char *ib = reinterpret_cast<const char *>(img) + tb;
+            if (DCLS != D_TOP && imgA) {
+                // A operand straight from the producers' A-layout copy
+                for (int u = 0; u < p.dy_tk; ++u) {
+                    const u32x4 *ta = imgA + (size_t)u * 384;
+                    ActSplit sp;
+#pragma unroll
+                    for (int lv = 0; lv < 3; ++lv) {
+                        sp.p[0][lv] = ta[lv * 128 + sa0];
+                        sp.p[1][lv] = ta[lv * 128 + sa1];
+                    }
+                    d = stream_pair<true>(wl + (size_t)u * p.dy_nt * kPairVec, dyt, lane, sp, d);
+                }
+            } else {
+                // A operand = the weight gradient's image read transposed (eight 2-byte reads per fragment)
+                for (int u = 0; u < p.dy_tk; ++u) {
+                    const int it = (DCLS == D_TOP && p.xshare && u >= p.dy_tf) ? u - p.dy_tf : p.tus + u;
+                    const char *tp = ib + (size_t)it * 6144;
+                    ActSplit sp;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int lv = 0; lv < 3; ++lv) {
+                            const char *q = tp + lv * 2048 + e * 256;
+                            unsigned h[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) h[j] = *reinterpret_cast<const unsigned short *>(q + ((j << 4) ^ sg16));
+                            u32x4 f = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+                            sp.p[e][lv] = f;
+                        }
+                    d = stream_pair<true>(wl + (size_t)u * p.dy_nt * kPairVec, dyt, lane, sp, d);
+                }
+            }
+            PN2_TICK(3)
+            // epilogue of the data-gradient GEMM: lane = column, register v = row 8 (v >> 2) + 4 hl + (v & 3). Branch-free:
+            // every row of the layer below is read from LDS up front (one wait), an unmasked pass multiplies it by zero
+            const rsrc_t ro = make_rsrc(p.dy_out + (size_t)b * 32 * p.dy_pitch, 32u * (unsigned)p.dy_pitch * 4u);
+            f32x16 zz;
+            {
+                const float *zs = zr + 4 * hl * zpitch + dyt * 32 + (lane & 31);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) zz[v] = zs[(8 * (v >> 2) + (v & 3)) * zpitch];
+            }
+            float s1 = 0.0f, s2 = 0.0f;
+            f32x16 gv;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float y = __fadd_rn(__fmul_rn(dy_ea, zz[v]), dy_ec);        // unmasked pass: ea = 0, ec = 1
+                const float g = y > 0.0f ? __fadd_rn(d[v], dy_b) : 0.0f;         // ReLU of the layer below
+                gv[v] = g;
+                s1 = __fadd_rn(s1, g);
+                s2 = fmaf(g, zz[v], s2);
+            }
+            if (p.dy_nt_store) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) bstore<true>(gv[v], ro, voff, (8 * (v >> 2) + (v & 3)) * rstep);
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) bstore<false>(gv[v], ro, voff, (8 * (v >> 2) + (v & 3)) * rstep);
+            }
+            if (voff != kWgOob) {
+                sd1 += (double)s1;
+                sd2 += (double)s2;
+            }
+            PN2_TICK(4)
+        }
+        if (DY && p.single) __syncthreads();                       // the one image is rewritten by the next block
     };
     if (DCLS == D_TOP) {
         // the column of ones (sum over the rows of h): fragment slot j of lanes with c == 0 is bf16 1.0 at level 1, constant
@@ -1081,7 +1279,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
                 const unsigned one2 = (lane & 31) == 0 ? 0x3f803f80u : 0u;
                 const u32x4 ones = {one2, one2, one2, one2}, zero = {0u, 0u, 0u, 0u};
                 for (int b = 0; b < 2; ++b) {
-                    u32x4 *o = img0 + (size_t)b * imgv + ((size_t)un[i].tile * 3 * 2 + un[i].e) * 64 + lane;
+                    u32x4 *o = (b ? img1 : img0) + ((size_t)un[i].tile * 3 * 2 + un[i].e) * 64 + wg_swz(lane, un[i].e);
                     o[0] = ones; o[128] = zero; o[256] = zero;
                 }
             }
@@ -1090,9 +1288,26 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
     long long blk = blockIdx.x;
     load(blk, ra);
     load(blk + step, rb);
-    for (; blk < blocks; blk += 2 * step) {
-        block(blk, ra, img0);
-        if (blk + step < blocks) block(blk + step, rb, img0 + imgv);      // uniform over the workgroup
+    auto run = [&](auto role) __attribute__((always_inline)) {
+        for (; blk < blocks; blk += 2 * step) {
+            block(blk, ra, img0, zr0, ia0, role);
+            if (blk + step < blocks) block(blk + step, rb, img1, zr1, ia1, role);      // uniform over the workgroup
+        }
+    };
+    if (DY && dyt >= 0) run(std::true_type{}); else run(std::false_type{});
+#ifdef PN2_WG_TIMING
+    if (p.timing && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)
+        for (int k = 0; k < 6; ++k) p.timing[wave * 6 + k] = tph[k];
+#endif
+    if (DY && dyt >= 0 && p.dy_stats) {
+        // per-channel sums of this workgroup's rows: ONE row of the (workgroups, 2, pitch) partial array, summed in a fixed
+        // order by the finalisation kernel
+        const int col = dyt * 32 + (lane & 31);
+        const double d1 = sd1 + __shfl_xor(sd1, 32), d2 = sd2 + __shfl_xor(sd2, 32);
+        if (lane < 32 && col < p.dy_cols) {
+            p.dy_stats[((size_t)blockIdx.x * 2 + 0) * p.dy_pitch + col] = d1;
+            p.dy_stats[((size_t)blockIdx.x * 2 + 1) * p.dy_pitch + col] = d2;
+        }
     }
     // dump: D[i = input channel mlp_chan(v, hl)][j = output channel lane & 31] of tile (u, t); one slab per WORKGROUP
     float4 *dst = reinterpret_cast<float4 *>(p.partial) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * nout * 256;
@@ -1603,7 +1818,7 @@ static GemmShape gemm_shape(long long rows, int K, int N, const Opts &o)
     return g;
 }
 
-struct WgradShape { int tus, tts, uslabs, tslabs, tpw, upw; long long gridx, nw, nchunks; size_t e, lds, partial_bytes, partial2_bytes; };
+struct WgradShape { int tus, tts, uslabs, tslabs, tpw, upw; long long gridx, nw, nchunks; size_t e, lds, lds_dy, partial_bytes, partial2_bytes; };
 
 static WgradShape wgrad_shape(long long rows, int KI, int NO, bool gather = false, int cus = 256)
 {
@@ -1636,10 +1851,40 @@ static WgradShape wgrad_shape(long long rows, int KI, int NO, bool gather = fals
     w.nw = gx;
     w.e = (size_t)nout * 1024;
     w.lds = (size_t)2 * (w.tus + w.tts) * 6144;
+    w.lds_dy = 0;
     w.nchunks = w.nw > 32 ? (w.nw + 31) / 32 : 0;
     w.partial_bytes = slabs * w.nw * w.e * sizeof(float);
     w.partial2_bytes = slabs * (size_t)w.nchunks * w.e * sizeof(float);
     return w;
+}
+
+// Can the layer's data gradient ride in its weight-gradient pass (tl_wgrad_kernel<.., DY>)? One slab (every tile of both
+// operands in the block image), at most four output tiles and two dW tiles per wave, and image(s) + resident W^T within the
+// CU's LDS -- with ONE image and two barriers per block when two do not fit. kc: channels of the contraction (= the second
+// operand's tiles that enter the product), ki: output columns.
+struct FuseShape { bool ok; int tk, nt, single, acopy, upw; size_t lds, pack_bytes; };
+static FuseShape fuse_shape(long long rows, const WgradShape &w, int kc, int ki, const Opts &o, bool dense = true)
+{
+    FuseShape f;
+    memset(&f, 0, sizeof(f));
+    if (o.fuse_wgrad == PN2_OPT_OFF || w.uslabs != 1 || w.tslabs != 1 || w.tpw > 2) return f;
+    // measured (scripts/lab_ab.sh fuse_wgrad): -7 % of a level's backward at 1 M rows (-25 % of the layer's two passes), -4 % at
+    // 0.5 M, nothing below -- there the passes are latency-bound and the resident W^T costs its load per workgroup
+    if (o.fuse_wgrad == PN2_OPT_AUTO && rows < (1ll << 19)) return f;
+    f.tk = tiles(kc); f.nt = tiles(ki);
+    if (f.nt > 4 || f.tk > 8) return f;
+    f.upw = w.upw;
+    f.acopy = dense ? 1 : 0;                                       // dense second operand: its fragments also in the data gradient's layout
+    const size_t img = (size_t)(w.tus + w.tts + (f.acopy ? f.tk : 0)) * 6144 + (size_t)32 * (w.tus * 32 + 2) * 4;      // operand fragments + the raw rows of the layer below
+    const size_t wb = (size_t)f.tk * f.nt * kPairWords * 4;
+    const size_t cap = (size_t)156 * 1024;
+    if (2 * img + wb <= cap) f.single = 0;
+    else if (img + wb <= cap) f.single = 1;
+    else return f;
+    f.lds = (f.single ? img : 2 * img) + wb;
+    f.pack_bytes = wb;
+    f.ok = true;
+    return f;
 }
 
 struct TlPlan {
@@ -1906,14 +2151,15 @@ static int launch_gemm(int amode, TlGemm &p, const GemmShape &g, hipStream_t st,
     return launch_gemm_ns<1>(amode, p, g, grid, st);
 }
 
-template <int TPW, bool GATHER, int DCLS>
+template <int TPW, bool GATHER, int DCLS, bool DY = false>
 static int launch_wgrad_kern(const TlWgrad &p, const WgradShape &w, dim3 grid, hipStream_t st)
 {
+    const size_t lds = DY ? w.lds_dy : w.lds;
 #define PN2_WG_CASE(U)                                                          \
     if (w.upw == U) {                                                           \
-        auto kern = tl_wgrad_kernel<TPW, U, GATHER, DCLS>;                      \
-        if (int rc = allow_dynamic_lds(kern, w.lds)) return rc;                 \
-        return launch(kern, grid, dim3(kTlThreads), w.lds, st, p);              \
+        auto kern = tl_wgrad_kernel<TPW, U, GATHER, DCLS, DY>;                  \
+        if (int rc = allow_dynamic_lds(kern, lds)) return rc;                   \
+        return launch(kern, grid, dim3(kTlThreads), lds, st, p);                \
     }
     PN2_WG_CASE(1) PN2_WG_CASE(2) PN2_WG_CASE(3)
 #undef PN2_WG_CASE
@@ -1923,6 +2169,13 @@ static int launch_wgrad_kern(const TlWgrad &p, const WgradShape &w, dim3 grid, h
 template <int TPW>
 static int launch_wgrad_tpw(const TlWgrad &p, const WgradShape &w, dim3 grid, hipStream_t st)
 {
+    if (p.dy_w) {                                                  // the data gradient in the same pass (fuse_shape: TPW <= 2, no gather)
+        if (TPW > 2 || p.amode == A_GATHER) return PN2_E_ARG;
+        constexpr int T = TPW > 2 ? 2 : TPW;
+        if (p.dmode == A_FILL) return launch_wgrad_kern<T, false, D_TOP, true>(p, w, grid, st);
+        return p.dmode == A_DZ_POOL ? launch_wgrad_kern<T, false, D_DZPOOL, true>(p, w, grid, st)
+                                    : launch_wgrad_kern<T, false, D_DZ, true>(p, w, grid, st);
+    }
     if (p.dmode == A_FILL) return launch_wgrad_kern<TPW, false, D_TOP>(p, w, grid, st);
     if (p.amode == A_GATHER)
         return p.dmode == A_DZ_POOL ? launch_wgrad_kern<TPW, true, D_DZPOOL>(p, w, grid, st)
@@ -1936,9 +2189,28 @@ static int launch_wgrad(TlWgrad &p, const WgradShape &w, float *partial2, const 
 {
     p.tus = w.tus; p.tts = w.tts; p.tslabs = w.tslabs;
     const dim3 grid((unsigned)w.gridx, (unsigned)(w.uslabs * w.tslabs));
+#ifdef PN2_WG_TIMING               /* lab build (scripts/build_mlp_labs.sh wgtime): cycles per phase and wave of workgroup 0, printed per launch */
+    static unsigned long long *tbuf = nullptr;
+    if (!tbuf) (void)hipMalloc(&tbuf, 48 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(tbuf, 0, 48 * sizeof(unsigned long long), st);
+    p.timing = tbuf;
+#endif
     int rc = w.tpw == 1 ? launch_wgrad_tpw<1>(p, w, grid, st) : w.tpw == 2 ? launch_wgrad_tpw<2>(p, w, grid, st)
                                                                              : launch_wgrad_tpw<4>(p, w, grid, st);
     if (rc) return rc;
+#ifdef PN2_WG_TIMING
+    {
+        unsigned long long h[48];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, tbuf, sizeof(h), hipMemcpyDeviceToHost);
+        const double nb = (double)((p.rows / 32 + w.gridx - 1) / w.gridx);
+        fprintf(stderr, "wgtime KI %d NO %d dy %d tus %d tts %d blocks/wg %.0f (cycles per block: units | barrier | loads+dW | dy mfma | dy epilogue | loop)\n",
+                p.KI, p.NO, p.dy_w ? 1 : 0, w.tus, w.tts, nb);
+        for (int wv = 0; wv < 8; ++wv)
+            fprintf(stderr, "  wave %d: %7.0f %7.0f %7.0f %7.0f %7.0f %7.0f\n", wv, h[wv * 6] / nb, h[wv * 6 + 1] / nb, h[wv * 6 + 2] / nb,
+                    h[wv * 6 + 3] / nb, h[wv * 6 + 4] / nb, h[wv * 6 + 5] / nb);
+    }
+#endif
     const float *src = p.partial;
     long long nw = w.nw;
     if (w.nchunks) {
@@ -2278,6 +2550,25 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
     const bool ztop = !top_stored(rows, nlayers, widths, pool_rows, o);     // pooled top layer without z_L (tl_top_mats_kernel)
     for (int l = 0; l < nlayers; ++l)
         if (!layers[l].z && !(ztop && l == nlayers - 1)) return PN2_E_NULL;
+    // Which layers run their data gradient inside the weight-gradient pass (one pass over the layer's activations instead of
+    // two, tl_wgrad_kernel<.., DY>): decided here, once, for the packing below and the launches
+    FuseShape fz[8];
+    WgradShape wz[8];
+    memset(fz, 0, sizeof(fz));
+    for (int l = 0; l < nlayers; ++l) {
+        const pn2_bn_layer &L = layers[l];
+        if (ztop && l == nlayers - 1) {
+            // (the z-free pooled top layer in one pass is correct and tested, but not yet faster than its three kernels -- 690 vs
+            // 590 us at the metric shape: two waves carry the whole data gradient, 72 MFMAs on transposed reads each -- so the
+            // size rule leaves it off; fuse_wgrad = PN2_OPT_ON forces it)
+            wz[l] = wgrad_shape(rows, L.cin, top_cols(L.cin, L.cout), false, cus);
+            if (o.fuse_wgrad == PN2_OPT_ON) fz[l] = fuse_shape(rows, wz[l], tiles(L.cout) * 32 + L.cin, L.cin, o, false);
+        } else if (!(l == 0 && (group || !want_dx))) {
+            wz[l] = wgrad_shape(rows, L.cin, L.cout, false, cus);
+            fz[l] = fuse_shape(rows, wz[l], L.cout, L.cin, o);
+        }
+        if (fz[l].ok) { wz[l].lds_dy = fz[l].lds; wz[l].upw = fz[l].upw; }
+    }
     {
         TlPackJobs jobs;                                          // W_l^T of every data-gradient GEMM, one launch
         memset(&jobs, 0, sizeof(jobs));
@@ -2285,7 +2576,12 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
         for (int l = 0; l < nlayers; ++l) {
             const pn2_bn_layer &L = layers[l];
             if ((l > 0 || want_dx) && !(ztop && l == nlayers - 1)) {      // dy_{l-1} = dz_l . W_l^T
-                if (l == 0 && group) {
+                if (fz[l].ok) {                                   // every output tile in ONE slab (the fused pass keeps W^T resident)
+                    GemmShape gg;
+                    memset(&gg, 0, sizeof(gg));
+                    gg.K = L.cout; gg.N = L.cin; gg.tk = fz[l].tk; gg.tn = fz[l].nt; gg.ns = fz[l].nt; gg.slabs = 1;
+                    add_pack_job(jobs, nj, L.weight, L.w_stride_n, L.w_stride_k, gg, base + pl.pack[l]);
+                } else if (l == 0 && group) {
                     // layer 1 of a grouped level: only the FEATURE rows of W_1 (the grouped xyz takes no gradient here);
                     // per point: the same tiles, for the GEMM over the b n points
                     const TlGather gt = make_gather(group);
@@ -2336,6 +2632,43 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 if (blocks > 4096) blocks = 4096;
                 if (int rc = launch(tl_top_mats_kernel, dim3((unsigned)blocks), dim3(256), 0, st, L.weight, L.w_stride_k, L.w_stride_n,
                                     K, NF, NFp, (const float *)coef, (const float *)nullptr, wp, rowc)) return rc;    // z_L = h W: no bias term
+            }
+            if (fz[l].ok) {
+                // ---- ONE pass over z_{l-1}: the routed gradient and h as operand tiles of the block image serve the weight
+                // gradient (S, Gram matrix, column sums: tl_top_wgrad_fix_kernel combines them) AND the data gradient
+                // dy_{l-1} = [s dy routed | h] . [W^T ; -M] - r, masked by the layer below (as separate kernels z_{l-1} crossed
+                // HBM in the data-gradient GEMM, in tl_top_s_kernel and in the Gram pass)
+                GemmShape gg;
+                memset(&gg, 0, sizeof(gg));
+                gg.K = NFp + K; gg.N = K; gg.tk = fz[l].tk; gg.tn = fz[l].nt; gg.ns = fz[l].nt; gg.slabs = 1;
+                if (int rc = launch_pack(wp, K, 1, gg, base + pl.pack[l], st)) return rc;
+                TlWgrad w;
+                memset(&w, 0, sizeof(w));
+                w.rows = rows;
+                w.KI = K;
+                w.amode = A_RELU; w.A = D.z; w.pa = D.save + 2 * D.cout; w.pc = D.save + 3 * D.cout;
+                w.dmode = A_FILL;
+                w.NO = ld; w.tf = tf; w.NF = NF;
+                w.G = gq; w.argsel = argsel; w.coef = coef; w.group_rows = pool_rows;
+                w.partial = reinterpret_cast<float *>(base + pl.partial);
+                w.xshare = 1;                                     // one slab: the "h again" tiles are the first operand's
+                w.dy_w = reinterpret_cast<const u32x4 *>(base + pl.pack[l]);
+                w.dy_tk = fz[l].tk; w.dy_nt = fz[l].nt; w.dy_tf = tf; w.single = fz[l].single;
+                w.dy_cols = K; w.dy_pitch = K;
+                w.dy_out = gnext;
+                w.dy_zprev = D.z; w.dy_ea = D.save + 2 * D.cout; w.dy_ec = D.save + 3 * D.cout;
+                w.dy_bias = rowc;
+                w.dy_stats = reinterpret_cast<double *>(base + pl.stats[l - 1]);
+                w.dy_nt_store = o.nt == PN2_OPT_OFF ? 0 : o.nt == PN2_OPT_ON ? 1 : (size_t)rows * K * sizeof(float) >= ((size_t)128 << 20);
+                if (int rc = launch_wgrad(w, wz[l], reinterpret_cast<float *>(base + pl.partial2), L, st, sf)) return rc;
+                long long blocks = ((long long)K * NF + 255) / 256;
+                if (blocks > 4096) blocks = 4096;
+                if (int rc = launch(tl_top_wgrad_fix_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const double *)sf, ld, K, NF,
+                                    tf * 32, tf * 32 + tiles(K) * 32, L.weight, L.w_stride_k, L.w_stride_n, (const float *)coef,
+                                    (const float *)nullptr, L.grad_weight, (const double *)nullptr, L.grad_accumulate)) return rc;
+                nparts[l - 1] = (int)wz[l].gridx;
+                float *tmp = gcur; gcur = gnext; gnext = tmp;
+                continue;
             }
             {
                 // weight gradient: the routed part S on the vector units (tl_top_s_kernel) when its shape allows, the Gram
@@ -2449,6 +2782,25 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
             w.coef = coef;
             w.group_rows = pool_rows;
             w.partial = reinterpret_cast<float *>(base + pl.partial);
+            if (fz[l].ok) {
+                // ... and the data gradient in the same pass over (dy_l, z_l, z_{l-1}), see tl_wgrad_kernel
+                w.dy_w = reinterpret_cast<const u32x4 *>(base + pl.pack[l]);
+                w.dy_tk = fz[l].tk; w.dy_nt = fz[l].nt; w.dy_tf = 0; w.single = fz[l].single; w.dy_acopy = fz[l].acopy;
+                w.dy_cols = L.cin; w.dy_pitch = L.cin;
+                if (l > 0) {
+                    const pn2_bn_layer &D = layers[l - 1];
+                    w.dy_out = gnext;
+                    w.dy_zprev = D.z; w.dy_ea = D.save + 2 * D.cout; w.dy_ec = D.save + 3 * D.cout;
+                    w.dy_stats = reinterpret_cast<double *>(base + pl.stats[l - 1]);
+                } else {
+                    w.dy_out = grad_x;
+                }
+                w.dy_nt_store = o.nt == PN2_OPT_OFF ? 0 : o.nt == PN2_OPT_ON ? 1 : (size_t)rows * L.cin * sizeof(float) >= ((size_t)128 << 20);
+                if (int rc = launch_wgrad(w, wz[l], reinterpret_cast<float *>(base + pl.partial2), L, st)) return rc;
+                if (l > 0) nparts[l - 1] = (int)wz[l].gridx;
+                float *tmp = gcur; gcur = gnext; gnext = tmp;
+                continue;
+            }
             const WgradShape ws_ = wgrad_shape(rows, L.cin, L.cout, w.amode == A_GATHER, cus);
             if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, st)) return rc;
         }

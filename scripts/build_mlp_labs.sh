@@ -11,7 +11,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize
 for spec in "$@"; do
     name=${spec%%:*}; defs=${spec#*:}; defs=${defs//,/ }
     ( hipcc $FLAGS $defs -c "$C/$SRC.hip" -o "$ROOT/build_lab/${SRC}_$name.o" &&
-      hipcc --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v "/$SRC.o") "$ROOT/build_lab/${SRC}_$name.o" -o "$ROOT/build_lab/libpn2ops_$name.so" &&
+      hipcc --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v "/$SRC.o" | grep -v polllab) "$ROOT/build_lab/${SRC}_$name.o" -o "$ROOT/build_lab/libpn2ops_$name.so" &&
       rm "$ROOT/build_lab/${SRC}_$name.o" ) &
 done
 wait

@@ -85,6 +85,19 @@ def test_routed_top_gradient_variants(cuda, name, kw):
     assert worst <= TOL, "%s: worst relative error %.2e" % (name, worst)
 
 
+# weight gradient and data gradient of a layer in ONE pass over its activations (tl_wgrad_kernel<.., DY>): the size rule
+# switches it on from 0.5 M rows, so the small shapes force it -- with the pooled top layer's pre-norm tensor kept (dense
+# dz tiles, their A-layout copy) and without it (routed-gradient tiles read transposed, one block image)
+@pytest.mark.parametrize("ztop", [False, True], ids=["z_L kept", "z_L free"])
+@pytest.mark.parametrize("name,kw", KERNEL_CASES, ids=[c[0] for c in KERNEL_CASES])
+def test_one_pass_backward_variants(cuda, name, kw, ztop):
+    from pointnet2_amd import train_mlp
+    from scripts import train_mlp_check as T
+    with train_mlp.options(fuse_wgrad=True, top_stored=not ztop, top_sparse=False if ztop else None):
+        worst = T.run_case(name, **kw)
+    assert worst <= TOL, "%s: worst relative error %.2e" % (name, worst)
+
+
 def _clone_module(mod):
     import copy
     return copy.deepcopy(mod)
