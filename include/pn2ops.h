@@ -362,8 +362,10 @@ typedef struct pn2_train_opts {
     int force_stream;              /* ON: weights streamed through LDS even where they would stay resident */
     int max_ns;                    /* cap on 32-column output tiles per wave: 0 (= 4), 1, 2, 4 */
     int nt;                        /* non-temporal stores: AUTO by size (outputs >= 128 MB), OFF never, ON always */
-    int fuse_wgrad;                /* weight gradient of a layer inside its data-gradient pass (one pass over the layer's
-                                      activations instead of two; AUTO: wherever the slab fits the registers), OFF: never */
+    int fuse_wgrad;                /* a layer's data gradient inside its weight-gradient pass (one pass over the layer's activations
+                                      instead of two; AUTO: from 0.5 M rows where the layer's tiles fit one slab; ON: wherever
+                                      they fit, the z-free pooled top layer included), OFF: never */
+    int wgrad_two_per_cu;          /* two weight-gradient workgroups per CU where registers and LDS allow (AUTO / ON), OFF: one */
 } pn2_train_opts;
 long long pn2_mlp_train_ws_bytes(long long rows, int nlayers, const int *widths /* cin_1, cout_1 .. cout_L */,
                                  int pool_rows, int backward,

@@ -1818,9 +1818,9 @@ static GemmShape gemm_shape(long long rows, int K, int N, const Opts &o)
     return g;
 }
 
-struct WgradShape { int tus, tts, uslabs, tslabs, tpw, upw; long long gridx, nw, nchunks; size_t e, lds, lds_dy, partial_bytes, partial2_bytes; };
+struct WgradShape { int tus, tts, uslabs, tslabs, tpw, upw, two; long long gridx, nw, nchunks; size_t e, lds, lds_dy, partial_bytes, partial2_bytes; };
 
-static WgradShape wgrad_shape(long long rows, int KI, int NO, bool gather = false, int cus = 256)
+static WgradShape wgrad_shape(long long rows, int KI, int NO, bool gather = false, int cus = 256, int two_opt = PN2_OPT_AUTO)
 {
     WgradShape w;
     const int tu = tiles(KI), tt = tiles(NO);
@@ -1844,7 +1844,15 @@ static WgradShape wgrad_shape(long long rows, int KI, int NO, bool gather = fals
     w.upw = (2 * (w.tus + w.tts) + 7) / 8;
     const size_t slabs = (size_t)w.uslabs * w.tslabs;
     const long long blocks = rows / 32;
-    long long gx = cus / (long long)slabs;                         // one workgroup per CU over all slabs
+    long long gx = cus / (long long)slabs;                         // one workgroup per CU over all slabs ...
+    // ... or TWO where a second one fits beside the first (<= 128 registers: one output tile and at most two units per wave,
+    // no gather; half the LDS): these passes run one barrier per 32-row block with little work behind it, and a second
+    // workgroup fills the waits of the first
+    // (measured, scripts/lab_ab.sh wgrad_two_per_cu: Gram pass 173 -> 124 us, layer-2 weight gradient 171 -> 140 us at the metric
+    // shape; nothing to gain below ~16 row blocks per workgroup, where the passes are a few microseconds of launch latency)
+    w.two = two_opt != PN2_OPT_OFF && w.tpw == 1 && w.upw <= 2 && !gather && (size_t)2 * (w.tus + w.tts) * 6144 <= (size_t)76 * 1024 &&
+            (two_opt == PN2_OPT_ON || blocks >= 16ll * cus);
+    if (w.two) gx *= 2;
     if (gx < 1) gx = 1;
     if (gx > (blocks + 3) / 4) gx = (blocks + 3) / 4;               // at least four row blocks per workgroup
     w.gridx = gx;
@@ -2561,10 +2569,10 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
             // (the z-free pooled top layer in one pass is correct and tested, but not yet faster than its three kernels -- 690 vs
             // 590 us at the metric shape: two waves carry the whole data gradient, 72 MFMAs on transposed reads each -- so the
             // size rule leaves it off; fuse_wgrad = PN2_OPT_ON forces it)
-            wz[l] = wgrad_shape(rows, L.cin, top_cols(L.cin, L.cout), false, cus);
+            wz[l] = wgrad_shape(rows, L.cin, top_cols(L.cin, L.cout), false, cus, PN2_OPT_OFF);
             if (o.fuse_wgrad == PN2_OPT_ON) fz[l] = fuse_shape(rows, wz[l], tiles(L.cout) * 32 + L.cin, L.cin, o, false);
         } else if (!(l == 0 && (group || !want_dx))) {
-            wz[l] = wgrad_shape(rows, L.cin, L.cout, false, cus);
+            wz[l] = wgrad_shape(rows, L.cin, L.cout, false, cus, PN2_OPT_OFF);
             fz[l] = fuse_shape(rows, wz[l], L.cout, L.cin, o);
         }
         if (fz[l].ok) { wz[l].lds_dy = fz[l].lds; wz[l].upw = fz[l].upw; }
@@ -2694,7 +2702,7 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 w.NO = ldw; w.tf = tfw; w.NF = ts.ok ? 0 : NF;
                 w.G = gq; w.argsel = argsel; w.coef = coef; w.group_rows = pool_rows;
                 w.partial = reinterpret_cast<float *>(base + pl.partial);
-                const WgradShape ws_ = wgrad_shape(rows, K, ldw, false, cus);
+                const WgradShape ws_ = wgrad_shape(rows, K, ldw, false, cus, o.wgrad_two_per_cu);
                 w.xshare = ws_.uslabs == 1;
                 if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, st, sf)) return rc;
                 long long blocks = ((long long)K * NF + 255) / 256;
@@ -2749,7 +2757,7 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 w.partial = reinterpret_cast<float *>(base + pl.partial);
                 pn2_bn_layer Lf = L;
                 Lf.grad_weight = L.grad_weight + gt.feat_off * L.w_stride_k;
-                const WgradShape ws_ = wgrad_shape(bn, gt.cfeat, L.cout, false, cus);
+                const WgradShape ws_ = wgrad_shape(bn, gt.cfeat, L.cout, false, cus, o.wgrad_two_per_cu);
                 if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), Lf, st)) return rc;
             }
             if (want_dx) {                                        // dPoints = S W1f^T
@@ -2801,7 +2809,7 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 float *tmp = gcur; gcur = gnext; gnext = tmp;
                 continue;
             }
-            const WgradShape ws_ = wgrad_shape(rows, L.cin, L.cout, w.amode == A_GATHER, cus);
+            const WgradShape ws_ = wgrad_shape(rows, L.cin, L.cout, w.amode == A_GATHER, cus, o.wgrad_two_per_cu);
             if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, st)) return rc;
         }
         // data gradient
