@@ -402,6 +402,19 @@ int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_bn_layer *l
                               const float *grad_out, float *grad_x, float *grad_feat_rows, float *grad_points,
                               int reproducible, void *ws, const pn2_train_opts *opts, void *stream);
 
+/* The input rows of a feature-propagation level's layer stack in ONE launch (pointnet_fp_module, utils/pointnet_util.py:211-219):
+ * inverse-distance weights from three_nn's `dist`, three_interpolate of points2 (b,m,c2), concatenation with the skip features
+ * points1 (b,n,c1; NULL with c1 = 0), zero columns up to `pitch` (a multiple of 4 >= c2 + c1: the training entry points read
+ * rows 16 bytes at a time) -> out (b,n,pitch); weight (b,n,3) receives the weights (needed by the gradient) unless NULL.
+ * Bit-identical to the operators: the same IEEE operations in the same order. The gradient call splits the stack's input
+ * gradient grad_x (b,n,pitch) into grad_points1 (b,n,c1; may be NULL) and the interpolated part (scratch, (b,n,c2) floats),
+ * which pn2_three_interpolate_grad_seg scatters onto grad_points2 (b,m,c2) (ws_seg: pn2_seg_grad_ws_bytes(b, m, 3 n)). */
+int pn2_fp_interp_concat(int b, int n, int m, int c2, int c1, int pitch, const float *points2, const float *points1,
+                         const int *idx, const float *dist, float *out, float *weight, void *stream);
+int pn2_fp_interp_concat_grad(int b, int n, int m, int c2, int c1, int pitch, const float *grad_x, const int *idx,
+                              const float *weight, float *grad_points2, float *grad_points1, float *scratch, void *ws_seg,
+                              int deterministic, void *stream);
+
 /* diagnostics: byte offsets inside the BACKWARD workspace of the two dy buffers ((rows, max width) each; after a
  * backward of L layers they hold dy_{L-1}, dy_{L-2}, ... alternately, starting with gb when pooled) and of the
  * per-layer (2, cout) fp64 sums / (3, cout) fp32 coefficients */

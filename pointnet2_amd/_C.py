@@ -77,6 +77,8 @@ _SIGNATURES = {
     "pn2_mlp_train_ws_layout": [_ll, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "pn2_mlp_train_forward": [_ll, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "pn2_mlp_train_backward": [_ll, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "pn2_fp_interp_concat": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pn2_fp_interp_concat_grad": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pn2_mlp_train_ws_bytes_ex": [_ll, _i, _vp, _i, _i, _vp, _vp],
     "pn2_mlp_train_layer1_per_point_ex": [_i, _vp, _vp, _vp],
     "pn2_mlp_train_top_stored_ex": [_ll, _i, _vp, _i, _vp],
@@ -91,6 +93,8 @@ _RESTYPES = {
     "pn2_sa_mlp3_ws_bytes": ctypes.c_longlong,
     "pn2_fp_mlp_ws_bytes": ctypes.c_longlong,
     "pn2_mlp_train_ws_bytes": ctypes.c_longlong,
+    "pn2_fp_interp_concat": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pn2_fp_interp_concat_grad": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pn2_mlp_train_ws_bytes_ex": ctypes.c_longlong,
     "pn2_sample_and_group_status_offset": ctypes.c_longlong,
     "pn2_ball_threshold": ctypes.c_float,

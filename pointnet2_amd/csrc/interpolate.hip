@@ -270,7 +270,102 @@ __global__ __launch_bounds__(kThreads) void three_interpolate_grad_kernel(long l
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// ---- the input rows of a feature-propagation level's layer stack in ONE launch (training path) ------------------------------
+// pointnet_fp_module, utils/pointnet_util.py:211-219: dist = max(dist, 1e-10); norm = sum(1/dist); weight = (1/dist)/norm;
+// interpolated = three_interpolate(points2, idx, weight); new_points1 = concat([interpolated, points1]). As operators that is
+// four elementwise launches for the weights, the interpolation, the concatenation and (odd widths) a zero pad; the small
+// levels of the segmentation networks are made of launch latencies. One thread per (row, four output columns); the
+// arithmetic is the operators' own, operation for operation (weights: IEEE divisions, (r1 + r2) + r3; rows:
+// (p1 w1 + p2 w2) + p3 w3 without FMA), so the result equals theirs bit for bit.
+__global__ __launch_bounds__(kThreads) void fp_interp_concat_kernel(long long chunks, int n, int m, int c2, int c1, int pitch,
+                                                                    const float *__restrict__ points2,
+                                                                    const float *__restrict__ points1,
+                                                                    const int *__restrict__ idx, const float *__restrict__ dist,
+                                                                    float *__restrict__ out, float *__restrict__ weight)
+{
+    const int pc4 = pitch / 4;
+    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < chunks; e += (long long)gridDim.x * kThreads) {
+        const long long r = e / pc4;                               // r = cloud * n + point
+        const int col = (int)(e - r * pc4) * 4;
+        const long long cloud = r / n;
+        float4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (col < c2) {
+            const int *q = idx + r * 3;
+            const float *dp = dist + r * 3;
+            const float r1 = __fdiv_rn(1.0f, fmaxf(dp[0], 1e-10f)), r2 = __fdiv_rn(1.0f, fmaxf(dp[1], 1e-10f)),
+                        r3 = __fdiv_rn(1.0f, fmaxf(dp[2], 1e-10f));                   // :212
+            const float norm = __fadd_rn(__fadd_rn(r1, r2), r3);                     // :213
+            const float w1 = __fdiv_rn(r1, norm), w2 = __fdiv_rn(r2, norm), w3 = __fdiv_rn(r3, norm);   // :215
+            if (col == 0 && weight) { weight[r * 3 + 0] = w1; weight[r * 3 + 1] = w2; weight[r * 3 + 2] = w3; }
+            const float *base = points2 + cloud * m * c2;
+            const float *pa = base + (long long)q[0] * c2, *pb = base + (long long)q[1] * c2, *pc = base + (long long)q[2] * c2;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = col + i;
+                v[i] = ch < c2 ? interp3(pa[ch], pb[ch], pc[ch], w1, w2, w3)          // :216
+                               : (ch - c2 < c1 ? points1[r * c1 + (ch - c2)] : 0.0f);   // :219 (a chunk that straddles the seam)
+            }
+            o = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = col + i - c2;
+                v[i] = k < c1 ? points1[r * c1 + k] : 0.0f;        // beyond c2 + c1: the zero pad the layer stack's 16-byte rows need
+            }
+            o = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        *reinterpret_cast<float4 *>(out + r * pitch + col) = o;
+    }
+}
+
+// backward of the concatenation: the layer stack's input gradient (rows, pitch) -> the interpolated part, contiguous (rows, c2)
+// (three_interpolate's gradient scatters it onto points2), and the skip features' part (rows, c1) = grad of points1
+__global__ __launch_bounds__(kThreads) void fp_split_grad_kernel(long long elems, int c2, int c1, int pitch,
+                                                                 const float *__restrict__ gx, float *__restrict__ gi,
+                                                                 float *__restrict__ g1)
+{
+    const int c = c2 + c1;
+    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < elems; e += (long long)gridDim.x * kThreads) {
+        const long long r = e / c;
+        const int ch = (int)(e - r * c);
+        const float v = gx[r * pitch + ch];
+        if (ch < c2) gi[r * c2 + ch] = v;
+        else if (g1) g1[r * c1 + (ch - c2)] = v;
+    }
+}
+
 }  // namespace pn2
+
+extern "C" int pn2_fp_interp_concat(int b, int n, int m, int c2, int c1, int pitch, const float *points2, const float *points1,
+                                    const int *idx, const float *dist, float *out, float *weight, void *stream)
+{
+    using namespace pn2;
+    if (b < 0 || n < 0 || m <= 0 || c2 <= 0 || c1 < 0 || pitch < c2 + c1 || pitch % 4) return PN2_E_SHAPE;
+    const long long rows = (long long)b * n;
+    if (rows == 0) return PN2_OK;
+    if (!points2 || !idx || !dist || !out || (c1 > 0 && !points1)) return PN2_E_NULL;
+    if (!aligned16(out)) return PN2_E_ARG;
+    const long long chunks = rows * (pitch / 4);
+    return launch(fp_interp_concat_kernel, dim3(grid_for(chunks)), dim3(kThreads), 0, as_stream(stream), chunks, n, m, c2, c1, pitch,
+                  points2, points1, idx, dist, out, weight);
+}
+
+extern "C" int pn2_fp_interp_concat_grad(int b, int n, int m, int c2, int c1, int pitch, const float *grad_x, const int *idx,
+                                         const float *weight, float *grad_points2, float *grad_points1, float *scratch,
+                                         void *ws_seg, int deterministic, void *stream)
+{
+    using namespace pn2;
+    if (b < 0 || n < 0 || m <= 0 || c2 <= 0 || c1 < 0 || pitch < c2 + c1) return PN2_E_SHAPE;
+    const long long rows = (long long)b * n;
+    if (rows == 0) return PN2_OK;
+    if (!grad_x || !idx || !weight || !scratch || !ws_seg || !grad_points2) return PN2_E_NULL;
+    const long long elems = rows * (c2 + (grad_points1 ? c1 : 0));
+    if (int rc = launch(fp_split_grad_kernel, dim3(grid_for(elems)), dim3(kThreads), 0, as_stream(stream), elems, c2,
+                        grad_points1 ? c1 : 0, pitch, grad_x, scratch, grad_points1)) return rc;
+    return pn2_three_interpolate_grad_seg(b, n, c2, m, scratch, idx, weight, grad_points2, ws_seg, deterministic, stream);
+}
 
 extern "C" int pn2_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx,
                             void *stream)

@@ -76,8 +76,9 @@ struct TlGemm {
     int out_pitch, col0, col1;  // E_PLAIN: columns [col0, col1) go to out[row * out_pitch + col - col0]
     double *stats;              // (2, N): E_STORE / E_POOL: sum z, sum z^2; E_MASK: sum dy, sum dy * zprev
     const float *zprev, *ea, *ec;   // E_MASK: pre-norm tensor of the layer below (rows, N) and its (a, c)
-    float *pmax, *pmin;         // E_POOL partials (rows / prow, N)
-    int *pamax, *pamin;
+    float *pmax;                // E_POOL partials (rows / prow, N): the extremum the pool will select -- the max of z where
+    int *pamax;                 // gamma >= 0, the min where gamma < 0 (batch norm + ReLU are monotone per channel) -- and its row
+    const float *pool_gamma;    // E_POOL: (N) batch-norm scale of this layer (its sign picks max or min)
     int prow;                   // 32 or 16
     int nt;                     // streaming (non-temporal) stores: outputs that do not fit the 256 MB Infinity Cache anyway
     int lab;                    // lab builds of the timing study only (PN2_TL_LAB): 1 = no stores, 2 = no statistics; 0 in production
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
         if (col < p.N) {
             if (p.emode == E_MASK) { ep0[t] = p.ea[col]; ep1[t] = p.ec[col]; }
             else if (p.emode != E_PLAIN && p.bias) ep0[t] = p.bias[col];
+            if (p.emode == E_POOL) ep1[t] = p.pool_gamma[col] >= 0.0f ? 0.0f : -0.0f;      // sign mask: the pool takes the min of z where gamma < 0
             if ((p.emode == E_MASK || p.emode == E_PLAIN) && p.bias) ep2[t] = p.bias[col];
         }
     }
@@ -488,38 +490,40 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
                     }
                 }
                 if (p.emode == E_POOL) {
-                    // max / min of z over the rows of the item -- of each half item when a group is 16 rows: registers 0-7 hold
-                    // rows 0-15, registers 8-15 rows 16-31 -- with the row number of the FIRST extremum; the other half of the
-                    // rows lives in lane l ^ 32. Fully unrolled: a runtime-indexed register array would live in scratch.
-                    float mx[2], mn[2];
-                    int ax[2], an[2];
+                    // The extremum of z over the rows of the item that the pool will select -- of each half item when a group is
+                    // 16 rows: registers 0-7 hold rows 0-15, registers 8-15 rows 16-31 -- with the row number of its FIRST
+                    // occurrence; the other half of the rows lives in lane l ^ 32. Which extremum is known at launch: batch
+                    // norm + ReLU are monotone per channel, increasing where gamma >= 0 (max), decreasing where gamma < 0 (min
+                    // = max of -z: one sign flip per value instead of a second compare / select chain and a second pair of
+                    // partial arrays). Fully unrolled: a runtime-indexed register array would live in scratch.
+                    const unsigned sgn = __float_as_uint(ep1[t]);
+                    float mx[2];
+                    int ax[2];
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
-                        mx[hf] = val[8 * hf]; mn[hf] = mx[hf]; ax[hf] = 8 * hf; an[hf] = 8 * hf;
+                        mx[hf] = __uint_as_float(__float_as_uint(val[8 * hf]) ^ sgn); ax[hf] = 8 * hf;
 #pragma unroll
                         for (int v = 8 * hf + 1; v < 8 * hf + 8; ++v) {
-                            if (val[v] > mx[hf]) { mx[hf] = val[v]; ax[hf] = v; }
-                            if (val[v] < mn[hf]) { mn[hf] = val[v]; an[hf] = v; }
+                            const float q = __uint_as_float(__float_as_uint(val[v]) ^ sgn);
+                            if (q > mx[hf]) { mx[hf] = q; ax[hf] = v; }
                         }
                     }
                     if (p.prow != 16) {                            // one group: registers 8-15 come after 0-7 in row order
                         if (mx[1] > mx[0]) { mx[0] = mx[1]; ax[0] = ax[1]; }
-                        if (mn[1] < mn[0]) { mn[0] = mn[1]; an[0] = an[1]; }
                     }
                     const int halves = p.prow == 16 ? 2 : 1;
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
                         if (hf < halves) {
-                            float bx = mx[hf], bn = mn[hf];
-                            int rx = mlp_chan(ax[hf], hl), rn = mlp_chan(an[hf], hl);
-                            const float omx = __shfl_xor(bx, 32), omn = __shfl_xor(bn, 32);
-                            const int orx = __shfl_xor(rx, 32), orn = __shfl_xor(rn, 32);
+                            float bx = mx[hf];
+                            int rx = mlp_chan(ax[hf], hl);
+                            const float omx = __shfl_xor(bx, 32);
+                            const int orx = __shfl_xor(rx, 32);
                             if (omx > bx || (omx == bx && orx < rx)) { bx = omx; rx = orx; }
-                            if (omn < bn || (omn == bn && orn < rn)) { bn = omn; rn = orn; }
                             if (ok && hl == 0) {
                                 const size_t o = (size_t)(eitem * halves + hf) * p.N + col;
-                                p.pmax[o] = bx; p.pmin[o] = bn;
-                                p.pamax[o] = rx - hf * 16; p.pamin[o] = rn - hf * 16;
+                                p.pmax[o] = __uint_as_float(__float_as_uint(bx) ^ sgn);
+                                p.pamax[o] = rx - hf * 16;
                             }
                         }
                     }
@@ -697,10 +701,10 @@ __global__ __launch_bounds__(256) void tl_bn_backward_finalize_kernel(const doub
     coef[2 * N + c] = (float)c1;
 }
 
-// pool: partial extrema of z -> out = relu(a zsel + c), the sample the gradient flows to, zsel (a >= 0: the max, else the min)
+// pool: partial extrema of z (the max where gamma >= 0, else the min) -> out = relu(a zsel + c), the sample the gradient flows to, zsel
 __global__ void tl_pool_finalize_kernel(long long groups, int N, int parts, int prow, const float *__restrict__ pmax,
-                                        const float *__restrict__ pmin, const int *__restrict__ pamax,
-                                        const int *__restrict__ pamin, const float *__restrict__ save,
+                                        const int *__restrict__ pamax, const float *__restrict__ gamma,
+                                        const float *__restrict__ save,
                                         float *__restrict__ out, int *__restrict__ argsel, float *__restrict__ zsel)
 {
     const long long total = groups * N;
@@ -708,13 +712,13 @@ __global__ void tl_pool_finalize_kernel(long long groups, int N, int parts, int 
         const long long g = i / N;
         const int c = (int)(i - g * N);
         const float a = save[2 * N + c], cc = save[3 * N + c];
-        const bool up = a >= 0.0f;
+        const bool up = gamma[c] >= 0.0f;                          // the rule of the GEMM epilogue that wrote the partials
         float best = 0.0f;
         int arg = 0;
         for (int q = 0; q < parts; ++q) {
             const size_t o = (size_t)(g * parts + q) * N + c;
-            const float v = up ? pmax[o] : pmin[o];
-            const int r = (up ? pamax[o] : pamin[o]) + q * prow;
+            const float v = pmax[o];
+            const int r = pamax[o] + q * prow;
             if (q == 0 || (up ? v > best : v < best)) { best = v; arg = r; }
         }
         out[i] = vmax(__fadd_rn(__fmul_rn(a, best), cc), 0.0f);
@@ -1899,7 +1903,7 @@ struct TlPlan {
     size_t pack[8];             // forward: W_l; backward: W_l^T
     size_t stats[8];            // (2, cout_l) doubles
     size_t coef[8];             // backward: (3, cout_l) floats
-    size_t pool;                // forward: pmax, pmin, pamax, pamin (4 arrays of parts_total x cout_L)
+    size_t pool;                // forward: pmax, pamax (2 arrays of parts_total x cout_L)
     size_t gq;                  // backward, pooled: (groups, cout_L)
     size_t ga, gb;              // backward: dy ping-pong (rows, max width)
     size_t partial, partial2;   // backward: weight-gradient partial sums
@@ -2015,7 +2019,7 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
     if (!backward) {
         if (pool_rows) {
             const long long parts = rows / (pool_rows == 16 ? 16 : 32);
-            pl.pool = off; off = align_up(off + (size_t)4 * parts * cl * 4);
+            pl.pool = off; off = align_up(off + (size_t)2 * parts * cl * 4);
         }
     } else {
         if (pool_rows) { pl.gq = off; off = align_up(off + (size_t)(rows / pool_rows) * cl * 4); }
@@ -2495,9 +2499,9 @@ extern "C" int pn2_mlp_train_forward_ex(long long rows, int nlayers, const pn2_b
         if (p.emode == E_POOL) {
             const long long parts = rows / (pool_rows == 16 ? 16 : 32);
             float *pp = reinterpret_cast<float *>(base + pl.pool);
-            p.pmax = pp; p.pmin = pp + parts * L.cout;
-            p.pamax = reinterpret_cast<int *>(pp + 2 * parts * L.cout);
-            p.pamin = reinterpret_cast<int *>(pp + 3 * parts * L.cout);
+            p.pmax = pp;
+            p.pamax = reinterpret_cast<int *>(pp + parts * L.cout);
+            p.pool_gamma = L.gamma;
             p.prow = pool_rows == 16 ? 16 : 32;
         }
         int nparts = 0;
@@ -2511,7 +2515,7 @@ extern "C" int pn2_mlp_train_forward_ex(long long rows, int nlayers, const pn2_b
             long long blocks = (groups * L.cout + 255) / 256;
             if (blocks > 4096) blocks = 4096;
             if (int rc = launch(tl_pool_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, st, groups, L.cout, pool_rows / prow,
-                                prow, (const float *)p.pmax, (const float *)p.pmin, (const int *)p.pamax, (const int *)p.pamin,
+                                prow, (const float *)p.pmax, (const int *)p.pamax, (const float *)L.gamma,
                                 (const float *)L.save, out, argsel, zsel)) return rc;
         } else if (last) {
             const long long total4 = rows * L.cout / 4;

@@ -37,8 +37,8 @@ def test_workspace_query_covers_the_reference_levels(name, rows, widths, pool, g
     # backward holds two dy buffers of the widest layer; nothing else scales with rows x width
     two_dy = 2 * rows * max(widths[1:]) * 4
     assert two_dy <= bwd <= two_dy + (320 << 20), (fwd, bwd, two_dy)
-    # forward: pool partials (four arrays, one row per 32 rows) + packed weights + partial sums: far below one activation tensor
-    assert fwd <= 4 * (rows // 16) * widths[-1] * 4 + (64 << 20)
+    # forward: pool partials (two arrays, one row per 16 / 32 rows) + packed weights + partial sums: far below one activation tensor
+    assert fwd <= 2 * (rows // 16) * widths[-1] * 4 + (64 << 20)
 
 
 def test_workspace_query_refuses_what_the_kernels_do_not_cover():
