@@ -406,7 +406,8 @@ int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_bn_layer *l
  * inverse-distance weights from three_nn's `dist`, three_interpolate of points2 (b,m,c2), concatenation with the skip features
  * points1 (b,n,c1; NULL with c1 = 0), zero columns up to `pitch` (a multiple of 4 >= c2 + c1: the training entry points read
  * rows 16 bytes at a time) -> out (b,n,pitch); weight (b,n,3) receives the weights (needed by the gradient) unless NULL.
- * Bit-identical to the operators: the same IEEE operations in the same order. The gradient call splits the stack's input
+ * The operators' formulas in IEEE fp32 (agreement with the composition of torch elementwise kernels + pn2_three_interpolate:
+ * 2e-6 of the tensor's scale, tests/test_fp_train_gpu.py). The gradient call splits the stack's input
  * gradient grad_x (b,n,pitch) into grad_points1 (b,n,c1; may be NULL) and the interpolated part (scratch, (b,n,c2) floats),
  * which pn2_three_interpolate_grad_seg scatters onto grad_points2 (b,m,c2) (ws_seg: pn2_seg_grad_ws_bytes(b, m, 3 n)). */
 int pn2_fp_interp_concat(int b, int n, int m, int c2, int c1, int pitch, const float *points2, const float *points1,

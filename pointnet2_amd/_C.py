@@ -93,8 +93,6 @@ _RESTYPES = {
     "pn2_sa_mlp3_ws_bytes": ctypes.c_longlong,
     "pn2_fp_mlp_ws_bytes": ctypes.c_longlong,
     "pn2_mlp_train_ws_bytes": ctypes.c_longlong,
-    "pn2_fp_interp_concat": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "pn2_fp_interp_concat_grad": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pn2_mlp_train_ws_bytes_ex": ctypes.c_longlong,
     "pn2_sample_and_group_status_offset": ctypes.c_longlong,
     "pn2_ball_threshold": ctypes.c_float,

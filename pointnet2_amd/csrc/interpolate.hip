@@ -276,7 +276,7 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 // four elementwise launches for the weights, the interpolation, the concatenation and (odd widths) a zero pad; the small
 // levels of the segmentation networks are made of launch latencies. One thread per (row, four output columns); the
 // arithmetic is the operators' own, operation for operation (weights: IEEE divisions, (r1 + r2) + r3; rows:
-// (p1 w1 + p2 w2) + p3 w3 without FMA), so the result equals theirs bit for bit.
+// (p1 w1 + p2 w2) + p3 w3 without FMA); against torch's elementwise kernels the weights may differ in the last place.
 __global__ __launch_bounds__(kThreads) void fp_interp_concat_kernel(long long chunks, int n, int m, int c2, int c1, int pitch,
                                                                     const float *__restrict__ points2,
                                                                     const float *__restrict__ points1,

@@ -18,7 +18,8 @@ import torch.nn as nn
 from .tf_sampling import farthest_point_sample, farthest_point_sample_gather, gather_point
 from .tf_grouping import (query_ball_point, group_point, knn_point, query_ball_group_xyz,
                           query_ball_group_xyz_msg, sample_and_group_xyz)
-from .tf_interpolate import three_nn, three_interpolate
+from .tf_interpolate import three_nn, three_interpolate, fp_interp_concat
+from ._tensors import use_segmented_grad
 from . import sa_mlp
 from . import train_mlp
 
@@ -426,6 +427,16 @@ class PointnetFPModule(nn.Module):
                 self._lvl_buffers = sa_mlp.LevelBuffers()
             return sa_mlp.fp_level(xyz1, xyz2, points1, points2, self._packed(points2.shape[2], c1, kind, points2.device),
                                    self._lvl_buffers if self.reuse_buffers else None)
+        if self.fused_mlp and self.training and points2.is_cuda and use_segmented_grad(points2.shape[0], points2.shape[1], points2.shape[2]) and \
+                train_mlp.stack_supported(self.mlp.net, xyz1.shape[0] * xyz1.shape[1], 0, False):
+            # training: three_nn, then ONE launch for weights + interpolation + concatenation (+ the zero pad of an odd width),
+            # then the layer stack with batch-statistics batch norm as one autograd node (train_mlp.py); backward: the stack's
+            # kernels, one split + the segmented scatter of three_interpolate's gradient
+            self.last_path = "fused_train"
+            dist, idx = three_nn(xyz1, xyz2)                                    # :211
+            x, _ = fp_interp_concat(points2, points1, idx, dist)                # :212-219
+            c = points2.shape[2] + (points1.shape[2] if points1 is not None else 0)
+            return train_mlp.fp_mlp_train(self.mlp.net, x, cin=c)
         idx, weight = three_nn_weights(xyz1, xyz2)                              # :211-215
         interpolated = three_interpolate(points2, idx, weight)                  # :216
         x = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated   # :219

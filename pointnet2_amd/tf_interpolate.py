@@ -101,3 +101,65 @@ def three_interpolate(points, idx, weight, out=None):
         require(not (points.requires_grad and torch.is_grad_enabled()), "out= is for inference: points requires grad")
         return _three_interpolate_launch(points, idx, weight, out)
     return _ThreeInterpolate.apply(points, idx, weight)
+
+
+class _FPInterpConcat(torch.autograd.Function):
+    """inputs: points2 (b,m,c2), points1 (b,n,c1) or None, idx (b,n,3) i32, dist (b,n,3) f32 (three_nn's), pitch."""
+
+    @staticmethod
+    def forward(ctx, points2, points1, idx, dist, pitch):
+        b, m, c2 = points2.shape
+        n = idx.shape[1]
+        c1 = points1.shape[2] if points1 is not None else 0
+        dev = points2.device
+        out = torch.empty((b, n, pitch), dtype=torch.float32, device=dev)
+        weight = torch.empty((b, n, 3), dtype=torch.float32, device=dev)
+        with on_device(dev):
+            _C.check(_C.lib().pn2_fp_interp_concat(b, n, m, c2, c1, pitch, ptr(points2), ptr(points1), ptr(idx), ptr(dist),
+                                                   ptr(out), ptr(weight), stream_ptr(dev)), "fp_interp_concat")
+        ctx.save_for_backward(idx, weight)
+        ctx.dims = (b, n, m, c2, c1, pitch)
+        ctx.mark_non_differentiable(weight)
+        return out, weight
+
+    @staticmethod
+    def backward(ctx, grad_x, _unused):
+        idx, weight = ctx.saved_tensors
+        b, n, m, c2, c1, pitch = ctx.dims
+        grad_x = f32(grad_x, "grad_x")
+        dev = grad_x.device
+        need2, need1 = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and c1 > 0
+        g2 = torch.empty((b, m, c2), dtype=torch.float32, device=dev)                 # zero-filled by the library
+        g1 = torch.empty((b, n, c1), dtype=torch.float32, device=dev) if need1 else None
+        scratch = torch.empty((b, n, c2), dtype=torch.float32, device=dev)
+        ws = seg_workspace(_C.lib(), b, m, 3 * n, dev)
+        with on_device(dev):
+            _C.check(_C.lib().pn2_fp_interp_concat_grad(b, n, m, c2, c1, pitch, ptr(grad_x), ptr(idx), ptr(weight), ptr(g2), ptr(g1),
+                                                        ptr(scratch), ptr(ws), 1 if is_deterministic() else 0, stream_ptr(dev)),
+                     "fp_interp_concat_grad")
+        return (g2 if need2 else None), g1, None, None, None
+
+
+def fp_interp_concat(points2, points1, idx, dist, pad_to=4):
+    """The input rows of pointnet_fp_module's layer stack (pointnet_util.py:211-219) in ONE launch: inverse-distance weights
+    from three_nn's squared distances, three_interpolate(points2, idx, weight), concat with the skip features points1 (or
+    None), zero columns up to a multiple of `pad_to`. -> x (b, n, pitch), weight (b, n, 3). Same formulas as the operators;
+    differentiable w.r.t. points2 and points1 (one launch for the split + the segmented scatter of three_interpolate's
+    gradient)."""
+    points2 = f32(points2, "points2")
+    idx = i32(idx, "idx")
+    dist = f32(dist, "dist")
+    require(points2.dim() == 3, "ThreeInterpolate expects (b,m,c) points shape")
+    b = points2.shape[0]
+    require(idx.dim() == 3 and idx.shape[0] == b and idx.shape[2] == 3, "ThreeInterpolate expects (b,n,3) idx shape")
+    require(dist.shape == idx.shape, "ThreeInterpolate expects (b,n,3) weight shape")
+    c = points2.shape[2]
+    if points1 is not None:
+        points1 = f32(points1, "points1")
+        require(points1.dim() == 3 and tuple(points1.shape[:2]) == (b, idx.shape[1]), "points1 must be (b, n, c1)")
+        c += points1.shape[2]
+        same_device(points2, points1, idx, dist)
+    else:
+        same_device(points2, idx, dist)
+    pitch = (c + pad_to - 1) // pad_to * pad_to
+    return _FPInterpConcat.apply(points2, points1, idx, dist, pitch)

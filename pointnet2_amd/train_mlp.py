@@ -404,13 +404,20 @@ def sa_mlp_train(net, xyz, new_xyz, points, idx, xyz_first=True):
     return out.view(b, lv.m, -1), argsel.view(b, lv.m, -1)
 
 
-def fp_mlp_train(net, x):
-    """Training-mode shared MLP of one FP level on plain rows: x (b, n, cin) -> (b, n, cout)."""
+def fp_mlp_train(net, x, cin=None):
+    """Training-mode shared MLP of one FP level on plain rows: x (b, n, cin) -> (b, n, cout).
+    cin: the first layer's input width when x already carries zero columns up to a multiple of 4 behind it
+    (tf_interpolate.fp_interp_concat writes them); default: x's own width (padded here if odd)."""
     pairs = conv_bn_pairs(net)
     require(pairs is not None, "fp_mlp_train expects Conv 1x1 + BatchNorm + ReLU triples")
     x = f32(x, "x")
     require(x.dim() == 3, "x must be (b, n, cin), got %s" % (tuple(x.shape),))
     b, n, c = x.shape
+    if cin is not None and cin != c:
+        require(cin < c and c % 4 == 0 and c - cin < 4, "x must be cin columns zero-padded to a multiple of 4")
+        prepadded, c = True, cin
+    else:
+        prepadded = False
     same_device(x, pairs[0][0].weight)
     lv = _Level()
     lv.pairs, lv.grouped, lv.xyz_first = pairs, False, True
@@ -420,12 +427,13 @@ def fp_mlp_train(net, x):
     require(stack_supported(net, lv.rows, 0, False), "unsupported stack for the fused training path")
     require(pairs[0][0].in_channels == c, "the first layer expects %d channels, got %d" % (pairs[0][0].in_channels, c))
     params = _params(pairs)
-    x = x.reshape(b * n, c)
+    x = x.reshape(b * n, x.shape[2])
     if c % 4:
         # the kernels read rows 16 bytes at a time: zero columns up to a multiple of 4 on the input and on the first
         # layer's weight (autograd slices both gradients back); part_seg's last level has 128 + 6 channels
         pad = 4 - c % 4
-        x = torch.nn.functional.pad(x, (0, pad))
+        if not prepadded:
+            x = torch.nn.functional.pad(x, (0, pad))
         w = params[0]
         params[0] = torch.nn.functional.pad(w, (0, 0) * (w.dim() - 2) + (0, pad))
     out = _TrainMLP.apply(lv, x, *params)
