@@ -830,6 +830,14 @@ struct TlWgrad {
     int dy_nt_store;            // streaming stores
     int single;                 // ONE block image in LDS (two barriers per block) instead of two
     int dy_acopy;               // the dense second-operand units also write their fragments in the data gradient's own layout
+    // Layer 1 of a level WITHOUT features below this layer (its input is the three centred coordinates x of a row): the
+    // data gradient produced here is dy_1, and all that is wanted from it is dW_1 = x^T dz_1. With dz_1 = s dy_1 - c0 - c1 z_1
+    // and z_1 = x W_1:   dW_1 = s (x^T dy_1) - c0 (x^T 1) - c1 ((x^T x) W_1)   -- the last two from nine moments of x, the
+    // first accumulated HERE from the epilogue's registers. dy_1 is then never written and the pass over (dy_1, z_1) that
+    // formed dW_1 (tl_l1_dz_kernel) disappears.
+    const float4 *l1x;          // (rows) centred coordinates of every row, w = 0 (tl_l1_xrows_kernel) or nullptr
+    double *l1a;                // (gridDim.x, 3, dy_pitch): sum over this workgroup's rows of x[k] * dy[.][col]
+    int xr_off;                 // byte offset of the coordinate rows in LDS
     unsigned long long *timing; // lab builds (PN2_WG_TIMING): per-wave cycle counts of the block loop's phases, workgroup 0
 };
 
@@ -1087,7 +1095,7 @@ __device__ __forceinline__ void wg_store_unit(const WgUnit &w, const WgRaw &r, i
 // sums, 128-byte row stores). The dy waves run their own copy of the block loop (template ROLE): vector-memory returns
 // are counted in order, and a wait shared with waves that issue no mask loads / stores between two prefetches could
 // only be the smaller count, i.e. the dy waves would wait for half of the prefetch they just issued.
-template <int TPW, int UPW, bool GATHER, int DCLS, bool DY>
+template <int TPW, int UPW, bool GATHER, int DCLS, bool DY, bool L1X = false>
 __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1128,6 +1136,11 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
     float *zr1 = (DY && !p.single) ? zr0 + 32 * zpitch : zr0;
     u32x4 *ia0 = (DY && p.dy_acopy) ? reinterpret_cast<u32x4 *>(zr0 + (size_t)(p.single ? 1 : 2) * 32 * zpitch) : nullptr;
     u32x4 *ia1 = (DY && p.dy_acopy && !p.single) ? ia0 + (size_t)p.dy_tk * 384 : ia0;
+    // centred coordinates of the block's rows (l1x): two blocks ahead in registers like the units, 32 x 16 bytes per image
+    float4 *xr0 = DY ? reinterpret_cast<float4 *>(reinterpret_cast<char *>(smem) + p.xr_off) : nullptr;
+    float4 *xr1 = (DY && !p.single) ? xr0 + 32 : xr0;
+    float4 xpa = {0.f, 0.f, 0.f, 0.f}, xpb = {0.f, 0.f, 0.f, 0.f};
+    double sda[3] = {0.0, 0.0, 0.0};
     double sd1 = 0.0, sd2 = 0.0;
     // transposed reads: lane = row r of the block = fragment slot (e_r, half hl_r, j_r) of the image; its eight values of a
     // K16 step are slots of eight channels' fragments: byte address = tile * 6144 + level * 2048 + 256 * (K16 step) + tb + 16 (j ^ sg)
@@ -1189,11 +1202,17 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
 #else
 #define PN2_TICK(K)
 #endif
-    auto block = [&](long long b, WgRaw (&r)[UPW], u32x4 *img, float *zr, u32x4 *imgA, auto role) __attribute__((always_inline)) {
+    auto xload = [&](long long b) __attribute__((always_inline)) {      // rows of block b (an empty descriptor when there are none: no branch)
+        const bool inb = b < blocks && p.l1x != nullptr;
+        const rsrc_t rx = make_rsrc(inb ? p.l1x + (size_t)b * 32 : nullptr, inb ? 512u : 0u);
+        return bload4(rx, (lane & 31) * 16, 0);
+    };
+    auto block = [&](long long b, WgRaw (&r)[UPW], u32x4 *img, float *zr, u32x4 *imgA, float4 *xr, float4 &xp, auto role) __attribute__((always_inline)) {
         constexpr bool ROLE = decltype(role)::value;
         PN2_TICK(5)
 #pragma unroll
         for (int i = 0; i < UPW; ++i) wg_store_unit<DCLS>(un[i], r[i], lane, img, zr, zpitch, imgA, p.tus);
+        if (L1X && ROLE && dyt == 0 && lane < 32) xr[lane] = xp;
         PN2_TICK(0)
         __syncthreads();
         PN2_TICK(1)
@@ -1201,6 +1220,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
         const int voff = (ROLE && col < p.dy_cols) ? (4 * hl * p.dy_pitch + col) * 4 : kWgOob;
         const int rstep = uni(p.dy_pitch * 4);
         load(b + 2 * step, r);
+        if (L1X && ROLE && dyt == 0) xp = xload(b + 2 * step);
         tiles_of_wave(img);
         PN2_TICK(2)
         if (ROLE) {
@@ -1243,7 +1263,9 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
             PN2_TICK(3)
             // epilogue of the data-gradient GEMM: lane = column, register v = row 8 (v >> 2) + 4 hl + (v & 3). Branch-free:
             // every row of the layer below is read from LDS up front (one wait), an unmasked pass multiplies it by zero
-            const rsrc_t ro = make_rsrc(p.dy_out + (size_t)b * 32 * p.dy_pitch, 32u * (unsigned)p.dy_pitch * 4u);
+            // (dy_out == nullptr: an empty descriptor -- the stores below are issued and dropped, the instruction stream stays the same)
+            const rsrc_t ro = make_rsrc(p.dy_out ? p.dy_out + (size_t)b * 32 * p.dy_pitch : nullptr,
+                                        p.dy_out ? 32u * (unsigned)p.dy_pitch * 4u : 0u);
             f32x16 zz;
             {
                 const float *zs = zr + 4 * hl * zpitch + dyt * 32 + (lane & 31);
@@ -1260,7 +1282,21 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
                 s1 = __fadd_rn(s1, g);
                 s2 = fmaf(g, zz[v], s2);
             }
-            if (p.dy_nt_store) {
+            if (L1X) {
+                // layer 1 below has the three coordinates as its input: dy's product with the rows' coordinates is what its
+                // weight gradient needs (see TlWgrad::l1x); dy itself is not written
+                float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float4 xv = xr[8 * (v >> 2) + 4 * hl + (v & 3)];      // the same address in 32 lanes: LDS broadcast
+                    a0 = fmaf(xv.x, gv[v], a0);
+                    a1 = fmaf(xv.y, gv[v], a1);
+                    a2 = fmaf(xv.z, gv[v], a2);
+                }
+                if (voff != kWgOob) { sda[0] += (double)a0; sda[1] += (double)a1; sda[2] += (double)a2; }
+            }
+            if (L1X) {
+            } else if (p.dy_nt_store) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) bstore<true>(gv[v], ro, voff, (8 * (v >> 2) + (v & 3)) * rstep);
             } else {
@@ -1292,10 +1328,11 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
     long long blk = blockIdx.x;
     load(blk, ra);
     load(blk + step, rb);
+    if (L1X && DY && dyt == 0) { xpa = xload(blk); xpb = xload(blk + step); }
     auto run = [&](auto role) __attribute__((always_inline)) {
         for (; blk < blocks; blk += 2 * step) {
-            block(blk, ra, img0, zr0, ia0, role);
-            if (blk + step < blocks) block(blk + step, rb, img1, zr1, ia1, role);      // uniform over the workgroup
+            block(blk, ra, img0, zr0, ia0, xr0, xpa, role);
+            if (blk + step < blocks) block(blk + step, rb, img1, zr1, ia1, xr1, xpb, role);      // uniform over the workgroup
         }
     };
     if (DY && dyt >= 0) run(std::true_type{}); else run(std::false_type{});
@@ -1311,6 +1348,14 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
         if (lane < 32 && col < p.dy_cols) {
             p.dy_stats[((size_t)blockIdx.x * 2 + 0) * p.dy_pitch + col] = d1;
             p.dy_stats[((size_t)blockIdx.x * 2 + 1) * p.dy_pitch + col] = d2;
+        }
+    }
+    if (L1X && DY && dyt >= 0 && p.l1a) {
+        const int col = dyt * 32 + (lane & 31);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double a = sda[k] + __shfl_xor(sda[k], 32);
+            if (lane < 32 && col < p.dy_cols) p.l1a[((size_t)blockIdx.x * 3 + k) * p.dy_pitch + col] = a;
         }
     }
     // dump: D[i = input channel mlp_chan(v, hl)][j = output channel lane & 31] of tile (u, t); one slab per WORKGROUP
@@ -1763,6 +1808,86 @@ __global__ __launch_bounds__(256) void tl_l1_wx_reduce_kernel(const float *__res
     gw[k * sk + col * sn] = accumulate ? __fadd_rn(gw[k * sk + col * sn], (float)sum) : (float)sum;
 }
 
+// ---- layer 1 of a level without features, weight gradient from moments (TlWgrad::l1x) ----------------------------------------
+// the centred coordinates of every row as (x, y, z, 0) -- the layer above's one-pass backward reads them 16 bytes per row
+// instead of gathering through idx -- and the nine moments sum x, sum x x^T of this workgroup's rows (fp64)
+__global__ __launch_bounds__(256) void tl_l1_xrows_kernel(const TlL1 p, float4 *__restrict__ xg, double *__restrict__ mom)
+{
+    double s[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s[i] = 0.0;
+    const unsigned rows = (unsigned)p.rows;
+    for (unsigned r = blockIdx.x * 256u + threadIdx.x; r < rows; r += gridDim.x * 256u) {
+        const unsigned grp = r / (unsigned)p.nsample;
+        const size_t pt = (size_t)(grp / (unsigned)p.m) * p.n + p.idx[r];
+        const float *px = p.xyz + pt * 3;
+        float x0 = px[0], x1 = px[1], x2 = px[2];
+        if (p.new_xyz) {
+            const float *pc = p.new_xyz + (size_t)grp * 3;
+            x0 = __fsub_rn(x0, pc[0]); x1 = __fsub_rn(x1, pc[1]); x2 = __fsub_rn(x2, pc[2]);      // pointnet_util.py:46
+        }
+        xg[r] = make_float4(x0, x1, x2, 0.0f);
+        const double d0 = x0, d1 = x1, d2 = x2;
+        s[0] += d0; s[1] += d1; s[2] += d2;
+        s[3] += d0 * d0; s[4] += d0 * d1; s[5] += d0 * d2; s[6] += d1 * d1; s[7] += d1 * d2; s[8] += d2 * d2;
+    }
+    __shared__ double red[9][256];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) red[i][threadIdx.x] = s[i];
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        double a = 0.0;
+        for (int t = 0; t < 256; ++t) a += red[threadIdx.x][t];
+        mom[(size_t)blockIdx.x * 9 + threadIdx.x] = a;
+    }
+}
+
+// dW_1[k][c] = s_c A[k][c] - c0_c (sum x_k) - c1_c ((sum x x^T) W_1)[k][c] in fp64. A block of 256 threads owns 8 of the 3 C
+// entries and adds the partial rows 32 at a time, in a fixed order (a thread per entry walking 256 rows was 160 us of
+// dependent L2 latencies); every block sums the nine moments itself the same way.
+__global__ __launch_bounds__(256) void tl_l1_wx_combine_kernel(const double *__restrict__ mom, int nmom, const double *__restrict__ l1a,
+                                                               int nparts, int C, int pitch, const float *__restrict__ coef,
+                                                               const float *__restrict__ wx, long long skx, long long sn,
+                                                               float *__restrict__ gw, int accumulate)
+{
+    __shared__ double sh[32][9];
+    __shared__ double m9[9];
+    const int g = threadIdx.x >> 3, cl = threadIdx.x & 7;
+    // moments: thread (g, j) for j < 9 (cl + 8 * (g & 1) covers 0..15) -- simpler: 32 groups x 9 values via two passes
+    for (int j = cl; j < 9; j += 8) {
+        double a = 0.0;
+        for (int q = g; q < nmom; q += 32) a += mom[(size_t)q * 9 + j];
+        sh[g][j] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        double a = 0.0;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) a += sh[r][threadIdx.x];
+        m9[threadIdx.x] = a;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 8 + cl;                             // entry k * C + c
+    const bool ok = i < 3 * C;
+    const int k = ok ? i / C : 0, c = ok ? i - k * C : 0;
+    double a = 0.0;
+    if (ok)
+        for (int q = g; q < nparts; q += 32) a += l1a[((size_t)q * 3 + k) * pitch + c];
+    __syncthreads();
+    sh[g][cl] = a;
+    __syncthreads();
+    if (g != 0 || !ok) return;
+    double sum = 0.0;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) sum += sh[r][cl];
+    const double xx[3][3] = {{m9[3], m9[4], m9[5]}, {m9[4], m9[6], m9[7]}, {m9[5], m9[7], m9[8]}};
+    double mw = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) mw += xx[k][j] * (double)wx[j * skx + c * sn];
+    const double gr = (double)coef[c] * sum - (double)coef[C + c] * m9[k] - (double)coef[2 * C + c] * mw;
+    gw[k * skx + c * sn] = accumulate ? __fadd_rn(gw[k * skx + c * sn], (float)gr) : (float)gr;
+}
+
 __global__ void tl_identity_coef_kernel(int C, float *__restrict__ coef)       // dz = 1 * g - 0 - 0 * z
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1874,7 +1999,7 @@ static WgradShape wgrad_shape(long long rows, int KI, int NO, bool gather = fals
 // operands in the block image), at most four output tiles and two dW tiles per wave, and image(s) + resident W^T within the
 // CU's LDS -- with ONE image and two barriers per block when two do not fit. kc: channels of the contraction (= the second
 // operand's tiles that enter the product), ki: output columns.
-struct FuseShape { bool ok; int tk, nt, single, acopy, upw; size_t lds, pack_bytes; };
+struct FuseShape { bool ok; int tk, nt, single, acopy, upw; size_t lds, xr_off, pack_bytes; };
 static FuseShape fuse_shape(long long rows, const WgradShape &w, int kc, int ki, const Opts &o, bool dense = true)
 {
     FuseShape f;
@@ -1893,7 +2018,8 @@ static FuseShape fuse_shape(long long rows, const WgradShape &w, int kc, int ki,
     if (2 * img + wb <= cap) f.single = 0;
     else if (img + wb <= cap) f.single = 1;
     else return f;
-    f.lds = (f.single ? img : 2 * img) + wb;
+    f.xr_off = (f.single ? img : 2 * img) + wb;                   // 2 x 32 coordinate rows behind everything else
+    f.lds = f.xr_off + 1024;
     f.pack_bytes = wb;
     f.ok = true;
     return f;
@@ -1911,6 +2037,7 @@ struct TlPlan {
     size_t tops_part, tops_part2, tops64;   // ... its routed part on the vector units: partials (two stages), S (K, C_L) fp64
     size_t l1p;                 // layer 1 per point: forward P (b n, cout_1); backward S (b n, cout_1)
     size_t l1seg, l1part, l1coef;   // backward: scratch of the segmented reduction, dW1x partials (256, 3, cout_1), identity coefficients
+    size_t l1xg, l1mom, l1a;        // backward, level without features: centred coordinates of every row, their moments, x^T dy_1 partials
     size_t total;
 };
 
@@ -2069,6 +2196,9 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
         }
     } else if (backward && l1_coords_only(nlayers, widths, gd, o)) {
         pl.l1part = off; off = align_up(off + (size_t)kMaxParts * 3 * widths[1] * 4);
+        pl.l1xg = off; off = align_up(off + (size_t)rows * 16);
+        pl.l1mom = off; off = align_up(off + (size_t)kMaxParts * 9 * sizeof(double));
+        pl.l1a = off; off = align_up(off + (size_t)kMaxParts * 3 * widths[1] * sizeof(double));
     }
     pl.total = off;
     return true;
@@ -2163,13 +2293,13 @@ static int launch_gemm(int amode, TlGemm &p, const GemmShape &g, hipStream_t st,
     return launch_gemm_ns<1>(amode, p, g, grid, st);
 }
 
-template <int TPW, bool GATHER, int DCLS, bool DY = false>
+template <int TPW, bool GATHER, int DCLS, bool DY = false, bool L1X = false>
 static int launch_wgrad_kern(const TlWgrad &p, const WgradShape &w, dim3 grid, hipStream_t st)
 {
     const size_t lds = DY ? w.lds_dy : w.lds;
 #define PN2_WG_CASE(U)                                                          \
     if (w.upw == U) {                                                           \
-        auto kern = tl_wgrad_kernel<TPW, U, GATHER, DCLS, DY>;                  \
+        auto kern = tl_wgrad_kernel<TPW, U, GATHER, DCLS, DY, L1X>;             \
         if (int rc = allow_dynamic_lds(kern, lds)) return rc;                   \
         return launch(kern, grid, dim3(kTlThreads), lds, st, p);                \
     }
@@ -2185,6 +2315,7 @@ static int launch_wgrad_tpw(const TlWgrad &p, const WgradShape &w, dim3 grid, hi
         if (TPW > 2 || p.amode == A_GATHER) return PN2_E_ARG;
         constexpr int T = TPW > 2 ? 2 : TPW;
         if (p.dmode == A_FILL) return launch_wgrad_kern<T, false, D_TOP, true>(p, w, grid, st);
+        if (p.l1x) return p.dmode == A_DZ ? launch_wgrad_kern<T, false, D_DZ, true, true>(p, w, grid, st) : PN2_E_ARG;
         return p.dmode == A_DZ_POOL ? launch_wgrad_kern<T, false, D_DZPOOL, true>(p, w, grid, st)
                                     : launch_wgrad_kern<T, false, D_DZ, true>(p, w, grid, st);
     }
@@ -2626,6 +2757,7 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                             grad_out, (const float *)T.z, ga, reinterpret_cast<double *>(base + pl.stats[nlayers - 1]))) return rc;
     }
     float *gcur = ga, *gnext = gb;                      // dy of the current layer (dense case) / of the layer below
+    int l1_moment_parts = 0;                            // > 0: layer 1's weight gradient comes from moments (TlWgrad::l1x)
     for (int l = nlayers - 1; l >= 0; --l) {
         const pn2_bn_layer &L = layers[l];
         float *coef = reinterpret_cast<float *>(base + pl.coef[l]);
@@ -2665,6 +2797,7 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 w.partial = reinterpret_cast<float *>(base + pl.partial);
                 w.xshare = 1;                                     // one slab: the "h again" tiles are the first operand's
                 w.dy_w = reinterpret_cast<const u32x4 *>(base + pl.pack[l]);
+                w.xr_off = (int)fz[l].xr_off;
                 w.dy_tk = fz[l].tk; w.dy_nt = fz[l].nt; w.dy_tf = tf; w.single = fz[l].single;
                 w.dy_cols = K; w.dy_pitch = K;
                 w.dy_out = gnext;
@@ -2738,7 +2871,17 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
             continue;
         }
         if (l == 0 && coords_only) {
-            // ---- a level without features: the first layer's weight gradient is dW1x, one pass over dy_1 and z_1
+            // ---- a level without features: the first layer's weight gradient is dW1x
+            if (l1_moment_parts) {                                // ... from x^T dy_1 of the pass above and the moments of x
+                const TlGather gt = make_gather(group);
+                if (int rc = launch(tl_l1_wx_combine_kernel, dim3((unsigned)((3 * L.cout + 7) / 8)), dim3(256), 0, st,
+                                    reinterpret_cast<const double *>(base + pl.l1mom), l1_moment_parts,
+                                    reinterpret_cast<const double *>(base + pl.l1a), nparts[0], L.cout, L.cout, (const float *)coef,
+                                    L.weight + gt.xyz_off * L.w_stride_k, L.w_stride_k, L.w_stride_n,
+                                    L.grad_weight + gt.xyz_off * L.w_stride_k, L.grad_accumulate)) return rc;
+                break;
+            }
+            // ... in one pass over dy_1 and z_1
             if (int rc = launch_l1_dz(rows, gd, group, L, gcur, coef, reinterpret_cast<float *>(base + pl.l1part), false, st)) return rc;
             break;
         }
@@ -2808,6 +2951,24 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                     w.dy_out = grad_x;
                 }
                 w.dy_nt_store = o.nt == PN2_OPT_OFF ? 0 : o.nt == PN2_OPT_ON ? 1 : (size_t)rows * L.cin * sizeof(float) >= ((size_t)128 << 20);
+                w.xr_off = (int)fz[l].xr_off;
+                if (l == 1 && coords_only) {
+                    // the layer below takes the three centred coordinates: dy_1 is wanted only as x^T dy_1 (TlWgrad::l1x) -- never
+                    // written, and tl_l1_dz_kernel's pass over (dy_1, z_1) is replaced by nine moments of x
+                    const pn2_bn_layer &D = layers[0];
+                    TlL1 q;
+                    memset(&q, 0, sizeof(q));
+                    q.rows = rows; q.n = gd.n; q.m = gd.m; q.nsample = gd.nsample; q.C = D.cout;
+                    q.xyz = group->xyz; q.new_xyz = group->new_xyz; q.idx = group->idx;
+                    long long xb = (rows + 255) / 256;
+                    if (xb > kMaxParts) xb = kMaxParts;
+                    l1_moment_parts = (int)xb;
+                    if (int rc = launch(tl_l1_xrows_kernel, dim3((unsigned)xb), dim3(256), 0, st, q, reinterpret_cast<float4 *>(base + pl.l1xg),
+                                        reinterpret_cast<double *>(base + pl.l1mom))) return rc;
+                    w.l1x = reinterpret_cast<const float4 *>(base + pl.l1xg);
+                    w.l1a = reinterpret_cast<double *>(base + pl.l1a);
+                    w.dy_out = nullptr;
+                }
                 if (int rc = launch_wgrad(w, wz[l], reinterpret_cast<float *>(base + pl.partial2), L, st)) return rc;
                 if (l > 0) nparts[l - 1] = (int)wz[l].gridx;
                 float *tmp = gcur; gcur = gnext; gnext = tmp;
