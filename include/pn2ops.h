@@ -366,6 +366,9 @@ typedef struct pn2_train_opts {
                                       instead of two; AUTO: from 0.5 M rows where the layer's tiles fit one slab; ON: wherever
                                       they fit, the z-free pooled top layer included), OFF: never */
     int wgrad_two_per_cu;          /* two weight-gradient workgroups per CU where registers and LDS allow (AUTO / ON), OFF: one */
+    int side_stream;               /* backward: the weight-gradient launches on a helper stream beside the data-gradient chain
+                                      (fork / join by events on the caller's stream): ON only -- measured slower on all but the
+                                      group_all level, so AUTO = OFF */
 } pn2_train_opts;
 long long pn2_mlp_train_ws_bytes(long long rows, int nlayers, const int *widths /* cin_1, cout_1 .. cout_L */,
                                  int pool_rows, int backward,

@@ -2412,6 +2412,64 @@ static int launch_top_s(TlTopS &p, const TopSShape &t, float *part2, double *s64
     return launch(tl_top_s_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, nparts, total, s64);
 }
 
+// ---- a helper stream for the backward pass of SMALL levels --------------------------------------------------------------------
+// A layer's weight gradient and its data gradient both start from (dy_l, z_l, z_{l-1}) and neither needs the other. On levels
+// of a few thousand rows each is a launch of 10-50 us that covers a fraction of the chip (the deep levels of the segmentation
+// networks: ~25 such launches per level, one after the other on the caller's stream, were 260 us per level whatever its
+// size). With a helper stream the weight-gradient launches (and their reductions / fix-ups) CAN run beside the data-gradient
+// chain (opt-in, pn2_train_opts.side_stream -- the measurement at its use site says why it is not the default): fork after the layer's batch-norm coefficients exist, join before the next layer's data gradient overwrites the
+// dy buffer the helper reads. One helper stream and two events per (device, caller stream), created on first use and kept
+// (with allow_dynamic_lds's table the library's only process state); event record / wait are legal under HIP graph capture
+// (the helper joins the capture at the fork and returns at the join), so a captured training step keeps working.
+struct SideKey { int dev; hipStream_t main; bool operator==(const SideKey &o) const { return dev == o.dev && main == o.main; } };
+struct SideKeyHash { size_t operator()(const SideKey &k) const { return std::hash<unsigned long long>()((unsigned long long)(uintptr_t)k.main * 31ull + (unsigned long long)k.dev); } };
+struct SideRes { hipStream_t side; hipEvent_t fork_ev, join_ev; };
+
+struct SideStream {
+    hipStream_t main = nullptr, side = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    bool forked = false;
+    int init(hipStream_t st, bool enable)
+    {
+        main = st;
+        if (!enable) return PN2_OK;
+        static std::mutex mu;
+        static std::unordered_map<SideKey, SideRes, SideKeyHash> table;
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return (int)e;
+        std::lock_guard<std::mutex> lock(mu);
+        const SideKey key = {dev, st};
+        auto it = table.find(key);
+        if (it == table.end()) {
+            SideRes r;
+            if ((e = hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking)) != hipSuccess) return (int)e;
+            if ((e = hipEventCreateWithFlags(&r.fork_ev, hipEventDisableTiming)) != hipSuccess) return (int)e;
+            if ((e = hipEventCreateWithFlags(&r.join_ev, hipEventDisableTiming)) != hipSuccess) return (int)e;
+            it = table.emplace(key, r).first;
+        }
+        side = it->second.side; fork_ev = it->second.fork_ev; join_ev = it->second.join_ev;
+        return PN2_OK;
+    }
+    hipStream_t get() const { return side ? side : main; }      // where the forked work goes
+    int fork()                                                   // the helper continues from here
+    {
+        if (!side || forked) return PN2_OK;
+        hipError_t e = hipEventRecord(fork_ev, main);
+        if (e == hipSuccess) e = hipStreamWaitEvent(side, fork_ev, 0);
+        forked = e == hipSuccess;
+        return (int)e;
+    }
+    int join()                                                   // the caller's stream waits for everything forked so far
+    {
+        if (!side || !forked) return PN2_OK;
+        hipError_t e = hipEventRecord(join_ev, side);
+        if (e == hipSuccess) e = hipStreamWaitEvent(main, join_ev, 0);
+        forked = false;
+        return (int)e;
+    }
+};
+
 static bool layers_ok(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group, int *widths)
 {
     if (!layers || nlayers < 1 || nlayers > 8) return false;
@@ -2758,12 +2816,20 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
     }
     float *gcur = ga, *gnext = gb;                      // dy of the current layer (dense case) / of the layer below
     int l1_moment_parts = 0;                            // > 0: layer 1's weight gradient comes from moments (TlWgrad::l1x)
+    // weight-gradient launches on a helper stream beside the data-gradient chain (SideStream above): OPT-IN. Measured
+    // (scripts/lab_ab.sh side_stream, profiles/r04/README.md): every fork / join is a cross-queue dependency of ~10 us on this
+    // runtime, three pairs per level -- sem_seg SA2 280 -> 330 us, SA4 250 -> 305, FP4 335 -> 380; only the group_all level
+    // (three wide layers over 4,096 rows) gains, 431 -> 379 us. The size rule therefore never switches it on.
+    SideStream sd;
+    if (int rc = sd.init(st, o.side_stream == PN2_OPT_ON)) return rc;
+    hipStream_t ss = sd.get();
     for (int l = nlayers - 1; l >= 0; --l) {
         const pn2_bn_layer &L = layers[l];
         float *coef = reinterpret_cast<float *>(base + pl.coef[l]);
         if (int rc = launch(tl_bn_backward_finalize_kernel, dim3((unsigned)((L.cout + 7) / 8)), dim3(256), 0, st,
                             reinterpret_cast<const double *>(base + pl.stats[l]), nparts[l], L.cout, (double)rows, L.gamma,
                             (const float *)L.save, L.grad_gamma, L.grad_beta, coef, L.grad_accumulate)) return rc;
+        if (int rc = sd.join()) return rc;                          // the helper's reads of the dy buffer this layer's data gradient overwrites
         const bool pooled_top = pool_rows && l == nlayers - 1;
         if (pooled_top && ztop) {
             // ---- the pooled top layer in terms of its input h = relu(a z_{l-1} + c): see tl_top_mats_kernel
@@ -2820,6 +2886,7 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 // matrix h^T h and the column sums of h from the dense kernel, combined by tl_top_wgrad_fix_kernel
                 const TopSShape ts = top_s_shape(rows, pool_rows, K, NF, o);
                 double *s64 = ts.ok ? reinterpret_cast<double *>(base + pl.tops64) : nullptr;
+                if (int rc = sd.fork()) return rc;                 // the weight gradient's three kernels beside the data gradient below
                 if (ts.ok) {
                     TlTopS q;
                     memset(&q, 0, sizeof(q));
@@ -2827,7 +2894,7 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                     q.z = D.z; q.pa = D.save + 2 * D.cout; q.pc = D.save + 3 * D.cout;
                     q.gq = gq; q.argsel = argsel; q.coef = coef;
                     q.partial = reinterpret_cast<float *>(base + pl.tops_part);
-                    if (int rc = launch_top_s(q, ts, reinterpret_cast<float *>(base + pl.tops_part2), s64, st)) return rc;
+                    if (int rc = launch_top_s(q, ts, reinterpret_cast<float *>(base + pl.tops_part2), s64, ss)) return rc;
                 }
                 const int tfw = ts.ok ? 0 : tf, ldw = ts.ok ? top_cols(K, 0) : ld;       // operand tiles of the dense kernel
                 TlWgrad w;
@@ -2841,10 +2908,10 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 w.partial = reinterpret_cast<float *>(base + pl.partial);
                 const WgradShape ws_ = wgrad_shape(rows, K, ldw, false, cus, o.wgrad_two_per_cu);
                 w.xshare = ws_.uslabs == 1;
-                if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, st, sf)) return rc;
+                if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, ss, sf)) return rc;
                 long long blocks = ((long long)K * NF + 255) / 256;
                 if (blocks > 4096) blocks = 4096;
-                if (int rc = launch(tl_top_wgrad_fix_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const double *)sf, ldw, K, NF,
+                if (int rc = launch(tl_top_wgrad_fix_kernel, dim3((unsigned)blocks), dim3(256), 0, ss, (const double *)sf, ldw, K, NF,
                                     tfw * 32, tfw * 32 + tiles(K) * 32, L.weight, L.w_stride_k, L.w_stride_n, (const float *)coef,
                                     (const float *)nullptr, L.grad_weight, (const double *)s64, L.grad_accumulate)) return rc;
             }
@@ -2905,7 +2972,8 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 pn2_bn_layer Lf = L;
                 Lf.grad_weight = L.grad_weight + gt.feat_off * L.w_stride_k;
                 const WgradShape ws_ = wgrad_shape(bn, gt.cfeat, L.cout, false, cus, o.wgrad_two_per_cu);
-                if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), Lf, st)) return rc;
+                if (int rc = sd.fork()) return rc;                 // beside the GEMM for dPoints below
+                if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), Lf, ss)) return rc;
             }
             if (want_dx) {                                        // dPoints = S W1f^T
                 const GemmShape g = gemm_shape(bn, L.cout, gt.cfeat, o);
@@ -2975,7 +3043,8 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 continue;
             }
             const WgradShape ws_ = wgrad_shape(rows, L.cin, L.cout, w.amode == A_GATHER, cus, o.wgrad_two_per_cu);
-            if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, st)) return rc;
+            if (int rc = sd.fork()) return rc;                     // beside the data-gradient GEMM below
+            if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, ss)) return rc;
         }
         // data gradient
         if (l > 0 || want_dx) {
@@ -3012,5 +3081,5 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
         }
         float *tmp = gcur; gcur = gnext; gnext = tmp;
     }
-    return PN2_OK;
+    return sd.join();                                              // everything of this call is ordered before what the caller enqueues next
 }

@@ -36,6 +36,8 @@ def _case(seed):
         env["fuse_wgrad"] = True                            # ... in ONE pass wherever the layer's tiles fit (the size rule starts at 0.5 M rows)
     if rng.random() < 0.35:
         env["wgrad_two_per_cu"] = True                      # two weight-gradient workgroups per CU (the size rule starts at 16 row blocks per CU)
+    if rng.random() < 0.3:
+        env["side_stream"] = rng.random() < 0.5             # weight-gradient launches on the helper stream (default below 0.5 M rows) / never
     if kind == "plain":
         b, n = rng.choice([(1, 32), (2, 48), (3, 64), (2, 1024), (5, 32)])
         kw = dict(b=b, n=n, m=0, ns=0, cfeat=0, widths=widths, plain_cin=rng.choice([4, 6, 30, 64, 134, 200]))
