@@ -3039,7 +3039,7 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 }
                 w.dy_nt_store = o.nt == PN2_OPT_OFF ? 0 : o.nt == PN2_OPT_ON ? 1 : (size_t)rows * L.cin * sizeof(float) >= ((size_t)128 << 20);
                 w.xr_off = (int)fz[l].xr_off;
-                if (l == 1 && coords_only) {
+                if (l == 1 && coords_only && !pooled_top) {            // (a pooled two-layer stack keeps the pass over dy_1: its dz comes from the routed gradient)
                     // the layer below takes the three centred coordinates: dy_1 is wanted only as x^T dy_1 (TlWgrad::l1x) -- never
                     // written, and tl_l1_dz_kernel's pass over (dy_1, z_1) is replaced by nine moments of x
                     const pn2_bn_layer &D = layers[0];
