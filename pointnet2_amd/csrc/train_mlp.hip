@@ -1644,8 +1644,14 @@ struct TlL1 {
     double *stats;                          // forward: (workgroups, 2, C) partial sums
     float *g;                               // backward: dy_1 in, dz_1 out (rows, C)
     const float *coef;                      // backward: (3, C): s, c0, c1
-    float *part;                            // backward: (workgroups, 3, C) partial dW1x
+    float *part;                            // backward: (workgroups, 3 + cf, C) partial dW1 rows: coordinates, then features
+    // a FEW feature channels beside the coordinates (normals: cls_msg / part_seg level 1), P == nullptr: gathered per row and
+    // handled like three more coordinates -- a layer of six inputs is no more a matrix-core job than one of three
+    const float *points;                    // (b n, cf) or nullptr
+    int cf;                                 // 0..kL1MaxFeat
+    const float *wf;                        // forward: W1f, cf rows of the weight: wf[k * skx + col * sn]
 };
+constexpr int kL1MaxFeat = 5;               // 3 + 5 = 8 inputs at most on the vector units
 
 // thread <-> (row lane, 4 columns): a block of kL1Threads covers kL1Threads / (C / 4) rows at a time, columns fixed per
 // thread, and every thread keeps kL1U rows in flight (all loads of a batch are issued before the first is used: the
@@ -1696,12 +1702,16 @@ __device__ __forceinline__ void l1_coords(const TlL1 &p, const L1Rows &r, float 
 __global__ __launch_bounds__(kL1Threads) void tl_l1_forward_kernel(const TlL1 p)
 {
     const int qpr = p.C / 4, q = threadIdx.x % qpr, rl = threadIdx.x / qpr, rpb = kL1Threads / qpr, col = 4 * q;
-    float a0[4], a1[4], a2[4], b4[4] = {0.f, 0.f, 0.f, 0.f};
+    float a0[4], a1[4], a2[4], b4[4] = {0.f, 0.f, 0.f, 0.f}, af[kL1MaxFeat][4];
     {
         const float *w = p.wx + (size_t)col * p.sn;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { a0[i] = w[i * p.sn]; a1[i] = w[p.skx + i * p.sn]; a2[i] = w[2 * p.skx + i * p.sn]; }
         if (p.bias) { const float4 b = ld4(p.bias + col); b4[0] = b.x; b4[1] = b.y; b4[2] = b.z; b4[3] = b.w; }
+#pragma unroll
+        for (int k = 0; k < kL1MaxFeat; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[k][i] = k < p.cf ? p.wf[(size_t)k * p.skx + (size_t)(col + i) * p.sn] : 0.0f;
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     // a workgroup walks ONE contiguous range of rows, a batch = kL1U consecutive slices of rpb rows (whole 32 KB runs of z)
@@ -1715,6 +1725,11 @@ __global__ __launch_bounds__(kL1Threads) void tl_l1_forward_kernel(const TlL1 p)
         l1_coords(p, r, x);
 #pragma unroll
         for (int u = 0; u < kL1U; ++u) pp[u] = p.P ? ld4(p.P + r.pt[u] * p.C + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float f[kL1U][kL1MaxFeat];
+#pragma unroll
+        for (int u = 0; u < kL1U; ++u)
+#pragma unroll
+            for (int k = 0; k < kL1MaxFeat; ++k) f[u][k] = k < p.cf ? p.points[r.pt[u] * p.cf + k] : 0.0f;     // (cf uniform: no loads when 0)
 #pragma unroll
         for (int u = 0; u < kL1U; ++u) {
             float z[4] = {pp[u].x + b4[0], pp[u].y + b4[1], pp[u].z + b4[2], pp[u].w + b4[3]};
@@ -1723,6 +1738,12 @@ __global__ __launch_bounds__(kL1Threads) void tl_l1_forward_kernel(const TlL1 p)
                 z[i] = fmaf(x[u][0], a0[i], z[i]);
                 z[i] = fmaf(x[u][1], a1[i], z[i]);
                 z[i] = fmaf(x[u][2], a2[i], z[i]);
+            }
+            if (p.cf > 0) {
+#pragma unroll
+                for (int k = 0; k < kL1MaxFeat; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) z[i] = fmaf(f[u][k], af[k][i], z[i]);          // zero weight beyond cf
             }
             if (r.ok[u]) {
 #pragma unroll
@@ -1751,20 +1772,26 @@ __global__ __launch_bounds__(kL1Threads) void tl_l1_forward_kernel(const TlL1 p)
 // dz_1 = s dy_1 - c0 - c1 z_1 and the coordinate rows of the weight gradient, dW1x = (xyz - c)^T dz_1, in one pass over the
 // rows. STORE: dz_1 overwrites dy_1 (the per-point path scatters it onto the points next); a level without features needs
 // only dW1x = its whole first-layer weight gradient.
-template <bool STORE>
+template <bool STORE, bool FEAT>
 __global__ __launch_bounds__(kL1Threads) void tl_l1_dz_kernel(const TlL1 p)
 {
+    constexpr int NIN = FEAT ? 3 + kL1MaxFeat : 3;               // rows of the weight gradient a thread accumulates
     const int qpr = p.C / 4, q = threadIdx.x % qpr, rl = threadIdx.x / qpr, rpb = kL1Threads / qpr, col = 4 * q;
+    const int nin = FEAT ? 3 + p.cf : 3;
     const float4 s4 = ld4(p.coef + col), c04 = ld4(p.coef + p.C + col), c14 = ld4(p.coef + 2 * p.C + col);
     const float s[4] = {s4.x, s4.y, s4.z, s4.w}, c0[4] = {c04.x, c04.y, c04.z, c04.w}, c1[4] = {c14.x, c14.y, c14.z, c14.w};
-    float acc[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float acc[NIN][4];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[k][i] = 0.0f;
     // a workgroup walks ONE contiguous range of rows, a batch = kL1U consecutive slices of rpb rows (whole 32 KB runs of z)
     const unsigned rows = (unsigned)p.rows, stride = (unsigned)rpb, span = kL1U * stride;
     const unsigned chunk = (rows + gridDim.x * span - 1) / (gridDim.x * span) * span;
     const unsigned first = blockIdx.x * chunk, stop = first + chunk < rows ? first + chunk : rows;
     for (unsigned base = first + rl; base < stop; base += span) {
         const L1Rows r = l1_rows(p, base, stride, rows);
-        float x[kL1U][3];
+        float x[kL1U][NIN];
         float4 g4[kL1U], z4[kL1U];
 #pragma unroll
         for (int u = 0; u < kL1U; ++u) {
@@ -1772,7 +1799,18 @@ __global__ __launch_bounds__(kL1Threads) void tl_l1_dz_kernel(const TlL1 p)
             g4[u] = ld4(p.g + o);
             z4[u] = ld4(p.z + o);
         }
-        l1_coords(p, r, x);
+        {
+            float xc[kL1U][3];
+            l1_coords(p, r, xc);
+#pragma unroll
+            for (int u = 0; u < kL1U; ++u) {
+                x[u][0] = xc[u][0]; x[u][1] = xc[u][1]; x[u][2] = xc[u][2];
+                if (FEAT) {
+#pragma unroll
+                    for (int k = 0; k < kL1MaxFeat; ++k) x[u][3 + k] = k < p.cf ? p.points[r.pt[u] * p.cf + k] : 0.0f;
+                }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < kL1U; ++u) {
             const float gg[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w}, zz[4] = {z4[u].x, z4[u].y, z4[u].z, z4[u].w};
@@ -1782,7 +1820,7 @@ __global__ __launch_bounds__(kL1Threads) void tl_l1_dz_kernel(const TlL1 p)
                 dz[i] = __fsub_rn(__fsub_rn(__fmul_rn(s[i], gg[i]), c0[i]), __fmul_rn(c1[i], zz[i]));      // s dy - c0 - c1 z
                 const float dv = r.ok[u] ? dz[i] : 0.0f;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) acc[k][i] = fmaf(x[u][k], dv, acc[k][i]);
+                for (int k = 0; k < NIN; ++k) acc[k][i] = fmaf(x[u][k], dv, acc[k][i]);
             }
             if (STORE && r.ok[u])
                 *reinterpret_cast<float4 *>(p.g + (size_t)r.row[u] * p.C + col) = make_float4(dz[0], dz[1], dz[2], dz[3]);
@@ -1790,41 +1828,50 @@ __global__ __launch_bounds__(kL1Threads) void tl_l1_dz_kernel(const TlL1 p)
     }
     __shared__ float red[3][kL1Threads][4];
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) red[k][threadIdx.x][i] = acc[k][i];
-    __syncthreads();
-    if (rl == 0) {
+    for (int k0 = 0; k0 < NIN; k0 += 3) {                          // three gradient rows per trip through the 24 KB buffer
+        if (k0) __syncthreads();
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                double a = 0.0;
-                for (int j = 0; j < rpb; ++j) a += (double)red[k][j * qpr + q][i];
-                p.part[((size_t)blockIdx.x * 3 + k) * p.C + col + i] = (float)a;
-            }
+            for (int i = 0; i < 4; ++i) red[k][threadIdx.x][i] = k0 + k < NIN ? acc[k0 + k < NIN ? k0 + k : 0][i] : 0.0f;
+        __syncthreads();
+        if (rl == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (k0 + k < nin) {
+                        double a = 0.0;
+                        for (int j = 0; j < rpb; ++j) a += (double)red[k][j * qpr + q][i];
+                        p.part[((size_t)blockIdx.x * nin + k0 + k) * p.C + col + i] = (float)a;
+                    }
+                }
+        }
     }
 }
 
 // dW1x[k][col] = sum over the workgroups' partials (fp64), written to rows [xyz_off, xyz_off + 3) of grad_weight.
 // A block of 256 threads owns 8 of the 3 C sums and adds the partial rows 32 at a time (a thread per sum walking all
 // 256 rows was 60 us of dependent L2 latencies).
-__global__ __launch_bounds__(256) void tl_l1_wx_reduce_kernel(const float *__restrict__ part, int nparts, int C, float *__restrict__ gw,
+// (nin = 3 + cf rows: the coordinate rows go to gw, the feature rows to gwf -- the two blocks of the layer's weight gradient)
+__global__ __launch_bounds__(256) void tl_l1_wx_reduce_kernel(const float *__restrict__ part, int nparts, int C, int nin,
+                                                              float *__restrict__ gw, float *__restrict__ gwf,
                                                               long long sk, long long sn, int accumulate)
 {
     __shared__ double sh[32][8];
     const int g = threadIdx.x >> 3, cl = threadIdx.x & 7, i = blockIdx.x * 8 + cl;
     double a = 0.0;
-    if (i < 3 * C)
-        for (int q = g; q < nparts; q += 32) a += (double)part[(size_t)q * 3 * C + i];
+    if (i < nin * C)
+        for (int q = g; q < nparts; q += 32) a += (double)part[(size_t)q * nin * C + i];
     sh[g][cl] = a;
     __syncthreads();
-    if (g != 0 || i >= 3 * C) return;
+    if (g != 0 || i >= nin * C) return;
     double sum = 0.0;
 #pragma unroll
     for (int r = 0; r < 32; ++r) sum += sh[r][cl];
     const int k = i / C, col = i - k * C;
-    gw[k * sk + col * sn] = accumulate ? __fadd_rn(gw[k * sk + col * sn], (float)sum) : (float)sum;
+    float *dst = k < 3 ? gw + k * sk + col * sn : gwf + (k - 3) * sk + col * sn;
+    *dst = accumulate ? __fadd_rn(*dst, (float)sum) : (float)sum;
 }
 
 // ---- layer 1 of a level without features, weight gradient from moments (TlWgrad::l1x) ----------------------------------------
@@ -2132,7 +2179,8 @@ static TopSShape top_s_shape(long long rows, int pool_rows, int K, int NF, const
 // units (tl_l1_forward_kernel with P == nullptr, tl_l1_dz_kernel<false>)? The first level of every reference network.
 static bool l1_coords_only(int nlayers, const int *widths, const GroupDims *g, const Opts &o)
 {
-    if (!g || !g->has_idx || g->cfeat != 0 || widths[0] != 3 || nlayers < 2 || o.l1_coords == PN2_OPT_OFF) return false;
+    // (round 4: also with up to kL1MaxFeat feature channels beside the coordinates -- normals -- gathered per row)
+    if (!g || !g->has_idx || g->cfeat > kL1MaxFeat || widths[0] != 3 + g->cfeat || nlayers < 2 || o.l1_coords == PN2_OPT_OFF) return false;
     const int c1 = widths[1];
     return c1 % 4 == 0 && c1 / 4 <= kL1Threads && kL1Threads % (c1 / 4) == 0;
 }
@@ -2214,7 +2262,7 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
             pl.l1coef = off; off = align_up(off + (size_t)3 * widths[1] * 4);
         }
     } else if (backward && l1_coords_only(nlayers, widths, gd, o)) {
-        pl.l1part = off; off = align_up(off + (size_t)kMaxParts * 3 * widths[1] * 4);
+        pl.l1part = off; off = align_up(off + (size_t)kMaxParts * (3 + kL1MaxFeat) * widths[1] * 4);
         pl.l1xg = off; off = align_up(off + (size_t)rows * 16);
         pl.l1mom = off; off = align_up(off + (size_t)kMaxParts * 9 * sizeof(double));
         pl.l1a = off; off = align_up(off + (size_t)kMaxParts * 3 * widths[1] * sizeof(double));
@@ -2579,6 +2627,9 @@ static int launch_l1_forward(long long rows, const GroupDims &gd, const pn2_grou
     q.rows = rows; q.n = gd.n; q.m = gd.m; q.nsample = gd.nsample; q.C = L.cout;
     q.xyz = group->xyz; q.new_xyz = group->new_xyz; q.idx = group->idx; q.P = P;
     q.wx = L.weight + gt.xyz_off * L.w_stride_k; q.skx = L.w_stride_k; q.sn = L.w_stride_n;
+    if (!P && gt.cfeat > 0) {                                     // a few feature channels gathered per row (l1_coords_only)
+        q.points = group->points; q.cf = gt.cfeat; q.wf = L.weight + gt.feat_off * L.w_stride_k;
+    }
     q.bias = nullptr; q.z = L.z;                  // no conv bias in the stored tensor (pn2_mlp_train_forward)
     q.stats = stats;
     const int rpb = kL1Threads / (L.cout / 4);
@@ -2598,13 +2649,18 @@ static int launch_l1_dz(long long rows, const GroupDims &gd, const pn2_group_src
     q.rows = rows; q.n = gd.n; q.m = gd.m; q.nsample = gd.nsample; q.C = L.cout;
     q.xyz = group->xyz; q.new_xyz = group->new_xyz; q.idx = group->idx;
     q.z = L.z; q.g = dy; q.coef = coef; q.part = part;
+    const bool feat = !store && gt.cfeat > 0;                     // (store = the per-point path: its features went through P)
+    if (feat) { q.points = group->points; q.cf = gt.cfeat; }
+    const int nin = 3 + q.cf;
     const int rpb = kL1Threads / (L.cout / 4);
     long long blocks = (rows + (long long)rpb * kL1U - 1) / ((long long)rpb * kL1U);
     if (blocks > kMaxParts) blocks = kMaxParts;
-    if (int rc = store ? launch(tl_l1_dz_kernel<true>, dim3((unsigned)blocks), dim3(kL1Threads), 0, st, q)
-                       : launch(tl_l1_dz_kernel<false>, dim3((unsigned)blocks), dim3(kL1Threads), 0, st, q)) return rc;
-    return launch(tl_l1_wx_reduce_kernel, dim3((unsigned)((3 * L.cout + 7) / 8)), dim3(256), 0, st, (const float *)part, (int)blocks,
-                  L.cout, L.grad_weight + gt.xyz_off * L.w_stride_k, L.w_stride_k, L.w_stride_n, L.grad_accumulate);
+    if (int rc = store ? launch(tl_l1_dz_kernel<true, false>, dim3((unsigned)blocks), dim3(kL1Threads), 0, st, q)
+                 : feat ? launch(tl_l1_dz_kernel<false, true>, dim3((unsigned)blocks), dim3(kL1Threads), 0, st, q)
+                        : launch(tl_l1_dz_kernel<false, false>, dim3((unsigned)blocks), dim3(kL1Threads), 0, st, q)) return rc;
+    return launch(tl_l1_wx_reduce_kernel, dim3((unsigned)((nin * L.cout + 7) / 8)), dim3(256), 0, st, (const float *)part, (int)blocks,
+                  L.cout, nin, L.grad_weight + gt.xyz_off * L.w_stride_k, L.grad_weight + gt.feat_off * L.w_stride_k, L.w_stride_k,
+                  L.w_stride_n, L.grad_accumulate);
 }
 }  // namespace pn2
 
@@ -2629,7 +2685,9 @@ extern "C" int pn2_mlp_train_forward_ex(long long rows, int nlayers, const pn2_b
     if (group) gd = group_dims(group);
     if (!tl_plan(rows, nlayers, widths, pool_rows, 0, pl, group ? &gd : nullptr, o)) return PN2_E_ARG;
     const bool per_point = group && l1_per_point(nlayers, widths, &gd, o);
-    const bool coords_only = group && l1_coords_only(nlayers, widths, &gd, o);
+    // forward: layer 1 on the vector units only WITHOUT features (with the input normals gathered per row the vector kernel
+    // measured slower than the gathered GEMM: cls_msg forward 2.51 -> 2.57 ms; its backward counterpart is the one that pays)
+    const bool coords_only = group && gd.cfeat == 0 && l1_coords_only(nlayers, widths, &gd, o);
     const bool keep_top = top_stored(rows, nlayers, widths, pool_rows, o);
     for (int l = 0; l < nlayers; ++l)
         if (!layers[l].z && (keep_top || l < nlayers - 1)) return PN2_E_NULL;
@@ -2956,8 +3014,9 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
             float *tmp = gcur; gcur = gnext; gnext = tmp;
             continue;
         }
-        if (l == 0 && coords_only) {
-            // ---- a level without features: the first layer's weight gradient is dW1x
+        if (l == 0 && coords_only && !(gd.cfeat > 0 && want_dx)) {
+            // ---- a level without features (or with a few whose gradient nobody wants -- the network's input normals): the
+            // first layer's weight gradient on the vector units
             if (l1_moment_parts) {                                // ... from x^T dy_1 of the pass above and the moments of x
                 const TlGather gt = make_gather(group);
                 if (int rc = launch(tl_l1_wx_combine_kernel, dim3((unsigned)((3 * L.cout + 7) / 8)), dim3(256), 0, st,
@@ -3039,7 +3098,7 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 }
                 w.dy_nt_store = o.nt == PN2_OPT_OFF ? 0 : o.nt == PN2_OPT_ON ? 1 : (size_t)rows * L.cin * sizeof(float) >= ((size_t)128 << 20);
                 w.xr_off = (int)fz[l].xr_off;
-                if (l == 1 && coords_only && !pooled_top) {            // (a pooled two-layer stack keeps the pass over dy_1: its dz comes from the routed gradient)
+                if (l == 1 && coords_only && gd.cfeat == 0 && !pooled_top) {            // (a pooled two-layer stack keeps the pass over dy_1: its dz comes from the routed gradient)
                     // the layer below takes the three centred coordinates: dy_1 is wanted only as x^T dy_1 (TlWgrad::l1x) -- never
                     // written, and tl_l1_dz_kernel's pass over (dy_1, z_1) is replaced by nine moments of x
                     const pn2_bn_layer &D = layers[0];

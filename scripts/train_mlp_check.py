@@ -73,7 +73,10 @@ def ref_stack(x64, pairs, eps_list, pool_ns=None, masks=None, argsel=None):
     return h, zs, moments, diag
 
 
-def run_case(name, b, n, m, ns, cfeat, widths, xyz_first=True, group_all=False, plain_cin=0, seed=0, fp32_baseline=False):
+def run_case(name, b, n, m, ns, cfeat, widths, xyz_first=True, group_all=False, plain_cin=0, seed=0, fp32_baseline=False,
+             feat_grad=True):
+    """feat_grad=False: the grouped features are data (a network's input normals): no gradient is asked for them, which
+    lets a level with a few feature channels take layer 1's backward on the vector units (tl_l1_dz_kernel<.., FEAT>)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     torch.manual_seed(seed)                      # the conv weights come from the global generator: same network every run
     if plain_cin:
@@ -100,7 +103,7 @@ def run_case(name, b, n, m, ns, cfeat, widths, xyz_first=True, group_all=False, 
         pool = None
     else:
         xyz = torch.rand((b, n, 3), generator=g).to(dev)
-        points = (torch.randn((b, n, cfeat), generator=g).to(dev).requires_grad_(True)) if cfeat else None
+        points = (torch.randn((b, n, cfeat), generator=g).to(dev).requires_grad_(feat_grad)) if cfeat else None
         if group_all:
             new_xyz = idx = None
             mm, nss = 1, n
@@ -173,7 +176,7 @@ def run_case(name, b, n, m, ns, cfeat, widths, xyz_first=True, group_all=False, 
         errs["rv%d" % (l + 1)] = rel(bn.running_var, (1 - bn.momentum) * rv0[l].double() + bn.momentum * var * nrows / (nrows - 1))
     if plain_cin:
         errs["dx"] = rel(x.grad.reshape(b * n, cin), rows64.grad)
-    elif cfeat:
+    elif cfeat and feat_grad:
         errs["dpts"] = rel(points.grad, p64.grad)
     worst = max(v for k, v in errs.items() if isinstance(v, float) and not k.startswith("db") and k != "flips")
     if fp32_baseline:

@@ -184,4 +184,6 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    # PN2_TRAIN_OPTS="l1_coords=0,fuse_wgrad=0": organisation overrides for A/B runs (train_mlp.options; read by this script)
+    with train_mlp.options(**train_mlp.parse_options(os.environ.get("PN2_TRAIN_OPTS", ""))):
+        main()

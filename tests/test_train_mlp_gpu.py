@@ -98,6 +98,28 @@ def test_one_pass_backward_variants(cuda, name, kw, ztop):
     assert worst <= TOL, "%s: worst relative error %.2e" % (name, worst)
 
 
+# Levels whose few feature channels are DATA (the input normals of cls_msg / part_seg level 1: no gradient is asked for them):
+# layer 1 runs on the vector units in both directions (tl_l1_forward_kernel / tl_l1_dz_kernel<false, true>: the features
+# gathered per row like three more coordinates). With a feature gradient wanted the backward takes the generic passes; both
+# channel orders; the reference shapes and small ones.
+FEATURE_DATA_CASES = [
+    ("normals msg order ns16", dict(b=2, n=256, m=64, ns=16, cfeat=3, widths=[32, 32, 64], xyz_first=False)),
+    ("normals xyz first ns32", dict(b=4, n=512, m=64, ns=32, cfeat=3, widths=[64, 64, 128])),
+    ("five features two layers", dict(b=2, n=256, m=32, ns=32, cfeat=5, widths=[64, 32], xyz_first=False)),
+    ("cfg3 cls_msg L1 s2", dict(b=32, n=4096, m=512, ns=32, cfeat=3, widths=[64, 64, 128], xyz_first=False)),
+    ("cfg3 cls_msg L1 s3", dict(b=32, n=4096, m=512, ns=128, cfeat=3, widths=[64, 96, 128], xyz_first=False)),
+    ("cfg4 part_seg SA1", dict(b=16, n=2048, m=512, ns=64, cfeat=3, widths=[64, 64, 128])),
+]
+
+
+@pytest.mark.parametrize("name,kw", FEATURE_DATA_CASES, ids=[c[0] for c in FEATURE_DATA_CASES])
+def test_feature_channels_without_gradient(cuda, name, kw):
+    from scripts import train_mlp_check as T
+    worst = T.run_case(name, fp32_baseline=True, feat_grad=False, **kw)
+    bound = max(TOL, 2.0 * T.run_case.baseline)
+    assert worst <= bound, "%s: worst relative error %.2e (torch fp32: %.2e)" % (name, worst, T.run_case.baseline)
+
+
 def _clone_module(mod):
     import copy
     return copy.deepcopy(mod)
