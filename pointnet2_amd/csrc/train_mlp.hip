@@ -1645,11 +1645,11 @@ struct TlL1 {
     float *g;                               // backward: dy_1 in, dz_1 out (rows, C)
     const float *coef;                      // backward: (3, C): s, c0, c1
     float *part;                            // backward: (workgroups, 3 + cf, C) partial dW1 rows: coordinates, then features
-    // a FEW feature channels beside the coordinates (normals: cls_msg / part_seg level 1), P == nullptr: gathered per row and
-    // handled like three more coordinates -- a layer of six inputs is no more a matrix-core job than one of three
+    // backward, a FEW feature channels beside the coordinates whose gradient nobody wants (the input normals of cls_msg /
+    // part_seg level 1): gathered per row and handled like three more coordinates -- the weight gradient of a layer of six
+    // inputs is no more a matrix-core job than one of three (forward keeps the gathered GEMM: measured faster there)
     const float *points;                    // (b n, cf) or nullptr
     int cf;                                 // 0..kL1MaxFeat
-    const float *wf;                        // forward: W1f, cf rows of the weight: wf[k * skx + col * sn]
 };
 constexpr int kL1MaxFeat = 5;               // 3 + 5 = 8 inputs at most on the vector units
 
@@ -1702,16 +1702,12 @@ __device__ __forceinline__ void l1_coords(const TlL1 &p, const L1Rows &r, float 
 __global__ __launch_bounds__(kL1Threads) void tl_l1_forward_kernel(const TlL1 p)
 {
     const int qpr = p.C / 4, q = threadIdx.x % qpr, rl = threadIdx.x / qpr, rpb = kL1Threads / qpr, col = 4 * q;
-    float a0[4], a1[4], a2[4], b4[4] = {0.f, 0.f, 0.f, 0.f}, af[kL1MaxFeat][4];
+    float a0[4], a1[4], a2[4], b4[4] = {0.f, 0.f, 0.f, 0.f};
     {
         const float *w = p.wx + (size_t)col * p.sn;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { a0[i] = w[i * p.sn]; a1[i] = w[p.skx + i * p.sn]; a2[i] = w[2 * p.skx + i * p.sn]; }
         if (p.bias) { const float4 b = ld4(p.bias + col); b4[0] = b.x; b4[1] = b.y; b4[2] = b.z; b4[3] = b.w; }
-#pragma unroll
-        for (int k = 0; k < kL1MaxFeat; ++k)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[k][i] = k < p.cf ? p.wf[(size_t)k * p.skx + (size_t)(col + i) * p.sn] : 0.0f;
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     // a workgroup walks ONE contiguous range of rows, a batch = kL1U consecutive slices of rpb rows (whole 32 KB runs of z)
@@ -1725,11 +1721,6 @@ __global__ __launch_bounds__(kL1Threads) void tl_l1_forward_kernel(const TlL1 p)
         l1_coords(p, r, x);
 #pragma unroll
         for (int u = 0; u < kL1U; ++u) pp[u] = p.P ? ld4(p.P + r.pt[u] * p.C + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float f[kL1U][kL1MaxFeat];
-#pragma unroll
-        for (int u = 0; u < kL1U; ++u)
-#pragma unroll
-            for (int k = 0; k < kL1MaxFeat; ++k) f[u][k] = k < p.cf ? p.points[r.pt[u] * p.cf + k] : 0.0f;     // (cf uniform: no loads when 0)
 #pragma unroll
         for (int u = 0; u < kL1U; ++u) {
             float z[4] = {pp[u].x + b4[0], pp[u].y + b4[1], pp[u].z + b4[2], pp[u].w + b4[3]};
@@ -1739,12 +1730,7 @@ __global__ __launch_bounds__(kL1Threads) void tl_l1_forward_kernel(const TlL1 p)
                 z[i] = fmaf(x[u][1], a1[i], z[i]);
                 z[i] = fmaf(x[u][2], a2[i], z[i]);
             }
-            if (p.cf > 0) {
-#pragma unroll
-                for (int k = 0; k < kL1MaxFeat; ++k)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) z[i] = fmaf(f[u][k], af[k][i], z[i]);          // zero weight beyond cf
-            }
+
             if (r.ok[u]) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { s1[i] += z[i]; s2[i] = fmaf(z[i], z[i], s2[i]); }
@@ -2627,9 +2613,7 @@ static int launch_l1_forward(long long rows, const GroupDims &gd, const pn2_grou
     q.rows = rows; q.n = gd.n; q.m = gd.m; q.nsample = gd.nsample; q.C = L.cout;
     q.xyz = group->xyz; q.new_xyz = group->new_xyz; q.idx = group->idx; q.P = P;
     q.wx = L.weight + gt.xyz_off * L.w_stride_k; q.skx = L.w_stride_k; q.sn = L.w_stride_n;
-    if (!P && gt.cfeat > 0) {                                     // a few feature channels gathered per row (l1_coords_only)
-        q.points = group->points; q.cf = gt.cfeat; q.wf = L.weight + gt.feat_off * L.w_stride_k;
-    }
+
     q.bias = nullptr; q.z = L.z;                  // no conv bias in the stored tensor (pn2_mlp_train_forward)
     q.stats = stats;
     const int rpb = kL1Threads / (L.cout / 4);
