@@ -800,7 +800,26 @@ __global__ __launch_bounds__(256) void tl_top_grad_kernel(long long rows, int N,
     const int ry = threadIdx.x >> 6;
     double s1 = 0.0, s2 = 0.0;
     if (c < N) {
-        for (long long r = (long long)blockIdx.y * 4 + ry; r < rows; r += (long long)gridDim.y * 4) {
+        // four rows per trip (independent loads in flight; one row at a time was a chain of memory latencies, as in
+        // tl_pool_grad_kernel): the sums keep their order
+        const long long rstep = (long long)gridDim.y * 4;
+        long long r = (long long)blockIdx.y * 4 + ry;
+        for (; r + 3 * rstep < rows; r += 4 * rstep) {
+            float o4[4], g4[4], z4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t o = (size_t)(r + u * rstep) * N + c;
+                o4[u] = out[o]; g4[u] = gout[o]; z4[u] = z[o];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float q = o4[u] > 0.0f ? g4[u] : 0.0f;
+                dy[(size_t)(r + u * rstep) * N + c] = q;
+                s1 += (double)q;
+                s2 += (double)q * (double)z4[u];
+            }
+        }
+        for (; r < rows; r += rstep) {
             const size_t o = (size_t)r * N + c;
             const float q = out[o] > 0.0f ? gout[o] : 0.0f;
             dy[o] = q;
