@@ -369,6 +369,9 @@ typedef struct pn2_train_opts {
     int side_stream;               /* backward: the weight-gradient launches on a helper stream beside the data-gradient chain
                                       (fork / join by events on the caller's stream): ON only -- measured slower on all but the
                                       group_all level, so AUTO = OFF */
+    int pair_launch;               /* backward: a layer's data-gradient GEMM and its weight-gradient pass as two ranges of workgroups
+                                      of ONE launch (independent passes over the same tensors; AUTO: below 0.5 M rows, where each is a
+                                      latency-bound launch over part of the chip; ON: wherever the shape pair has a kernel), OFF: never */
 } pn2_train_opts;
 long long pn2_mlp_train_ws_bytes(long long rows, int nlayers, const int *widths /* cin_1, cout_1 .. cout_L */,
                                  int pool_rows, int backward,

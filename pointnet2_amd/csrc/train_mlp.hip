@@ -308,8 +308,23 @@ __device__ __forceinline__ f32x16 tl_finish(const ARaw &r, const RowCtx &rc, int
     return x;
 }
 
-template <int NS, int AMODE>
-__global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
+// The workgroup's position in its (gx, slabs) grid comes from an index provider: the hardware's blockIdx / gridDim for the
+// stand-alone kernels (HwIx: the very expressions the kernels were written with -- their register allocation is tight, and
+// plain integer parameters moved several of them into scratch), a range of the block numbers for tl_pair_kernel (SubIx).
+struct HwIx {
+    __device__ __forceinline__ unsigned bx() const { return blockIdx.x; }
+    __device__ __forceinline__ unsigned by() const { return blockIdx.y; }
+    __device__ __forceinline__ unsigned gx() const { return gridDim.x; }
+};
+struct SubIx {
+    unsigned x, y, g;
+    __device__ __forceinline__ unsigned bx() const { return x; }
+    __device__ __forceinline__ unsigned by() const { return y; }
+    __device__ __forceinline__ unsigned gx() const { return g; }
+};
+
+template <int NS, int AMODE, class IX>
+__device__ __forceinline__ void tl_gemm_body(const TlGemm &p, const IX ix)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int kpad = p.tk * 32;
@@ -317,7 +332,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
     u32x4 *wst = reinterpret_cast<u32x4 *>(lp2 + kpad);
     const int tid = threadIdx.x, lane = tid & 63, hl = lane >> 5, s = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // wave-uniform: item bases live in SGPRs
-    const int slab = blockIdx.y;
+    const int slab = ix.by();
     constexpr int kStageV = NS * kPairVec;
     constexpr int PV = (kStageV + kTlThreads - 1) / kTlThreads;
     constexpr bool PREFZ = (AMODE == A_DZ || AMODE == A_FILL) && NS <= 2;              // prefetch the ReLU mask's source rows (E_MASK)
@@ -397,7 +412,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
         bool nvalid = other.valid;
         if (DEPTH == 1) {
             nu = sl.u + 1; nr = sl.round;
-            if (nu >= p.tk) { nu = 0; nr += gridDim.x; }
+            if (nu >= p.tk) { nu = 0; nr += ix.gx(); }
             nvalid = nr < rounds;
         }
         const u32x4 *stage;
@@ -449,7 +464,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
             int u2 = nu;
             if (DEPTH == 2) {
                 u2 = nu + 1;
-                if (u2 >= p.tk) { u2 = 0; r2 += gridDim.x; }
+                if (u2 >= p.tk) { u2 = 0; r2 += ix.gx(); }
             }
             if (nvalid) assign(sl, r2, u2); else sl.valid = false;
             if ((AMODE != A_GATHER || DEPTH == 1) && sl.valid) fetch(sl);
@@ -560,13 +575,13 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
         }
     };
     Slot s0;
-    assign(s0, blockIdx.x, 0);
+    assign(s0, ix.bx(), 0);
     fetch(s0);
     if (DEPTH == 2) {
         Slot s1;
-        long long r1 = blockIdx.x;
+        long long r1 = ix.bx();
         int u1 = 1;
-        if (u1 >= p.tk) { u1 = 0; r1 += gridDim.x; }
+        if (u1 >= p.tk) { u1 = 0; r1 += ix.gx(); }
         if (s0.valid) assign(s1, r1, u1); else s1.valid = false;
         if (s1.valid) fetch(s1);
         while (s0.valid) {
@@ -597,9 +612,15 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
             double sum = 0.0;
 #pragma unroll
             for (int w = 0; w < kTlWaves; ++w) sum += red[(w * 2 + which) * (NS * 32) + c];
-            if (col < p.N) p.stats[((size_t)blockIdx.x * 2 + which) * p.N + col] = sum;
+            if (col < p.N) p.stats[((size_t)ix.bx() * 2 + which) * p.N + col] = sum;
         }
     }
+}
+
+template <int NS, int AMODE>
+__global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
+{
+    tl_gemm_body<NS, AMODE>(p, HwIx());
 }
 
 // ---- weights -> three-level bf16 operand tiles, on the device ---------------------------------------------------------
@@ -1133,17 +1154,17 @@ __device__ __forceinline__ void wg_store_unit(const WgUnit &w, const WgRaw &r, i
 // sums, 128-byte row stores). The dy waves run their own copy of the block loop (template ROLE): vector-memory returns
 // are counted in order, and a wait shared with waves that issue no mask loads / stores between two prefetches could
 // only be the smaller count, i.e. the dy waves would wait for half of the prefetch they just issued.
-template <int TPW, int UPW, bool GATHER, int DCLS, bool DY, bool L1X = false>
-__global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
+template <int TPW, int UPW, bool GATHER, int DCLS, bool DY, bool L1X, class IX>
+__device__ __forceinline__ void tl_wgrad_body(const TlWgrad &p, const IX ix)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // uniform: scalar branches
-    const int us = blockIdx.y / p.tslabs, ts = blockIdx.y % p.tslabs;
+    const int us = ix.by() / p.tslabs, ts = ix.by() % p.tslabs;
     const int ntiles = p.tus + p.tts, nunits = 2 * ntiles, nout = p.tus * p.tts;
     const int imgv = ntiles * 3 * 2 * 64;                           // 16-byte vectors of one block image
     u32x4 *img0 = reinterpret_cast<u32x4 *>(smem);
     u32x4 *img1 = (DY && p.single) ? img0 : img0 + imgv;
-    const long long blocks = p.rows / 32, step = gridDim.x;
+    const long long blocks = p.rows / 32, step = ix.gx();
     f32x16 acc[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
@@ -1363,7 +1384,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
             }
         }
     }
-    long long blk = blockIdx.x;
+    long long blk = ix.bx();
     load(blk, ra);
     load(blk + step, rb);
     if (L1X && DY && dyt == 0) { xpa = xload(blk); xpb = xload(blk + step); }
@@ -1375,7 +1396,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
     };
     if (DY && dyt >= 0) run(std::true_type{}); else run(std::false_type{});
 #ifdef PN2_WG_TIMING
-    if (p.timing && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)
+    if (p.timing && ix.bx() == 0 && ix.by() == 0 && lane == 0)
         for (int k = 0; k < 6; ++k) p.timing[wave * 6 + k] = tph[k];
 #endif
     if (DY && dyt >= 0 && p.dy_stats) {
@@ -1384,8 +1405,8 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
         const int col = dyt * 32 + (lane & 31);
         const double d1 = sd1 + __shfl_xor(sd1, 32), d2 = sd2 + __shfl_xor(sd2, 32);
         if (lane < 32 && col < p.dy_cols) {
-            p.dy_stats[((size_t)blockIdx.x * 2 + 0) * p.dy_pitch + col] = d1;
-            p.dy_stats[((size_t)blockIdx.x * 2 + 1) * p.dy_pitch + col] = d2;
+            p.dy_stats[((size_t)ix.bx() * 2 + 0) * p.dy_pitch + col] = d1;
+            p.dy_stats[((size_t)ix.bx() * 2 + 1) * p.dy_pitch + col] = d2;
         }
     }
     if (L1X && DY && dyt >= 0 && p.l1a) {
@@ -1393,11 +1414,11 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const double a = sda[k] + __shfl_xor(sda[k], 32);
-            if (lane < 32 && col < p.dy_cols) p.l1a[((size_t)blockIdx.x * 3 + k) * p.dy_pitch + col] = a;
+            if (lane < 32 && col < p.dy_cols) p.l1a[((size_t)ix.bx() * 3 + k) * p.dy_pitch + col] = a;
         }
     }
     // dump: D[i = input channel mlp_chan(v, hl)][j = output channel lane & 31] of tile (u, t); one slab per WORKGROUP
-    float4 *dst = reinterpret_cast<float4 *>(p.partial) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * nout * 256;
+    float4 *dst = reinterpret_cast<float4 *>(p.partial) + ((size_t)ix.by() * ix.gx() + ix.bx()) * nout * 256;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int q = wave + 8 * i;
@@ -1408,6 +1429,36 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
                 dst[(size_t)q * 256 + v4 * 64 + lane] = o;
             }
         }
+    }
+}
+
+template <int TPW, int UPW, bool GATHER, int DCLS, bool DY, bool L1X = false>
+__global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
+{
+    tl_wgrad_body<TPW, UPW, GATHER, DCLS, DY, L1X>(p, HwIx());
+}
+
+// ---- a layer's data gradient AND its weight gradient in one launch, side by side (small levels) ---------------------------------
+// dy_{l-1} = dz_l W_l^T (tl_gemm_body) and dW_l = h_{l-1}^T dz_l (tl_wgrad_body) read the same tensors and write disjoint ones. On
+// a level of a few thousand rows each is a launch of 10-50 us that occupies a fraction of the chip for a few dependent
+// round trips to memory, and one after the other they were half of such a level's backward time (profiles/r04: sem_seg SA4
+// 25 + 29 and 40 + 30 us for its two upper layers). Two streams cost more than they gave (~10 us per cross-queue
+// dependency, SideStream above). Here the two passes are two RANGES OF WORKGROUPS of one grid -- blocks [0, ga * gsl) run the
+// GEMM on a (ga, gsl) grid, the rest the weight gradient on a (gw, slabs) grid -- like the producers and consumers of
+// sa_fused_kernel, but with nothing to exchange. Registers and LDS are the larger of the two bodies'. One instantiation per
+// shape pair that occurs at the reference networks' levels (launch_pair's table); any other pair takes the two launches.
+template <int NS, int AMODE, int TPW, int UPW, int DCLS>
+__global__ __launch_bounds__(kTlThreads) void tl_pair_kernel(const TlGemm pg, const TlWgrad pw, const unsigned ga, const unsigned gsl,
+                                                             const unsigned gw)
+{
+    const unsigned na = ga * gsl;
+    if (blockIdx.x < na) {
+        const SubIx ix = {blockIdx.x % ga, blockIdx.x / ga, ga};
+        tl_gemm_body<NS, AMODE>(pg, ix);
+    } else {
+        const unsigned b = blockIdx.x - na;
+        const SubIx ix = {b % gw, b / gw, gw};
+        tl_wgrad_body<TPW, UPW, false, DCLS, false, false>(pw, ix);
     }
 }
 
@@ -1444,6 +1495,45 @@ __global__ __launch_bounds__(256) void tl_wgrad_reduce_b_kernel(const float *__r
         for (long long w = 0; w < nw; ++w) sum += (double)in[(slab * nw + w) * e + off];
         if (plain) plain[i] = sum;                                 // (KI, NO) row-major fp64, for the pooled top layer's fix-up
         else gw[k * sk + n * sn] = accumulate ? __fadd_rn(gw[k * sk + n * sn], (float)sum) : (float)sum;
+    }
+}
+
+// Both stages in ONE launch when there are at most 8 chunks (every level but the two-workgroups-per-CU passes): thread
+// (output, chunk) adds its chunk's partials in fp32 -- stage A's sum, same order --, the chunk sums meet in LDS and are added in
+// fp64 in chunk order -- stage B's. Bit-identical to the two launches; what it saves is a launch of ~10 us per weight
+// gradient on the levels whose whole backward is 250 us (a block owns 32 outputs, so 8 K outputs still fill the chip).
+__global__ __launch_bounds__(256) void tl_wgrad_reduce_ab_kernel(const float *__restrict__ in, long long nw, int nchunks, int TU, int TT,
+                                                                 int tslabs, int KI, int NO, float *__restrict__ gw, long long sk,
+                                                                 long long sn, double *__restrict__ plain, int accumulate)
+{
+    __shared__ float sh[8][32];
+    const int ox = threadIdx.x & 31, ck = threadIdx.x >> 5;
+    const long long total = (long long)KI * NO;
+    for (long long base = (long long)blockIdx.x * 32; base < total; base += (long long)gridDim.x * 32) {      // uniform trip count
+        const long long i = base + ox;
+        const bool live = i < total;
+        const int k = live ? (int)(i / NO) : 0, n = live ? (int)(i - (long long)k * NO) : 0;
+        float sum = 0.0f;
+        if (live && ck < nchunks) {
+            const int u = k >> 5, kk = k & 31, t = n >> 5;
+            const int hh = (kk >> 2) & 1, v = 4 * (kk >> 3) + (kk & 3), lane = (n & 31) + 32 * hh;
+            const int us = u / TU, ul = u % TU, ts = t / TT, tl = t % TT;
+            const long long slab = (long long)us * tslabs + ts;
+            const size_t e = (size_t)TU * TT * 1024, off = (size_t)(ul * TT + tl) * 1024 + (v >> 2) * 256 + lane * 4 + (v & 3);
+            const long long w0 = (long long)ck * 32, w1 = w0 + 32 < nw ? w0 + 32 : nw;
+            const float *src = in + (size_t)(slab * nw + w0) * e + off;
+#pragma unroll 8
+            for (long long w = w0; w < w1; ++w, src += e) sum += *src;
+        }
+        sh[ck][ox] = sum;
+        __syncthreads();
+        if (ck == 0 && live) {
+            double d = 0.0;
+            for (int c = 0; c < nchunks; ++c) d += (double)sh[c][ox];
+            if (plain) plain[i] = d;
+            else gw[k * sk + n * sn] = accumulate ? __fadd_rn(gw[k * sk + n * sn], (float)d) : (float)d;
+        }
+        __syncthreads();
     }
 }
 
@@ -2292,6 +2382,10 @@ static TlGather make_gather(const pn2_group_src *g)
     return t;
 }
 
+// (Measured and not kept, round 4: a workgroup splitting its own resident slab from the fp32 weight instead of copying the
+// packed tiles -- one launch of 7-9 us fewer per direction, but +5-7 us in EVERY GEMM of the level (4-6 trips of eight strided
+// loads and a split per thread ahead of the first MFMA; with all loads issued up front the 48 live registers cost more than
+// the latency they hid: sem_seg SA4 backward 245 -> 269 us, the metric level's data gradient 266 -> 292 us).
 static void add_pack_job(TlPackJobs &jobs, int &n, const float *w, long long sk, long long sn, const GemmShape &g, void *out)
 {
     TlPackJob &q = jobs.j[n++];
@@ -2342,7 +2436,7 @@ static int launch_gemm_ns(int amode, const TlGemm &p, const GemmShape &g, dim3 g
     return PN2_E_ARG;
 }
 
-static int launch_gemm(int amode, TlGemm &p, const GemmShape &g, hipStream_t st, const Opts &o, int *nparts = nullptr)
+static dim3 prep_gemm(TlGemm &p, const GemmShape &g, const Opts &o)
 {
     p.K = g.K; p.N = g.N; p.tk = g.tk; p.resident = g.resident;
     {
@@ -2358,8 +2452,13 @@ static int launch_gemm(int amode, TlGemm &p, const GemmShape &g, hipStream_t st,
     long long gx = kMaxParts / g.slabs;                        // persistent: one 8-wave workgroup per CU over all slabs
     if (gx < 1) gx = 1;
     if (gx > rounds) gx = rounds;
-    const dim3 grid((unsigned)gx, (unsigned)g.slabs);
-    if (nparts) *nparts = (int)gx;
+    return dim3((unsigned)gx, (unsigned)g.slabs);
+}
+
+static int launch_gemm(int amode, TlGemm &p, const GemmShape &g, hipStream_t st, const Opts &o, int *nparts = nullptr)
+{
+    const dim3 grid = prep_gemm(p, g, o);
+    if (nparts) *nparts = (int)grid.x;
     if (g.ns == 4) return launch_gemm_ns<4>(amode, p, g, grid, st);
     if (g.ns == 2) return launch_gemm_ns<2>(amode, p, g, grid, st);
     return launch_gemm_ns<1>(amode, p, g, grid, st);
@@ -2399,6 +2498,8 @@ static int launch_wgrad_tpw(const TlWgrad &p, const WgradShape &w, dim3 grid, hi
                                 : launch_wgrad_kern<TPW, false, D_DZ>(p, w, grid, st);
 }
 
+static int launch_wgrad_reduce(const TlWgrad &p, const WgradShape &w, float *partial2, const pn2_bn_layer &L, hipStream_t st, double *plain);
+
 static int launch_wgrad(TlWgrad &p, const WgradShape &w, float *partial2, const pn2_bn_layer &L, hipStream_t st,
                         double *plain = nullptr)
 {
@@ -2426,8 +2527,22 @@ static int launch_wgrad(TlWgrad &p, const WgradShape &w, float *partial2, const 
                     h[wv * 6 + 3] / nb, h[wv * 6 + 4] / nb, h[wv * 6 + 5] / nb);
     }
 #endif
+    return launch_wgrad_reduce(p, w, partial2, L, st, plain);
+}
+
+// the sum of the workgroups' slabs -> the caller's weight gradient (or `plain`, fp64, for the pooled top layer's fix-up)
+static int launch_wgrad_reduce(const TlWgrad &p, const WgradShape &w, float *partial2, const pn2_bn_layer &L, hipStream_t st, double *plain)
+{
+    int rc = PN2_OK;
     const float *src = p.partial;
     long long nw = w.nw;
+    if (w.nchunks && w.nchunks <= 8) {                             // both reduction stages in one launch
+        const long long total = (long long)p.KI * p.NO;
+        long long blocks = (total + 31) / 32;
+        if (blocks > 2048) blocks = 2048;
+        return launch(tl_wgrad_reduce_ab_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, nw, (int)w.nchunks, w.tus, w.tts,
+                      w.tslabs, p.KI, p.NO, L.grad_weight, L.w_stride_k, L.w_stride_n, plain, L.grad_accumulate);
+    }
     if (w.nchunks) {
         const long long e4 = (long long)w.e / 4;
         long long bx = (e4 + 255) / 256;
@@ -2441,6 +2556,55 @@ static int launch_wgrad(TlWgrad &p, const WgradShape &w, float *partial2, const 
     const long long total = (long long)p.KI * p.NO;
     return launch(tl_wgrad_reduce_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, nw, w.tus, w.tts, w.tslabs,
                   p.KI, p.NO, L.grad_weight, L.w_stride_k, L.w_stride_n, plain, L.grad_accumulate);
+}
+
+// One launch for a layer's data-gradient GEMM (its workgroups first) and its weight-gradient pass (tl_pair_kernel), then the
+// weight gradient's reduction. kNoPair: no kernel for this pair of shapes -- the caller launches the two passes one after the
+// other. The table = the pairs the size rules produce at the levels of the four reference networks below 0.5 M rows
+// (scripts/train_pairs.py lists them); a level of other widths simply takes the two launches.
+constexpr int kNoPair = -12345;
+static int launch_pair(int amode, TlGemm &pg, const GemmShape &g, TlWgrad &pw, const WgradShape &w, float *partial2, const pn2_bn_layer &L,
+                       hipStream_t st, const Opts &o, int *nparts, double *plain = nullptr)
+{
+    if (pw.amode == A_GATHER || pw.dy_w) return kNoPair;
+    const int dcls = pw.dmode == A_FILL ? D_TOP : pw.dmode == A_DZ_POOL ? D_DZPOOL : D_DZ;
+    const size_t lds = g.lds > w.lds ? g.lds : w.lds;
+#define PN2_PAIR(AM, NS_, DC, TP, UP)                                                                                    \
+    if (amode == AM && g.ns == NS_ && dcls == DC && w.tpw == TP && w.upw == UP) {                                        \
+        auto kern = tl_pair_kernel<NS_, AM, TP, UP, DC>;                                                                 \
+        const dim3 ga = prep_gemm(pg, g, o);                                                                             \
+        pw.tus = w.tus; pw.tts = w.tts; pw.tslabs = w.tslabs;                                                            \
+        if (int rc = allow_dynamic_lds(kern, lds)) return rc;                                                            \
+        const unsigned total = ga.x * ga.y + (unsigned)w.gridx * (unsigned)(w.uslabs * w.tslabs);                        \
+        if (int rc = launch(kern, dim3(total), dim3(kTlThreads), lds, st, pg, pw, ga.x, ga.y, (unsigned)w.gridx)) return rc; \
+        if (nparts) *nparts = (int)ga.x;                                                                                 \
+        return launch_wgrad_reduce(pw, w, partial2, L, st, plain);                                                       \
+    }
+    PN2_PAIR(A_DZ, 1, D_DZ, 1, 1)
+    PN2_PAIR(A_DZ, 1, D_DZ, 1, 2)
+    PN2_PAIR(A_DZ, 1, D_DZ, 2, 2)
+    PN2_PAIR(A_DZ, 1, D_DZ, 4, 3)
+    PN2_PAIR(A_DZ, 2, D_DZ, 1, 1)
+    PN2_PAIR(A_DZ, 2, D_DZ, 2, 2)
+    PN2_PAIR(A_DZ, 2, D_DZ, 4, 3)
+    PN2_PAIR(A_DZ, 4, D_DZ, 2, 2)
+    PN2_PAIR(A_DZ_POOL, 1, D_DZPOOL, 4, 3)
+    PN2_PAIR(A_DZ_POOL, 2, D_DZPOOL, 4, 3)
+    PN2_PAIR(A_FILL, 1, D_TOP, 1, 2)
+    PN2_PAIR(A_FILL, 2, D_TOP, 2, 3)
+    PN2_PAIR(A_FILL, 4, D_TOP, 4, 3)
+#undef PN2_PAIR
+#ifdef PN2_PAIR_TRACE              /* lab build: which pairs a run asks for that the table does not hold */
+    fprintf(stderr, "no pair kernel: amode %d ns %d dcls %d tpw %d upw %d (rows %lld)\n", amode, g.ns, dcls, w.tpw, w.upw, pg.rows);
+#endif
+    return kNoPair;
+}
+
+// Is the pair launch wanted for this layer? (pn2_train_opts.pair_launch; the helper stream, when asked for, keeps the two launches)
+static inline bool pair_wanted(long long rows, const Opts &o)
+{
+    if (o.pair_launch == PN2_OPT_OFF || o.side_stream == PN2_OPT_ON) return false;
+    return o.pair_launch == PN2_OPT_ON || rows < (1ll << 19);
 }
 
 template <int KC>
@@ -2963,10 +3127,12 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
             }
             {
                 // weight gradient: the routed part S on the vector units (tl_top_s_kernel) when its shape allows, the Gram
-                // matrix h^T h and the column sums of h from the dense kernel, combined by tl_top_wgrad_fix_kernel
+                // matrix h^T h and the column sums of h from the dense kernel, combined by tl_top_wgrad_fix_kernel;
+                // data gradient: the GEMM over [routed gradient | h]. The dense kernel and the GEMM are independent passes over
+                // z_{l-1}: one launch for both where the pair has a kernel (tl_pair_kernel)
                 const TopSShape ts = top_s_shape(rows, pool_rows, K, NF, o);
                 double *s64 = ts.ok ? reinterpret_cast<double *>(base + pl.tops64) : nullptr;
-                if (int rc = sd.fork()) return rc;                 // the weight gradient's three kernels beside the data gradient below
+                if (int rc = sd.fork()) return rc;                 // the weight gradient's kernels beside the data gradient below
                 if (ts.ok) {
                     TlTopS q;
                     memset(&q, 0, sizeof(q));
@@ -2988,14 +3154,6 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 w.partial = reinterpret_cast<float *>(base + pl.partial);
                 const WgradShape ws_ = wgrad_shape(rows, K, ldw, false, cus, o.wgrad_two_per_cu);
                 w.xshare = ws_.uslabs == 1;
-                if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, ss, sf)) return rc;
-                long long blocks = ((long long)K * NF + 255) / 256;
-                if (blocks > 4096) blocks = 4096;
-                if (int rc = launch(tl_top_wgrad_fix_kernel, dim3((unsigned)blocks), dim3(256), 0, ss, (const double *)sf, ldw, K, NF,
-                                    tfw * 32, tfw * 32 + tiles(K) * 32, L.weight, L.w_stride_k, L.w_stride_n, (const float *)coef,
-                                    (const float *)nullptr, L.grad_weight, (const double *)s64, L.grad_accumulate)) return rc;
-            }
-            {
                 const GemmShape g = gemm_shape(rows, NFp + K, K, o);
                 if (int rc = launch_pack(wp, K, 1, g, base + pl.pack[l], st)) return rc;
                 TlGemm p;
@@ -3010,9 +3168,19 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 p.out = gnext;
                 p.zprev = D.z; p.ea = D.save + 2 * D.cout; p.ec = D.save + 3 * D.cout;
                 p.stats = reinterpret_cast<double *>(base + pl.stats[l - 1]);
-                int np = 0;
-                if (int rc = launch_gemm(A_FILL, p, g, st, o, &np)) return rc;
+                int np = 0, rc = kNoPair;
+                if (pair_wanted(rows, o)) rc = launch_pair(A_FILL, p, g, w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, st, o, &np, sf);
+                if (rc == kNoPair) {
+                    if ((rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, ss, sf))) return rc;
+                    rc = launch_gemm(A_FILL, p, g, st, o, &np);
+                }
+                if (rc) return rc;
                 nparts[l - 1] = np;
+                long long blocks = ((long long)K * NF + 255) / 256;
+                if (blocks > 4096) blocks = 4096;
+                if (int rc2 = launch(tl_top_wgrad_fix_kernel, dim3((unsigned)blocks), dim3(256), 0, ss, (const double *)sf, ldw, K, NF,
+                                     tfw * 32, tfw * 32 + tiles(K) * 32, L.weight, L.w_stride_k, L.w_stride_n, (const float *)coef,
+                                     (const float *)nullptr, L.grad_weight, (const double *)s64, L.grad_accumulate)) return rc2;
             }
             float *tmp = gcur; gcur = gnext; gnext = tmp;
             continue;
@@ -3124,41 +3292,49 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 continue;
             }
             const WgradShape ws_ = wgrad_shape(rows, L.cin, L.cout, w.amode == A_GATHER, cus, o.wgrad_two_per_cu);
-            if (int rc = sd.fork()) return rc;                     // beside the data-gradient GEMM below
-            if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, ss)) return rc;
-        }
-        // data gradient
-        if (l > 0 || want_dx) {
-            const GemmShape g = (l == 0 && group) ? gemm_shape(rows, L.cout, make_gather(group).cfeat, o) : gemm_shape(rows, L.cout, L.cin, o);
-            TlGemm p;
-            memset(&p, 0, sizeof(p));
-            p.rows = rows;
-            p.A = L.z;
-            p.G = pooled_top ? gq : gcur;
-            p.argsel = argsel;
-            p.p0 = coef; p.p1 = coef + L.cout; p.p2 = coef + 2 * L.cout;
-            p.group_rows = pool_rows;
-            p.wpacked = reinterpret_cast<const u32x4 *>(base + pl.pack[l]);
-            if (l > 0) {
-                const pn2_bn_layer &D = layers[l - 1];
-                p.emode = E_MASK;
-                p.out = gnext;
-                p.zprev = D.z;
-                p.ea = D.save + 2 * D.cout;
-                p.ec = D.save + 3 * D.cout;
-                p.stats = reinterpret_cast<double *>(base + pl.stats[l - 1]);
+            if (!(l > 0 || want_dx)) {                             // no data gradient below this layer
+                if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, st)) return rc;
             } else {
-                p.emode = E_PLAIN;
-                if (group) {
-                    const TlGather gt = make_gather(group);
-                    p.out = grad_feat_rows; p.out_pitch = gt.cfeat; p.col0 = 0; p.col1 = gt.cfeat;
+                // data gradient: independent of the weight gradient -- ONE launch for both where the pair has a kernel
+                // (tl_pair_kernel), else the weight gradient first (on the helper stream when that is asked for)
+                const GemmShape g = (l == 0 && group) ? gemm_shape(rows, L.cout, make_gather(group).cfeat, o) : gemm_shape(rows, L.cout, L.cin, o);
+                TlGemm p;
+                memset(&p, 0, sizeof(p));
+                p.rows = rows;
+                p.A = L.z;
+                p.G = pooled_top ? gq : gcur;
+                p.argsel = argsel;
+                p.p0 = coef; p.p1 = coef + L.cout; p.p2 = coef + 2 * L.cout;
+                p.group_rows = pool_rows;
+                p.wpacked = reinterpret_cast<const u32x4 *>(base + pl.pack[l]);
+                if (l > 0) {
+                    const pn2_bn_layer &D = layers[l - 1];
+                    p.emode = E_MASK;
+                    p.out = gnext;
+                    p.zprev = D.z;
+                    p.ea = D.save + 2 * D.cout;
+                    p.ec = D.save + 3 * D.cout;
+                    p.stats = reinterpret_cast<double *>(base + pl.stats[l - 1]);
                 } else {
-                    p.out = grad_x; p.out_pitch = L.cin; p.col0 = 0; p.col1 = L.cin;
+                    p.emode = E_PLAIN;
+                    if (group) {
+                        const TlGather gt = make_gather(group);
+                        p.out = grad_feat_rows; p.out_pitch = gt.cfeat; p.col0 = 0; p.col1 = gt.cfeat;
+                    } else {
+                        p.out = grad_x; p.out_pitch = L.cin; p.col0 = 0; p.col1 = L.cin;
+                    }
                 }
+                const int amode = pooled_top ? A_DZ_POOL : A_DZ;
+                int np = 0, rc = kNoPair;
+                if (pair_wanted(rows, o)) rc = launch_pair(amode, p, g, w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, st, o, &np);
+                if (rc == kNoPair) {
+                    if ((rc = sd.fork())) return rc;               // beside the data-gradient GEMM
+                    if ((rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, ss))) return rc;
+                    rc = launch_gemm(amode, p, g, st, o, &np);
+                }
+                if (rc) return rc;
+                if (l > 0) nparts[l - 1] = np;
             }
-            int np = 0;
-            if (int rc = launch_gemm(pooled_top ? A_DZ_POOL : A_DZ, p, g, st, o, &np)) return rc;
-            if (l > 0) nparts[l - 1] = np;
         }
         float *tmp = gcur; gcur = gnext; gnext = tmp;
     }

@@ -54,6 +54,8 @@ def _case(seed):
                   xyz_first=rng.random() < 0.6)
     if kw.get("cfeat") and rng.random() < 0.3:              # (drawn last: the cases of earlier rounds keep their seeds)
         kw["feat_grad"] = False                             # the features are data: layer 1's backward on the vector units when they are few
+    if rng.random() < 0.4:
+        env["pair_launch"] = rng.random() < 0.6             # a layer's two backward passes in one launch wherever the pair has a kernel / never
     return kw, env
 
 

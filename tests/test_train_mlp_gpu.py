@@ -98,6 +98,54 @@ def test_one_pass_backward_variants(cuda, name, kw, ztop):
     assert worst <= TOL, "%s: worst relative error %.2e" % (name, worst)
 
 
+# A layer's data-gradient GEMM and its weight-gradient pass as two ranges of workgroups of ONE launch (tl_pair_kernel; the
+# default below 0.5 M rows, so the config cases above already run it against float64): the same arithmetic in the same order
+# as the two launches -- every gradient must come out BIT-identical with the pair forced on and forced off. One level per
+# kernel family of launch_pair's table: dense layers (FP levels), a pooled top layer with its pre-norm tensor kept (SA3, SA4)
+# and without it (SA2: routed-gradient tiles + Gram matrix beside the GEMM over [routed gradient | h]).
+PAIR_CASES = [c for c in CONFIG_CASES if c[0] in ("cfg5 sem_seg SA2", "cfg5 sem_seg SA3", "cfg5 sem_seg SA4", "cfg5 sem_seg FP2",
+                                                    "cfg5 sem_seg FP3", "cfg5 sem_seg FP4", "cfg4 part_seg FP1", "cfg4 part_seg FP3")]
+
+
+@pytest.mark.parametrize("name,kw", PAIR_CASES, ids=[c[0] for c in PAIR_CASES])
+def test_pair_launch_is_bit_identical_to_two_launches(cuda, name, kw):
+    import pointnet2_amd.pointnet_util as U
+    from pointnet2_amd import train_mlp
+    g = torch.Generator(device="cpu").manual_seed(7)
+    torch.manual_seed(7)
+    plain = bool(kw.get("plain_cin"))
+    cin = kw["plain_cin"] if plain else 3 + kw["cfeat"]
+    net = U._SharedMLP(cin, kw["widths"], bn=True).to(cuda).train()
+    b, n = kw["b"], kw["n"]
+    if plain:
+        x = torch.randn((b, n, cin), generator=g).to(cuda).requires_grad_(True)
+        leaves = [x]
+        fn = lambda: train_mlp.fp_mlp_train(net.net, x)
+    else:
+        xyz = torch.rand((b, n, 3), generator=g).to(cuda)
+        pts = torch.randn((b, n, kw["cfeat"]), generator=g).to(cuda).requires_grad_(True)
+        new_xyz = xyz[:, :kw["m"]].contiguous()
+        idx = torch.randint(0, n, (b, kw["m"], kw["ns"]), generator=g, dtype=torch.int32).to(cuda)
+        leaves = [pts]
+        fn = lambda: train_mlp.sa_mlp_train(net.net, xyz, new_xyz, pts, idx, True)[0]
+    params = [p for p in net.parameters()] + leaves
+    results = []
+    from pointnet2_amd._tensors import set_deterministic
+    set_deterministic(True)        # (the scatter of dz_1 onto the points adds in arrival order otherwise: layer 1's weight gradient and
+    try:                           # the point gradient of an SA level then differ in the last bits from run to run, pair or not)
+        for pair in (True, False):
+            with train_mlp.options(pair_launch=pair):
+                out = fn()
+                if not results:
+                    gw = torch.randn(out.shape, generator=g).to(cuda)
+                grads = torch.autograd.grad(out, params, gw)
+            results.append([out.detach().clone()] + [t.clone() for t in grads])
+    finally:
+        set_deterministic(False)
+    for a, c in zip(*results):
+        assert torch.equal(a, c), name
+
+
 # Levels whose few feature channels are DATA (the input normals of cls_msg / part_seg level 1: no gradient is asked for them):
 # layer 1 runs on the vector units in both directions (tl_l1_forward_kernel / tl_l1_dz_kernel<false, true>: the features
 # gathered per row like three more coordinates). With a feature gradient wanted the backward takes the generic passes; both
