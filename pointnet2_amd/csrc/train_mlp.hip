@@ -626,10 +626,15 @@ __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
 // ---- weights -> three-level bf16 operand tiles, on the device ---------------------------------------------------------
 // value for K16 step e, level, lane l, slot j of pair (slab, u, t) = level of W[32u + 16e + 8(l >> 5) + j][32(slab NS + t) + (l & 31)]
 struct TlPackJob { const float *w; long long sk, sn; int K, N, tk, ns, slabs; u32x4 *out; };
-struct TlPackJobs { TlPackJob j[8]; };                            // one launch packs every layer of a level (blockIdx.y = layer)
+struct TlPackJobs {                                               // one launch packs every layer of a level (blockIdx.y = layer)
+    TlPackJob j[8];
+    float *ident; int ident_c;                                    // ... and writes the identity coefficients (1, 0, 0) x ident_c, if wanted
+};
 
 __global__ __launch_bounds__(256) void tl_pack_kernel(const TlPackJobs jobs)
 {
+    if (jobs.ident && blockIdx.x == 0 && blockIdx.y == 0)         // dz = 1 * g - 0 - 0 * z (layer 1 per point: S enters as it is)
+        for (int i = threadIdx.x; i < 3 * jobs.ident_c; i += 256) jobs.ident[i] = i < jobs.ident_c ? 1.0f : 0.0f;
     const TlPackJob &q = jobs.j[blockIdx.y];
     const long long total = (long long)q.slabs * q.tk * q.ns * 128;     // one thread per (pair, e, lane)
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -1447,7 +1452,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
 // GEMM on a (ga, gsl) grid, the rest the weight gradient on a (gw, slabs) grid -- like the producers and consumers of
 // sa_fused_kernel, but with nothing to exchange. Registers and LDS are the larger of the two bodies'. One instantiation per
 // shape pair that occurs at the reference networks' levels (launch_pair's table); any other pair takes the two launches.
-template <int NS, int AMODE, int TPW, int UPW, int DCLS>
+template <int NS, int AMODE, int TPW, int UPW, int DCLS, bool GATHER = false>
 __global__ __launch_bounds__(kTlThreads) void tl_pair_kernel(const TlGemm pg, const TlWgrad pw, const unsigned ga, const unsigned gsl,
                                                              const unsigned gw)
 {
@@ -1458,7 +1463,7 @@ __global__ __launch_bounds__(kTlThreads) void tl_pair_kernel(const TlGemm pg, co
     } else {
         const unsigned b = blockIdx.x - na;
         const SubIx ix = {b % gw, b / gw, gw};
-        tl_wgrad_body<TPW, UPW, false, DCLS, false, false>(pw, ix);
+        tl_wgrad_body<TPW, UPW, GATHER, DCLS, false, false>(pw, ix);
     }
 }
 
@@ -1483,17 +1488,24 @@ __global__ __launch_bounds__(256) void tl_wgrad_reduce_b_kernel(const float *__r
                                                                 int tslabs, int KI, int NO, float *__restrict__ gw,
                                                                 long long sk, long long sn, double *__restrict__ plain, int accumulate)
 {
-    const long long total = (long long)KI * NO;
+    // A thread owns one float of the slab layout ([slab][tile][v >> 2][lane][v & 3]: what the workgroups dumped), so a wave
+    // reads 256 contiguous bytes of every partial; the element (k, n) it stands for follows from its position. (One thread per
+    // OUTPUT element read 4 of every 16 bytes it touched: 10-13 us for the 16 MB of partials of a 512 x 256 layer, a third of
+    // what the weight-gradient kernel itself takes on a level of 4,096 rows.)
+    const int tu = (KI + 31) / 32, tt = (NO + 31) / 32, uslabs = (tu + TU - 1) / TU;
+    const long long e = (long long)TU * TT * 1024, total = (long long)uslabs * tslabs * e;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int k = (int)(i / NO), n = (int)(i - (long long)k * NO);
-        const int u = k >> 5, kk = k & 31, t = n >> 5;
-        const int hh = (kk >> 2) & 1, v = 4 * (kk >> 3) + (kk & 3), lane = (n & 31) + 32 * hh;
-        const int us = u / TU, ul = u % TU, ts = t / TT, tl = t % TT;
-        const long long slab = (long long)us * tslabs + ts;
-        const size_t e = (size_t)TU * TT * 1024, off = (size_t)(ul * TT + tl) * 1024 + (v >> 2) * 256 + lane * 4 + (v & 3);
+        const long long slab = i / e;
+        const int r = (int)(i - slab * e), tile = r >> 10, q = r & 1023;
+        const int v = ((q >> 8) << 2) | (q & 3), lane = (q >> 2) & 63;
+        const int us = (int)(slab / tslabs), ts = (int)(slab - (long long)us * tslabs), ul = tile / TT, tl = tile - ul * TT;
+        const int k = (us * TU + ul) * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), n = (ts * TT + tl) * 32 + (lane & 31);
+        if (us * TU + ul >= tu || ts * TT + tl >= tt || k >= KI || n >= NO) continue;
+        const float *src = in + (size_t)slab * nw * e + r;
         double sum = 0.0;
-        for (long long w = 0; w < nw; ++w) sum += (double)in[(slab * nw + w) * e + off];
-        if (plain) plain[i] = sum;                                 // (KI, NO) row-major fp64, for the pooled top layer's fix-up
+#pragma unroll 8
+        for (long long w = 0; w < nw; ++w) sum += (double)src[(size_t)w * e];
+        if (plain) plain[(size_t)k * NO + n] = sum;                // (KI, NO) row-major fp64, for the pooled top layer's fix-up
         else gw[k * sk + n * sn] = accumulate ? __fadd_rn(gw[k * sk + n * sn], (float)sum) : (float)sum;
     }
 }
@@ -1508,20 +1520,20 @@ __global__ __launch_bounds__(256) void tl_wgrad_reduce_ab_kernel(const float *__
 {
     __shared__ float sh[8][32];
     const int ox = threadIdx.x & 31, ck = threadIdx.x >> 5;
-    const long long total = (long long)KI * NO;
+    // 32 consecutive floats of the slab layout per block and trip (see tl_wgrad_reduce_b_kernel: contiguous reads)
+    const int tu = (KI + 31) / 32, tt = (NO + 31) / 32, uslabs = (tu + TU - 1) / TU;
+    const long long e = (long long)TU * TT * 1024, total = (long long)uslabs * tslabs * e;
     for (long long base = (long long)blockIdx.x * 32; base < total; base += (long long)gridDim.x * 32) {      // uniform trip count
-        const long long i = base + ox;
-        const bool live = i < total;
-        const int k = live ? (int)(i / NO) : 0, n = live ? (int)(i - (long long)k * NO) : 0;
+        const long long i = base + ox, slab = i / e;
+        const int r = (int)(i - slab * e), tile = r >> 10, q = r & 1023;
+        const int v = ((q >> 8) << 2) | (q & 3), lane = (q >> 2) & 63;
+        const int us = (int)(slab / tslabs), ts = (int)(slab - (long long)us * tslabs), ul = tile / TT, tl = tile - ul * TT;
+        const int k = (us * TU + ul) * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), n = (ts * TT + tl) * 32 + (lane & 31);
+        const bool live = us * TU + ul < tu && ts * TT + tl < tt && k < KI && n < NO;
         float sum = 0.0f;
         if (live && ck < nchunks) {
-            const int u = k >> 5, kk = k & 31, t = n >> 5;
-            const int hh = (kk >> 2) & 1, v = 4 * (kk >> 3) + (kk & 3), lane = (n & 31) + 32 * hh;
-            const int us = u / TU, ul = u % TU, ts = t / TT, tl = t % TT;
-            const long long slab = (long long)us * tslabs + ts;
-            const size_t e = (size_t)TU * TT * 1024, off = (size_t)(ul * TT + tl) * 1024 + (v >> 2) * 256 + lane * 4 + (v & 3);
             const long long w0 = (long long)ck * 32, w1 = w0 + 32 < nw ? w0 + 32 : nw;
-            const float *src = in + (size_t)(slab * nw + w0) * e + off;
+            const float *src = in + (size_t)(slab * nw + w0) * e + r;
 #pragma unroll 8
             for (long long w = w0; w < w1; ++w, src += e) sum += *src;
         }
@@ -1530,7 +1542,7 @@ __global__ __launch_bounds__(256) void tl_wgrad_reduce_ab_kernel(const float *__
         if (ck == 0 && live) {
             double d = 0.0;
             for (int c = 0; c < nchunks; ++c) d += (double)sh[c][ox];
-            if (plain) plain[i] = d;
+            if (plain) plain[(size_t)k * NO + n] = d;
             else gw[k * sk + n * sn] = accumulate ? __fadd_rn(gw[k * sk + n * sn], (float)d) : (float)d;
         }
         __syncthreads();
@@ -2537,7 +2549,7 @@ static int launch_wgrad_reduce(const TlWgrad &p, const WgradShape &w, float *par
     const float *src = p.partial;
     long long nw = w.nw;
     if (w.nchunks && w.nchunks <= 8) {                             // both reduction stages in one launch
-        const long long total = (long long)p.KI * p.NO;
+        const long long total = (long long)w.uslabs * w.tslabs * (long long)w.e;
         long long blocks = (total + 31) / 32;
         if (blocks > 2048) blocks = 2048;
         return launch(tl_wgrad_reduce_ab_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, nw, (int)w.nchunks, w.tus, w.tts,
@@ -2553,7 +2565,7 @@ static int launch_wgrad_reduce(const TlWgrad &p, const WgradShape &w, float *par
         src = partial2;
         nw = w.nchunks;
     }
-    const long long total = (long long)p.KI * p.NO;
+    const long long total = (long long)w.uslabs * w.tslabs * (long long)w.e;     // one thread per float of the slab layout
     return launch(tl_wgrad_reduce_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, nw, w.tus, w.tts, w.tslabs,
                   p.KI, p.NO, L.grad_weight, L.w_stride_k, L.w_stride_n, plain, L.grad_accumulate);
 }
@@ -2566,12 +2578,14 @@ constexpr int kNoPair = -12345;
 static int launch_pair(int amode, TlGemm &pg, const GemmShape &g, TlWgrad &pw, const WgradShape &w, float *partial2, const pn2_bn_layer &L,
                        hipStream_t st, const Opts &o, int *nparts, double *plain = nullptr)
 {
-    if (pw.amode == A_GATHER || pw.dy_w) return kNoPair;
+    if (pw.dy_w) return kNoPair;
+    const bool gather = pw.amode == A_GATHER;
     const int dcls = pw.dmode == A_FILL ? D_TOP : pw.dmode == A_DZ_POOL ? D_DZPOOL : D_DZ;
     const size_t lds = g.lds > w.lds ? g.lds : w.lds;
-#define PN2_PAIR(AM, NS_, DC, TP, UP)                                                                                    \
-    if (amode == AM && g.ns == NS_ && dcls == DC && w.tpw == TP && w.upw == UP) {                                        \
-        auto kern = tl_pair_kernel<NS_, AM, TP, UP, DC>;                                                                 \
+#define PN2_PAIR(AM, NS_, DC, TP, UP) PN2_PAIR_G(AM, NS_, DC, TP, UP, false)
+#define PN2_PAIR_G(AM, NS_, DC, TP, UP, GA)                                                                              \
+    if (amode == AM && g.ns == NS_ && dcls == DC && w.tpw == TP && w.upw == UP && gather == GA) {                        \
+        auto kern = tl_pair_kernel<NS_, AM, TP, UP, DC, GA>;                                                             \
         const dim3 ga = prep_gemm(pg, g, o);                                                                             \
         pw.tus = w.tus; pw.tts = w.tts; pw.tslabs = w.tslabs;                                                            \
         if (int rc = allow_dynamic_lds(kern, lds)) return rc;                                                            \
@@ -2593,9 +2607,18 @@ static int launch_pair(int amode, TlGemm &pg, const GemmShape &g, TlWgrad &pw, c
     PN2_PAIR(A_FILL, 1, D_TOP, 1, 2)
     PN2_PAIR(A_FILL, 2, D_TOP, 2, 3)
     PN2_PAIR(A_FILL, 4, D_TOP, 4, 3)
+    PN2_PAIR(A_PLAIN, 1, D_DZ, 1, 1)                               // layer 1 per point: dPoints = S W1f^T beside dW1f = points^T S
+    PN2_PAIR(A_PLAIN, 1, D_DZ, 2, 2)
+    PN2_PAIR(A_PLAIN, 2, D_DZ, 2, 2)
+    PN2_PAIR(A_PLAIN, 4, D_DZ, 1, 2)
+    PN2_PAIR(A_PLAIN, 4, D_DZ, 2, 2)
+    PN2_PAIR_G(A_DZ, 1, D_DZ, 4, 3, true)                          // layer 1 of a group_all level (gathered input) with a feature gradient
+    PN2_PAIR_G(A_DZ, 1, D_DZ, 2, 2, true)
+    PN2_PAIR_G(A_DZ, 2, D_DZ, 4, 3, true)
 #undef PN2_PAIR
+#undef PN2_PAIR_G
 #ifdef PN2_PAIR_TRACE              /* lab build: which pairs a run asks for that the table does not hold */
-    fprintf(stderr, "no pair kernel: amode %d ns %d dcls %d tpw %d upw %d (rows %lld)\n", amode, g.ns, dcls, w.tpw, w.upw, pg.rows);
+    fprintf(stderr, "no pair kernel: amode %d ns %d dcls %d tpw %d upw %d gather %d (rows %lld)\n", amode, g.ns, dcls, w.tpw, w.upw, (int)gather, pg.rows);
 #endif
     return kNoPair;
 }
@@ -3014,6 +3037,7 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
         }
         if (fz[l].ok) { wz[l].lds_dy = fz[l].lds; wz[l].upw = fz[l].upw; }
     }
+    bool ident_written = false;
     {
         TlPackJobs jobs;                                          // W_l^T of every data-gradient GEMM, one launch
         memset(&jobs, 0, sizeof(jobs));
@@ -3037,6 +3061,11 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 }
             }
         }
+        if (per_point && nj > 0) {                                // the identity coefficients of layer 1's per-point weight gradient
+            jobs.ident = reinterpret_cast<float *>(base + pl.l1coef);
+            jobs.ident_c = layers[0].cout;
+        }
+        ident_written = jobs.ident != nullptr;
         if (int rc = launch_pack_jobs(jobs, nj, st)) return rc;
     }
     float *ga = reinterpret_cast<float *>(base + pl.ga), *gb = reinterpret_cast<float *>(base + pl.gb);
@@ -3211,7 +3240,8 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
             if (int rc = launch_l1_dz(rows, gd, group, L, gcur, coef, part, true, st)) return rc;
             if (int rc = pn2_group_point_grad_seg(gd.b, gd.n, L.cout, gd.m, gd.nsample, gcur, group->idx, S, base + pl.l1seg,
                                                   reproducible, stream)) return rc;
-            if (int rc = launch(tl_identity_coef_kernel, dim3((unsigned)((3 * L.cout + 127) / 128)), dim3(128), 0, st, L.cout, ident)) return rc;
+            if (!ident_written)
+                if (int rc = launch(tl_identity_coef_kernel, dim3((unsigned)((3 * L.cout + 127) / 128)), dim3(128), 0, st, L.cout, ident)) return rc;
             {
                 TlWgrad w;                                        // dW1f = points^T S
                 memset(&w, 0, sizeof(w));
@@ -3221,11 +3251,11 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 pn2_bn_layer Lf = L;
                 Lf.grad_weight = L.grad_weight + gt.feat_off * L.w_stride_k;
                 const WgradShape ws_ = wgrad_shape(bn, gt.cfeat, L.cout, false, cus, o.wgrad_two_per_cu);
-                if (int rc = sd.fork()) return rc;                 // beside the GEMM for dPoints below
-                if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), Lf, ss)) return rc;
-            }
-            if (want_dx) {                                        // dPoints = S W1f^T
-                const GemmShape g = gemm_shape(bn, L.cout, gt.cfeat, o);
+                if (!want_dx) {
+                    if (int rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), Lf, st)) return rc;
+                    break;
+                }
+                const GemmShape g = gemm_shape(bn, L.cout, gt.cfeat, o);      // dPoints = S W1f^T: beside it, in one launch where the pair has a kernel
                 TlGemm p;
                 memset(&p, 0, sizeof(p));
                 p.rows = bn;
@@ -3233,7 +3263,14 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 p.wpacked = reinterpret_cast<const u32x4 *>(base + pl.pack[l]);
                 p.emode = E_PLAIN;
                 p.out = grad_points; p.out_pitch = gt.cfeat; p.col0 = 0; p.col1 = gt.cfeat;
-                if (int rc = launch_gemm(A_PLAIN, p, g, st, o)) return rc;
+                int rc = kNoPair;
+                if (pair_wanted(rows, o)) rc = launch_pair(A_PLAIN, p, g, w, ws_, reinterpret_cast<float *>(base + pl.partial2), Lf, st, o, nullptr);
+                if (rc == kNoPair) {
+                    if ((rc = sd.fork())) return rc;
+                    if ((rc = launch_wgrad(w, ws_, reinterpret_cast<float *>(base + pl.partial2), Lf, ss))) return rc;
+                    rc = launch_gemm(A_PLAIN, p, g, st, o);
+                }
+                if (rc) return rc;
             }
             break;
         }
