@@ -308,319 +308,16 @@ __device__ __forceinline__ f32x16 tl_finish(const ARaw &r, const RowCtx &rc, int
     return x;
 }
 
-// The workgroup's position in its (gx, slabs) grid comes from an index provider: the hardware's blockIdx / gridDim for the
-// stand-alone kernels (HwIx: the very expressions the kernels were written with -- their register allocation is tight, and
-// plain integer parameters moved several of them into scratch), a range of the block numbers for tl_pair_kernel (SubIx).
-struct HwIx {
-    __device__ __forceinline__ unsigned bx() const { return blockIdx.x; }
-    __device__ __forceinline__ unsigned by() const { return blockIdx.y; }
-    __device__ __forceinline__ unsigned gx() const { return gridDim.x; }
-};
-struct SubIx {
-    unsigned x, y, g;
-    __device__ __forceinline__ unsigned bx() const { return x; }
-    __device__ __forceinline__ unsigned by() const { return y; }
-    __device__ __forceinline__ unsigned gx() const { return g; }
-};
-
-template <int NS, int AMODE, class IX>
-__device__ __forceinline__ void tl_gemm_body(const TlGemm &p, const IX ix)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int kpad = p.tk * 32;
-    float *lp0 = reinterpret_cast<float *>(smem), *lp1 = lp0 + kpad, *lp2 = lp1 + kpad;
-    u32x4 *wst = reinterpret_cast<u32x4 *>(lp2 + kpad);
-    const int tid = threadIdx.x, lane = tid & 63, hl = lane >> 5, s = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // wave-uniform: item bases live in SGPRs
-    const int slab = ix.by();
-    constexpr int kStageV = NS * kPairVec;
-    constexpr int PV = (kStageV + kTlThreads - 1) / kTlThreads;
-    constexpr bool PREFZ = (AMODE == A_DZ || AMODE == A_FILL) && NS <= 2;              // prefetch the ReLU mask's source rows (E_MASK)
-    constexpr int DEPTH = AMODE >= A_DZ ? 1 : 2;                  // A tiles in flight ahead of the MFMAs (register budget)
-    const u32x4 *wsrc = p.wpacked + (size_t)slab * p.tk * kStageV;
-
-    if (AMODE == A_FILL) {
-        for (int i = tid; i < kpad; i += kTlThreads) {
-            const int j = i - p.tk0 * 32;
-            lp0[i] = i < p.K0 ? p.p0[i] : (j >= 0 && j < p.K1) ? p.q0[j] : 0.0f;
-            lp1[i] = (j >= 0 && j < p.K1) ? p.q1[j] : 0.0f;
-            lp2[i] = 0.0f;
-        }
-    } else if (AMODE >= A_RELU) {
-        for (int i = tid; i < kpad; i += kTlThreads) {
-            const bool in = i < p.K;
-            lp0[i] = in ? p.p0[i] : 0.0f;
-            lp1[i] = in ? p.p1[i] : 0.0f;
-            lp2[i] = (in && AMODE >= A_DZ) ? p.p2[i] : 0.0f;
-        }
-    }
-    if (p.resident)
-        for (int i = tid; i < p.tk * kStageV; i += kTlThreads) wst[i] = wsrc[i];
-    __syncthreads();
-
-    const long long items = p.rows / 32;
-    const long long rounds = (items + kTlWaves - 1) / kTlWaves;
-    u32x4 pre[PV];
-    if (!p.resident) {
-#pragma unroll
-        for (int i = 0; i < PV; ++i) {
-            const int j = tid + i * kTlThreads;
-            if (j < kStageV) pre[i] = wsrc[j];
-        }
-    }
-    unsigned parity = 0;
-    double sd1[NS], sd2[NS];
-#pragma unroll
-    for (int t = 0; t < NS; ++t) { sd1[t] = 0.0; sd2[t] = 0.0; }
-
-    // per-column parameters of the epilogue (the lane's columns never change): fetched once -- a global load inside the
-    // round loop would be waited for with vmcnt(0), which also drains the A prefetch
-    float ep0[NS], ep1[NS], ep2[NS];
-#pragma unroll
-    for (int t = 0; t < NS; ++t) {
-        const int col = (slab * NS + t) * 32 + s;
-        ep0[t] = 0.0f; ep1[t] = 0.0f; ep2[t] = 0.0f;
-        if (col < p.N) {
-            if (p.emode == E_MASK) { ep0[t] = p.ea[col]; ep1[t] = p.ec[col]; }
-            else if (p.emode != E_PLAIN && p.bias) ep0[t] = p.bias[col];
-            if (p.emode == E_POOL) ep1[t] = p.pool_gamma[col] >= 0.0f ? 0.0f : -0.0f;      // sign mask: the pool takes the min of z where gamma < 0
-            if ((p.emode == E_MASK || p.emode == E_PLAIN) && p.bias) ep2[t] = p.bias[col];
-        }
-    }
-    // The A operand is a STREAM of k tiles -- (round, u) in consumption order, across rounds -- and runs TWO tiles ahead of
-    // the MFMAs in two register slots: these passes move 0.5-1 KB per MFMA, so what they need is bytes in flight
-    // (8 KB per wave, 64 KB per CU). Gathered rows (layer 1 of an SA level) take two steps: the point index is fetched
-    // when the slot is assigned, the coordinates / features it points to one step later, so neither wait is exposed.
-    struct Slot { ARaw raw; RowCtx rc; long long round, row0, row; int u; bool active, valid, pending; };
-    auto assign = [&](Slot &sl, long long round, int u) {
-        sl.round = round; sl.u = u; sl.valid = round < rounds;
-        const long long item = round * kTlWaves + wave;
-        sl.row0 = item * 32; sl.row = sl.row0 + s;
-        sl.active = sl.valid && item < items;
-        sl.rc = tl_row_ctx<AMODE>(p, sl.row, sl.active);
-        sl.pending = sl.valid;
-    };
-    auto fetch = [&](Slot &sl) {
-        if (sl.pending) tl_load_raw<AMODE>(p, sl.row0, sl.row, sl.rc, sl.u, hl, sl.active, sl.raw);
-        sl.pending = false;
-    };
-    f32x16 acc[NS], zp[PREFZ ? NS : 1];
-    auto consume = [&](Slot &sl, Slot &other) {
-        if (AMODE == A_GATHER) fetch(other);                       // second step of the other slot's gather
-        long long nr = other.round;                               // the step consumed after this one
-        int nu = other.u;
-        bool nvalid = other.valid;
-        if (DEPTH == 1) {
-            nu = sl.u + 1; nr = sl.round;
-            if (nu >= p.tk) { nu = 0; nr += ix.gx(); }
-            nvalid = nr < rounds;
-        }
-        const u32x4 *stage;
-        if (p.resident) {
-            stage = wst + (size_t)sl.u * kStageV;
-        } else {
-            u32x4 *dst = wst + (parity & 1u) * kStageV;
-#pragma unroll
-            for (int i = 0; i < PV; ++i) {
-                const int j = tid + i * kTlThreads;
-                if (j < kStageV) dst[j] = pre[i];
-            }
-            __syncthreads();
-            if (nvalid) {                                          // the next step's weights
-                const u32x4 *nsrc = wsrc + (size_t)nu * kStageV;
-#pragma unroll
-                for (int i = 0; i < PV; ++i) {
-                    const int j = tid + i * kTlThreads;
-                    if (j < kStageV) pre[i] = nsrc[j];
-                }
-            }
-            stage = dst;
-            ++parity;
-        }
-        if (sl.u == 0) {
-#pragma unroll
-            for (int t = 0; t < NS; ++t)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) acc[t][v] = 0.0f;
-        }
-        const ActSplit sp = split_act(tl_finish<AMODE>(sl.raw, sl.rc, sl.u, p.tk0, hl, lp0, lp1, lp2));
-        const bool last = sl.u + 1 == p.tk;
-        const long long erow0 = sl.row0, eitem = sl.round * kTlWaves + wave;
-        const bool eactive = sl.active;
-        if (PREFZ && last && p.emode == E_MASK && eactive) {        // the mask's source rows, under the last tile's MFMAs
-            const rsrc_t rz = make_rsrc(p.zprev + (size_t)erow0 * p.N, 32u * (unsigned)p.N * 4u);
-#pragma unroll
-            for (int t = 0; t < NS; ++t) {
-                const int col = (slab * NS + t) * 32 + s;
-                if (col < p.N) {
-#pragma unroll
-                    for (int v = 0; v < 16; ++v)
-                        zp[t][v] = bload(rz, (4 * hl * p.N + col) * 4, (8 * (v >> 2) + (v & 3)) * p.N * 4);
-                }
-            }
-        }
-        {                                                          // this slot: the tile DEPTH steps ahead
-            long long r2 = nr;
-            int u2 = nu;
-            if (DEPTH == 2) {
-                u2 = nu + 1;
-                if (u2 >= p.tk) { u2 = 0; r2 += ix.gx(); }
-            }
-            if (nvalid) assign(sl, r2, u2); else sl.valid = false;
-            if ((AMODE != A_GATHER || DEPTH == 1) && sl.valid) fetch(sl);
-        }
-#pragma unroll
-        for (int t = 0; t < NS; ++t) acc[t] = stream_pair<true>(stage, t, lane, sp, acc[t]);
-        if (!last) return;
-        // ---- epilogue: lane = column 32(slab NS + t) + s, register v = row row0 + mlp_chan(v, hl) ----------------------
-        // buffer addressing: descriptor at the item's first row, lane offset = (4 hl) rows + its column, uniform offset = the
-        // register's row 8(v >> 2) + (v & 3)
-        const unsigned obytes = 32u * (unsigned)p.N * 4u;
-        const rsrc_t ro = make_rsrc(p.emode == E_PLAIN ? nullptr : p.out + (size_t)erow0 * p.N, p.emode == E_PLAIN ? 0u : obytes);
-#pragma unroll
-        for (int t = 0; t < NS; ++t) {
-            const int col = (slab * NS + t) * 32 + s;
-            const bool ok = eactive && col < p.N;
-            const int voff = (4 * hl * p.N + col) * 4;
-            if (p.emode == E_STORE || p.emode == E_POOL) {
-                // (no bias: the pre-norm tensors are stored without it, pn2_mlp_train_forward; ep0 is 0 in these modes)
-                float s1 = 0.0f, s2 = 0.0f;
-                const f32x16 &val = acc[t];
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    s1 = __fadd_rn(s1, val[v]);
-                    s2 = fmaf(val[v], val[v], s2);
-                }
-                if (ok && !(p.lab & 2)) {
-                    sd1[t] += (double)s1;
-                    sd2[t] += (double)s2;
-                }
-                if (ok && !(p.lab & 1) && p.out) {
-                    if (p.nt) {
-#pragma unroll
-                        for (int v = 0; v < 16; ++v) bstore<true>(val[v], ro, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
-                    } else {
-#pragma unroll
-                        for (int v = 0; v < 16; ++v) bstore<false>(val[v], ro, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
-                    }
-                }
-                if (p.emode == E_POOL) {
-                    // The extremum of z over the rows of the item that the pool will select -- of each half item when a group is
-                    // 16 rows: registers 0-7 hold rows 0-15, registers 8-15 rows 16-31 -- with the row number of its FIRST
-                    // occurrence; the other half of the rows lives in lane l ^ 32. Which extremum is known at launch: batch
-                    // norm + ReLU are monotone per channel, increasing where gamma >= 0 (max), decreasing where gamma < 0 (min
-                    // = max of -z: one sign flip per value instead of a second compare / select chain and a second pair of
-                    // partial arrays). Fully unrolled: a runtime-indexed register array would live in scratch.
-                    const unsigned sgn = __float_as_uint(ep1[t]);
-                    float mx[2];
-                    int ax[2];
-#pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) {
-                        mx[hf] = __uint_as_float(__float_as_uint(val[8 * hf]) ^ sgn); ax[hf] = 8 * hf;
-#pragma unroll
-                        for (int v = 8 * hf + 1; v < 8 * hf + 8; ++v) {
-                            const float q = __uint_as_float(__float_as_uint(val[v]) ^ sgn);
-                            if (q > mx[hf]) { mx[hf] = q; ax[hf] = v; }
-                        }
-                    }
-                    if (p.prow != 16) {                            // one group: registers 8-15 come after 0-7 in row order
-                        if (mx[1] > mx[0]) { mx[0] = mx[1]; ax[0] = ax[1]; }
-                    }
-                    const int halves = p.prow == 16 ? 2 : 1;
-#pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) {
-                        if (hf < halves) {
-                            float bx = mx[hf];
-                            int rx = mlp_chan(ax[hf], hl);
-                            const float omx = __shfl_xor(bx, 32);
-                            const int orx = __shfl_xor(rx, 32);
-                            if (omx > bx || (omx == bx && orx < rx)) { bx = omx; rx = orx; }
-                            if (ok && hl == 0) {
-                                const size_t o = (size_t)(eitem * halves + hf) * p.N + col;
-                                p.pmax[o] = __uint_as_float(__float_as_uint(bx) ^ sgn);
-                                p.pamax[o] = rx - hf * 16;
-                            }
-                        }
-                    }
-                }
-            } else if (p.emode == E_MASK) {
-                const float ea = ep0[t], ec = ep1[t];
-                float s1 = 0.0f, s2 = 0.0f;
-                if (ok) {
-                    if (!PREFZ) {                                  // wide slabs: no registers to spare, fetched here
-                        const rsrc_t rz = make_rsrc(p.zprev + (size_t)erow0 * p.N, obytes);
-#pragma unroll
-                        for (int v = 0; v < 16; ++v) zp[0][v] = bload(rz, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
-                    }
-                    const f32x16 &zz = zp[PREFZ ? t : 0];
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) {
-                        const float y = __fadd_rn(__fmul_rn(ea, zz[v]), ec);
-                        const float g = y > 0.0f ? __fadd_rn(acc[t][v], ep2[t]) : 0.0f;   // ReLU of the layer below
-                        if (p.nt) bstore<true>(g, ro, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
-                        else bstore<false>(g, ro, voff, (8 * (v >> 2) + (v & 3)) * p.N * 4);
-                        s1 = __fadd_rn(s1, g);
-                        s2 = fmaf(g, zz[v], s2);
-                    }
-                    sd1[t] += (double)s1;
-                    sd2[t] += (double)s2;
-                }
-            } else {
-                if (eactive && col >= p.col0 && col < p.col1) {
-#pragma unroll
-                    for (int v = 0; v < 16; ++v)
-                        p.out[(size_t)(erow0 + mlp_chan(v, hl)) * p.out_pitch + (col - p.col0)] = __fadd_rn(acc[t][v], ep2[t]);
-                }
-            }
-        }
-    };
-    Slot s0;
-    assign(s0, ix.bx(), 0);
-    fetch(s0);
-    if (DEPTH == 2) {
-        Slot s1;
-        long long r1 = ix.bx();
-        int u1 = 1;
-        if (u1 >= p.tk) { u1 = 0; r1 += ix.gx(); }
-        if (s0.valid) assign(s1, r1, u1); else s1.valid = false;
-        if (s1.valid) fetch(s1);
-        while (s0.valid) {
-            consume(s0, s1);
-            if (!s1.valid) break;
-            consume(s1, s0);
-        }
-    } else {
-        while (s0.valid) consume(s0, s0);
-    }
-    if (p.emode != E_PLAIN && p.stats) {
-        // per-channel sums of this workgroup's rows: the eight waves' partial sums meet in LDS and leave as ONE row of the
-        // (row workgroups, 2, N) partial array -- no atomics (2048 waves adding into the same 2N addresses serialise in the
-        // L2 for ~100 us per pass), and the finalisation kernel adds the rows in a fixed order
-        __syncthreads();                                           // the weight stages are dead: reuse their LDS
-        double *red = reinterpret_cast<double *>(smem);
-#pragma unroll
-        for (int t = 0; t < NS; ++t) {
-            const double d1 = sd1[t] + __shfl_xor(sd1[t], 32), d2 = sd2[t] + __shfl_xor(sd2[t], 32);
-            if (hl == 0) {
-                red[(wave * 2 + 0) * (NS * 32) + t * 32 + s] = d1;
-                red[(wave * 2 + 1) * (NS * 32) + t * 32 + s] = d2;
-            }
-        }
-        __syncthreads();
-        if (tid < 2 * NS * 32) {
-            const int which = tid / (NS * 32), c = tid % (NS * 32), col = slab * NS * 32 + c;
-            double sum = 0.0;
-#pragma unroll
-            for (int w = 0; w < kTlWaves; ++w) sum += red[(w * 2 + which) * (NS * 32) + c];
-            if (col < p.N) p.stats[((size_t)ix.bx() * 2 + which) * p.N + col] = sum;
-        }
-    }
-}
-
 template <int NS, int AMODE>
 __global__ __launch_bounds__(kTlThreads) void tl_gemm_kernel(const TlGemm p)
 {
-    tl_gemm_body<NS, AMODE>(p, HwIx());
+#define PN2_BX blockIdx.x
+#define PN2_BY blockIdx.y
+#define PN2_GX gridDim.x
+#include "tl_gemm_body.inc"
+#undef PN2_BX
+#undef PN2_BY
+#undef PN2_GX
 }
 
 // ---- weights -> three-level bf16 operand tiles, on the device ---------------------------------------------------------
@@ -1159,288 +856,16 @@ __device__ __forceinline__ void wg_store_unit(const WgUnit &w, const WgRaw &r, i
 // sums, 128-byte row stores). The dy waves run their own copy of the block loop (template ROLE): vector-memory returns
 // are counted in order, and a wait shared with waves that issue no mask loads / stores between two prefetches could
 // only be the smaller count, i.e. the dy waves would wait for half of the prefetch they just issued.
-template <int TPW, int UPW, bool GATHER, int DCLS, bool DY, bool L1X, class IX>
-__device__ __forceinline__ void tl_wgrad_body(const TlWgrad &p, const IX ix)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // uniform: scalar branches
-    const int us = ix.by() / p.tslabs, ts = ix.by() % p.tslabs;
-    const int ntiles = p.tus + p.tts, nunits = 2 * ntiles, nout = p.tus * p.tts;
-    const int imgv = ntiles * 3 * 2 * 64;                           // 16-byte vectors of one block image
-    u32x4 *img0 = reinterpret_cast<u32x4 *>(smem);
-    u32x4 *img1 = (DY && p.single) ? img0 : img0 + imgv;
-    const long long blocks = p.rows / 32, step = ix.gx();
-    f32x16 acc[TPW];
-#pragma unroll
-    for (int i = 0; i < TPW; ++i)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[i][v] = 0.0f;
-    WgRaw ra[UPW], rb[UPW];
-    WgUnit un[UPW];
-    // (measured: taking the unit loads away from the waves that produce the data gradient -- the block's critical path --
-    // made the pass slower, 286 -> 306 us at the metric shape: the other waves' second unit costs more than it frees)
-#pragma unroll
-    for (int i = 0; i < UPW; ++i) un[i] = wg_plan_unit(p, wave + 8 * i, nunits, us, ts, lane);
-    // output tiles of this wave: image slots of their two operands (fixed)
-    int xa_off[TPW], xb_off[TPW];
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int q = wave + 8 * i, u = q < nout ? q / p.tts : 0, t = q < nout ? q % p.tts : 0, tg = ts * p.tts + t;
-        const bool shared = p.dmode == A_FILL && p.xshare && tg >= p.tf && tg < p.tf + p.tus;
-        xa_off[i] = u * 384;
-        xb_off[i] = (shared ? tg - p.tf : p.tus + t) * 384;
-    }
-    const int sw0 = wg_swz(lane, 0), sw1 = 64 + wg_swz(lane, 1);     // lane's fragment of K16 step 0 / 1 inside a (tile, level)
-    const int grows = p.group_rows > 0 ? p.group_rows : 32;
-    // ---- data-gradient role: the LAST dy_nt waves take one output tile each (they own the fewest dW tiles)
-    const int dyt = DY ? uni(7 - wave < p.dy_nt ? 7 - wave : -1) : -1;
-    const u32x4 *wl = img0 + (size_t)((DY && p.single) ? 1 : 2) * imgv;      // packed W^T, resident
-    const int zpitch = p.tus * 32 + 2;                             // raw rows of the layer below: 8 rows apart = 16 banks apart
-    float *zr0 = DY ? reinterpret_cast<float *>(const_cast<u32x4 *>(wl) + (size_t)p.dy_tk * p.dy_nt * kPairVec) : nullptr;
-    float *zr1 = (DY && !p.single) ? zr0 + 32 * zpitch : zr0;
-    u32x4 *ia0 = (DY && p.dy_acopy) ? reinterpret_cast<u32x4 *>(zr0 + (size_t)(p.single ? 1 : 2) * 32 * zpitch) : nullptr;
-    u32x4 *ia1 = (DY && p.dy_acopy && !p.single) ? ia0 + (size_t)p.dy_tk * 384 : ia0;
-    // centred coordinates of the block's rows (l1x): two blocks ahead in registers like the units, 32 x 16 bytes per image
-    float4 *xr0 = DY ? reinterpret_cast<float4 *>(reinterpret_cast<char *>(smem) + p.xr_off) : nullptr;
-    float4 *xr1 = (DY && !p.single) ? xr0 + 32 : xr0;
-    float4 xpa = {0.f, 0.f, 0.f, 0.f}, xpb = {0.f, 0.f, 0.f, 0.f};
-    double sda[3] = {0.0, 0.0, 0.0};
-    double sd1 = 0.0, sd2 = 0.0;
-    // transposed reads: lane = row r of the block = fragment slot (e_r, half hl_r, j_r) of the image; its eight values of a
-    // K16 step are slots of eight channels' fragments: byte address = tile * 6144 + level * 2048 + 256 * (K16 step) + tb + 16 (j ^ sg)
-    int tb = 0, sg16 = 0, sa0 = 0, sa1 = 0;
-    if (DY) {
-        const int r = lane & 31, g = lane >> 5, er = r >> 4, hr = (r >> 3) & 1, jr = r & 7;
-        tb = er * 1024 + (8 * g + 32 * hr) * 16 + jr * 2;
-        sg16 = (g | (hr << 1) | (er << 2)) << 4;
-        sa0 = lane ^ (g | (hr << 1));                              // lane's fragment of K16 step 0 / 1 in the A-layout copy
-        sa1 = 64 + (lane ^ (g | (hr << 1) | 4));
-    }
-    float dy_ea = 0.0f, dy_ec = 0.0f, dy_b = 0.0f;
-    if (DY && dyt >= 0) {
-        const int col = dyt * 32 + (lane & 31);
-        dy_ec = 1.0f;                                              // no mask: y = 0 * z + 1 > 0
-        if (col < p.dy_cols) {
-            if (p.dy_zprev) { dy_ea = p.dy_ea[col]; dy_ec = p.dy_ec[col]; }
-            if (p.dy_bias) dy_b = p.dy_bias[col];
-        }
-    }
-    if (DY) {
-        u32x4 *wdst = const_cast<u32x4 *>(wl);
-        const int nv = p.dy_tk * p.dy_nt * kPairVec;
-        for (int i = threadIdx.x; i < nv; i += kTlThreads) wdst[i] = p.dy_w[i];
-        // the raw rows are only written when the first operand goes through a ReLU (a masked pass); an unmasked pass reads them
-        // too (times zero): defined values
-        const int nz = (p.single ? 1 : 2) * 32 * zpitch;
-        for (int i = threadIdx.x; i < nz; i += kTlThreads) zr0[i] = 0.0f;
-    }
-    auto load = [&](long long b, WgRaw (&r)[UPW]) __attribute__((always_inline)) {   // the same instruction sequence for every wave and block
-        const bool inb = b < blocks;
-        const long long row0 = (inb ? b : 0) * 32;
-        const int grp_u = (int)((unsigned)row0 / (unsigned)grows), off_u = (int)row0 - grp_u * grows;
-#pragma unroll
-        for (int i = 0; i < UPW; ++i) wg_load_unit<GATHER, DCLS>(p, un[i], row0, grp_u, off_u, lane, inb, r[i]);
-    };
-    auto tiles_of_wave = [&](const u32x4 *img) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            if (wave + 8 * i < nout) {
-                const u32x4 *xa = img + xa_off[i], *xb = img + xb_off[i];
-                {
-                    const u32x4 a[3] = {xa[sw0], xa[128 + sw0], xa[256 + sw0]};
-                    const u32x4 d[3] = {xb[sw0], xb[128 + sw0], xb[256 + sw0]};
-                    acc[i] = mma_x6<false>(a, d, acc[i]);
-                }
-                {
-                    const u32x4 a[3] = {xa[sw1], xa[128 + sw1], xa[256 + sw1]};
-                    const u32x4 d[3] = {xb[sw1], xb[128 + sw1], xb[256 + sw1]};
-                    acc[i] = mma_x6<false>(a, d, acc[i]);
-                }
-            }
-        }
-    };
-    // ROLE = 1: this wave also produces tile dyt of the data gradient
-#ifdef PN2_WG_TIMING
-    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
-#define PN2_TICK(K) { const unsigned long long tnow = __builtin_readcyclecounter(); tph[K] += tnow - tlast; tlast = tnow; }
-#else
-#define PN2_TICK(K)
-#endif
-    auto xload = [&](long long b) __attribute__((always_inline)) {      // rows of block b (an empty descriptor when there are none: no branch)
-        const bool inb = b < blocks && p.l1x != nullptr;
-        const rsrc_t rx = make_rsrc(inb ? p.l1x + (size_t)b * 32 : nullptr, inb ? 512u : 0u);
-        return bload4(rx, (lane & 31) * 16, 0);
-    };
-    auto block = [&](long long b, WgRaw (&r)[UPW], u32x4 *img, float *zr, u32x4 *imgA, float4 *xr, float4 &xp, auto role) __attribute__((always_inline)) {
-        constexpr bool ROLE = decltype(role)::value;
-        PN2_TICK(5)
-#pragma unroll
-        for (int i = 0; i < UPW; ++i) wg_store_unit<DCLS>(un[i], r[i], lane, img, zr, zpitch, imgA, p.tus);
-        if (L1X && ROLE && dyt == 0 && lane < 32) xr[lane] = xp;
-        PN2_TICK(0)
-        __syncthreads();
-        PN2_TICK(1)
-        const int hl = lane >> 5, col = dyt * 32 + (lane & 31);
-        const int voff = (ROLE && col < p.dy_cols) ? (4 * hl * p.dy_pitch + col) * 4 : kWgOob;
-        const int rstep = uni(p.dy_pitch * 4);
-        load(b + 2 * step, r);
-        if (L1X && ROLE && dyt == 0) xp = xload(b + 2 * step);
-        tiles_of_wave(img);
-        PN2_TICK(2)
-        if (ROLE) {
-            f32x16 d;
-#pragma unroll
-            for (int v = 0; v < 16; ++v) d[v] = 0.0f;
-            const char *ib = reinterpret_cast<const char *>(img) + tb;
-            if (DCLS != D_TOP && imgA) {
-                // A operand straight from the producers' A-layout copy
-                for (int u = 0; u < p.dy_tk; ++u) {
-                    const u32x4 *ta = imgA + (size_t)u * 384;
-                    ActSplit sp;
-#pragma unroll
-                    for (int lv = 0; lv < 3; ++lv) {
-                        sp.p[0][lv] = ta[lv * 128 + sa0];
-                        sp.p[1][lv] = ta[lv * 128 + sa1];
-                    }
-                    d = stream_pair<true>(wl + (size_t)u * p.dy_nt * kPairVec, dyt, lane, sp, d);
-                }
-            } else {
-                // A operand = the weight gradient's image read transposed (eight 2-byte reads per fragment)
-                for (int u = 0; u < p.dy_tk; ++u) {
-                    const int it = (DCLS == D_TOP && p.xshare && u >= p.dy_tf) ? u - p.dy_tf : p.tus + u;
-                    const char *tp = ib + (size_t)it * 6144;
-                    ActSplit sp;
-#pragma unroll
-                    for (int e = 0; e < 2; ++e)
-#pragma unroll
-                        for (int lv = 0; lv < 3; ++lv) {
-                            const char *q = tp + lv * 2048 + e * 256;
-                            unsigned h[8];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) h[j] = *reinterpret_cast<const unsigned short *>(q + ((j << 4) ^ sg16));
-                            u32x4 f = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
-                            sp.p[e][lv] = f;
-                        }
-                    d = stream_pair<true>(wl + (size_t)u * p.dy_nt * kPairVec, dyt, lane, sp, d);
-                }
-            }
-            PN2_TICK(3)
-            // epilogue of the data-gradient GEMM: lane = column, register v = row 8 (v >> 2) + 4 hl + (v & 3). Branch-free:
-            // every row of the layer below is read from LDS up front (one wait), an unmasked pass multiplies it by zero
-            // (dy_out == nullptr: an empty descriptor -- the stores below are issued and dropped, the instruction stream stays the same)
-            const rsrc_t ro = make_rsrc(p.dy_out ? p.dy_out + (size_t)b * 32 * p.dy_pitch : nullptr,
-                                        p.dy_out ? 32u * (unsigned)p.dy_pitch * 4u : 0u);
-            f32x16 zz;
-            {
-                const float *zs = zr + 4 * hl * zpitch + dyt * 32 + (lane & 31);
-#pragma unroll
-                for (int v = 0; v < 16; ++v) zz[v] = zs[(8 * (v >> 2) + (v & 3)) * zpitch];
-            }
-            float s1 = 0.0f, s2 = 0.0f;
-            f32x16 gv;
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const float y = __fadd_rn(__fmul_rn(dy_ea, zz[v]), dy_ec);        // unmasked pass: ea = 0, ec = 1
-                const float g = y > 0.0f ? __fadd_rn(d[v], dy_b) : 0.0f;         // ReLU of the layer below
-                gv[v] = g;
-                s1 = __fadd_rn(s1, g);
-                s2 = fmaf(g, zz[v], s2);
-            }
-            if (L1X) {
-                // layer 1 below has the three coordinates as its input: dy's product with the rows' coordinates is what its
-                // weight gradient needs (see TlWgrad::l1x); dy itself is not written
-                float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float4 xv = xr[8 * (v >> 2) + 4 * hl + (v & 3)];      // the same address in 32 lanes: LDS broadcast
-                    a0 = fmaf(xv.x, gv[v], a0);
-                    a1 = fmaf(xv.y, gv[v], a1);
-                    a2 = fmaf(xv.z, gv[v], a2);
-                }
-                if (voff != kWgOob) { sda[0] += (double)a0; sda[1] += (double)a1; sda[2] += (double)a2; }
-            }
-            if (L1X) {
-            } else if (p.dy_nt_store) {
-#pragma unroll
-                for (int v = 0; v < 16; ++v) bstore<true>(gv[v], ro, voff, (8 * (v >> 2) + (v & 3)) * rstep);
-            } else {
-#pragma unroll
-                for (int v = 0; v < 16; ++v) bstore<false>(gv[v], ro, voff, (8 * (v >> 2) + (v & 3)) * rstep);
-            }
-            if (voff != kWgOob) {
-                sd1 += (double)s1;
-                sd2 += (double)s2;
-            }
-            PN2_TICK(4)
-        }
-        if (DY && p.single) __syncthreads();                       // the one image is rewritten by the next block
-    };
-    if (DCLS == D_TOP) {
-        // the column of ones (sum over the rows of h): fragment slot j of lanes with c == 0 is bf16 1.0 at level 1, constant
-#pragma unroll
-        for (int i = 0; i < UPW; ++i) {
-            if (un[i].kind == K_ONES) {
-                const unsigned one2 = (lane & 31) == 0 ? 0x3f803f80u : 0u;
-                const u32x4 ones = {one2, one2, one2, one2}, zero = {0u, 0u, 0u, 0u};
-                for (int b = 0; b < 2; ++b) {
-                    u32x4 *o = (b ? img1 : img0) + ((size_t)un[i].tile * 3 * 2 + un[i].e) * 64 + wg_swz(lane, un[i].e);
-                    o[0] = ones; o[128] = zero; o[256] = zero;
-                }
-            }
-        }
-    }
-    long long blk = ix.bx();
-    load(blk, ra);
-    load(blk + step, rb);
-    if (L1X && DY && dyt == 0) { xpa = xload(blk); xpb = xload(blk + step); }
-    auto run = [&](auto role) __attribute__((always_inline)) {
-        for (; blk < blocks; blk += 2 * step) {
-            block(blk, ra, img0, zr0, ia0, xr0, xpa, role);
-            if (blk + step < blocks) block(blk + step, rb, img1, zr1, ia1, xr1, xpb, role);      // uniform over the workgroup
-        }
-    };
-    if (DY && dyt >= 0) run(std::true_type{}); else run(std::false_type{});
-#ifdef PN2_WG_TIMING
-    if (p.timing && ix.bx() == 0 && ix.by() == 0 && lane == 0)
-        for (int k = 0; k < 6; ++k) p.timing[wave * 6 + k] = tph[k];
-#endif
-    if (DY && dyt >= 0 && p.dy_stats) {
-        // per-channel sums of this workgroup's rows: ONE row of the (workgroups, 2, pitch) partial array, summed in a fixed
-        // order by the finalisation kernel
-        const int col = dyt * 32 + (lane & 31);
-        const double d1 = sd1 + __shfl_xor(sd1, 32), d2 = sd2 + __shfl_xor(sd2, 32);
-        if (lane < 32 && col < p.dy_cols) {
-            p.dy_stats[((size_t)ix.bx() * 2 + 0) * p.dy_pitch + col] = d1;
-            p.dy_stats[((size_t)ix.bx() * 2 + 1) * p.dy_pitch + col] = d2;
-        }
-    }
-    if (L1X && DY && dyt >= 0 && p.l1a) {
-        const int col = dyt * 32 + (lane & 31);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const double a = sda[k] + __shfl_xor(sda[k], 32);
-            if (lane < 32 && col < p.dy_cols) p.l1a[((size_t)ix.bx() * 3 + k) * p.dy_pitch + col] = a;
-        }
-    }
-    // dump: D[i = input channel mlp_chan(v, hl)][j = output channel lane & 31] of tile (u, t); one slab per WORKGROUP
-    float4 *dst = reinterpret_cast<float4 *>(p.partial) + ((size_t)ix.by() * ix.gx() + ix.bx()) * nout * 256;
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int q = wave + 8 * i;
-        if (q < nout) {
-#pragma unroll
-            for (int v4 = 0; v4 < 4; ++v4) {
-                const float4 o = {acc[i][4 * v4], acc[i][4 * v4 + 1], acc[i][4 * v4 + 2], acc[i][4 * v4 + 3]};
-                dst[(size_t)q * 256 + v4 * 64 + lane] = o;
-            }
-        }
-    }
-}
-
 template <int TPW, int UPW, bool GATHER, int DCLS, bool DY, bool L1X = false>
 __global__ __launch_bounds__(kTlThreads) void tl_wgrad_kernel(const TlWgrad p)
 {
-    tl_wgrad_body<TPW, UPW, GATHER, DCLS, DY, L1X>(p, HwIx());
+#define PN2_BX blockIdx.x
+#define PN2_BY blockIdx.y
+#define PN2_GX gridDim.x
+#include "tl_wgrad_body.inc"
+#undef PN2_BX
+#undef PN2_BY
+#undef PN2_GX
 }
 
 // ---- a layer's data gradient AND its weight gradient in one launch, side by side (small levels) ---------------------------------
@@ -1458,16 +883,73 @@ __global__ __launch_bounds__(kTlThreads) void tl_pair_kernel(const TlGemm pg, co
 {
     const unsigned na = ga * gsl;
     if (blockIdx.x < na) {
-        const SubIx ix = {blockIdx.x % ga, blockIdx.x / ga, ga};
-        tl_gemm_body<NS, AMODE>(pg, ix);
+        const unsigned sbx = blockIdx.x % ga, sby = blockIdx.x / ga;
+        const TlGemm &p = pg;
+#define PN2_BX sbx
+#define PN2_BY sby
+#define PN2_GX ga
+#include "tl_gemm_body.inc"
+#undef PN2_BX
+#undef PN2_BY
+#undef PN2_GX
     } else {
-        const unsigned b = blockIdx.x - na;
-        const SubIx ix = {b % gw, b / gw, gw};
-        tl_wgrad_body<TPW, UPW, GATHER, DCLS, false, false>(pw, ix);
+        const unsigned sb = blockIdx.x - na, sbx = sb % gw, sby = sb / gw;
+        constexpr bool DY = false, L1X = false;
+        const TlWgrad &p = pw;
+#define PN2_BX sbx
+#define PN2_BY sby
+#define PN2_GX gw
+#include "tl_wgrad_body.inc"
+#undef PN2_BX
+#undef PN2_BY
+#undef PN2_GX
     }
 }
 
-// stage A of the reduction: sums of `chunk` consecutive waves' slabs (layout unchanged): in [slab][nw][E] -> out [slab][nchunks][E]
+// The sum of the workgroups' slabs ([slab][workgroup][E floats]) -> the caller's weight gradient, ONE launch: a block owns 32
+// consecutive floats of the slab layout ([tile][v >> 2][lane][v & 3]: what the workgroups dumped, so every partial is read as
+// contiguous 128-byte pieces) and its eight groups of 32 threads each add an eighth of the workgroups, in order, in fp64;
+// the eight sums meet in LDS and are added in order. A fixed order whatever the timing; two stages in two launches (fp32
+// sums of 32 workgroups, then fp64) were 17-20 us per weight gradient on levels whose whole backward is 200 us, one thread
+// per OUTPUT element read 4 of every 16 bytes it touched.
+// (tl_wgrad_reduce_a_kernel below still serves tl_top_s_kernel's partials.)
+__global__ __launch_bounds__(256) void tl_wgrad_reduce_kernel(const float *__restrict__ in, long long nw, int TU, int TT, int tslabs,
+                                                              int KI, int NO, float *__restrict__ gw, long long sk, long long sn,
+                                                              double *__restrict__ plain, int accumulate)
+{
+    __shared__ double sh[8][32];
+    const int ox = threadIdx.x & 31, ck = threadIdx.x >> 5;
+    const int tu = (KI + 31) / 32, tt = (NO + 31) / 32, uslabs = (tu + TU - 1) / TU;
+    const long long e = (long long)TU * TT * 1024, total = (long long)uslabs * tslabs * e;
+    const long long chunk = (nw + 7) / 8;
+    for (long long base = (long long)blockIdx.x * 32; base < total; base += (long long)gridDim.x * 32) {      // uniform trip count
+        const long long i = base + ox, slab = i / e;
+        const int r = (int)(i - slab * e), tile = r >> 10, q = r & 1023;
+        const int v = ((q >> 8) << 2) | (q & 3), lane = (q >> 2) & 63;
+        const int us = (int)(slab / tslabs), ts = (int)(slab - (long long)us * tslabs), ul = tile / TT, tl = tile - ul * TT;
+        const int k = (us * TU + ul) * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), n = (ts * TT + tl) * 32 + (lane & 31);
+        const bool live = us * TU + ul < tu && ts * TT + tl < tt && k < KI && n < NO;
+        double sum = 0.0;
+        if (live) {
+            const long long w0 = ck * chunk, w1 = w0 + chunk < nw ? w0 + chunk : nw;
+            const float *src = in + (size_t)(slab * nw + w0) * e + r;
+#pragma unroll 8
+            for (long long w = w0; w < w1; ++w, src += e) sum += (double)*src;
+        }
+        sh[ck][ox] = sum;
+        __syncthreads();
+        if (ck == 0 && live) {
+            double d = sh[0][ox];
+#pragma unroll
+            for (int c = 1; c < 8; ++c) d += sh[c][ox];
+            if (plain) plain[(size_t)k * NO + n] = d;              // (KI, NO) row-major fp64, for the pooled top layer's fix-up
+            else gw[k * sk + n * sn] = accumulate ? __fadd_rn(gw[k * sk + n * sn], (float)d) : (float)d;
+        }
+        __syncthreads();
+    }
+}
+
+// sums of `chunk` consecutive workgroups' partials (layout unchanged): in [slab][nw][E] -> out [slab][nchunks][E]
 __global__ __launch_bounds__(256) void tl_wgrad_reduce_a_kernel(const float4 *__restrict__ in, float4 *__restrict__ out,
                                                                 long long nw, int chunk, long long nchunks, long long e4)
 {
@@ -1480,72 +962,6 @@ __global__ __launch_bounds__(256) void tl_wgrad_reduce_a_kernel(const float4 *__
             sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
         }
         out[(slab * nchunks + ck) * e4 + i] = sum;
-    }
-}
-
-// stage B: fp64 sum over the remaining partials, written with the caller's weight strides
-__global__ __launch_bounds__(256) void tl_wgrad_reduce_b_kernel(const float *__restrict__ in, long long nw, int TU, int TT,
-                                                                int tslabs, int KI, int NO, float *__restrict__ gw,
-                                                                long long sk, long long sn, double *__restrict__ plain, int accumulate)
-{
-    // A thread owns one float of the slab layout ([slab][tile][v >> 2][lane][v & 3]: what the workgroups dumped), so a wave
-    // reads 256 contiguous bytes of every partial; the element (k, n) it stands for follows from its position. (One thread per
-    // OUTPUT element read 4 of every 16 bytes it touched: 10-13 us for the 16 MB of partials of a 512 x 256 layer, a third of
-    // what the weight-gradient kernel itself takes on a level of 4,096 rows.)
-    const int tu = (KI + 31) / 32, tt = (NO + 31) / 32, uslabs = (tu + TU - 1) / TU;
-    const long long e = (long long)TU * TT * 1024, total = (long long)uslabs * tslabs * e;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long slab = i / e;
-        const int r = (int)(i - slab * e), tile = r >> 10, q = r & 1023;
-        const int v = ((q >> 8) << 2) | (q & 3), lane = (q >> 2) & 63;
-        const int us = (int)(slab / tslabs), ts = (int)(slab - (long long)us * tslabs), ul = tile / TT, tl = tile - ul * TT;
-        const int k = (us * TU + ul) * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), n = (ts * TT + tl) * 32 + (lane & 31);
-        if (us * TU + ul >= tu || ts * TT + tl >= tt || k >= KI || n >= NO) continue;
-        const float *src = in + (size_t)slab * nw * e + r;
-        double sum = 0.0;
-#pragma unroll 8
-        for (long long w = 0; w < nw; ++w) sum += (double)src[(size_t)w * e];
-        if (plain) plain[(size_t)k * NO + n] = sum;                // (KI, NO) row-major fp64, for the pooled top layer's fix-up
-        else gw[k * sk + n * sn] = accumulate ? __fadd_rn(gw[k * sk + n * sn], (float)sum) : (float)sum;
-    }
-}
-
-// Both stages in ONE launch when there are at most 8 chunks (every level but the two-workgroups-per-CU passes): thread
-// (output, chunk) adds its chunk's partials in fp32 -- stage A's sum, same order --, the chunk sums meet in LDS and are added in
-// fp64 in chunk order -- stage B's. Bit-identical to the two launches; what it saves is a launch of ~10 us per weight
-// gradient on the levels whose whole backward is 250 us (a block owns 32 outputs, so 8 K outputs still fill the chip).
-__global__ __launch_bounds__(256) void tl_wgrad_reduce_ab_kernel(const float *__restrict__ in, long long nw, int nchunks, int TU, int TT,
-                                                                 int tslabs, int KI, int NO, float *__restrict__ gw, long long sk,
-                                                                 long long sn, double *__restrict__ plain, int accumulate)
-{
-    __shared__ float sh[8][32];
-    const int ox = threadIdx.x & 31, ck = threadIdx.x >> 5;
-    // 32 consecutive floats of the slab layout per block and trip (see tl_wgrad_reduce_b_kernel: contiguous reads)
-    const int tu = (KI + 31) / 32, tt = (NO + 31) / 32, uslabs = (tu + TU - 1) / TU;
-    const long long e = (long long)TU * TT * 1024, total = (long long)uslabs * tslabs * e;
-    for (long long base = (long long)blockIdx.x * 32; base < total; base += (long long)gridDim.x * 32) {      // uniform trip count
-        const long long i = base + ox, slab = i / e;
-        const int r = (int)(i - slab * e), tile = r >> 10, q = r & 1023;
-        const int v = ((q >> 8) << 2) | (q & 3), lane = (q >> 2) & 63;
-        const int us = (int)(slab / tslabs), ts = (int)(slab - (long long)us * tslabs), ul = tile / TT, tl = tile - ul * TT;
-        const int k = (us * TU + ul) * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), n = (ts * TT + tl) * 32 + (lane & 31);
-        const bool live = us * TU + ul < tu && ts * TT + tl < tt && k < KI && n < NO;
-        float sum = 0.0f;
-        if (live && ck < nchunks) {
-            const long long w0 = (long long)ck * 32, w1 = w0 + 32 < nw ? w0 + 32 : nw;
-            const float *src = in + (size_t)(slab * nw + w0) * e + r;
-#pragma unroll 8
-            for (long long w = w0; w < w1; ++w, src += e) sum += *src;
-        }
-        sh[ck][ox] = sum;
-        __syncthreads();
-        if (ck == 0 && live) {
-            double d = 0.0;
-            for (int c = 0; c < nchunks; ++c) d += (double)sh[c][ox];
-            if (plain) plain[(size_t)k * NO + n] = d;
-            else gw[k * sk + n * sn] = accumulate ? __fadd_rn(gw[k * sk + n * sn], (float)d) : (float)d;
-        }
-        __syncthreads();
     }
 }
 
@@ -2545,28 +1961,11 @@ static int launch_wgrad(TlWgrad &p, const WgradShape &w, float *partial2, const 
 // the sum of the workgroups' slabs -> the caller's weight gradient (or `plain`, fp64, for the pooled top layer's fix-up)
 static int launch_wgrad_reduce(const TlWgrad &p, const WgradShape &w, float *partial2, const pn2_bn_layer &L, hipStream_t st, double *plain)
 {
-    int rc = PN2_OK;
-    const float *src = p.partial;
-    long long nw = w.nw;
-    if (w.nchunks && w.nchunks <= 8) {                             // both reduction stages in one launch
-        const long long total = (long long)w.uslabs * w.tslabs * (long long)w.e;
-        long long blocks = (total + 31) / 32;
-        if (blocks > 2048) blocks = 2048;
-        return launch(tl_wgrad_reduce_ab_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, nw, (int)w.nchunks, w.tus, w.tts,
-                      w.tslabs, p.KI, p.NO, L.grad_weight, L.w_stride_k, L.w_stride_n, plain, L.grad_accumulate);
-    }
-    if (w.nchunks) {
-        const long long e4 = (long long)w.e / 4;
-        long long bx = (e4 + 255) / 256;
-        if (bx > 64) bx = 64;
-        rc = launch(tl_wgrad_reduce_a_kernel, dim3((unsigned)bx, (unsigned)w.nchunks, (unsigned)(w.uslabs * w.tslabs)), dim3(256), 0,
-                    st, reinterpret_cast<const float4 *>(p.partial), reinterpret_cast<float4 *>(partial2), w.nw, 32, w.nchunks, e4);
-        if (rc) return rc;
-        src = partial2;
-        nw = w.nchunks;
-    }
-    const long long total = (long long)w.uslabs * w.tslabs * (long long)w.e;     // one thread per float of the slab layout
-    return launch(tl_wgrad_reduce_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, nw, w.tus, w.tts, w.tslabs,
+    (void)partial2;                                                // (the second stage's buffer of the two-launch reduction)
+    const long long total = (long long)w.uslabs * w.tslabs * (long long)w.e;     // floats of the slab layout
+    long long blocks = (total + 31) / 32;
+    if (blocks > 4096) blocks = 4096;
+    return launch(tl_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)p.partial, w.nw, w.tus, w.tts, w.tslabs,
                   p.KI, p.NO, L.grad_weight, L.w_stride_k, L.w_stride_n, plain, L.grad_accumulate);
 }
 
