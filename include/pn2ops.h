@@ -372,6 +372,12 @@ typedef struct pn2_train_opts {
     int pair_launch;               /* backward: a layer's data-gradient GEMM and its weight-gradient pass as two ranges of workgroups
                                       of ONE launch (independent passes over the same tensors; AUTO: below 0.5 M rows, where each is a
                                       latency-bound launch over part of the chip; ON: wherever the shape pair has a kernel), OFF: never */
+    int fold_finalize;             /* the per-channel finalisation of a pass's sums (batch moments -> coefficients, running statistics;
+                                      backward: grad_gamma, grad_beta, dz coefficients) by the LAST workgroup of the pass that produced
+                                      them (ticket; write-through partial rows) instead of a launch of its own: ON only -- measured
+                                      1-8 us SLOWER per pass than the 5 us launch it saves (the XCDs' L2s are not coherent: the hand-off
+                                      is four trips to memory), so AUTO = OFF. The sums are added in a fixed order either way; the two
+                                      orders differ, so results agree to the fp64 rounding of the sums, not bit for bit */
 } pn2_train_opts;
 long long pn2_mlp_train_ws_bytes(long long rows, int nlayers, const int *widths /* cin_1, cout_1 .. cout_L */,
                                  int pool_rows, int backward,

@@ -45,6 +45,148 @@ constexpr int kMaxParts = 256;           // rows of a per-channel partial-sum ar
 enum { A_PLAIN = 0, A_GATHER = 1, A_RELU = 2, A_DZ = 3, A_DZ_POOL = 4, A_FILL = 5 };
 enum { E_STORE = 0, E_POOL = 1, E_MASK = 2, E_PLAIN = 3 };
 
+// ---- per-channel finalisations, folded into the launch that produces their partial sums --------------------------------------
+// Between two passes of a level stands a reduction over ALL rows: the workgroups of a pass leave one partial row each, and a
+// 5 us launch (tl_bn_finalize_kernel / tl_bn_backward_finalize_kernel) turns the rows into the next pass's coefficients. A
+// level of a few thousand rows is ~25 launches of which a third are such 5 us finalisations (profiles/r04: sem_seg SA4 forward
+// 89 us in 9 launches, 24 of them in pack / finalise launches). TlFin folds the finalisation into the producer: every workgroup
+// publishes its partial row (device-scope release), takes a ticket, and the workgroup that draws the LAST ticket -- all rows
+// are then visible to it (device-scope acquire) -- does the finalisation before it exits. No workgroup ever waits for another:
+// nothing can hang. The sums are added in a fixed order (J contiguous chunks of the partial rows, each in ascending order, the
+// chunk sums in ascending order), so results do not depend on which workgroup comes last. Tickets live in the caller's workspace
+// and are zeroed by the direction's first launch (tl_pack_kernel).
+struct TlFin {
+    unsigned *ticket;           // nullptr: not folded (the caller launches the finalisation kernel)
+    unsigned total;             // workgroups that publish a partial row (all of them take a ticket)
+    int mode;                   // 1: batch moments -> (mean, invstd, a, c) + running statistics; 2: (sum dy, sum dy z) -> grad_gamma, grad_beta, dz coefficients
+    int nparts, N;
+    const double *stats;        // (nparts, 2, N) partial rows -- written by THIS launch, read after the ticket
+    double count;
+    const float *gamma, *beta, *bias;
+    float *running_mean, *running_var;
+    float momentum, eps;
+    int var_biased;
+    float *save;                // mode 1: written (4, N); mode 2: read
+    float *grad_gamma, *grad_beta, *coef;
+    int accumulate;
+};
+
+// batch moments of one channel -> (mean, invstd, a, c), running statistics (torch.nn.BatchNorm semantics: unbiased variance in
+// the average unless var_biased -- tf.contrib.layers.batch_norm, tf_util.py:512-531, averages the biased one)
+__device__ __forceinline__ void tl_bn_finalize_channel(int c, int N, double s1, double s2, double count, const float *gamma,
+                                                       const float *beta, float *running_mean, float *running_var, float momentum,
+                                                       float eps, float *save, const float *bias, int var_biased)
+{
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double a = (double)gamma[c] * invstd;
+    save[c] = (float)mean;
+    save[N + c] = (float)invstd;
+    save[2 * N + c] = (float)a;
+    save[3 * N + c] = (float)((double)beta[c] - a * mean);
+    // the stored pre-norm tensor is h W WITHOUT the conv bias (see pn2_mlp_train_forward): the layer's batch mean is mean + b
+    if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * (mean + (bias ? (double)bias[c] : 0.0)));
+    if (running_var) {
+        const double bv = (var_biased || count <= 1.0) ? var : var * count / (count - 1.0);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * bv);
+    }
+}
+
+// (sum dy, sum dy z) of one channel -> grad_gamma, grad_beta and the coefficients of dz = s dy - c0 - c1 z
+__device__ __forceinline__ void tl_bn_backward_finalize_channel(int c, int N, double s1, double s2, double count, const float *gamma,
+                                                                const float *save, float *grad_gamma, float *grad_beta, float *coef,
+                                                                int accumulate)
+{
+    const double mean = save[c], invstd = save[N + c];
+    const double dbeta = s1, dgamma = (s2 - mean * s1) * invstd;
+    const double s = (double)gamma[c] * invstd;
+    const double c1 = s * dgamma * invstd / count;
+    const double c0 = s * dbeta / count - c1 * mean;
+    if (grad_gamma) grad_gamma[c] = accumulate ? __fadd_rn(grad_gamma[c], (float)dgamma) : (float)dgamma;
+    if (grad_beta) grad_beta[c] = accumulate ? __fadd_rn(grad_beta[c], (float)dbeta) : (float)dbeta;
+    coef[c] = (float)s;
+    coef[N + c] = (float)c0;
+    coef[2 * N + c] = (float)c1;
+}
+
+constexpr size_t kFinLds = 16 * 512 + 64;          // LDS the tail needs at 512 threads: two doubles per thread + the flag
+constexpr int kFinTickets = 16;                    // one counter per layer of a direction
+
+// Device-scope traffic of the hand-off WITHOUT cache-wide fences. A release fence at agent scope is a write-back of the whole
+// L2 of the XCD (buffer_wbl2) and an acquire fence invalidates it: with one such pair per workgroup the folded form measured
+// 20-35 us SLOWER per pass than the separate launch (the passes' own outputs are tens of megabytes of dirty lines, and the
+// invalidate costs the workgroups still running their weights). Instead the partial rows are written with write-through
+// stores (agent-scope relaxed atomic stores: sc1), the storing threads wait for the write acknowledgements (s_waitcnt
+// vmcnt(0)) before the workgroup takes its ticket (agent-scope relaxed atomic add, performed at the memory side), and the last
+// workgroup reads the rows with agent-scope relaxed atomic loads, which bypass the non-coherent copies of its own L2 -- the
+// hand-off form of sa_fused.hip's sample granules, with the ticket in place of the tag.
+typedef unsigned long long __attribute__((address_space(1))) tl_gu64;
+typedef unsigned __attribute__((address_space(1))) tl_gu32;
+
+__device__ __forceinline__ void tl_fin_store(double *p, double v)     // a partial sum another workgroup of this launch will read
+{
+    __hip_atomic_store((tl_gu64 *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ double tl_fin_load(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load((const tl_gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// The tail of a producing workgroup of NT threads (every thread of every workgroup of the launch calls it, after its
+// tl_fin_store()s of the partial row). `lds`: >= 16 NT + 16 bytes of the workgroup's LDS that nobody uses any more.
+template <int NT>
+__device__ __forceinline__ void tl_fin_tail(const TlFin &f, char *lds)
+{
+    const int tid = threadIdx.x;
+    unsigned *flag = reinterpret_cast<unsigned *>(lds);
+    double *sh = reinterpret_cast<double *>(lds + 16);              // [2][NT]
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this thread's write-through stores are acknowledged ...
+    __syncthreads();                                                // ... and so are every other thread's of this workgroup
+    if (tid == 0)
+        *flag = (__hip_atomic_fetch_add((tl_gu32 *)f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f.total - 1u) ? 1u : 0u;
+    __syncthreads();
+    if (*flag == 0u) return;                                        // workgroup-uniform
+    int cb = 32;                                                    // channels per sweep (a power of two), J = NT / cb threads each
+    while (cb < f.N && cb < NT) cb <<= 1;
+    const int J = NT / cb, c = tid & (cb - 1), j = tid / cb;
+    const int chunk = (f.nparts + J - 1) / J;
+    const int N = f.N;
+    const double *st = f.stats;
+    for (int c0 = 0; c0 < N; c0 += cb) {
+        const int ch = c0 + c;
+        double s1 = 0.0, s2 = 0.0;
+        if (ch < N) {
+            int q = j * chunk;
+            const int q1 = min(f.nparts, q + chunk);
+            const double *src = st + (size_t)q * 2 * N + ch;
+            for (; q + 8 <= q1; q += 8, src += (size_t)16 * N) {    // sixteen independent loads in flight, the sums in order
+                double a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { a[u] = tl_fin_load(src + (size_t)(2 * u) * N); b[u] = tl_fin_load(src + (size_t)(2 * u + 1) * N); }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { s1 += a[u]; s2 += b[u]; }
+            }
+            for (; q < q1; ++q, src += (size_t)2 * N) { s1 += tl_fin_load(src); s2 += tl_fin_load(src + N); }
+        }
+        sh[tid] = s1;
+        sh[NT + tid] = s2;
+        __syncthreads();
+        if (j == 0 && ch < N) {
+            double t1 = sh[c], t2 = sh[NT + c];
+            for (int jj = 1; jj < J; ++jj) { t1 += sh[jj * cb + c]; t2 += sh[NT + jj * cb + c]; }
+            if (f.mode == 1)
+                tl_bn_finalize_channel(ch, N, t1, t2, f.count, f.gamma, f.beta, f.running_mean, f.running_var, f.momentum, f.eps, f.save,
+                                       f.bias, f.var_biased);
+            else
+                tl_bn_backward_finalize_channel(ch, N, t1, t2, f.count, f.gamma, f.save, f.grad_gamma, f.grad_beta, f.coef, f.accumulate);
+        }
+        __syncthreads();
+    }
+}
+
 struct TlGather {
     int n, m, nsample, cfeat, xyz_off, feat_off;
     const float *xyz, *new_xyz, *points;
@@ -82,6 +224,7 @@ struct TlGemm {
     int prow;                   // 32 or 16
     int nt;                     // streaming (non-temporal) stores: outputs that do not fit the 256 MB Infinity Cache anyway
     int lab;                    // lab builds of the timing study only (PN2_TL_LAB): 1 = no stores, 2 = no statistics; 0 in production
+    TlFin fin;                  // the per-channel finalisation of `stats`, by the workgroup that finishes last (fin.ticket != nullptr)
 };
 
 // ---- A operand: load + prologue. Register v = 8e + j of lane (row s, half hl) <-> channel 32u + 16e + 8hl + j ------------
@@ -326,12 +469,14 @@ struct TlPackJob { const float *w; long long sk, sn; int K, N, tk, ns, slabs; u3
 struct TlPackJobs {                                               // one launch packs every layer of a level (blockIdx.y = layer)
     TlPackJob j[8];
     float *ident; int ident_c;                                    // ... and writes the identity coefficients (1, 0, 0) x ident_c, if wanted
+    unsigned *tickets;                                            // ... and zeroes the tickets of the direction's folded finalisations (TlFin)
 };
 
 __global__ __launch_bounds__(256) void tl_pack_kernel(const TlPackJobs jobs)
 {
     if (jobs.ident && blockIdx.x == 0 && blockIdx.y == 0)         // dz = 1 * g - 0 - 0 * z (layer 1 per point: S enters as it is)
         for (int i = threadIdx.x; i < 3 * jobs.ident_c; i += 256) jobs.ident[i] = i < jobs.ident_c ? 1.0f : 0.0f;
+    if (jobs.tickets && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kFinTickets) jobs.tickets[threadIdx.x] = 0u;
     const TlPackJob &q = jobs.j[blockIdx.y];
     const long long total = (long long)q.slabs * q.tk * q.ns * 128;     // one thread per (pair, e, lane)
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -384,22 +529,7 @@ __global__ __launch_bounds__(256) void tl_bn_finalize_kernel(const double *__res
     tl_sum_parts(stats, nparts, N, s1, s2);
     const int c = blockIdx.x * 8 + (threadIdx.x & 7);
     if (threadIdx.x >= 8 || c >= N) return;
-    const double mean = s1 / count;
-    double var = s2 / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const double invstd = 1.0 / sqrt(var + (double)eps);
-    const double a = (double)gamma[c] * invstd;
-    save[c] = (float)mean;
-    save[N + c] = (float)invstd;
-    save[2 * N + c] = (float)a;
-    save[3 * N + c] = (float)((double)beta[c] - a * mean);
-    // the stored pre-norm tensor is h W WITHOUT the conv bias (see pn2_mlp_train_forward): the layer's batch mean is mean + b
-    if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * (mean + (bias ? (double)bias[c] : 0.0)));
-    if (running_var) {
-        // torch.nn.BatchNorm averages the UNBIASED batch variance, tf.contrib.layers.batch_norm (tf_util.py:512-531) the biased one
-        const double bv = (var_biased || count <= 1.0) ? var : var * count / (count - 1.0);
-        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * bv);
-    }
+    tl_bn_finalize_channel(c, N, s1, s2, count, gamma, beta, running_mean, running_var, momentum, eps, save, bias, var_biased);
 }
 
 // (sum dy, sum dy z) -> grad_gamma, grad_beta and the coefficients of dz = s dy - c0 - c1 z
@@ -412,16 +542,7 @@ __global__ __launch_bounds__(256) void tl_bn_backward_finalize_kernel(const doub
     tl_sum_parts(stats, nparts, N, s1, s2);
     const int c = blockIdx.x * 8 + (threadIdx.x & 7);
     if (threadIdx.x >= 8 || c >= N) return;
-    const double mean = save[c], invstd = save[N + c];
-    const double dbeta = s1, dgamma = (s2 - mean * s1) * invstd;
-    const double s = (double)gamma[c] * invstd;
-    const double c1 = s * dgamma * invstd / count;
-    const double c0 = s * dbeta / count - c1 * mean;
-    if (grad_gamma) grad_gamma[c] = accumulate ? __fadd_rn(grad_gamma[c], (float)dgamma) : (float)dgamma;
-    if (grad_beta) grad_beta[c] = accumulate ? __fadd_rn(grad_beta[c], (float)dbeta) : (float)dbeta;
-    coef[c] = (float)s;
-    coef[N + c] = (float)c0;
-    coef[2 * N + c] = (float)c1;
+    tl_bn_backward_finalize_channel(c, N, s1, s2, count, gamma, save, grad_gamma, grad_beta, coef, accumulate);
 }
 
 // pool: partial extrema of z (the max where gamma >= 0, else the min) -> out = relu(a zsel + c), the sample the gradient flows to, zsel
@@ -1627,6 +1748,7 @@ struct TlPlan {
     size_t l1p;                 // layer 1 per point: forward P (b n, cout_1); backward S (b n, cout_1)
     size_t l1seg, l1part, l1coef;   // backward: scratch of the segmented reduction, dW1x partials (256, 3, cout_1), identity coefficients
     size_t l1xg, l1mom, l1a;        // backward, level without features: centred coordinates of every row, their moments, x^T dy_1 partials
+    size_t tickets;             // kFinTickets counters of the folded finalisations (TlFin), zeroed by the direction's pack launch
     size_t total;
 };
 
@@ -1790,6 +1912,7 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
         pl.l1mom = off; off = align_up(off + (size_t)kMaxParts * 9 * sizeof(double));
         pl.l1a = off; off = align_up(off + (size_t)kMaxParts * 3 * widths[1] * sizeof(double));
     }
+    pl.tickets = off; off = align_up(off + sizeof(unsigned) * kFinTickets);
     pl.total = off;
     return true;
 }
@@ -1849,9 +1972,10 @@ static int launch_gemm_ns(int amode, const TlGemm &p, const GemmShape &g, dim3 g
 #define PN2_TL_CASE(M)                                                                   \
     case M: {                                                                            \
         auto kern = tl_gemm_kernel<NS, M>;                                               \
-        if (int rc = allow_dynamic_lds(kern, g.lds)) return rc;                          \
-        return launch(kern, grid, dim3(kTlThreads), g.lds, st, p);                       \
+        if (int rc = allow_dynamic_lds(kern, lds)) return rc;                            \
+        return launch(kern, grid, dim3(kTlThreads), lds, st, p);                         \
     }
+    const size_t lds = (p.fin.ticket && g.lds < kFinLds) ? kFinLds : g.lds;             // the folded finalisation's scratch (tl_fin_tail)
     switch (amode) {
         PN2_TL_CASE(A_PLAIN)
         PN2_TL_CASE(A_GATHER)
@@ -1887,6 +2011,7 @@ static int launch_gemm(int amode, TlGemm &p, const GemmShape &g, hipStream_t st,
 {
     const dim3 grid = prep_gemm(p, g, o);
     if (nparts) *nparts = (int)grid.x;
+    if (p.fin.ticket) { p.fin.total = grid.x * grid.y; p.fin.nparts = (int)grid.x; }
     if (g.ns == 4) return launch_gemm_ns<4>(amode, p, g, grid, st);
     if (g.ns == 2) return launch_gemm_ns<2>(amode, p, g, grid, st);
     return launch_gemm_ns<1>(amode, p, g, grid, st);
@@ -1980,12 +2105,14 @@ static int launch_pair(int amode, TlGemm &pg, const GemmShape &g, TlWgrad &pw, c
     if (pw.dy_w) return kNoPair;
     const bool gather = pw.amode == A_GATHER;
     const int dcls = pw.dmode == A_FILL ? D_TOP : pw.dmode == A_DZ_POOL ? D_DZPOOL : D_DZ;
-    const size_t lds = g.lds > w.lds ? g.lds : w.lds;
+    size_t lds = g.lds > w.lds ? g.lds : w.lds;
+    if (pg.fin.ticket && lds < kFinLds) lds = kFinLds;
 #define PN2_PAIR(AM, NS_, DC, TP, UP) PN2_PAIR_G(AM, NS_, DC, TP, UP, false)
 #define PN2_PAIR_G(AM, NS_, DC, TP, UP, GA)                                                                              \
     if (amode == AM && g.ns == NS_ && dcls == DC && w.tpw == TP && w.upw == UP && gather == GA) {                        \
         auto kern = tl_pair_kernel<NS_, AM, TP, UP, DC, GA>;                                                             \
         const dim3 ga = prep_gemm(pg, g, o);                                                                             \
+        if (pg.fin.ticket) { pg.fin.total = ga.x * ga.y; pg.fin.nparts = (int)ga.x; }                                    \
         pw.tus = w.tus; pw.tts = w.tts; pw.tslabs = w.tslabs;                                                            \
         if (int rc = allow_dynamic_lds(kern, lds)) return rc;                                                            \
         const unsigned total = ga.x * ga.y + (unsigned)w.gridx * (unsigned)(w.uslabs * w.tslabs);                        \
@@ -2253,6 +2380,36 @@ static int launch_l1_dz(long long rows, const GroupDims &gd, const pn2_group_src
 }
 }  // namespace pn2
 
+namespace pn2 {
+// Per-channel finalisations inside the launches that produce their sums (TlFin): OPT-IN. Measured (rocprofv3 per-dispatch
+// traces, profiles/r04/fold_finalize_experiment.txt): the folded pass is 5-7 us longer on a level of 4,096 rows (sem_seg SA4:
+// 17.1 / 25.8 / 31.6 against 15.2 / 18.6 / 26.2 us) and 13 us longer with 256 partial rows of 128 channels (sem_seg FP4), for a
+// finalisation launch of 4.5-6 us saved -- the write-through stores, the ticket and the last workgroup's reads are four or
+// more dependent trips to memory, because the L2s of the eight XCDs are not coherent with each other. With release / acquire
+// fences instead (a write-back and an invalidate of the whole L2 per workgroup) it was 20-35 us longer.
+static inline bool fold_wanted(const Opts &o) { return o.fold_finalize == PN2_OPT_ON; }
+
+static TlFin fin_forward(const pn2_bn_layer &L, long long rows, double *stats, unsigned *ticket)
+{
+    TlFin f;
+    memset(&f, 0, sizeof(f));
+    f.ticket = ticket; f.mode = 1; f.N = L.cout; f.stats = stats; f.count = (double)rows;
+    f.gamma = L.gamma; f.beta = L.beta; f.bias = L.bias; f.running_mean = L.running_mean; f.running_var = L.running_var;
+    f.momentum = L.momentum; f.eps = L.eps; f.var_biased = L.running_var_biased; f.save = L.save;
+    return f;
+}
+
+static TlFin fin_backward(const pn2_bn_layer &L, long long rows, double *stats, float *coef, unsigned *ticket)
+{
+    TlFin f;
+    memset(&f, 0, sizeof(f));
+    f.ticket = ticket; f.mode = 2; f.N = L.cout; f.stats = stats; f.count = (double)rows;
+    f.gamma = L.gamma; f.save = L.save; f.grad_gamma = L.grad_gamma; f.grad_beta = L.grad_beta; f.coef = coef;
+    f.accumulate = L.grad_accumulate;
+    return f;
+}
+}  // namespace pn2
+
 extern "C" int pn2_mlp_train_forward(long long rows, int nlayers, const pn2_bn_layer *layers, const pn2_group_src *group,
                                      const float *x, int pool_rows, float *out, int *argsel, float *zsel, void *ws, void *stream)
 {
@@ -2282,6 +2439,8 @@ extern "C" int pn2_mlp_train_forward_ex(long long rows, int nlayers, const pn2_b
         if (!layers[l].z && (keep_top || l < nlayers - 1)) return PN2_E_NULL;
     hipStream_t st = as_stream(stream);
     char *base = static_cast<char *>(ws);
+    unsigned *tickets = reinterpret_cast<unsigned *>(base + pl.tickets);
+    bool fold = false;                                            // the finalisation of a layer's batch moments inside the pass that sums them
     {
         TlPackJobs jobs;                                          // every layer's weights -> operand tiles, one launch
         memset(&jobs, 0, sizeof(jobs));
@@ -2297,6 +2456,8 @@ extern "C" int pn2_mlp_train_forward_ex(long long rows, int nlayers, const pn2_b
                 add_pack_job(jobs, nj, L.weight, L.w_stride_k, L.w_stride_n, gemm_shape(rows, L.cin, L.cout, o), base + pl.pack[l]);
             }
         }
+        fold = fold_wanted(o) && nj > 0;                          // (the pack launch zeroes the tickets)
+        if (fold) jobs.tickets = tickets;
         if (int rc = launch_pack_jobs(jobs, nj, st)) return rc;
     }
     // The conv bias is NOT added to the pre-norm tensors: batch normalisation removes any per-channel constant, so
@@ -2360,10 +2521,12 @@ extern "C" int pn2_mlp_train_forward_ex(long long rows, int nlayers, const pn2_b
             p.prow = pool_rows == 16 ? 16 : 32;
         }
         int nparts = 0;
+        if (fold) p.fin = fin_forward(L, rows, p.stats, tickets + l);
         if (int rc = launch_gemm(amode, p, g, st, o, &nparts)) return rc;
-        if (int rc = launch(tl_bn_finalize_kernel, dim3((unsigned)((L.cout + 7) / 8)), dim3(256), 0, st,
-                            reinterpret_cast<const double *>(base + pl.stats[l]), nparts, L.cout, (double)rows, L.gamma, L.beta,
-                            L.running_mean, L.running_var, L.momentum, L.eps, L.save, L.bias, L.running_var_biased)) return rc;
+        if (!fold)
+            if (int rc = launch(tl_bn_finalize_kernel, dim3((unsigned)((L.cout + 7) / 8)), dim3(256), 0, st,
+                                reinterpret_cast<const double *>(base + pl.stats[l]), nparts, L.cout, (double)rows, L.gamma, L.beta,
+                                L.running_mean, L.running_var, L.momentum, L.eps, L.save, L.bias, L.running_var_biased)) return rc;
         if (last && pool_rows) {
             const long long groups = rows / pool_rows;
             const int prow = pool_rows == 16 ? 16 : 32;
@@ -2437,6 +2600,8 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
         if (fz[l].ok) { wz[l].lds_dy = fz[l].lds; wz[l].upw = fz[l].upw; }
     }
     bool ident_written = false;
+    unsigned *tickets = reinterpret_cast<unsigned *>(base + pl.tickets);
+    bool fold = false;
     {
         TlPackJobs jobs;                                          // W_l^T of every data-gradient GEMM, one launch
         memset(&jobs, 0, sizeof(jobs));
@@ -2465,8 +2630,17 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
             jobs.ident_c = layers[0].cout;
         }
         ident_written = jobs.ident != nullptr;
+        fold = fold_wanted(o) && nj > 0;                          // (the pack launch zeroes the tickets)
+        if (fold) jobs.tickets = tickets;
         if (int rc = launch_pack_jobs(jobs, nj, st)) return rc;
     }
+    bool folded[8] = {false, false, false, false, false, false, false, false};     // layers whose backward finalisation ran inside the pass above
+    // the data-gradient GEMM that sums (dy, dy z) of layer l - 1 also turns the sums into that layer's gradients and coefficients
+    auto fold_below = [&](TlGemm &q, int l) {
+        if (!fold || l < 1) return;
+        q.fin = fin_backward(layers[l - 1], rows, q.stats, reinterpret_cast<float *>(base + pl.coef[l - 1]), tickets + (l - 1));
+        folded[l - 1] = true;
+    };
     float *ga = reinterpret_cast<float *>(base + pl.ga), *gb = reinterpret_cast<float *>(base + pl.gb);
     float *gq = reinterpret_cast<float *>(base + pl.gq);
     const pn2_bn_layer &T = layers[nlayers - 1];
@@ -2498,9 +2672,10 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
     for (int l = nlayers - 1; l >= 0; --l) {
         const pn2_bn_layer &L = layers[l];
         float *coef = reinterpret_cast<float *>(base + pl.coef[l]);
-        if (int rc = launch(tl_bn_backward_finalize_kernel, dim3((unsigned)((L.cout + 7) / 8)), dim3(256), 0, st,
-                            reinterpret_cast<const double *>(base + pl.stats[l]), nparts[l], L.cout, (double)rows, L.gamma,
-                            (const float *)L.save, L.grad_gamma, L.grad_beta, coef, L.grad_accumulate)) return rc;
+        if (!folded[l])
+            if (int rc = launch(tl_bn_backward_finalize_kernel, dim3((unsigned)((L.cout + 7) / 8)), dim3(256), 0, st,
+                                reinterpret_cast<const double *>(base + pl.stats[l]), nparts[l], L.cout, (double)rows, L.gamma,
+                                (const float *)L.save, L.grad_gamma, L.grad_beta, coef, L.grad_accumulate)) return rc;
         if (int rc = sd.join()) return rc;                          // the helper's reads of the dy buffer this layer's data gradient overwrites
         const bool pooled_top = pool_rows && l == nlayers - 1;
         if (pooled_top && ztop) {
@@ -2596,6 +2771,7 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 p.out = gnext;
                 p.zprev = D.z; p.ea = D.save + 2 * D.cout; p.ec = D.save + 3 * D.cout;
                 p.stats = reinterpret_cast<double *>(base + pl.stats[l - 1]);
+                fold_below(p, l);
                 int np = 0, rc = kNoPair;
                 if (pair_wanted(rows, o)) rc = launch_pair(A_FILL, p, g, w, ws_, reinterpret_cast<float *>(base + pl.partial2), L, st, o, &np, sf);
                 if (rc == kNoPair) {
@@ -2751,6 +2927,7 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                     p.ea = D.save + 2 * D.cout;
                     p.ec = D.save + 3 * D.cout;
                     p.stats = reinterpret_cast<double *>(base + pl.stats[l - 1]);
+                    fold_below(p, l);
                 } else {
                     p.emode = E_PLAIN;
                     if (group) {

@@ -37,7 +37,7 @@ class BnLayer(ctypes.Structure):           # pn2_bn_layer
 class TrainOpts(ctypes.Structure):         # pn2_train_opts: 0 = automatic, 1 = off, 2 = on
     _fields_ = [("top_stored", _i), ("top_sparse", _i), ("l1_per_point", _i), ("l1_coords", _i), ("force_stream", _i),
                 ("max_ns", _i), ("nt", _i), ("fuse_wgrad", _i), ("wgrad_two_per_cu", _i), ("side_stream", _i),
-                ("pair_launch", _i)]
+                ("pair_launch", _i), ("fold_finalize", _i)]
 
 
 _OPT_NAMES = tuple(name for name, _ in TrainOpts._fields_)
@@ -76,7 +76,7 @@ def parse_options(text):
 @contextlib.contextmanager
 def options(**kw):
     """Force the organisation of the training passes inside the block (tests that cover every variant, A/B timing):
-    top_stored / top_sparse / l1_per_point / l1_coords / force_stream / nt / fuse_wgrad / wgrad_two_per_cu / side_stream / pair_launch = True | False | None (automatic),
+    top_stored / top_sparse / l1_per_point / l1_coords / force_stream / nt / fuse_wgrad / wgrad_two_per_cu / side_stream / pair_launch / fold_finalize = True | False | None (automatic),
     max_ns = 1 | 2 | 4. Results never depend on them. They travel to the library as a per-call argument
     (pn2_mlp_train_*_ex); the library itself reads no environment variable. A node's backward runs under the options its
     forward ran under."""

@@ -55,6 +55,7 @@ for l in open(sys.argv[1]):
 PY
     ;;
     fuzzsurvey) timeout ${FUZZ_TIMEOUT:-900} python scripts/train_fuzz_survey.py ${FUZZ_CASES:-600} > "$OUT/train_fuzz_survey.txt" 2> "$OUT/train_fuzz_survey.err"; tail -5 "$OUT/train_fuzz_survey.txt" ;;
+    timeline)  for lv in ${TL_LEVELS:-sem_seg:SA4 FP:sem_seg}; do name=$(echo $lv | tr ':' ' '); (cd /tmp && export TMPDIR=/tmp && PN2_TRAIN_OPTS="${PN2_TRAIN_OPTS:-}" PN2_TRAIN_BENCH_KERNEL_ONLY=1 timeout 200 rocprofv3 --kernel-trace --output-format csv -d "$OUT/tl_$lv" -- python $ROOT/scripts/train_mlp_bench.py "$name" > "$OUT/tl_$lv.log" 2>&1); f=$(find "$OUT/tl_$lv" -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python scripts/level_timeline.py "$f" "$OUT/timeline_$lv.txt"; rm -rf "$OUT/tl_$lv"; cat "$OUT/timeline_$lv.txt"; done ;;
     profile)   timeout 1200 bash scripts/profile_round.sh > "$OUT/profile.log" 2>&1; tail -5 "$OUT/profile.log" ;;
     *)         echo "unknown step $step" ;;
     esac

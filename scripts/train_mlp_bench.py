@@ -47,10 +47,10 @@ def timeit(fn, iters=10, warm=3):
 
 
 def main():
-    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    only = (sys.argv[1] if len(sys.argv) > 1 else "").split("|")          # "sem_seg SA4|group_all": any of the substrings
     g = torch.Generator(device="cpu").manual_seed(0)
     for name, b, n, m, ns, cfeat, widths, xyz_first in LEVELS:
-        if only not in name:
+        if not any(o in name for o in only):
             continue
         plain = m == -1
         group_all = m == 0

@@ -56,6 +56,8 @@ def _case(seed):
         kw["feat_grad"] = False                             # the features are data: layer 1's backward on the vector units when they are few
     if rng.random() < 0.4:
         env["pair_launch"] = rng.random() < 0.6             # a layer's two backward passes in one launch wherever the pair has a kernel / never
+    if rng.random() < 0.3:
+        env["fold_finalize"] = True                         # the per-channel finalisations inside their producing passes (opt-in: measured slower)
     return kw, env
 
 

@@ -146,6 +146,62 @@ def test_pair_launch_is_bit_identical_to_two_launches(cuda, name, kw):
         assert torch.equal(a, c), name
 
 
+# The per-channel finalisations (batch moments -> coefficients and running statistics; backward: grad_gamma, grad_beta and the
+# dz coefficients) run as launches of their own or -- fold_finalize = True, opt-in (measured slower, profiles/r04/
+# fold_finalize_experiment.txt) -- inside the pass that produces their sums, by its last workgroup (TlFin, csrc/train_mlp.hip). Both add the workgroups' partial rows in a fixed order, but not the same one:
+# the outputs agree to the fp64 rounding of those sums (far below fp32 resolution), the running statistics likewise.
+FOLD_CASES = [c for c in CONFIG_CASES if c[0] in ("cfg2 cls_ssg L1", "cfg5 sem_seg SA2", "cfg5 sem_seg SA4", "cfg5 sem_seg FP2", "cfg5 sem_seg FP4",
+                                                    "cfg4 part_seg FP1", "cfg2 cls_ssg L3 group_all")]
+
+
+@pytest.mark.parametrize("name,kw", FOLD_CASES, ids=[c[0] for c in FOLD_CASES])
+def test_folded_finalisation_matches_separate_launches(cuda, name, kw):
+    import pointnet2_amd.pointnet_util as U
+    from pointnet2_amd import train_mlp
+    g = torch.Generator(device="cpu").manual_seed(11)
+    plain = bool(kw.get("plain_cin"))
+    group_all = bool(kw.get("group_all"))
+    cin = kw["plain_cin"] if plain else 3 + kw["cfeat"]
+    b, n = kw["b"], kw["n"]
+    if plain:
+        x = torch.randn((b, n, cin), generator=g).to(cuda).requires_grad_(True)
+        leaves = [x]
+    else:
+        xyz = torch.rand((b, n, 3), generator=g).to(cuda)
+        pts = torch.randn((b, n, kw["cfeat"]), generator=g).to(cuda).requires_grad_(True) if kw["cfeat"] else None
+        leaves = [pts] if pts is not None else []
+        if not group_all:
+            new_xyz = xyz[:, :kw["m"]].contiguous()
+            idx = torch.randint(0, n, (b, kw["m"], kw["ns"]), generator=g, dtype=torch.int32).to(cuda)
+    results = []
+    from pointnet2_amd._tensors import set_deterministic
+    set_deterministic(True)
+    try:
+        for fold in (True, False):
+            torch.manual_seed(11)
+            net = U._SharedMLP(cin, kw["widths"], bn=True).to(cuda).train()
+            with train_mlp.options(fold_finalize=fold):
+                if plain:
+                    out = train_mlp.fp_mlp_train(net.net, x)
+                elif group_all:
+                    out = train_mlp.sa_mlp_train(net.net, xyz, None, pts, None, True)[0]
+                else:
+                    out = train_mlp.sa_mlp_train(net.net, xyz, new_xyz, pts, idx, kw.get("xyz_first", True))[0]
+                if not results:
+                    gw = torch.randn(out.shape, generator=g).to(cuda)
+                params = [q for q in net.parameters()] + leaves
+                grads = torch.autograd.grad(out, params, gw, allow_unused=True)
+            stats = [t.detach().clone() for mod in net.modules() if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm)
+                     for t in (mod.running_mean, mod.running_var)]
+            results.append([out.detach().clone()] + [t.clone() for t in grads if t is not None] + stats)
+    finally:
+        set_deterministic(False)
+    assert len(results[0]) == len(results[1])
+    for a, c in zip(*results):
+        scale = max(1e-30, float(c.abs().max()))
+        assert float((a - c).abs().max()) <= 2e-6 * scale, name
+
+
 # Levels whose few feature channels are DATA (the input normals of cls_msg / part_seg level 1: no gradient is asked for them):
 # layer 1 runs on the vector units in both directions (tl_l1_forward_kernel / tl_l1_dz_kernel<false, true>: the features
 # gathered per row like three more coordinates). With a feature gradient wanted the backward takes the generic passes; both
