@@ -171,6 +171,13 @@ long long pn2_sa_mlp3_ws_bytes(int b, int n, int m, int cin, int c1, int c2, int
 int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, const float *xyz, const float *new_xyz,
                         const float *points, const int *idx, int c1, int c2, int c3, const float *wpacked,
                         const float *bpacked, float *out, void *ws, void *stream);
+/* The same with the organisation of the resident kernel chosen by the caller: variant 0 = by the size rule, 1 = one 32-sample
+ * item per wave (two waves per SIMD), 2 / 3 = two items per wave, half a layer apart (csrc/sa_mlp.hip: sa_mlp3_pair_kernel), one /
+ * two waves per SIMD; nsample 32 or 16, at most 16 input channels and widths up to (64, 64, 128), else ignored. Results are
+ * bit-identical. */
+int pn2_sa_mlp3_maxpool_ex(int b, int n, int m, int nsample, int cfeat, const float *xyz, const float *new_xyz,
+                           const float *points, const int *idx, int c1, int c2, int c3, const float *wpacked,
+                           const float *bpacked, float *out, void *ws, int variant, void *stream);
 
 /* ---- a feature-propagation layer behind three_nn, fused, on the matrix cores --------------------------
  * (no reference kernel; replaces for INFERENCE the TF graph of utils/pointnet_util.py:212-226: the

@@ -248,6 +248,251 @@ __global__ __launch_bounds__(NT) void sa_mlp3_kernel(int n, int m, int nsample, 
     }
 }
 
+// ---- two items per wave -------------------------------------------------------------------------------------------
+// What the kernel above leaves on the table (profiles/r04/ubench_mfma_valu.txt): on gfx950 a wave's vector instructions
+// hide completely under its OWN queued MFMAs (four per v_mfma_f32_32x32x16_bf16 cost nothing) as long as they do not
+// depend on them, while the vector work of the OTHER wave of the SIMD hides only by half. Within one 32-sample item the
+// level split of a layer's output depends on the layer's last MFMAs and feeds the next layer's first ones, so with one
+// item per wave the kernel runs at MFMA time + vector time (81 + 54 us at the metric shape). Here a wave carries TWO
+// items, A and B, half a phase apart: every layer of one item ("host": its weight reads and MFMAs, step by step) is
+// followed, step by step, by pieces of the other item's vector work ("guest": ReLU + level split of the previous layer's
+// accumulators, the input subtraction, the pooling tail),
+//     L1(A) | input split B      L1(B) | split h1 A      L2(A) | split h1 B
+//     L2(B) | split h2 A         L3(A) | split h2 B      L3(B) | pool A, input split of A's next item
+// so the guest's instructions are independent of the MFMAs in flight. One wave per SIMD (256 threads, up to 512 registers
+// with the accumulation registers as overflow) carries the state of both items. A sched_barrier after every step keeps
+// hipcc from regrouping the two streams. Arithmetic and results are bit-identical to the kernel above. Levels of one
+// 32-sample group per centroid (nsample 32 or 16) and at most 16 input channels; the rest keeps one item per wave.
+template <bool RELU>
+__device__ __forceinline__ void split_piece(const f32x16 &x, int e, int d, ActSplit &s)
+{
+    float a = x[8 * e + 2 * d], b = x[8 * e + 2 * d + 1];
+    // a piece belongs to the step of the host layer it is written in: the empty volatile statement is ordered with the steps'
+    // sched_barriers, and the piece's arithmetic depends on it (left alone, instruction selection emits a guest's whole split
+    // in front of the host layer, and the barriers then keep it there)
+    asm volatile("" : "+v"(a), "+v"(b));
+    if (RELU) { a = vmax(a, 0.0f); b = vmax(b, 0.0f); }
+    const unsigned int p1 = pack_bf16(a, b);
+    const float ra = __fsub_rn(a, __uint_as_float(p1 << 16)), rb = __fsub_rn(b, __uint_as_float(p1 & 0xffff0000u));
+    const unsigned int p2 = pack_bf16(ra, rb);
+    const float sa = __fsub_rn(ra, __uint_as_float(p2 << 16)), sb = __fsub_rn(rb, __uint_as_float(p2 & 0xffff0000u));
+    unsigned int q1 = p1, q2 = p2, q3 = pack_bf16(sa, sb);
+    asm volatile("" : "+v"(q1), "+v"(q2), "+v"(q3));      // ... and its results exist when the step ends (nothing sinks to the consumer)
+    s.p[e][0][d] = q1;
+    s.p[e][1][d] = q2;
+    s.p[e][2][d] = q3;
+}
+
+// pieces [lo, hi) of "ReLU + level split of the T tiles x" (eight pieces per tile); lo, hi are literals after unrolling
+template <int T>
+__device__ __forceinline__ void split_pieces(const f32x16 (&x)[T], ActSplit (&s)[T], int lo, int hi)
+{
+#pragma unroll
+    for (int c = 0; c < T * 8; ++c)
+        if (c >= lo && c < hi) split_piece<true>(x[c >> 3], (c >> 2) & 1, c & 3, s[c >> 3]);
+}
+
+// mlp_layer with a guest: hook(i) runs after the MFMAs of step i (i = 2 (t TIN + u) + e), and nothing is scheduled across
+// the end of a step. The ReLU of a hidden layer is left to the consumer's split (out[t] = bias + sums).
+template <int TOUT, int TIN, bool LAST, int KSTEPS, typename Hook>
+__device__ __forceinline__ void mlp_layer_host(const float *wp, const float *bp, const ActSplit (&in)[TIN], f32x16 (&out)[TOUT],
+                                               int lane, int h, Hook hook)
+{
+    const u32x4 *w4 = reinterpret_cast<const u32x4 *>(wp) + lane;
+    u32x4 cur[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) cur[l] = w4[l * 64];
+    f32x16 acc;
+    constexpr int kSteps = TOUT * TIN * 2;
+#pragma unroll
+    for (int i = 0; i < kSteps; ++i) {
+        const int pair = i >> 1, e = i & 1, t = pair / TIN, u = pair % TIN;
+        u32x4 nxt[3];
+        if (i + 1 < kSteps) {
+#pragma unroll
+            for (int l = 0; l < 3; ++l) nxt[l] = w4[((i + 1) * 3 + l) * 64];
+        }
+        if (u == 0 && e == 0) {
+            if (LAST) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+            } else {
+                acc = mlp_bias(bp, t, h);
+            }
+        }
+        if (e < KSTEPS) acc = mma_x6<LAST>(cur, in[u].p[e], acc);
+        if (u == TIN - 1 && e == 1) out[t] = acc;
+        hook(i);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < kSteps) {
+#pragma unroll
+            for (int l = 0; l < 3; ++l) cur[l] = nxt[l];
+        }
+    }
+}
+
+template <int T1, int T2, int T3, int SPAN, int NT>
+__global__ __launch_bounds__(NT) void sa_mlp3_pair_kernel(int n, int m, int nsample, int cfeat, int c3, long long rows,
+                                                           const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                           const float *__restrict__ points, const int *__restrict__ idx,
+                                                           const float *__restrict__ wpacked, const float *__restrict__ bpacked,
+                                                           float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *w1 = reinterpret_cast<float *>(smem);
+    float *w2 = w1 + mlp_w_floats(T1, 1);
+    float *w3 = w2 + mlp_w_floats(T2, T1);
+    float *b1 = w3 + mlp_w_floats(T3, T2);
+    float *b2 = b1 + mlp_b_floats(T1);
+    float *b3 = b2 + mlp_b_floats(T2);
+    {
+        const size_t wf = mlp_w_floats(T1, 1) + mlp_w_floats(T2, T1) + mlp_w_floats(T3, T2);
+        const size_t bf = mlp_b_floats(T1) + mlp_b_floats(T2) + mlp_b_floats(T3);
+        const float4 *src = reinterpret_cast<const float4 *>(wpacked);
+        float4 *dst = reinterpret_cast<float4 *>(w1);
+        for (size_t i = threadIdx.x; i < wf / 4; i += NT) dst[i] = src[i];
+        for (size_t i = threadIdx.x; i < bf; i += NT) b1[i] = bpacked[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5, s = lane & 31;
+    const int cin = 3 + cfeat;                           // <= 16: one K16 step in layer 1, input registers 0 .. 7
+    const long long wave = (long long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * (NT / 64);
+    const long long groups = SPAN == 32 ? rows : (rows + 1) / 2;
+
+    auto item_row = [&](long long g) __attribute__((always_inline)) -> long long {
+        const long long r = SPAN == 32 ? g : g * 2 + (s >> 4);
+        return r < rows ? r : rows - 1;
+    };
+    auto load_index = [&](long long g) __attribute__((always_inline)) -> int {
+        const int sample = SPAN == 32 ? s : (s & 15);
+        return idx[item_row(g) * nsample + sample];
+    };
+    // layer-1 operand registers 0 .. 7 of this lane's sample (channels mlp_chan(v, h)) and what to subtract from them
+    auto load_x0 = [&](long long g, int p, float (&x0)[8], float (&cen)[8]) __attribute__((always_inline)) {
+        const long long row = item_row(g), cloud = row / m;
+        const float *px = xyz + ((size_t)cloud * n + p) * 3;
+        const float *c = new_xyz + row * 3;
+        if (!points) {                                   // xyz only: channels 0-2 live in registers 0-2 of lanes 0-31
+            const float keep = h == 0 ? 1.0f : 0.0f;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) { x0[v] = 0.0f; cen[v] = 0.0f; }
+#pragma unroll
+            for (int v = 0; v < 3; ++v) { x0[v] = px[v] * keep; cen[v] = c[v] * keep; }
+            return;
+        }
+        const float *pf = points + ((size_t)cloud * n + p) * cfeat;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const int k = mlp_chan(v, h);
+            float val = 0.0f, sub = 0.0f;
+            if (k < 3) { val = px[k]; sub = c[k]; }
+            else if (k < cin) val = pf[k - 3];
+            x0[v] = val;
+            cen[v] = sub;
+        }
+    };
+    // the input split: (x0 - centroid) -> the three levels of K16 step 0
+    auto input_split = [&](const float (&x0)[8], const float (&cen)[8], ActSplit &s0) __attribute__((always_inline)) {
+        f32x16 in0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) in0[v] = __fsub_rn(x0[v], cen[v]);
+#pragma unroll
+        for (int v = 4; v < 8; ++v) in0[v] = x0[v];
+#pragma unroll
+        for (int v = 8; v < 16; ++v) in0[v] = 0.0f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) split_piece<false>(in0, 0, d, s0);
+#pragma unroll
+        for (int l = 0; l < 3; ++l) s0.p[1][l] = u32x4{0u, 0u, 0u, 0u};
+    };
+    // pool + bias + ReLU + store of output tile t of item g (see sa_mlp3_kernel)
+    auto pool_tile = [&](const f32x16 (&best)[T3], int t, long long g) __attribute__((always_inline)) {
+        const long long row = item_row(g);
+        const int ch = 32 * t + s;
+        const float bias = b3_at(b3, ch);
+        const bool live = g < groups && h == 0 && ch < c3;
+        if (SPAN == 32) {
+            float mx = best[t][0];
+            asm volatile("" : "+v"(mx));                 // (pinned to its step, see split_piece)
+#pragma unroll
+            for (int v = 1; v < 16; ++v) mx = fmaxf(mx, best[t][v]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            if (live) out[row * c3 + ch] = fmaxf(__fadd_rn(mx, bias), 0.0f);
+        } else {
+            float m0 = best[t][0], m1 = best[t][8];
+            asm volatile("" : "+v"(m0), "+v"(m1));
+#pragma unroll
+            for (int v = 1; v < 8; ++v) { m0 = fmaxf(m0, best[t][v]); m1 = fmaxf(m1, best[t][8 + v]); }
+            m0 = fmaxf(m0, __shfl_xor(m0, 32));
+            m1 = fmaxf(m1, __shfl_xor(m1, 32));
+            if (live) {
+                out[(2 * g) * c3 + ch] = fmaxf(__fadd_rn(m0, bias), 0.0f);
+                if (2 * g + 1 < rows) out[(2 * g + 1) * c3 + ch] = fmaxf(__fadd_rn(m1, bias), 0.0f);
+            }
+        }
+    };
+    auto clampg = [&](long long g) __attribute__((always_inline)) -> long long { return g < groups ? g : groups - 1; };
+
+    // stream A: items wave, wave + 2 nwaves, ...; stream B: wave + nwaves, wave + 3 nwaves, ... (an item beyond the end
+    // recomputes the last one and stores nothing)
+    long long gA = wave, gB = wave + nwaves;
+    if (gA >= groups) return;
+    float xA[8], cA[8], xB[8], cB[8];
+    load_x0(clampg(gA), load_index(clampg(gA)), xA, cA);
+    load_x0(clampg(gB), load_index(clampg(gB)), xB, cB);
+    ActSplit s0A[1], s0B[1];
+    input_split(xA, cA, s0A[0]);
+    while (gA < groups) {
+        const long long gAn = clampg(gA + 2 * nwaves), gBn = clampg(gB + 2 * nwaves);
+        const int pnA = load_index(gAn);                 // x, c of A are consumed: its next item's index first, the row later
+        f32x16 h1A[T1], h1B[T1], h2A[T2], h2B[T2], accA[T3], accB[T3];
+        ActSplit s1A[T1], s1B[T1], s2A[T2], s2B[T2];
+        // L1(A) | input split of B
+        mlp_layer_host<T1, 1, false, 1>(w1, b1, s0A, h1A, lane, h, [&](int i) __attribute__((always_inline)) {
+            if (i == 0) input_split(xB, cB, s0B[0]);
+        });
+        const int pnB = load_index(gBn);
+        // L1(B) | ReLU + split of A's first layer
+        mlp_layer_host<T1, 1, false, 1>(w1, b1, s0B, h1B, lane, h, [&](int i) __attribute__((always_inline)) {
+            constexpr int NP = T1 * 8, NS = T1 * 2;
+            split_pieces<T1>(h1A, s1A, i * NP / NS, (i + 1) * NP / NS);
+        });
+        // L2(A) | ReLU + split of B's first layer
+        mlp_layer_host<T2, T1, false, 2>(w2, b2, s1A, h2A, lane, h, [&](int i) __attribute__((always_inline)) {
+            constexpr int NP = T1 * 8, NS = T2 * T1 * 2;
+            split_pieces<T1>(h1B, s1B, i * NP / NS, (i + 1) * NP / NS);
+        });
+        load_x0(gAn, pnA, xA, cA);                       // in flight under the next layers
+        // L2(B) | ReLU + split of A's second layer
+        mlp_layer_host<T2, T1, false, 2>(w2, b2, s1B, h2B, lane, h, [&](int i) __attribute__((always_inline)) {
+            constexpr int NP = T2 * 8, NS = T2 * T1 * 2;
+            split_pieces<T2>(h2A, s2A, i * NP / NS, (i + 1) * NP / NS);
+        });
+        load_x0(gBn, pnB, xB, cB);
+        // L3(A) | ReLU + split of B's second layer
+        mlp_layer_host<T3, T2, true, 2>(w3, b3, s2A, accA, lane, h, [&](int i) __attribute__((always_inline)) {
+            constexpr int NP = T2 * 8, NS = T3 * T2 * 2;
+            split_pieces<T2>(h2B, s2B, i * NP / NS, (i + 1) * NP / NS);
+        });
+        // L3(B) | pool of A (its MFMAs were queued before this layer's), then the input split of A's next item
+        mlp_layer_host<T3, T2, true, 2>(w3, b3, s2B, accB, lane, h, [&](int i) __attribute__((always_inline)) {
+            constexpr int NS = T3 * T2 * 2, first = NS / 4;          // leave the first steps to A's last MFMAs
+#pragma unroll
+            for (int t = 0; t < T3; ++t)
+                if (i == first + t * ((NS - first - 1) / T3)) pool_tile(accA, t, gA);
+            if (i == NS - 1) input_split(xA, cA, s0A[0]);
+        });
+        // pool of B: nothing left to hide it under
+#pragma unroll
+        for (int t = 0; t < T3; ++t) pool_tile(accB, t, gB);
+        gA += 2 * nwaves;
+        gB += 2 * nwaves;
+    }
+}
+
 // ---- host side: bf16 levels of the weights ------------------------------------------------------------------
 static unsigned short bf16_nearest_even(float f)
 {
@@ -308,7 +553,7 @@ static size_t mlp_total_b(const MlpConfig &c) { return mlp_b_floats(c.t1) + mlp_
 
 template <int T1, int T2, int T3>
 static int launch_mlp(int b, int n, int m, int nsample, int cfeat, int c3, const float *xyz, const float *new_xyz,
-                      const float *points, const int *idx, const float *wp, const float *bp, float *out, hipStream_t st)
+                      const float *points, const int *idx, const float *wp, const float *bp, float *out, hipStream_t st, int variant)
 {
     const MlpConfig cfg = {T1, T2, T3};
     const size_t lds = sizeof(float) * (mlp_total_w(cfg) + mlp_total_b(cfg));
@@ -316,6 +561,32 @@ static int launch_mlp(int b, int n, int m, int nsample, int cfeat, int c3, const
     const long long rows = (long long)b * m;
     const bool half = nsample == 16;
     const long long groups = half ? (rows + 1) / 2 : rows;
+    // two items per wave (sa_mlp3_pair_kernel): one 32-sample group per centroid, at most 16 input channels
+    // (variant: 0 by the size rule below, 1 never, 2 / 3 wherever the kernel covers the shape: four / eight waves per workgroup)
+    const bool pair_ok = (nsample == 32 || nsample == 16) && 3 + cfeat <= 16 && T2 <= 2;      // (T2 = 3: two items' state spills)
+    // size rule (measured, profiles/r04/mlp_two_items.txt): eight waves x two items is 6-8 % faster than eight waves x one from
+    // ~8k items (metric shape 139 -> 131 us, cls_ssg SA1 36 -> 33), neutral below; four waves x two items is no faster than
+    // one item per wave (142 us): kept for tests / A-B only
+    if (variant == 0 && pair_ok && groups >= 8192) variant = 3;
+    if (pair_ok && variant >= 2) {
+        if constexpr (T2 <= 2) {
+          if (variant == 2) {                                           // four waves x two items
+            long long blocks = (groups + 7) / 8;
+            if (blocks > 256) blocks = 256;
+            auto kern = half ? sa_mlp3_pair_kernel<T1, T2, T3, 16, 256> : sa_mlp3_pair_kernel<T1, T2, T3, 32, 256>;
+            if (int rc = allow_dynamic_lds(kern, lds)) return rc;
+            return launch(kern, dim3((unsigned)blocks), dim3(256), lds, st, n, m, nsample, cfeat, c3, rows, xyz, new_xyz, points, idx,
+                          wp, bp, out);
+          }
+          // eight waves x two items (fits 256 registers)
+            long long blocks = (groups + 15) / 16;
+            if (blocks > 256) blocks = 256;
+            auto kern = half ? sa_mlp3_pair_kernel<T1, T2, T3, 16, 512> : sa_mlp3_pair_kernel<T1, T2, T3, 32, 512>;
+            if (int rc = allow_dynamic_lds(kern, lds)) return rc;
+            return launch(kern, dim3((unsigned)blocks), dim3(512), lds, st, n, m, nsample, cfeat, c3, rows, xyz, new_xyz, points, idx,
+                          wp, bp, out);
+        }
+    }
     // eight waves share one copy of the weights (two per SIMD: one wave's operand splitting overlaps the other's
     // MFMAs) when a wave fits in 256 registers; persistent: every workgroup stages the weights once
     constexpr int NT = 512;
@@ -448,7 +719,17 @@ extern "C" int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, 
                                    const float *points, const int *idx, int c1, int c2, int c3, const float *wpacked,
                                    const float *bpacked, float *out, void *ws, void *stream)
 {
+    return pn2_sa_mlp3_maxpool_ex(b, n, m, nsample, cfeat, xyz, new_xyz, points, idx, c1, c2, c3, wpacked, bpacked, out, ws, 0, stream);
+}
+
+// variant: the organisation of the resident kernel -- 0: by the size rule, 1: one item per wave, 2 / 3: two items per wave
+// (four / eight waves per workgroup) wherever that kernel covers the shape (results are bit-identical; tests and A/B timing)
+extern "C" int pn2_sa_mlp3_maxpool_ex(int b, int n, int m, int nsample, int cfeat, const float *xyz, const float *new_xyz,
+                                      const float *points, const int *idx, int c1, int c2, int c3, const float *wpacked,
+                                      const float *bpacked, float *out, void *ws, int variant, void *stream)
+{
     using namespace pn2;
+    if (variant < 0 || variant > 3) return PN2_E_ARG;
     if (b < 0 || n <= 0 || m < 0 || cfeat < 0) return PN2_E_SHAPE;
     if (nsample <= 0) return PN2_E_ARG;
     if (b == 0 || m == 0) return PN2_OK;
@@ -474,7 +755,7 @@ extern "C" int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, 
         return mlp_stream_launch(sc, b, n, m, nsample, cfeat, c3, xyz, new_xyz, pts ? pts : xyz, idx, wpacked, bpacked, out, ws, st);
 #define PN2_MLP_CASE(A, B, C) \
     if (cfg.t1 == A && cfg.t2 == B && cfg.t3 == C) \
-        return launch_mlp<A, B, C>(b, n, m, nsample, cfeat, c3, xyz, new_xyz, pts, idx, wpacked, bpacked, out, st)
+        return launch_mlp<A, B, C>(b, n, m, nsample, cfeat, c3, xyz, new_xyz, pts, idx, wpacked, bpacked, out, st, variant)
     PN2_MLP_CASE(1, 1, 2);
     PN2_MLP_CASE(2, 2, 4);
     PN2_MLP_CASE(2, 3, 4);

@@ -13,6 +13,17 @@ from . import _C
 from ._tensors import f32, i32, on_device, ptr, require, same_device, stream_ptr
 
 
+_RESIDENT_VARIANT = 0
+
+
+def set_resident_variant(variant):
+    """Organisation of the resident kernel (tests, A/B timing; results are bit-identical): 0 = the library's size rule,
+    1 = one 32-sample item per wave, 2 = two items per wave wherever that kernel covers the shape (csrc/sa_mlp.hip)."""
+    global _RESIDENT_VARIANT
+    require(variant in (0, 1, 2, 3), "resident variant must be 0 .. 3")
+    _RESIDENT_VARIANT = int(variant)
+
+
 def fold_batch_norm(conv_weight, conv_bias, bn=None):
     """(cout, cin[,1,1]) conv weight + bias and an optional eval-mode BatchNorm -> W (cin, cout), b (cout)
     with the norm folded in: y = (xW + b - mean) * gamma / sqrt(var + eps) + beta."""
@@ -117,9 +128,10 @@ def sa_mlp_maxpool(xyz, new_xyz, points, idx, packed):
     if nbytes:
         ws = torch.empty(((nbytes + 3) // 4,), dtype=torch.float32, device=dev)
     with on_device(dev):
-        _C.check(_C.lib().pn2_sa_mlp3_maxpool(b, n, m, ns, cfeat, ptr(xyz), ptr(new_xyz), ptr(points), ptr(idx),
-                                              packed.widths[0], packed.widths[1], packed.widths[2], ptr(packed.wp),
-                                              ptr(packed.bp), ptr(out), ptr(ws), stream_ptr(dev)), "sa_mlp3_maxpool")
+        _C.check(_C.lib().pn2_sa_mlp3_maxpool_ex(b, n, m, ns, cfeat, ptr(xyz), ptr(new_xyz), ptr(points), ptr(idx),
+                                                 packed.widths[0], packed.widths[1], packed.widths[2], ptr(packed.wp),
+                                                 ptr(packed.bp), ptr(out), ptr(ws), _RESIDENT_VARIANT, stream_ptr(dev)),
+                 "sa_mlp3_maxpool")
     return out
 
 

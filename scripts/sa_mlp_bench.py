@@ -14,6 +14,7 @@ import pointnet2_amd.pointnet_util as U
 from pointnet2_amd import sa_mlp, synthetic as S
 
 dev = torch.device("cuda:0")
+sa_mlp.set_resident_variant(int(os.environ.get("PN2_MLP_VARIANT", "0")))      # A/B of the resident kernel's organisation (read by this script)
 
 
 def timeit(fn, iters=20, warm=3):
@@ -47,7 +48,10 @@ CONFIGS = [
 
 def main():
     rows = []
+    only = os.environ.get("PN2_MLP_BENCH_ONLY", "")               # substring of the configurations to run
     for name, b, n, m, r, ns, cfeat, mlp in CONFIGS:
+        if only not in name:
+            continue
         torch.manual_seed(1)
         xyz = torch.from_numpy(S.sphere_clouds(b, n, 1)).to(dev)
         pts = torch.randn(b, n, cfeat, device=dev) if cfeat else None

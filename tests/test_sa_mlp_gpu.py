@@ -55,6 +55,39 @@ def test_fused_mlp_matches_torch(cuda, cfeat, widths, ns):
     assert err <= 5e-6 * max(1.0, scale), (err, scale)
 
 
+# The resident kernel with TWO items per wave (sa_mlp3_pair_kernel: one item's layers host the other's vector work) is the
+# same arithmetic in the same order per item: bit-identical to one item per wave, on every tile configuration, both group
+# sizes it covers, with and without features, odd item counts (a stream that runs out recomputes the last item and stores
+# nothing) and fewer items than waves.
+@pytest.mark.parametrize("cfeat,widths,ns,b,m", [(0, (64, 64, 128), 32, 3, 77), (0, (32, 32, 64), 16, 3, 77), (6, (64, 96, 128), 32, 2, 130),
+                                                 (0, (32, 32, 64), 32, 1, 5), (3, (64, 64, 128), 16, 2, 33), (13, (64, 64, 128), 32, 32, 512),
+                                                 (0, (64, 64, 128), 32, 32, 1024), (1, (17, 33, 65), 16, 5, 41), (0, (32, 32, 64), 16, 32, 600)])
+def test_two_items_per_wave_is_bit_identical(cuda, cfeat, widths, ns, b, m):
+    import pointnet2_amd as P
+    from pointnet2_amd import sa_mlp
+    rng = np.random.default_rng(cfeat * 10 + ns + m)
+    n = 1024
+    xyz = torch.from_numpy(S.sphere_clouds(b, n, 4)).to(cuda)
+    new_xyz = P.gather_point(xyz, P.farthest_point_sample(m, xyz))
+    idx, _ = P.query_ball_point(0.3, ns, xyz, new_xyz)
+    points = torch.from_numpy(rng.standard_normal((b, n, cfeat)).astype(np.float32)).to(cuda) if cfeat else None
+    dims = (3 + cfeat,) + tuple(widths)
+    layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
+               (0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32)) for i in range(3)]
+    packed = sa_mlp.PackedMLP3(layers, cuda, ns)
+    assert packed.kind == "resident"
+    outs = []
+    try:
+        for variant in (1, 2, 3, 0):
+            sa_mlp.set_resident_variant(variant)
+            outs.append(sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, packed).clone())
+    finally:
+        sa_mlp.set_resident_variant(0)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    want = _reference(xyz, new_xyz, points, idx, layers)
+    assert (outs[1].double() - want).abs().max().item() <= 5e-6 * max(1.0, want.abs().max().item())
+
+
 @pytest.mark.parametrize("cfeat,widths", [(3, (64, 64, 128)), (64, (128, 128, 256))])
 def test_fused_mlp_features_first_order(cuda, cfeat, widths):
     """xyz_first=False: the first layer's weight rows are [features, xyz] (the MSG module's concat order)."""
