@@ -299,18 +299,26 @@ __device__ __forceinline__ void mlp_layer_host(const float *wp, const float *bp,
                                                int lane, int h, Hook hook)
 {
     const u32x4 *w4 = reinterpret_cast<const u32x4 *>(wp) + lane;
-    u32x4 cur[3];
-#pragma unroll
-    for (int l = 0; l < 3; ++l) cur[l] = w4[l * 64];
-    f32x16 acc;
+    // the weights of a step are read from LDS PN2_PAIR_PREFETCH steps ahead (three buffers in rotation)
+#ifndef PN2_PAIR_PREFETCH
+#define PN2_PAIR_PREFETCH 1
+#endif
+    constexpr int PF = PN2_PAIR_PREFETCH;
+    u32x4 wb[PF + 1][3];
     constexpr int kSteps = TOUT * TIN * 2;
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+        if (j < kSteps) {
+#pragma unroll
+            for (int l = 0; l < 3; ++l) wb[j][l] = w4[(j * 3 + l) * 64];
+        }
+    f32x16 acc;
 #pragma unroll
     for (int i = 0; i < kSteps; ++i) {
         const int pair = i >> 1, e = i & 1, t = pair / TIN, u = pair % TIN;
-        u32x4 nxt[3];
-        if (i + 1 < kSteps) {
+        if (i + PF < kSteps) {
 #pragma unroll
-            for (int l = 0; l < 3; ++l) nxt[l] = w4[((i + 1) * 3 + l) * 64];
+            for (int l = 0; l < 3; ++l) wb[(i + PF) % (PF + 1)][l] = w4[((i + PF) * 3 + l) * 64];
         }
         if (u == 0 && e == 0) {
             if (LAST) {
@@ -320,14 +328,12 @@ __device__ __forceinline__ void mlp_layer_host(const float *wp, const float *bp,
                 acc = mlp_bias(bp, t, h);
             }
         }
-        if (e < KSTEPS) acc = mma_x6<LAST>(cur, in[u].p[e], acc);
+        if (e < KSTEPS) acc = mma_x6<LAST>(wb[i % (PF + 1)], in[u].p[e], acc);
         if (u == TIN - 1 && e == 1) out[t] = acc;
         hook(i);
+#ifndef PN2_PAIR_NOBARRIER                 /* lab switch (scripts/build_mlp_labs.sh): what the step barriers are worth */
         __builtin_amdgcn_sched_barrier(0);
-        if (i + 1 < kSteps) {
-#pragma unroll
-            for (int l = 0; l < 3; ++l) cur[l] = nxt[l];
-        }
+#endif
     }
 }
 
