@@ -7,6 +7,11 @@
 //   inter     the same wave alternates: MFMA, K VALU, MFMA, K VALU ... (independent registers; the order is pinned)
 //   burst     the same wave: 6 MFMAs, then 6 K VALU (what the kernels do today: a layer's MFMAs, then its split)
 //   spec      wave-specialised: the first wave of each SIMD only MFMAs, the second only VALU (2 waves per SIMD)
+//   inter_acc like inter, but the VALU instructions READ registers that an MFMA wrote long ago (a second accumulator, idle
+//             during the loop) -- what a level split of a finished layer does
+//   mfma_lds / inter_lds: the MFMAs' A operands come from LDS, three ds_read_b128 per trip issued one trip ahead (the weight
+//             reads of the kernels: 3 KB per wave and six MFMAs), without / with the K VALU instructions per MFMA
+//   inter_wop like inter, but the VALU instructions WRITE registers that a LATER MFMA reads as its B operand (the split's results)
 // Times are whole-launch HIP-event times per trip with all 256 CUs busy (the clock under load is part of the answer) and
 // s_memtime ticks (100 MHz) of wave 0.  hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/ubench_mfma_valu.hip -o build_lab/ubench_mfma_valu
 #include <hip/hip_runtime.h>
@@ -17,7 +22,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-enum { MFMA = 0, VALU = 1, INTER = 2, BURST = 3, SPEC = 4 };
+enum { MFMA = 0, VALU = 1, INTER = 2, BURST = 3, SPEC = 4, INTER_ACC = 5, INTER_WOP = 6, MFMA_LDS = 7, INTER_LDS = 8 };
 
 // K VALU instructions of the split's kinds on registers the MFMAs do not touch; asm volatile: a scheduling barrier,
 // so the MFMA builtins between two calls stay where they are written
@@ -43,12 +48,17 @@ template <int MODE, int K, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k(float *sink, unsigned long long *ticks, int iters)
 {
     const int t = threadIdx.x;
+    __shared__ u32x4 lds_w[26 * 3 * 64];                           // 78 KB: the resident kernel's weights of one item (26 steps x 3 levels)
+    if (MODE == MFMA_LDS || MODE == INTER_LDS)
+        for (int i = t; i < 26 * 3 * 64; i += 64 * WAVES) lds_w[i] = u32x4{0x3f803f80u + (unsigned)i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
     f32x16 acc = {0};
     u32x4 w[3], x[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { w[i] = u32x4{0x3f803f80u + t, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u + i}; x[i] = u32x4{0x3f803f80u, 0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u + t}; }
     float a[4] = {1.0f + t, 2.0f + t, 3.0f + t, 4.0f + t}, b = 2.0f + t;
     unsigned p[4] = {(unsigned)t, 1u, 2u, 3u}, q[4] = {(unsigned)t + 1u, 5u, 6u, 7u};
+    f32x16 acc2 = {0};
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[0]), __builtin_bit_cast(bf16x8, x[0]), acc2, 0, 0, 0);     // MFMA-written, then idle
     const bool mfma_wave = MODE != SPEC || (t >> 6) < WAVES / 2;      // SPEC: waves 0..3 (one per SIMD) run the MFMAs, 4..7 the VALU work
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -60,6 +70,31 @@ __global__ __launch_bounds__(64 * WAVES) void k(float *sink, unsigned long long 
         if (MODE == INTER) {
             M(0, 2); valu<K>(a, b, p, q, phase); M(1, 1); valu<K>(a, b, p, q, phase); M(2, 0); valu<K>(a, b, p, q, phase);
             M(0, 1); valu<K>(a, b, p, q, phase); M(1, 0); valu<K>(a, b, p, q, phase); M(0, 0); valu<K>(a, b, p, q, phase);
+        }
+        if (MODE == INTER_ACC) {                                   // the cvt of every fourth VALU instruction reads an MFMA-written register
+#define VA(i0) { a[0] = acc2[(i0) & 15]; a[1] = acc2[((i0) + 1) & 15]; a[2] = acc2[((i0) + 2) & 15]; a[3] = acc2[((i0) + 3) & 15]; valu<K>(a, b, p, q, phase); }
+            M(0, 2); VA(0) M(1, 1); VA(4) M(2, 0); VA(8) M(0, 1); VA(12) M(1, 0); VA(2) M(0, 0); VA(6)
+#undef VA
+        }
+        if (MODE == INTER_WOP) {                                   // the VALU results become the B operand of the MFMA two slots later
+#define VW(XL) { valu<K>(a, b, p, q, phase); x[XL][1] = p[0]; x[XL][2] = q[1]; }
+            M(0, 2); VW(0) M(1, 1); VW(2) M(2, 0); VW(1) M(0, 1); VW(0) M(1, 0); VW(1) M(0, 0); VW(2)
+#undef VW
+        }
+        if (MODE == MFMA_LDS || MODE == INTER_LDS) {
+            const u32x4 *w4 = lds_w + (t & 63);
+            const int step = (it + 1) % 26;
+            u32x4 nw[3];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) nw[l] = w4[(step * 3 + l) * 64];      // next trip's weights
+            asm volatile("" ::: "memory");
+            if (MODE == MFMA_LDS) { M(0, 2); M(1, 1); M(2, 0); M(0, 1); M(1, 0); M(0, 0); }
+            else {
+                M(0, 2); valu<K>(a, b, p, q, phase); M(1, 1); valu<K>(a, b, p, q, phase); M(2, 0); valu<K>(a, b, p, q, phase);
+                M(0, 1); valu<K>(a, b, p, q, phase); M(1, 0); valu<K>(a, b, p, q, phase); M(0, 0); valu<K>(a, b, p, q, phase);
+            }
+#pragma unroll
+            for (int l = 0; l < 3; ++l) w[l] = nw[l];
         }
         if (MODE == BURST) { M(0, 2); M(1, 1); M(2, 0); M(0, 1); M(1, 0); M(0, 0); valu<6 * K>(a, b, p, q, phase); }
         if (MODE == SPEC) {
@@ -75,7 +110,7 @@ __global__ __launch_bounds__(64 * WAVES) void k(float *sink, unsigned long long 
 #pragma unroll
     for (int i = 0; i < 4; ++i) s += a[i] + __uint_as_float(p[i]) + __uint_as_float(q[i]);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s += acc[i];
+    for (int i = 0; i < 16; ++i) s += acc[i] + acc2[i];
     sink[blockIdx.x * 64 * WAVES + t] = s;
 }
 
@@ -108,6 +143,14 @@ int main()
     run<INTER, 6, 4>("inter  K=6 1 wave/SIMD");
     run<INTER, 4, 8>("inter  K=4 2 waves/SIMD");
     run<INTER, 6, 8>("inter  K=6 2 waves/SIMD");
+    run<INTER_ACC, 4, 4>("inter_acc K=4 1 wave/SIMD (VALU reads MFMA-written regs)");
+    run<INTER_ACC, 4, 8>("inter_acc K=4 2 waves/SIMD");
+    run<INTER_WOP, 4, 4>("inter_wop K=4 1 wave/SIMD (VALU writes later MFMA operands)");
+    run<INTER_WOP, 4, 8>("inter_wop K=4 2 waves/SIMD");
+    run<MFMA_LDS, 0, 4>("mfma_lds  1 wave/SIMD (3 ds_read_b128 per 6 MFMAs)");
+    run<MFMA_LDS, 0, 8>("mfma_lds  2 waves/SIMD");
+    run<INTER_LDS, 4, 4>("inter_lds K=4 1 wave/SIMD");
+    run<INTER_LDS, 4, 8>("inter_lds K=4 2 waves/SIMD");
     run<BURST, 4, 4>("burst  K=4 1 wave/SIMD");
     run<BURST, 4, 8>("burst  K=4 2 waves/SIMD");
     run<BURST, 6, 8>("burst  K=6 2 waves/SIMD");
