@@ -49,6 +49,32 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     assert "gfx950" in out and out.strip().endswith("-3")          # radius <= 0 is PN2_E_ARG, from plain C
 
 
+def test_python_struct_mirrors_match_the_header(tmp_path):
+    """The ctypes mirrors of the header's structs (pn2_group_src, pn2_bn_layer, pn2_train_opts) must have the C compiler's
+    size and field offsets: a field added on one side only would shift every later one silently."""
+    import ctypes
+    from pointnet2_amd import train_mlp
+    src = tmp_path / "lay.c"
+    checks = [("pn2_train_opts", train_mlp.TrainOpts), ("pn2_bn_layer", train_mlp.BnLayer), ("pn2_group_src", train_mlp.GroupSrc)]
+    body = ['#include "pn2ops.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
+    for cname, py in checks:
+        body.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for fname, _ in py._fields_:
+            body.append('printf(" %%zu", offsetof(%s, %s));' % (cname, fname))
+        body.append('printf("\\n");')
+    body.append("return 0; }")
+    src.write_text("\n".join(body) + "\n")
+    exe = tmp_path / "lay"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True, capture_output=True)
+    lines = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    assert len(lines) == len(checks)
+    for line, (cname, py) in zip(lines, checks):
+        parts = line.split()
+        assert parts[0] == cname
+        assert int(parts[1]) == ctypes.sizeof(py), cname
+        assert [int(v) for v in parts[2:]] == [getattr(py, f).offset for f, _ in py._fields_], cname
+
+
 def test_library_contains_gfx950_code_object():
     from pointnet2_amd import _C
     blob = open(_C.LIB_PATH, "rb").read()
@@ -116,6 +142,8 @@ def test_c_abi_argument_validation_of_the_extra_entry_points():
     assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 32, 0, one, one, None, one, 512, 512, 512, one, one, one, None, None) == -4
     assert lib.pn2_sa_mlp3_maxpool(2, 64, 3, 64, 0, one, None, None, None, 256, 512, 1024, one, one, one, None, None) == -3  # group_all needs m = 1, nsample = n
     assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 32, 4, one, one, None, one, 64, 64, 128, one, one, one, None, None) == -1   # points missing
+    assert lib.pn2_sa_mlp3_maxpool_ex(1, 64, 8, 32, 0, one, one, None, one, 64, 64, 128, one, one, one, None, 9, None) == -3   # unknown organisation of the resident kernel
+    assert lib.pn2_sa_mlp3_maxpool_ex(1, 64, 8, 32, 4, one, one, None, one, 64, 64, 128, one, one, one, None, 3, None) == -1   # the same checks as the plain entry point
     assert lib.pn2_sa_mlp3_pack(3, 64, 64, 128, 32, 1, None, None, None, None, None, None, None, None) == -1
     # scratch: only the streamed kernel needs any (the per-point part of layer 1: b * n rows of the padded first width)
     assert lib.pn2_sa_mlp3_ws_bytes(2, 100, 7, 3, 64, 64, 128, 32) == 0
