@@ -349,8 +349,11 @@ typedef struct pn2_bn_layer {
     int grad_accumulate;           /* backward: 0 = the three gradients are written, 1 = ADDED to what the buffers hold (one fp32
                                       add per element, as a framework's own accumulation into .grad would do) */
     int running_var_biased;        /* which batch variance enters running_var: 0 = the UNBIASED one, var * N / (N - 1)
-                                      (torch.nn.BatchNorm); 1 = the biased one (tf.contrib.layers.batch_norm as the reference
-                                      calls it, tf_util.py:512-531: the moving variance receives tf.nn.moments' variance) */
+                                      (torch.nn.BatchNorm; also tf.contrib.layers.batch_norm, the reference's live path
+                                      tf_util.py:526-531, wherever it takes the fused kernel); 1 = the biased one, var
+                                      (tf.nn.moments: contrib's non-fused path, the default of the TF 1.2 the reference
+                                      was tested on). The struct gained this trailing field in library version 0.2.0:
+                                      callers MUST zero-initialise pn2_bn_layer (memset / = {0}) before filling it. */
 } pn2_bn_layer;
 
 /* pool_rows: 0 = no pooling, out is (rows, cout_L) = relu(bn(z_L)); else the group size (nsample: 16 or a multiple of

@@ -19,4 +19,4 @@ from .tf_grouping import (query_ball_point, group_point, knn_point, select_top_k
 from .tf_interpolate import three_nn, three_interpolate  # noqa: F401
 from ._tensors import set_deterministic, is_deterministic  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

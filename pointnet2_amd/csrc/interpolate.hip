@@ -359,7 +359,15 @@ extern "C" int pn2_fp_interp_concat_grad(int b, int n, int m, int c2, int c1, in
     using namespace pn2;
     if (b < 0 || n < 0 || m <= 0 || c2 <= 0 || c1 < 0 || pitch < c2 + c1) return PN2_E_SHAPE;
     const long long rows = (long long)b * n;
-    if (rows == 0) return PN2_OK;
+    if (rows == 0) {
+        // no unknown point: the gradient of points2 is zero, and this entry point -- like pn2_three_interpolate_grad_seg --
+        // owns the zero fill (callers allocate it uninitialised); nothing flows to points1 (b * n == 0 rows)
+        if (b > 0 && grad_points2) {
+            hipError_t e = hipMemsetAsync(grad_points2, 0, sizeof(float) * (size_t)b * m * c2, as_stream(stream));
+            if (e != hipSuccess) return (int)e;
+        }
+        return PN2_OK;
+    }
     if (!grad_x || !idx || !weight || !scratch || !ws_seg || !grad_points2) return PN2_E_NULL;
     const long long elems = rows * (c2 + (grad_points1 ? c1 : 0));
     if (int rc = launch(fp_split_grad_kernel, dim3(grid_for(elems)), dim3(kThreads), 0, as_stream(stream), elems, c2,

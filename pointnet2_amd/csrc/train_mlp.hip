@@ -698,6 +698,7 @@ struct TlWgrad {
     const float *coef;          // (3, NO): s, c0, c1
     int group_rows;
     float *partial;             // [slab][workgroup][tus * tts tiles][1024]
+    size_t partial_cap;         // host side: bytes planned for `partial` (0 = unchecked); a launch whose slabs need more is refused
     int tus, tts, tslabs;       // tiles of h / of dz per slab; slabs along dz
     // ---- the layer's DATA gradient in the same pass (template flag DY; one slab only): dy_{l-1} = (second operand) . Wt,
     // contraction over the k tiles the block image already holds, see "One pass per layer" below
@@ -1743,6 +1744,7 @@ struct TlPlan {
     size_t gq;                  // backward, pooled: (groups, cout_L)
     size_t ga, gb;              // backward: dy ping-pong (rows, max width)
     size_t partial, partial2;   // backward: weight-gradient partial sums
+    size_t partial_cap, partial2_cap;   // ... and the bytes planned for them (launch_wgrad / launch_pair refuse a larger shape)
     size_t topw, topsf;         // backward, pooled top layer without z_L: stacked fp32 weight + constant row; [S | G | sumh] fp64
     size_t tops_part, tops_part2, tops64;   // ... its routed part on the vector units: partials (two stages), S (K, C_L) fp64
     size_t l1p;                 // layer 1 per point: forward P (b n, cout_1); backward S (b n, cout_1)
@@ -1830,6 +1832,15 @@ static bool l1_coords_only(int nlayers, const int *widths, const GroupDims *g, c
     return c1 % 4 == 0 && c1 / 4 <= kL1Threads && kL1Threads % (c1 / 4) == 0;
 }
 
+// The weight-gradient launch's slab shape AS PLANNED: the launches call wgrad_shape with the device's CU count (<= 256,
+// device_cus) and the caller's wgrad_two_per_cu, both of which can only make the grid -- hence the `partial` buffers --
+// SMALLER than 256 CUs with two workgroups per CU wherever the shape allows them (planned with the
+// defaults, an opted-in second workgroup or a 129..255-CU device wrote its slabs past the planned buffer).
+static WgradShape wgrad_plan_shape(long long rows, int KI, int NO, bool gather, const Opts &o)
+{
+    return wgrad_shape(rows, KI, NO, gather, 256, o.wgrad_two_per_cu == PN2_OPT_OFF ? PN2_OPT_OFF : PN2_OPT_ON);
+}
+
 static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_rows, int backward, TlPlan &pl,
                     const GroupDims *gd, const Opts &o)
 {
@@ -1869,23 +1880,24 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
         for (int l = 0; l < nlayers; ++l) {
             const bool zt = ztop && l == nlayers - 1;
             for (int gat = 0; gat < (l == 0 ? 2 : 1); ++gat) {      // layer 1 may be a gathered input (other slab shape)
-                const WgradShape w = wgrad_shape(rows, widths[l], zt ? top_cols(widths[l], widths[l + 1]) : widths[l + 1], gat != 0);
+                const WgradShape w = wgrad_plan_shape(rows, widths[l], zt ? top_cols(widths[l], widths[l + 1]) : widths[l + 1], gat != 0, o);
                 if (w.partial_bytes > p1) p1 = w.partial_bytes;
                 if (w.partial2_bytes > p2) p2 = w.partial2_bytes;
             }
             if (zt) {                                              // without the routed tiles (tl_top_s_kernel takes them)
-                const WgradShape w = wgrad_shape(rows, widths[l], top_cols(widths[l], 0));
+                const WgradShape w = wgrad_plan_shape(rows, widths[l], top_cols(widths[l], 0), false, o);
                 if (w.partial_bytes > p1) p1 = w.partial_bytes;
                 if (w.partial2_bytes > p2) p2 = w.partial2_bytes;
             }
         }
         if (l1_per_point(nlayers, widths, gd, o)) {                  // dW1f = points^T S over the b n points
-            const WgradShape w = wgrad_shape((long long)gd->b * gd->n, gd->cfeat, widths[1]);
+            const WgradShape w = wgrad_plan_shape((long long)gd->b * gd->n, gd->cfeat, widths[1], false, o);
             if (w.partial_bytes > p1) p1 = w.partial_bytes;
             if (w.partial2_bytes > p2) p2 = w.partial2_bytes;
         }
         pl.partial = off; off = align_up(off + p1);
         pl.partial2 = off; off = align_up(off + p2);
+        pl.partial_cap = p1; pl.partial2_cap = p2;
         if (ztop) {
             const int kin = widths[nlayers - 1];
             pl.topw = off; off = align_up(off + sizeof(float) * (size_t)(tiles(cl) * 32 + kin + 1) * kin);
@@ -2056,6 +2068,7 @@ static int launch_wgrad_reduce(const TlWgrad &p, const WgradShape &w, float *par
 static int launch_wgrad(TlWgrad &p, const WgradShape &w, float *partial2, const pn2_bn_layer &L, hipStream_t st,
                         double *plain = nullptr)
 {
+    if (p.partial_cap && w.partial_bytes > p.partial_cap) return PN2_E_ARG;   // never write past the planned buffer
     p.tus = w.tus; p.tts = w.tts; p.tslabs = w.tslabs;
     const dim3 grid((unsigned)w.gridx, (unsigned)(w.uslabs * w.tslabs));
 #ifdef PN2_WG_TIMING               /* lab build (scripts/build_mlp_labs.sh wgtime): cycles per phase and wave of workgroup 0, printed per launch */
@@ -2103,6 +2116,7 @@ static int launch_pair(int amode, TlGemm &pg, const GemmShape &g, TlWgrad &pw, c
                        hipStream_t st, const Opts &o, int *nparts, double *plain = nullptr)
 {
     if (pw.dy_w) return kNoPair;
+    if (pw.partial_cap && w.partial_bytes > pw.partial_cap) return PN2_E_ARG;   // never write past the planned buffer
     const bool gather = pw.amode == A_GATHER;
     const int dcls = pw.dmode == A_FILL ? D_TOP : pw.dmode == A_DZ_POOL ? D_DZPOOL : D_DZ;
     size_t lds = g.lds > w.lds ? g.lds : w.lds;
@@ -2227,15 +2241,27 @@ struct SideStream {
         const SideKey key = {dev, st};
         auto it = table.find(key);
         if (it == table.end()) {
-            SideRes r;
-            if ((e = hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking)) != hipSuccess) return (int)e;
-            if ((e = hipEventCreateWithFlags(&r.fork_ev, hipEventDisableTiming)) != hipSuccess) return (int)e;
-            if ((e = hipEventCreateWithFlags(&r.join_ev, hipEventDisableTiming)) != hipSuccess) return (int)e;
+            SideRes r = {nullptr, nullptr, nullptr};
+            if ((e = hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking)) == hipSuccess &&
+                (e = hipEventCreateWithFlags(&r.fork_ev, hipEventDisableTiming)) == hipSuccess)
+                e = hipEventCreateWithFlags(&r.join_ev, hipEventDisableTiming);
+            if (e != hipSuccess) {                                 // nothing half-built stays behind
+                if (r.join_ev) (void)hipEventDestroy(r.join_ev);
+                if (r.fork_ev) (void)hipEventDestroy(r.fork_ev);
+                if (r.side) (void)hipStreamDestroy(r.side);
+                return (int)e;
+            }
             it = table.emplace(key, r).first;
         }
         side = it->second.side; fork_ev = it->second.fork_ev; join_ev = it->second.join_ev;
         return PN2_OK;
     }
+    // Scope guard: an error return between fork() and join() must not leave the helper stream forked -- under HIP graph
+    // capture that would be an unjoined capture, which invalidates it. join() is idempotent.
+    ~SideStream() { (void)join(); }
+    SideStream() = default;
+    SideStream(const SideStream &) = delete;
+    SideStream &operator=(const SideStream &) = delete;
     hipStream_t get() const { return side ? side : main; }      // where the forked work goes
     int fork()                                                   // the helper continues from here
     {
@@ -2707,7 +2733,7 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 w.dmode = A_FILL;
                 w.NO = ld; w.tf = tf; w.NF = NF;
                 w.G = gq; w.argsel = argsel; w.coef = coef; w.group_rows = pool_rows;
-                w.partial = reinterpret_cast<float *>(base + pl.partial);
+                w.partial = reinterpret_cast<float *>(base + pl.partial); w.partial_cap = pl.partial_cap;
                 w.xshare = 1;                                     // one slab: the "h again" tiles are the first operand's
                 w.dy_w = reinterpret_cast<const u32x4 *>(base + pl.pack[l]);
                 w.xr_off = (int)fz[l].xr_off;
@@ -2754,7 +2780,7 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 w.dmode = A_FILL;
                 w.NO = ldw; w.tf = tfw; w.NF = ts.ok ? 0 : NF;
                 w.G = gq; w.argsel = argsel; w.coef = coef; w.group_rows = pool_rows;
-                w.partial = reinterpret_cast<float *>(base + pl.partial);
+                w.partial = reinterpret_cast<float *>(base + pl.partial); w.partial_cap = pl.partial_cap;
                 const WgradShape ws_ = wgrad_shape(rows, K, ldw, false, cus, o.wgrad_two_per_cu);
                 w.xshare = ws_.uslabs == 1;
                 const GemmShape g = gemm_shape(rows, NFp + K, K, o);
@@ -2822,7 +2848,7 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                 memset(&w, 0, sizeof(w));
                 w.rows = bn; w.KI = gt.cfeat; w.amode = A_PLAIN; w.A = group->points;
                 w.dmode = A_DZ; w.NO = L.cout; w.Z = S; w.G = S; w.coef = ident;
-                w.partial = reinterpret_cast<float *>(base + pl.partial);
+                w.partial = reinterpret_cast<float *>(base + pl.partial); w.partial_cap = pl.partial_cap;
                 pn2_bn_layer Lf = L;
                 Lf.grad_weight = L.grad_weight + gt.feat_off * L.w_stride_k;
                 const WgradShape ws_ = wgrad_shape(bn, gt.cfeat, L.cout, false, cus, o.wgrad_two_per_cu);
@@ -2865,7 +2891,7 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
             w.argsel = argsel;
             w.coef = coef;
             w.group_rows = pool_rows;
-            w.partial = reinterpret_cast<float *>(base + pl.partial);
+            w.partial = reinterpret_cast<float *>(base + pl.partial); w.partial_cap = pl.partial_cap;
             if (fz[l].ok) {
                 // ... and the data gradient in the same pass over (dy_l, z_l, z_{l-1}), see tl_wgrad_kernel
                 w.dy_w = reinterpret_cast<const u32x4 *>(base + pl.pack[l]);

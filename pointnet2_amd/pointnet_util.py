@@ -88,11 +88,15 @@ def three_nn_weights(xyz1, xyz2):
 
 
 def use_tf_moving_variance(model, flag=True):
-    """Make every batch norm of `model` feed the BIASED batch variance to its running variance in the fused training path,
-    as tf.contrib.layers.batch_norm does in the reference (tf_util.py:512-531: tf.nn.moments' variance goes straight
-    into the moving average; torch.nn.BatchNorm averages the unbiased one, var * N / (N - 1) -- a relative difference of
-    1 / N, 2.4e-4 on a 4,096-row level). pn2_bn_layer.running_var_biased. The layer-by-layer torch path keeps torch's
-    convention."""
+    """Make every batch norm of `model` feed the BIASED batch variance (tf.nn.moments: 1 / N) to its running variance in the
+    fused training path instead of torch's unbiased one (var * N / (N - 1); a relative difference of 1 / N, 2.4e-4 on a
+    4,096-row level). pn2_bn_layer.running_var_biased. WHICH convention the reference has depends on the TensorFlow it runs
+    on: its live path is tf.contrib.layers.batch_norm (tf_util.py:526-531; the tf.nn.moments code at :487-510 is
+    batch_norm_template_unused). With `fused` off -- the default of the TF 1.2 the README names -- contrib's moving
+    variance receives tf.nn.moments' biased variance (flag=True reproduces that); where contrib takes the fused kernel
+    (the default of later TF 1.x for rank-2/4 inputs) the moving average receives the Bessel-corrected variance, which is
+    torch's convention (leave the flag off). Not a parity claim by itself: pick the convention of the checkpoint you load.
+    The layer-by-layer torch path always keeps torch's convention."""
     for mod in model.modules():
         if isinstance(mod, (nn.BatchNorm1d, nn.BatchNorm2d)):
             mod.running_var_biased = bool(flag)

@@ -89,3 +89,20 @@ def test_fp_module_training_uses_the_one_launch_input(cuda):
         if float(pb.grad.abs().max()) < 1e-6:
             continue
         assert float((pa.grad - pb.grad).norm() / pb.grad.norm()) <= 5e-3, na
+
+
+def test_fp_interp_concat_without_unknown_points_gives_a_zero_gradient(cuda):
+    """n == 0: nothing is interpolated, so the gradient of points2 is exactly zero -- the library owns the
+    zero fill of grad_points2 (the wrapper allocates it uninitialised) on this early-return path too."""
+    from pointnet2_amd.tf_interpolate import fp_interp_concat
+    b, m, c2 = 3, 17, 20
+    p2 = torch.randn((b, m, c2), device=cuda).requires_grad_(True)
+    idx = torch.empty((b, 0, 3), dtype=torch.int32, device=cuda)
+    dist = torch.empty((b, 0, 3), dtype=torch.float32, device=cuda)
+    for _ in range(3):                                            # fresh (dirty) allocations every time
+        junk = torch.full((b, m, c2), 7.0, device=cuda)
+        del junk
+        out, weight = fp_interp_concat(p2, None, idx, dist)
+        assert out.shape == (b, 0, c2) and weight.shape == (b, 0, 3)
+        (g,) = torch.autograd.grad(out.sum(), p2)
+        assert g.shape == p2.shape and float(g.abs().max()) == 0.0

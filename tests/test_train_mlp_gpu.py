@@ -98,6 +98,27 @@ def test_one_pass_backward_variants(cuda, name, kw, ztop):
     assert worst <= TOL, "%s: worst relative error %.2e" % (name, worst)
 
 
+# the weight-gradient `partial` workspace was planned with the default slab shape (256 CUs, the automatic
+# one-or-two-workgroups-per-CU rule) while the launches use the caller's wgrad_two_per_cu -- forced on at 64 k - 128 k rows a
+# 64 -> 64 layer launched 512 workgroups against 256 planned slabs and wrote past the buffer. The plan now sizes for the
+# largest grid any setting can launch (wgrad_plan_shape) and the launches refuse a shape larger than the plan.
+TWO_PER_CU_CASES = [
+    ("64k rows 64-64-128", dict(b=8, n=1024, m=256, ns=32, cfeat=0, widths=[64, 64, 128])),
+    ("128k rows c64 64-64-128", dict(b=16, n=1024, m=256, ns=32, cfeat=64, widths=[64, 64, 128])),
+    ("96k rows plain 64-64", dict(b=12, n=8192, m=0, ns=0, cfeat=0, widths=[64, 64], plain_cin=64)),
+]
+
+
+@pytest.mark.parametrize("two", [True, False, None], ids=["two per CU", "one per CU", "automatic"])
+@pytest.mark.parametrize("name,kw", TWO_PER_CU_CASES, ids=[c[0] for c in TWO_PER_CU_CASES])
+def test_two_weight_gradient_workgroups_per_cu_stay_inside_the_plan(cuda, name, kw, two):
+    from pointnet2_amd import train_mlp
+    from scripts import train_mlp_check as T
+    with train_mlp.options(wgrad_two_per_cu=two):
+        worst = T.run_case(name, **kw)
+    assert worst <= TOL, "%s: worst relative error %.2e" % (name, worst)
+
+
 # A layer's data-gradient GEMM and its weight-gradient pass as two ranges of workgroups of ONE launch (tl_pair_kernel; the
 # default below 0.5 M rows, so the config cases above already run it against float64): the same arithmetic in the same order
 # as the two launches -- every gradient must come out BIT-identical with the pair forced on and forced off. One level per
