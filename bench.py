@@ -137,6 +137,28 @@ class Stage:
                                                             self.cnt.data_ptr(), self.grouped.data_ptr(), 1, self.stream),
                       "sample_and_group_xyz")
 
+    def status_word(self):
+        """The overlapped launch's status word (pn2_sample_and_group_status_offset): 0 unless a consumer workgroup ever gave
+        up waiting for its producer. Synchronises."""
+        off = self.lib.pn2_sample_and_group_status_offset(self.b, M)
+        return int(self.ws[off:off + 4].view(torch.int32).item())
+
+    def verify(self, path):
+        """Are the outputs the timed path left in this stage's buffers bit-identical to the four reference-shaped operators
+        on the same input, and did no overlapped launch report a give-up? Device-side comparison AFTER the timed region
+        (the timed loops never looked at a byte). -> dict of booleans."""
+        torch.cuda.synchronize()
+        got = [t.clone() for t in (self.fps, self.new_xyz, self.idx, self.cnt, self.grouped)]
+        status = self.status_word() if path == "overlap" else 0
+        self.step_ops()                                   # FPS, gather, ball query, group_point: grouped WITHOUT the centroid
+        torch.cuda.synchronize()
+        want_grouped = self.grouped if path == "ops" else self.grouped - self.new_xyz[:, :, None, :]
+        res = {"fps_idx": bool(torch.equal(got[0], self.fps)), "new_xyz": bool(torch.equal(got[1], self.new_xyz)),
+               "idx": bool(torch.equal(got[2], self.idx)), "pts_cnt": bool(torch.equal(got[3], self.cnt)),
+               "grouped_xyz": bool(torch.equal(got[4], want_grouped)), "status_word": status}
+        res["ok"] = all(v for k, v in res.items() if k != "status_word") and status == 0
+        return res
+
     def step_ops(self):
         self.fps_()
         self.gather_()
@@ -225,10 +247,11 @@ def concurrent_throughput(dev, rank, path, streams, steps):
     separate HIP streams. One FPS launch occupies 32 of the 256 CUs for its whole serial chain, so
     independent batches (prefetched SA1 inputs, concurrent requests) overlap almost perfectly."""
     ss = [torch.cuda.Stream(device=dev) for _ in range(streams)]
-    fns = []
+    fns, stages = [], []
     for i, st in enumerate(ss):
         with torch.cuda.stream(st):
-            fns.append(Stage(dev, synthetic.sphere_clouds(B, N, 2000 + 97 * rank + i)).step(path))
+            stages.append(Stage(dev, synthetic.sphere_clouds(B, N, 2000 + 97 * rank + i)))
+            fns.append(stages[-1].step(path))
     for st, fn in zip(ss, fns):
         with torch.cuda.stream(st):
             fn()
@@ -239,8 +262,14 @@ def concurrent_throughput(dev, rank, path, streams, steps):
             fns[i % streams]()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # what the streams left in their buffers while they shared the device, against the operator path one stream at a time
+    checks = []
+    for st, stg in zip(ss, stages):
+        with torch.cuda.stream(st):
+            checks.append(stg.verify(path))
     return {"streams": streams, "steps": steps, "value": B * steps / dt, "unit": "clouds/s",
-            "ms_per_step": dt / steps * 1e3,
+            "ms_per_step": dt / steps * 1e3, "verified": all(c["ok"] for c in checks),
+            "verify_failures": [dict(c, stream=i) for i, c in enumerate(checks) if not c["ok"]],
             "note": "independent batches on separate HIP streams; reported beside `value`, which times "
                     "strictly sequential steps on one stream"}
 
@@ -408,6 +437,11 @@ def main():
     elapsed = sharding.max_over_ranks(elapsed, dev)     # whole-job time = slowest rank
     launch_s = (ev0.elapsed_time(ev1) * 1e-3 / args.steps) if ev0 is not None else elapsed / args.steps
 
+    # outputs of the LAST timed step against the four-operator path (and the overlapped launch's status word): every rank
+    verified = None
+    if not args.stub:
+        v = stage.verify(args.path)
+        verified = dict(v, ok=bool(sharding.max_over_ranks(0.0 if v["ok"] else 1.0, dev) == 0.0))
     extras = not args.no_extras and not args.stub
     allred = allreduce_leg(dev, dist) if dist is not None else None
     conc = None
@@ -438,6 +472,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "verified": None if verified is None else verified["ok"],
             "config": {"workload": "SA stage FPS+gather+ball_query+group, N=4096->npoint=1024, radius=0.2, nsample=32, "
                                    "xyz only (BASELINE metric shape); %s"
                                    % ("B=32 per GPU" if args.scaling == "weak" else
@@ -457,6 +492,10 @@ def main():
                                  "HIP-event time per step on the launch stream. Bound by the FPS chain (latency), "
                                  "not by HBM: see fps_latency_model"},
         }
+        if verified is not None:
+            line["verify"] = dict(verified, note="after the timed region: fps_idx / new_xyz / idx / pts_cnt / grouped_xyz of the last "
+                                  "timed step compared on the device with the four reference-shaped operators on the same batch "
+                                  "(bit-exact), and the overlapped launch's status word read back; `verified` = all ranks ok")
         if allred is not None:
             line["allreduce"] = allred
         if extras:
