@@ -81,6 +81,8 @@ TIMED_KERNEL = {"overlap": "sa_fused_kernel (pn2_sample_and_group_xyz: the whole
 class Stage:
     """The launches of one step, through the C ABI, with preallocated buffers."""
 
+    fps_variant = 0        # PN2_FPS_AUTO / _FULL (1) / _PRUNED (2): --fps-variant, results never depend on it
+
     def __init__(self, dev, xyz_np, radius=RADIUS):
         from pointnet2_amd import _C
         self._C = _C
@@ -99,9 +101,10 @@ class Stage:
         self.gen = 0                                  # granule generation of the overlapped launch (see overlap_)
         self.stream = torch.cuda.current_stream(dev).cuda_stream
 
-    def fps_(self):
-        self._C.check(self.lib.pn2_farthest_point_sample(self.b, N, M, self.xyz.data_ptr(), None, self.fps.data_ptr(),
-                                                         self.stream), "fps")
+    def fps_(self, variant=None):
+        self._C.check(self.lib.pn2_farthest_point_sample_variant(self.fps_variant if variant is None else variant, self.b, N, M,
+                                                                 self.xyz.data_ptr(), None, self.fps.data_ptr(), None,
+                                                                 self.stream), "fps")
 
     def gather_(self):
         self._C.check(self.lib.pn2_gather_point(self.b, N, M, self.xyz.data_ptr(), self.fps.data_ptr(),
@@ -117,9 +120,9 @@ class Stage:
                                                self.grouped.data_ptr(), self.stream), "group")
 
     def fps_gather_(self):
-        self._C.check(self.lib.pn2_farthest_point_sample_gather(self.b, N, M, self.xyz.data_ptr(), None,
-                                                                self.fps.data_ptr(), self.new_xyz.data_ptr(),
-                                                                self.stream), "fps_gather")
+        self._C.check(self.lib.pn2_farthest_point_sample_variant(self.fps_variant, self.b, N, M, self.xyz.data_ptr(), None,
+                                                                 self.fps.data_ptr(), self.new_xyz.data_ptr(),
+                                                                 self.stream), "fps_gather")
 
     def ball_group_(self):
         self._C.check(self.lib.pn2_query_ball_group_xyz(self.b, N, M, self.radius, NS, self.xyz.data_ptr(),
@@ -131,10 +134,10 @@ class Stage:
         # generation-tagged granules (what pointnet2_amd.sample_and_group_xyz does): ws was zeroed once at
         # allocation, every step uses the next tag, so no per-step clear of the workspace
         self.gen += 1
-        self._C.check(self.lib.pn2_sample_and_group_xyz_gen(self.b, N, M, self.radius, NS, self.xyz.data_ptr(),
-                                                            self.ws.data_ptr(), self.gen, self.fps.data_ptr(),
-                                                            self.new_xyz.data_ptr(), self.idx.data_ptr(),
-                                                            self.cnt.data_ptr(), self.grouped.data_ptr(), 1, self.stream),
+        self._C.check(self.lib.pn2_sample_and_group_xyz_ex(self.b, N, M, self.radius, NS, self.xyz.data_ptr(),
+                                                           self.ws.data_ptr(), self.gen, self.fps_variant, self.fps.data_ptr(),
+                                                           self.new_xyz.data_ptr(), self.idx.data_ptr(),
+                                                           self.cnt.data_ptr(), self.grouped.data_ptr(), 1, self.stream),
                       "sample_and_group_xyz")
 
     def status_word(self):
@@ -374,6 +377,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--path", choices=("overlap", "fused", "ops"), default="overlap")
+    ap.add_argument("--fps-variant", choices=("auto", "full", "pruned"), default="auto",
+                    help="FPS tier of every launch (pn2_farthest_point_sample_variant): auto = the library's rule")
     ap.add_argument("--streams", type=int, default=8, help="batches in flight for the extra `concurrent` figure (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -384,6 +389,7 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(respawn(args))
 
+    Stage.fps_variant = {"auto": 0, "full": 1, "pruned": 2}[args.fps_variant]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -484,6 +490,7 @@ def main():
                            "fused": " (2 launches: FPS+gather, ball query+group+centroid subtract)",
                            "ops": " (4 reference-shaped operator launches)"}[args.path],
                        "sharding": "%d independent batch shard(s), no data-path collective" % world,
+                       "fps_variant": args.fps_variant,
                        "requested_gpus": args.gpus},
             "roofline": {"bound": "hbm", "kernel": TIMED_KERNEL[args.path], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
@@ -505,8 +512,15 @@ def main():
                    "query_ball_group_xyz": event_time(stage.ball_group_)}
             kto = event_time(stage.overlap_)
             total_k = sum(kt.values())
+            t_full = event_time(lambda: stage.fps_(1))
+            t_pruned = event_time(lambda: stage.fps_(2))
             line["fps_latency_model"] = {"rounds": M - 1, "ns_per_round": kt["farthest_point_sample"] / (M - 1) * 1e9,
                                          "kernel_us": kt["farthest_point_sample"] * 1e6,
+                                         "tiers": {"full_us": t_full * 1e6, "full_ns_per_round": t_full / (M - 1) * 1e9,
+                                                   "pruned_us": t_pruned * 1e6, "pruned_ns_per_round": t_pruned / (M - 1) * 1e9,
+                                                   "note": "full = every running distance updated every round (fps_body.h); pruned = "
+                                                           "kd-grouped slots, only the groups the new sample can reach are updated "
+                                                           "(fps_pruned_body.h; its kd build is inside the figure); same indices"},
                                          "share_of_step": kt["farthest_point_sample"] / launch_s,
                                          "note": "m-1 dependent rounds of (distance update, block-wide arg-max); "
                                                  "per-round floor analysis in DESIGN.md section 4.1"}

@@ -256,6 +256,22 @@ int pn2_three_interpolate_ex(int b, int m, int c, int n, const float *points, co
  * returns the same indices; tests cover all of them, scripts/ time them. Stateless. */
 int pn2_farthest_point_sample_ex(int T, int P, int b, int n, int m, const float *inp, int *out, void *stream);
 
+/* farthest_point_sample [+ gather_point when out_xyz != NULL] with the TIER chosen by the caller. Every tier returns the
+ * reference's indices (tf_sampling_g.cu:105-170); tests force each one, scripts time them.
+ *   PN2_FPS_AUTO    what pn2_farthest_point_sample does: the pruned tier for 2049..8192 rank slots (512 * ceil(n / 512))
+ *                   and npoint >= 128, the full tier otherwise;
+ *   PN2_FPS_FULL    every point's running distance is updated against every new sample (csrc/fps_body.h);
+ *   PN2_FPS_PRUNED  points dealt to the threads by a kd-tree built in LDS; per round only the groups whose bounding box
+ *                   lies within the current farthest-point distance of the new sample are updated -- exactly the points
+ *                   the reference's min() can change (csrc/fps_pruned_body.h). PN2_E_ARG outside 2049..8192 rank slots. */
+#define PN2_FPS_AUTO 0
+#define PN2_FPS_FULL 1
+#define PN2_FPS_PRUNED 2
+int pn2_farthest_point_sample_variant(int variant, int b, int n, int m, const float *inp, float *temp, int *out,
+                                      float *out_xyz, void *stream);
+/* lab hook: the pruned tier with `gs` rank slots per group (0 = default, 2 or 4) */
+int pn2_farthest_point_sample_pruned_ex(int gs, int b, int n, int m, const float *inp, int *out, void *stream);
+
 /* The whole xyz half of sample_and_group (pointnet_util.py:40-46) in ONE launch, with the ball
  * queries overlapped under the farthest-point-sampling chain: producer workgroups (one per cloud)
  * publish each sample as they select it, consumer workgroups on the other CUs run query j as soon as
@@ -283,6 +299,12 @@ int pn2_sample_and_group_xyz_gen(int b, int n, int m, float radius, int nsample,
  * library never synchronises, so a caller that wants to assert forward progress reads the word after
  * synchronising the stream. */
 long long pn2_sample_and_group_status_offset(int b, int m);
+/* pn2_sample_and_group_xyz[_gen] with the FPS tier of the producer workgroups chosen by the caller (PN2_FPS_AUTO / PN2_FPS_FULL /
+ * PN2_FPS_PRUNED as in pn2_farthest_point_sample_variant; outputs never depend on it). generation 0 = clear `ws` first. */
+int pn2_sample_and_group_xyz_ex(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws, unsigned generation,
+                                int fps_variant, int *fps_idx, float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz,
+                                int subtract_centroid, void *stream);
+
 
 /* ---- one call per level (inference) ---------------------------------------------------------------------
  * pn2_sa_level = pointnet_sa_module (utils/pointnet_util.py:87-154) for max pooling and three layers: the overlapped

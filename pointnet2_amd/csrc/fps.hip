@@ -35,12 +35,8 @@
 // branches and a non-rank-ordered lane arg-max cost more than the skipped distances).
 // Clouds too large for the register tiers fall back to a global-memory tier
 // that keeps the running distances in the caller's `temp` buffer.
-// scripts/build_labs.sh compiles this file against scripts/fps_body_r2_experiments.h (the round body with
-// the rejected round-2 variants behind -DPN2_FPS_* switches) by overriding the header name.
-#ifndef PN2_FPS_BODY_HEADER
-#define PN2_FPS_BODY_HEADER "fps_body.h"
-#endif
-#include PN2_FPS_BODY_HEADER
+#include "fps_body.h"
+#include "fps_pruned_body.h"
 
 #include <limits.h>
 
@@ -52,6 +48,16 @@ __global__ __launch_bounds__(T) void fps_reg_kernel(int n, int m, int Q, const f
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     fps_reg_body<T, P, LDSXYZ, false>(n, m, Q, blockIdx.x, xyz, out, out_xyz, nullptr, smem);
+}
+
+// Pruned tier (fps_pruned_body.h): kd-grouped slots, per-round box tests, only the groups the new sample can reach are
+// updated. 2049..8192 rank slots, chains long enough to pay for the kd build.
+template <int P, int GS>
+__global__ __launch_bounds__(kPrT) void fps_pruned_kernel(int n, int m, int Q, const float *__restrict__ xyz,
+                                                          int *__restrict__ out, float *__restrict__ out_xyz)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    fps_pruned_body<P, GS, false>(n, m, Q, blockIdx.x, xyz, out, out_xyz, nullptr, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -136,6 +142,35 @@ static int launch_reg(int b, int n, int m, int Q, const float *inp, int *out, fl
     return PN2_OK;
 }
 
+template <int P, int GS>
+static int launch_pruned(int b, int n, int m, int Q, const float *inp, int *out, float *oxyz, hipStream_t st)
+{
+    const size_t lds = fps_pruned_lds_bytes(P, kPrW * (P / GS));
+    auto kern = fps_pruned_kernel<P, GS>;
+    if (int rc = allow_dynamic_lds(kern, lds)) return rc;
+    return launch(kern, dim3(b), dim3(kPrT), lds, st, n, m, Q, inp, out, oxyz);
+}
+
+// Does the pruned tier cover this shape, and does it pay? (the kd build costs about as much as fifteen rounds save)
+constexpr int kPrunedMinSamples = 128;
+static bool pruned_covers(int ranks) { return ranks > 2048 && ranks <= 8192; }
+
+// gs = slots per group (0: the default of the slot count)
+static int fps_launch_pruned(int gs, int b, int n, int m, const float *inp, int *out, float *oxyz, hipStream_t st)
+{
+    const int Q = (n + kRefThreads - 1) / kRefThreads;
+    const int ranks = kRefThreads * Q;
+    if (!pruned_covers(ranks)) return PN2_E_ARG;
+    if (ranks <= 4096) {
+        if (gs == 0 || gs == 2) return launch_pruned<16, 2>(b, n, m, Q, inp, out, oxyz, st);
+        if (gs == 4) return launch_pruned<16, 4>(b, n, m, Q, inp, out, oxyz, st);
+        return PN2_E_ARG;
+    }
+    if (gs == 0 || gs == 4) return launch_pruned<32, 4>(b, n, m, Q, inp, out, oxyz, st);
+    if (gs == 2) return launch_pruned<32, 2>(b, n, m, Q, inp, out, oxyz, st);
+    return PN2_E_ARG;
+}
+
 constexpr int kMaxLdsSlots = 8192;     // 256 B + 16 B per rank slot <= 160 KiB
 constexpr int kMaxRegPoints = 16384;
 
@@ -181,7 +216,8 @@ extern "C" long long pn2_fps_temp_floats(int b, int n)
     return n > pn2::kMaxRegPoints ? (long long)b * n : 0;
 }
 
-static int fps_entry(int b, int n, int m, const float *inp, float *temp, int *out, float *out_xyz, void *stream)
+static int fps_entry(int b, int n, int m, const float *inp, float *temp, int *out, float *out_xyz, void *stream,
+                     int variant = PN2_FPS_AUTO)
 {
     using namespace pn2;
     if (m <= 0 || b == 0) return PN2_OK;          // tf_sampling_g.cu:106
@@ -196,6 +232,8 @@ static int fps_entry(int b, int n, int m, const float *inp, float *temp, int *ou
     }
     const int Q = (n + kRefThreads - 1) / kRefThreads;
     const int ranks = kRefThreads * Q;
+    if (variant == PN2_FPS_PRUNED || (variant == PN2_FPS_AUTO && pruned_covers(ranks) && m >= kPrunedMinSamples))
+        return fps_launch_pruned(0, b, n, m, inp, out, out_xyz, st);
     // default geometry (measured, scripts/fps_prod_lab.hip, ns per round at n = 1024/2048/4096/8192):
     // 256 threads with the packed distance update 273/312/402/585, 512 threads (scalar) 288/326/393/552
     const int T = ranks <= 2048 ? 256 : 512;
@@ -213,6 +251,23 @@ extern "C" int pn2_farthest_point_sample_gather(int b, int n, int m, const float
 {
     if (m > 0 && b > 0 && !out_xyz) return PN2_E_NULL;
     return fps_entry(b, n, m, inp, temp, out, out_xyz, stream);
+}
+
+// Same operator with the tier chosen by the caller (tests, A/B timing; results never depend on it): PN2_FPS_AUTO = the
+// size rule of pn2_farthest_point_sample, PN2_FPS_FULL = every point updated every round (fps_reg_body), PN2_FPS_PRUNED =
+// the kd-grouped tier (PN2_E_ARG outside 2049..8192 rank slots). out_xyz may be NULL.
+extern "C" int pn2_farthest_point_sample_variant(int variant, int b, int n, int m, const float *inp, float *temp, int *out,
+                                                 float *out_xyz, void *stream)
+{
+    if (variant < PN2_FPS_AUTO || variant > PN2_FPS_PRUNED) return PN2_E_ARG;
+    return fps_entry(b, n, m, inp, temp, out, out_xyz, stream, variant);
+}
+
+// lab hook: the pruned tier with an explicit group size (slots per group: 2 or 4)
+extern "C" int pn2_farthest_point_sample_pruned_ex(int gs, int b, int n, int m, const float *inp, int *out, void *stream)
+{
+    if (m <= 0 || b <= 0 || n <= 0 || !inp || !out) return PN2_E_ARG;
+    return pn2::fps_launch_pruned(gs, b, n, m, inp, out, nullptr, pn2::as_stream(stream));
 }
 
 // tuning / test hook: run the register tier with an explicit geometry

@@ -90,8 +90,8 @@ __device__ __forceinline__ void fps_gather_epilogue(int m, const float *__restri
 // ---------------------------------------------------------------------------
 // Packed fp32 (VOP3P v_pk_*_f32: two IEEE fp32 operations per lane and instruction, each rounded
 // exactly like its scalar twin). The distance update is the VALU-throughput part of a round and packs
-// perfectly: two slots per instruction, the selected point broadcast from one half of a register pair
-// (op_sel), its negation folded into the add (neg_lo/neg_hi; a + (-s) == a - s bit for bit).
+// perfectly: two slots per instruction, the selected point broadcast from the LOW half of a register pair
+// (op_sel_hi:[1,0]), its negation folded into the add (neg_lo/neg_hi; a + (-s) == a - s bit for bit).
 // Measured (scripts/ubench_pk.hip, 2 waves per SIMD): 3.76 cycles per v_pk op vs 3.26 per scalar op,
 // i.e. 1.7x the fp32 rate. hipcc's own SLP packing of the scalar code was slower (-fno-slp-vectorize):
 // it assembles the pairs with extra moves on the critical path; here the slots LIVE as pairs.
@@ -107,12 +107,14 @@ __device__ __forceinline__ pn2_f2 pk_sub_bcast_lo(pn2_f2 a, pn2_f2 s)   // a - s
     return r;
 }
 
-__device__ __forceinline__ pn2_f2 pk_sub_bcast_hi(pn2_f2 a, pn2_f2 s)   // a - s.y in both halves
-{
-    pn2_f2 r;
-    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(s));
-    return r;
-}
+// There is deliberately NO "broadcast the HIGH half" twin (op_sel:[0,1] op_sel_hi:[1,1]). Round 5 found that form returning
+// wrong values whenever a wave of ANOTHER kernel issues MFMAs on the same SIMD (scripts/pk_hazard_lab.hip: 2e5 of 1.3e9
+// lanes disagree with the scalar evaluation beside a v_mfma_f32_32x32x16_bf16 loop, none alone, none beside a VALU loop, no
+// number of wait states helps; the low-half form, with or without the neg modifiers, and hipcc's own packed code -- which
+// only ever emits the low-half form -- are exact in all three situations). Rounds 1-4 used it for the y coordinate: every
+// packed FPS variant (256 and 1024 threads) picked different samples beside the fused MLP kernels -- the "flaky result
+// under two-stream use" of profiles/r04/geometry_prefetch_experiment.txt; tests/test_multistream_gpu.py now covers it.
+// The selected point therefore lives in THREE register pairs with the coordinate in the low half.
 
 __device__ __forceinline__ pn2_f2 pk_mul(pn2_f2 a, pn2_f2 b)
 {
@@ -178,7 +180,7 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
     }
     __syncthreads();
 
-    pn2_f2 sxy = {0.f, 0.f}, szk = {0.f, 0.f};         // the selected point as two register pairs (packed path)
+    pn2_f2 sxy = {0.f, 0.f}, syy = {0.f, 0.f}, szk = {0.f, 0.f};   // the selected point, each coordinate in the LOW half of a pair (packed path)
     float sx, sy, sz;                                  // the point selected last (starts at k = 0 = rank 0)
     if (LDSXYZ) {
         const float4 s = lds_rank[NS - 1];
@@ -186,7 +188,7 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
     } else {
         sx = src[0]; sy = src[1]; sz = src[2];
     }
-    sxy.x = sx; sxy.y = sy; szk.x = sz;
+    sxy.x = sx; sxy.y = sy; syy.x = sy; szk.x = sz;
     if (t == 0) {
         dst[0] = 0;                                    // tf_sampling_g.cu:114-116
         if (PUBLISH) __hip_atomic_store(gtag, (unsigned long long)tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -207,7 +209,7 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
 #pragma unroll
             for (int h = 0; h < PH; ++h) dx[h] = pk_sub_bcast_lo(xx[h], sxy);
 #pragma unroll
-            for (int h = 0; h < PH; ++h) dy[h] = pk_sub_bcast_hi(yy[h], sxy);
+            for (int h = 0; h < PH; ++h) dy[h] = pk_sub_bcast_lo(yy[h], syy);
 #pragma unroll
             for (int h = 0; h < PH; ++h) dz[h] = pk_sub_bcast_lo(zz[h], szk);
 #pragma unroll
@@ -276,12 +278,12 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
         if (LDSXYZ) {
             const float4 s = lds_rank[win];            // same address in every lane: LDS broadcast
             sx = s.x; sy = s.y; sz = s.z;
-            sxy.x = s.x; sxy.y = s.y; szk.x = s.z; szk.y = s.w;
+            sxy.x = s.x; sxy.y = s.y; syy.x = s.y; szk.x = s.z; szk.y = s.w;
             k = __float_as_int(s.w);
         } else {
             k = lds_k[win];
             sx = src[(size_t)k * 3 + 0]; sy = src[(size_t)k * 3 + 1]; sz = src[(size_t)k * 3 + 2];
-            sxy.x = sx; sxy.y = sy; szk.x = sz;
+            sxy.x = sx; sxy.y = sy; syy.x = sy; szk.x = sz;
         }
         if (t == 0) {
             dst[j] = k;

@@ -39,6 +39,7 @@
 // counter's memory channel, i.e. the producers end up bunched on one XCD). Not shipped.
 #include "ball_query_body.h"
 #include "fps_body.h"
+#include "fps_pruned_body.h"
 
 #include <limits.h>
 
@@ -51,7 +52,9 @@ constexpr size_t kFusedMinLds = 82 * 1024;      // > 160 KiB / 2: one workgroup 
 
 // LPQ: lanes per query of the cell-list consumers; 0 = sweep consumers (clouds whose cell list does not fit
 // beside the position table: n > ~6000).
-template <int P, int LPQ>
+// PRUNED: the producers run the kd-grouped chain of fps_pruned_body.h (4096 / 8192 rank slots: P = 8, 16) on four waves.
+constexpr int fused_pruned_gs(int P) { return P == 8 ? 2 : 4; }       // slots per group at 16 / 32 slots per thread
+template <int P, int LPQ, bool PRUNED = false>
 __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, int m, int Q, int nsample, float thr,
                                                                  float radius, int qpb, unsigned tag,
                                                                  const float *__restrict__ xyz,
@@ -75,7 +78,10 @@ __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, i
         // at n = 1024, 312 vs 326 at 2048: a smaller block-wide arg-max; profiles/r02/fps_experiments.txt), which is what
         // pn2_farthest_point_sample launches at these sizes: the upper four waves of a producer retire at once
         // (a retired wave no longer counts at the workgroup's barriers).
-        if (kFusedThreads * P <= 2048) {
+        if constexpr (PRUNED) {
+            if (threadIdx.x >= kPrT) return;
+            fps_pruned_body<2 * P, fused_pruned_gs(P), PN2_FUSED_LAB_PUBLISH>(n, m, Q, blk, xyz, fps_idx, nullptr, tagged, smem, tag);
+        } else if constexpr (kFusedThreads * P <= 2048) {
             if (threadIdx.x >= kFusedThreads / 2) return;
             fps_reg_body<kFusedThreads / 2, 2 * P, true, PN2_FUSED_LAB_PUBLISH>(n, m, Q, blk, xyz, fps_idx, nullptr, tagged, smem, tag);
         } else {
@@ -120,7 +126,7 @@ static size_t fused_cells_lds(int n, int nsample, int lpq)
     return cells > sweep ? cells : sweep;
 }
 
-template <int P, int LPQ>
+template <int P, int LPQ, bool PRUNED = false>
 static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, float radius, unsigned tag, const float *xyz,
                         unsigned long long *ws, int *fps_idx, float *new_xyz, int *idx, int *pts_cnt,
                         float *grouped, int subtract, hipStream_t st)
@@ -130,13 +136,14 @@ static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, floa
     int qpb = 64;
     if (qpb > m) qpb = ((m + kGran - 1) / kGran) * kGran;
     const int nq = (m + qpb - 1) / qpb;
-    size_t lds_f = 256 + sizeof(float4) * (size_t)kFusedThreads * P;
+    size_t lds_f = PRUNED ? fps_pruned_lds_bytes(2 * P, kPrW * (2 * P / fused_pruned_gs(P)))
+                          : 256 + sizeof(float4) * (size_t)kFusedThreads * P;
     size_t lds_q = LPQ ? fused_cells_lds(n, nsample, LPQ)
                        : sizeof(float4) * (size_t)((n + 127) & ~127) + sizeof(int) * (size_t)nsample * kGran;
     size_t lds = lds_f > lds_q ? lds_f : lds_q;
     if (lds < kFusedMinLds) lds = kFusedMinLds;
     if (lds > 160 * 1024) return PN2_E_TOO_LARGE;
-    auto kern = sa_fused_kernel<P, LPQ>;
+    auto kern = sa_fused_kernel<P, LPQ, PRUNED>;
     if (int rc = allow_dynamic_lds(kern, lds)) return rc;
     {
         // residency (header): room for every producer plus at least one consumer at the same time
@@ -165,7 +172,7 @@ extern "C" long long pn2_sample_and_group_ws_bytes(int b, int m)
 
 static int sample_and_group_common(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws, unsigned tag,
                                    int *fps_idx, float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz,
-                                   int subtract_centroid, void *stream)
+                                   int subtract_centroid, void *stream, int fps_variant = PN2_FPS_AUTO)
 {
     using namespace pn2;
     if (!(radius > 0.0f) || nsample <= 0 || m <= 0) return PN2_E_ARG;
@@ -187,12 +194,18 @@ static int sample_and_group_common(int b, int n, int m, float radius, int nsampl
     if (n >= 1024)
         for (int cand : {8, 16, 32})
             if (fused_cells_lds(n, nsample, cand) <= 160 * 1024) { lpq = cand; break; }
-#define PN2_FUSED_CASE(PP, LL)                                                                                         \
-    if (P == PP && lpq == LL)                                                                                          \
-        return launch_fused<PP, LL>(b, n, m, Q, nsample, thr, radius, tag, xyz, w, fps_idx, new_xyz, idx, pts_cnt,       \
-                                    grouped_xyz, subtract_centroid, st)
-#define PN2_FUSED_P(PP) PN2_FUSED_CASE(PP, 0); PN2_FUSED_CASE(PP, 8); PN2_FUSED_CASE(PP, 16); PN2_FUSED_CASE(PP, 32)
-    PN2_FUSED_P(1); PN2_FUSED_P(2); PN2_FUSED_P(4); PN2_FUSED_P(8); PN2_FUSED_P(16);
+    // producers: the kd-grouped chain where it exists (4096 / 8192 rank slots) and the chain is long enough to pay for the
+    // kd build (the rule of pn2_farthest_point_sample, fps.hip)
+    if (fps_variant < PN2_FPS_AUTO || fps_variant > PN2_FPS_PRUNED) return PN2_E_ARG;
+    if (fps_variant == PN2_FPS_PRUNED && P != 8 && P != 16) return PN2_E_ARG;
+    const bool pruned = fps_variant == PN2_FPS_PRUNED || (fps_variant == PN2_FPS_AUTO && (P == 8 || P == 16) && m >= 128);
+#define PN2_FUSED_CASE(PP, LL, PR)                                                                                     \
+    if (P == PP && lpq == LL && pruned == PR)                                                                          \
+        return launch_fused<PP, LL, PR>(b, n, m, Q, nsample, thr, radius, tag, xyz, w, fps_idx, new_xyz, idx, pts_cnt,   \
+                                        grouped_xyz, subtract_centroid, st)
+#define PN2_FUSED_P(PP, PR) PN2_FUSED_CASE(PP, 0, PR); PN2_FUSED_CASE(PP, 8, PR); PN2_FUSED_CASE(PP, 16, PR); PN2_FUSED_CASE(PP, 32, PR)
+    PN2_FUSED_P(1, false); PN2_FUSED_P(2, false); PN2_FUSED_P(4, false); PN2_FUSED_P(8, false); PN2_FUSED_P(16, false);
+    PN2_FUSED_P(8, true); PN2_FUSED_P(16, true);
 #undef PN2_FUSED_P
 #undef PN2_FUSED_CASE
     return PN2_E_TOO_LARGE;
@@ -217,6 +230,16 @@ extern "C" int pn2_sample_and_group_xyz_gen(int b, int n, int m, float radius, i
     if (generation == 0u) return PN2_E_ARG;
     return sample_and_group_common(b, n, m, radius, nsample, xyz, ws, generation, fps_idx, new_xyz, idx, pts_cnt,
                                    grouped_xyz, subtract_centroid, stream);
+}
+
+// The same launch with the FPS tier of the producers chosen by the caller (PN2_FPS_AUTO / _FULL / _PRUNED, see
+// pn2_farthest_point_sample_variant; PN2_E_ARG for _PRUNED outside 2049..8192 rank slots). generation 0 = clear `ws` first.
+extern "C" int pn2_sample_and_group_xyz_ex(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,
+                                           unsigned generation, int fps_variant, int *fps_idx, float *new_xyz, int *idx,
+                                           int *pts_cnt, float *grouped_xyz, int subtract_centroid, void *stream)
+{
+    return sample_and_group_common(b, n, m, radius, nsample, xyz, ws, generation, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz,
+                                   subtract_centroid, stream, fps_variant);
 }
 
 // Offset (bytes) of the launch status word inside `ws`: 0 = ok, 1 = a consumer gave up waiting for its

@@ -89,6 +89,18 @@ def gather_point(inp, idx, out=None):
     return _GatherPoint.apply(inp, idx)
 
 
+# Tier of the farthest-point-sampling kernels, passed with every call (pn2_farthest_point_sample_variant): 0 = the
+# library's size rule, 1 = every point updated every round (csrc/fps_body.h), 2 = kd-grouped slots with exact box pruning
+# (csrc/fps_pruned_body.h; 2049..8192 rank slots only). Results never depend on it: the tests force every tier.
+FPS_AUTO, FPS_FULL, FPS_PRUNED = 0, 1, 2
+_FPS_VARIANT = [FPS_AUTO]
+
+
+def set_fps_variant(variant=FPS_AUTO):
+    require(int(variant) in (FPS_AUTO, FPS_FULL, FPS_PRUNED), "fps variant must be 0 (auto), 1 (full) or 2 (pruned)")
+    _FPS_VARIANT[0] = int(variant)
+
+
 def farthest_point_sample_gather(npoint, inp):
     """Fused farthest_point_sample + gather_point (pointnet_util.py:40 in one launch).
 
@@ -109,8 +121,12 @@ def farthest_point_sample_gather(npoint, inp):
     tf = lib.pn2_fps_temp_floats(b, n)
     temp = torch.empty((tf,), dtype=torch.float32, device=dev) if tf > 0 else None
     with on_device(dev):
-        _C.check(lib.pn2_farthest_point_sample_gather(b, n, m, ptr(inp), ptr(temp), ptr(out), ptr(new_xyz),
-                                                      stream_ptr(dev)), "farthest_point_sample_gather")
+        if _FPS_VARIANT[0]:
+            _C.check(lib.pn2_farthest_point_sample_variant(_FPS_VARIANT[0], b, n, m, ptr(inp), ptr(temp), ptr(out), ptr(new_xyz),
+                                                           stream_ptr(dev)), "farthest_point_sample_gather")
+        else:
+            _C.check(lib.pn2_farthest_point_sample_gather(b, n, m, ptr(inp), ptr(temp), ptr(out), ptr(new_xyz),
+                                                          stream_ptr(dev)), "farthest_point_sample_gather")
     return out, new_xyz
 
 
@@ -133,6 +149,10 @@ def farthest_point_sample(npoint, inp, out=None):
     tf = lib.pn2_fps_temp_floats(b, n)
     temp = torch.empty((tf,), dtype=torch.float32, device=dev) if tf > 0 else None   # allocate_temp, tf_sampling.cpp:115
     with on_device(dev):
-        _C.check(lib.pn2_farthest_point_sample(b, n, m, ptr(inp), ptr(temp), ptr(out), stream_ptr(dev)),
-                 "farthest_point_sample")
+        if _FPS_VARIANT[0]:
+            _C.check(lib.pn2_farthest_point_sample_variant(_FPS_VARIANT[0], b, n, m, ptr(inp), ptr(temp), ptr(out), None,
+                                                           stream_ptr(dev)), "farthest_point_sample")
+        else:
+            _C.check(lib.pn2_farthest_point_sample(b, n, m, ptr(inp), ptr(temp), ptr(out), stream_ptr(dev)),
+                     "farthest_point_sample")
     return out

@@ -1,23 +1,18 @@
 #!/bin/bash
-# Builds the FPS lab binaries (scripts/fps_prod_lab.hip = the product kernel under -DPN2_FPS_* switches) into
-# build_lab/ so that one gpurun call can A/B them. Development aid.
+# Builds the FPS lab binaries into build_lab/ so that one gpurun call can A/B them. Development aid.
+#   fps_product          scripts/fps_prod_lab.hip: the product FPS kernels (fps.hip included verbatim), every (T, P) geometry
+#   fps_pruned_lab       scripts/fps_pruned_lab.hip: pruned tier against the full tiers, ns per round, kd build cost
+#   fps_concurrency_lab  scripts/fps_concurrency_lab.hip: FPS beside synthetic neighbours (VALU, LDS, VGPR, MFMA, memory)
+#   pk_hazard_lab        scripts/pk_hazard_lab.hip: v_pk_*_f32 operand forms beside an MFMA kernel
+# (The rejected round-2 variants of the round body -- 32-bit DPP ladder, barrier-free exchange, runner-up speculation -- were
+# removed from the tree in round 5; their measurements are profiles/r02/fps_experiments.txt and profiles/r03/DESIGN_round3.md.)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$ROOT/build_lab"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -munsafe-fp-atomics"
-build() { # name, extra flags
-    local name=$1; shift
-    hipcc $FLAGS "$@" "$ROOT/scripts/fps_prod_lab.hip" -o "$ROOT/build_lab/fps_$name" &
-}
-EXP='-DPN2_FPS_BODY_HEADER="../../scripts/fps_body_r2_experiments.h"'
-build product                                   # pointnet2_amd/csrc/fps_body.h as shipped
-build base $EXP
-build bcast $EXP -DPN2_FPS_BCAST_FULL=1
-build w32 $EXP -DPN2_FPS_WAVE32=1
-build w32nonop $EXP -DPN2_FPS_WAVE32=1 -DPN2_FPS_W32_NOP=0
-build poll $EXP -DPN2_FPS_POLL=1
-build late $EXP -DPN2_FPS_LATE_STORE=1
-build diag $EXP -DPN2_FPS_DIAG=1
-build diag_bcast_p512 $EXP -DPN2_FPS_DIAG=1 -DPN2_FPS_BCAST_FULL=1 -DPN2_FPS_PACK_512=1
+hipcc $FLAGS "$@" "$ROOT/scripts/fps_prod_lab.hip" -o "$ROOT/build_lab/fps_product" &
+hipcc $FLAGS "$@" "$ROOT/scripts/fps_pruned_lab.hip" -o "$ROOT/build_lab/fps_pruned_lab" &
+hipcc $FLAGS "$@" "$ROOT/scripts/fps_concurrency_lab.hip" -o "$ROOT/build_lab/fps_concurrency_lab" &
+hipcc $FLAGS "$@" "$ROOT/scripts/pk_hazard_lab.hip" -o "$ROOT/build_lab/pk_hazard_lab" &
 wait
 ls -la "$ROOT/build_lab"

@@ -1,0 +1,70 @@
+// fps_pruned_lab.hip -- A/B of the pruned FPS tier (csrc/fps_pruned_body.h) against the full tiers, product code included
+// verbatim. Prints ns per round, the kd build's cost (a launch with m = 1 runs the build and no round) and whether the
+// indices agree. Development aid (scripts/build_labs.sh builds it into build_lab/fps_pruned_lab).
+#include "../pointnet2_amd/csrc/fps.hip"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+static float timed(int reps, const std::function<void()> &fn)
+{
+    fn();
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r) fn();
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3f / reps;   // us
+}
+
+int main(int argc, char **argv)
+{
+    const int b = 32;
+    for (int n : {4096, 8192, 3000}) {
+        for (int kind = 0; kind < 2; ++kind) {
+            const int m = n == 3000 ? 750 : 1024;
+            std::vector<float> h((size_t)b * n * 3);
+            uint32_t s = 12345u + kind;
+            auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
+            for (size_t i = 0; i < h.size(); i += 3) {
+                float x = rnd(), y = rnd(), z = rnd();
+                if (kind == 1) {           // sphere surface, radius 0.9 .. 1.0
+                    x = 2 * x - 1; y = 2 * y - 1; z = 2 * z - 1;
+                    const float r = sqrtf(x * x + y * y + z * z) + 1e-9f, q = (0.9f + 0.1f * rnd()) / r;
+                    x *= q; y *= q; z *= q;
+                }
+                h[i] = x; h[i + 1] = y; h[i + 2] = z;
+            }
+            float *d_xyz; int *d_out;
+            CK(hipMalloc(&d_xyz, h.size() * 4)); CK(hipMalloc(&d_out, (size_t)b * m * 4));
+            CK(hipMemcpy(d_xyz, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+            std::vector<int> ref((size_t)b * m), got((size_t)b * m);
+            const int P512 = n <= 4096 ? 8 : 16, P256 = 2 * P512;
+            struct V { const char *name; std::function<int(int)> run; };
+            std::vector<V> vs = {
+                {"full 512", [&](int mm) { return pn2_farthest_point_sample_ex(512, P512, b, n, mm, d_xyz, d_out, nullptr); }},
+                {"full 256", [&](int mm) { return pn2_farthest_point_sample_ex(256, P256, b, n, mm, d_xyz, d_out, nullptr); }},
+                {"pruned gs2", [&](int mm) { return pn2_farthest_point_sample_pruned_ex(2, b, n, mm, d_xyz, d_out, nullptr); }},
+                {"pruned gs4", [&](int mm) { return pn2_farthest_point_sample_pruned_ex(4, b, n, mm, d_xyz, d_out, nullptr); }},
+            };
+            for (size_t vi = 0; vi < vs.size(); ++vi) {
+                CK(hipMemset(d_out, 0xff, (size_t)b * m * 4));
+                if (int rc = vs[vi].run(m)) { printf("%-10s n=%5d %s : launch refused (%d)\n", vs[vi].name, n, kind ? "sphere" : "cube  ", rc); continue; }
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(got.data(), d_out, got.size() * 4, hipMemcpyDeviceToHost));
+                if (vi == 0) ref = got;
+                const float us = timed(5, [&]() { vs[vi].run(m); });
+                const float us1 = timed(5, [&]() { vs[vi].run(1); });
+                const float us_half = timed(5, [&]() { vs[vi].run(m / 2); });
+                printf("%-10s n=%5d %s m=%4d : %7.1f us, prologue (m=1) %6.1f us, %6.1f ns/round overall, %6.1f ns/round in the second half  %s\n",
+                       vs[vi].name, n, kind ? "sphere" : "cube  ", m, us, us1, (us - us1) * 1e3f / (m - 1), (us - us_half) * 1e3f / (m - m / 2),
+                       got == ref ? "same" : "DIFF");
+            }
+            CK(hipFree(d_xyz)); CK(hipFree(d_out));
+        }
+    }
+    return 0;
+}

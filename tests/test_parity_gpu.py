@@ -97,6 +97,72 @@ def test_fps_all_geometries_agree(cuda, oracle):
             assert np.array_equal(host(out), want), (T, Pp)
 
 
+# The pruned tier (csrc/fps_pruned_body.h): kd-grouped slots, only the groups the new sample can reach are updated. Same
+# indices as the oracle on every kind of cloud -- the ones it prunes well (sphere, cube), the ones it cannot prune
+# (identical points, 87 % of the cloud on one spot), exact ties everywhere (lattice, duplicates), clouds that leave padding
+# slots (n not a multiple of 512, n just above a tier boundary), m > n, and both group sizes of both slot counts.
+PRUNED_CASES = [
+    ("sphere4096", lambda: S.sphere_clouds(4, 4096, 200), 1024, 0),
+    ("cube4096", lambda: S.uniform_clouds(3, 4096, 201), 512, 0),
+    ("sphere4096_gs4", lambda: S.sphere_clouds(2, 4096, 202), 700, 4),
+    ("dup4096", lambda: S.duplicated_clouds(3, 4096, 203), 1024, 0),
+    ("drop4096", lambda: S.dropout_clouds(3, 4096, 204), 600, 0),
+    ("same3000", lambda: S.identical_clouds(2, 3000, 205), 200, 0),
+    ("lattice4000", lambda: S.lattice_clouds(3, 4000, 206), 1500, 0),
+    ("lattice4096_gs4", lambda: S.lattice_clouds(2, 4096, 207), 900, 4),
+    ("n2049", lambda: S.sphere_clouds(2, 2049, 208), 300, 0),
+    ("n3100", lambda: S.uniform_clouds(2, 3100, 209), 3100, 0),       # every point sampled
+    ("n2500_m_gt_n", lambda: S.duplicated_clouds(2, 2500, 210), 2600, 0),
+    ("cube8192", lambda: S.uniform_clouds(2, 8192, 211), 1024, 0),    # sem_seg SA1: 32 slots per thread
+    ("cube8192_gs2", lambda: S.uniform_clouds(2, 8192, 212), 600, 2),
+    ("sphere5000", lambda: S.sphere_clouds(2, 5000, 213), 777, 0),
+    ("dup8000_gs2", lambda: S.duplicated_clouds(2, 8000, 214), 1000, 2),
+    ("lattice6000", lambda: S.lattice_clouds(2, 6000, 215), 2000, 0),
+    ("flat4096", lambda: S.sphere_clouds(2, 4096, 216) * np.array([1.0, 1.0, 0.0], np.float32), 512, 0),   # a degenerate axis
+    ("line4096", lambda: S.sphere_clouds(2, 4096, 217) * np.array([1.0, 0.0, 0.0], np.float32), 300, 0),
+    ("far_offset", lambda: S.sphere_clouds(2, 4096, 218) * np.float32(1e-3) + np.float32(100.0), 400, 0),  # coarse fp32 grid
+    ("tiny_scale", lambda: S.sphere_clouds(2, 4096, 219) * np.float32(1e-18), 300, 0),                      # squares underflow
+]
+
+
+@pytest.mark.parametrize("name,make,m,gs", PRUNED_CASES, ids=[c[0] for c in PRUNED_CASES])
+def test_fps_pruned_tier_index_exact(cuda, oracle, name, make, m, gs):
+    from pointnet2_amd import _C
+    xyz = np.ascontiguousarray(make(), dtype=np.float32)
+    b, n, _ = xyz.shape
+    want = oracle.farthest_point_sample(m, xyz)
+    x = dev(xyz, cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    for rep in range(2):                                             # the kd build's tickets are timing dependent; results are not
+        out = torch.full((b, m), -1, dtype=torch.int32, device=cuda)
+        rc = _C.lib().pn2_farthest_point_sample_pruned_ex(gs, b, n, m, x.data_ptr(), out.data_ptr(), st)
+        assert rc == 0, rc
+        got = host(out)
+        assert np.array_equal(got, want), "%s rep %d: first mismatch at %s" % (name, rep, np.argwhere(got != want)[:3])
+    # the same through the operator with the tier forced, incl. the fused gather
+    import pointnet2_amd as P
+    from pointnet2_amd import tf_sampling
+    for variant in (tf_sampling.FPS_PRUNED, tf_sampling.FPS_FULL, tf_sampling.FPS_AUTO):
+        tf_sampling.set_fps_variant(variant)
+        try:
+            idx, new_xyz = P.farthest_point_sample_gather(m, x)
+            assert np.array_equal(host(P.farthest_point_sample(m, x)), want), variant
+        finally:
+            tf_sampling.set_fps_variant(tf_sampling.FPS_AUTO)
+        assert np.array_equal(host(idx), want), variant
+        assert np.array_equal(host(new_xyz), oracle.gather_point(xyz, want)), variant
+
+
+def test_fps_pruned_tier_refuses_other_sizes(cuda):
+    from pointnet2_amd import _C
+    st = torch.cuda.current_stream().cuda_stream
+    for n in (64, 2048, 8193, 20000):
+        x = torch.rand((1, n, 3), device=cuda)
+        out = torch.zeros((1, 8), dtype=torch.int32, device=cuda)
+        assert _C.lib().pn2_farthest_point_sample_pruned_ex(0, 1, n, 8, x.data_ptr(), out.data_ptr(), st) == -3
+        assert _C.lib().pn2_farthest_point_sample_variant(2, 1, n, 8, x.data_ptr(), None, out.data_ptr(), None, st) == -3 or n > 16384
+
+
 def test_fps_gather_fused(cuda, oracle):
     import pointnet2_amd as P
     for xyz, m in [(S.duplicated_clouds(3, 1024, 22), 256), (S.uniform_clouds(2, 12000, 23), 40),
