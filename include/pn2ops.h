@@ -258,8 +258,8 @@ int pn2_farthest_point_sample_ex(int T, int P, int b, int n, int m, const float 
 
 /* farthest_point_sample [+ gather_point when out_xyz != NULL] with the TIER chosen by the caller. Every tier returns the
  * reference's indices (tf_sampling_g.cu:105-170); tests force each one, scripts time them.
- *   PN2_FPS_AUTO    what pn2_farthest_point_sample does: the pruned tier for 2049..8192 rank slots (512 * ceil(n / 512))
- *                   and npoint >= 128, the full tier otherwise;
+ *   PN2_FPS_AUTO    what pn2_farthest_point_sample does: the pruned tier where it measured faster (rank slots =
+ *                   512 * ceil(n / 512): 2049..4096 with npoint >= 768, 4097..8192 with npoint >= 128), the full tier otherwise;
  *   PN2_FPS_FULL    every point's running distance is updated against every new sample (csrc/fps_body.h);
  *   PN2_FPS_PRUNED  points dealt to the threads by a kd-tree built in LDS; per round only the groups whose bounding box
  *                   lies within the current farthest-point distance of the new sample are updated -- exactly the points
@@ -269,8 +269,6 @@ int pn2_farthest_point_sample_ex(int T, int P, int b, int n, int m, const float 
 #define PN2_FPS_PRUNED 2
 int pn2_farthest_point_sample_variant(int variant, int b, int n, int m, const float *inp, float *temp, int *out,
                                       float *out_xyz, void *stream);
-/* lab hook: the pruned tier with `gs` rank slots per group (0 = default, 2 or 4) */
-int pn2_farthest_point_sample_pruned_ex(int gs, int b, int n, int m, const float *inp, int *out, void *stream);
 
 /* The whole xyz half of sample_and_group (pointnet_util.py:40-46) in ONE launch, with the ball
  * queries overlapped under the farthest-point-sampling chain: producer workgroups (one per cloud)

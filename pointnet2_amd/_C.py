@@ -69,7 +69,6 @@ _SIGNATURES = {
     "pn2_version": [],
     "pn2_farthest_point_sample_ex": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "pn2_farthest_point_sample_variant": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
-    "pn2_farthest_point_sample_pruned_ex": [_i, _i, _i, _i, _vp, _vp, _vp],
     "pn2_query_ball_group_xyz_ex": [_i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "pn2_query_ball_group_xyz_msg": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "pn2_sa_level": [_i, _i, _i, _f, _i, _i, _vp, _vp, _vp, ctypes.c_uint, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -145,30 +145,22 @@ static int launch_reg(int b, int n, int m, int Q, const float *inp, int *out, fl
 template <int P, int GS>
 static int launch_pruned(int b, int n, int m, int Q, const float *inp, int *out, float *oxyz, hipStream_t st)
 {
-    const size_t lds = fps_pruned_lds_bytes(P, kPrW * (P / GS));
+    const size_t lds = fps_pruned_lds_bytes(P);
     auto kern = fps_pruned_kernel<P, GS>;
     if (int rc = allow_dynamic_lds(kern, lds)) return rc;
     return launch(kern, dim3(b), dim3(kPrT), lds, st, n, m, Q, inp, out, oxyz);
 }
 
-// Does the pruned tier cover this shape, and does it pay? (the kd build costs about as much as fifteen rounds save)
-constexpr int kPrunedMinSamples = 128;
 static bool pruned_covers(int ranks) { return ranks > 2048 && ranks <= 8192; }
 
-// gs = slots per group (0: the default of the slot count)
-static int fps_launch_pruned(int gs, int b, int n, int m, const float *inp, int *out, float *oxyz, hipStream_t st)
+static int fps_launch_pruned(int b, int n, int m, const float *inp, int *out, float *oxyz, hipStream_t st)
 {
     const int Q = (n + kRefThreads - 1) / kRefThreads;
     const int ranks = kRefThreads * Q;
     if (!pruned_covers(ranks)) return PN2_E_ARG;
-    if (ranks <= 4096) {
-        if (gs == 0 || gs == 2) return launch_pruned<16, 2>(b, n, m, Q, inp, out, oxyz, st);
-        if (gs == 4) return launch_pruned<16, 4>(b, n, m, Q, inp, out, oxyz, st);
-        return PN2_E_ARG;
-    }
-    if (gs == 0 || gs == 4) return launch_pruned<32, 4>(b, n, m, Q, inp, out, oxyz, st);
-    if (gs == 2) return launch_pruned<32, 2>(b, n, m, Q, inp, out, oxyz, st);
-    return PN2_E_ARG;
+    // 32 groups either way: 16 slots per thread in groups of 2, 32 in groups of 4
+    if (ranks <= 4096) return launch_pruned<16, 2>(b, n, m, Q, inp, out, oxyz, st);
+    return launch_pruned<32, 4>(b, n, m, Q, inp, out, oxyz, st);
 }
 
 constexpr int kMaxLdsSlots = 8192;     // 256 B + 16 B per rank slot <= 160 KiB
@@ -232,8 +224,8 @@ static int fps_entry(int b, int n, int m, const float *inp, float *temp, int *ou
     }
     const int Q = (n + kRefThreads - 1) / kRefThreads;
     const int ranks = kRefThreads * Q;
-    if (variant == PN2_FPS_PRUNED || (variant == PN2_FPS_AUTO && pruned_covers(ranks) && m >= kPrunedMinSamples))
-        return fps_launch_pruned(0, b, n, m, inp, out, out_xyz, st);
+    if (variant == PN2_FPS_PRUNED || (variant == PN2_FPS_AUTO && fps_pruned_pays(ranks, m)))
+        return fps_launch_pruned(b, n, m, inp, out, out_xyz, st);
     // default geometry (measured, scripts/fps_prod_lab.hip, ns per round at n = 1024/2048/4096/8192):
     // 256 threads with the packed distance update 273/312/402/585, 512 threads (scalar) 288/326/393/552
     const int T = ranks <= 2048 ? 256 : 512;
@@ -261,13 +253,6 @@ extern "C" int pn2_farthest_point_sample_variant(int variant, int b, int n, int 
 {
     if (variant < PN2_FPS_AUTO || variant > PN2_FPS_PRUNED) return PN2_E_ARG;
     return fps_entry(b, n, m, inp, temp, out, out_xyz, stream, variant);
-}
-
-// lab hook: the pruned tier with an explicit group size (slots per group: 2 or 4)
-extern "C" int pn2_farthest_point_sample_pruned_ex(int gs, int b, int n, int m, const float *inp, int *out, void *stream)
-{
-    if (m <= 0 || b <= 0 || n <= 0 || !inp || !out) return PN2_E_ARG;
-    return pn2::fps_launch_pruned(gs, b, n, m, inp, out, nullptr, pn2::as_stream(stream));
 }
 
 // tuning / test hook: run the register tier with an explicit geometry

@@ -8,15 +8,14 @@
 // value that just won the arg-max), and after a few dozen samples that ball holds a few per cent of the cloud.
 //
 // Organisation. 256 threads (four waves, one per SIMD), P = 16 or 32 rank slots per thread as in fps_reg_body, but the
-// points are dealt to the slots SPATIALLY: a balanced kd-tree with G = 32 or 64 leaves is built once per cloud in LDS
-// (histogram medians, below), leaf g becomes GROUP (wave g % 4, group g / 4 of that wave) = GS = 2 or 4 slots of all 64
-// lanes, and every group keeps the tight bounding box of its 64 * GS points. Per round, lane l of every wave tests
-// group l's box against the new sample (16 vector instructions for all groups at once); a group whose box lies
-// farther from the sample than sqrt(v*) cannot change and is SKIPPED, a wave none of whose groups is touched skips
-// its whole reduction and re-publishes its cached wave key. The tie rule is untouched: a slot's key is still
-// (value bits : NS - 1 - rank) with rank = (k mod 512) * ceil(n / 512) + k / 512, it just lives in a register loaded
-// once instead of being derived from the thread number, and the winner's (x, y, z, k) still comes from the LDS mirror
-// kept in rank order.
+// points are dealt to the slots SPATIALLY: the cloud is cut into 32 leaves of equal size (three counting passes in LDS,
+// below), a leaf becomes a GROUP = GS = 2 or 4 slots of all 64 lanes of one wave (eight groups per wave), and every group
+// keeps the tight bounding box of its 64 * GS points. Per round, lane l of every wave tests group l's box against the new
+// sample (14 vector instructions for all groups at once); a group whose box lies farther from the sample than sqrt(v*)
+// cannot change and is SKIPPED, a wave none of whose groups is touched skips its whole reduction and re-publishes its
+// cached wave key. The tie rule is untouched: a slot's key is still (value bits : NS - 1 - rank) with
+// rank = (k mod 512) * ceil(n / 512) + k / 512, it just lives in a register loaded once instead of being derived from
+// the thread number, and the winner's (x, y, z, k) still comes from the LDS mirror kept in rank order.
 //
 // Exactness of the skip. Let bd be the fp32-evaluated squared distance from the sample s to a group's box. For a point p
 // of the group the exact |p - s|^2 >= the exact box distance; the fp32 evaluations of both carry relative errors below
@@ -28,28 +27,41 @@
 // uniform-cube clouds, 3.5-4.6 of 32 at n = 8192; a cloud with 87 % of its points on one spot (provider.py:227-233)
 // prunes little (10 of 16) and costs what fps_reg_body costs.
 //
-// kd-tree. L = log2(G) levels; at every level each segment is cut at the median of its widest axis: 64-bin histogram
-// along that axis (LDS atomics), the bin holding the median found by a wave prefix sum, points below / above go left /
-// right, the points IN the median bin are dealt out by an LDS ticket so that both halves have exactly the same size.
-// Which of them go where is timing dependent -- and irrelevant: any grouping gives the same samples, grouping only
-// decides how much is skipped. Points never move during the build (they sit in registers with a segment number); one
-// final scatter through LDS puts them into their slots.
+// Grouping. Any partition gives the same samples; a compact one gives more skips. A balanced kd-tree built level by level
+// (histogram medians with per-segment axis choice and tickets for the median bin: the first version of this file) grouped well
+// but took 27-34 us per cloud -- as much as the pruning saved at n = 4096. The three counting passes of the body (4 x 4 x 2
+// parts along the axes sorted by extent, one returning LDS atomic and one LDS read per item and pass, six barriers)
+// prune as well in simulation and on the GPU (profiles/r05/fps_pruned.txt).
 #pragma once
 #include "fps_body.h"
 
 #include <math.h>
 
+#include <type_traits>
+
 namespace pn2 {
 
 constexpr int kPrT = 256;              // threads of the pruned tier
 constexpr int kPrW = kPrT / PN2_WAVE;  // 4 waves: one per SIMD
-constexpr int kPrBins = 64;            // histogram bins per median search (= one wave)
+constexpr int kPrBins = 64;            // histogram bins per axis (= one wave)
+constexpr int kPrK0 = 4, kPrK1 = 4, kPrK2 = 2;                 // parts per pass: 32 leaves
+constexpr int kPrGroups = kPrK0 * kPrK1 * kPrK2;
+constexpr int kPrHistRows = 1 + kPrK0 + kPrK0 * kPrK1;         // segments of the three passes
 
 // LDS layout (bytes): [0,64) wave keys (2 parities x 4) | [64,256) reduction scratch | mirror / staging 16 * NS |
-// hist G * 64 ints | segtab G float4 | split G int2 | cursor G ints | leafcur G ints | cell 2 x G x 8 floats | gbox G x 8 floats
-__host__ __device__ constexpr size_t fps_pruned_lds_bytes(int P, int G)
+// hist 21 x 64 ints | gbox 32 x 8 floats
+__host__ __device__ constexpr size_t fps_pruned_lds_bytes(int P)
 {
-    return 256 + (size_t)16 * kPrT * P + (size_t)G * (kPrBins * 4 + 16 + 8 + 4 + 4 + 2 * 32 + 32);
+    return 256 + (size_t)16 * kPrT * P + (size_t)kPrHistRows * kPrBins * 4 + (size_t)kPrGroups * 32;
+}
+
+// Where the pruned tier pays (measured, profiles/r05/fps_pruned.txt): its grouping costs 8.5 us (16 slots per thread) / 14 us
+// (32) more than fps_reg_body's prologue and its first ~64 rounds prune nothing; after that a round is 353-362 ns against 392
+// at 4096 rank slots and 386-395 against 545 at 8192. ranks = 512 * ceil(n / 512).
+inline bool fps_pruned_pays(int ranks, int m)
+{
+    if (ranks > 2048 && ranks <= 4096) return m >= 768;
+    return ranks > 4096 && ranks <= 8192 && m >= 128;
 }
 
 __device__ __forceinline__ int pr_prefix_sum_incl(int v)
@@ -88,22 +100,15 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
 {
     constexpr int T = kPrT, W = kPrW, NS = T * P;
     constexpr int GW = P / GS;                    // groups per wave
-    constexpr int G = W * GW;                     // groups = kd leaves = test lanes
-    static_assert(G <= 64 && GS >= 2 && (GS & 1) == 0 && (G & (G - 1)) == 0, "group geometry");
-    constexpr int LV = G == 64 ? 6 : G == 32 ? 5 : G == 16 ? 4 : 3;
-    static_assert((1 << LV) == G, "G must be 8, 16, 32 or 64");
+    constexpr int G = W * GW;                     // groups = leaves = test lanes
+    static_assert(G == kPrGroups && GW == 8 && (GS & 1) == 0, "32 groups: 16 slots per thread in groups of 2, 32 in groups of 4");
 
     unsigned long long *partial = reinterpret_cast<unsigned long long *>(smem);        // [2][W]
     float *scratch = reinterpret_cast<float *>(smem + 64);                              // 48 floats
     float4 *lds_rank = reinterpret_cast<float4 *>(smem + 256);                          // mirror [NS], first the staging copy
     char *tab = smem + 256 + (size_t)16 * NS;
-    int *hist = reinterpret_cast<int *>(tab);                                           // [G][64]
-    float4 *segtab = reinterpret_cast<float4 *>(tab + (size_t)G * kPrBins * 4);         // [G] {axis, lo, scale, bin width}
-    int2 *split = reinterpret_cast<int2 *>(reinterpret_cast<char *>(segtab) + (size_t)G * 16);   // [G] {median bin, tickets that go left}
-    int *cursor = reinterpret_cast<int *>(reinterpret_cast<char *>(split) + (size_t)G * 8);      // [G]
-    int *leafcur = cursor + G;                                                          // [G]
-    float *cell = reinterpret_cast<float *>(leafcur + G);                               // [2][G][8]: lo xyz, -, hi xyz, -
-    float *gbox = cell + 2 * G * 8;                                                     // [G][8]
+    int *hist = reinterpret_cast<int *>(tab);                                           // [1 + K0 + K0 * K1][64]: one histogram row per segment and level
+    float *gbox = reinterpret_cast<float *>(tab + (size_t)kPrHistRows * kPrBins * 4);   // [G][8]
 
     const float *__restrict__ src = xyz + (size_t)cloud * n * 3;
     int *__restrict__ dst = out + (size_t)cloud * m;
@@ -115,14 +120,12 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
 
     // ---- the items in natural order: item i = point i, or (i >= n) a padding item at point 0's position ----------------
     float px[P], py[P], pz[P];
-    int seg[P], bin[P];
     float lx = INFINITY, ly = INFINITY, lz = INFINITY, hx = -INFINITY, hy = -INFINITY, hz = -INFINITY;
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         const int i = t + j * T;
         const int k = i < n ? i : 0;
         px[j] = src[(size_t)k * 3 + 0]; py[j] = src[(size_t)k * 3 + 1]; pz[j] = src[(size_t)k * 3 + 2];
-        seg[j] = 0;
         lx = fminf(lx, px[j]); ly = fminf(ly, py[j]); lz = fminf(lz, pz[j]);
         hx = fmaxf(hx, px[j]); hy = fmaxf(hy, py[j]); hz = fmaxf(hz, pz[j]);
     }
@@ -132,106 +135,99 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
         scratch[w * 8 + 0] = lx; scratch[w * 8 + 1] = ly; scratch[w * 8 + 2] = lz;
         scratch[w * 8 + 4] = hx; scratch[w * 8 + 5] = hy; scratch[w * 8 + 6] = hz;
     }
-    for (int i = t; i < G; i += T) leafcur[i] = 0;
-    __syncthreads();
-    if (t < 8 && (t & 3) != 3) {                   // root cell = the cloud's bounding box
-        float v = scratch[t];
-#pragma unroll
-        for (int ww = 1; ww < W; ++ww) v = t < 4 ? fminf(v, scratch[ww * 8 + t]) : fmaxf(v, scratch[ww * 8 + t]);
-        cell[t] = v;
-    }
+    for (int i = t; i < kPrHistRows * kPrBins; i += T) hist[i] = 0;
     __syncthreads();
 
-    // ---- balanced kd-tree, one level per iteration ---------------------------------------------------------------------
-    for (int lev = 0; lev < LV; ++lev) {
-        const int nseg = 1 << lev;
-        float *cur = cell + (lev & 1) * G * 8, *nxt = cell + ((lev & 1) ^ 1) * G * 8;
-        if (t < nseg) {                                  // the segment's split axis: the widest side of its cell
-            const float *c = cur + t * 8;
-            const float ex = c[4] - c[0], ey = c[5] - c[1], ez = c[6] - c[2];
-            int a = 0; float e = ex, lo = c[0];
-            if (ey > e) { a = 1; e = ey; lo = c[1]; }
-            if (ez > e) { a = 2; e = ez; lo = c[2]; }
-            const bool ok = e > 0.0f && e < INFINITY;    // degenerate / non-finite cell: every point in bin 0, tickets split it
-            segtab[t] = make_float4(__int_as_float(a), ok ? lo : 0.0f, ok ? (float)kPrBins / e : 0.0f, ok ? e * (1.0f / kPrBins) : 0.0f);
-        }
-        for (int i = t; i < nseg * kPrBins; i += T) hist[i] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-            const float4 st = segtab[seg[j]];
-            const int a = __float_as_int(st.x);
-            const float c = a == 0 ? px[j] : a == 1 ? py[j] : pz[j];
-            int b = (int)((c - st.y) * st.z);            // NaN -> 0
-            b = b < 0 ? 0 : b > kPrBins - 1 ? kPrBins - 1 : b;
-            bin[j] = b;
-            atomicAdd(&hist[seg[j] * kPrBins + b], 1);
-        }
-        __syncthreads();
-        for (int s = w; s < nseg; s += W) {              // one wave per segment: the bin that holds the median
-            const int h = hist[s * kPrBins + lane];
-            const int incl = pr_prefix_sum_incl(h);
-            const int half = (NS >> lev) >> 1;
-            const unsigned long long ge = __ballot(incl >= half);
-            const int mb = __builtin_ctzll(ge);          // exists: incl of lane 63 = the segment's size >= half
-            const int incl_mb = __builtin_amdgcn_readlane(incl, mb), h_mb = __builtin_amdgcn_readlane(h, mb);
-            if (lane == 0) {
-                split[s] = make_int2(mb, half - (incl_mb - h_mb));       // tickets 0 .. k-1 of the median bin go left
-                cursor[s] = 0;
-                const float4 st = segtab[s];
-                const int a = __float_as_int(st.x);
-                const float *c = cur + s * 8;
-                float *l = nxt + (2 * s) * 8, *r = nxt + (2 * s + 1) * 8;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { l[q] = c[q]; r[q] = c[q]; }
-                if (st.z > 0.0f) {                        // children overlap by the median bin
-                    l[4 + a] = st.y + (float)(mb + 1) * st.w;
-                    r[a] = st.y + (float)mb * st.w;
-                }
-            }
-        }
-        __syncthreads();
-        int tk[P];
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-            const int2 sp = split[seg[j]];
-            tk[j] = 0;
-            if (bin[j] == sp.x) tk[j] = atomicAdd(&cursor[seg[j]], 1) - sp.y;      // >= 0: right
-            else if (bin[j] > sp.x) tk[j] = 0;
-            else tk[j] = -1;
-        }
-#pragma unroll
-        for (int j = 0; j < P; ++j) seg[j] = 2 * seg[j] + (tk[j] >= 0 ? 1 : 0);
-        // the next level rewrites hist / segtab behind its own barrier and split / cursor two barriers from here
-    }
-
-    // ---- scatter into the slots: leaf g -> wave g % W, group g / W; ticket r of the leaf -> lane r % 64, slot r / 64 -------
+    // ---- spatial grouping: three counting passes --------------------------------------------------------------------------
+    // The cloud's bounding box is cut into 64 bins per axis once. Pass 1 cuts the cloud into K0 = 4 equal parts along its
+    // widest axis, pass 2 every part into K1 = 4 along the second widest, pass 3 every piece into K2 = 2 along the third:
+    // 32 leaves of NS / 32 items. A pass is: every item takes a ticket in its (segment, bin) counter (one returning LDS
+    // atomic: the counters end up as the histogram), a wave turns each segment's histogram into exclusive prefix sums,
+    // and an item's RANK inside its segment is prefix[bin] + ticket -- its child is rank / child size. Items of one bin are
+    // ordered by ticket, i.e. arbitrarily: which of them lands on which side of a cut is timing dependent and irrelevant
+    // (header). The last pass's rank is also the item's position inside its leaf.
+    float blo[3], bsc[3];
+    int ax[3];
     {
-        int r[P];
+        float lo3[3], ex[3];
 #pragma unroll
-        for (int j = 0; j < P; ++j) r[j] = atomicAdd(&leafcur[seg[j]], 1);
+        for (int a = 0; a < 3; ++a) {
+            float l = scratch[a], h = scratch[4 + a];
+#pragma unroll
+            for (int ww = 1; ww < W; ++ww) { l = fminf(l, scratch[ww * 8 + a]); h = fmaxf(h, scratch[ww * 8 + 4 + a]); }
+            const float e = h - l;
+            const bool ok = e > 0.0f && e < INFINITY;     // degenerate / non-finite axis: every item in bin 0, tickets cut it
+            lo3[a] = ok ? l : 0.0f;
+            ex[a] = ok ? e : 0.0f;
+        }
+        // axes by extent, widest first (wave-uniform values; ties keep x, y, z order)
+        int a0 = 0, a1 = 1, a2 = 2;
+        if (ex[a1] > ex[a0]) { const int q = a0; a0 = a1; a1 = q; }
+        if (ex[a2] > ex[a0]) { const int q = a0; a0 = a2; a2 = q; }
+        if (ex[a2] > ex[a1]) { const int q = a1; a1 = a2; a2 = q; }
+        ax[0] = a0; ax[1] = a1; ax[2] = a2;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const int a = ax[l];
+            const float e = a == 0 ? ex[0] : a == 1 ? ex[1] : ex[2];
+            blo[l] = a == 0 ? lo3[0] : a == 1 ? lo3[1] : lo3[2];
+            bsc[l] = e > 0.0f ? (float)kPrBins / e : 0.0f;
+        }
+    }
+    int seg[P], rank[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) seg[j] = 0;
+    constexpr int kLevelK[3] = {kPrK0, kPrK1, kPrK2};
+    constexpr int kLevelRow[3] = {0, 1, 1 + kPrK0};                   // first histogram row of the level
+    constexpr int kLevelSegs[3] = {1, kPrK0, kPrK0 * kPrK1};
+#pragma unroll
+    for (int lev = 0; lev < 3; ++lev) {
+        int *hl = hist + kLevelRow[lev] * kPrBins;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {                                            // seg[j] becomes the item's counter: segment * 64 + bin
+            const float c = ax[lev] == 0 ? px[j] : ax[lev] == 1 ? py[j] : pz[j];
+            int q = (int)((c - blo[lev]) * bsc[lev]);                             // NaN -> 0
+            q = q < 0 ? 0 : q > kPrBins - 1 ? kPrBins - 1 : q;
+            seg[j] = seg[j] * kPrBins + q;
+        }
+#pragma unroll
+        for (int j = 0; j < P; ++j) rank[j] = atomicAdd(&hl[seg[j]], 1);        // the ticket; all P in flight
+        __syncthreads();
+        for (int sg = w; sg < kLevelSegs[lev]; sg += W) {                        // counts -> exclusive prefix sums, in place
+            const int h = hl[sg * kPrBins + lane];
+            hl[sg * kPrBins + lane] = pr_prefix_sum_incl(h) - h;
+        }
+        __syncthreads();
+        const int child = NS / (lev == 0 ? kPrK0 : lev == 1 ? kPrK0 * kPrK1 : kPrK0 * kPrK1 * kPrK2);   // a power of two, constant once unrolled
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-            const int g = seg[j];
-            const int dt = (g & (W - 1)) * 64 + (r[j] & 63);
-            const int dp = (g / W) * GS + (r[j] >> 6);
-            lds_rank[dt * P + dp] = make_float4(px[j], py[j], pz[j], __int_as_float(t + j * T));
+            rank[j] += hl[seg[j]];
+            seg[j] = (seg[j] >> 6) * kLevelK[lev] + (int)((unsigned)rank[j] / (unsigned)child);
+            rank[j] &= child - 1;                                               // rank inside the child
         }
+    }
+
+    // ---- scatter into the slots. Leaf id = 8 * a + r (a = part along the widest axis, r = the rest): wave (r + a) % 4 --
+    // neighbours along every axis go to different waves (simulation: the busiest wave has 1.26 touched groups per round
+    // with this map, 1.56 with id % 4) --, group 2 * a + r / 4 of that wave; position p of the leaf -> lane p % 64, slot p / 64
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int a = seg[j] >> 3, r = seg[j] & 7;
+        const int dt = ((r + a) & (W - 1)) * 64 + (rank[j] & 63);
+        const int dp = (2 * a + (r >> 2)) * GS + (rank[j] >> 6);
+        lds_rank[dt * P + dp] = make_float4(px[j], py[j], pz[j], __int_as_float(t + j * T));
     }
     __syncthreads();
     pn2_f2 xx[P / 2], yy[P / 2], zz[P / 2];
-    float md[P];
+    float md[P];                                        // until the mirror is written: the bits of the slot's item number
     unsigned low[P];
-    int kk[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const float4 v = lds_rank[t * P + p];
         const int i = __float_as_int(v.w);
-        const bool real = i < n;
         const int rank = (i & (kRefThreads - 1)) * Q + (i >> 9);      // tie rank of point i (fps_body.h)
-        kk[p] = real ? i : 0;
-        low[p] = real ? (unsigned)(NS - 1 - rank) : 0u;                // padding: value 0, lowest key (never wins over rank 0)
-        md[p] = real ? 1e38f : 0.0f;                                   // tf_sampling_g.cu:118
+        low[p] = i < n ? (unsigned)(NS - 1 - rank) : 0u;               // padding: value 0, lowest key (never wins over rank 0)
+        md[p] = v.w;
         if (p & 1) { xx[p / 2].y = v.x; yy[p / 2].y = v.y; zz[p / 2].y = v.z; }
         else { xx[p / 2].x = v.x; yy[p / 2].x = v.y; zz[p / 2].x = v.z; }
     }
@@ -240,7 +236,10 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
     for (int p = 0; p < P; ++p) {
         const float X = (p & 1) ? xx[p / 2].y : xx[p / 2].x, Y = (p & 1) ? yy[p / 2].y : yy[p / 2].x,
                     Z = (p & 1) ? zz[p / 2].y : zz[p / 2].x;
-        if (md[p] != 0.0f) lds_rank[low[p]] = make_float4(X, Y, Z, __int_as_float(kk[p]));
+        const int i = __float_as_int(md[p]);
+        const bool real = i < n;
+        if (real) lds_rank[low[p]] = make_float4(X, Y, Z, md[p]);     // (x, y, z, bits of k)
+        md[p] = real ? 1e38f : 0.0f;                                   // tf_sampling_g.cu:118
     }
     // tight box of every group of this wave -> gbox[w * GW + gi]
 #pragma unroll
@@ -281,69 +280,81 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
         dst[0] = 0;                                     // tf_sampling_g.cu:114-116
         if (PUBLISH) __hip_atomic_store(gtag, (unsigned long long)tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    double gk[GW];                                      // lane-level key of every group (cached across rounds)
+    double gk[GW], gp[GW / 2];                          // lane-level key of every group and of every pair of groups (cached across rounds)
 #pragma unroll
     for (int gi = 0; gi < GW; ++gi) gk[gi] = 0.0;
+#pragma unroll
+    for (int q = 0; q < GW / 2; ++q) gp[q] = 0.0;
     double wave_key = 0.0;                              // lane 63: the wave's key (cached while no group of the wave changes)
 
     auto round = [&](const int j, const int par) __attribute__((always_inline)) {
         // which groups can the new sample change? (all lanes, lane l = group l)
         const float thr = __fadd_rn(__fmul_rn(vstar, 1.00001f), 1e-30f);
-        const float ax = __builtin_fmaxf(__builtin_fmaxf(__fsub_rn(blx, sxy.x), __fsub_rn(sxy.x, bhx)), 0.0f);
-        const float ay = __builtin_fmaxf(__builtin_fmaxf(__fsub_rn(bly, sxy.y), __fsub_rn(sxy.y, bhy)), 0.0f);
-        const float az = __builtin_fmaxf(__builtin_fmaxf(__fsub_rn(blz, szk.x), __fsub_rn(szk.x, bhz)), 0.0f);
+        // distance from the sample to the box = sample - clamp(sample, lo, hi) per axis (v_med3_f32 is the clamp)
+        const float ax = __fsub_rn(sxy.x, __builtin_amdgcn_fmed3f(sxy.x, blx, bhx));
+        const float ay = __fsub_rn(syy.x, __builtin_amdgcn_fmed3f(syy.x, bly, bhy));
+        const float az = __fsub_rn(szk.x, __builtin_amdgcn_fmed3f(szk.x, blz, bhz));
         const float bd = __fadd_rn(__fadd_rn(__fmul_rn(ax, ax), __fmul_rn(ay, ay)), __fmul_rn(az, az));
         const unsigned long long far_mask = __ballot(bd >= thr);          // NaN -> not far -> updated
         const unsigned mybits = (unsigned)(~far_mask >> (w * GW)) & ((1u << GW) - 1u);   // scalar
         unsigned long long *slot = partial + par * W;
         if (mybits != 0u) {                                               // wave-uniform
+            auto update_group = [&](auto gic) __attribute__((always_inline)) {
+                constexpr int gi = decltype(gic)::value;
+                constexpr int H = GS / 2;
+                pn2_f2 dx[H], dy[H], dz[H];
 #pragma unroll
-            for (int gi = 0; gi < GW; ++gi) {
-                if (mybits & (1u << gi)) {                                // wave-uniform
-                    constexpr int H = GS / 2;
-                    pn2_f2 dx[H], dy[H], dz[H];
+                for (int h = 0; h < H; ++h) dx[h] = pk_sub_bcast_lo(xx[gi * H + h], sxy);
 #pragma unroll
-                    for (int h = 0; h < H; ++h) dx[h] = pk_sub_bcast_lo(xx[gi * H + h], sxy);
+                for (int h = 0; h < H; ++h) dy[h] = pk_sub_bcast_lo(yy[gi * H + h], syy);
 #pragma unroll
-                    for (int h = 0; h < H; ++h) dy[h] = pk_sub_bcast_lo(yy[gi * H + h], syy);
+                for (int h = 0; h < H; ++h) dz[h] = pk_sub_bcast_lo(zz[gi * H + h], szk);
 #pragma unroll
-                    for (int h = 0; h < H; ++h) dz[h] = pk_sub_bcast_lo(zz[gi * H + h], szk);
+                for (int h = 0; h < H; ++h) dx[h] = pk_mul(dx[h], dx[h]);
 #pragma unroll
-                    for (int h = 0; h < H; ++h) dx[h] = pk_mul(dx[h], dx[h]);
+                for (int h = 0; h < H; ++h) dy[h] = pk_mul(dy[h], dy[h]);
 #pragma unroll
-                    for (int h = 0; h < H; ++h) dy[h] = pk_mul(dy[h], dy[h]);
+                for (int h = 0; h < H; ++h) dz[h] = pk_mul(dz[h], dz[h]);
 #pragma unroll
-                    for (int h = 0; h < H; ++h) dz[h] = pk_mul(dz[h], dz[h]);
+                for (int h = 0; h < H; ++h) dx[h] = pk_add(dx[h], dy[h]);
 #pragma unroll
-                    for (int h = 0; h < H; ++h) dx[h] = pk_add(dx[h], dy[h]);
+                for (int h = 0; h < H; ++h) dx[h] = pk_add(dx[h], dz[h]);
+                double kd[GS];
 #pragma unroll
-                    for (int h = 0; h < H; ++h) dx[h] = pk_add(dx[h], dz[h]);
-                    double kd[GS];
-#pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        const int p0 = gi * GS + 2 * h;
-                        md[p0] = vmin_f32(dx[h].x, md[p0]);              // min(d,td), :144
-                        md[p0 + 1] = vmin_f32(dx[h].y, md[p0 + 1]);
-                        kd[2 * h] = __hiloint2double(__float_as_int(md[p0]), (int)low[p0]);
-                        kd[2 * h + 1] = __hiloint2double(__float_as_int(md[p0 + 1]), (int)low[p0 + 1]);
-                    }
-#pragma unroll
-                    for (int st = 1; st < GS; st <<= 1)
-#pragma unroll
-                        for (int i = 0; i + st < GS; i += 2 * st)
-                            asm("v_max_f64 %0, %1, %2" : "=v"(kd[i]) : "v"(kd[i]), "v"(kd[i + st]));
-                    gk[gi] = kd[0];
+                for (int h = 0; h < H; ++h) {
+                    const int p0 = gi * GS + 2 * h;
+                    md[p0] = vmin_f32(dx[h].x, md[p0]);              // min(d,td), :144
+                    md[p0 + 1] = vmin_f32(dx[h].y, md[p0 + 1]);
+                    kd[2 * h] = __hiloint2double(__float_as_int(md[p0]), (int)low[p0]);
+                    kd[2 * h + 1] = __hiloint2double(__float_as_int(md[p0 + 1]), (int)low[p0 + 1]);
                 }
+#pragma unroll
+                for (int st = 1; st < GS; st <<= 1)
+#pragma unroll
+                    for (int i = 0; i + st < GS; i += 2 * st)
+                        asm("v_max_f64 %0, %1, %2" : "=v"(kd[i]) : "v"(kd[i]), "v"(kd[i + st]));
+                gk[gi] = kd[0];
+            };
+#define PN2_PR_GROUP(g) if (mybits & (1u << (g))) update_group(std::integral_constant<int, g>())
+            // nested bit tests (structured: hipcc turns a switch on the bit number, or a loop over the set bits, into flag
+            // variables and copies of every slot register): six scalar tests for the usual single touched group instead of eight
+#define PN2_PR_PAIR(q) asm("v_max_f64 %0, %1, %2" : "=v"(gp[q]) : "v"(gk[2 * (q)]), "v"(gk[2 * (q) + 1]))
+            if (mybits & 0x0fu) {
+                if (mybits & 0x03u) { PN2_PR_GROUP(0); PN2_PR_GROUP(1); PN2_PR_PAIR(0); }
+                if (mybits & 0x0cu) { PN2_PR_GROUP(2); PN2_PR_GROUP(3); PN2_PR_PAIR(1); }
             }
-            double kt[GW];
-#pragma unroll
-            for (int gi = 0; gi < GW; ++gi) kt[gi] = gk[gi];
-#pragma unroll
-            for (int st = 1; st < GW; st <<= 1)
-#pragma unroll
-                for (int i = 0; i + st < GW; i += 2 * st)
-                    asm("v_max_f64 %0, %1, %2" : "=v"(kt[i]) : "v"(kt[i]), "v"(kt[i + st]));
-            wave_key = wave_max_f64_lane63(kt[0]);
+            if (mybits & 0xf0u) {
+                if (mybits & 0x30u) { PN2_PR_GROUP(4); PN2_PR_GROUP(5); PN2_PR_PAIR(2); }
+                if (mybits & 0xc0u) { PN2_PR_GROUP(6); PN2_PR_GROUP(7); PN2_PR_PAIR(3); }
+            }
+#undef PN2_PR_PAIR
+#undef PN2_PR_GROUP
+            // lane key = max over the four cached pair keys (only the touched pairs were recomputed above)
+            double k01, k23, kl;
+            asm("v_max_f64 %0, %1, %2" : "=v"(k01) : "v"(gp[0]), "v"(gp[1]));
+            asm("v_max_f64 %0, %1, %2" : "=v"(k23) : "v"(gp[2]), "v"(gp[3]));
+            asm("v_max_f64 %0, %1, %2" : "=v"(kl) : "v"(k01), "v"(k23));
+            wave_key = wave_max_f64_lane63(kl);
         }
         if (lane == 63) reinterpret_cast<double *>(slot)[w] = wave_key;
         __syncthreads();

@@ -136,7 +136,7 @@ static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, floa
     int qpb = 64;
     if (qpb > m) qpb = ((m + kGran - 1) / kGran) * kGran;
     const int nq = (m + qpb - 1) / qpb;
-    size_t lds_f = PRUNED ? fps_pruned_lds_bytes(2 * P, kPrW * (2 * P / fused_pruned_gs(P)))
+    size_t lds_f = PRUNED ? fps_pruned_lds_bytes(2 * P)
                           : 256 + sizeof(float4) * (size_t)kFusedThreads * P;
     size_t lds_q = LPQ ? fused_cells_lds(n, nsample, LPQ)
                        : sizeof(float4) * (size_t)((n + 127) & ~127) + sizeof(int) * (size_t)nsample * kGran;
@@ -198,7 +198,7 @@ static int sample_and_group_common(int b, int n, int m, float radius, int nsampl
     // kd build (the rule of pn2_farthest_point_sample, fps.hip)
     if (fps_variant < PN2_FPS_AUTO || fps_variant > PN2_FPS_PRUNED) return PN2_E_ARG;
     if (fps_variant == PN2_FPS_PRUNED && P != 8 && P != 16) return PN2_E_ARG;
-    const bool pruned = fps_variant == PN2_FPS_PRUNED || (fps_variant == PN2_FPS_AUTO && (P == 8 || P == 16) && m >= 128);
+    const bool pruned = fps_variant == PN2_FPS_PRUNED || (fps_variant == PN2_FPS_AUTO && fps_pruned_pays(ranks, m));
 #define PN2_FUSED_CASE(PP, LL, PR)                                                                                     \
     if (P == PP && lpq == LL && pruned == PR)                                                                          \
         return launch_fused<PP, LL, PR>(b, n, m, Q, nsample, thr, radius, tag, xyz, w, fps_idx, new_xyz, idx, pts_cnt,   \

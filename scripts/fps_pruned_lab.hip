@@ -47,8 +47,7 @@ int main(int argc, char **argv)
             std::vector<V> vs = {
                 {"full 512", [&](int mm) { return pn2_farthest_point_sample_ex(512, P512, b, n, mm, d_xyz, d_out, nullptr); }},
                 {"full 256", [&](int mm) { return pn2_farthest_point_sample_ex(256, P256, b, n, mm, d_xyz, d_out, nullptr); }},
-                {"pruned gs2", [&](int mm) { return pn2_farthest_point_sample_pruned_ex(2, b, n, mm, d_xyz, d_out, nullptr); }},
-                {"pruned gs4", [&](int mm) { return pn2_farthest_point_sample_pruned_ex(4, b, n, mm, d_xyz, d_out, nullptr); }},
+                {"pruned", [&](int mm) { return pn2_farthest_point_sample_variant(PN2_FPS_PRUNED, b, n, mm, d_xyz, nullptr, d_out, nullptr, nullptr); }},
             };
             for (size_t vi = 0; vi < vs.size(); ++vi) {
                 CK(hipMemset(d_out, 0xff, (size_t)b * m * 4));

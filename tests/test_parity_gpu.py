@@ -104,19 +104,19 @@ def test_fps_all_geometries_agree(cuda, oracle):
 PRUNED_CASES = [
     ("sphere4096", lambda: S.sphere_clouds(4, 4096, 200), 1024, 0),
     ("cube4096", lambda: S.uniform_clouds(3, 4096, 201), 512, 0),
-    ("sphere4096_gs4", lambda: S.sphere_clouds(2, 4096, 202), 700, 4),
+    ("sphere4096_b", lambda: S.sphere_clouds(2, 4096, 202), 700, 4),
     ("dup4096", lambda: S.duplicated_clouds(3, 4096, 203), 1024, 0),
     ("drop4096", lambda: S.dropout_clouds(3, 4096, 204), 600, 0),
     ("same3000", lambda: S.identical_clouds(2, 3000, 205), 200, 0),
     ("lattice4000", lambda: S.lattice_clouds(3, 4000, 206), 1500, 0),
-    ("lattice4096_gs4", lambda: S.lattice_clouds(2, 4096, 207), 900, 4),
+    ("lattice4096_b", lambda: S.lattice_clouds(2, 4096, 207), 900, 4),
     ("n2049", lambda: S.sphere_clouds(2, 2049, 208), 300, 0),
     ("n3100", lambda: S.uniform_clouds(2, 3100, 209), 3100, 0),       # every point sampled
     ("n2500_m_gt_n", lambda: S.duplicated_clouds(2, 2500, 210), 2600, 0),
     ("cube8192", lambda: S.uniform_clouds(2, 8192, 211), 1024, 0),    # sem_seg SA1: 32 slots per thread
-    ("cube8192_gs2", lambda: S.uniform_clouds(2, 8192, 212), 600, 2),
+    ("cube8192_b", lambda: S.uniform_clouds(2, 8192, 212), 600, 2),
     ("sphere5000", lambda: S.sphere_clouds(2, 5000, 213), 777, 0),
-    ("dup8000_gs2", lambda: S.duplicated_clouds(2, 8000, 214), 1000, 2),
+    ("dup8000", lambda: S.duplicated_clouds(2, 8000, 214), 1000, 2),
     ("lattice6000", lambda: S.lattice_clouds(2, 6000, 215), 2000, 0),
     ("flat4096", lambda: S.sphere_clouds(2, 4096, 216) * np.array([1.0, 1.0, 0.0], np.float32), 512, 0),   # a degenerate axis
     ("line4096", lambda: S.sphere_clouds(2, 4096, 217) * np.array([1.0, 0.0, 0.0], np.float32), 300, 0),
@@ -135,7 +135,7 @@ def test_fps_pruned_tier_index_exact(cuda, oracle, name, make, m, gs):
     st = torch.cuda.current_stream().cuda_stream
     for rep in range(2):                                             # the kd build's tickets are timing dependent; results are not
         out = torch.full((b, m), -1, dtype=torch.int32, device=cuda)
-        rc = _C.lib().pn2_farthest_point_sample_pruned_ex(gs, b, n, m, x.data_ptr(), out.data_ptr(), st)
+        rc = _C.lib().pn2_farthest_point_sample_variant(2, b, n, m, x.data_ptr(), None, out.data_ptr(), None, st)
         assert rc == 0, rc
         got = host(out)
         assert np.array_equal(got, want), "%s rep %d: first mismatch at %s" % (name, rep, np.argwhere(got != want)[:3])
@@ -159,7 +159,6 @@ def test_fps_pruned_tier_refuses_other_sizes(cuda):
     for n in (64, 2048, 8193, 20000):
         x = torch.rand((1, n, 3), device=cuda)
         out = torch.zeros((1, 8), dtype=torch.int32, device=cuda)
-        assert _C.lib().pn2_farthest_point_sample_pruned_ex(0, 1, n, 8, x.data_ptr(), out.data_ptr(), st) == -3
         assert _C.lib().pn2_farthest_point_sample_variant(2, 1, n, 8, x.data_ptr(), None, out.data_ptr(), None, st) == -3 or n > 16384
 
 
