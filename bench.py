@@ -82,6 +82,7 @@ class Stage:
     """The launches of one step, through the C ABI, with preallocated buffers."""
 
     fps_variant = 0        # PN2_FPS_AUTO / _FULL (1) / _PRUNED (2): --fps-variant, results never depend on it
+    consumers = 0          # persistent consumer workgroups per cloud of the overlapped launch (0 = the library's choice)
 
     def __init__(self, dev, xyz_np, radius=RADIUS):
         from pointnet2_amd import _C
@@ -135,7 +136,7 @@ class Stage:
         # allocation, every step uses the next tag, so no per-step clear of the workspace
         self.gen += 1
         self._C.check(self.lib.pn2_sample_and_group_xyz_ex(self.b, N, M, self.radius, NS, self.xyz.data_ptr(),
-                                                           self.ws.data_ptr(), self.gen, self.fps_variant, self.fps.data_ptr(),
+                                                           self.ws.data_ptr(), self.gen, self.fps_variant, self.consumers, self.fps.data_ptr(),
                                                            self.new_xyz.data_ptr(), self.idx.data_ptr(),
                                                            self.cnt.data_ptr(), self.grouped.data_ptr(), 1, self.stream),
                       "sample_and_group_xyz")
@@ -379,6 +380,7 @@ def main():
     ap.add_argument("--path", choices=("overlap", "fused", "ops"), default="overlap")
     ap.add_argument("--fps-variant", choices=("auto", "full", "pruned"), default="auto",
                     help="FPS tier of every launch (pn2_farthest_point_sample_variant): auto = the library's rule")
+    ap.add_argument("--consumers", type=int, default=0, help="consumer workgroups per cloud of the overlapped launch (0 = library default)")
     ap.add_argument("--streams", type=int, default=8, help="batches in flight for the extra `concurrent` figure (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -390,6 +392,7 @@ def main():
         sys.exit(respawn(args))
 
     Stage.fps_variant = {"auto": 0, "full": 1, "pruned": 2}[args.fps_variant]
+    Stage.consumers = args.consumers
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -490,7 +493,7 @@ def main():
                            "fused": " (2 launches: FPS+gather, ball query+group+centroid subtract)",
                            "ops": " (4 reference-shaped operator launches)"}[args.path],
                        "sharding": "%d independent batch shard(s), no data-path collective" % world,
-                       "fps_variant": args.fps_variant,
+                       "fps_variant": args.fps_variant, "consumers_per_cloud": args.consumers or "library default",
                        "requested_gpus": args.gpus},
             "roofline": {"bound": "hbm", "kernel": TIMED_KERNEL[args.path], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

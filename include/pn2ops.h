@@ -297,11 +297,14 @@ int pn2_sample_and_group_xyz_gen(int b, int n, int m, float radius, int nsample,
  * library never synchronises, so a caller that wants to assert forward progress reads the word after
  * synchronising the stream. */
 long long pn2_sample_and_group_status_offset(int b, int m);
-/* pn2_sample_and_group_xyz[_gen] with the FPS tier of the producer workgroups chosen by the caller (PN2_FPS_AUTO / PN2_FPS_FULL /
- * PN2_FPS_PRUNED as in pn2_farthest_point_sample_variant; outputs never depend on it). generation 0 = clear `ws` first. */
+/* pn2_sample_and_group_xyz[_gen] with the organisation of the launch chosen by the caller (outputs never depend on it):
+ * fps_variant = FPS tier of the producer workgroups (PN2_FPS_AUTO / PN2_FPS_FULL / PN2_FPS_PRUNED as in
+ * pn2_farthest_point_sample_variant); consumers = persistent consumer workgroups per cloud (0 = the library's choice; each
+ * stages its cloud once and walks the 64-query ranges c, c + consumers, ... in publish order; the grid is
+ * b * (1 + consumers) workgroups). generation 0 = clear `ws` first. */
 int pn2_sample_and_group_xyz_ex(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws, unsigned generation,
-                                int fps_variant, int *fps_idx, float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz,
-                                int subtract_centroid, void *stream);
+                                int fps_variant, int consumers, int *fps_idx, float *new_xyz, int *idx, int *pts_cnt,
+                                float *grouped_xyz, int subtract_centroid, void *stream);
 
 
 /* ---- one call per level (inference) ---------------------------------------------------------------------

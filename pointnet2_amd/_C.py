@@ -64,7 +64,7 @@ _SIGNATURES = {
     "pn2_sample_and_group_ws_bytes": [_i, _i],
     "pn2_sample_and_group_status_offset": [_i, _i],
     "pn2_sample_and_group_xyz_gen": [_i, _i, _i, _f, _i, _vp, _vp, ctypes.c_uint, _vp, _vp, _vp, _vp, _vp, _i, _vp],
-    "pn2_sample_and_group_xyz_ex": [_i, _i, _i, _f, _i, _vp, _vp, ctypes.c_uint, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "pn2_sample_and_group_xyz_ex": [_i, _i, _i, _f, _i, _vp, _vp, ctypes.c_uint, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pn2_ball_threshold": [_f],
     "pn2_version": [],
     "pn2_farthest_point_sample_ex": [_i, _i, _i, _i, _i, _vp, _vp, _vp],

@@ -136,7 +136,7 @@ __device__ __forceinline__ int bq_poll_sample(const unsigned long long *tagged, 
 // row_stride: ints between two row buffers (0 = nsample; the multi-radius kernel passes its largest nsample
 // so that waves working on different radii never share a buffer).
 template <bool LDS_CLOUD, bool FUSE, bool POLL, int NT = kBqThreads, bool STAGED = false>
-__device__ __forceinline__ void bq_block_body(int n, int m, int nsample, float thr, int bi, int q0, int q1,
+__device__ __forceinline__ bool bq_block_body(int n, int m, int nsample, float thr, int bi, int q0, int q1,
                                               const float *__restrict__ xyz1, const float *__restrict__ xyz2,
                                               const unsigned long long *__restrict__ tagged,
                                               float *__restrict__ new_xyz, int *__restrict__ idx,
@@ -180,7 +180,7 @@ __device__ __forceinline__ void bq_block_body(int n, int m, int nsample, float t
             const int kb = bq_poll_sample(tagged + row1, tag);
             if (ka < 0 || kb < 0) {                              // wave-uniform; see bq_poll_sample
                 if (lane == 0 && status) atomicExch(status, 1u);
-                return;
+                return false;
             }
             const float4 pa = cloud[ka], pb = cloud[kb];          // POLL implies LDS_CLOUD
             ax = pa.x; ay = pa.y; az = pa.z; bx = pb.x; by = pb.y; bz = pb.z;
@@ -246,6 +246,7 @@ __device__ __forceinline__ void bq_block_body(int n, int m, int nsample, float t
                                      grouped, subtract, lane);
         asm volatile("" ::: "memory");
     }
+    return true;
 }
 
 
@@ -521,7 +522,7 @@ __device__ __forceinline__ int group_prefix_sum_incl(int v, int sub)
 // by run. Hits go into the query's bitmap (bit k = point k) with LDS atomic ORs; the bitmap is then
 // turned into the ascending index list by a group prefix sum of popcounts and a bit-peeling loop.
 template <int NT, int LPQ, bool FUSE, bool POLL>
-__device__ __forceinline__ void bq_cells_query_loop(int n, int m, int nsample, float thr, float radius, float reach,
+__device__ __forceinline__ bool bq_cells_query_loop(int n, int m, int nsample, float thr, float radius, float reach,
                                                     int bi, int q0, int q1, const BqGrid &g,
                                                     const float *__restrict__ data,
                                                     const float *__restrict__ xyz2,
@@ -568,7 +569,7 @@ __device__ __forceinline__ void bq_cells_query_loop(int n, int m, int nsample, f
             const int ka = bq_poll_sample(tagged + row, tag);
             if (__any(ka < 0)) {                                 // see bq_poll_sample: report, give up
                 if (lane == 0 && status) atomicExch(status, 1u);
-                return;
+                return false;
             }
             const float4 qp = sorted[pos_tab[ka]];               // POLL implies pos_tab: exact copy of xyz[ka]
             qx = qp.x; qy = qp.y; qz = qp.z;
@@ -736,11 +737,15 @@ __device__ __forceinline__ void bq_cells_query_loop(int n, int m, int nsample, f
         }
         asm volatile("" ::: "memory");
     }
+    return true;
 }
 
 // Cell-list workgroup body with the brute-force sweep as the block-uniform fallback (coarse grid or
 // crowded cells). `radius` is the caller's radius; reach = radius * 1.001f exceeds the largest
 // |coordinate difference| of any hit (<= radius * (1 + 4 ulp)) by 0.1 %.
+// q_stride > 0: the workgroup is PERSISTENT -- after [q0, q1) it goes on to [q0 + q_stride, q1 + q_stride), ... up to m with
+// the cloud staged and binned ONCE (the overlapped launch's consumers: a few workgroups per cloud walk the query ranges in
+// the order the samples are published).
 template <int NT, int LPQ, bool FUSE, bool POLL>
 __device__ __forceinline__ void bq_cells_block_body(int n, int m, int nsample, float thr, float radius, int bi, int q0,
                                                     int q1, const float *__restrict__ xyz1,
@@ -749,7 +754,7 @@ __device__ __forceinline__ void bq_cells_block_body(int n, int m, int nsample, f
                                                     float *__restrict__ new_xyz, int *__restrict__ idx,
                                                     int *__restrict__ pts_cnt, float *__restrict__ grouped,
                                                     int subtract, char *smem, unsigned tag = 1u,
-                                                    unsigned *status = nullptr)
+                                                    unsigned *status = nullptr, int q_stride = 0)
 {
     float4 *sorted = reinterpret_cast<float4 *>(smem);
     int *tab = reinterpret_cast<int *>(smem + sizeof(float4) * (size_t)n);
@@ -759,16 +764,24 @@ __device__ __forceinline__ void bq_cells_block_body(int n, int m, int nsample, f
     unsigned short *pos_tab = POLL ? reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(misc) + kBqMiscBytes) : nullptr;
     const float *__restrict__ data = xyz1 + (size_t)bi * n * 3;
     const float reach = radius * 1.001f;
+    const int qlen = q1 - q0;
     BqGrid g;
     if (threadIdx.x == 0) tab[0] = 0;
     if (bq_build_grid<NT>(n, reach, data, sorted, tab + 1, misc, g, pos_tab)) {
-        bq_cells_query_loop<NT, LPQ, FUSE, POLL>(n, m, nsample, thr, radius, reach, bi, q0, q1, g, data, xyz2, tagged,
-                                             new_xyz, idx, pts_cnt, grouped, subtract, sorted, tab, wave_area, 0, tag,
-                                             status, pos_tab);
+        for (int a = q0; a < m; a += q_stride) {
+            if (!bq_cells_query_loop<NT, LPQ, FUSE, POLL>(n, m, nsample, thr, radius, reach, bi, a, min(a + qlen, m), g, data, xyz2, tagged,
+                                                       new_xyz, idx, pts_cnt, grouped, subtract, sorted, tab, wave_area, 0, tag,
+                                                       status, pos_tab)) return;
+            if (q_stride <= 0) break;
+        }
     } else {
         __syncthreads();                                         // scratch was read by everyone before it is reused
-        bq_block_body<true, FUSE, POLL, NT>(n, m, nsample, thr, bi, q0, q1, xyz1, xyz2, tagged, new_xyz, idx, pts_cnt,
-                                        grouped, subtract, smem, tag, 0, status);
+        if (!bq_block_body<true, FUSE, POLL, NT>(n, m, nsample, thr, bi, q0, q1, xyz1, xyz2, tagged, new_xyz, idx, pts_cnt,
+                                                 grouped, subtract, smem, tag, 0, status)) return;
+        if (q_stride > 0)
+            for (int a = q0 + q_stride; a < m; a += q_stride)   // the LDS copy of the cloud stays
+                if (!bq_block_body<true, FUSE, POLL, NT, true>(n, m, nsample, thr, bi, a, min(a + qlen, m), xyz1, xyz2, tagged, new_xyz,
+                                                               idx, pts_cnt, grouped, subtract, smem, tag, 0, status)) return;
     }
 }
 

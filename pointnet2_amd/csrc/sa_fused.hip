@@ -13,8 +13,11 @@
 // in a stream. Query j, however, needs nothing but sample j. Here the grid is heterogeneous:
 //     blocks [0, b)          FPS producers, one per cloud; thread 0 publishes every selected index as
 //                            an 8-byte {tag, index} granule with one write-through store;
-//     blocks [b, b + nq*b)   ball-query consumers, ordered by query range first, cloud second; each wave
-//                            polls the granules of its two queries, then sweeps the LDS copy of the cloud.
+//     blocks [b, b + c*b)    PERSISTENT ball-query consumers, c (= 1) per cloud (round 5): a consumer stages and bins its
+//                            cloud once and walks the 64-query ranges in publish order, each wave polling the granules
+//                            of its queries. (Rounds 2-4: one workgroup per range, 16 per cloud at the metric shape --
+//                            544 workgroups, 224 of them spinning on every idle CU for the whole chain, each re-staging
+//                            the cloud. Now 2 b = 64 workgroups; the step time is the same, 192 CUs stay free.)
 // Hand-off: form R2 of the CDNA programming guide (Guideline 16) -- the data is the flag, agent-scope
 // relaxed 8-byte atomics on both sides, no fences; the granule array is zeroed on the stream before the
 // launch, tag = 1. Every workgroup asks for more than half of the CU's LDS, so producers never share
@@ -48,6 +51,8 @@ namespace pn2 {
 constexpr int kFusedThreads = 512;
 constexpr int kFusedMaxClouds = 128;            // producers must leave most CUs to the consumers
 constexpr size_t kFusedMinLds = 82 * 1024;      // > 160 KiB / 2: one workgroup per CU
+constexpr int kFusedConsumers = 1;              // persistent consumer workgroups per cloud: 1 / 2 / 4 / 16 measured 397.6 / 398.0 / 398.5 /
+                                                // 398.4 us per step at the metric shape (profiles/r05/fused_consumers.txt)
 
 
 // LPQ: lanes per query of the cell-list consumers; 0 = sweep consumers (clouds whose cell list does not fit
@@ -56,7 +61,7 @@ constexpr size_t kFusedMinLds = 82 * 1024;      // > 160 KiB / 2: one workgroup 
 constexpr int fused_pruned_gs(int P) { return P == 8 ? 2 : 4; }       // slots per group at 16 / 32 slots per thread
 template <int P, int LPQ, bool PRUNED = false>
 __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, int m, int Q, int nsample, float thr,
-                                                                 float radius, int qpb, unsigned tag,
+                                                                 float radius, int qpb, int cpc, unsigned tag,
                                                                  const float *__restrict__ xyz,
                                                                  unsigned long long *__restrict__ tagged,
                                                                  int *__restrict__ fps_idx,
@@ -102,16 +107,24 @@ __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, i
 #ifdef PN2_FUSED_LAB_NO_CONSUMERS
         return;
 #endif
+        // PERSISTENT consumers (round 5): cpc workgroups per cloud; consumer c stages (and bins) its cloud ONCE and walks the
+        // query ranges c, c + cpc, c + 2 cpc, ... in the order the producer publishes them. (Rounds 2-4 launched one workgroup per
+        // RANGE, m / 64 = 16 per cloud at the metric shape: 512 workgroups spinning on 224 CUs, each re-staging the cloud.)
         const int id = blk - b;
-        const int cloud = id % b;                // query range first, cloud second: the consumers that can
+        const int cloud = id % b;                // consumer number first, cloud second: the consumers that can
         const int q0 = (id / b) * qpb;           // start earliest are dispatched first
-        if (LPQ == 0)
-            bq_block_body<true, true, true>(n, m, nsample, thr, cloud, q0, min(q0 + qpb, m), xyz, nullptr, tagged,
-                                            new_xyz, idx, pts_cnt, grouped, subtract, smem, tag, 0, status);
-        else
+        const int stride = cpc * qpb;
+        if (LPQ == 0) {
+            if (bq_block_body<true, true, true>(n, m, nsample, thr, cloud, q0, min(q0 + qpb, m), xyz, nullptr, tagged,
+                                                new_xyz, idx, pts_cnt, grouped, subtract, smem, tag, 0, status))
+                for (int a = q0 + stride; a < m; a += stride)
+                    if (!bq_block_body<true, true, true, kBqThreads, true>(n, m, nsample, thr, cloud, a, min(a + qpb, m), xyz, nullptr, tagged,
+                                                                           new_xyz, idx, pts_cnt, grouped, subtract, smem, tag, 0, status)) break;
+        } else {
             bq_cells_block_body<kFusedThreads, (LPQ ? LPQ : 8), true, true>(n, m, nsample, thr, radius, cloud, q0,
                                                                           min(q0 + qpb, m), xyz, nullptr, tagged, new_xyz,
-                                                                          idx, pts_cnt, grouped, subtract, smem, tag, status);
+                                                                          idx, pts_cnt, grouped, subtract, smem, tag, status, stride);
+        }
 #ifdef PN2_FUSED_LAB_TIMES
         if (threadIdx.x == 0) atomicMax(status + 3, (unsigned)__builtin_amdgcn_s_memrealtime());
 #endif
@@ -129,13 +142,14 @@ static size_t fused_cells_lds(int n, int nsample, int lpq)
 template <int P, int LPQ, bool PRUNED = false>
 static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, float radius, unsigned tag, const float *xyz,
                         unsigned long long *ws, int *fps_idx, float *new_xyz, int *idx, int *pts_cnt,
-                        float *grouped, int subtract, hipStream_t st)
+                        float *grouped, int subtract, hipStream_t st, int consumers)
 {
     constexpr int kGran = kBqWaves * kBqQpw;
-    // consumers: about one per free CU and query range; a range is a multiple of 16 queries
+    // a query range is 64 queries (a multiple of 16); `consumers` persistent workgroups per cloud share the ranges
     int qpb = 64;
     if (qpb > m) qpb = ((m + kGran - 1) / kGran) * kGran;
-    const int nq = (m + qpb - 1) / qpb;
+    const int nranges = (m + qpb - 1) / qpb;
+    const int nq = consumers <= 0 ? (nranges < kFusedConsumers ? nranges : kFusedConsumers) : consumers < nranges ? consumers : nranges;
     size_t lds_f = PRUNED ? fps_pruned_lds_bytes(2 * P)
                           : 256 + sizeof(float4) * (size_t)kFusedThreads * P;
     size_t lds_q = LPQ ? fused_cells_lds(n, nsample, LPQ)
@@ -156,7 +170,7 @@ static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, floa
         if (e != hipSuccess) return (int)e;
         tag = 1u;
     }
-    if (int rc = launch(kern, dim3(b + nq * b), dim3(kFusedThreads), lds, st, b, n, m, Q, nsample, thr, radius, qpb, tag, xyz, ws,
+    if (int rc = launch(kern, dim3(b + nq * b), dim3(kFusedThreads), lds, st, b, n, m, Q, nsample, thr, radius, qpb, nq, tag, xyz, ws,
                        fps_idx, new_xyz, idx, pts_cnt, grouped, subtract)) return rc;
     return PN2_OK;
 }
@@ -172,7 +186,7 @@ extern "C" long long pn2_sample_and_group_ws_bytes(int b, int m)
 
 static int sample_and_group_common(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws, unsigned tag,
                                    int *fps_idx, float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz,
-                                   int subtract_centroid, void *stream, int fps_variant = PN2_FPS_AUTO)
+                                   int subtract_centroid, void *stream, int fps_variant = PN2_FPS_AUTO, int consumers = 0)
 {
     using namespace pn2;
     if (!(radius > 0.0f) || nsample <= 0 || m <= 0) return PN2_E_ARG;
@@ -202,7 +216,7 @@ static int sample_and_group_common(int b, int n, int m, float radius, int nsampl
 #define PN2_FUSED_CASE(PP, LL, PR)                                                                                     \
     if (P == PP && lpq == LL && pruned == PR)                                                                          \
         return launch_fused<PP, LL, PR>(b, n, m, Q, nsample, thr, radius, tag, xyz, w, fps_idx, new_xyz, idx, pts_cnt,   \
-                                        grouped_xyz, subtract_centroid, st)
+                                        grouped_xyz, subtract_centroid, st, consumers)
 #define PN2_FUSED_P(PP, PR) PN2_FUSED_CASE(PP, 0, PR); PN2_FUSED_CASE(PP, 8, PR); PN2_FUSED_CASE(PP, 16, PR); PN2_FUSED_CASE(PP, 32, PR)
     PN2_FUSED_P(1, false); PN2_FUSED_P(2, false); PN2_FUSED_P(4, false); PN2_FUSED_P(8, false); PN2_FUSED_P(16, false);
     PN2_FUSED_P(8, true); PN2_FUSED_P(16, true);
@@ -232,14 +246,16 @@ extern "C" int pn2_sample_and_group_xyz_gen(int b, int n, int m, float radius, i
                                    grouped_xyz, subtract_centroid, stream);
 }
 
-// The same launch with the FPS tier of the producers chosen by the caller (PN2_FPS_AUTO / _FULL / _PRUNED, see
-// pn2_farthest_point_sample_variant; PN2_E_ARG for _PRUNED outside 2049..8192 rank slots). generation 0 = clear `ws` first.
+// The same launch with the FPS tier of the producers (PN2_FPS_AUTO / _FULL / _PRUNED, see pn2_farthest_point_sample_variant;
+// PN2_E_ARG for _PRUNED outside 2049..8192 rank slots) and the number of persistent consumer workgroups per cloud (0 = the
+// library's choice; more than one per 64 queries is clamped) chosen by the caller. generation 0 = clear `ws` first.
 extern "C" int pn2_sample_and_group_xyz_ex(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,
-                                           unsigned generation, int fps_variant, int *fps_idx, float *new_xyz, int *idx,
-                                           int *pts_cnt, float *grouped_xyz, int subtract_centroid, void *stream)
+                                           unsigned generation, int fps_variant, int consumers, int *fps_idx, float *new_xyz,
+                                           int *idx, int *pts_cnt, float *grouped_xyz, int subtract_centroid, void *stream)
 {
+    if (consumers < 0) return PN2_E_ARG;
     return sample_and_group_common(b, n, m, radius, nsample, xyz, ws, generation, fps_idx, new_xyz, idx, pts_cnt, grouped_xyz,
-                                   subtract_centroid, stream, fps_variant);
+                                   subtract_centroid, stream, fps_variant, consumers);
 }
 
 // Offset (bytes) of the launch status word inside `ws`: 0 = ok, 1 = a consumer gave up waiting for its
