@@ -89,8 +89,7 @@ def test_sample_and_group_at_config_shape(cuda, oracle, level):
     """pointnet_util.sample_and_group (the overlapped launch when the shape allows it) == oracle composition
     (pointnet_util.py:40-50: FPS, gather, ball query, group, centroid subtraction, xyz-first concat)."""
     from pointnet2_amd.pointnet_util import sample_and_group
-    label, b, n, npoint, scales, c = level
-    b = min(b, 8)
+    label, b, n, npoint, scales, c = level                # the config's REAL batch: the overlapped launch runs with its real producer count
     xyz = _cloud(label, b, n, 800 + len(label))
     feats = np.random.default_rng(6).standard_normal((b, n, c)).astype(np.float32) if c else None
     radius, ns = scales[0]
