@@ -195,6 +195,7 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
     }
 
     const unsigned low0 = (unsigned)(NS - 1 - t * P);   // key low word of this thread's slot 0: larger = smaller rank
+    int kprev = 0;                                     // index selected by the previous round (stored one round late)
     // one round; `par` (the partial buffer parity) is a literal at both call sites so the slot
     // addresses fold to constants (scalar address arithmetic costs 4-cycle issue slots)
     auto round = [&](const int j, const int par) __attribute__((always_inline)) {
@@ -253,10 +254,21 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
         // block arg-max: v_max_f64 tournament over the W keys, every wave redundantly (wave-uniform data)
         const double *dslot = reinterpret_cast<const double *>(slot);
         unsigned win;                                  // low word of the winning key = mirror index
+        // the PREVIOUS round's index leaves under the latency of the key reads (behind the winner read its address
+        // arithmetic and exec juggling sat on the serial path: 14 cycles per round, scripts/ubench_xchg.hip kinds 14 / 15)
+        auto store_prev = [&]() __attribute__((always_inline)) {
+            if (t == 0 && j > 1) {
+                dst[j - 1] = kprev;
+                if (PUBLISH)
+                    __hip_atomic_store(gtag + (j - 1), ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)kprev,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
         if (W >= 16) {
         // lane i reads key i mod W (ONE LDS read per wave instead of W/2 broadcast reads) and the W
         // keys are combined across lanes with log2(W) butterfly DPP steps: every lane ends with the max
         double kq = dslot[lane & (W - 1)];
+        store_prev();
         if (W >= 2) kq = dpp_max_f64_step<0xB1>(kq);    // lane ^ 1
         if (W >= 4) kq = dpp_max_f64_step<0x4E>(kq);    // lane ^ 2
         if (W >= 8) kq = dpp_max_f64_step<0x141>(kq);   // other quad of the half row
@@ -267,6 +279,7 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
         double key[W];
 #pragma unroll
         for (int i = 0; i < W; ++i) key[i] = dslot[i];
+        store_prev();
 #pragma unroll
         for (int st = 1; st < W; st <<= 1)
 #pragma unroll
@@ -285,12 +298,7 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
             sx = src[(size_t)k * 3 + 0]; sy = src[(size_t)k * 3 + 1]; sz = src[(size_t)k * 3 + 2];
             sxy.x = sx; sxy.y = sy; syy.x = sy; szk.x = sz;
         }
-        if (t == 0) {
-            dst[j] = k;
-            if (PUBLISH)
-                __hip_atomic_store(gtag + j, ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)k, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
+        kprev = k;
     };
     int j = 1;
     for (; j + 1 < m; j += 2) {
@@ -298,6 +306,12 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
         round(j + 1, 0);
     }
     if (j < m) round(j, 1);
+    if (t == 0 && m > 1) {                             // the last round's index
+        dst[m - 1] = kprev;
+        if (PUBLISH)
+            __hip_atomic_store(gtag + (m - 1), ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)kprev, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
     fps_gather_epilogue<T>(m, src, dst, dxyz);
 }
 

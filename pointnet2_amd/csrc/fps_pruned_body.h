@@ -41,6 +41,9 @@
 
 namespace pn2 {
 
+#ifndef PN2_PR_DISPATCH
+#define PN2_PR_DISPATCH 1
+#endif
 constexpr int kPrT = 256;              // threads of the pruned tier
 constexpr int kPrW = kPrT / PN2_WAVE;  // 4 waves: one per SIMD
 constexpr int kPrBins = 64;            // histogram bins per axis (= one wave)
@@ -286,6 +289,7 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
 #pragma unroll
     for (int q = 0; q < GW / 2; ++q) gp[q] = 0.0;
     double wave_key = 0.0;                              // lane 63: the wave's key (cached while no group of the wave changes)
+    int kprev = 0;                                      // index selected by the previous round (stored one round late, below)
 
     auto round = [&](const int j, const int par) __attribute__((always_inline)) {
         // which groups can the new sample change? (all lanes, lane l = group l)
@@ -335,18 +339,59 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
                         asm("v_max_f64 %0, %1, %2" : "=v"(kd[i]) : "v"(kd[i]), "v"(kd[i + st]));
                 gk[gi] = kd[0];
             };
-#define PN2_PR_GROUP(g) if (mybits & (1u << (g))) update_group(std::integral_constant<int, g>())
-            // nested bit tests (structured: hipcc turns a switch on the bit number, or a loop over the set bits, into flag
-            // variables and copies of every slot register): six scalar tests for the usual single touched group instead of eight
 #define PN2_PR_PAIR(q) asm("v_max_f64 %0, %1, %2" : "=v"(gp[q]) : "v"(gk[2 * (q)]), "v"(gk[2 * (q) + 1]))
+#define PN2_PR_ONE(g) { update_group(std::integral_constant<int, g>()); PN2_PR_PAIR((g) / 2); }
+#define PN2_PR_GROUP(g) if (rest & (1u << (g))) update_group(std::integral_constant<int, g>())
+            // Scalar tests and branches, not vector work, are what a touched wave spends its time on (a taken or untaken
+            // s_cmp + s_cbranch pair costs as much as four vector instructions on a lone wave; the update of a group is 13).
+            // The LOWEST touched group -- the only one in most rounds -- is found by a binary search on its isolated bit
+            // (three compare + branch pairs); further groups take nested bit tests (structured: hipcc turns a switch on
+            // the bit number, or a loop over the set bits, into flag variables and copies of every slot register).
+#if PN2_PR_DISPATCH == 2
+            for (unsigned bits = mybits; bits != 0u;) {
+                const unsigned lowbit = bits & (0u - bits);
+                bits ^= lowbit;
+                if (lowbit < 0x10u) {
+                    if (lowbit < 0x04u) { if (lowbit == 0x01u) PN2_PR_ONE(0) else PN2_PR_ONE(1) }
+                    else { if (lowbit == 0x04u) PN2_PR_ONE(2) else PN2_PR_ONE(3) }
+                } else {
+                    if (lowbit < 0x40u) { if (lowbit == 0x10u) PN2_PR_ONE(4) else PN2_PR_ONE(5) }
+                    else { if (lowbit == 0x40u) PN2_PR_ONE(6) else PN2_PR_ONE(7) }
+                }
+            }
+#elif PN2_PR_DISPATCH == 1
+            const unsigned lowbit = mybits & (0u - mybits);
+            const unsigned rest = mybits ^ lowbit;
+            if (lowbit < 0x10u) {
+                if (lowbit < 0x04u) { if (lowbit == 0x01u) PN2_PR_ONE(0) else PN2_PR_ONE(1) }
+                else { if (lowbit == 0x04u) PN2_PR_ONE(2) else PN2_PR_ONE(3) }
+            } else {
+                if (lowbit < 0x40u) { if (lowbit == 0x10u) PN2_PR_ONE(4) else PN2_PR_ONE(5) }
+                else { if (lowbit == 0x40u) PN2_PR_ONE(6) else PN2_PR_ONE(7) }
+            }
+            if (rest != 0u) {
+                if (rest & 0x0fu) {
+                    if (rest & 0x03u) { PN2_PR_GROUP(1); PN2_PR_PAIR(0); }
+                    if (rest & 0x0cu) { PN2_PR_GROUP(2); PN2_PR_GROUP(3); PN2_PR_PAIR(1); }
+                }
+                if (rest & 0xf0u) {
+                    if (rest & 0x30u) { PN2_PR_GROUP(4); PN2_PR_GROUP(5); PN2_PR_PAIR(2); }
+                    if (rest & 0xc0u) { PN2_PR_GROUP(6); PN2_PR_GROUP(7); PN2_PR_PAIR(3); }
+                }
+            }
+#else
+#define PN2_PR_GROUP0(g) if (mybits & (1u << (g))) update_group(std::integral_constant<int, g>())
             if (mybits & 0x0fu) {
-                if (mybits & 0x03u) { PN2_PR_GROUP(0); PN2_PR_GROUP(1); PN2_PR_PAIR(0); }
-                if (mybits & 0x0cu) { PN2_PR_GROUP(2); PN2_PR_GROUP(3); PN2_PR_PAIR(1); }
+                if (mybits & 0x03u) { PN2_PR_GROUP0(0); PN2_PR_GROUP0(1); PN2_PR_PAIR(0); }
+                if (mybits & 0x0cu) { PN2_PR_GROUP0(2); PN2_PR_GROUP0(3); PN2_PR_PAIR(1); }
             }
             if (mybits & 0xf0u) {
-                if (mybits & 0x30u) { PN2_PR_GROUP(4); PN2_PR_GROUP(5); PN2_PR_PAIR(2); }
-                if (mybits & 0xc0u) { PN2_PR_GROUP(6); PN2_PR_GROUP(7); PN2_PR_PAIR(3); }
+                if (mybits & 0x30u) { PN2_PR_GROUP0(4); PN2_PR_GROUP0(5); PN2_PR_PAIR(2); }
+                if (mybits & 0xc0u) { PN2_PR_GROUP0(6); PN2_PR_GROUP0(7); PN2_PR_PAIR(3); }
             }
+#undef PN2_PR_GROUP0
+#endif
+#undef PN2_PR_ONE
 #undef PN2_PR_PAIR
 #undef PN2_PR_GROUP
             // lane key = max over the four cached pair keys (only the touched pairs were recomputed above)
@@ -362,6 +407,14 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
         double key[W];
 #pragma unroll
         for (int i = 0; i < W; ++i) key[i] = dslot[i];
+        // the PREVIOUS round's index leaves here, under the latency of the key reads (behind the mirror read its address
+        // arithmetic and exec juggling were 14 cycles of every round: scripts/ubench_xchg.hip, kinds 14 / 15)
+        if (t == 0 && j > 1) {
+            dst[j - 1] = kprev;
+            if (PUBLISH)
+                __hip_atomic_store(gtag + (j - 1), ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)kprev,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #pragma unroll
         for (int st = 1; st < W; st <<= 1)
 #pragma unroll
@@ -371,13 +424,7 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
         vstar = __int_as_float(__double2hiint(key[0]));
         const float4 s = lds_rank[win];                // same address in every lane: LDS broadcast
         sxy.x = s.x; sxy.y = s.y; syy.x = s.y; szk.x = s.z; szk.y = s.w;
-        if (t == 0) {
-            const int k = __float_as_int(s.w);
-            dst[j] = k;
-            if (PUBLISH)
-                __hip_atomic_store(gtag + j, ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)k, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
+        kprev = __float_as_int(s.w);
     };
     int j = 1;
     for (; j + 1 < m; j += 2) {
@@ -385,6 +432,12 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
         round(j + 1, 0);
     }
     if (j < m) round(j, 1);
+    if (t == 0 && m > 1) {                              // the last round's index
+        dst[m - 1] = kprev;
+        if (PUBLISH)
+            __hip_atomic_store(gtag + (m - 1), ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)kprev, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
     fps_gather_epilogue<T>(m, src, dst, dxyz);
 }
 
