@@ -214,6 +214,20 @@ int pn2_fp_mlp(int b, int n, int m, int c2, int c1, const float *points2, const 
 int pn2_farthest_point_sample_gather(int b, int n, int m, const float *inp, float *temp, int *out, float *out_xyz,
                                      void *stream);
 
+/* farthest_point_sample (+ gather_point when out_xyz is not NULL) for input the caller BELIEVES to be in farthest-point
+ * order already -- the second and later levels of every network sample from the previous level's samples
+ * (models/pointnet2_sem_seg.py:28-31, pointnet2_cls_ssg.py:27-29), whose first m points are, up to exact ties under the
+ * renumbered tie rule (tf_sampling_g.cu:146,153-163) and clouds that ran out of distinct points, selected as 0, 1, ..., m-1.
+ * The belief is CHECKED in parallel (n independent prefix-minimum rows, no dependent rounds) and the chain runs only for
+ * the clouds where it fails: the result is pn2_farthest_point_sample's for any input. ws: pn2_fps_ordered_ws_bytes(b)
+ * bytes, zeroed ONCE by the caller (every call leaves it zeroed). Outside 2 <= m <= min(n, 1024), n <= 2048 the call is
+ * the plain operator (PN2_E_TOO_LARGE beyond 16384 points, where that one needs its temp buffer). */
+long long pn2_fps_ordered_ws_bytes(int b);
+int pn2_farthest_point_sample_ordered(int b, int n, int m, const float *inp, int *out, float *out_xyz, void *ws, void *stream);
+/* test hook: the check alone. flags (b ints, zeroed by the caller) comes back 1 exactly for the clouds whose sampling is not
+ * 0 .. m-1. PN2_E_ARG outside the short cut's envelope. */
+int pn2_fps_ordered_check(int b, int n, int m, const float *inp, int *flags, void *stream);
+
 /* query_ball_point + group_point(xyz1, idx) - centroid in one pass over the
  * LDS-resident cloud: what pointnet_util.py:44-46 computes with three ops.
  * grouped_xyz (b,m,nsample,3) = xyz1[idx] - xyz2[:, :, None] when subtract_centroid!=0,
@@ -280,7 +294,10 @@ int pn2_farthest_point_sample_variant(int variant, int b, int n, int m, const fl
  * granules and a status word.
  * Returns PN2_E_TOO_LARGE for shapes outside the overlapped launch's envelope (b > 128, n > 8192,
  * n < 64, nsample > 256) and when the device cannot hold all b producer workgroups plus a consumer at once
- * (occupancy query at launch): use pn2_farthest_point_sample_gather + pn2_query_ball_group_xyz then. */
+ * (occupancy query at launch): use pn2_farthest_point_sample_gather + pn2_query_ball_group_xyz then.
+ * Clouds too large for a cell list beside their sorted copy in LDS (n > ~7000) are served by exactly those two launches from
+ * inside this call (their consumers would have to sweep the whole cloud per query and no longer hide under the chain:
+ * 478 us against 459 at b = 8, 8192 -> 1024); same outputs, ws untouched. */
 int pn2_sample_and_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,
                              int *fps_idx, float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz,
                              int subtract_centroid, void *stream);
@@ -299,7 +316,8 @@ int pn2_sample_and_group_xyz_gen(int b, int n, int m, float radius, int nsample,
 long long pn2_sample_and_group_status_offset(int b, int m);
 /* pn2_sample_and_group_xyz[_gen] with the organisation of the launch chosen by the caller (outputs never depend on it):
  * fps_variant = FPS tier of the producer workgroups (PN2_FPS_AUTO / PN2_FPS_FULL / PN2_FPS_PRUNED as in
- * pn2_farthest_point_sample_variant); consumers = persistent consumer workgroups per cloud (0 = the library's choice; each
+ * pn2_farthest_point_sample_variant); consumers = persistent consumer workgroups per cloud (0 = the library's choice, which
+ * includes the two launches for clouds beyond ~7000 points; > 0 = always the overlapped launch; each
  * stages its cloud once and walks the 64-query ranges c, c + consumers, ... in publish order; the grid is
  * b * (1 + consumers) workgroups). generation 0 = clear `ws` first. */
 int pn2_sample_and_group_xyz_ex(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws, unsigned generation,
@@ -322,6 +340,12 @@ int pn2_sa_level(int b, int n, int m, float radius, int nsample, int cfeat, cons
 int pn2_fp_level(int b, int n, int m, int c2, int c1, const float *xyz1, const float *xyz2, const float *points2,
                  const float *points1, int nlayers, const int *widths, int kind, const float *wpacked, const float *bpacked,
                  float *dist, int *idx, float *out, void *ws, void *stream);
+/* pn2_sa_level for a level whose xyz is believed to be in farthest-point order (the previous level's new_xyz):
+ * pn2_farthest_point_sample_ordered (ws_ordered: its workspace) + pn2_query_ball_group_xyz + pn2_sa_mlp3_maxpool. Same
+ * outputs as pn2_sa_level for any input. */
+int pn2_sa_level_ordered(int b, int n, int m, float radius, int nsample, int cfeat, const float *xyz, const float *points,
+                         void *ws_ordered, int c1, int c2, int c3, const float *wpacked, const float *bpacked, int *fps_idx,
+                         float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz, float *out, void *ws_mlp, void *stream);
 
 /* ---- training mode of the shared MLPs (second half) ---------------------------
  *

@@ -29,7 +29,11 @@ _ll = ctypes.c_longlong
 _SIGNATURES = {
     "pn2_farthest_point_sample": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "pn2_farthest_point_sample_gather": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pn2_farthest_point_sample_ordered": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pn2_sa_level_ordered": [_i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pn2_fps_ordered_check": [_i, _i, _i, _vp, _vp, _vp],
     "pn2_fps_temp_floats": [_i, _i],
+    "pn2_fps_ordered_ws_bytes": [_i],
     "pn2_gather_point": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "pn2_gather_point_grad": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "pn2_prob_sample": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
@@ -90,6 +94,7 @@ _SIGNATURES = {
 }
 _RESTYPES = {
     "pn2_fps_temp_floats": ctypes.c_longlong,
+    "pn2_fps_ordered_ws_bytes": ctypes.c_longlong,
     "pn2_det_grad_ws_bytes": ctypes.c_longlong,
     "pn2_seg_grad_ws_bytes": ctypes.c_longlong,
     "pn2_sample_and_group_ws_bytes": ctypes.c_longlong,

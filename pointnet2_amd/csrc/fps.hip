@@ -61,6 +61,161 @@ __global__ __launch_bounds__(kPrT) void fps_pruned_kernel(int n, int m, int Q, c
 }
 
 // ---------------------------------------------------------------------------
+// Input that is ALREADY in farthest-point order (round 5; pn2_farthest_point_sample_ordered).
+// The second and later levels of every network sample from the previous level's samples
+// (pointnet2_sem_seg.py:28-31: l2 = sa(l1_xyz, ...)): the first m of them, in the order level 1 picked them, are a
+// farthest-point order of the subset with the same fp32 running distances, so farthest_point_sample(m, new_xyz_1) is
+// 0, 1, ..., m-1 -- unless the reference's tie rule (smallest (k mod 512, k), tf_sampling_g.cu:146,153-163), applied to the
+// RENUMBERED points, breaks an exact tie the other way, or the cloud has run out of distinct points (every further sample
+// is index 0). Whether it is the identity is decidable without the chain: sample i is selected at step i iff no other
+// point j beats it there, i.e. iff for every j != i the running distance r_i(j) = min_{s<i} d(j, s) and the selection
+// value v_i = r_i(i) satisfy (r_i(j), tie key j) < (v_i, tie key i). All r and v are prefix minima of the n x m distance
+// matrix: n independent rows, no reduction. fps_verify_kernel evaluates them (parts x b workgroups) and flags a cloud on
+// the first violation; the chain kernel behind it writes 0..m-1 for unflagged clouds and runs the real chain for
+// flagged ones, so the result never depends on the guess.
+// ---------------------------------------------------------------------------
+constexpr int kVerT = 1024;
+// a < b ? x : y as a bit select on a mask the compiler cannot see through (it turned the plain select into an exec-mask
+// branch around the computation of x: one exposed LDS latency per step; a volatile barrier on x serialised the reads)
+__device__ __forceinline__ float pick_lt(int a, int b, float x, float y)
+{
+    unsigned sel = (unsigned)((a - b) >> 31);                  // all ones when a < b (|a - b| < 2^31 here)
+    asm("" : "+v"(sel));
+    return __uint_as_float((__float_as_uint(x) & sel) | (__float_as_uint(y) & ~sel));
+}
+// Work decomposition: n x (m - 1) prefix-minimum entries per cloud would be m - 1 DEPENDENT steps per thread if a thread
+// owned a row (60 us at m = 256: one LDS read + ten dependent vector instructions per step and nothing to overlap them with).
+// A row is therefore cut into C chunks of L source samples (C a power of two <= 16, L ~ 32): chunk minima first, an exclusive
+// minimum over the earlier chunks as the carry, then the chunk's own steps against the selection values -- 2 L dependent
+// steps. A workgroup is C waves = C chunks x 64 points (sample reads are LDS broadcasts; small workgroups, because the work of
+// a cloud is vector-issue bound on the CUs it lands on: 1024-thread workgroups measured 10.8 us at m = 128).
+// The selection values v_i = r_i(i) are rows of the same matrix; every workgroup first rebuilds them for its cloud
+// (triangular, the same chunks, LDS atomic minimum of the fp32 bit patterns: the values are >= 0) -- m^2 / 2 distance tests
+// next to the workgroup's own 64 x 2 m, cheaper than a launch boundary.
+__global__ __launch_bounds__(kVerT) void fps_verify_kernel(int n, int m, int C, int L, const float *__restrict__ xyz, int *__restrict__ flags)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *sm = reinterpret_cast<float4 *>(smem);             // [m]: x, y, z of sample e and the value sample e + 1 was selected with
+    float *part = reinterpret_cast<float *>(sm + m);           // [C][64] chunk minima
+    const int cloud = blockIdx.y, t = threadIdx.x;
+    const float *__restrict__ src = xyz + (size_t)cloud * n * 3;
+    const int T = C * 64;                                      // one wave per chunk, 64 points per workgroup
+    for (int i = t; i < m; i += T)
+        sm[i] = make_float4(src[(size_t)i * 3 + 0], src[(size_t)i * 3 + 1], src[(size_t)i * 3 + 2], 1e38f);   // 1e38: tf_sampling_g.cu:118
+    __syncthreads();
+    const int E = m - 1;                                       // source samples 0 .. m - 2 (the last sample updates nothing)
+    // selection values: v_i = min_{e < i} d(i, e), i = 1 .. m - 1 (tf_sampling_g.cu:144)
+    const int mpad = (m + 63) & ~63;
+    for (int item = t; item < mpad * C; item += T) {
+        // c is wave-uniform (mpad and the wave's first item are multiples of 64); the compiler is told so, the loops below are
+        // scalar-controlled and hand-blocked by 8 (a runtime-bound loop is not unrolled for this target: one LDS read and ten
+        // dependent instructions per step otherwise)
+        const int c = __builtin_amdgcn_readfirstlane(item / mpad), i = item - c * mpad;
+        const int e0 = c * L;
+        const int eend = min(min(e0 + L, E), __builtin_amdgcn_readfirstlane(i | 63));   // no lane of the wave has a source at or beyond it
+        if (e0 >= eend) continue;
+        const float4 p = sm[min(i, m - 1)];
+        float r = 1e38f;
+        int eb = e0;
+        for (; eb + 8 <= eend; eb += 8) {                        // whole blocks: eight independent LDS reads in flight
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 q = sm[eb + u];
+                r = vmin_f32(pick_lt(eb + u, i, sqdist(p.x, p.y, p.z, q.x, q.y, q.z), 1e38f), r);
+            }
+        }
+        for (; eb < eend; ++eb) {
+            const float4 q = sm[eb];
+            r = vmin_f32(pick_lt(eb, i, sqdist(p.x, p.y, p.z, q.x, q.y, q.z), 1e38f), r);
+        }
+        if (i >= 1 && i < m) atomicMin(reinterpret_cast<unsigned *>(&sm[i - 1].w), __float_as_uint(r));
+    }
+    __syncthreads();
+    // every point against every step
+    constexpr int JB = 64;
+    const int c = __builtin_amdgcn_readfirstlane(t / JB), jl = t - c * JB;
+    const int j = blockIdx.x * JB + jl;
+    const bool live = j < n;
+    const int jc = live ? j : 0;
+    const float px = src[(size_t)jc * 3 + 0], py = src[(size_t)jc * 3 + 1], pz = src[(size_t)jc * 3 + 2];
+    const int e0 = c * L, e1 = min(e0 + L, E);
+    float r = 1e38f;
+    if (C > 1) {                                               // kernel-uniform
+        float a = 1e38f;
+        int eb = e0;
+        for (; eb + 8 <= e1; eb += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 q = sm[eb + u];
+                a = vmin_f32(sqdist(px, py, pz, q.x, q.y, q.z), a);
+            }
+        }
+        for (; eb < e1; ++eb) {
+            const float4 q = sm[eb];
+            a = vmin_f32(sqdist(px, py, pz, q.x, q.y, q.z), a);
+        }
+        part[c * JB + jl] = a;
+        __syncthreads();
+        for (int c2 = 0; c2 < c; ++c2) r = vmin_f32(part[c2 * JB + jl], r);
+    }
+    const unsigned tkj = ((unsigned)(j & (kRefThreads - 1)) << 22) | (unsigned)(j >> 9);
+    // a coordinate that is not a finite number: v_min drops NaNs where the chain's arg-max sees them -- leave it to the chain
+    int bad = !(__builtin_fabsf(px) <= 3.402823466e38f && __builtin_fabsf(py) <= 3.402823466e38f && __builtin_fabsf(pz) <= 3.402823466e38f);
+    auto step = [&](int e) {
+        const float4 q = sm[e];                                     // sample e and the value sample e + 1 was selected with
+        r = vmin_f32(sqdist(px, py, pz, q.x, q.y, q.z), r);         // r_i(j), i = e + 1
+        const int i = e + 1;
+        const unsigned tki = ((unsigned)(i & (kRefThreads - 1)) << 22) | (unsigned)(i >> 9);
+        bad |= (int)(j != i) & ~((int)(r < q.w) | ((int)(r == q.w) & (int)(tkj >= tki)));   // (value, key) order of tf_sampling_g.cu:146,153-163
+    };
+    int eb = e0;
+    for (; eb + 8 <= e1; eb += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) step(eb + u);
+    }
+    for (; eb < e1; ++eb) step(eb);
+    if (live && (bad & 1)) flags[cloud] = 1;
+}
+
+// chunks of ~32 source samples, at most 16 of them
+static void fps_verify_shape(int m, int &C, int &L)
+{
+    const int E = m - 1;
+    C = 1;
+    while (C < 16 && C * 32 < E) C <<= 1;
+    L = (E + C - 1) / C;
+}
+
+static int launch_verify(int b, int n, int m, const float *inp, int *flags, hipStream_t st)
+{
+    int C, L;
+    fps_verify_shape(m, C, L);
+    return launch(fps_verify_kernel, dim3((n + 63) / 64, b), dim3(C * 64), sizeof(float4) * (size_t)m + sizeof(float) * C * 64, st, n, m, C,
+                  L, inp, flags);
+}
+
+// the chain behind the verifier: identity for unflagged clouds, the real chain (and a cleared flag) for the others
+template <int P>
+__global__ __launch_bounds__(256) void fps_reg_cond_kernel(int n, int m, int Q, const float *__restrict__ xyz, int *__restrict__ out,
+                                                           float *__restrict__ out_xyz, int *__restrict__ flags)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int cloud = blockIdx.x, t = threadIdx.x;
+    if (flags[cloud] == 0) {                                     // block-uniform
+        int *__restrict__ dst = out + (size_t)cloud * m;
+        for (int j = t; j < m; j += 256) dst[j] = j;
+        if (out_xyz) {
+            const float *__restrict__ src = xyz + (size_t)cloud * n * 3;
+            float *__restrict__ d = out_xyz + (size_t)cloud * m * 3;
+            for (int e = t; e < m * 3; e += 256) d[e] = src[e];
+        }
+        return;
+    }
+    fps_reg_body<256, P, true, false>(n, m, Q, cloud, xyz, out, out_xyz, nullptr, smem);
+    if (t == 0) flags[cloud] = 0;                                // the workspace is left as it was found
+}
+
+// ---------------------------------------------------------------------------
 // Generic tier: any n. Running distances in global `temp` (b*n floats), cloud
 // re-read from global/L2 each round, 64-bit (value, tie-key) reduction.
 // Slow path for clouds beyond the register tiers (n > 16384).
@@ -200,6 +355,15 @@ static int fps_launch_config(int T, int P, int b, int n, int m, const float *inp
     }
 }
 
+template <int P>
+static int launch_cond(int b, int n, int m, int Q, const float *inp, int *out, float *oxyz, int *flags, hipStream_t st)
+{
+    const size_t lds = 256 + sizeof(float4) * (size_t)256 * P;
+    auto kern = fps_reg_cond_kernel<P>;
+    if (int rc = allow_dynamic_lds(kern, lds)) return rc;
+    return launch(kern, dim3(b), dim3(256), lds, st, n, m, Q, inp, out, oxyz, flags);
+}
+
 }  // namespace pn2
 
 extern "C" long long pn2_fps_temp_floats(int b, int n)
@@ -253,6 +417,49 @@ extern "C" int pn2_farthest_point_sample_variant(int variant, int b, int n, int 
 {
     if (variant < PN2_FPS_AUTO || variant > PN2_FPS_PRUNED) return PN2_E_ARG;
     return fps_entry(b, n, m, inp, temp, out, out_xyz, stream, variant);
+}
+
+// farthest_point_sample for input the caller BELIEVES to be in farthest-point order already (the previous level's samples:
+// pointnet2_sem_seg.py:28-31, pointnet2_cls_ssg.py:27-29): verified in parallel, the chain runs only for clouds where the
+// belief is wrong -- the result is pn2_farthest_point_sample's whatever the input is. ws: pn2_fps_ordered_ws_bytes(b) bytes,
+// zeroed by the caller ONCE (every call leaves it zeroed). Outside 2 <= m <= min(n, 1024), n <= 2048 there is nothing to
+// gain and the call is pn2_farthest_point_sample_gather / pn2_farthest_point_sample (PN2_E_TOO_LARGE beyond the register
+// tiers, where that operator needs its temp buffer). out_xyz may be NULL.
+extern "C" long long pn2_fps_ordered_ws_bytes(int b) { return b > 0 ? (long long)b * 4 : 0; }
+
+extern "C" int pn2_farthest_point_sample_ordered(int b, int n, int m, const float *inp, int *out, float *out_xyz, void *ws,
+                                                 void *stream)
+{
+    using namespace pn2;
+    if (m <= 0 || b == 0) return PN2_OK;
+    if (b < 0 || n <= 0) return PN2_E_SHAPE;
+    if (!inp || !out) return PN2_E_NULL;
+    if (n > kMaxRegPoints) return PN2_E_TOO_LARGE;
+    if (m < 2 || m > n || m > 1024 || n > 2048) return fps_entry(b, n, m, inp, nullptr, out, out_xyz, stream);
+    if (!ws) return PN2_E_NULL;
+    if (b > 65535) return PN2_E_TOO_LARGE;
+    hipStream_t st = as_stream(stream);
+    int *flags = static_cast<int *>(ws);
+    if (int rc = launch_verify(b, n, m, inp, flags, st)) return rc;
+    const int Q = (n + kRefThreads - 1) / kRefThreads;
+    const int P = next_pow2((kRefThreads * Q + 255) / 256);
+    switch (P) {
+    case 2: return launch_cond<2>(b, n, m, Q, inp, out, out_xyz, flags, st);
+    case 4: return launch_cond<4>(b, n, m, Q, inp, out, out_xyz, flags, st);
+    case 8: return launch_cond<8>(b, n, m, Q, inp, out, out_xyz, flags, st);
+    default: return PN2_E_ARG;
+    }
+}
+
+// test hook: the verifier of pn2_farthest_point_sample_ordered alone. flags (b ints, zeroed by the caller) comes back 1 for the
+// clouds whose farthest-point sampling is NOT 0 .. m-1 (exactly those: the first violated step is where the chain leaves the
+// identity). Same envelope as the short cut: 2 <= m <= min(n, 1024), n <= 2048.
+extern "C" int pn2_fps_ordered_check(int b, int n, int m, const float *inp, int *flags, void *stream)
+{
+    using namespace pn2;
+    if (b <= 0 || !inp || !flags) return PN2_E_ARG;
+    if (m < 2 || m > n || m > 1024 || n > 2048 || b > 65535) return PN2_E_ARG;
+    return launch_verify(b, n, m, inp, flags, as_stream(stream));
 }
 
 // tuning / test hook: run the register tier with an explicit geometry

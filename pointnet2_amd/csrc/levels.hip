@@ -31,6 +31,18 @@ extern "C" int pn2_sa_level(int b, int n, int m, float radius, int nsample, int 
     return pn2_sa_mlp3_maxpool(b, n, m, nsample, cfeat, xyz, new_xyz, points, idx, c1, c2, c3, wpacked, bpacked, out, ws_mlp, stream);
 }
 
+extern "C" int pn2_sa_level_ordered(int b, int n, int m, float radius, int nsample, int cfeat, const float *xyz, const float *points,
+                                    void *ws_ordered, int c1, int c2, int c3, const float *wpacked, const float *bpacked,
+                                    int *fps_idx, float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz, float *out,
+                                    void *ws_mlp, void *stream)
+{
+    // xyz is (believed to be) the previous level's samples in the order they were picked (pointnet2_sem_seg.py:28-31): the
+    // dependent rounds are replaced by a parallel check, clouds that fail it run the chain (fps.hip)
+    if (int rc = pn2_farthest_point_sample_ordered(b, n, m, xyz, fps_idx, new_xyz, ws_ordered, stream)) return rc;
+    if (int rc = pn2_query_ball_group_xyz(b, n, m, radius, nsample, xyz, new_xyz, 1, idx, pts_cnt, grouped_xyz, stream)) return rc;
+    return pn2_sa_mlp3_maxpool(b, n, m, nsample, cfeat, xyz, new_xyz, points, idx, c1, c2, c3, wpacked, bpacked, out, ws_mlp, stream);
+}
+
 extern "C" int pn2_fp_level(int b, int n, int m, int c2, int c1, const float *xyz1, const float *xyz2, const float *points2,
                             const float *points1, int nlayers, const int *widths, int kind, const float *wpacked,
                             const float *bpacked, float *dist, int *idx, float *out, void *ws, void *stream)

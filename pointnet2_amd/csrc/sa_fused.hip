@@ -208,6 +208,15 @@ static int sample_and_group_common(int b, int n, int m, float radius, int nsampl
     if (n >= 1024)
         for (int cand : {8, 16, 32})
             if (fused_cells_lds(n, nsample, cand) <= 160 * 1024) { lpq = cand; break; }
+    // Clouds too large for a cell list beside their sorted copy (n > ~7000) leave the consumers the full sweep, and a sweep of
+    // 8192 points per query does not hide under the chain: one persistent consumer per cloud 968 us, sixteen 478 us, the
+    // two launches 459 us (sem_seg SA1, b = 8, 8192 -> 1024; profiles/r05/fused_sweep_consumers.txt). The library's own choice
+    // there is the two launches -- same outputs, `ws` untouched; an explicit consumer count still gets the overlapped launch.
+    if (lpq == 0 && n >= 1024 && consumers == 0) {
+        if (fps_variant < PN2_FPS_AUTO || fps_variant > PN2_FPS_PRUNED) return PN2_E_ARG;
+        if (int rc = pn2_farthest_point_sample_variant(fps_variant, b, n, m, xyz, nullptr, fps_idx, new_xyz, stream)) return rc;
+        return pn2_query_ball_group_xyz(b, n, m, radius, nsample, xyz, new_xyz, subtract_centroid, idx, pts_cnt, grouped_xyz, stream);
+    }
     // producers: the kd-grouped chain where it exists (4096 / 8192 rank slots) and the chain is long enough to pay for the
     // kd build (the rule of pn2_farthest_point_sample, fps.hip)
     if (fps_variant < PN2_FPS_AUTO || fps_variant > PN2_FPS_PRUNED) return PN2_E_ARG;

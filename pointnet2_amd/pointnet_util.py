@@ -15,7 +15,7 @@ in behaviour (concat order, pooling modes, weight formula).
 import torch
 import torch.nn as nn
 
-from .tf_sampling import farthest_point_sample, farthest_point_sample_gather, gather_point
+from .tf_sampling import farthest_point_sample, farthest_point_sample_gather, gather_point, mark_fps_ordered
 from .tf_grouping import (query_ball_point, group_point, knn_point, query_ball_group_xyz,
                           query_ball_group_xyz_msg, sample_and_group_xyz)
 from .tf_interpolate import three_nn, three_interpolate, fp_interp_concat
@@ -42,7 +42,7 @@ def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=Tr
     elif fused:
         _, new_xyz = farthest_point_sample_gather(npoint, xyz)                # :40 in one launch
     else:
-        new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))       # :40
+        new_xyz = mark_fps_ordered(gather_point(xyz, farthest_point_sample(npoint, xyz)))   # :40
     if fused and not knn:
         pass
     elif knn:
@@ -363,7 +363,7 @@ class PointnetSAModuleMSG(nn.Module):
         if fused:
             new_xyz, scales = self._group_scales(xyz, points is not None)
         else:
-            new_xyz = gather_point(xyz, farthest_point_sample(self.npoint, xyz))   # :173
+            new_xyz = mark_fps_ordered(gather_point(xyz, farthest_point_sample(self.npoint, xyz)))   # :173
         outs = []
         for si, (radius, nsample, mlp) in enumerate(zip(self.radius_list, self.nsample_list, self.mlps)):
             if fused:

@@ -262,6 +262,16 @@ def sa_level(npoint, radius, nsample, xyz, points, packed, buffers=None):
         if buffers is not None:
             buffers.key, buffers.t = key, (fps_idx, new_xyz, idx, cnt, grouped, out, ws, temp)
     st = stream_ptr(dev)
+    from . import tf_sampling as TS
+    if TS.ordered_hint(xyz, m):
+        # xyz is the previous level's samples in the order they were picked: checked identity instead of the chain
+        with on_device(dev):
+            wso = TS.ordered_workspace(lib, dev, st, b)
+            _C.check(lib.pn2_sa_level_ordered(b, n, m, float(radius), ns, cfeat, ptr(xyz), ptr(points), ptr(wso),
+                                              packed.widths[0], packed.widths[1], packed.widths[2], ptr(packed.wp), ptr(packed.bp),
+                                              ptr(fps_idx), ptr(new_xyz), ptr(idx), ptr(cnt), ptr(grouped), ptr(out), ptr(ws), st),
+                     "sa_level_ordered")
+        return TS.mark_fps_ordered(new_xyz), out, idx, fps_idx, cnt, grouped
     with on_device(dev):
         if not G._OVERLAP[0]:
             # set_overlapped_launch(False) / PN2_OVERLAP=0 (what OverlappedLaunchError tells the user to do): no workspace ->
@@ -279,7 +289,7 @@ def sa_level(npoint, radius, nsample, xyz, points, packed, buffers=None):
                                   ptr(fps_idx), ptr(new_xyz), ptr(idx), ptr(cnt), ptr(grouped), ptr(out), ptr(ws), st), "sa_level")
         if ent is not None:
             G._fetch_status(ent)
-    return new_xyz, out, idx, fps_idx, cnt, grouped
+    return TS.mark_fps_ordered(new_xyz), out, idx, fps_idx, cnt, grouped
 
 
 def fp_level(xyz1, xyz2, points1, points2, packed, buffers=None):

@@ -269,7 +269,10 @@ def sample_and_group_xyz(npoint, radius, nsample, xyz, subtract_centroid=True):
     m, ns = int(npoint), int(nsample)
     dev = xyz.device
     lib = _C.lib()
-    if b == 0 or not _OVERLAP[0] or not (b <= 128 and 64 <= n <= 8192 and ns <= 256):
+    from .tf_sampling import mark_fps_ordered, ordered_hint
+    if b == 0 or not _OVERLAP[0] or not (b <= 128 and 64 <= n <= 8192 and ns <= 256) or ordered_hint(xyz, m):
+        # (input hinted to be in farthest-point order: a checked identity + the ball queries in two launches beats a chain
+        # of m dependent rounds -- tf_sampling.farthest_point_sample_gather follows the hint)
         return _two_launch_path(m, radius, ns, xyz, subtract_centroid)
     fps_idx = torch.empty((b, m), dtype=torch.int32, device=dev)
     new_xyz = torch.empty((b, m, 3), dtype=torch.float32, device=dev)
@@ -296,7 +299,7 @@ def sample_and_group_xyz(npoint, radius, nsample, xyz, subtract_centroid=True):
                 return _two_launch_path(m, radius, ns, xyz, subtract_centroid)
             _C.check(rc, "sample_and_group_xyz")
             _fetch_status(ent)
-    return fps_idx, new_xyz, idx, cnt, grouped
+    return fps_idx, mark_fps_ordered(new_xyz), idx, cnt, grouped
 
 
 def select_top_k(k, dist):

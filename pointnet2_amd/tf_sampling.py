@@ -101,13 +101,63 @@ def set_fps_variant(variant=FPS_AUTO):
     _FPS_VARIANT[0] = int(variant)
 
 
-def farthest_point_sample_gather(npoint, inp):
+# ---- input that is already in farthest-point order ------------------------------------------------------------------------
+# The second and later levels of every network sample from the previous level's samples (pointnet2_sem_seg.py:28-31): the
+# first m of them are, up to exact ties and exhausted clouds, selected as 0 .. m-1. new_xyz tensors that come out of a
+# farthest-point sampling here carry a HINT (a Python attribute); an operator that receives a hinted tensor calls
+# pn2_farthest_point_sample_ordered, which checks the belief on the device and runs the chain only where it fails -- the
+# hint can cost time, never a result (tests/test_fps_ordered_gpu.py feeds it wrong hints). set_ordered_hints(False) ignores
+# the hints.
+_ORDERED = [True]
+_ORDERED_WS = {}
+
+
+def set_ordered_hints(flag=True):
+    _ORDERED[0] = bool(flag)
+
+
+def mark_fps_ordered(t):
+    """Tag a (b, m, 3) tensor as being in farthest-point order (the output of a farthest-point sampling)."""
+    try:
+        t._pn2_fps_ordered = True
+    except Exception:        # noqa: BLE001 -- a tensor subclass without attributes: no hint, nothing lost
+        pass
+    return t
+
+
+def ordered_hint(t, m):
+    """Is the ordered entry point worth calling for m samples out of `t`? (hinted, and a chain long enough to pay for the
+    check + one more launch: 128 <= m <= min(n, 1024), n <= 2048)"""
+    return (_ORDERED[0] and getattr(t, "_pn2_fps_ordered", False) and t.dim() == 3 and 128 <= int(m) <= min(t.shape[1], 1024)
+            and t.shape[1] <= 2048 and t.shape[0] > 0)
+
+
+def ordered_workspace(lib, dev, stream, b):
+    """Flag words of pn2_farthest_point_sample_ordered, one buffer per (device, stream, batch): zeroed once, every call leaves
+    it zeroed. Under graph capture a fresh zeroed buffer belongs to the graph."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros((b,), dtype=torch.int32, device=dev)
+    key = (dev.index, stream, b)
+    ws = _ORDERED_WS.get(key)
+    if ws is None:
+        if len(_ORDERED_WS) > 64:
+            _ORDERED_WS.clear()              # buffers still referenced by enqueued launches stay alive with their tensors' storage
+        ws = torch.zeros((max(1, lib.pn2_fps_ordered_ws_bytes(b) // 4),), dtype=torch.int32, device=dev)
+        _ORDERED_WS[key] = ws
+    return ws
+
+
+def farthest_point_sample_gather(npoint, inp, ordered=None):
     """Fused farthest_point_sample + gather_point (pointnet_util.py:40 in one launch).
 
     npoint int, inp (b, ndataset, 3) f32 -> idx (b, npoint) i32, new_xyz (b, npoint, 3) f32
     with new_xyz == gather_point(inp, idx) bit for bit. No reference counterpart
     (SURVEY.md 8f1); not differentiable -- use gather_point when inp needs a gradient.
+    ordered: None = follow inp's hint (above), True / False = force / forbid the checked short cut for input in
+    farthest-point order (same results either way).
     """
+    if ordered is None:
+        ordered = isinstance(inp, torch.Tensor) and ordered_hint(inp, npoint)
     require(int(npoint) > 0, "FarthestPointSample expects positive npoint")
     inp = f32(inp.detach() if isinstance(inp, torch.Tensor) else inp, "inp")
     require(inp.dim() == 3 and inp.shape[2] == 3, "FarthestPointSample expects (batch_size,num_points,3) inp shape")
@@ -121,13 +171,18 @@ def farthest_point_sample_gather(npoint, inp):
     tf = lib.pn2_fps_temp_floats(b, n)
     temp = torch.empty((tf,), dtype=torch.float32, device=dev) if tf > 0 else None
     with on_device(dev):
-        if _FPS_VARIANT[0]:
+        if ordered and b > 0 and n <= 16384:
+            st = stream_ptr(dev)
+            ws = ordered_workspace(lib, dev, st, b)
+            _C.check(lib.pn2_farthest_point_sample_ordered(b, n, m, ptr(inp), ptr(out), ptr(new_xyz), ptr(ws), st),
+                     "farthest_point_sample_ordered")
+        elif _FPS_VARIANT[0]:
             _C.check(lib.pn2_farthest_point_sample_variant(_FPS_VARIANT[0], b, n, m, ptr(inp), ptr(temp), ptr(out), ptr(new_xyz),
                                                            stream_ptr(dev)), "farthest_point_sample_gather")
         else:
             _C.check(lib.pn2_farthest_point_sample_gather(b, n, m, ptr(inp), ptr(temp), ptr(out), ptr(new_xyz),
                                                           stream_ptr(dev)), "farthest_point_sample_gather")
-    return out, new_xyz
+    return out, mark_fps_ordered(new_xyz)
 
 
 def farthest_point_sample(npoint, inp, out=None):
@@ -137,6 +192,7 @@ def farthest_point_sample(npoint, inp, out=None):
     kernel tf_sampling_g.cu:105-170 (tie rule: smallest (k mod 512, k)).
     out: optional preallocated (b, npoint) i32 result.
     """
+    hinted = isinstance(inp, torch.Tensor) and ordered_hint(inp, npoint)      # the previous level's samples: checked short cut
     require(int(npoint) > 0, "FarthestPointSample expects positive npoint")
     inp = f32(inp.detach() if isinstance(inp, torch.Tensor) else inp, "inp")
     require(inp.dim() == 3 and inp.shape[2] == 3, "FarthestPointSample expects (batch_size,num_points,3) inp shape")
@@ -149,7 +205,11 @@ def farthest_point_sample(npoint, inp, out=None):
     tf = lib.pn2_fps_temp_floats(b, n)
     temp = torch.empty((tf,), dtype=torch.float32, device=dev) if tf > 0 else None   # allocate_temp, tf_sampling.cpp:115
     with on_device(dev):
-        if _FPS_VARIANT[0]:
+        if hinted and b > 0 and n <= 16384:
+            st = stream_ptr(dev)
+            _C.check(lib.pn2_farthest_point_sample_ordered(b, n, m, ptr(inp), ptr(out), None, ptr(ordered_workspace(lib, dev, st, b)),
+                                                           st), "farthest_point_sample_ordered")
+        elif _FPS_VARIANT[0]:
             _C.check(lib.pn2_farthest_point_sample_variant(_FPS_VARIANT[0], b, n, m, ptr(inp), ptr(temp), ptr(out), None,
                                                            stream_ptr(dev)), "farthest_point_sample")
         else:

@@ -10,6 +10,7 @@ for step in "$@"; do
     echo "=== $step $(date +%T)"
     case $step in
     tests)     timeout 1500 python -m pytest tests -m gpu -x -q > "$OUT/tests.log" 2>&1; tail -5 "$OUT/tests.log" ;;
+    ordered)   timeout 600 python -m pytest tests/test_fps_ordered_gpu.py tests/test_modules_gpu.py tests/test_graph_capture_gpu.py -m gpu -q > "$OUT/ordered.log" 2>&1; tail -15 "$OUT/ordered.log" ;;
     tests_new) timeout 900 python -m pytest tests/test_configs_gpu.py tests/test_ball_cells_gpu.py -m gpu -q > "$OUT/tests_new.log" 2>&1; tail -15 "$OUT/tests_new.log" ;;
     fpslab)    for f in build_lab/fps_*; do n=$(basename $f); case $n in *lab*|*prof*) continue;; esac; timeout 90 $f $n > "$OUT/$n.log" 2>&1; grep "n= 4096" "$OUT/$n.log"; done ;;
     prof_bw)   (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bw" -- python $ROOT/scripts/bw_probe.py > "$OUT/prof_bw.log" 2>&1); find "$OUT/prof_bw" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_bw_probe.csv" \;; rm -rf "$OUT/prof_bw"; cut -d, -f1-8 "$OUT/kernel_stats_bw_probe.csv" | head -30 ;;
