@@ -37,6 +37,8 @@ Extra objects on the JSON line:
   kernels / stage   -- every op-level kernel of the step the same way.
   d2           -- the same step on D2 clouds (uniform U[0,1)^3, radius 0.1: the reference harnesses'
                   distribution).
+  vector_rooflines -- query_ball_point (metric shape) and three_nn (sem_seg FP4 shape): brute-force pair tests x 8 flops /
+                  time against the fp32 vector peak (157.3 TFLOP/s).
   sustained    -- the same step repeated for >= 1 s (not `value`; lets an external sampler see the GPU).
   allreduce    -- N > 1: training's only exchange, the gradient mean over ranks (train_multi_gpu.py:91-126)
                   as one flat-bucket all-reduce (sharding.allreduce_mean_) at the two model sizes.
@@ -244,6 +246,34 @@ def sa_train_level(stage):
             "forward_us": t_f * 1e6, "backward_us": t_b * 1e6,
             "speed_fp32_equiv": {"value": 3 * flops / (t_f + t_b) / 1e12, "unit": "TFLOP/s",
                                  "note": "forward + data gradient + weight gradient FLOPs of the layer stack per second"}}
+
+
+def vector_rooflines(stage, t_ball):
+    """EXTRA object: the two pair-test kernels priced against the fp32 VECTOR peak of
+    MI355X_MICROARCH.md (157.3 TFLOP/s = 256 CUs x 4 SIMDs x 16 lanes x packed x FMA x 2.4 GHz). A squared distance is
+    3 subtractions, 3 multiplications and 2 additions, each rounded on its own (results must round like the reference's CPU
+    build: no FMA), so eight flops are eight unpacked or four packed instructions -- half of the spec figure is the most these
+    kernels could ever reach; the fraction is quoted against the full figure anyway. `pair_tests` is the BRUTE-FORCE count
+    (every query against every point, what the reference kernels execute: tf_grouping_g.cu:3-36, tf_interpolate.cpp:60-103);
+    query_ball_point's cell lists test fewer (`tests_executed_est`), so its fraction is of work AVOIDED + done, a speed."""
+    import pointnet2_amd as P
+    peak = 157.3
+    out = {"peak": peak, "unit": "TFLOP/s", "flops_per_pair_test": 8,
+           "note": "8 flops per squared distance (no FMA: separate roundings), brute-force pair counts; time = HIP events, median of 10"}
+    tests = float(stage.b) * M * N
+    out["query_ball_point"] = {"shape": "b=%d n=%d m=%d radius=%.2f nsample=%d (metric shape)" % (stage.b, N, M, stage.radius, NS),
+                               "us": t_ball * 1e6, "pair_tests": tests, "achieved": tests * 8 / t_ball / 1e12,
+                               "frac": tests * 8 / t_ball / 1e12 / peak,
+                               "mean_pts_cnt": float(stage.cnt.float().mean().item())}
+    # three_nn at sem_seg's last feature-propagation level (pointnet2_sem_seg.py:37: 8192 unknown points, 1024 known), b = 8
+    b3, n3, m3 = 8, 8192, 1024
+    unknown = torch.from_numpy(synthetic.uniform_clouds(b3, n3, 91)).to(stage.dev)
+    known = unknown[:, :m3].contiguous()
+    t3 = event_time(lambda: P.three_nn(unknown, known))
+    tests3 = float(b3) * n3 * m3
+    out["three_nn"] = {"shape": "b=%d n=%d unknown, m=%d known (sem_seg FP4)" % (b3, n3, m3), "us": t3 * 1e6, "pair_tests": tests3,
+                       "achieved": tests3 * 8 / t3 / 1e12, "frac": tests3 * 8 / t3 / 1e12 / peak}
+    return out
 
 
 def concurrent_throughput(dev, rank, path, streams, steps):
@@ -555,6 +585,10 @@ def main():
                     line["sa_train"] = sa_train_level(stage)
                 except Exception as e:
                     line["sa_train"] = {"error": repr(e)}
+                try:
+                    line["vector_rooflines"] = vector_rooflines(stage, kt["query_ball_point"])
+                except Exception as e:
+                    line["vector_rooflines"] = {"error": repr(e)}
                 # >= 5 s of back-to-back steps (not `value`), BEFORE the CPU-baseline legs: long enough for an external
                 # utilisation sampler to see the GPU busy
                 n_sus = max(args.steps, int(5.0 / max(launch_s, 1e-6)))
