@@ -22,6 +22,7 @@ from .tf_interpolate import three_nn, three_interpolate, fp_interp_concat
 from ._tensors import use_segmented_grad
 from . import sa_mlp
 from . import train_mlp
+from .geometry import SAGeometry
 
 
 def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True, fused=None):
@@ -219,7 +220,40 @@ class PointnetSAModule(nn.Module):
             self._packed(device)
         return self
 
-    def forward(self, xyz, points):
+    def geometry(self, xyz):
+        """This level's sampling and grouping alone (:40-46; what forward() launches before its layer stack) -> SAGeometry, or
+        None for a group_all level (no sampling, the group is the cloud). geometry.GeometryAhead calls it on its own stream."""
+        if self.group_all:
+            return None
+        if self.knn:
+            _, new_xyz = farthest_point_sample_gather(self.npoint, xyz)
+            _, idx = knn_point(self.nsample, xyz, new_xyz)
+        else:
+            _, new_xyz, idx, _, _ = sample_and_group_xyz(self.npoint, self.radius, self.nsample, xyz, True)
+        return SAGeometry(new_xyz, idx)
+
+    def _forward_on(self, xyz, points, g):
+        """forward() on a geometry computed ahead (geometry.py): the layer stack only, same paths, same results."""
+        new_xyz, idx = g.new_xyz, g.idx
+        if self._train_fused_ok(xyz, points):
+            self.last_path = "fused_train"
+            out, _ = train_mlp.sa_mlp_train(self.mlp.net, xyz, new_xyz, points, idx, True)
+            return new_xyz, out, idx
+        if self._fused_ok(xyz, points):
+            self.last_path = "fused"
+            return new_xyz, sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, self._packed(xyz.device)), idx
+        self.last_path = "unfused"
+        grouped_xyz = group_point(xyz, idx) - new_xyz.unsqueeze(2)            # :45-46
+        if points is not None:
+            grouped_points = group_point(points, idx)                         # :48
+            new_points = torch.cat([grouped_xyz, grouped_points], dim=-1) if self.use_xyz else grouped_points   # :50
+        else:
+            new_points = grouped_xyz
+        return self._stack_and_pool(new_xyz, new_points, idx, grouped_xyz)
+
+    def forward(self, xyz, points, geometry=None):
+        if geometry is not None and not self.group_all:
+            return self._forward_on(xyz, points, geometry.wait())
         if self._train_fused_ok(xyz, points):
             # training: the level's geometry in the fused launches, then ONE autograd node for gather + layer stack
             # (batch-statistics batch norm) + max-pool, forward and backward on the matrix cores (train_mlp.py)
@@ -258,6 +292,10 @@ class PointnetSAModule(nn.Module):
         else:
             new_xyz, new_points, idx, grouped_xyz = sample_and_group(self.npoint, self.radius, self.nsample, xyz,
                                                                      points, self.knn, self.use_xyz)
+        return self._stack_and_pool(new_xyz, new_points, idx, grouped_xyz)
+
+    def _stack_and_pool(self, new_xyz, new_points, idx, grouped_xyz):
+        """The layer stack, the pooling and mlp2 of the layer-by-layer path (:117-152)."""
         x = self.mlp(new_points.permute(0, 3, 1, 2))                 # (b, C, npoint, nsample)
         if self.pooling == "max":
             x = x.max(dim=3, keepdim=True)[0]
@@ -329,10 +367,18 @@ class PointnetSAModuleMSG(nn.Module):
             scales += [(i, g) for i, _, g in rest]
         return new_xyz, scales
 
-    def _forward_fused(self, xyz, points):
-        """Inference: the grouping launches of _group_scales, then one fused MLP + max-pool kernel per scale;
-        no grouped tensor is ever materialised."""
+    def geometry(self, xyz):
+        """This level's sampling and every radius' grouping alone (:173-180) -> SAGeometry with one idx per radius."""
         new_xyz, scales = self._group_scales(xyz, True)
+        return SAGeometry(new_xyz, [idx for idx, _ in scales])
+
+    def _forward_fused(self, xyz, points, g=None):
+        """Inference: the grouping launches of _group_scales (or a geometry computed ahead), then one fused MLP + max-pool
+        kernel per scale; no grouped tensor is ever materialised."""
+        if g is None:
+            new_xyz, scales = self._group_scales(xyz, True)
+        else:
+            new_xyz, scales = g.new_xyz, [(idx, None) for idx in g.idx]
         outs = [sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, self._packed(si, xyz.device))
                 for si, (idx, _) in enumerate(scales)]
         return new_xyz, torch.cat(outs, dim=2)
@@ -345,22 +391,29 @@ class PointnetSAModuleMSG(nn.Module):
         rows = xyz.shape[0] * self.npoint
         return all(train_mlp.stack_supported(mlp.net, rows * ns, ns, True) for mlp, ns in zip(self.mlps, self.nsample_list))
 
-    def forward(self, xyz, points):
+    def forward(self, xyz, points, geometry=None):
+        g = None if geometry is None else geometry.wait()          # a geometry computed ahead (geometry.py): same results
         if self._fused_ok(xyz, points):
             self.last_path = "fused"
-            return self._forward_fused(xyz, points)
+            return self._forward_fused(xyz, points, g)
         if self._train_fused_ok(xyz, points):
             # training: grouping launches as in inference, then one autograd node per scale (train_mlp.py);
             # channel order features FIRST (:184)
             self.last_path = "fused_train"
-            new_xyz, scales = self._group_scales(xyz, True)
+            if g is None:
+                new_xyz, scales = self._group_scales(xyz, True)
+            else:
+                new_xyz, scales = g.new_xyz, [(idx, None) for idx in g.idx]
             outs = [train_mlp.sa_mlp_train(mlp.net, xyz, new_xyz, points, idx, False)[0]
                     for mlp, (idx, _) in zip(self.mlps, scales)]
             return new_xyz, torch.cat(outs, dim=2)
         self.last_path = "unfused"
-        fused = not (torch.is_grad_enabled() and xyz.requires_grad)
+        fused = g is not None or not (torch.is_grad_enabled() and xyz.requires_grad)
         scales = None
-        if fused:
+        if g is not None:
+            new_xyz = g.new_xyz
+            scales = [(idx, group_point(xyz, idx) - new_xyz.unsqueeze(2)) for idx in g.idx]     # :179-180
+        elif fused:
             new_xyz, scales = self._group_scales(xyz, points is not None)
         else:
             new_xyz = mark_fps_ordered(gather_point(xyz, farthest_point_sample(self.npoint, xyz)))   # :173
@@ -420,7 +473,26 @@ class PointnetFPModule(nn.Module):
             self._packed(c2, c1, kind, device)
         return self
 
-    def forward(self, xyz1, xyz2, points1, points2):
+    def _forward_on(self, xyz1, points1, points2, g):
+        """forward() on three_nn's result computed ahead (geometry.py): everything after :211, same paths, same results."""
+        dist, idx = g.dist, g.idx
+        kind = self._fused_kind(points1, points2, xyz1.shape[0] * xyz1.shape[1])
+        c1 = points1.shape[2] if points1 is not None else 0
+        if kind is not None:
+            self.last_path = "fused"
+            return sa_mlp.fp_mlp(points2, points1, idx, dist, self._packed(points2.shape[2], c1, kind, points2.device))
+        if self.fused_mlp and self.training and points2.is_cuda and use_segmented_grad(points2.shape[0], points2.shape[1], points2.shape[2]) and \
+                train_mlp.stack_supported(self.mlp.net, xyz1.shape[0] * xyz1.shape[1], 0, False):
+            self.last_path = "fused_train"
+            x, _ = fp_interp_concat(points2, points1, idx, dist)                # :212-219
+            return train_mlp.fp_mlp_train(self.mlp.net, x, cin=points2.shape[2] + c1)
+        inv = 1.0 / torch.clamp(dist, min=1e-10)                                # :212
+        weight = inv / inv.sum(dim=2, keepdim=True)                             # :213-215
+        return self._after_weights(points1, points2, idx, weight)
+
+    def forward(self, xyz1, xyz2, points1, points2, geometry=None):
+        if geometry is not None:
+            return self._forward_on(xyz1, points1, points2, geometry.wait())
         kind = self._fused_kind(points1, points2, xyz1.shape[0] * xyz1.shape[1])
         if kind is not None:
             # ONE C call (csrc/levels.hip): three_nn, then one kernel for weights, interpolation, concatenation and the
@@ -442,6 +514,10 @@ class PointnetFPModule(nn.Module):
             c = points2.shape[2] + (points1.shape[2] if points1 is not None else 0)
             return train_mlp.fp_mlp_train(self.mlp.net, x, cin=c)
         idx, weight = three_nn_weights(xyz1, xyz2)                              # :211-215
+        return self._after_weights(points1, points2, idx, weight)
+
+    def _after_weights(self, points1, points2, idx, weight):
+        """:216-226 of the layer-by-layer path."""
         interpolated = three_interpolate(points2, idx, weight)                  # :216
         x = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated   # :219
         if self.fused_mlp and self.training and x.is_cuda and \

@@ -11,6 +11,7 @@ for step in "$@"; do
     case $step in
     tests)     timeout 1500 python -m pytest tests -m gpu -x -q > "$OUT/tests.log" 2>&1; tail -5 "$OUT/tests.log" ;;
     ordered)   timeout 600 python -m pytest tests/test_fps_ordered_gpu.py tests/test_modules_gpu.py tests/test_graph_capture_gpu.py -m gpu -q > "$OUT/ordered.log" 2>&1; tail -15 "$OUT/ordered.log" ;;
+    ahead)     timeout 600 python -m pytest tests/test_geometry_ahead_gpu.py tests/test_modules_gpu.py -m gpu -q > "$OUT/ahead.log" 2>&1; tail -25 "$OUT/ahead.log" ;;
     tests_new) timeout 900 python -m pytest tests/test_configs_gpu.py tests/test_ball_cells_gpu.py -m gpu -q > "$OUT/tests_new.log" 2>&1; tail -15 "$OUT/tests_new.log" ;;
     fpslab)    for f in build_lab/fps_*; do n=$(basename $f); case $n in *lab*|*prof*) continue;; esac; timeout 90 $f $n > "$OUT/$n.log" 2>&1; grep "n= 4096" "$OUT/$n.log"; done ;;
     prof_bw)   (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bw" -- python $ROOT/scripts/bw_probe.py > "$OUT/prof_bw.log" 2>&1); find "$OUT/prof_bw" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_bw_probe.csv" \;; rm -rf "$OUT/prof_bw"; cut -d, -f1-8 "$OUT/kernel_stats_bw_probe.csv" | head -30 ;;
@@ -35,13 +36,14 @@ for l in open(sys.argv[1]):
     print("%-58s fused %7.1f + %7.1f us | layer by layer %7.1f + %7.1f us | x%.2f" % (r["level"][:58], r["fused"]["forward_us"], r["fused"]["backward_us"], r["layer_by_layer"]["forward_us"], r["layer_by_layer"]["backward_us"], r["speedup_step"]))
 PY
     ;;
-    trainstep) timeout 900 python scripts/train_step_bench.py --steps 8 2> "$OUT/train_step.err" | grep "^{" > "$OUT/train_step.jsonl"; python - "$OUT/train_step.jsonl" <<'PY'
+    trainstep) timeout 900 python scripts/train_step_bench.py --steps 8 --graph 2> "$OUT/train_step.err" | grep "^{" > "$OUT/train_step.jsonl"; python - "$OUT/train_step.jsonl" <<'PY'
 import json, sys
 for l in open(sys.argv[1]):
     r = json.loads(l)
     f, u = r["fused"], r["layer_by_layer"]
     d = r.get("fused_direct", f)
-    print("%-50s layer by layer %6.2f + %6.2f = %6.2f ms | fused %6.2f + %6.2f = %6.2f ms x%.2f | gradients added in the kernels %6.2f ms x%.2f" % (r["model"][:50], u["forward_ms"], u["backward_ms"], u["step_ms"], f["forward_ms"], f["backward_ms"], f["step_ms"], r["speedup"], d["step_ms"], r.get("speedup_direct", 0.0)))
+    g, ga = r.get("fused_direct_graph", {}), r.get("fused_direct_graph_ahead", {})
+    print("%-50s layer by layer %6.2f + %6.2f = %6.2f ms | fused %6.2f + %6.2f = %6.2f ms x%.2f | gradients added in the kernels %6.2f ms x%.2f | as one HIP graph %s ms, with the geometry one step ahead %s ms" % (r["model"][:50], u["forward_ms"], u["backward_ms"], u["step_ms"], f["forward_ms"], f["backward_ms"], f["step_ms"], r["speedup"], d["step_ms"], r.get("speedup_direct", 0.0), g.get("step_ms", "-"), ga.get("step_ms", "-")))
 PY
     ;;
     trainrccl) timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 scripts/train_step_bench.py sem_seg --steps 8 --fused-only 2> "$OUT/train_rccl.err" | grep "^{" > "$OUT/train_step_rccl.jsonl"; cat "$OUT/train_step_rccl.jsonl" | cut -c1-400

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 import pointnet2_amd.pointnet_util as U
+from pointnet2_amd.geometry import GeometryAhead, PipelinedInference
 from pointnet2_amd import synthetic as S
 
 dev = torch.device("cuda:0")
@@ -25,9 +26,13 @@ class ClsSSG(nn.Module):                      # models/pointnet2_cls_ssg.py:20-4
         self.fc = nn.Sequential(nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.ReLU(), nn.Linear(512, 256),
                                 nn.BatchNorm1d(256), nn.ReLU(), nn.Linear(256, 40))
 
-    def forward(self, xyz):
-        x1, f1, _ = self.sa1(xyz, None)
-        x2, f2, _ = self.sa2(x1, f1)
+    def ahead(self):                          # the network's geometry on its own stream (pointnet2_amd/geometry.py)
+        return GeometryAhead([self.sa1, self.sa2, self.sa3])
+
+    def forward(self, xyz, geometry=None):
+        g = geometry
+        x1, f1, _ = self.sa1(xyz, None, g and g.sa[0])
+        x2, f2, _ = self.sa2(x1, f1, g and g.sa[1])
         _, f3, _ = self.sa3(x2, f2)
         return self.fc(f3.reshape(xyz.shape[0], -1))
 
@@ -45,15 +50,19 @@ class SemSeg(nn.Module):                      # models/pointnet2_sem_seg.py:20-5
         self.fp4 = U.PointnetFPModule(128, [128, 128, 128])
         self.head = nn.Sequential(nn.Conv1d(128, 128, 1), nn.BatchNorm1d(128), nn.ReLU(), nn.Conv1d(128, classes, 1))
 
-    def forward(self, xyz):
-        x1, f1, _ = self.sa1(xyz, None)
-        x2, f2, _ = self.sa2(x1, f1)
-        x3, f3, _ = self.sa3(x2, f2)
-        x4, f4, _ = self.sa4(x3, f3)
-        g3 = self.fp1(x3, x4, f3, f4)
-        g2 = self.fp2(x2, x3, f2, g3)
-        g1 = self.fp3(x1, x2, f1, g2)
-        g0 = self.fp4(xyz, x1, None, g1)
+    def ahead(self):
+        return GeometryAhead([self.sa1, self.sa2, self.sa3, self.sa4], [(3, 4), (2, 3), (1, 2), (0, 1)])
+
+    def forward(self, xyz, geometry=None):
+        g = geometry
+        x1, f1, _ = self.sa1(xyz, None, g and g.sa[0])
+        x2, f2, _ = self.sa2(x1, f1, g and g.sa[1])
+        x3, f3, _ = self.sa3(x2, f2, g and g.sa[2])
+        x4, f4, _ = self.sa4(x3, f3, g and g.sa[3])
+        g3 = self.fp1(x3, x4, f3, f4, g and g.fp[0])
+        g2 = self.fp2(x2, x3, f2, g3, g and g.fp[1])
+        g1 = self.fp3(x1, x2, f1, g2, g and g.fp[2])
+        g0 = self.fp4(xyz, x1, None, g1, g and g.fp[3])
         return self.head(g0.permute(0, 2, 1))
 
 
@@ -67,10 +76,14 @@ class ClsMSG(nn.Module):                      # models/pointnet2_cls_msg.py:20-4
         self.fc = nn.Sequential(nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.ReLU(), nn.Linear(512, 256),
                                 nn.BatchNorm1d(256), nn.ReLU(), nn.Linear(256, 40))
 
-    def forward(self, cloud):                 # (b, n, 6): xyz + normals, sliced like pointnet2_part_seg.py:22-23
+    def ahead(self):
+        return GeometryAhead([self.sa1, self.sa2, self.sa3])
+
+    def forward(self, cloud, geometry=None):  # (b, n, 6): xyz + normals, sliced like pointnet2_part_seg.py:22-23
+        g = geometry
         xyz, normals = cloud[:, :, :3].contiguous(), cloud[:, :, 3:].contiguous()
-        x1, f1 = self.sa1(xyz, normals)
-        x2, f2 = self.sa2(x1, f1)
+        x1, f1 = self.sa1(xyz, normals, g and g.sa[0])
+        x2, f2 = self.sa2(x1, f1, g and g.sa[1])
         _, f3, _ = self.sa3(x2, f2)
         return self.fc(f3.reshape(cloud.shape[0], -1))
 
@@ -86,14 +99,18 @@ class PartSeg(nn.Module):                     # models/pointnet2_part_seg.py:15-
         self.fp3 = U.PointnetFPModule(128 + 6, [128, 128, 128])
         self.head = nn.Sequential(nn.Conv1d(128, 128, 1), nn.BatchNorm1d(128), nn.ReLU(), nn.Conv1d(128, classes, 1))
 
-    def forward(self, cloud):                 # (b, n, 6)
+    def ahead(self):
+        return GeometryAhead([self.sa1, self.sa2, self.sa3], [(2, 3), (1, 2), (0, 1)])
+
+    def forward(self, cloud, geometry=None):  # (b, n, 6)
+        g = geometry
         xyz, normals = cloud[:, :, :3].contiguous(), cloud[:, :, 3:].contiguous()
-        x1, f1, _ = self.sa1(xyz, normals)
-        x2, f2, _ = self.sa2(x1, f1)
+        x1, f1, _ = self.sa1(xyz, normals, g and g.sa[0])
+        x2, f2, _ = self.sa2(x1, f1, g and g.sa[1])
         x3, f3, _ = self.sa3(x2, f2)
-        g2 = self.fp1(x2, x3, f2, f3)
-        g1 = self.fp2(x1, x2, f1, g2)
-        g0 = self.fp3(xyz, x1, cloud, g1)     # points1 = concat(l0_xyz, l0_points), :33
+        g2 = self.fp1(x2, x3, f2, f3, g and g.fp[0])
+        g1 = self.fp2(x1, x2, f1, g2, g and g.fp[1])
+        g0 = self.fp3(xyz, x1, cloud, g1, g and g.fp[2])     # points1 = concat(l0_xyz, l0_points), :33
         return self.head(g0.permute(0, 2, 1))
 
 
@@ -108,6 +125,26 @@ def timeit(fn, iters=10, warm=3):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
+
+
+def graphed_pipeline(model, ahead, coords, inputs, expect):
+    """The serving loop of pointnet2_amd.geometry.PipelinedInference on two inputs in rotation: per slot one HIP graph of the
+    geometry on the geometry stream and one of the layer stacks on a stack stream; the stacks of batch i run beside the
+    geometry of batch i + 1. -> (ms per batch, outputs bit-identical to `expect`)"""
+    pipe = PipelinedInference(model, ahead, inputs[0], coords)
+    state = {"i": 0}
+
+    def step():
+        y = pipe.push(inputs[state["i"] % 2], False)                   # resident inputs: nothing to wait for
+        state["i"] += 1
+        return y
+    y0 = step().clone()
+    y1 = step().clone()
+    torch.cuda.synchronize()
+    same = torch.equal(y0, expect[0]) and torch.equal(y1, expect[1])
+    t = timeit(step, iters=40, warm=4)
+    torch.cuda.synchronize()
+    return t, same
 
 
 def set_fused(model, flag):
@@ -152,9 +189,31 @@ def main():
             with torch.cuda.graph(graph):
                 model(xyz)
             t_graph = timeit(graph.replay)
+            # geometry ahead on its own stream (pointnet2_amd/geometry.py): within the batch, and one batch ahead (two inputs in
+            # rotation: batch i + 1's geometry is submitted before batch i's stacks run -- a serving / prefetching loop)
+            ahead = model.ahead()
+            coords = (lambda c: c[:, :, :3].contiguous()) if normals else (lambda c: c)
+            inputs = [xyz, torch.roll(xyz, 1, 0).contiguous()]
+            same = torch.equal(model(xyz, ahead.submit(coords(xyz))), out)
+            t_within = timeit(lambda: model(xyz, ahead.submit(coords(xyz))))
+            state = {"g": ahead.submit(coords(inputs[0])), "i": 0}
+
+            def pipelined():
+                i = state["i"]
+                g_next = ahead.submit(coords(inputs[(i + 1) % 2]))
+                y = model(inputs[i % 2], state["g"])
+                state["g"], state["i"] = g_next, i + 1
+                return y
+            t_pipe = timeit(pipelined, iters=20)
+            state = {"g": ahead.submit(coords(inputs[0])), "i": 0}
+            same = same and torch.equal(pipelined(), out) and torch.equal(pipelined(), model(inputs[1]))
+            torch.cuda.synchronize()
+            t_pipe_graph, same_graph = graphed_pipeline(model, ahead, coords, inputs, [out, model(inputs[1])])
         paths = [m.last_path for m in model.modules() if hasattr(m, "last_path")]
-        print("%-58s unfused %7.3f ms | fused MLPs %7.3f ms | fused + HIP graph %7.3f ms | rel. diff %.1e | SA paths %s"
-              % (name, t_unfused, t_fused, t_graph, err, paths), flush=True)
+        print("%-58s unfused %7.3f ms | fused MLPs %7.3f ms | fused + HIP graph %7.3f ms | geometry on its own stream %7.3f ms, one "
+              "batch ahead %7.3f ms per batch (bit-identical: %s), as HIP graphs on the two streams %7.3f ms per batch (bit-identical: %s) "
+              "| rel. diff %.1e | SA paths %s"
+              % (name, t_unfused, t_fused, t_graph, t_within, t_pipe, same, t_pipe_graph, same_graph, err, paths), flush=True)
 
 
 if __name__ == "__main__":

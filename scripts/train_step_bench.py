@@ -50,16 +50,25 @@ def make_input(b, n, normals, dev, seed):
     return torch.from_numpy(cloud).to(dev)
 
 
-def run_steps(model, opt, bucket, x, labels, kind, steps, warm, batch):
+def run_steps(model, opt, bucket, x, labels, kind, steps, warm, batch, ahead=None):
+    """ahead: a GeometryAhead of the model -- the NEXT step's sampling / grouping / three_nn is enqueued on the geometry stream
+    before this step's forward (what a prefetching input pipeline does: the geometry needs coordinates only and no gradient)."""
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(steps)]
     loss = None
+    coords = (lambda c: c[:, :, :3].contiguous()) if x.shape[2] > 3 else (lambda c: c)
+    g = ahead.submit(coords(x)) if ahead is not None else None
     for it in range(warm + steps):
         set_bn_momentum(model, bn_momentum(it, batch))
         rec = ev[it - warm] if it >= warm else None
         if rec:
             rec[0].record()
         bucket.zero_()
-        out = model(x)
+        if ahead is not None:
+            g_next = ahead.submit(coords(x))
+            out = model(x, g)
+            g = g_next
+        else:
+            out = model(x)
         loss = F.cross_entropy(out, labels) if kind == "cls" else F.cross_entropy(out, labels)
         if rec:
             rec[1].record()
@@ -109,6 +118,35 @@ def graph_step(model, opt, bucket, x, labels, steps):
     return {"step_ms": round(e0.elapsed_time(e1) / steps, 3), "loss": float(loss)}
 
 
+def graph_step_ahead(model, opt, bucket, x, labels, steps):
+    """The same captured step with the geometry one step ahead (pointnet2_amd.geometry.PipelinedInference with a training step
+    as its `model`): per slot a HIP graph of the geometry on the geometry stream and one of forward + loss + backward + SGD step
+    on the main stream; step i's graph runs beside step i + 1's geometry."""
+    import gc
+    from pointnet2_amd.geometry import PipelinedInference
+    gc.collect()
+    torch.cuda.synchronize()
+    coords = (lambda c: c[:, :, :3].contiguous()) if x.shape[2] > 3 else None
+
+    def train_step(inp, g):
+        bucket.zero_()
+        loss = F.cross_entropy(model(inp, g), labels)
+        loss.backward()
+        opt.step()
+        return loss.detach()
+    pipe = PipelinedInference(train_step, model.ahead(), x, coords, no_grad=False)
+    for _ in range(2):
+        pipe.push(x, False)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        loss = pipe.push(x, False)
+    e1.record()
+    torch.cuda.synchronize()
+    return {"step_ms": round(e0.elapsed_time(e1) / steps, 3), "loss": float(loss)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("which", nargs="?", default="")
@@ -118,6 +156,11 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="additionally capture forward + loss + backward + optimiser step of the fused path in ONE HIP graph "
                          "and time its replay (a level's step is ~40 small launches: eager runs are launch-bound on small levels)")
+    ap.add_argument("--ahead", action="store_true",
+                    help="additionally run the eager step with the next step's geometry enqueued on a second stream before the forward "
+                         "(pointnet2_amd.geometry.GeometryAhead). Measured: no gain at best (2.80 against 2.78 ms on cls_ssg) and 2-3x "
+                         "SLOWER whenever the runtime puts the two streams into one hardware queue (7.0 / 11.2 ms on cls_ssg / sem_seg in "
+                         "some process layouts) -- profiles/r05/geometry_ahead.txt; the captured form (--graph) does not have that problem")
     args = ap.parse_args()
     distributed = "RANK" in os.environ
     rank, world = 0, 1
@@ -142,6 +185,8 @@ def main():
         # three variants: the layer-by-layer path, the fused nodes, and the fused nodes adding their parameter gradients
         # straight into the bucket's views (train_mlp.set_accumulate_into_grad: no `grad += new` launches by autograd)
         variants = [("layer_by_layer", False, False), ("fused", True, False), ("fused_direct", True, True)]
+        if args.ahead:
+            variants.append(("fused_direct_ahead", True, True))
         for key, fused, direct in (variants[1:] if args.fused_only else variants):
             train_mlp.set_accumulate_into_grad(direct)
             model = ctor().to(dev)
@@ -158,13 +203,19 @@ def main():
             grads[key] = (float(loss0), bucket.flat.clone())
             del loss0                                      # no reference to an old autograd graph may survive into a capture
             paths = [m.last_path for m in model.modules() if hasattr(m, "last_path")]
-            ph, loss = run_steps(model, opt, bucket, x, labels, kind, args.steps, args.warmup, b * world)
+            ph, loss = run_steps(model, opt, bucket, x, labels, kind, args.steps, args.warmup, b * world,
+                                 model.ahead() if key.endswith("_ahead") else None)
             row[key] = {"forward_ms": round(float(ph[0]), 3), "backward_ms": round(float(ph[1]), 3),
                         "allreduce_ms": round(float(ph[2]), 3), "optimizer_ms": round(float(ph[3]), 3),
                         "step_ms": round(float(ph.sum()), 3), "loss": loss, "paths": paths,
                         "grad_floats": int(bucket.flat.numel())}
-            if key == "fused" and args.graph and not distributed:
-                row["fused_graph"] = graph_step(model, opt, bucket, x, labels, args.steps)
+            if key == "fused_direct" and args.graph and not distributed:
+                for gkey, fn in (("fused_direct_graph", graph_step), ("fused_direct_graph_ahead", graph_step_ahead)):
+                    try:
+                        row[gkey] = fn(model, opt, bucket, x, labels, args.steps)
+                    except Exception as e:                       # noqa: BLE001 -- a capture torch refuses is a result, not a crash
+                        row[gkey] = {"error": repr(e)[:300]}
+                        torch.cuda.synchronize()
             del model, opt, bucket
             torch.cuda.empty_cache()
         train_mlp.set_accumulate_into_grad(False)
@@ -174,6 +225,8 @@ def main():
             row["grad_rel_diff"] = float((ga - gb).norm() / gb.norm())
             row["speedup"] = round(row["layer_by_layer"]["step_ms"] / row["fused"]["step_ms"], 2)
             row["speedup_direct"] = round(row["layer_by_layer"]["step_ms"] / row["fused_direct"]["step_ms"], 2)
+            if "fused_direct_ahead" in row:
+                row["speedup_direct_ahead"] = round(row["layer_by_layer"]["step_ms"] / row["fused_direct_ahead"]["step_ms"], 2)
         if "fused" in grads and "fused_direct" in grads:
             row["direct_grad_rel_diff"] = float((grads["fused_direct"][1] - grads["fused"][1]).norm() / grads["fused"][1].norm())
         if rank == 0:
