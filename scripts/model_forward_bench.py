@@ -169,6 +169,13 @@ def main():
             cloud = np.concatenate([cloud, nrm.astype(np.float32)], axis=2)
         xyz = torch.from_numpy(cloud).to(dev)
         with torch.no_grad():
+            if os.environ.get("PN2_MODEL_PIPELINE_ONLY"):  # for rocprofv3: the serving loop alone (scripts/overlap_timeline.py)
+                set_fused(model, True)
+                coords = (lambda c: c[:, :, :3].contiguous()) if normals else (lambda c: c)
+                t, same = graphed_pipeline(model, model.ahead(), coords, [xyz, torch.roll(xyz, 1, 0).contiguous()],
+                                           [model(xyz), model(torch.roll(xyz, 1, 0).contiguous())])
+                print("%-58s HIP graphs on the two streams %7.3f ms per batch (bit-identical: %s)" % (name, t, same), flush=True)
+                continue
             if os.environ.get("PN2_MODEL_FUSED_ONLY"):     # for rocprofv3: only the fused path's kernels in the trace
                 set_fused(model, True)
                 print("%-58s fused MLPs %7.3f ms (eager)" % (name, timeit(lambda: model(xyz), iters=20)), flush=True)
