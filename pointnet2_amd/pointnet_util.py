@@ -129,13 +129,21 @@ class _SharedMLP(nn.Module):
         self.c_out = c_in
         self.widths = tuple(widths)
 
-    def folded_layers(self):
-        """[(W (cin, cout), b (cout))] with eval-mode batch norm folded in (sa_mlp.fold_batch_norm)."""
+    def folded_layers(self, zero_xyz_rows=None):
+        """[(W (cin, cout), b (cout))] with eval-mode batch norm folded in (sa_mlp.fold_batch_norm).
+        zero_xyz_rows: "first" / "last" -- three ZERO rows added to the first layer's weight where the fused kernels feed the
+        grouped coordinates (use_xyz=False levels, pointnet_util.py:49-52: the coordinates then contribute exact zeros to
+        every sum, which is the layer stack on the features alone)."""
         out, mods = [], list(self.net)
         for i, mod in enumerate(mods):
             if isinstance(mod, nn.Conv2d):
                 bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d) else None
                 out.append(sa_mlp.fold_batch_norm(mod.weight, mod.bias, bn))
+        if zero_xyz_rows is not None:
+            import numpy as np
+            w, b = out[0]
+            z = np.zeros((3, w.shape[1]), dtype=w.dtype)
+            out[0] = (np.concatenate([z, w] if zero_xyz_rows == "first" else [w, z], axis=0), b)
         return out
 
     def forward(self, x):
@@ -150,6 +158,7 @@ class PointnetSAModule(nn.Module):
         super().__init__()
         self.npoint, self.radius, self.nsample = npoint, radius, nsample
         self.group_all, self.pooling, self.knn, self.use_xyz = group_all, pooling, knn, use_xyz
+        self.c_in = c_in
         feat = 3 if c_in == 0 else (c_in + 3 if use_xyz else c_in)
         self.mlp = _SharedMLP(feat, mlp, bn)
         c = self.mlp.c_out * (2 if pooling == "max_and_avg" else 1)
@@ -173,8 +182,7 @@ class PointnetSAModule(nn.Module):
             return False
         if self.pooling != "max" or self.mlp2 is not None or not xyz.is_cuda:
             return False
-        if points is not None and not self.use_xyz:
-            return False
+        # (use_xyz=False: the kernels still gather the coordinates, against three zero rows of weight -- _packed)
         cin = 3 + (points.shape[2] if points is not None else 0)
         if self.group_all:                         # only the cooperative kernel gathers a whole cloud without idx
             return sa_mlp.supported(cin, self.mlp.widths, xyz.shape[1]) and sa_mlp.kind(cin, self.mlp.widths, xyz.shape[1]) == "cooperative"
@@ -203,7 +211,8 @@ class PointnetSAModule(nn.Module):
             _no_packing_under_capture()
             if len(self._pack_cache[1]) >= 8:
                 self._pack_cache[1].clear()
-            hit = sa_mlp.PackedMLP3(self.mlp.folded_layers(), device, nsample, True)
+            no_xyz = not self.use_xyz and self.c_in > 0                 # features only (pointnet_util.py:49-52)
+            hit = sa_mlp.PackedMLP3(self.mlp.folded_layers("first" if no_xyz else None), device, nsample, True)
             self._pack_cache[1][nsample] = hit
         return hit
 
@@ -212,7 +221,7 @@ class PointnetSAModule(nn.Module):
         device-to-host copy and an upload): call it once after loading weights / before capturing a HIP
         graph, so that forward() finds the cache warm. group_all levels pack per cloud size: pass n (the number of
         points this level will see)."""
-        cin = self.mlp.net[0].in_channels
+        cin = self.mlp.net[0].in_channels + (3 if not self.use_xyz and self.c_in > 0 else 0)
         if self.group_all:
             if n and sa_mlp.supported(cin, self.mlp.widths, n) and sa_mlp.kind(cin, self.mlp.widths, n) == "cooperative":
                 self._packed(device, n)
@@ -322,6 +331,7 @@ class PointnetSAModuleMSG(nn.Module):
     def __init__(self, c_in, npoint, radius_list, nsample_list, mlp_list, bn=True, use_xyz=True):
         super().__init__()
         self.npoint, self.radius_list, self.nsample_list, self.use_xyz = npoint, radius_list, nsample_list, use_xyz
+        self.c_in = c_in
         feat = 3 if c_in == 0 else (c_in + 3 if use_xyz else c_in)
         self.mlps = nn.ModuleList([_SharedMLP(feat, widths, bn) for widths in mlp_list])
         self.fused_mlp = True          # eval-mode forward may use the fused MFMA kernel (sa_mlp.py)
@@ -331,9 +341,7 @@ class PointnetSAModuleMSG(nn.Module):
     def _fused_ok(self, xyz, points):
         if not self.fused_mlp or self.training or torch.is_grad_enabled() or not xyz.is_cuda:
             return False
-        if points is not None and not self.use_xyz:
-            return False
-        cin = 3 + (points.shape[2] if points is not None else 0)
+        cin = 3 + (points.shape[2] if points is not None else 0)       # (use_xyz=False: three zero rows of weight, _packed)
         return all(sa_mlp.supported(cin, mlp.widths, ns) for mlp, ns in zip(self.mlps, self.nsample_list))
 
     def _packed(self, si, device):
@@ -343,13 +351,15 @@ class PointnetSAModuleMSG(nn.Module):
         if hit is None or hit[0] != stamp:
             _no_packing_under_capture()
             # the MSG module concatenates features FIRST (:184): xyz_first=False
-            hit = (stamp, sa_mlp.PackedMLP3(mlp.folded_layers(), device, self.nsample_list[si], xyz_first=False))
+            no_xyz = not self.use_xyz and self.c_in > 0                 # features only (:182-184 without the concat)
+            hit = (stamp, sa_mlp.PackedMLP3(mlp.folded_layers("last" if no_xyz else None), device, self.nsample_list[si],
+                                            xyz_first=False))
             self._pack_cache[si] = hit
         return hit[1]
 
     def prepare_fused(self, device):
         """See PointnetSAModule.prepare_fused."""
-        cin = self.mlps[0].net[0].in_channels
+        cin = self.mlps[0].net[0].in_channels + (3 if not self.use_xyz and self.c_in > 0 else 0)
         if all(sa_mlp.supported(cin, mlp.widths, ns) for mlp, ns in zip(self.mlps, self.nsample_list)):
             for si in range(len(self.mlps)):
                 self._packed(si, device)

@@ -110,3 +110,42 @@ def test_level_entry_points_equal_the_operator_sequence(cuda):
         u1 = fp(xyz, new_xyz, feat, pooled)
         u2 = fp(xyz, new_xyz, feat, pooled)
         assert u1.data_ptr() == u2.data_ptr() and torch.equal(u2, want_up)
+
+
+@pytest.mark.parametrize("kind", ["ssg", "msg", "group_all"])
+def test_use_xyz_false_takes_the_fused_kernels(cuda, kind):
+    """use_xyz=False (pointnet_util.py:49-52, :182-184): the level's stack sees the grouped features only. The fused kernels
+    always gather the coordinates; they meet three ZERO rows of weight, so the fused result must agree with the
+    layer-by-layer path (fp32 accuracy: 1e-5 of the output scale) and the level must not fall off the fused path."""
+    import pointnet2_amd.pointnet_util as U
+    torch.manual_seed(4)
+    xyz = _dev(S.sphere_clouds(4, 1024, 12), cuda)
+    feat = torch.randn(4, 1024, 16, device=cuda)
+    if kind == "ssg":
+        mod = U.PointnetSAModule(16, 256, 0.2, 32, [32, 32, 64], use_xyz=False)
+    elif kind == "msg":
+        mod = U.PointnetSAModuleMSG(16, 256, [0.1, 0.2], [16, 32], [[32, 32, 64], [32, 48, 64]], use_xyz=False)
+    else:                                                           # cls_ssg's last level (pointnet2_cls_ssg.py:29) without the concat
+        xyz, feat = xyz[:, :128].contiguous(), torch.randn(4, 128, 256, device=cuda)
+        mod = U.PointnetSAModule(256, None, None, None, [256, 512, 1024], group_all=True, use_xyz=False)
+    mod = mod.to(cuda).eval()
+    first = (mod.mlp if kind != "msg" else mod.mlps[0]).net[0]
+    assert first.in_channels == feat.shape[2]                       # no coordinate channels in the learned weights
+    with torch.no_grad():
+        got = mod(xyz, feat)
+        assert mod.last_path == "fused"
+        mod.fused_mlp = False
+        want = mod(xyz, feat)
+        assert mod.last_path == "unfused"
+    for u, v in zip(got[:2], want[:2]):
+        assert u.shape == v.shape
+        assert (u - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item())
+    # and with a feature-less input the flag changes nothing (the coordinates ARE the input then, :53-54)
+    if kind == "ssg":
+        bare = U.PointnetSAModule(0, 256, 0.2, 32, [32, 32, 64], use_xyz=False).to(cuda).eval()
+        with torch.no_grad():
+            a = bare(xyz, None)
+            assert bare.last_path == "fused"
+            bare.fused_mlp = False
+            b = bare(xyz, None)
+        assert (a[1] - b[1]).abs().max().item() <= 1e-5 * max(1.0, b[1].abs().max().item())
