@@ -38,3 +38,25 @@ def test_metric_shape_kernels_hold_their_times(cuda):
     tr = bench.sa_train_level(stage)
     assert tr["forward_us"] <= 450.0, "training level forward: %.1f us (round 4: 395-406)" % tr["forward_us"]
     assert tr["backward_us"] <= 1050.0, "training level backward: %.1f us (round 4: 934-957)" % tr["backward_us"]
+
+
+def test_large_cloud_and_second_level_shapes_hold_their_times(cuda):
+    """Two tripwires of round 5. (1) sem_seg's first level (b = 8, 8192 -> 1024): the overlapped launch's consumers must sweep
+    such clouds, and with one persistent consumer per cloud the launch took 968 us against 459 for two launches for a whole
+    session before a model-level number showed it -- whatever pn2_sample_and_group_xyz does there must not lose to the
+    two-launch path by more than 10 %. (2) A level-2 input through the checked identity must beat the chain (67 -> 17 us)."""
+    import pointnet2_amd as P
+    from pointnet2_amd import synthetic as S, tf_grouping as G, tf_sampling as TS
+    x = torch.from_numpy(S.uniform_clouds(8, 8192, 3)).to(cuda)
+    t_auto = _event_us(lambda: P.sample_and_group_xyz(1024, 0.1, 32, x))
+    G.set_overlapped_launch(False)
+    try:
+        t_two = _event_us(lambda: P.sample_and_group_xyz(1024, 0.1, 32, x))
+    finally:
+        G.set_overlapped_launch(True)
+    assert t_auto <= 1.10 * t_two + 10.0, "sample_and_group_xyz 8 x 8192 -> 1024: %.1f us against %.1f us for the two launches" % (t_auto, t_two)
+    assert t_auto <= 560.0, "sample_and_group_xyz 8 x 8192 -> 1024: %.1f us (round 5: 459)" % t_auto
+    _, l1, _, _, _ = P.sample_and_group_xyz(1024, 0.1, 32, x)
+    t_chain = _event_us(lambda: TS.farthest_point_sample_gather(256, l1, ordered=False))
+    t_ord = _event_us(lambda: TS.farthest_point_sample_gather(256, l1, ordered=True))
+    assert t_ord <= 0.6 * t_chain, "checked identity at 1024 -> 256: %.1f us against the chain's %.1f (round 5: 17 / 67)" % (t_ord, t_chain)
