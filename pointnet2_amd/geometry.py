@@ -152,8 +152,8 @@ class PipelinedInference:
     """A serving loop with the geometry one batch ahead and no host time in the loop: per input slot (two of them) one HIP
     graph of the network's geometry, replayed on the geometry stream, and one of its layer stacks reading that graph's output
     tensors, replayed on the caller's stream; two events per batch order them. While the stacks of batch i fill the CUs, the
-    farthest-point chains of batch i + 1 run beside them (eval forwards per batch: cls_ssg 0.49 -> 0.42 ms, part_seg
-    0.60 -> 0.50, sem_seg 0.90 -> 0.57; profiles/r05/model_forward.txt).
+    farthest-point chains of batch i + 1 run beside them (eval forwards per batch: cls_ssg 0.49 -> 0.43 ms, part_seg
+    0.59 -> 0.45, sem_seg 0.89 -> 0.58, 0.48 with geometry_streams=2; profiles/r05/model_forward.txt).
 
         pipe = PipelinedInference(net, net.ahead(), example_batch)        # captures; shapes are fixed from here on
         for x, ready in loader:                                           # x filled by the loader's stream, `ready` its event
@@ -161,8 +161,8 @@ class PipelinedInference:
             consume(y)                                                    # ... on the current stream
 
     model(x, geometry) is the network (modules called with `geometry=`), in eval mode under no_grad; coords(x) -> the (b, n, 3)
-    coordinates the geometry is computed from (default: x itself). The output is a static buffer of its slot: the second
-    push after the one that returned it overwrites it -- consume or clone it before.
+    coordinates the geometry is computed from (default: x itself). The output is a static buffer of its slot: push number
+    geometry_streams + 1 after the one that returned it overwrites it -- consume or clone it before.
 
     What was measured on the way (profiles/r05/geometry_ahead.txt): ONE graph with a forked branch does not overlap anything,
     hipGraphLaunch ran the two branches one after the other (0.72 ms on cls_ssg against 0.49 plain). The stacks on a stream
@@ -171,18 +171,24 @@ class PipelinedInference:
     stream (its own queue class) is 0.45-0.46 every time, hence this organisation.
     """
 
-    def __init__(self, model, ahead, example, coords=None, no_grad=True):
+    def __init__(self, model, ahead, example, coords=None, no_grad=True, geometry_streams=1):
+        """geometry_streams: how many batches' geometry may run at once (each on a high-priority stream of its own; the input
+        slots are geometry_streams + 1). 1 hides the geometry of batch i + 1 under the stacks of batch i; 2 pays when the
+        geometry stream is the bottleneck (sem_seg: 435 us of one-CU-per-cloud chains per batch on 8 of 256 CUs)."""
         self.ahead = ahead
         coords = coords or (lambda x: x)
         dev = example.device
         capture_stream = torch.cuda.Stream(device=dev)
-        self._in = [example.clone(), example.clone()]
+        G = max(1, int(geometry_streams))
+        S = G + 1
+        self._geo_streams = [ahead.stream] + [torch.cuda.Stream(device=dev, priority=-1) for _ in range(G - 1)]
+        self._in = [example.clone() for _ in range(S)]
         self._geo_graphs, self._stack_graphs, self._sets, self._outs = [], [], [], []
         cur = torch.cuda.current_stream(dev)
         # no_grad=False: `model` is a whole training step (forward, loss, backward, optimiser step on static gradient
         # buffers) -- scripts/train_step_bench.py --graph; what must hold for such a capture is torch's (torch.cuda.graphs)
         with (torch.no_grad() if no_grad else torch.enable_grad()):
-            for k in (0, 1):
+            for k in range(S):
                 ahead.stream.wait_stream(cur)
                 with torch.cuda.stream(ahead.stream):                   # warm-up on the capture streams (lazy initialisations)
                     g = ahead.compute(coords(self._in[k]))
@@ -198,8 +204,8 @@ class PipelinedInference:
                     self._outs.append(model(self._in[k], self._sets[k]))
                 self._geo_graphs.append(gg)
                 self._stack_graphs.append(sg)
-        self._geo_done = [torch.cuda.Event(), torch.cuda.Event()]
-        self._stack_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self._geo_done = [torch.cuda.Event() for _ in range(S)]
+        self._stack_done = [torch.cuda.Event() for _ in range(S)]
         for e in self._stack_done:
             e.record(cur)
         self._i = 0
@@ -209,13 +215,13 @@ class PipelinedInference:
         ready: an event recorded after x's producer (a loader stream); False = x is complete already; None = x was produced on
         the current stream (an event is recorded there now -- which also orders this batch's geometry behind everything the
         current stream holds, the previous batch's stacks included: correct, but nothing overlaps)."""
-        k = self._i % 2
+        k = self._i % len(self._in)
+        a = self._geo_streams[self._i % len(self._geo_streams)]
         self._i += 1
-        a = self.ahead.stream
         cur = torch.cuda.current_stream(x.device)
         if ready is not False:
             a.wait_event(cur.record_event() if ready is None else ready)
-        a.wait_event(self._stack_done[k])                               # the stacks that read this slot two pushes ago
+        a.wait_event(self._stack_done[k])                               # the stacks that read this slot len(slots) pushes ago
         x.record_stream(a)
         with torch.cuda.stream(a):
             self._in[k].copy_(x, non_blocking=True)

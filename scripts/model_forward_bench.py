@@ -127,11 +127,11 @@ def timeit(fn, iters=10, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
-def graphed_pipeline(model, ahead, coords, inputs, expect):
+def graphed_pipeline(model, ahead, coords, inputs, expect, geometry_streams=1):
     """The serving loop of pointnet2_amd.geometry.PipelinedInference on two inputs in rotation: per slot one HIP graph of the
     geometry on the geometry stream and one of the layer stacks on a stack stream; the stacks of batch i run beside the
     geometry of batch i + 1. -> (ms per batch, outputs bit-identical to `expect`)"""
-    pipe = PipelinedInference(model, ahead, inputs[0], coords)
+    pipe = PipelinedInference(model, ahead, inputs[0], coords, geometry_streams=geometry_streams)
     state = {"i": 0}
 
     def step():
@@ -216,11 +216,13 @@ def main():
             same = same and torch.equal(pipelined(), out) and torch.equal(pipelined(), model(inputs[1]))
             torch.cuda.synchronize()
             t_pipe_graph, same_graph = graphed_pipeline(model, ahead, coords, inputs, [out, model(inputs[1])])
+            t_pipe_graph2, same_graph2 = graphed_pipeline(model, model.ahead(), coords, inputs, [out, model(inputs[1])], 2)
+            same_graph = same_graph and same_graph2
         paths = [m.last_path for m in model.modules() if hasattr(m, "last_path")]
         print("%-58s unfused %7.3f ms | fused MLPs %7.3f ms | fused + HIP graph %7.3f ms | geometry on its own stream %7.3f ms, one "
-              "batch ahead %7.3f ms per batch (bit-identical: %s), as HIP graphs on the two streams %7.3f ms per batch (bit-identical: %s) "
-              "| rel. diff %.1e | SA paths %s"
-              % (name, t_unfused, t_fused, t_graph, t_within, t_pipe, same, t_pipe_graph, same_graph, err, paths), flush=True)
+              "batch ahead %7.3f ms per batch (bit-identical: %s), as HIP graphs on the two streams %7.3f ms per batch, with two geometry "
+              "streams %7.3f (bit-identical: %s) | rel. diff %.1e | SA paths %s"
+              % (name, t_unfused, t_fused, t_graph, t_within, t_pipe, same, t_pipe_graph, t_pipe_graph2, same_graph, err, paths), flush=True)
 
 
 if __name__ == "__main__":

@@ -127,15 +127,16 @@ def test_training_step_on_geometry_ahead_is_bit_identical(cuda):
         assert torch.equal(ba, bb), na
 
 
-def test_pipelined_inference_serving_loop(cuda):
-    """geometry.PipelinedInference: per-slot HIP graphs on two streams; every batch's output equals the plain forward's."""
+@pytest.mark.parametrize("geometry_streams", [1, 2])
+def test_pipelined_inference_serving_loop(cuda, geometry_streams):
+    """geometry.PipelinedInference: per-slot HIP graphs on two (three) streams; every batch's output equals the plain forward's."""
     from pointnet2_amd.geometry import PipelinedInference
     torch.manual_seed(2)
     net = _Net().to(cuda).eval()
     batches = [_cloud(cuda, 4, 1024, 40 + i) for i in range(7)]
     with torch.no_grad():
         plain = [net(c) for c in batches]
-        pipe = PipelinedInference(net, net.ahead(), batches[0], coords=_coords)
+        pipe = PipelinedInference(net, net.ahead(), batches[0], coords=_coords, geometry_streams=geometry_streams)
         loader = torch.cuda.Stream()
         got = []
         for i, c in enumerate(batches):
