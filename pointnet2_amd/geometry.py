@@ -141,6 +141,8 @@ class GeometryAhead:
     def submit(self, xyz):
         """xyz (b, n, 3) f32 on the device, produced on the current stream -> NetworkGeometry (launches enqueued on
         self.stream, one event per level, nothing waited for)."""
+        if not (isinstance(xyz, torch.Tensor) and xyz.is_cuda and xyz.device == self.device and xyz.dim() == 3 and xyz.shape[2] == 3):
+            raise ValueError("GeometryAhead.submit expects (batch_size, num_points, 3) coordinates on %s" % (self.device,))
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_event(cur.record_event())
         xyz.record_stream(self.stream)
@@ -215,6 +217,10 @@ class PipelinedInference:
         ready: an event recorded after x's producer (a loader stream); False = x is complete already; None = x was produced on
         the current stream (an event is recorded there now -- which also orders this batch's geometry behind everything the
         current stream holds, the previous batch's stacks included: correct, but nothing overlaps)."""
+        ref = self._in[0]
+        if not (isinstance(x, torch.Tensor) and x.shape == ref.shape and x.dtype == ref.dtype and x.device == ref.device):
+            raise ValueError("PipelinedInference.push: the batch must be a %s tensor of shape %s on %s like the example (the graphs "
+                             "were captured for that)" % (ref.dtype, tuple(ref.shape), ref.device))
         k = self._i % len(self._in)
         a = self._geo_streams[self._i % len(self._geo_streams)]
         self._i += 1

@@ -170,3 +170,19 @@ def test_static_copy_and_refill(cuda):
         st.copy_(ahead.compute(_coords(y)))
         assert _same(net(y, st), net(y), net)
     assert isinstance(ahead, GeometryAhead) and len(st.tensors()) == len(gx.tensors()) == 2 + 3 + 2 + 2
+
+
+def test_argument_checks(cuda):
+    from pointnet2_amd.geometry import PipelinedInference
+    net = _Net().to(cuda).eval()
+    ahead = net.ahead()
+    with pytest.raises(ValueError):
+        ahead.submit(torch.zeros(2, 64, 4, device=cuda))
+    with pytest.raises(ValueError):
+        ahead.submit(torch.zeros(2, 64, 3))
+    x = _cloud(cuda, 2, 512, 61)
+    with torch.no_grad():
+        pipe = PipelinedInference(net, ahead, x, coords=_coords)
+        with pytest.raises(ValueError):
+            pipe.push(_cloud(cuda, 3, 512, 62))
+        assert torch.equal(pipe.push(x, False), net(x))
