@@ -280,7 +280,11 @@ def concurrent_throughput(dev, rank, path, streams, steps):
     """EXTRA figure (not `value`): the same step on `streams` independent B=32 batches in flight on
     separate HIP streams. One FPS launch occupies 32 of the 256 CUs for its whole serial chain, so
     independent batches (prefetched SA1 inputs, concurrent requests) overlap almost perfectly."""
-    ss = [torch.cuda.Stream(device=dev) for _ in range(streams)]
+    # streams of BOTH priority classes, alternating: the runtime keeps separate hardware queues per class (what made the
+    # geometry stream of pointnet2_amd/geometry.py independent of the stacks' queue), so eight streams reach more queues than
+    # eight streams of one class do (PN2_BENCH_ONE_PRIORITY=1: all of the normal class, the organisation of rounds 2-4)
+    one_class = bool(os.environ.get("PN2_BENCH_ONE_PRIORITY"))
+    ss = [torch.cuda.Stream(device=dev, priority=0 if (one_class or i % 2 == 0) else -1) for i in range(streams)]
     fns, stages = [], []
     for i, st in enumerate(ss):
         with torch.cuda.stream(st):
@@ -304,11 +308,14 @@ def concurrent_throughput(dev, rank, path, streams, steps):
     return {"streams": streams, "steps": steps, "value": B * steps / dt, "unit": "clouds/s",
             "ms_per_step": dt / steps * 1e3, "verified": all(c["ok"] for c in checks),
             "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
+            "stream_priorities": "all normal" if one_class else "normal / high alternating",
             "verify_failures": [dict(c, stream=i) for i, c in enumerate(checks) if not c["ok"]],
             "note": "independent batches on separate HIP streams; reported beside `value`, which times strictly sequential steps "
                     "on one stream. Bounded by the runtime's hardware queues, not by the kernels (a launch occupies 64 of 256 CUs): "
-                    "measured 210 k clouds/s with the default 4 queues, 239-252 k with GPU_MAX_HW_QUEUES=8, 319-396 k with 16 "
-                    "(profiles/r05/concurrent_hw_queues.txt)"}
+                    "with streams of one priority class 210-224 k clouds/s on the default 4 queues, 239-252 k with "
+                    "GPU_MAX_HW_QUEUES=8, 319-396 k with 16 (profiles/r05/concurrent_hw_queues.txt); streams of both classes "
+                    "alternating (the default here) 244 k on the default queues. Four launches fill the device: every workgroup "
+                    "of the overlapped launch reserves more than half of a CU's LDS"}
 
 
 def _oracle_stage(O, xyz, radius):
