@@ -121,3 +121,38 @@ def test_ordered_sa_level_matches_sa_level(cuda):
     for x, y in zip(a, b_):
         assert torch.equal(x, y)
     assert torch.equal(a[0], l1_xyz[:, :256])                          # uniform clouds: the short cut held
+
+
+def test_fuzz_random_shapes_and_clouds(cuda, oracle):
+    """Seeded survey: random (b, n1, m1, m2) and cloud kinds -- level-2 inputs (subsets in the order level 1 picked them), raw
+    clouds, clouds with repeated points, lattices, a few non-finite coordinates -- through the ordered entry point and its
+    check alone, against the oracle; every chunking of the check (m2 from 2 to 1024) gets hit."""
+    import pointnet2_amd as P
+    from pointnet2_amd import tf_sampling as TS
+    rng = np.random.default_rng(2025)
+    makers = [S.uniform_clouds, S.sphere_clouds, S.duplicated_clouds, S.lattice_clouds, S.dropout_clouds]
+    for case in range(60):
+        b = int(rng.integers(1, 5))
+        n1 = int(rng.integers(8, 3000))
+        m1 = int(rng.integers(2, min(n1, 2048) + 1))
+        m2 = int(rng.integers(2, min(m1, 1024) + 1))
+        make = makers[case % len(makers)]
+        cloud = make(b, n1, 3000 + case)
+        if case % 4 == 3:
+            level = cloud[:, :m1].copy()                          # raw points: no order at all
+        else:
+            level = _level1(cuda, cloud, m1)                      # a true level-2 input
+        if case % 15 == 14:
+            level[0, min(5, m1 - 1), 1] = np.inf                  # the check must leave such clouds to the chain
+        want = oracle.farthest_point_sample(m2, level)
+        t = dev(level, cuda)
+        got, got_xyz = TS.farthest_point_sample_gather(m2, t, ordered=True)
+        assert np.array_equal(host(got), want), "case %d (%s b=%d n=%d m=%d): %s" % (case, make.__name__, b, m1, m2, np.argwhere(host(got) != want)[:3])
+        assert np.array_equal(host(got_xyz), np.take_along_axis(level, want[..., None].astype(np.int64), axis=1), equal_nan=True)
+        flags = torch.zeros((b,), dtype=torch.int32, device=t.device)
+        P._C.check(P._C.lib().pn2_fps_ordered_check(b, m1, m2, t.data_ptr(), flags.data_ptr(), TS.stream_ptr(t.device)), "check")
+        ident = (want == np.arange(m2, dtype=np.int32)[None]).all(axis=1)
+        finite = np.isfinite(level).all(axis=(1, 2))
+        # flagged <=> not the identity, except that a cloud with a non-finite coordinate is flagged whatever its sampling is
+        assert np.array_equal((host(flags) != 0)[finite], ~ident[finite]), "case %d" % case
+        assert (host(flags) != 0)[~finite].all()
