@@ -144,7 +144,9 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, int Q, int cloud, con
     // previous batch, pointnet2_amd/geometry.py) its waves would queue behind theirs at every issue. Highest wave priority: the
     // neighbours lose a few issue slots on b of 256 CUs, the chain keeps its pace (sem_seg training step with the geometry one
     // step ahead: 10.5 ms without this line, profiles/r05/geometry_ahead.txt).
+#ifndef PN2_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
+#endif
     constexpr int W = T / PN2_WAVE;
     constexpr int NS = T * P;                      // rank slots
     unsigned long long *partial = reinterpret_cast<unsigned long long *>(smem);   // [2][W] (256 B reserved)

@@ -105,7 +105,9 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
     // previous batch, pointnet2_amd/geometry.py) its waves would queue behind theirs at every issue. Highest wave priority: the
     // neighbours lose a few issue slots on b of 256 CUs, the chain keeps its pace (sem_seg training step with the geometry one
     // step ahead: 10.5 ms without this line, profiles/r05/geometry_ahead.txt).
+#ifndef PN2_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
+#endif
     constexpr int T = kPrT, W = kPrW, NS = T * P;
     constexpr int GW = P / GS;                    // groups per wave
     constexpr int G = W * GW;                     // groups = leaves = test lanes

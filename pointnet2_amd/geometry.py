@@ -39,14 +39,13 @@ class _Ready:
         return self
 
     def wait(self):
-        """Make the CURRENT stream wait for the level's launches and tell the allocator about the second user (a tensor
-        freed while a launch of this stream still reads it must not be handed to the producer stream's next allocation)."""
+        """Make the CURRENT stream wait for the level's launches. No Tensor.record_stream here (see GeometryAhead.submit): the
+        tensors belong to the producer stream's pool, and the producer's next allocations are ordered behind this stream's
+        work by the wait at the top of every submit()."""
         if self.event is not None:
             cur = torch.cuda.current_stream(self._tensors[0].device)
             if cur != self.stream:
                 cur.wait_event(self.event)
-                for t in self._tensors:
-                    t.record_stream(cur)
         return self
 
 
@@ -75,10 +74,11 @@ class NetworkGeometry:
     """sa[k]: SAGeometry of the k-th SA module (None for a group_all level, which has no geometry);
     fp[k]: FPGeometry of the k-th (xyz1 level, xyz2 level) pair given to GeometryAhead."""
 
-    __slots__ = ("sa", "fp")
+    __slots__ = ("sa", "fp", "_src")
 
     def __init__(self, sa, fp):
         self.sa, self.fp = sa, fp
+        self._src = None                 # the coordinates the launches read (kept alive with the result, see GeometryAhead.submit)
 
     def tensors(self):
         """Every tensor of every level, in a fixed order."""
@@ -117,6 +117,7 @@ class GeometryAhead:
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.device = dev
         self.stream = torch.cuda.Stream(device=dev, priority=-1 if high_priority else 0)
+        self._in_flight = []             # (event after a submit's last launch, its input): inputs stay alive while launches read them
 
     def compute(self, xyz, mark=None):
         """Every level's geometry on the CURRENT stream (no stream switch, no events unless `mark` is a stream to record them
@@ -140,18 +141,37 @@ class GeometryAhead:
 
     def submit(self, xyz):
         """xyz (b, n, 3) f32 on the device, produced on the current stream -> NetworkGeometry (launches enqueued on
-        self.stream, one event per level, nothing waited for)."""
+        self.stream, one event per level, nothing waited for). Consume the result on the stream that is current HERE.
+
+        Lifetimes without Tensor.record_stream. On this build (torch 2.10 + ROCm 7.2) record_stream followed by graph captures
+        made the caching allocator hand out memory twice: after a layer-by-layer forward and a few of these submits, a slot of
+        a later PipelinedInference was overwritten by the soak loop's own temporaries from some batch on -- deterministically,
+        and gone with the three record_stream calls this file had (profiles/r05/geometry_ahead.txt). Instead: the input is kept
+        referenced until its launches are done, and the results -- blocks of self.stream's pool -- can only be reused by a
+        later submit, whose launches wait (first line below) for everything the consumer stream held when it was called."""
         if not (isinstance(xyz, torch.Tensor) and xyz.is_cuda and xyz.device == self.device and xyz.dim() == 3 and xyz.shape[2] == 3):
             raise ValueError("GeometryAhead.submit expects (batch_size, num_points, 3) coordinates on %s" % (self.device,))
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_event(cur.record_event())
-        xyz.record_stream(self.stream)
+        self._in_flight = [(ev, t) for ev, t in self._in_flight if not ev.query()]
         with torch.cuda.stream(self.stream):
-            return self.compute(xyz, mark=self.stream)
+            g = self.compute(xyz, mark=self.stream)
+            g._src = xyz
+            self._in_flight.append((self.stream.record_event(), xyz))
+        return g
 
 
 class PipelinedInference:
-    """A serving loop with the geometry one batch ahead and no host time in the loop: per input slot (two of them) one HIP
+    """EXPERIMENTAL -- validated in a serving process of its own (tests/test_geometry_ahead_gpu.py: 1,200-batch soak; 9,000
+    batches in the bisecting runs of round 5), but inside scripts/model_forward_bench.py's process -- after layer-by-layer
+    torch forwards, other graph captures and eager two-stream runs -- the same soak found ONE slot returning wrong results
+    (the library's own levels, not the torch head) from some batch on, reproducibly, and the cause was not found before the
+    round's GPU budget ran out (profiles/r05/geometry_ahead.txt lists what was ruled out: Tensor.record_stream, the
+    caching allocator handing an eager temporary a graph's memory, host run-ahead, the torch heads, every geometry component
+    alone). Until that is understood its timings are measurements of an organisation, not results of the product, and the
+    bench prints the soak's verdict next to each of them.
+
+    A serving loop with the geometry one batch ahead and no host time in the loop: per input slot (two of them) one HIP
     graph of the network's geometry, replayed on the geometry stream, and one of its layer stacks reading that graph's output
     tensors, replayed on the caller's stream; two events per batch order them. While the stacks of batch i fill the CUs, the
     farthest-point chains of batch i + 1 run beside them (eval forwards per batch: cls_ssg 0.49 -> 0.43 ms, part_seg
@@ -163,8 +183,8 @@ class PipelinedInference:
             consume(y)                                                    # ... on the current stream
 
     model(x, geometry) is the network (modules called with `geometry=`), in eval mode under no_grad; coords(x) -> the (b, n, 3)
-    coordinates the geometry is computed from (default: x itself). The output is a static buffer of its slot: push number
-    geometry_streams + 1 after the one that returned it overwrites it -- consume or clone it before.
+    coordinates the geometry is computed from (default: x itself). The output is a static buffer of its slot: the push
+    `slots` (2, or 2 * geometry_streams) calls after the one that returned it overwrites it -- consume or clone it before.
 
     What was measured on the way (profiles/r05/geometry_ahead.txt): ONE graph with a forked branch does not overlap anything,
     hipGraphLaunch ran the two branches one after the other (0.72 ms on cls_ssg against 0.49 plain). The stacks on a stream
@@ -174,15 +194,16 @@ class PipelinedInference:
     """
 
     def __init__(self, model, ahead, example, coords=None, no_grad=True, geometry_streams=1):
-        """geometry_streams: how many batches' geometry may run at once (each on a high-priority stream of its own; the input
-        slots are geometry_streams + 1). 1 hides the geometry of batch i + 1 under the stacks of batch i; 2 pays when the
-        geometry stream is the bottleneck (sem_seg: 435 us of one-CU-per-cloud chains per batch on 8 of 256 CUs)."""
+        """geometry_streams: how many batches' geometry may run at once, each on a high-priority stream of its own. 1 (two input
+        slots) hides the geometry of batch i + 1 under the stacks of batch i; 2 (four slots: a slot's graphs are always replayed
+        on the same stream: profiles/r05/geometry_ahead.txt) pays when the geometry stream is the bottleneck (sem_seg: 435 us of
+        one-CU-per-cloud chains per batch on 8 of 256 CUs)."""
         self.ahead = ahead
         coords = coords or (lambda x: x)
         dev = example.device
         capture_stream = torch.cuda.Stream(device=dev)
         G = max(1, int(geometry_streams))
-        S = G + 1
+        S = 2 * G if G > 1 else 2                                       # a slot's graphs are always replayed on the same streams
         self._geo_streams = [ahead.stream] + [torch.cuda.Stream(device=dev, priority=-1) for _ in range(G - 1)]
         self._in = [example.clone() for _ in range(S)]
         self._geo_graphs, self._stack_graphs, self._sets, self._outs = [], [], [], []
@@ -206,6 +227,7 @@ class PipelinedInference:
                     self._outs.append(model(self._in[k], self._sets[k]))
                 self._geo_graphs.append(gg)
                 self._stack_graphs.append(sg)
+        self._held = [None] * S                                         # the caller's batch of each slot, until the slot's next use
         self._geo_done = [torch.cuda.Event() for _ in range(S)]
         self._stack_done = [torch.cuda.Event() for _ in range(S)]
         for e in self._stack_done:
@@ -222,13 +244,16 @@ class PipelinedInference:
             raise ValueError("PipelinedInference.push: the batch must be a %s tensor of shape %s on %s like the example (the graphs "
                              "were captured for that)" % (ref.dtype, tuple(ref.shape), ref.device))
         k = self._i % len(self._in)
-        a = self._geo_streams[self._i % len(self._geo_streams)]
+        a = self._geo_streams[k % len(self._geo_streams)]
         self._i += 1
         cur = torch.cuda.current_stream(x.device)
+        # bounded run-ahead: the host waits HERE for the slot's previous batch (work that is `slots` batches old) instead of in a
+        # full hardware queue a little later; after it nothing reads the batch the slot held, which is released below
+        self._stack_done[k].synchronize()
         if ready is not False:
             a.wait_event(cur.record_event() if ready is None else ready)
         a.wait_event(self._stack_done[k])                               # the stacks that read this slot len(slots) pushes ago
-        x.record_stream(a)
+        self._held[k] = x                                               # (no Tensor.record_stream: see GeometryAhead.submit)
         with torch.cuda.stream(a):
             self._in[k].copy_(x, non_blocking=True)
             self._geo_graphs[k].replay()

@@ -148,8 +148,7 @@ def test_pipelined_inference_serving_loop(cuda, geometry_streams):
                 with torch.cuda.stream(loader):
                     x = c.clone()
                     ev = loader.record_event()
-                got.append(pipe.push(x, ev).clone())
-                x.record_stream(torch.cuda.current_stream())
+                got.append(pipe.push(x, ev).clone())            # (the pipeline keeps x referenced while its copy is in flight)
     torch.cuda.synchronize()
     assert all(p == "fused" for p in _paths(net)), _paths(net)
     for i, (u, v) in enumerate(zip(got, plain)):
@@ -186,3 +185,80 @@ def test_argument_checks(cuda):
         with pytest.raises(ValueError):
             pipe.push(_cloud(cuda, 3, 512, 62))
         assert torch.equal(pipe.push(x, False), net(x))
+
+
+_SOAK = r"""
+import sys
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+import torch
+from test_geometry_ahead_gpu import _Net, _cloud, _coords
+from pointnet2_amd.geometry import PipelinedInference
+cuda = torch.device("cuda:0")
+torch.manual_seed(5)
+net = _Net().to(cuda).eval()
+ins = [_cloud(cuda, 4, 1024, 70 + i) for i in range(3)]
+with torch.no_grad():
+    want = [net(c).clone() for c in ins]
+    for gs in (1, 2, 1, 2):
+        pipe = PipelinedInference(net, net.ahead(), ins[0], coords=_coords, geometry_streams=gs)
+        bad = torch.zeros((300,), dtype=torch.int64, device=cuda)
+        for i in range(300):
+            bad[i] = (pipe.push(ins[i %% 3], False) != want[i %% 3]).sum()
+        torch.cuda.synchronize()
+        wrong = (bad != 0).nonzero().flatten().tolist()
+        assert not wrong, "geometry_streams=%%d: wrong batches %%s" %% (gs, wrong[:8])
+        del pipe
+print("soak ok")
+"""
+
+
+def test_pipelined_inference_soak_in_a_serving_process(cuda):
+    """Three inputs in rotation (every slot sees changing content) through two- and four-slot pipelines created one after the
+    other, 300 batches each, every output compared on the device in stream order -- in a process of its own, which is the
+    condition the loop is validated for: inside scripts/model_forward_bench.py's process (layer-by-layer torch forwards,
+    other graph captures and eager two-stream runs before it) the same soak found a slot returning wrong results from some
+    batch on, cause not found (profiles/r05/geometry_ahead.txt)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _SOAK % (root, os.path.join(root, "tests"))], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "soak ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_argument_checks(cuda):
+    from pointnet2_amd.geometry import PipelinedInference
+    net = _Net().to(cuda).eval()
+    ahead = net.ahead()
+    with pytest.raises(ValueError):
+        ahead.submit(torch.zeros(2, 64, 4, device=cuda))
+    with pytest.raises(ValueError):
+        ahead.submit(torch.zeros(2, 64, 3))
+    x = _cloud(cuda, 2, 512, 61)
+    with torch.no_grad():
+        pipe = PipelinedInference(net, ahead, x, coords=_coords)
+        with pytest.raises(ValueError):
+            pipe.push(_cloud(cuda, 3, 512, 62))
+        assert torch.equal(pipe.push(x, False), net(x))
+
+
+def test_pipelined_inference_soak_with_changing_slot_content(cuda):
+    """Three inputs in rotation through two- and four-slot pipelines created one after the other (every slot sees changing
+    content; a graph replayed alternately on two streams returned wrong results from its fourth batch on in round 5's
+    bisection -- profiles/r05/geometry_ahead.txt -- which is why a slot's graphs keep their streams): 300 batches each,
+    every output compared on the device in stream order."""
+    from pointnet2_amd.geometry import PipelinedInference
+    torch.manual_seed(5)
+    net = _Net().to(cuda).eval()
+    ins = [_cloud(cuda, 4, 1024, 70 + i) for i in range(3)]
+    with torch.no_grad():
+        want = [net(c).clone() for c in ins]
+        for gs in (1, 2, 1, 2):
+            pipe = PipelinedInference(net, net.ahead(), ins[0], coords=_coords, geometry_streams=gs)
+            bad = torch.zeros((300,), dtype=torch.int64, device=cuda)
+            for i in range(300):
+                bad[i] = (pipe.push(ins[i % 3], False) != want[i % 3]).sum()
+            torch.cuda.synchronize()
+            assert int((bad != 0).sum()) == 0, "geometry_streams=%d: wrong batches %s" % (gs, (bad != 0).nonzero().flatten().tolist()[:8])
+            del pipe
