@@ -278,9 +278,8 @@ def sa_level(npoint, radius, nsample, xyz, points, packed, buffers=None):
             # pn2_sa_level takes the two-launch path, no sa_fused_kernel is launched
             ent, gen, wsp = None, 0, None
         elif torch.cuda.is_current_stream_capturing():
-            wss = torch.empty((lib.pn2_sample_and_group_ws_bytes(b, m),), dtype=torch.uint8, device=dev)
-            ent, gen = None, 0
-            wsp = ptr(wss)
+            # no overlapped launch inside a captured graph (tf_grouping.sample_and_group_xyz says why): NULL workspace = two launches
+            ent, gen, wsp = None, 0, None
         else:
             ent = G._granule_workspace(lib, dev, st, b, m)         # raises if an earlier launch on it reported a give-up
             gen, wsp = ent[1], ptr(ent[0])

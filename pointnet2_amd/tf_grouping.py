@@ -280,25 +280,22 @@ def sample_and_group_xyz(npoint, radius, nsample, xyz, subtract_centroid=True):
     cnt = torch.empty((b, m), dtype=torch.int32, device=dev)
     grouped = torch.empty((b, m, ns, 3), dtype=torch.float32, device=dev)
     st = stream_ptr(dev)
+    if torch.cuda.is_current_stream_capturing():
+        # A captured launch is replayed with the same arguments: generations cannot advance, the workspace would have to be
+        # cleared INSIDE the graph (hipMemsetAsync + tag 1, what rounds 2-4 did here). Round 5's soak of a serving loop found
+        # geometry graphs whose overlapped launch served STALE granules -- samples of the slot's previous batch, duplicated
+        # rows in new_xyz -- from some replay on, and kept doing so replayed alone (profiles/r05/geometry_ahead.txt): the
+        # memset node is not something a hand-off protocol can rest on here. A captured level takes the two launches.
+        return _two_launch_path(m, radius, ns, xyz, subtract_centroid)
     with on_device(dev):
-        if torch.cuda.is_current_stream_capturing():
-            # a captured launch is replayed with the same arguments: generations cannot advance, so the
-            # workspace is cleared inside the graph instead
-            ws = torch.empty((lib.pn2_sample_and_group_ws_bytes(b, m),), dtype=torch.uint8, device=dev)
-            rc = lib.pn2_sample_and_group_xyz(b, n, m, float(radius), ns, ptr(xyz), ptr(ws), ptr(fps_idx), ptr(new_xyz),
-                                              ptr(idx), ptr(cnt), ptr(grouped), 1 if subtract_centroid else 0, st)
-            if rc == -4:
-                return _two_launch_path(m, radius, ns, xyz, subtract_centroid)
-            _C.check(rc, "sample_and_group_xyz")
-        else:
-            ent = _granule_workspace(lib, dev, st, b, m)          # raises if an earlier launch on it reported a give-up
-            rc = lib.pn2_sample_and_group_xyz_gen(b, n, m, float(radius), ns, ptr(xyz), ptr(ent[0]), ent[1], ptr(fps_idx),
-                                                  ptr(new_xyz), ptr(idx), ptr(cnt), ptr(grouped),
-                                                  1 if subtract_centroid else 0, st)
-            if rc == -4:                                          # PN2_E_TOO_LARGE: e.g. too few CUs to hold every producer
-                return _two_launch_path(m, radius, ns, xyz, subtract_centroid)
-            _C.check(rc, "sample_and_group_xyz")
-            _fetch_status(ent)
+        ent = _granule_workspace(lib, dev, st, b, m)              # raises if an earlier launch on it reported a give-up
+        rc = lib.pn2_sample_and_group_xyz_gen(b, n, m, float(radius), ns, ptr(xyz), ptr(ent[0]), ent[1], ptr(fps_idx),
+                                              ptr(new_xyz), ptr(idx), ptr(cnt), ptr(grouped),
+                                              1 if subtract_centroid else 0, st)
+        if rc == -4:                                              # PN2_E_TOO_LARGE: e.g. too few CUs to hold every producer
+            return _two_launch_path(m, radius, ns, xyz, subtract_centroid)
+        _C.check(rc, "sample_and_group_xyz")
+        _fetch_status(ent)
     return fps_idx, mark_fps_ordered(new_xyz), idx, cnt, grouped
 
 

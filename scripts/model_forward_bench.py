@@ -171,6 +171,35 @@ def graphed_pipeline(model, ahead, coords, inputs, expect, geometry_streams=1):
     if priv:
         print("   eager temporaries inside private pools: %d of 600" % hits, flush=True)
     nb = (bad != 0).nonzero().flatten().tolist()
+    if nb and os.environ.get("PN2_BENCH_DIAG"):
+        # which graph of the bad slot is wrong? one more batch into every slot, host-synchronised, its geometry against an eager one
+        torch.cuda.synchronize()
+        S_ = len(pipe._in)
+        for j in range(S_):
+            x = ins[j % 3]
+            y = pipe.push(x, False)
+            torch.cuda.synchronize()
+            k = (pipe._i - 1) % S_
+            ge = ahead.compute(coords(x))
+            torch.cuda.synchronize()
+            names = []
+            for li, lv in enumerate(list(ge.sa) + list(ge.fp)):
+                if lv is not None:
+                    names += ["L%d.t%d" % (li, ti) for ti in range(len(lv._tensors))]
+            cnt = [int((a != e).sum()) for a, e in zip(pipe._sets[k].tensors(), ge.tensors())]
+            yy = model(x)
+            # the slot's stack graph on the EAGER geometry copied into its static set: is the stack graph itself sound?
+            print("   slot %d: output wrong %s | geometry tensors differing from an eager geometry: %s | static input intact %s"
+                  % (k, not torch.equal(y, yy), {n: c for n, c in zip(names, cnt) if c}, torch.equal(pipe._in[k], x)), flush=True)
+            if any(cnt):
+                pipe._geo_graphs[k].replay()
+                torch.cuda.synchronize()
+                cnt2 = [int((a != e).sum()) for a, e in zip(pipe._sets[k].tensors(), ge.tensors())]
+                print("      its geometry graph replayed alone (default stream): still differing %s" % {n: c for n, c in zip(names, cnt2) if c}, flush=True)
+                a0, e0 = pipe._sets[k].tensors()[0], ge.tensors()[0]
+                w = (a0 != e0).nonzero()[:4]
+                if len(w):
+                    print("      level-1 new_xyz: where %s got %s want %s" % (w.tolist(), [round(a0[tuple(q)].item(), 4) for q in w], [round(e0[tuple(q)].item(), 4) for q in w]), flush=True)
     if nb:
         print("   soak, geometry_streams=%d: %d wrong batches of 600, first %s, elements %s" % (geometry_streams, len(nb), nb[:8], bad[nb[:4]].tolist()), flush=True)
     return t, same and not nb
