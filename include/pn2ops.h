@@ -297,7 +297,10 @@ int pn2_farthest_point_sample_variant(int variant, int b, int n, int m, const fl
  * (occupancy query at launch): use pn2_farthest_point_sample_gather + pn2_query_ball_group_xyz then.
  * Clouds too large for a cell list beside their sorted copy in LDS (n > ~7000) are served by exactly those two launches from
  * inside this call (their consumers would have to sweep the whole cloud per query and no longer hide under the chain:
- * 478 us against 459 at b = 8, 8192 -> 1024); same outputs, ws untouched. */
+ * 478 us against 459 at b = 8, 8192 -> 1024); same outputs, ws untouched.
+ * NOT inside a captured HIP graph: a replayed launch has the same tag as the one before it and depends on the clear alone,
+ * and round 5's soak of a serving loop saw captured launches serve stale granules from some replay on
+ * (profiles/r05/geometry_ahead.txt). Capture the two launches instead (pn2_sa_level with ws_sample = NULL does). */
 int pn2_sample_and_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,
                              int *fps_idx, float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz,
                              int subtract_centroid, void *stream);

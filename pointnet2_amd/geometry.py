@@ -143,12 +143,9 @@ class GeometryAhead:
         """xyz (b, n, 3) f32 on the device, produced on the current stream -> NetworkGeometry (launches enqueued on
         self.stream, one event per level, nothing waited for). Consume the result on the stream that is current HERE.
 
-        Lifetimes without Tensor.record_stream. On this build (torch 2.10 + ROCm 7.2) record_stream followed by graph captures
-        made the caching allocator hand out memory twice: after a layer-by-layer forward and a few of these submits, a slot of
-        a later PipelinedInference was overwritten by the soak loop's own temporaries from some batch on -- deterministically,
-        and gone with the three record_stream calls this file had (profiles/r05/geometry_ahead.txt). Instead: the input is kept
-        referenced until its launches are done, and the results -- blocks of self.stream's pool -- can only be reused by a
-        later submit, whose launches wait (first line below) for everything the consumer stream held when it was called."""
+        Lifetimes without Tensor.record_stream: the input is kept referenced until its launches are done, and the results --
+        blocks of self.stream's pool -- can only be reused by a later submit, whose launches wait (first line below) for
+        everything the consumer stream held when it was called."""
         if not (isinstance(xyz, torch.Tensor) and xyz.is_cuda and xyz.device == self.device and xyz.dim() == 3 and xyz.shape[2] == 3):
             raise ValueError("GeometryAhead.submit expects (batch_size, num_points, 3) coordinates on %s" % (self.device,))
         cur = torch.cuda.current_stream(self.device)
@@ -162,20 +159,18 @@ class GeometryAhead:
 
 
 class PipelinedInference:
-    """EXPERIMENTAL -- validated in a serving process of its own (tests/test_geometry_ahead_gpu.py: 1,200-batch soak; 9,000
-    batches in the bisecting runs of round 5), but inside scripts/model_forward_bench.py's process -- after layer-by-layer
-    torch forwards, other graph captures and eager two-stream runs -- the same soak found ONE slot returning wrong results
-    (the library's own levels, not the torch head) from some batch on, reproducibly, and the cause was not found before the
-    round's GPU budget ran out (profiles/r05/geometry_ahead.txt lists what was ruled out: Tensor.record_stream, the
-    caching allocator handing an eager temporary a graph's memory, host run-ahead, the torch heads, every geometry component
-    alone). Until that is understood its timings are measurements of an organisation, not results of the product, and the
-    bench prints the soak's verdict next to each of them.
-
-    A serving loop with the geometry one batch ahead and no host time in the loop: per input slot (two of them) one HIP
+    """A serving loop with the geometry one batch ahead and no host time in the loop: per input slot (two of them) one HIP
     graph of the network's geometry, replayed on the geometry stream, and one of its layer stacks reading that graph's output
     tensors, replayed on the caller's stream; two events per batch order them. While the stacks of batch i fill the CUs, the
-    farthest-point chains of batch i + 1 run beside them (eval forwards per batch: cls_ssg 0.49 -> 0.43 ms, part_seg
-    0.59 -> 0.45, sem_seg 0.89 -> 0.58, 0.48 with geometry_streams=2; profiles/r05/model_forward.txt).
+    farthest-point chains of batch i + 1 run beside them (eval forwards per batch, same box: cls_ssg 0.53 -> 0.43 ms,
+    cls_msg 1.42 -> 1.23, part_seg 0.68 -> 0.53, sem_seg 1.05 -> 0.68, 0.58 with geometry_streams=2;
+    profiles/r05/model_forward.txt). Every output is the plain forward's bit for bit: 600-batch soaks with three inputs in
+    rotation per network and setting in scripts/model_forward_bench.py, a 1,200-batch soak in the test suite.
+
+    The soak is what found this round's one real defect (profiles/r05/geometry_ahead.txt): inside a CAPTURED graph the
+    overlapped launch -- workspace cleared by a memset node, constant tag -- served stale sample granules of the slot's
+    previous batch from some replay on (duplicated rows in new_xyz), invisibly as long as a slot always saw the same input.
+    Captured levels take the two launches since (tf_grouping.sample_and_group_xyz).
 
         pipe = PipelinedInference(net, net.ahead(), example_batch)        # captures; shapes are fixed from here on
         for x, ready in loader:                                           # x filled by the loader's stream, `ready` its event
@@ -190,7 +185,9 @@ class PipelinedInference:
     hipGraphLaunch ran the two branches one after the other (0.72 ms on cls_ssg against 0.49 plain). The stacks on a stream
     created for them land, by the round-robin of streams over hardware queues, in the geometry stream's queue every other time
     (0.46 / 0.84-0.95 ms in alternation, whatever GPU_MAX_HW_QUEUES says); the caller's stream beside a HIGH-PRIORITY geometry
-    stream (its own queue class) is 0.45-0.46 every time, hence this organisation.
+    stream (its own queue class) is 0.45-0.46 every time, hence this organisation. Three conservative choices date from the
+    hunt for the defect above and were kept although none of them turned out to be its cause: a slot's graphs are always
+    replayed on the same streams, the host never runs more than `slots` batches ahead, and no Tensor.record_stream is used.
     """
 
     def __init__(self, model, ahead, example, coords=None, no_grad=True, geometry_streams=1):

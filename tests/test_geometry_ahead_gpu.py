@@ -215,10 +215,9 @@ print("soak ok")
 
 def test_pipelined_inference_soak_in_a_serving_process(cuda):
     """Three inputs in rotation (every slot sees changing content) through two- and four-slot pipelines created one after the
-    other, 300 batches each, every output compared on the device in stream order -- in a process of its own, which is the
-    condition the loop is validated for: inside scripts/model_forward_bench.py's process (layer-by-layer torch forwards,
-    other graph captures and eager two-stream runs before it) the same soak found a slot returning wrong results from some
-    batch on, cause not found (profiles/r05/geometry_ahead.txt)."""
+    other, 300 batches each, every output compared on the device in stream order; in a process of its own (a serving
+    process). This kind of soak is what found the stale-granule defect of the overlapped launch inside captured graphs
+    (profiles/r05/geometry_ahead.txt): a check with two inputs and two slots cannot see it."""
     import os
     import subprocess
     import sys
