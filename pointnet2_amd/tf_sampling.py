@@ -156,9 +156,9 @@ def farthest_point_sample_gather(npoint, inp, ordered=None):
     ordered: None = follow inp's hint (above), True / False = force / forbid the checked short cut for input in
     farthest-point order (same results either way).
     """
-    if ordered is None:
-        ordered = isinstance(inp, torch.Tensor) and ordered_hint(inp, npoint)
     require(int(npoint) > 0, "FarthestPointSample expects positive npoint")
+    if ordered is None:                                    # (before detach(): the hint is an attribute of the caller's tensor object)
+        ordered = isinstance(inp, torch.Tensor) and ordered_hint(inp, npoint)
     inp = f32(inp.detach() if isinstance(inp, torch.Tensor) else inp, "inp")
     require(inp.dim() == 3 and inp.shape[2] == 3, "FarthestPointSample expects (batch_size,num_points,3) inp shape")
     b, n, _ = inp.shape
@@ -192,8 +192,8 @@ def farthest_point_sample(npoint, inp, out=None):
     kernel tf_sampling_g.cu:105-170 (tie rule: smallest (k mod 512, k)).
     out: optional preallocated (b, npoint) i32 result.
     """
-    hinted = isinstance(inp, torch.Tensor) and ordered_hint(inp, npoint)      # the previous level's samples: checked short cut
     require(int(npoint) > 0, "FarthestPointSample expects positive npoint")
+    hinted = isinstance(inp, torch.Tensor) and ordered_hint(inp, npoint)      # the previous level's samples: checked short cut
     inp = f32(inp.detach() if isinstance(inp, torch.Tensor) else inp, "inp")
     require(inp.dim() == 3 and inp.shape[2] == 3, "FarthestPointSample expects (batch_size,num_points,3) inp shape")
     b, n, _ = inp.shape
