@@ -1,6 +1,7 @@
 #!/bin/bash
 # One gpurun call = several measurements. Usage: scripts/gpu_session.sh <tag> <step> [<step> ...]
-# Steps: tests, tests_new, fpslab, bw, bq, bench, profile. Logs land in gpurun_out/<tag>/.
+# Steps: tests, ordered, ahead, tests_new, fpslab, bw, bq, models, prof_model(s), bench, smoke, trainbench, trainstep, profile, ...
+# (the case list below is the reference). Logs land in gpurun_out/<tag>/.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1; shift
 OUT=$ROOT/gpurun_out/$TAG
