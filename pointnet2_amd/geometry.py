@@ -14,8 +14,8 @@ this overlaps level k's stack with the geometry of levels k+1..; submitting batc
 geometry, level-1 chain included, under batch i's stacks (what a serving loop or a training loop with a prefetching loader
 does) -- scripts/model_forward_bench.py reports both.
 
-The results are the results of the plain forward, bit for bit (tests/test_geometry_ahead_gpu.py): the same launches compute
-them, only their stream differs. Multi-stream use of the library is a tested contract since round 5
+The results are the results of the plain forward, bit for bit (tests/test_geometry_ahead_gpu.py): the same kernels compute
+them, only their stream differs (and, inside captured graphs, a level's two launches stand for its overlapped one). Multi-stream use of the library is a tested contract since round 5
 (tests/test_multistream_gpu.py; the v_pk_add_f32 hazard beside MFMA kernels is documented in csrc/pn2_device.h).
 """
 import torch
