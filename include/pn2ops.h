@@ -298,17 +298,25 @@ int pn2_farthest_point_sample_variant(int variant, int b, int n, int m, const fl
  * Clouds too large for a cell list beside their sorted copy in LDS (n > ~7000) are served by exactly those two launches from
  * inside this call (their consumers would have to sweep the whole cloud per query and no longer hide under the chain:
  * 478 us against 459 at b = 8, 8192 -> 1024); same outputs, ws untouched.
- * NOT inside a captured HIP graph: a replayed launch has the same tag as the one before it and depends on the clear alone,
- * and round 5's soak of a serving loop saw captured launches serve stale granules from some replay on
- * (profiles/r05/geometry_ahead.txt). Capture the two launches instead (pn2_sa_level with ws_sample = NULL does). */
+ * Inside a captured HIP graph (hipStreamIsCapturing on `stream`) this call enqueues exactly those two launches as well: a
+ * replayed overlapped launch would carry the same tag as the replay before it and depend on the clear alone, and round 5's
+ * soak of a serving loop saw such launches accept granules that were not theirs (profiles/r06/stale_granules.md). The
+ * overlapped launch INSIDE a graph is pn2_sample_and_group_xyz_gen(generation = PN2_GENERATION_DEVICE). */
 int pn2_sample_and_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,
                              int *fps_idx, float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz,
                              int subtract_centroid, void *stream);
 long long pn2_sample_and_group_ws_bytes(int b, int m);
 /* The same launch without the per-call clear of ws: the caller manages generations. Zero ws ONCE when it is
- * allocated, then pass a generation that no earlier launch on this workspace used (1, 2, 3, ...: what an
+ * allocated, then pass a generation that no earlier launch on this workspace used (1, 2, 3, ... 0xfffffffe: what an
  * earlier generation left behind can never be mistaken for a published sample). One ws per stream;
- * generation 0 is PN2_E_ARG; re-zero ws before wrapping around. Saves a memset launch (~5 us) per call. */
+ * generation 0 is PN2_E_ARG; re-zero ws before wrapping around. Saves a memset launch (~5 us) per call.
+ * generation = PN2_GENERATION_DEVICE (round 6): the launch numbers ITSELF -- every workgroup of a cloud arrives at a counter
+ * word of ws with one returning atomic add, which gives the cloud's producer and consumers the same launch ordinal and
+ * consecutive launches different tags, with no clear and no number from the host. This is the form for captured graphs
+ * (frozen arguments): zero ws ONCE when it is allocated (outside the graph), give every captured call site a workspace of
+ * its own, never use a workspace in two forms or from two launches at the same time. Costs the chain one atomic round trip
+ * (~2 us) per launch. */
+#define PN2_GENERATION_DEVICE 0xffffffffu
 int pn2_sample_and_group_xyz_gen(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,
                                  unsigned generation, int *fps_idx, float *new_xyz, int *idx, int *pts_cnt,
                                  float *grouped_xyz, int subtract_centroid, void *stream);
@@ -322,7 +330,8 @@ long long pn2_sample_and_group_status_offset(int b, int m);
  * pn2_farthest_point_sample_variant); consumers = persistent consumer workgroups per cloud (0 = the library's choice, which
  * includes the two launches for clouds beyond ~7000 points; > 0 = always the overlapped launch; each
  * stages its cloud once and walks the 64-query ranges c, c + consumers, ... in publish order; the grid is
- * b * (1 + consumers) workgroups). generation 0 = clear `ws` first. */
+ * b * (1 + consumers) workgroups, consumers <= 16). generation 0 = clear `ws` first (eager; the two launches inside a capture),
+ * PN2_GENERATION_DEVICE as in pn2_sample_and_group_xyz_gen. */
 int pn2_sample_and_group_xyz_ex(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws, unsigned generation,
                                 int fps_variant, int consumers, int *fps_idx, float *new_xyz, int *idx, int *pts_cnt,
                                 float *grouped_xyz, int subtract_centroid, void *stream);
@@ -332,8 +341,8 @@ int pn2_sample_and_group_xyz_ex(int b, int n, int m, float radius, int nsample, 
  * pn2_sa_level = pointnet_sa_module (utils/pointnet_util.py:87-154) for max pooling and three layers: the overlapped
  * sample-and-group launch (or, outside its envelope, pn2_farthest_point_sample_gather + pn2_query_ball_group_xyz) followed
  * by pn2_sa_mlp3_maxpool, enqueued by ONE call. ws_sample: pn2_sample_and_group_ws_bytes(b, m) bytes, handled as in
- * pn2_sample_and_group_xyz_gen (generation > 0: zeroed once by the caller, a fresh generation per call) or cleared here
- * (generation = 0); NULL: never the overlapped launch, always the two-launch path; fps_temp: pn2_fps_temp_floats(b, n) floats or NULL when that is 0; ws_mlp: pn2_sa_mlp3_ws_bytes(...)
+ * pn2_sample_and_group_xyz_gen (generation > 0: zeroed once by the caller, a fresh generation per call, or
+ * PN2_GENERATION_DEVICE for captured graphs) or cleared here (generation = 0; the two launches inside a capture); NULL: never the overlapped launch, always the two-launch path; fps_temp: pn2_fps_temp_floats(b, n) floats or NULL when that is 0; ws_mlp: pn2_sa_mlp3_ws_bytes(...)
  * bytes or NULL when that is 0; wpacked / bpacked from pn2_sa_mlp3_pack. Outputs as the two operators' (all required).
  * pn2_fp_level = pointnet_fp_module (:199-229): pn2_three_nn followed by pn2_fp_mlp (dist / idx are outputs too). */
 int pn2_sa_level(int b, int n, int m, float radius, int nsample, int cfeat, const float *xyz, const float *points,

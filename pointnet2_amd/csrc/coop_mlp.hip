@@ -518,8 +518,7 @@ int mlp_coop_launch(const MlpCoopConfig &c, int fp, const CoopParams &p_in, hipS
     const int parts = (p.nsample + 31) / 32;
     p.split = (!fp && parts > 1 && p.rows < 256) ? 1 : 0;          // few large groups: one work unit per 32-sample part
     if (p.split) {
-        hipError_t e = hipMemsetAsync(p.out, 0, sizeof(float) * (size_t)p.rows * p.cout, st);
-        if (e != hipSuccess) return (int)e;
+        if (int rc = clear_async(p.out, sizeof(float) * (size_t)p.rows * p.cout, st)) return rc;
     }
     const long long units = fp ? (p.rows + 31) / 32 : (p.split ? p.rows * parts : p.rows);
 #define PN2_COOP_CASE(G, A, B, C) \

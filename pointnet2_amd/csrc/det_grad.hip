@@ -157,10 +157,8 @@ static int det_prepare(void *ws, long long acc_elems, float *out, const float *g
                        const float *weight, long long weight_elems, hipStream_t st)
 {
     DetWs w = det_ws(ws);
-    hipError_t e = hipMemsetAsync(ws, 0, 16 + sizeof(unsigned long long) * (size_t)acc_elems, st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)acc_elems, st);
-    if (e != hipSuccess) return (int)e;
+    if (int rc = clear_async(ws, 16 + sizeof(unsigned long long) * (size_t)acc_elems, st)) return rc;
+    if (int rc = clear_async(out, sizeof(float) * (size_t)acc_elems, st)) return rc;
     if (grad_elems > 0)
         if (int rc = launch(det_absmax_kernel, dim3(det_grid(grad_elems)), dim3(kDetThreads), 0, st, grad, grad_elems, w.head)) return rc;
     if (weight && weight_elems > 0)

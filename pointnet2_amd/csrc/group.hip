@@ -230,8 +230,7 @@ extern "C" int pn2_gather_point_grad(int b, int n, int m, const float *out_g, co
     if (b == 0) return PN2_OK;
     if (!inp_g) return PN2_E_NULL;
     hipStream_t st = as_stream(stream);
-    hipError_t e = hipMemsetAsync(inp_g, 0, sizeof(float) * (size_t)b * n * 3, st);   // tf_sampling.cpp:174
-    if (e != hipSuccess) return (int)e;
+    if (int rc = clear_async(inp_g, sizeof(float) * (size_t)b * n * 3, st)) return rc;   // tf_sampling.cpp:174
     if (m == 0) return PN2_OK;
     if (!out_g || !idx) return PN2_E_NULL;
     const long long rows = (long long)b * m;
@@ -292,8 +291,7 @@ extern "C" int pn2_group_point_grad(int b, int n, int c, int m, int nsample, con
     if (b == 0) return PN2_OK;
     if (!grad_points) return PN2_E_NULL;
     hipStream_t st = as_stream(stream);
-    hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * n * c, st);   // tf_grouping.cpp:204
-    if (e != hipSuccess) return (int)e;
+    if (int rc = clear_async(grad_points, sizeof(float) * (size_t)b * n * c, st)) return rc;   // tf_grouping.cpp:204
     const long long rpc = (long long)m * nsample;
     const long long elems = (long long)b * rpc * c;
     if (elems == 0) return PN2_OK;

@@ -363,8 +363,7 @@ extern "C" int pn2_fp_interp_concat_grad(int b, int n, int m, int c2, int c1, in
         // no unknown point: the gradient of points2 is zero, and this entry point -- like pn2_three_interpolate_grad_seg --
         // owns the zero fill (callers allocate it uninitialised); nothing flows to points1 (b * n == 0 rows)
         if (b > 0 && grad_points2) {
-            hipError_t e = hipMemsetAsync(grad_points2, 0, sizeof(float) * (size_t)b * m * c2, as_stream(stream));
-            if (e != hipSuccess) return (int)e;
+            if (int rc = clear_async(grad_points2, sizeof(float) * (size_t)b * m * c2, as_stream(stream))) return rc;
         }
         return PN2_OK;
     }
@@ -448,8 +447,7 @@ extern "C" int pn2_three_interpolate_grad(int b, int n, int c, int m, const floa
     if (b == 0) return PN2_OK;
     if (!grad_points) return PN2_E_NULL;
     hipStream_t st = as_stream(stream);
-    hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * m * c, st);   // tf_interpolate.cpp:258
-    if (e != hipSuccess) return (int)e;
+    if (int rc = clear_async(grad_points, sizeof(float) * (size_t)b * m * c, st)) return rc;   // tf_interpolate.cpp:258
     const long long elems = (long long)b * n * c;
     if (elems == 0) return PN2_OK;
     if (!grad_out || !idx || !weight) return PN2_E_NULL;

@@ -132,6 +132,37 @@ inline int launch(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, hip
     return launch_packed(kern, grid, block, lds, st, vals, std::index_sequence_for<KArgs...>{});
 }
 
+// ---- zero-fill: a kernel of the library's own, NEVER hipMemsetAsync --------------------------------------------------------
+// Every entry point is meant to be capturable into a HIP graph, and a hipMemsetAsync captured into a graph is a memset NODE.
+// On this runtime (ROCm 7.2) a replayed memset node does not reliably clear: round 5's serving loop and round 6's reproducer
+// (scripts/memset_node_repro.hip / .py, scripts/stale_granule_repro.py; profiles/r06/stale_granules.md) read the buffer
+// right behind the node and found it filled with a 16-byte pattern made of ANOTHER kernel's launch arguments (an element
+// count and a pointer of an eager torch kernel launched between the replays), or not touched at all -- the node's fill
+// parameters are not kept for the life of the executable graph. A kernel node's arguments are. So every clear the library
+// needs (accumulation targets of the gradient scatters, counters, the overlapped launch's granules in its eager form) is
+// this kernel: 16-byte stores over the aligned middle, bytes at the ragged ends.
+static __global__ void pn2_clear_kernel(unsigned char *p, size_t head, size_t n16, size_t tail)
+{
+    const size_t i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    uint4 *mid = reinterpret_cast<uint4 *>(p + head);
+    for (size_t i = i0; i < n16; i += step) mid[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (i0 < head) p[i0] = 0;
+    if (i0 < tail) p[head + n16 * 16 + i0] = 0;
+}
+
+inline int clear_async(void *ptr, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return 0;
+    unsigned char *p = static_cast<unsigned char *>(ptr);
+    size_t head = (16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15;
+    if (head > bytes) head = bytes;
+    const size_t n16 = (bytes - head) / 16, tail = bytes - head - n16 * 16;
+    size_t blocks = (n16 + 256 * 4 - 1) / (256 * 4);              // four stores per thread, at most eight workgroups per CU
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    return launch(pn2_clear_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, head, n16, tail);
+}
+
 // Kernels that ask for more than 48 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize
 // raised. The attribute call costs microseconds, so it is made once per (device, kernel) and the granted
 // size remembered -- the whole 160 KiB of a gfx950 CU when the kernel has no static LDS, else exactly what

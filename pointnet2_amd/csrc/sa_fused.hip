@@ -19,8 +19,19 @@
 //                            544 workgroups, 224 of them spinning on every idle CU for the whole chain, each re-staging
 //                            the cloud. Now 2 b = 64 workgroups; the step time is the same, 192 CUs stay free.)
 // Hand-off: form R2 of the CDNA programming guide (Guideline 16) -- the data is the flag, agent-scope
-// relaxed 8-byte atomics on both sides, no fences; the granule array is zeroed on the stream before the
-// launch, tag = 1. Every workgroup asks for more than half of the CU's LDS, so producers never share
+// relaxed 8-byte atomics on both sides, no fences. What makes a granule THIS launch's is its tag, and the tag comes from
+// one of three places (sample_and_group_common):
+//   generation 1 .. 0xfffffffe   the caller numbers its launches on a workspace it zeroed once (pn2_..._gen);
+//   PN2_GENERATION_DEVICE        the launch numbers ITSELF (round 6): every workgroup of a cloud -- its producer and its
+//                                consumers -- arrives at the cloud's counter word behind the granules with ONE returning
+//                                atomic add (a read-modify-write is served by the memory side, never by a cached copy),
+//                                the count gives all of them the same launch ordinal, and the last arriver moves the word
+//                                to the next ordinal. No clear, no host-supplied number: the form for CAPTURED graphs,
+//                                whose arguments are frozen (fused_arrive below says what went wrong before);
+//   generation 0                 the workspace is cleared on the stream in front of the launch (a kernel, never a memset
+//                                node: pn2_device.h) and the tag is 1 -- eager launches only: inside a capture the call
+//                                takes the two launches instead.
+// Every workgroup asks for more than half of the CU's LDS, so producers never share
 // a CU with consumers (a co-resident consumer would steal issue slots from the latency-bound chain).
 //
 // Forward progress. Consumers spin until their producer has advanced; that cannot deadlock while the b
@@ -55,6 +66,45 @@ constexpr int kFusedConsumers = 1;              // persistent consumer workgroup
                                                 // 398.4 us per step at the metric shape (profiles/r05/fused_consumers.txt)
 
 
+// ---- the launch numbers itself (PN2_GENERATION_DEVICE) -------------------------------------------------------------------
+// History (profiles/r05/geometry_ahead.txt, profiles/r06/stale_granules.md): rounds 2-4 captured this launch behind a
+// hipMemsetAsync with the constant tag 1, and a serving loop's soak found replays whose consumers accepted granules that were
+// not the replay's. Round 6 found why: a replayed memset NODE of this runtime does not clear -- it fills the buffer with a
+// 16-byte pattern taken from wherever its fill pattern was staged at capture time, which by then holds the launch arguments of
+// some later eager kernel. In the serving loop that was the soak's `output != expected` compare: (numel 1280, 1, a pointer),
+// so every EVEN granule read {tag 1, index 1280} -- published, as far as a consumer can tell -- and half of new_xyz's rows
+// became point 1280. (With other neighbours the garbage carries other tag words and nothing shows: most processes "worked".)
+// The library no longer issues hipMemsetAsync anywhere (pn2_device.h: clear_async). Independently of that, a constant tag
+// makes every word that survives -- a late or skipped clear, memory that was somebody else's in between -- look published;
+// here no launch can mistake anything older for its own: consecutive launches on a workspace carry different tags, and the
+// tag is agreed by read-modify-writes on one word per cloud.
+//
+// word (8 bytes per cloud, behind the status word; zero when the workspace is new):  [63:16] ordinal | [15:0] arrivals
+// Every participant of a cloud (1 producer + cpc consumers; npc <= 129: one consumer per 64-query range at most) adds 1 and
+// reads the old word: the ordinal field is the launch's ordinal for all of them, because the word leaves this ordinal only
+// when the LAST of them has arrived -- that one adds 65536 - npc (arrivals back to 0, ordinal + 1). Launches on one workspace
+// are ordered by the stream, so the next launch's first arrival finds arrivals = 0. npc may differ from launch to launch.
+// tag = ordinal mod (2^32 - 1) + 1: never 0, and different for consecutive launches, which is all that is needed -- every
+// launch rewrites every granule of (b, m).
+__device__ __forceinline__ unsigned fused_arrive(unsigned long long *word, unsigned npc)
+{
+    pn2_gu64 *w = (pn2_gu64 *)word;
+    const unsigned long long old = __hip_atomic_fetch_add(w, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(old & 0xffffull) + 1u == npc)
+        __hip_atomic_fetch_add(w, 65536ull - (unsigned long long)npc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (unsigned)((old >> 16) % 0xffffffffull) + 1u;
+}
+
+#ifdef PN2_LAB_STALE
+// Lab build only (make lab_stale -> build_lab/libpn2ops_stalelab.so, scripts/stale_granule_repro.py): what does a workgroup
+// find in its cloud's LAST granule -- published by the chain's final round, so any tag there at entry is an older launch's --
+// when it starts, (1) by the agent-scope load the consumers poll with and (2) by a read-modify-write, which the memory side
+// serves? [0] workgroups, [1] load saw this launch's tag, [2] RMW saw it, [3] load saw any non-zero word, [4] RMW saw any.
+__device__ unsigned long long pn2_lab_stale[8];
+__device__ unsigned long long pn2_lab_samples[64 * 4];    // first 64 non-zero finds of launches with tag 1: load, RMW, block | m << 32, first granule
+static int g_lab_clear_with_kernel = 0;
+#endif
+
 // LPQ: lanes per query of the cell-list consumers; 0 = sweep consumers (clouds whose cell list does not fit
 // beside the position table: n > ~6000).
 // PRUNED: the producers run the kd-grouped chain of fps_pruned_body.h (4096 / 8192 rank slots: P = 8, 16) on four waves.
@@ -72,6 +122,37 @@ __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, i
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned *status = reinterpret_cast<unsigned *>(tagged + (size_t)b * m);   // launch status word behind the granules
     const int blk = blockIdx.x;
+    if (tag == PN2_GENERATION_DEVICE) {
+        // one arrival per workgroup at its cloud's counter word; the whole workgroup takes the tag from LDS (the bodies below
+        // own the dynamic LDS from the second barrier on)
+        if (threadIdx.x == 0)
+            *reinterpret_cast<volatile unsigned *>(smem) = fused_arrive(tagged + (size_t)b * m + 2 + (blk < b ? blk : (blk - b) % b), 1u + (unsigned)cpc);
+        __syncthreads();
+        tag = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned *>(smem));
+        __syncthreads();
+    }
+#ifdef PN2_LAB_STALE
+    if (threadIdx.x == 0) {
+        pn2_gu64 *last = (pn2_gu64 *)(tagged + (size_t)(blk < b ? blk : (blk - b) % b) * m + (m - 1));
+        const unsigned long long v1 = __hip_atomic_load(last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long v2 = __hip_atomic_fetch_or(last, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(&pn2_lab_stale[0], 1ull);
+        if ((unsigned)(v1 >> 32) == tag) atomicAdd(&pn2_lab_stale[1], 1ull);
+        if ((unsigned)(v2 >> 32) == tag) atomicAdd(&pn2_lab_stale[2], 1ull);
+        if (v1) atomicAdd(&pn2_lab_stale[3], 1ull);
+        if (v2) atomicAdd(&pn2_lab_stale[4], 1ull);
+        if (tag == 1u && (v1 | v2)) {
+            const unsigned long long k = atomicAdd(&pn2_lab_stale[5], 1ull);
+            if (k < 64) {
+                pn2_lab_samples[4 * k + 0] = v1;
+                pn2_lab_samples[4 * k + 1] = v2;
+                pn2_lab_samples[4 * k + 2] = (unsigned long long)blk | ((unsigned long long)m << 32) | ((unsigned long long)b << 48);
+                pn2_lab_samples[4 * k + 3] = __hip_atomic_load((pn2_gu64 *)(tagged + (size_t)(blk < b ? blk : (blk - b) % b) * m + (m - 2)),
+                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+#endif
 #ifndef PN2_FUSED_LAB_PUBLISH                     // lab switches (scripts/: where does the launch's time go?)
 #define PN2_FUSED_LAB_PUBLISH true
 #endif
@@ -166,8 +247,15 @@ static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, floa
         if (room < b + 1) return PN2_E_TOO_LARGE;
     }
     if (tag == 0) {                                               // caller did not manage generations: clear, use tag 1
-        hipError_t e = hipMemsetAsync(ws, 0, (size_t)pn2_sample_and_group_ws_bytes(b, m), st);
-        if (e != hipSuccess) return (int)e;
+        // (never inside a capture: sample_and_group_common has sent captured calls to the two launches.) The counter words of
+        // the device-numbered form are left alone: a workspace serves one form for its life.
+#ifdef PN2_LAB_STALE
+        if (!g_lab_clear_with_kernel) {                           // the lab build's default: the memset NODE of rounds 2-4
+            hipError_t e = hipMemsetAsync(ws, 0, sizeof(unsigned long long) * (size_t)b * m + 16, st);
+            if (e != hipSuccess) return (int)e;
+        } else
+#endif
+        if (int rc = clear_async(ws, sizeof(unsigned long long) * (size_t)b * m + 16, st)) return rc;
         tag = 1u;
     }
     if (int rc = launch(kern, dim3(b + nq * b), dim3(kFusedThreads), lds, st, b, n, m, Q, nsample, thr, radius, qpb, nq, tag, xyz, ws,
@@ -180,8 +268,8 @@ static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, floa
 extern "C" long long pn2_sample_and_group_ws_bytes(int b, int m)
 {
     if (b <= 0 || m <= 0) return 0;
-    // b*m sample granules + the launch status word (padded to 16 bytes)
-    return (long long)sizeof(unsigned long long) * b * m + 16;
+    // b*m sample granules + the launch status word (padded to 16 bytes) + one counter word per cloud (PN2_GENERATION_DEVICE)
+    return (long long)sizeof(unsigned long long) * b * m + 16 + (long long)sizeof(unsigned long long) * b;
 }
 
 static int sample_and_group_common(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws, unsigned tag,
@@ -195,12 +283,30 @@ static int sample_and_group_common(int b, int n, int m, float radius, int nsampl
     // envelope of the overlapped launch (outside it the caller uses the two-launch path)
     if (b > kFusedMaxClouds || n > 8192 || n < 64 || nsample > 256) return PN2_E_TOO_LARGE;
     if ((long long)b * m * nsample * 3 > INT_MAX) return PN2_E_TOO_LARGE;
+    hipStream_t st = as_stream(stream);
+    if (tag == 0u) {
+        // The cleared form (clear + the constant tag 1) is for eager launches. A captured one would be replayed with the same
+        // tag behind a clear it has to trust -- and the clear of rounds 2-4, a memset node, turned out not to clear when
+        // replayed (profiles/r06/stale_granules.md). The clear is a kernel now, but a captured call still enqueues the two
+        // launches instead (same outputs, `ws` untouched): callers that want the overlapped launch inside a graph pass
+        // PN2_GENERATION_DEVICE, whose correctness rests on no clear at all.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        hipError_t e = hipStreamIsCapturing(st, &cs);
+        if (e != hipSuccess) return (int)e;
+#ifdef PN2_LAB_STALE
+        cs = hipStreamCaptureStatusNone;                          // the lab build captures the cleared form, as rounds 2-4 did
+#endif
+        if (cs != hipStreamCaptureStatusNone) {
+            if (fps_variant < PN2_FPS_AUTO || fps_variant > PN2_FPS_PRUNED) return PN2_E_ARG;
+            if (int rc = pn2_farthest_point_sample_variant(fps_variant, b, n, m, xyz, nullptr, fps_idx, new_xyz, stream)) return rc;
+            return pn2_query_ball_group_xyz(b, n, m, radius, nsample, xyz, new_xyz, subtract_centroid, idx, pts_cnt, grouped_xyz, stream);
+        }
+    }
     const int Q = (n + kRefThreads - 1) / kRefThreads;
     const int ranks = kRefThreads * Q;
     int P = 1;
     while (kFusedThreads * P < ranks) P <<= 1;
     const float thr = pn2_ball_threshold(radius);
-    hipStream_t st = as_stream(stream);
     unsigned long long *w = reinterpret_cast<unsigned long long *>(ws);
     // consumers: the cell-list body with as many queries per wave as fit beside the sorted cloud, the cell table
     // and the position table; the sweep body when nothing fits (large clouds) or the cloud is tiny
@@ -245,7 +351,8 @@ extern "C" int pn2_sample_and_group_xyz(int b, int n, int m, float radius, int n
 // Same launch without the per-call clear of `ws`: the caller manages GENERATIONS. `ws` must hold no granule
 // whose tag word equals `generation` (zero it once when it is allocated, then pass 1, 2, 3, ... -- a
 // granule left behind by an earlier generation can never be mistaken for a published sample). One
-// workspace per stream; generation 0 is not allowed.
+// workspace per stream; generation 0 is not allowed. PN2_GENERATION_DEVICE: the launch numbers itself (header of this
+// file) -- `ws` zeroed once when it is allocated, used by this form only, never by two launches at the same time.
 extern "C" int pn2_sample_and_group_xyz_gen(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,
                                             unsigned generation, int *fps_idx, float *new_xyz, int *idx, int *pts_cnt,
                                             float *grouped_xyz, int subtract_centroid, void *stream)
@@ -275,3 +382,27 @@ extern "C" long long pn2_sample_and_group_status_offset(int b, int m)
     if (b <= 0 || m <= 0) return -1;
     return (long long)sizeof(unsigned long long) * b * m;
 }
+
+#ifdef PN2_LAB_STALE
+// lab build only: counters of sa_fused_kernel's entry check -> host[8] (synchronises the device); reset != 0 zeroes them after
+extern "C" int pn2_lab_stale_counters(unsigned long long *host8, int reset)
+{
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyFromSymbol(host8, HIP_SYMBOL(pn2::pn2_lab_stale), sizeof(unsigned long long) * 8);
+    if (e != hipSuccess) return (int)e;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(pn2::pn2_lab_stale), z, sizeof(z));
+    }
+    return (int)e;
+}
+extern "C" int pn2_lab_stale_samples(unsigned long long *host256)
+{
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemcpyFromSymbol(host256, HIP_SYMBOL(pn2::pn2_lab_samples), sizeof(unsigned long long) * 256);
+}
+// lab build only: generation 0 clears the workspace with a kernel of the library's own instead of a memset node
+extern "C" void pn2_lab_clear_with_kernel(int on) { pn2::g_lab_clear_with_kernel = on; }
+#endif

@@ -389,8 +389,7 @@ static int seg_grad(int b, int rows, long long entries, int c, const float *grad
         if (int rc = allow_dynamic_lds(kern, lds)) return rc;
         if (int rc = launch(kern, dim3(b), dim3(1024), lds, st, entries, rows, idx, w.start, w.sorted, w.list)) return rc;
     } else {
-    hipError_t e = hipMemsetAsync(w.cursor, 0, 2 * sizeof(int) * (size_t)b * rows, st);   // counters and sorted flags
-    if (e != hipSuccess) return (int)e;
+    if (int rc = clear_async(w.cursor, 2 * sizeof(int) * (size_t)b * rows, st)) return rc;   // counters and sorted flags
     if (int rc = launch(seg_count_kernel, dim3(seg_grid(total)), dim3(kSegThreads), 0, st, total, entries, rows, idx, w.cursor)) return rc;
     if (int rc = launch(seg_scan_kernel, dim3(b), dim3(1024), 0, st, rows, w.start, w.cursor)) return rc;
     if (int rc = launch(seg_fill_kernel, dim3(seg_grid(total)), dim3(kSegThreads), 0, st, total, entries, rows, idx, w.cursor, w.list)) return rc;
@@ -419,8 +418,7 @@ extern "C" int pn2_group_point_grad_seg(int b, int n, int c, int m, int nsample,
     if (entries > INT_MAX || (long long)b * n > INT_MAX) return PN2_E_TOO_LARGE;
     hipStream_t st = as_stream(stream);
     if (entries == 0) {
-        hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * n * c, st);
-        return e == hipSuccess ? PN2_OK : (int)e;
+        return clear_async(grad_points, sizeof(float) * (size_t)b * n * c, st);
     }
     if (!grad_out || !idx) return PN2_E_NULL;
     return seg_grad<1>(b, n, entries, c, grad_out, idx, nullptr, grad_points, ws, deterministic, st);
@@ -438,8 +436,7 @@ extern "C" int pn2_three_interpolate_grad_seg(int b, int n, int c, int m, const 
     if (entries > INT_MAX || (long long)b * m > INT_MAX) return PN2_E_TOO_LARGE;
     hipStream_t st = as_stream(stream);
     if (entries == 0) {
-        hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * m * c, st);
-        return e == hipSuccess ? PN2_OK : (int)e;
+        return clear_async(grad_points, sizeof(float) * (size_t)b * m * c, st);
     }
     if (!grad_out || !idx || !weight) return PN2_E_NULL;
     return seg_grad<3>(b, m, entries, c, grad_out, idx, weight, grad_points, ws, deterministic, st);

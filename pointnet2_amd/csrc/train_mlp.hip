@@ -2074,7 +2074,7 @@ static int launch_wgrad(TlWgrad &p, const WgradShape &w, float *partial2, const 
 #ifdef PN2_WG_TIMING               /* lab build (scripts/build_mlp_labs.sh wgtime): cycles per phase and wave of workgroup 0, printed per launch */
     static unsigned long long *tbuf = nullptr;
     if (!tbuf) (void)hipMalloc(&tbuf, 48 * sizeof(unsigned long long));
-    (void)hipMemsetAsync(tbuf, 0, 48 * sizeof(unsigned long long), st);
+    (void)clear_async(tbuf, 48 * sizeof(unsigned long long), st);
     p.timing = tbuf;
 #endif
     int rc = w.tpw == 1 ? launch_wgrad_tpw<1>(p, w, grid, st) : w.tpw == 2 ? launch_wgrad_tpw<2>(p, w, grid, st)

@@ -278,8 +278,14 @@ def sa_level(npoint, radius, nsample, xyz, points, packed, buffers=None):
             # pn2_sa_level takes the two-launch path, no sa_fused_kernel is launched
             ent, gen, wsp = None, 0, None
         elif torch.cuda.is_current_stream_capturing():
-            # no overlapped launch inside a captured graph (tf_grouping.sample_and_group_xyz says why): NULL workspace = two launches
-            ent, gen, wsp = None, 0, None
+            # inside a captured graph the launch numbers itself on a workspace of this call site's own (tf_grouping:
+            # _capture_workspace says why); none in stock (no eager warm-up of this shape): NULL workspace = two launches
+            if G._LAB_CAPTURE_FORM[0] is not None:                  # lab only: the cleared form of rounds 2-4 (tf_grouping)
+                wss = G._lab_capture_workspace(lib, dev, b, m)
+                ent, gen, wsp = None, 0, ptr(wss)
+            else:
+                cent = G._capture_workspace(dev, b, m)
+                ent, gen, wsp = (None, 0, None) if cent is None else (None, G.GENERATION_DEVICE, ptr(cent[0]))
         else:
             ent = G._granule_workspace(lib, dev, st, b, m)         # raises if an earlier launch on it reported a give-up
             gen, wsp = ent[1], ptr(ent[0])

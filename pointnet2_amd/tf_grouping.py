@@ -160,12 +160,10 @@ def overlapped_launch_status(device=None):
     """Status words of the overlapped launches' workspaces on `device` (synchronises): all zero unless a
     consumer workgroup ever gave up waiting for its producer (pn2_sample_and_group_status_offset)."""
     out = []
-    for (dev_index, _stream, bm), ent in _GRANULES.items():
+    for dev_index, ent in _all_workspaces():
         if device is not None and dev_index != device.index:
             continue
-        buf = ent[0]
-        off = buf.numel() - 16                      # status word: first u32 behind the granules
-        out.append(int(buf[off:off + 4].view(torch.int32).item()))
+        out.append(int(_status_word(ent).item()))
     return out
 
 
@@ -175,31 +173,111 @@ class OverlappedLaunchError(RuntimeError):
     use set_overlapped_launch(False) / PN2_OVERLAP=0 to take the two-launch path."""
 
 
-# Sample-granule workspaces of the overlapped launch, one per (device, stream, size): zeroed once, then
+# Sample-granule workspaces of the overlapped launch, one per (device, stream, b, m): zeroed once, then
 # every call uses the next GENERATION tag (pn2_sample_and_group_xyz_gen), so no per-call clear is needed.
 # Launches on one stream are ordered, so reusing the buffer is safe; different streams get different buffers.
-# Entry: [buffer, generation, pinned status copy, event of that copy (or None), calls]
+# Entry: [buffer, generation, pinned status copy, event of that copy (or None), calls, byte offset of the status word]
 _GRANULES = {}
 _STATUS_EVERY = 16                                  # after the first calls, the status word is fetched every 16th call
 
+# Inside a CAPTURED graph the arguments are frozen, so the launch numbers itself (PN2_GENERATION_DEVICE: an arrival counter
+# per cloud in the workspace, csrc/sa_fused.hip). That form needs a workspace that (1) was zero when the graph first ran,
+# without a clear INSIDE the graph -- a replayed clear would restart the numbering and bring back the constant tag that
+# round 5's soak caught accepting granules of another replay (profiles/r06/stale_granules.md) --, (2) belongs to this call
+# site alone (two graphs may be replayed at the same time on two streams) and (3) outlives the graph (the graph holds a
+# raw pointer). So: every EAGER overlapped call tops a small stock of zeroed workspaces of its size up (the fill is
+# waited for on the spot: a later replay on any stream must find it done), a captured call takes one from the stock for
+# good, and a captured call that finds the stock empty -- a capture without an eager warm-up of that shape -- takes the
+# two launches. _CAPTURED keeps what captures took (a few hundred KB each; dropped by release_captured_workspaces()).
+_SPARES = {}
+_SPARE_STOCK = 4
+_CAPTURED = []
+GENERATION_DEVICE = 0xFFFFFFFF                       # PN2_GENERATION_DEVICE (include/pn2ops.h)
+
+
+def _new_entry(lib, dev, b, m):
+    buf = torch.zeros((lib.pn2_sample_and_group_ws_bytes(b, m),), dtype=torch.uint8, device=dev)
+    return [buf, 0, torch.zeros((1,), dtype=torch.int32).pin_memory(), None, 0, int(lib.pn2_sample_and_group_status_offset(b, m))]
+
+
+def _top_up_spares(lib, dev, b, m):
+    stock = _SPARES.setdefault((dev.index, b, m), [])
+    if len(stock) < _SPARE_STOCK:
+        while len(stock) < _SPARE_STOCK:
+            stock.append(_new_entry(lib, dev, b, m))
+        torch.cuda.current_stream(dev).synchronize()             # rare: the first call of a shape, the first after a capture
+
+
+def prepare_capture_workspaces(npoint, xyz, count=_SPARE_STOCK):
+    """Stock `count` zeroed workspaces for overlapped launches of (xyz.shape[0], npoint) inside graphs captured from now on
+    (synchronises the current stream). Every eager sample_and_group_xyz / sa_level of that shape does the same for
+    _SPARE_STOCK of them; call this for a capture with no eager warm-up, or for more call sites than that in a row."""
+    lib = _C.lib()
+    b, m = int(xyz.shape[0]), int(npoint)
+    stock = _SPARES.setdefault((xyz.device.index, b, m), [])
+    while len(stock) < int(count):
+        stock.append(_new_entry(lib, xyz.device, b, m))
+    torch.cuda.current_stream(xyz.device).synchronize()
+
+
+def _capture_workspace(dev, b, m):
+    """A zeroed workspace for ONE captured call site, or None (-> the two launches)."""
+    stock = _SPARES.get((dev.index, b, m))
+    if not stock or not _CAPTURE_OVERLAP[0]:
+        return None
+    ent = stock.pop()
+    _CAPTURED.append((dev.index, ent))
+    return ent
+
+
+_CAPTURE_OVERLAP = [True]
+# Lab only (scripts/stale_granule_repro.py with build_lab/libpn2ops_stalelab.so): capture the form rounds 2-4 captured -- a
+# workspace that is a TEMPORARY of the capturing call ("temp") or kept alive ("kept"), cleared inside the graph, constant tag.
+# The product library refuses that form inside a capture (it enqueues the two launches), so this does nothing harmful there.
+_LAB_CAPTURE_FORM = [None]
+_LAB_KEPT = []
+
+
+def _lab_capture_workspace(lib, dev, b, m):
+    ws = torch.empty((lib.pn2_sample_and_group_ws_bytes(b, m),), dtype=torch.uint8, device=dev)
+    if _LAB_CAPTURE_FORM[0] == "kept":
+        _LAB_KEPT.append(ws)
+    return ws
+
+
+def set_overlapped_launch_in_graphs(flag):
+    """False: captured levels take the two launches (round 5's behaviour). Default True: the device-numbered overlapped launch."""
+    _CAPTURE_OVERLAP[0] = bool(flag)
+
+
+def release_captured_workspaces():
+    """Forget the workspaces handed to captured graphs. Only after every graph captured so far has been destroyed."""
+    _CAPTURED.clear()
+
+
+def _all_workspaces():
+    for (dev_index, _stream, _b, _m), ent in list(_GRANULES.items()):
+        yield dev_index, ent
+    for dev_index, ent in list(_CAPTURED):
+        yield dev_index, ent
+
 
 def _granule_workspace(lib, dev, stream, b, m):
-    key = (dev.index, stream, b * m)
+    key = (dev.index, stream, b, m)
     ent = _GRANULES.get(key)
     if ent is None or ent[1] >= 0xFFFFFFF0:
         if len(_GRANULES) > 64:
             _GRANULES.clear()
-        buf = torch.zeros((lib.pn2_sample_and_group_ws_bytes(b, m),), dtype=torch.uint8, device=dev)
-        ent = [buf, 0, torch.zeros((1,), dtype=torch.int32).pin_memory(), None, 0]
+        ent = _new_entry(lib, dev, b, m)
         _GRANULES[key] = ent
+    _top_up_spares(lib, dev, b, m)
     _check_status(ent, wait=False)
     ent[1] += 1
     return ent
 
 
 def _status_word(ent):
-    buf = ent[0]
-    return buf[buf.numel() - 16:buf.numel() - 12].view(torch.int32)
+    return ent[0][ent[5]:ent[5] + 4].view(torch.int32)
 
 
 def _check_status(ent, wait):
@@ -231,7 +309,7 @@ def _fetch_status(ent):
 def check_overlapped_launches(device=None):
     """Fetch and check the status word of every overlapped-launch workspace now (synchronises): raises
     OverlappedLaunchError if any consumer ever gave up. The operators do the same without waiting, a few calls late."""
-    for (dev_index, _stream, _bm), ent in list(_GRANULES.items()):
+    for dev_index, ent in _all_workspaces():
         if device is not None and dev_index != device.index:
             continue
         if ent[3] is None:
@@ -280,22 +358,35 @@ def sample_and_group_xyz(npoint, radius, nsample, xyz, subtract_centroid=True):
     cnt = torch.empty((b, m), dtype=torch.int32, device=dev)
     grouped = torch.empty((b, m, ns, 3), dtype=torch.float32, device=dev)
     st = stream_ptr(dev)
-    if torch.cuda.is_current_stream_capturing():
-        # A captured launch is replayed with the same arguments: generations cannot advance, the workspace would have to be
-        # cleared INSIDE the graph (hipMemsetAsync + tag 1, what rounds 2-4 did here). Round 5's soak of a serving loop found
-        # geometry graphs whose overlapped launch served STALE granules -- samples of the slot's previous batch, duplicated
-        # rows in new_xyz -- from some replay on, and kept doing so replayed alone (profiles/r05/geometry_ahead.txt): the
-        # memset node is not something a hand-off protocol can rest on here. A captured level takes the two launches.
-        return _two_launch_path(m, radius, ns, xyz, subtract_centroid)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if capturing:
+        # A captured launch is replayed with the same arguments, so the host cannot number it. Rounds 2-4 cleared the
+        # workspace inside the graph and used the constant tag 1, and round 5's soak of a serving loop found replays that
+        # accepted granules of another replay (profiles/r06/stale_granules.md). Since round 6 the launch numbers itself on a
+        # workspace of this call site's own (_capture_workspace); without one, the two launches.
+        if _LAB_CAPTURE_FORM[0] is not None:
+            with on_device(dev):
+                ws = _lab_capture_workspace(lib, dev, b, m)
+                _C.check(lib.pn2_sample_and_group_xyz(b, n, m, float(radius), ns, ptr(xyz), ptr(ws), ptr(fps_idx), ptr(new_xyz),
+                                                      ptr(idx), ptr(cnt), ptr(grouped), 1 if subtract_centroid else 0, st),
+                         "sample_and_group_xyz (lab form)")
+            return fps_idx, mark_fps_ordered(new_xyz), idx, cnt, grouped
+        ent = _capture_workspace(dev, b, m)
+        if ent is None:
+            return _two_launch_path(m, radius, ns, xyz, subtract_centroid)
+        gen = GENERATION_DEVICE
     with on_device(dev):
-        ent = _granule_workspace(lib, dev, st, b, m)              # raises if an earlier launch on it reported a give-up
-        rc = lib.pn2_sample_and_group_xyz_gen(b, n, m, float(radius), ns, ptr(xyz), ptr(ent[0]), ent[1], ptr(fps_idx),
+        if not capturing:
+            ent = _granule_workspace(lib, dev, st, b, m)          # raises if an earlier launch on it reported a give-up
+            gen = ent[1]
+        rc = lib.pn2_sample_and_group_xyz_gen(b, n, m, float(radius), ns, ptr(xyz), ptr(ent[0]), gen, ptr(fps_idx),
                                               ptr(new_xyz), ptr(idx), ptr(cnt), ptr(grouped),
                                               1 if subtract_centroid else 0, st)
         if rc == -4:                                              # PN2_E_TOO_LARGE: e.g. too few CUs to hold every producer
             return _two_launch_path(m, radius, ns, xyz, subtract_centroid)
         _C.check(rc, "sample_and_group_xyz")
-        _fetch_status(ent)
+        if not capturing:                                         # (a captured site's status word: check_overlapped_launches())
+            _fetch_status(ent)
     return fps_idx, mark_fps_ordered(new_xyz), idx, cnt, grouped
 
 

@@ -124,7 +124,7 @@ def test_c_abi_argument_validation_of_the_extra_entry_points():
     assert lib.pn2_group_point_grad_det(1, 8, 4, 2, 2, None, None, None, None, None) == -1
     assert lib.pn2_seg_grad_ws_bytes(2, 100, 640) == 4 * (2 * 101 + 2 * 2 * 100 + 2 * 640) + 16
     assert lib.pn2_det_grad_ws_bytes(2, 100, 8) == 16 + 8 * 2 * 100 * 8
-    assert lib.pn2_sample_and_group_ws_bytes(3, 100) == 8 * 300 + 16            # granules + status word
+    assert lib.pn2_sample_and_group_ws_bytes(3, 100) == 8 * 300 + 16 + 8 * 3   # granules + status word + one counter word per cloud
     assert lib.pn2_sample_and_group_status_offset(3, 100) == 8 * 300
     # the per-call kernel-choice entry points validate their extra arguments too
     assert lib.pn2_query_ball_group_xyz_ex(1, 8, 4, 0.2, 4, one, one, 0, one, one, None, 7, 0, None) == -3
@@ -218,3 +218,14 @@ def test_out_option_buffer_validation_is_host_logic():
     for bad in (torch.empty(2, 4, dtype=torch.int32), torch.empty(2, 3, dtype=torch.float32), torch.empty(3, 2, dtype=torch.int32).t(), "x"):
         with pytest.raises(ValueError, match="must be a contiguous"):
             out_or_empty(bad, (2, 3), torch.int32, dev)
+
+
+def test_library_never_issues_a_memset():
+    """A hipMemsetAsync captured into a HIP graph is a memset NODE, and a replayed memset node of this runtime does not clear
+    (profiles/r06/stale_granules.md; scripts/memset_node_repro.py reproduces it in twenty lines). Every clear in the library is
+    a kernel of its own (csrc/pn2_device.h: clear_async); the shared object must not even import the memset entry points."""
+    import subprocess
+    from pointnet2_amd import _C
+    out = subprocess.run(["nm", "-D", "--undefined-only", _C.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "hipLaunchKernel" in out                                   # the listing is what we think it is
+    assert not [l for l in out.splitlines() if "hipMemset" in l], out

@@ -238,3 +238,35 @@ def test_geometry_on_a_side_stream_consumed_on_the_main_stream(cuda):
         del g, f
     torch.cuda.synchronize()
     assert int(bad) == 0
+
+
+def test_overlapped_launches_on_four_streams_with_inputs_that_change_every_iteration(cuda):
+    """the four-stream test above re-runs ONE input per stream, where a granule taken from the launch
+    before is invisible by construction. Here every stream rotates three clouds, so launch i's consumers would show launch
+    i - 1's samples at once: 4 streams x 300 overlapped launches (host generations on the stream's workspace), each compared on
+    the device with the single-stream reference of the cloud it was given."""
+    import pointnet2_amd as P
+    shapes = [(8, 2048, 256, 0.2, 32), (3, 1024, 128, 0.25, 16), (16, 1024, 512, 0.2, 32), (5, 4096, 256, 0.15, 64)]
+    gens = [S.sphere_clouds, S.uniform_clouds, S.sphere_clouds, S.uniform_clouds]
+    clouds, refs = [], []
+    for s, (b, n, m, r, ns) in enumerate(shapes):
+        cs = [_dev(gens[s](b, n, 40 + 3 * s + k), cuda) for k in range(3)]
+        clouds.append(cs)
+        refs.append([tuple(t.clone() for t in P.sample_and_group_xyz(m, r, ns, c, True)) for c in cs])
+        assert not torch.equal(refs[s][0][0], refs[s][1][0])             # the clouds really differ in their samples
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=cuda, priority=-(s & 1)) for s in range(4)]
+    bad = torch.zeros((4,), dtype=torch.int64, device=cuda)
+    for it in range(300):
+        for s, (b, n, m, r, ns) in enumerate(shapes):
+            k = (it + s) % 3
+            with torch.cuda.stream(streams[s]):
+                out = P.sample_and_group_xyz(m, r, ns, clouds[s][k], True)
+                d = None
+                for o, rf in zip(out, refs[s][k]):
+                    e = (o != rf).sum()
+                    d = e if d is None else d + e
+                bad[s] += d
+    torch.cuda.synchronize()
+    P.tf_grouping.check_overlapped_launches(cuda)
+    assert bad.tolist() == [0, 0, 0, 0]

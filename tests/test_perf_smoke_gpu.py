@@ -1,6 +1,7 @@
-"""Performance smoke test: the kernels the bench line reports must not silently regress. Bounds are
-the slowest box of the pool seen so far plus ~10 % (boxes of the pool differ by a few per cent; HIP-event medians of 10 runs):
-not a benchmark, a tripwire for an accidental fallback or a broken size rule."""
+"""Performance smoke test: the kernels the bench line reports must not silently regress. The two
+chain-bound times are held to measured + 5 % (they do not move between boxes: the chain runs at the shader clock on b CUs),
+the others to the slowest box of the pool seen so far plus ~10 %; HIP-event medians of 10 runs. Not a benchmark, a tripwire
+for an accidental fallback or a broken size rule."""
 import numpy as np
 import pytest
 import torch
@@ -27,9 +28,12 @@ def test_metric_shape_kernels_hold_their_times(cuda):
     t_overlap = _event_us(stage.overlap_)
     t_fps = _event_us(stage.fps_)
     t_ball = _event_us(stage.ball_group_)
-    assert stage.verify("overlap")["ok"] or True                   # (verify() re-runs the operator path; the numbers below are what is asserted)
-    assert t_overlap <= 430.0, "overlapped sample-and-group launch: %.1f us (round 5: 398)" % t_overlap
-    assert t_fps <= 425.0, "farthest_point_sample at the metric shape: %.1f us (round 5: 394)" % t_fps
+    stage.overlap_()
+    v = stage.verify("overlap")                                    # the timed launch's outputs against the operator path, on the device
+    assert v["ok"], v
+    # measured + 5 %: 378 / 367-369 us on every box seen in rounds 5-6; round 4's kernels (417 / 402) must fail here
+    assert t_overlap <= 400.0, "overlapped sample-and-group launch: %.1f us (rounds 5-6: 377-380)" % t_overlap
+    assert t_fps <= 390.0, "farthest_point_sample at the metric shape: %.1f us (rounds 5-6: 367-369)" % t_fps
     assert t_ball <= 36.0, "query_ball_group_xyz: %.1f us (round 5: 29.8)" % t_ball
     stage.overlap_()
     torch.cuda.synchronize()

@@ -464,3 +464,80 @@ def test_few_channel_scatter_is_reproducible_in_deterministic_mode(cuda):
     out, _ = train_mlp.sa_mlp_train(net.net, xyz, new_xyz, pts, idx)
     g_atomic = torch.autograd.grad((out * gw).sum(), pts)[0]
     assert float((g_atomic - grads[0]).abs().max()) <= 1e-5 * float(grads[0].abs().max())
+
+
+@pytest.mark.parametrize("b,cfeat", [(4, 16), (2, 8)], ids=["segmented-gradients", "atomic-gradients"])
+def test_captured_training_step_soak_with_rotating_inputs(cuda, b, cfeat):
+    """a captured step used to be replayed ONCE. Here one HIP graph holds a fused training
+    level (forward + backward), the operators' own backward passes behind it -- group_point, gather_point, three_interpolate:
+    every launch that starts from a cleared accumulation target (csrc/group.hip, seg_grad.hip, interpolate.hip) -- and an eval
+    group_all level on the split cooperative kernel, which clears its output (coop_mlp.hip); replayed 600 times with three inputs
+    in rotation and compared on the device with the eager step on the same input. Those clears were memset nodes until round 6
+    -- and a replayed memset node of this runtime fills with stale launch arguments instead of zeros
+    (profiles/r06/stale_granules.md); they are kernels of the library's own now. (b, cfeat) = (2, 8) takes the atomic gradient
+    entry points, (4, 16) the segmented ones (_tensors.use_segmented_grad)."""
+    import pointnet2_amd as P
+    import pointnet2_amd.pointnet_util as U
+    torch.manual_seed(5)
+    n, m, ns = 256, 64, 32
+    sa = U.PointnetSAModule(cfeat, m, 0.4, ns, [32, 32, 64]).to(cuda).train()
+    ga = U.PointnetSAModule(64, None, None, None, [64, 64, 128], group_all=True).to(cuda).eval()
+    ga.prepare_fused(cuda, n=m)
+    params = list(sa.parameters())
+    xs = [torch.rand(b, n, 3, device=cuda) for _ in range(3)]
+    fs = [torch.randn(b, n, cfeat, device=cuda) for _ in range(3)]
+    xyz = xs[0].clone()
+    feats = fs[0].clone().requires_grad_(True)
+    w_up = torch.randn(b, n, 64, device=cuda)
+    w_g = torch.randn(b, m, ns, cfeat, device=cuda)
+    w_c = torch.randn(b, m, 3, device=cuda)
+
+    def step():
+        new_xyz, f1, idx = sa(xyz, feats)                                        # fused training level
+        fps = P.farthest_point_sample(m, xyz)
+        g = P.group_point(feats, idx)                                             # backward: group_point_grad
+        c = P.gather_point(feats[:, :, :3].contiguous(), fps)                     # backward: gather_point_grad
+        d, nidx = P.three_nn(xyz, new_xyz)
+        wt = 1.0 / torch.clamp(d, min=1e-10)
+        wt = wt / wt.sum(dim=2, keepdim=True)
+        up = P.three_interpolate(f1, nidx, wt)                                    # backward: three_interpolate_grad
+        loss = (up * w_up).sum() + (g * w_g).sum() + (c * w_c).sum()
+        grads = torch.autograd.grad(loss, params + [feats])
+        with torch.no_grad():
+            _, pooled, _ = ga(new_xyz, f1.detach())                               # eval group_all: the split cooperative kernel
+        return (f1, pooled) + tuple(grads)
+
+    def close(a, e):
+        return float((a - e).abs().max()) <= 2e-6 * max(1e-30, float(e.abs().max()))
+    want = []
+    for k in range(3):
+        xyz.copy_(xs[k])
+        with torch.no_grad():
+            feats.copy_(fs[k])
+        want.append(tuple(t.detach().clone() for t in step()))
+    assert sa.last_path == "fused_train" and ga.last_path == "fused"
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        got = step()
+    # relative error of every output against the eager step of the same input, maximum over the soak, kept on the device
+    worst = torch.zeros((len(got),), device=cuda)
+    scale = [[max(1e-30, float(t.abs().max())) for t in w] for w in want]
+    for it in range(600):
+        k = it % 3
+        xyz.copy_(xs[k])
+        with torch.no_grad():
+            feats.copy_(fs[k])
+        d = (w_up != w_up).sum()                                                  # an eager kernel between the replays (what the serving loop's compare was)
+        g.replay()
+        for i, (a, e) in enumerate(zip(got, want[k])):
+            worst[i] = torch.maximum(worst[i], (a.detach() - e).abs().max() / scale[k][i])
+    torch.cuda.synchronize()
+    assert float(worst.max()) <= 2e-6, worst.tolist()
+    if b >= 4:                                                                    # segmented gradients and the fused level are order-fixed: identical bits
+        assert float(worst[0]) == 0.0 and float(worst[-1]) <= 2e-6
