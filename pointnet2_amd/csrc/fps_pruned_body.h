@@ -44,6 +44,17 @@ namespace pn2 {
 #ifndef PN2_PR_DISPATCH
 #define PN2_PR_DISPATCH 1
 #endif
+// Lab switches of round 6 (scripts/build_labs.sh, profiles/r06/fps_round6.txt); the product builds with both at 0.
+//   PN2_PR_EARLY_ALL = J: rounds 1 .. J update EVERY group in straight-line code, without the box test and the dispatch
+//                         (the first rounds prune nothing and pay the pruned round);
+//   PN2_PR_SPEC_MIRROR = 4 / 2: the mirror rows of all four wave candidates (or of the two semi-final winners) are read
+//                         BEFORE the tournament is decided and the winner's row is selected in registers (next 2d).
+#ifndef PN2_PR_EARLY_ALL
+#define PN2_PR_EARLY_ALL 0
+#endif
+#ifndef PN2_PR_SPEC_MIRROR
+#define PN2_PR_SPEC_MIRROR 0
+#endif
 constexpr int kPrT = 256;              // threads of the pruned tier
 constexpr int kPrW = kPrT / PN2_WAVE;  // 4 waves: one per SIMD
 constexpr int kPrBins = 64;            // histogram bins per axis (= one wave)
@@ -298,7 +309,10 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
     double wave_key = 0.0;                              // lane 63: the wave's key (cached while no group of the wave changes)
     int kprev = 0;                                      // index selected by the previous round (stored one round late, below)
 
-    auto round = [&](const int j, const int par) __attribute__((always_inline)) {
+    auto round = [&](const int j, const int par, auto allc) __attribute__((always_inline)) {
+        constexpr bool ALL = decltype(allc)::value;
+        unsigned mybits = (1u << GW) - 1u;
+        if constexpr (!ALL) {
         // which groups can the new sample change? (all lanes, lane l = group l)
         const float thr = __fadd_rn(__fmul_rn(vstar, 1.00001f), 1e-30f);
         // distance from the sample to the box = sample - clamp(sample, lo, hi) per axis (v_med3_f32 is the clamp)
@@ -307,9 +321,10 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
         const float az = __fsub_rn(szk.x, __builtin_amdgcn_fmed3f(szk.x, blz, bhz));
         const float bd = __fadd_rn(__fadd_rn(__fmul_rn(ax, ax), __fmul_rn(ay, ay)), __fmul_rn(az, az));
         const unsigned long long far_mask = __ballot(bd >= thr);          // NaN -> not far -> updated
-        const unsigned mybits = (unsigned)(~far_mask >> (w * GW)) & ((1u << GW) - 1u);   // scalar
+        mybits = (unsigned)(~far_mask >> (w * GW)) & ((1u << GW) - 1u);   // scalar
+        }
         unsigned long long *slot = partial + par * W;
-        if (mybits != 0u) {                                               // wave-uniform
+        if (ALL || mybits != 0u) {                                        // wave-uniform
             auto update_group = [&](auto gic) __attribute__((always_inline)) {
                 constexpr int gi = decltype(gic)::value;
                 constexpr int H = GS / 2;
@@ -354,6 +369,12 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
             // The LOWEST touched group -- the only one in most rounds -- is found by a binary search on its isolated bit
             // (three compare + branch pairs); further groups take nested bit tests (structured: hipcc turns a switch on
             // the bit number, or a loop over the set bits, into flag variables and copies of every slot register).
+            if constexpr (ALL) {
+                update_group(std::integral_constant<int, 0>()); update_group(std::integral_constant<int, 1>()); PN2_PR_PAIR(0);
+                update_group(std::integral_constant<int, 2>()); update_group(std::integral_constant<int, 3>()); PN2_PR_PAIR(1);
+                update_group(std::integral_constant<int, 4>()); update_group(std::integral_constant<int, 5>()); PN2_PR_PAIR(2);
+                update_group(std::integral_constant<int, 6>()); update_group(std::integral_constant<int, 7>()); PN2_PR_PAIR(3);
+            } else {
 #if PN2_PR_DISPATCH == 2
             for (unsigned bits = mybits; bits != 0u;) {
                 const unsigned lowbit = bits & (0u - bits);
@@ -398,6 +419,7 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
             }
 #undef PN2_PR_GROUP0
 #endif
+            }
 #undef PN2_PR_ONE
 #undef PN2_PR_PAIR
 #undef PN2_PR_GROUP
@@ -422,6 +444,35 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
                 __hip_atomic_store(gtag + (j - 1), ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)kprev,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+#if PN2_PR_SPEC_MIRROR == 4
+        // lab: all four candidates' mirror rows are requested as soon as the keys are there, the tournament runs under their
+        // latency, the winner's row is selected in registers
+        static_assert(W == 4, "four waves");
+        float4 cand[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) cand[i] = lds_rank[(unsigned)__double2loint(key[i])];
+        double k01, k23, kw;
+        asm("v_max_f64 %0, %1, %2" : "=v"(k01) : "v"(key[0]), "v"(key[1]));
+        asm("v_max_f64 %0, %1, %2" : "=v"(k23) : "v"(key[2]), "v"(key[3]));
+        asm("v_max_f64 %0, %1, %2" : "=v"(kw) : "v"(k01), "v"(k23));
+        const bool lo_half = __double2loint(kw) == __double2loint(k01) && __double2hiint(kw) == __double2hiint(k01);
+        const bool first = lo_half ? (__double2loint(kw) == __double2loint(key[0]) && __double2hiint(kw) == __double2hiint(key[0]))
+                                   : (__double2loint(kw) == __double2loint(key[2]) && __double2hiint(kw) == __double2hiint(key[2]));
+        const float4 sa = lo_half ? cand[0] : cand[2], sb = lo_half ? cand[1] : cand[3];
+        const float4 s = first ? sa : sb;
+        vstar = __int_as_float(__double2hiint(kw));
+#elif PN2_PR_SPEC_MIRROR == 2
+        // lab: semi-finals first, the two semi-final winners' rows requested, the final runs under their latency
+        static_assert(W == 4, "four waves");
+        double k01, k23, kw;
+        asm("v_max_f64 %0, %1, %2" : "=v"(k01) : "v"(key[0]), "v"(key[1]));
+        asm("v_max_f64 %0, %1, %2" : "=v"(k23) : "v"(key[2]), "v"(key[3]));
+        const float4 sa = lds_rank[(unsigned)__double2loint(k01)], sb = lds_rank[(unsigned)__double2loint(k23)];
+        asm("v_max_f64 %0, %1, %2" : "=v"(kw) : "v"(k01), "v"(k23));
+        const bool first = __double2loint(kw) == __double2loint(k01) && __double2hiint(kw) == __double2hiint(k01);
+        const float4 s = first ? sa : sb;
+        vstar = __int_as_float(__double2hiint(kw));
+#else
 #pragma unroll
         for (int st = 1; st < W; st <<= 1)
 #pragma unroll
@@ -430,15 +481,25 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
         const unsigned win = (unsigned)__double2loint(key[0]);
         vstar = __int_as_float(__double2hiint(key[0]));
         const float4 s = lds_rank[win];                // same address in every lane: LDS broadcast
+#endif
         sxy.x = s.x; sxy.y = s.y; syy.x = s.y; szk.x = s.z; szk.y = s.w;
         kprev = __float_as_int(s.w);
     };
     int j = 1;
-    for (; j + 1 < m; j += 2) {
-        round(j, 1);
-        round(j + 1, 0);
+#if PN2_PR_EARLY_ALL > 0
+    {
+        const int je = m - 1 < (PN2_PR_EARLY_ALL) ? m - 1 : (PN2_PR_EARLY_ALL);       // even count: the parities below stay aligned
+        for (; j + 1 <= (je & ~1); j += 2) {
+            round(j, 1, std::true_type());
+            round(j + 1, 0, std::true_type());
+        }
     }
-    if (j < m) round(j, 1);
+#endif
+    for (; j + 1 < m; j += 2) {
+        round(j, 1, std::false_type());
+        round(j + 1, 0, std::false_type());
+    }
+    if (j < m) round(j, 1, std::false_type());
     if (t == 0 && m > 1) {                              // the last round's index
         dst[m - 1] = kprev;
         if (PUBLISH)

@@ -11,8 +11,13 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$ROOT/build_lab"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -munsafe-fp-atomics"
 hipcc $FLAGS "$@" "$ROOT/scripts/fps_prod_lab.hip" -o "$ROOT/build_lab/fps_product" &
-hipcc $FLAGS "$@" "$ROOT/scripts/fps_pruned_lab.hip" -o "$ROOT/build_lab/fps_pruned_lab" &
+hipcc $FLAGS -mllvm -structurizecfg-skip-uniform-regions "$@" "$ROOT/scripts/fps_pruned_lab.hip" -o "$ROOT/build_lab/fps_pruned_lab" &
 hipcc $FLAGS "$@" "$ROOT/scripts/fps_concurrency_lab.hip" -o "$ROOT/build_lab/fps_concurrency_lab" &
 hipcc $FLAGS "$@" "$ROOT/scripts/pk_hazard_lab.hip" -o "$ROOT/build_lab/pk_hazard_lab" &
 wait
 ls -la "$ROOT/build_lab"
+# round 6 (profiles/r06/fps_round6.txt): the pruned tier's lab switches, one binary each
+for v in "c16:-DPN2_PR_EARLY_ALL=16" "c32:-DPN2_PR_EARLY_ALL=32" "c64:-DPN2_PR_EARLY_ALL=64" "d4:-DPN2_PR_SPEC_MIRROR=4" "d2:-DPN2_PR_SPEC_MIRROR=2" "c16d2:-DPN2_PR_EARLY_ALL=16 -DPN2_PR_SPEC_MIRROR=2"; do
+    hipcc $FLAGS -mllvm -structurizecfg-skip-uniform-regions ${v#*:} "$ROOT/scripts/fps_pruned_lab.hip" -o "$ROOT/build_lab/fps_pruned_lab_${v%%:*}" &
+done
+wait

@@ -481,7 +481,7 @@ def test_captured_training_step_soak_with_rotating_inputs(cuda, b, cfeat):
     torch.manual_seed(5)
     n, m, ns = 256, 64, 32
     sa = U.PointnetSAModule(cfeat, m, 0.4, ns, [32, 32, 64]).to(cuda).train()
-    ga = U.PointnetSAModule(64, None, None, None, [64, 64, 128], group_all=True).to(cuda).eval()
+    ga = U.PointnetSAModule(64, None, None, None, [256, 256, 512], group_all=True).to(cuda).eval()
     ga.prepare_fused(cuda, n=m)
     params = list(sa.parameters())
     xs = [torch.rand(b, n, 3, device=cuda) for _ in range(3)]
