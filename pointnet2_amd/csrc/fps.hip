@@ -436,8 +436,8 @@ extern "C" int pn2_farthest_point_sample_ordered(int b, int n, int m, const floa
     if (!inp || !out) return PN2_E_NULL;
     if (n > kMaxRegPoints) return PN2_E_TOO_LARGE;
     if (m < 2 || m > n || m > 1024 || n > 2048) return fps_entry(b, n, m, inp, nullptr, out, out_xyz, stream);
+    if (b > 65535) return fps_entry(b, n, m, inp, nullptr, out, out_xyz, stream);   // beyond the check launch's grid.y: the plain operator (same result)
     if (!ws) return PN2_E_NULL;
-    if (b > 65535) return PN2_E_TOO_LARGE;
     hipStream_t st = as_stream(stream);
     int *flags = static_cast<int *>(ws);
     if (int rc = launch_verify(b, n, m, inp, flags, st)) return rc;

@@ -301,12 +301,33 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
         dst[0] = 0;                                     // tf_sampling_g.cu:114-116
         if (PUBLISH) __hip_atomic_store(gtag, (unsigned long long)tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    double gk[GW], gp[GW / 2];                          // lane-level key of every group and of every pair of groups (cached across rounds)
+    // lane-level key of every group and of every pair of groups, and (lane 63) the wave's key: cached across rounds, so they
+    // start as the keys of the INITIAL running distances (1e38 : low) -- a group whose box is farther than ~1e19 from point 0 is
+    // skipped in round 1 already, and its points must then compete with the reference's td = 1e38 (tf_sampling_g.cu:118), not
+    // with a key of 0
+    double gk[GW], gp[GW / 2];
 #pragma unroll
-    for (int gi = 0; gi < GW; ++gi) gk[gi] = 0.0;
+    for (int gi = 0; gi < GW; ++gi) {
+        double kd[GS];
 #pragma unroll
-    for (int q = 0; q < GW / 2; ++q) gp[q] = 0.0;
-    double wave_key = 0.0;                              // lane 63: the wave's key (cached while no group of the wave changes)
+        for (int q = 0; q < GS; ++q) kd[q] = __hiloint2double(__float_as_int(md[gi * GS + q]), (int)low[gi * GS + q]);
+#pragma unroll
+        for (int st = 1; st < GS; st <<= 1)
+#pragma unroll
+            for (int i = 0; i + st < GS; i += 2 * st)
+                asm("v_max_f64 %0, %1, %2" : "=v"(kd[i]) : "v"(kd[i]), "v"(kd[i + st]));
+        gk[gi] = kd[0];
+    }
+#pragma unroll
+    for (int q = 0; q < GW / 2; ++q) asm("v_max_f64 %0, %1, %2" : "=v"(gp[q]) : "v"(gk[2 * q]), "v"(gk[2 * q + 1]));
+    double wave_key;                                    // lane 63: the wave's key (cached while no group of the wave changes)
+    {
+        double k01, k23, kl;
+        asm("v_max_f64 %0, %1, %2" : "=v"(k01) : "v"(gp[0]), "v"(gp[1]));
+        asm("v_max_f64 %0, %1, %2" : "=v"(k23) : "v"(gp[2]), "v"(gp[3]));
+        asm("v_max_f64 %0, %1, %2" : "=v"(kl) : "v"(k01), "v"(k23));
+        wave_key = wave_max_f64_lane63(kl);
+    }
     int kprev = 0;                                      // index selected by the previous round (stored one round late, below)
 
     auto round = [&](const int j, const int par, auto allc) __attribute__((always_inline)) {

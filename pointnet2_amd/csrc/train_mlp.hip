@@ -1744,7 +1744,8 @@ struct TlPlan {
     size_t gq;                  // backward, pooled: (groups, cout_L)
     size_t ga, gb;              // backward: dy ping-pong (rows, max width)
     size_t partial, partial2;   // backward: weight-gradient partial sums
-    size_t partial_cap, partial2_cap;   // ... and the bytes planned for them (launch_wgrad / launch_pair refuse a larger shape)
+    size_t partial_cap;         // ... and the bytes planned for `partial` (launch_wgrad / launch_pair refuse a larger shape; `partial2` is the
+                                // second-stage buffer of the former two-launch reduction: still planned, no longer written)
     size_t topw, topsf;         // backward, pooled top layer without z_L: stacked fp32 weight + constant row; [S | G | sumh] fp64
     size_t tops_part, tops_part2, tops64;   // ... its routed part on the vector units: partials (two stages), S (K, C_L) fp64
     size_t l1p;                 // layer 1 per point: forward P (b n, cout_1); backward S (b n, cout_1)
@@ -1897,7 +1898,7 @@ static bool tl_plan(long long rows, int nlayers, const int *widths, int pool_row
         }
         pl.partial = off; off = align_up(off + p1);
         pl.partial2 = off; off = align_up(off + p2);
-        pl.partial_cap = p1; pl.partial2_cap = p2;
+        pl.partial_cap = p1;
         if (ztop) {
             const int kin = widths[nlayers - 1];
             pl.topw = off; off = align_up(off + sizeof(float) * (size_t)(tiles(cl) * 32 + kin + 1) * kin);

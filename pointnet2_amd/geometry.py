@@ -2,8 +2,11 @@
 
 Every level of the reference networks samples, groups and interpolates from coordinates only
 (models/pointnet2_sem_seg.py:28-37, pointnet2_cls_ssg.py:27-29, pointnet2_part_seg.py:24-33): l{k}_xyz depends on
-l{k-1}_xyz, never on a feature, and no gradient flows through any of it (farthest_point_sample, query_ball_point and
+l{k-1}_xyz, never on a feature, and the INDEX outputs carry no gradient (farthest_point_sample, query_ball_point and
 three_nn are registered NotDifferentiable / index outputs: tf_sampling.py:57, tf_grouping.py:29, tf_interpolate.py:20).
+The one gradient that does pass through a level's geometry is GatherPoint's (tf_sampling.py:43-47: d new_xyz / d xyz): a
+geometry is computed from xyz.detach(), so a module whose xyz requires a gradient rebuilds new_xyz from the geometry's
+sample indices with the differentiable gather_point (SAGeometry.new_xyz_for) -- same values, the centroid term kept.
 The farthest-point chains are also the one part of a forward that cannot use the machine: b workgroups on 256 CUs for
 hundreds of microseconds (132 us of cls_ssg's 486, 435 us of sem_seg's 897), while the layer stacks that follow fill every CU.
 
@@ -15,7 +18,7 @@ geometry, level-1 chain included, under batch i's stacks (what a serving loop or
 does) -- scripts/model_forward_bench.py reports both.
 
 The results are the results of the plain forward, bit for bit (tests/test_geometry_ahead_gpu.py): the same kernels compute
-them, only their stream differs (and, inside captured graphs, a level's two launches stand for its overlapped one). Multi-stream use of the library is a tested contract since round 5
+them, only their stream differs (inside captured graphs the overlapped launch numbers itself: tf_grouping._capture_workspace). Multi-stream use of the library is a tested contract since round 5
 (tests/test_multistream_gpu.py; the v_pk_add_f32 hazard beside MFMA kernels is documented in csrc/pn2_device.h).
 """
 import torch
@@ -51,13 +54,27 @@ class _Ready:
 
 class SAGeometry(_Ready):
     """One set-abstraction level: new_xyz (b, m, 3) and idx (b, m, nsample) i32 -- a list of idx, one per radius, for an
-    MSG level (pointnet_util.py:156-197)."""
+    MSG level (pointnet_util.py:156-197). fps_idx (b, m) i32: the samples' indices, kept so that a consumer whose xyz needs a
+    gradient can rebuild new_xyz = gather_point(xyz, fps_idx) differentiably (the reference registers a gradient for
+    GatherPoint, tf_sampling.py:43-47); None for a geometry that was copied without it."""
 
-    __slots__ = ("new_xyz", "idx")
+    __slots__ = ("new_xyz", "idx", "fps_idx")
 
-    def __init__(self, new_xyz, idx):
-        self.new_xyz, self.idx = new_xyz, idx
-        self._init([new_xyz] + (list(idx) if isinstance(idx, (list, tuple)) else [idx]))
+    def __init__(self, new_xyz, idx, fps_idx=None):
+        self.new_xyz, self.idx, self.fps_idx = new_xyz, idx, fps_idx
+        self._init([new_xyz] + (list(idx) if isinstance(idx, (list, tuple)) else [idx]) + ([fps_idx] if fps_idx is not None else []))
+
+    def new_xyz_for(self, xyz):
+        """new_xyz as the consumer must use it: the precomputed tensor, or -- when xyz needs a gradient -- the same values
+        gathered from xyz by the differentiable operator, so that the centroid term of d / d xyz is not lost (the geometry
+        itself is computed from xyz.detach())."""
+        if not (torch.is_grad_enabled() and xyz.requires_grad):
+            return self.new_xyz
+        if self.fps_idx is None:
+            raise ValueError("this geometry carries no sample indices, and xyz requires a gradient: the centroids cannot be "
+                             "rebuilt differentiably -- compute the geometry with GeometryAhead / module.geometry(), or detach xyz")
+        from .tf_sampling import gather_point
+        return gather_point(xyz, self.fps_idx)
 
 
 class FPGeometry(_Ready):
@@ -87,7 +104,7 @@ class NetworkGeometry:
     def static_copy(self):
         """The same geometry in tensors of its own, without events."""
         sa = [None if g is None else SAGeometry(g.new_xyz.clone(), [i.clone() for i in g.idx] if isinstance(g.idx, (list, tuple))
-                                                else g.idx.clone()) for g in self.sa]
+                                                else g.idx.clone(), None if g.fps_idx is None else g.fps_idx.clone()) for g in self.sa]
         fp = [None if g is None else FPGeometry(g.dist.clone(), g.idx.clone()) for g in self.fp]
         return NetworkGeometry(sa, fp)
 
@@ -167,12 +184,15 @@ class PipelinedInference:
     profiles/r05/model_forward.txt). Every output is the plain forward's bit for bit: 600-batch soaks with three inputs in
     rotation per network and setting in scripts/model_forward_bench.py, a 1,200-batch soak in the test suite.
 
-    The soak is what found this round's one real defect (profiles/r05/geometry_ahead.txt): inside a CAPTURED graph the
-    overlapped launch -- workspace cleared by a memset node, constant tag -- served stale sample granules of the slot's
-    previous batch from some replay on (duplicated rows in new_xyz), invisibly as long as a slot always saw the same input.
-    Captured levels take the two launches since (tf_grouping.sample_and_group_xyz).
+    The soak is what found round 5's one real defect (profiles/r05/geometry_ahead.txt): inside a CAPTURED graph the
+    overlapped launch -- workspace cleared by a memset node, constant tag -- accepted sample granules that were not the
+    replay's own from some replay on (duplicated rows in new_xyz). Round 6 found the cause (profiles/r06/stale_granules.md: a
+    replayed memset NODE of this runtime fills with stale launch arguments instead of zeros) and a form that depends on no
+    clear: inside graphs the launch numbers itself (tf_grouping.sample_and_group_xyz, PN2_GENERATION_DEVICE), on a
+    workspace per captured call site that the eager warm-up below stocks.
 
-        pipe = PipelinedInference(net, net.ahead(), example_batch)        # captures; shapes are fixed from here on
+        ahead = GeometryAhead([net.sa1, net.sa2, net.sa3], [(2, 3), (1, 2), (0, 1)])   # the network's SA modules / FP pairs
+        pipe = PipelinedInference(net, ahead, example_batch)              # captures; shapes are fixed from here on
         for x, ready in loader:                                           # x filled by the loader's stream, `ready` its event
             y = pipe.push(x, ready)                                       # returns at once; y is valid in stream order
             consume(y)                                                    # ... on the current stream

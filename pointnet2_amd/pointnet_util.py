@@ -235,15 +235,17 @@ class PointnetSAModule(nn.Module):
         if self.group_all:
             return None
         if self.knn:
-            _, new_xyz = farthest_point_sample_gather(self.npoint, xyz)
+            fps_idx, new_xyz = farthest_point_sample_gather(self.npoint, xyz)
             _, idx = knn_point(self.nsample, xyz, new_xyz)
         else:
-            _, new_xyz, idx, _, _ = sample_and_group_xyz(self.npoint, self.radius, self.nsample, xyz, True)
-        return SAGeometry(new_xyz, idx)
+            fps_idx, new_xyz, idx, _, _ = sample_and_group_xyz(self.npoint, self.radius, self.nsample, xyz, True)
+        return SAGeometry(new_xyz, idx, fps_idx)
 
     def _forward_on(self, xyz, points, g):
-        """forward() on a geometry computed ahead (geometry.py): the layer stack only, same paths, same results."""
-        new_xyz, idx = g.new_xyz, g.idx
+        """forward() on a geometry computed ahead (geometry.py): the layer stack only, same paths, same results -- and the same
+        gradients: with xyz.requires_grad the centroids are re-gathered differentiably (SAGeometry.new_xyz_for; the fused
+        paths below are not taken then, _train_fused_ok / _fused_ok refuse an xyz that needs a gradient)."""
+        new_xyz, idx = g.new_xyz_for(xyz), g.idx
         if self._train_fused_ok(xyz, points):
             self.last_path = "fused_train"
             out, _ = train_mlp.sa_mlp_train(self.mlp.net, xyz, new_xyz, points, idx, True)
@@ -365,22 +367,22 @@ class PointnetSAModuleMSG(nn.Module):
                 self._packed(si, device)
         return self
 
-    def _group_scales(self, xyz, want_idx):
+    def _group_scales(self, xyz, want_idx, with_fps=False):
         """FPS + every radius of the level: the single overlapped launch covers FPS and the first radius
         (:173-180), ONE multi-radius launch (one staging / binning of the cloud) the remaining radii --
         the reference rescans the cloud once per radius (:175-186).
-        -> new_xyz, [(idx or None, grouped_xyz) per scale]"""
-        _, new_xyz, idx0, _, gx0 = sample_and_group_xyz(self.npoint, self.radius_list[0], self.nsample_list[0], xyz, True)
+        -> new_xyz, [(idx or None, grouped_xyz) per scale] (with_fps: and the samples' indices)"""
+        fps_idx, new_xyz, idx0, _, gx0 = sample_and_group_xyz(self.npoint, self.radius_list[0], self.nsample_list[0], xyz, True)
         scales = [(idx0, gx0)]
         if len(self.radius_list) > 1:
             rest = query_ball_group_xyz_msg(self.radius_list[1:], self.nsample_list[1:], xyz, new_xyz, True, want_idx=want_idx)
             scales += [(i, g) for i, _, g in rest]
-        return new_xyz, scales
+        return (new_xyz, scales, fps_idx) if with_fps else (new_xyz, scales)
 
     def geometry(self, xyz):
         """This level's sampling and every radius' grouping alone (:173-180) -> SAGeometry with one idx per radius."""
-        new_xyz, scales = self._group_scales(xyz, True)
-        return SAGeometry(new_xyz, [idx for idx, _ in scales])
+        new_xyz, scales, fps_idx = self._group_scales(xyz, True, with_fps=True)
+        return SAGeometry(new_xyz, [idx for idx, _ in scales], fps_idx)
 
     def _forward_fused(self, xyz, points, g=None):
         """Inference: the grouping launches of _group_scales (or a geometry computed ahead), then one fused MLP + max-pool
@@ -421,7 +423,7 @@ class PointnetSAModuleMSG(nn.Module):
         fused = g is not None or not (torch.is_grad_enabled() and xyz.requires_grad)
         scales = None
         if g is not None:
-            new_xyz = g.new_xyz
+            new_xyz = g.new_xyz_for(xyz)               # (re-gathered differentiably when xyz needs a gradient: tf_sampling.py:43-47)
             scales = [(idx, group_point(xyz, idx) - new_xyz.unsqueeze(2)) for idx in g.idx]     # :179-180
         elif fused:
             new_xyz, scales = self._group_scales(xyz, points is not None)

@@ -226,10 +226,15 @@ class LevelBuffers:
         self.key, self.t = None, None
 
 
-def sa_level(npoint, radius, nsample, xyz, points, packed, buffers=None):
+def sa_level(npoint, radius, nsample, xyz, points, packed, buffers=None, ordered=None):
     """pointnet_sa_module (max pooling, three layers) in ONE call: xyz (b,n,3), points (b,n,c) or None, packed: PackedMLP3
-    -> new_xyz (b,m,3), pooled features (b,m,c3), idx (b,m,nsample), fps_idx (b,m), pts_cnt (b,m), grouped_xyz (b,m,ns,3)."""
+    -> new_xyz (b,m,3), pooled features (b,m,c3), idx (b,m,nsample), fps_idx (b,m), pts_cnt (b,m), grouped_xyz (b,m,ns,3).
+    ordered: is xyz in farthest-point order (None = the tag on the caller's tensor, read before any conversion; see
+    tf_grouping.sample_and_group_xyz)."""
     from . import tf_grouping as G
+    from . import tf_sampling as TS
+    if ordered is None:
+        ordered = isinstance(xyz, torch.Tensor) and TS.ordered_hint(xyz, int(npoint))
     xyz = f32(xyz, "xyz")
     require(xyz.dim() == 3 and xyz.shape[2] == 3, "xyz must be (b, n, 3)")
     b, n, _ = xyz.shape
@@ -262,8 +267,7 @@ def sa_level(npoint, radius, nsample, xyz, points, packed, buffers=None):
         if buffers is not None:
             buffers.key, buffers.t = key, (fps_idx, new_xyz, idx, cnt, grouped, out, ws, temp)
     st = stream_ptr(dev)
-    from . import tf_sampling as TS
-    if TS.ordered_hint(xyz, m):
+    if ordered and TS.ordered_worthwhile(xyz, m):
         # xyz is the previous level's samples in the order they were picked: checked identity instead of the chain
         with on_device(dev):
             wso = TS.ordered_workspace(lib, dev, st, b)

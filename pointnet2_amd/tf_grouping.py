@@ -320,20 +320,24 @@ def check_overlapped_launches(device=None):
         _check_status(ent, wait=True)
 
 
-def _two_launch_path(m, radius, ns, xyz, subtract_centroid):
-    """farthest_point_sample_gather + query_ball_group_xyz: what the overlapped launch computes, in two launches."""
+def _two_launch_path(m, radius, ns, xyz, subtract_centroid, ordered=None):
+    """farthest_point_sample_gather + query_ball_group_xyz: what the overlapped launch computes, in two launches.
+    ordered: the farthest-point-order hint of the CALLER's tensor (None = read it from xyz)."""
     from .tf_sampling import farthest_point_sample_gather
-    fps_idx, new_xyz = farthest_point_sample_gather(m, xyz)
+    fps_idx, new_xyz = farthest_point_sample_gather(m, xyz, ordered=ordered)
     idx, cnt, grouped = query_ball_group_xyz(radius, ns, xyz, new_xyz, subtract_centroid)
     return fps_idx, new_xyz, idx, cnt, grouped
 
 
-def sample_and_group_xyz(npoint, radius, nsample, xyz, subtract_centroid=True):
+def sample_and_group_xyz(npoint, radius, nsample, xyz, subtract_centroid=True, ordered=None):
     """The xyz half of sample_and_group (pointnet_util.py:40-46) in ONE launch: farthest point
     sampling, gather, ball query and grouping of xyz, with the ball queries running on the idle CUs
     while the FPS chain is still selecting (csrc/sa_fused.hip). Bit-identical to the separate
     operators. Not differentiable. Shapes outside the overlapped launch's envelope fall back to the
     two-launch path (farthest_point_sample_gather + query_ball_group_xyz).
+    ordered: is xyz in farthest-point order (a previous level's new_xyz)? None = the hint the sampling operators leave on the
+    tensors they return (read from the caller's tensor object BEFORE any conversion: a dtype / layout copy does not carry it);
+    True / False = say so explicitly. A wrong True costs a check (11-14 us), never a result (tf_sampling.py).
 
     -> fps_idx (b,m) i32, new_xyz (b,m,3) f32, idx (b,m,nsample) i32, pts_cnt (b,m) i32,
        grouped_xyz (b,m,nsample,3) f32
@@ -341,17 +345,20 @@ def sample_and_group_xyz(npoint, radius, nsample, xyz, subtract_centroid=True):
     require(int(npoint) > 0, "FarthestPointSample expects positive npoint")
     require(float(radius) > 0, "QueryBallPoint expects positive radius")
     require(int(nsample) > 0, "QueryBallPoint expects positive nsample")
+    from .tf_sampling import mark_fps_ordered, ordered_hint, ordered_worthwhile
+    if ordered is None:
+        ordered = isinstance(xyz, torch.Tensor) and ordered_hint(xyz, int(npoint))
     xyz = f32(xyz, "xyz")
     require(xyz.dim() == 3 and xyz.shape[2] == 3, "FarthestPointSample expects (batch_size,num_points,3) inp shape")
     b, n, _ = xyz.shape
     m, ns = int(npoint), int(nsample)
     dev = xyz.device
     lib = _C.lib()
-    from .tf_sampling import mark_fps_ordered, ordered_hint
-    if b == 0 or not _OVERLAP[0] or not (b <= 128 and 64 <= n <= 8192 and ns <= 256) or ordered_hint(xyz, m):
-        # (input hinted to be in farthest-point order: a checked identity + the ball queries in two launches beats a chain
-        # of m dependent rounds -- tf_sampling.farthest_point_sample_gather follows the hint)
-        return _two_launch_path(m, radius, ns, xyz, subtract_centroid)
+    ordered = bool(ordered) and ordered_worthwhile(xyz, m)
+    if b == 0 or not _OVERLAP[0] or not (b <= 128 and 64 <= n <= 8192 and ns <= 256) or ordered:
+        # (input in farthest-point order: a checked identity + the ball queries in two launches beats a chain of m dependent
+        # rounds)
+        return _two_launch_path(m, radius, ns, xyz, subtract_centroid, ordered)
     fps_idx = torch.empty((b, m), dtype=torch.int32, device=dev)
     new_xyz = torch.empty((b, m, 3), dtype=torch.float32, device=dev)
     idx = torch.empty((b, m, ns), dtype=torch.int32, device=dev)
@@ -373,7 +380,7 @@ def sample_and_group_xyz(npoint, radius, nsample, xyz, subtract_centroid=True):
             return fps_idx, mark_fps_ordered(new_xyz), idx, cnt, grouped
         ent = _capture_workspace(dev, b, m)
         if ent is None:
-            return _two_launch_path(m, radius, ns, xyz, subtract_centroid)
+            return _two_launch_path(m, radius, ns, xyz, subtract_centroid, False)
         gen = GENERATION_DEVICE
     with on_device(dev):
         if not capturing:
@@ -383,7 +390,7 @@ def sample_and_group_xyz(npoint, radius, nsample, xyz, subtract_centroid=True):
                                               ptr(new_xyz), ptr(idx), ptr(cnt), ptr(grouped),
                                               1 if subtract_centroid else 0, st)
         if rc == -4:                                              # PN2_E_TOO_LARGE: e.g. too few CUs to hold every producer
-            return _two_launch_path(m, radius, ns, xyz, subtract_centroid)
+            return _two_launch_path(m, radius, ns, xyz, subtract_centroid, False)
         _C.check(rc, "sample_and_group_xyz")
         if not capturing:                                         # (a captured site's status word: check_overlapped_launches())
             _fetch_status(ent)

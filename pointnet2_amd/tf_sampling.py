@@ -125,11 +125,16 @@ def mark_fps_ordered(t):
     return t
 
 
+def ordered_worthwhile(t, m):
+    """Is the ordered entry point worth calling for m samples out of `t`? (a chain long enough to pay for the check + one more
+    launch: 128 <= m <= min(n, 1024), n <= 2048)"""
+    return _ORDERED[0] and t.dim() == 3 and 128 <= int(m) <= min(t.shape[1], 1024) and t.shape[1] <= 2048 and t.shape[0] > 0
+
+
 def ordered_hint(t, m):
-    """Is the ordered entry point worth calling for m samples out of `t`? (hinted, and a chain long enough to pay for the
-    check + one more launch: 128 <= m <= min(n, 1024), n <= 2048)"""
-    return (_ORDERED[0] and getattr(t, "_pn2_fps_ordered", False) and t.dim() == 3 and 128 <= int(m) <= min(t.shape[1], 1024)
-            and t.shape[1] <= 2048 and t.shape[0] > 0)
+    """Does `t` carry the farthest-point-order tag (an attribute of the tensor OBJECT a sampling operator returned: read it
+    before any dtype / layout conversion or detach(), which make new objects), and is the short cut worthwhile for m samples?"""
+    return bool(getattr(t, "_pn2_fps_ordered", False)) and ordered_worthwhile(t, m)
 
 
 def ordered_workspace(lib, dev, stream, b):

@@ -261,3 +261,42 @@ def test_pipelined_inference_soak_with_changing_slot_content(cuda):
             torch.cuda.synchronize()
             assert int((bad != 0).sum()) == 0, "geometry_streams=%d: wrong batches %s" % (gs, (bad != 0).nonzero().flatten().tolist()[:8])
             del pipe
+
+
+@pytest.mark.parametrize("kind", ["ssg", "msg"])
+def test_gradient_with_respect_to_xyz_survives_a_geometry_computed_ahead(cuda, kind):
+    """the geometry is computed from xyz.detach(); with `geometry=` the modules used its detached
+    new_xyz in `group_point(xyz, idx) - new_xyz`, silently dropping the centroid term of d / d xyz that the plain forward
+    keeps through the differentiable gather_point (the reference registers a gradient for GatherPoint, tf_sampling.py:43-47).
+    With the sample indices kept in SAGeometry the centroids are re-gathered: same outputs, same gradient as the plain forward."""
+    from pointnet2_amd.geometry import GeometryAhead
+    from pointnet2_amd.pointnet_util import PointnetSAModule, PointnetSAModuleMSG
+    torch.manual_seed(2)
+    if kind == "ssg":
+        mod = PointnetSAModule(0, 64, 0.3, 16, [16, 16, 32], bn=False).to(cuda).train()
+    else:
+        mod = PointnetSAModuleMSG(0, 64, [0.2, 0.4], [16, 32], [[16, 16, 32], [16, 16, 32]], bn=False).to(cuda).train()
+    xyz0 = _dev(S.sphere_clouds(4, 512, 5), cuda)
+    w = None
+    grads, outs = [], []
+    for ahead in (False, True):
+        xyz = xyz0.clone().requires_grad_(True)
+        g = GeometryAhead([mod]).submit(xyz).sa[0] if ahead else None
+        res = mod(xyz, None, g)
+        out = res[1]
+        assert mod.last_path == "unfused"                    # an xyz that needs a gradient takes the differentiable operators
+        if w is None:
+            w = torch.randn_like(out)
+        (gx,) = torch.autograd.grad((out * w).sum(), xyz)
+        grads.append(gx)
+        outs.append(out.detach())
+    torch.cuda.synchronize()
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-6 * float(outs[0].abs().max())
+    scale = float(grads[0].abs().max())
+    assert scale > 0 and float((grads[0] - grads[1]).abs().max()) <= 1e-5 * scale
+    # the dropped term was not small: the gradient WITHOUT it differs visibly (what the bug returned)
+    xyz = xyz0.clone().requires_grad_(True)
+    gg = GeometryAhead([mod]).submit(xyz).sa[0]
+    gg.fps_idx = None
+    with pytest.raises(ValueError):
+        mod(xyz, None, gg)

@@ -101,6 +101,12 @@ def test_fps_all_geometries_agree(cuda, oracle):
 # indices as the oracle on every kind of cloud -- the ones it prunes well (sphere, cube), the ones it cannot prune
 # (identical points, 87 % of the cloud on one spot), exact ties everywhere (lattice, duplicates), clouds that leave padding
 # slots (n not a multiple of 512, n just above a tier boundary), m > n, and both group sizes of both slot counts.
+def _islands(c, shift):
+    c = np.array(c, dtype=np.float32)
+    c[:, c.shape[1] // 2:, 0] += np.float32(shift)           # the second half of every cloud: an island ~shift away along x
+    return c
+
+
 PRUNED_CASES = [
     ("sphere4096", lambda: S.sphere_clouds(4, 4096, 200), 1024, 0),
     ("cube4096", lambda: S.uniform_clouds(3, 4096, 201), 512, 0),
@@ -122,7 +128,13 @@ PRUNED_CASES = [
     ("line4096", lambda: S.sphere_clouds(2, 4096, 217) * np.array([1.0, 0.0, 0.0], np.float32), 300, 0),
     ("far_offset", lambda: S.sphere_clouds(2, 4096, 218) * np.float32(1e-3) + np.float32(100.0), 400, 0),  # coarse fp32 grid
     ("tiny_scale", lambda: S.sphere_clouds(2, 4096, 219) * np.float32(1e-18), 300, 0),                      # squares underflow
+    # groups farther than ~1e19 from point 0 are skipped in round 1 already (their squared distance overflows to
+    # inf >= v*); the reference leaves such points at td = 1e38 and samples them next (tf_sampling_g.cu:118,144) -- the cached
+    # group keys must start from (1e38 : rank), not from 0
+    ("islands_1e19", lambda: _islands(S.sphere_clouds(2, 4096, 220), 3e19), 300, 0),
+    ("islands_1e19_8192", lambda: _islands(S.uniform_clouds(2, 8192, 221), 2.5e19), 200, 2),
 ]
+
 
 
 @pytest.mark.parametrize("name,make,m,gs", PRUNED_CASES, ids=[c[0] for c in PRUNED_CASES])
