@@ -39,12 +39,18 @@ Extra objects on the JSON line:
                   distribution).
   vector_rooflines -- query_ball_point (metric shape) and three_nn (sem_seg FP4 shape): brute-force pair tests x 8 flops /
                   time against the fp32 vector peak (157.3 TFLOP/s).
+  bandwidth_rooflines -- the kernels of the path that ARE HBM-bound, at the shapes where the reference's models move data:
+                  group_point c=128 (cls_ssg L2) and c=320 (cls_msg L2, 640 MB out), three_interpolate c=128 (sem_seg FP4), and the
+                  gradient of each: algorithmic bytes / HIP-event time / 8 TB/s (+ the PMC bytes of profiles/hbm_traffic.json).
   sustained    -- the same step repeated for >= 1 s (not `value`; lets an external sampler see the GPU).
   allreduce    -- N > 1: training's only exchange, the gradient mean over ranks (train_multi_gpu.py:91-126)
                   as one flat-bucket all-reduce (sharding.allreduce_mean_) at the two model sizes.
   cpu_baseline -- the CPU oracle (oracle/pn2_oracle.c, a serial C restatement of the reference
                   algorithms) on whole batches of the same workload, ONE thread (the reference's CPU
-                  loops are serial); cpu_baseline_all_cores -- the same code, one cloud per task on a
+                  loops are serial); cpu_baseline_reference -- the reference's OWN query_ball_point_cpu + group_point_cpu
+                  (tf_ops/grouping/test/query_ball_point.cpp:19-66, compiled where it lies into oracle/_ref/) on the ball-query +
+                  group part of the same batches, kind "reference" (the reference has no CPU farthest point sampling);
+                  cpu_baseline_all_cores -- the same code, one cloud per task on a
                   thread pool over every logical core (SURVEY 8d "for fairness").
 """
 import argparse
@@ -276,6 +282,65 @@ def vector_rooflines(stage, t_ball):
     return out
 
 
+def bandwidth_rooflines(dev):
+    """EXTRA object: the HBM-bound kernels of the path at the shapes where the reference's models
+    actually move data (SURVEY 8a per-config table), driver-timed: algorithmic bytes (SURVEY 8d's formulas: every input read
+    once, every output written once) / HIP-event time (median of 10) / 8 TB/s. Real geometry (FPS + ball query / three_nn of
+    the level), random features. `traffic` = HBM bytes of the same launch from the last rocprofv3 --pmc pass
+    (profiles/hbm_traffic.json, key = the row's name) or None."""
+    import pointnet2_amd as P
+    rows = {}
+    tj = {}
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    except Exception:
+        pass
+
+    def row(name, shape, nbytes, fn, kernel):
+        t = event_time(fn)
+        rows[name] = {"shape": shape, "kernel": kernel, "us": t * 1e6, "algorithmic_bytes": nbytes, "achieved": nbytes / t / 1e9,
+                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS, "traffic": tj.get(name)}
+
+    def group_level(name, b, n, m, r, ns, c, seed):
+        xyz = torch.from_numpy(synthetic.sphere_clouds(b, n, seed)).to(dev)
+        _, new_xyz = P.farthest_point_sample_gather(m, xyz)
+        idx, _ = P.query_ball_point(r, ns, xyz, new_xyz)
+        pts = torch.randn(b, n, c, device=dev)
+        out = torch.empty((b, m, ns, c), device=dev)
+        nbytes = b * (m * ns * 4 + n * c * 4 + m * ns * c * 4)
+        shape = "b=%d n=%d m=%d nsample=%d c=%d (%.0f MB out)" % (b, n, m, ns, c, b * m * ns * c * 4 / 1e6)
+        row(name, shape, nbytes, lambda: P.group_point(pts, idx, out=out), "group_rows_v4_kernel (pn2_group_point)")
+        go = torch.randn(b, m, ns, c, device=dev)
+        pts.requires_grad_(True)
+        y = P.group_point(pts, idx)
+        row(name + "_grad", shape, nbytes, lambda: torch.autograd.grad(y, pts, go, retain_graph=True),
+            "index inversion + segmented row sums (pn2_group_point_grad_seg)")
+
+    group_level("group_point_c128_cls_ssg_L2", 32, 512, 128, 0.4, 64, 128, 31)      # pointnet2_cls_ssg.py:33
+    group_level("group_point_c320_cls_msg_L2", 32, 512, 128, 0.8, 128, 320, 32)     # pointnet2_cls_msg.py:29, largest radius
+    # three_interpolate at sem_seg's last feature-propagation level (pointnet2_sem_seg.py:37)
+    b, n, m, c = 8, 8192, 1024, 128
+    unknown = torch.from_numpy(synthetic.uniform_clouds(b, n, 91)).to(dev)
+    known = unknown[:, :m].contiguous()
+    dist, idx = P.three_nn(unknown, known)
+    w = 1.0 / torch.clamp(dist, min=1e-10)
+    w = (w / w.sum(dim=2, keepdim=True)).contiguous()
+    pts = torch.randn(b, m, c, device=dev)
+    nbytes = b * (m * c * 4 + n * 24 + n * c * 4)
+    shape = "b=%d n=%d unknown, m=%d known, c=%d (%.0f MB out)" % (b, n, m, c, b * n * c * 4 / 1e6)
+    out = torch.empty((b, n, c), device=dev)
+    row("three_interpolate_c128_sem_seg_FP4", shape, nbytes, lambda: P.three_interpolate(pts, idx, w, out=out),
+        "three_interpolate rows kernel (pn2_three_interpolate)")
+    pts.requires_grad_(True)
+    y = P.three_interpolate(pts, idx, w)
+    go = torch.randn(b, n, c, device=dev)
+    row("three_interpolate_c128_sem_seg_FP4_grad", shape, nbytes, lambda: torch.autograd.grad(y, pts, go, retain_graph=True),
+        "index inversion + segmented weighted row sums (pn2_three_interpolate_grad_seg)")
+    rows["note"] = ("HBM-bound rows of the path (gather / scatter of feature rows); a launch below ~40 MB is bounded by its ramp "
+                    "(a 5 us kernel moves 40 MB at 8 TB/s), which is what three_interpolate at 39 MB shows")
+    return rows
+
+
 def concurrent_throughput(dev, rank, path, streams, steps):
     """EXTRA figure (not `value`): the same step on `streams` independent B=32 batches in flight on
     separate HIP streams. One FPS launch occupies 32 of the 256 CUs for its whole serial chain, so
@@ -342,6 +407,37 @@ def cpu_baseline(seed, budget_s=10.0):
             "sample": "%d whole B=32 batches of the bench workload (D1 clouds, N=4096->1024, r=0.2, nsample=32) "
                       "through oracle/pn2_oracle.c in %.1f s; host has %d logical cores, 1 used"
                       % (batches, dt, os.cpu_count() or 0)}
+
+
+def cpu_baseline_reference(seed, budget_s=5.0):
+    """The reference's OWN CPU functions -- query_ball_point_cpu + group_point_cpu of tf_ops/grouping/test/query_ball_point.cpp
+    (:19-47, :52-66), compiled where they lie into oracle/_ref/libref_grouping.so by oracle/Makefile -- on the ball-query +
+    group part of the bench workload (the query points come from the oracle's farthest point sampling, OUTSIDE the timed
+    region: the reference has no CPU FPS). One thread, like the reference's loops. None when the library did not travel."""
+    import oracle as O
+    if not O.ref_available("grouping"):
+        return None
+    xyz = synthetic.sphere_clouds(B, N, seed)
+    new_xyz = O.gather_point(xyz, O.farthest_point_sample(M, xyz))
+    t0 = O.now()
+    batches = 0
+    while True:
+        idx, _ = O.ref_query_ball_point(RADIUS, NS, xyz, new_xyz)
+        O.ref_group_point(xyz, idx)
+        batches += 1
+        dt = O.now() - t0
+        if dt >= budget_s:
+            break
+    # the port on the same part, for the ratio
+    t1 = O.now()
+    idx, _ = O.query_ball_point(RADIUS, NS, xyz, new_xyz)
+    O.group_point(xyz, idx)
+    t_port = O.now() - t1
+    return {"value": batches * B / dt, "unit": "clouds/s", "cores": 1, "kind": "reference",
+            "part": "query_ball_point + group_point only (no CPU farthest point sampling exists in the reference)",
+            "port_same_part_clouds_per_s": B / t_port,
+            "sample": "%d whole B=32 batches (D1 clouds, N=4096, m=1024, r=0.2, nsample=32) through the reference's query_ball_point_cpu + "
+                      "group_point_cpu (oracle/_ref/libref_grouping.so) in %.1f s, 1 of %d logical cores" % (batches, dt, os.cpu_count() or 0)}
 
 
 def cpu_baseline_all_cores(seed, budget_s=10.0):
@@ -490,8 +586,42 @@ def main():
     verified = None
     if not args.stub:
         v = stage.verify(args.path)
-        verified = dict(v, ok=bool(sharding.max_over_ranks(0.0 if v["ok"] else 1.0, dev) == 0.0))
+        verified = dict(v, ok=bool(sharding.max_over_ranks(0.0 if v["ok"] else 1.0, dev) == 0.0))   # ok = EVERY rank's outputs verified
     extras = not args.no_extras and not args.stub
+    # who took part: every rank reports (rank, seed of its clouds, verify ok); rank 0 asserts the census is 0 .. N-1 with
+    # N different seeds (weak scaling: every rank its own batch) and counts the ranks whose outputs verified
+    seed = 1000 + (rank if args.scaling == "weak" else 0)
+    census = sharding.gather_ints([rank, seed, -1 if verified is None else int(v["ok"])], dev)
+    if rank == 0:
+        assert sorted(c[0] for c in census) == list(range(world)), census
+        if args.scaling == "weak":
+            assert len({c[1] for c in census}) == world, "ranks share a seed: %r" % (census,)
+    # N > 1, weak run: the STRONG-scaling figure too, in the same invocation (one SCALE run captures both): ONE global B=32
+    # batch sliced 32/N per rank, same barriers, same max-over-ranks clock
+    strong = None
+    if world > 1 and args.scaling == "weak" and B % world == 0 and not args.no_extras:
+        lo, hi = sharding.shard_bounds(B, world, rank)
+        st2 = StubStage(hi - lo) if args.stub else Stage(dev, synthetic.sphere_clouds(B, N, 1000)[lo:hi])
+        step2 = st2.step(args.path)
+        for _ in range(max(args.warmup, 1)):
+            step2()
+        sync()
+        dist.barrier()
+        sync()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            step2()
+        sync()
+        dist.barrier()
+        sync()
+        e2 = sharding.max_over_ranks(time.perf_counter() - t2, dev)
+        ok2 = True if args.stub else bool(st2.verify(args.path)["ok"])
+        ok2 = sharding.max_over_ranks(0.0 if ok2 else 1.0, dev) == 0.0
+        strong = {"scaling": "strong", "value": B * args.steps / e2, "unit": "clouds/s", "ms_per_step": e2 / args.steps * 1e3,
+                  "clouds_per_gpu": hi - lo, "verified": ok2,
+                  "note": "the same K steps on ONE global B=32 batch sliced like tf.slice in the reference's tower loop "
+                          "(train_multi_gpu.py:185-188); a rank with 32/N clouds still runs the whole 1023-round chain, so this "
+                          "figure is expected flat in N (SURVEY 8e)"}
     allred = allreduce_leg(dev, dist) if dist is not None else None
     conc = None
     if extras and args.streams > 1 and world == 1:
@@ -535,13 +665,20 @@ def main():
                        "sharding": "%d independent batch shard(s), no data-path collective" % world,
                        "fps_variant": args.fps_variant, "consumers_per_cloud": args.consumers or "library default",
                        "requested_gpus": args.gpus},
-            "roofline": {"bound": "hbm", "kernel": TIMED_KERNEL[args.path], "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "latency (FPS chain: 1023 dependent rounds per cloud); fraction quoted against hbm", "bound_class": "hbm",
+                         "kernel": TIMED_KERNEL[args.path], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": STAGE_BYTES * b_local,
                          "note": "the kernel(s) of the timed region: SURVEY 8(d) bytes per cloud x clouds per launch / "
                                  "HIP-event time per step on the launch stream. Bound by the FPS chain (latency), "
                                  "not by HBM: see fps_latency_model"},
         }
+        line["ranks_seen"] = sorted(c[0] for c in census)
+        line["ranks_verified"] = None if verified is None else sum(1 for c in census if c[2] == 1)
+        line["rank_seeds"] = [c[1] for c in sorted(census)]
+        line["collective_library"] = sharding.collective_library_version(args.stub)
+        if strong is not None:
+            line["strong"] = strong
         if verified is not None:
             line["verify"] = dict(verified, note="after the timed region: fps_idx / new_xyz / idx / pts_cnt / grouped_xyz of the last "
                                   "timed step compared on the device with the four reference-shaped operators on the same batch "
@@ -596,6 +733,10 @@ def main():
                     line["vector_rooflines"] = vector_rooflines(stage, kt["query_ball_point"])
                 except Exception as e:
                     line["vector_rooflines"] = {"error": repr(e)}
+                try:
+                    line["bandwidth_rooflines"] = bandwidth_rooflines(dev)
+                except Exception as e:
+                    line["bandwidth_rooflines"] = {"error": repr(e)}
                 # >= 5 s of back-to-back steps (not `value`), BEFORE the CPU-baseline legs: long enough for an external
                 # utilisation sampler to see the GPU busy
                 n_sus = max(args.steps, int(5.0 / max(launch_s, 1e-6)))
@@ -609,6 +750,12 @@ def main():
                 line["concurrent"] = conc
             if world == 1 and not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(1000, args.cpu_seconds)
+                try:
+                    ref = cpu_baseline_reference(1000, min(5.0, args.cpu_seconds))
+                    if ref is not None:
+                        line["cpu_baseline_reference"] = ref
+                except Exception as e:
+                    line["cpu_baseline_reference"] = {"error": repr(e)}
                 try:
                     line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(1000, args.cpu_seconds)
                 except Exception as e:

@@ -45,6 +45,28 @@ def max_over_ranks(seconds, device=None):
     return float(t.item())
 
 
+def gather_ints(values, device=None):
+    """Every rank's list of ints, on every rank: [[rank 0's values], [rank 1's values], ...] (one all_gather; the census
+    bench.py prints as ranks_seen / rank_seeds / ranks_verified)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [list(int(v) for v in values)]
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[int(x) for x in o.tolist()] for o in out]
+
+
+def collective_library_version(stub=False):
+    """'RCCL x.y.z' (torch's nccl binding IS RCCL on ROCm) / 'gloo' for the CPU test mode / None without one."""
+    if stub:
+        return "gloo (CPU test mode)"
+    try:
+        v = torch.cuda.nccl.version()
+        return "RCCL %s" % ".".join(str(x) for x in v) if isinstance(v, tuple) else "RCCL %s" % (v,)
+    except Exception:                                  # noqa: BLE001 -- a build without the binding
+        return None
+
+
 class GradBucket:
     """ONE persistent flat fp32 buffer that every parameter's .grad is a view of: autograd accumulates straight into
     it, the gradient mean over ranks is a single in-place all-reduce of the buffer (RCCL over xGMI; nothing is

@@ -131,9 +131,29 @@ def test_bench_spawns_its_own_ranks(scaling):
     assert ar["sem_seg"]["mean_ok"] and ar["cls_ssg"]["mean_ok"] and ar["sem_seg"]["us"] > 0
 
 
+@pytest.mark.timeout(600)
+def test_bench_with_eight_ranks():
+    """What the driver's 8-GPU run does, as far as a machine without GPUs can go: `bench.py --gpus 8`
+    starts eight ranks itself, every rank takes part (ranks_seen), the weak run gives every rank its own seed, and the same
+    invocation carries the strong-scaling figure (one global batch, 4 clouds per rank). Stub step, gloo."""
+    line = _run_bench(["--gpus", "8"])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak"
+    assert line["ranks_seen"] == list(range(8)) and line["rank_seeds"] == [1000 + r for r in range(8)]
+    assert line["collective_library"].startswith("gloo")
+    assert abs(line["value"] - 8 * 32 * 5 / (line["ms_per_step"] * 5e-3)) < 1e-6 * line["value"]
+    st = line["strong"]
+    assert st["scaling"] == "strong" and st["clouds_per_gpu"] == 4 and st["verified"] is True
+    assert abs(st["value"] - 32 * 5 / (st["ms_per_step"] * 5e-3)) < 1e-6 * st["value"]
+    assert line["allreduce"]["sem_seg"]["mean_ok"]
+    strong = _run_bench(["--gpus", "8", "--scaling", "strong"])
+    assert strong["n_gpus"] == 8 and strong["scaling"] == "strong" and strong["ranks_seen"] == list(range(8))
+    assert strong["rank_seeds"] == [1000] * 8 and "strong" not in strong
+
+
 def test_bench_single_rank_stub_line():
     line = _run_bench(["--gpus", "1"])
     assert line["n_gpus"] == 1 and "allreduce" not in line and line["unit"] == "clouds/s"
+    assert line["ranks_seen"] == [0] and line["ranks_verified"] is None and "strong" not in line
     assert "traffic_source" in line["roofline"]
     for key in ("metric", "value", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in line
