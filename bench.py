@@ -282,13 +282,34 @@ def vector_rooflines(stage, t_ball):
     return out
 
 
+def event_time_batched(fn, inner=20, reps=5):
+    """Average duration of one call with `inner` calls queued back to back between two HIP events (the GPU never waits for
+    the host: what a kernel costs inside a stream of work), median over `reps`."""
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(inner):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / inner)
+    return float(np.median(ts)) * 1e-3
+
+
 def bandwidth_rooflines(dev):
     """EXTRA object: the HBM-bound kernels of the path at the shapes where the reference's models
-    actually move data (SURVEY 8a per-config table), driver-timed: algorithmic bytes (SURVEY 8d's formulas: every input read
-    once, every output written once) / HIP-event time (median of 10) / 8 TB/s. Real geometry (FPS + ball query / three_nn of
-    the level), random features. `traffic` = HBM bytes of the same launch from the last rocprofv3 --pmc pass
-    (profiles/hbm_traffic.json, key = the row's name) or None."""
+    actually move data (SURVEY 8a per-config table), driver-timed through the C ABI with preallocated buffers: algorithmic
+    bytes (SURVEY 8d's formulas: every input read once, every output written once) / time / 8 TB/s, time = 20 launches queued
+    back to back between two HIP events (median of 5). Real geometry (FPS + ball query / three_nn of the level), random
+    features. `traffic` = HBM bytes of the same launch from the last rocprofv3 --pmc pass (profiles/hbm_traffic.json, key =
+    the row's name) or None."""
     import pointnet2_amd as P
+    from pointnet2_amd import _C
+    lib = _C.lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
     rows = {}
     tj = {}
     try:
@@ -297,9 +318,12 @@ def bandwidth_rooflines(dev):
         pass
 
     def row(name, shape, nbytes, fn, kernel):
-        t = event_time(fn)
+        t = event_time_batched(fn)
         rows[name] = {"shape": shape, "kernel": kernel, "us": t * 1e6, "algorithmic_bytes": nbytes, "achieved": nbytes / t / 1e9,
                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS, "traffic": tj.get(name)}
+
+    def seg_ws(b, rows_, entries):
+        return torch.empty(((lib.pn2_seg_grad_ws_bytes(b, rows_, entries) + 7) // 8,), dtype=torch.int64, device=dev)
 
     def group_level(name, b, n, m, r, ns, c, seed):
         xyz = torch.from_numpy(synthetic.sphere_clouds(b, n, seed)).to(dev)
@@ -309,12 +333,13 @@ def bandwidth_rooflines(dev):
         out = torch.empty((b, m, ns, c), device=dev)
         nbytes = b * (m * ns * 4 + n * c * 4 + m * ns * c * 4)
         shape = "b=%d n=%d m=%d nsample=%d c=%d (%.0f MB out)" % (b, n, m, ns, c, b * m * ns * c * 4 / 1e6)
-        row(name, shape, nbytes, lambda: P.group_point(pts, idx, out=out), "group_rows_v4_kernel (pn2_group_point)")
-        go = torch.randn(b, m, ns, c, device=dev)
-        pts.requires_grad_(True)
-        y = P.group_point(pts, idx)
-        row(name + "_grad", shape, nbytes, lambda: torch.autograd.grad(y, pts, go, retain_graph=True),
-            "index inversion + segmented row sums (pn2_group_point_grad_seg)")
+        row(name, shape, nbytes, lambda: _C.check(lib.pn2_group_point(b, n, c, m, ns, pts.data_ptr(), idx.data_ptr(), out.data_ptr(), st), "group_point"),
+            "group_rows_v4_kernel (pn2_group_point)")
+        gp = torch.empty((b, n, c), device=dev)
+        ws = seg_ws(b, n, m * ns)
+        row(name + "_grad", shape, nbytes,
+            lambda: _C.check(lib.pn2_group_point_grad_seg(b, n, c, m, ns, out.data_ptr(), idx.data_ptr(), gp.data_ptr(), ws.data_ptr(), 0, st), "group_point_grad"),
+            "index inversion + segmented row sums (pn2_group_point_grad_seg: what group_point's backward launches)")
 
     group_level("group_point_c128_cls_ssg_L2", 32, 512, 128, 0.4, 64, 128, 31)      # pointnet2_cls_ssg.py:33
     group_level("group_point_c320_cls_msg_L2", 32, 512, 128, 0.8, 128, 320, 32)     # pointnet2_cls_msg.py:29, largest radius
@@ -329,16 +354,48 @@ def bandwidth_rooflines(dev):
     nbytes = b * (m * c * 4 + n * 24 + n * c * 4)
     shape = "b=%d n=%d unknown, m=%d known, c=%d (%.0f MB out)" % (b, n, m, c, b * n * c * 4 / 1e6)
     out = torch.empty((b, n, c), device=dev)
-    row("three_interpolate_c128_sem_seg_FP4", shape, nbytes, lambda: P.three_interpolate(pts, idx, w, out=out),
+    row("three_interpolate_c128_sem_seg_FP4", shape, nbytes,
+        lambda: _C.check(lib.pn2_three_interpolate(b, m, c, n, pts.data_ptr(), idx.data_ptr(), w.data_ptr(), out.data_ptr(), st), "three_interpolate"),
         "three_interpolate rows kernel (pn2_three_interpolate)")
-    pts.requires_grad_(True)
-    y = P.three_interpolate(pts, idx, w)
-    go = torch.randn(b, n, c, device=dev)
-    row("three_interpolate_c128_sem_seg_FP4_grad", shape, nbytes, lambda: torch.autograd.grad(y, pts, go, retain_graph=True),
-        "index inversion + segmented weighted row sums (pn2_three_interpolate_grad_seg)")
-    rows["note"] = ("HBM-bound rows of the path (gather / scatter of feature rows); a launch below ~40 MB is bounded by its ramp "
-                    "(a 5 us kernel moves 40 MB at 8 TB/s), which is what three_interpolate at 39 MB shows")
+    gp = torch.empty((b, m, c), device=dev)
+    ws = seg_ws(b, m, 3 * n)
+    row("three_interpolate_c128_sem_seg_FP4_grad", shape, nbytes,
+        lambda: _C.check(lib.pn2_three_interpolate_grad_seg(b, n, c, m, out.data_ptr(), idx.data_ptr(), w.data_ptr(), gp.data_ptr(), ws.data_ptr(), 0, st),
+                         "three_interpolate_grad"),
+        "index inversion + segmented weighted row sums (pn2_three_interpolate_grad_seg: what three_interpolate's backward launches)")
+    rows["note"] = ("HBM-bound rows of the path (gather / scatter of feature rows), C ABI, buffers preallocated, launches queued back "
+                    "to back. A launch below ~40 MB is bounded by its ramp (a 5 us kernel moves 40 MB at 8 TB/s): three_interpolate "
+                    "at 39 MB")
     return rows
+
+
+def batched_throughput(dev, rank):
+    """EXTRA figure: throughput that does not depend on the runtime's hardware queues -- MORE CLOUDS
+    PER LAUNCH. One overlapped launch over b = 64 / 128 / 256 clouds of the metric shape on ONE stream (the reference's
+    kernels stride over the batch the same way, tf_sampling_g.cu:113). Every cloud's outputs are verified against the
+    operator path, and the first 32 clouds against a b = 32 launch of the same clouds (bit-identical per cloud)."""
+    out = {"unit": "clouds/s", "note": "one launch per step, launches queued back to back on one stream; b producer workgroups (one CU each) + b "
+                                       "persistent consumers: up to b = 128 every consumer runs beside its producer, beyond that the "
+                                       "remaining consumers start when chains end"}
+    base = None
+    clouds = synthetic.sphere_clouds(256, N, 3000 + rank)
+    for b in (32, 64, 128, 256):
+        try:
+            stg = Stage(dev, np.ascontiguousarray(clouds[:b]))
+            t = event_time_batched(stg.overlap_, inner=10, reps=3)
+            stg.overlap_()
+            v = stg.verify("overlap")
+            same = None
+            if b == 32:
+                base = [t_.clone() for t_ in (stg.fps, stg.idx)]
+            elif base is not None:
+                stg.overlap_()
+                torch.cuda.synchronize()
+                same = bool(torch.equal(stg.fps[:32], base[0]) and torch.equal(stg.idx[:32], base[1]))
+            out["b%d" % b] = {"value": b / t, "us_per_launch": t * 1e6, "verified": v["ok"], "first_32_clouds_identical_to_b32": same}
+        except Exception as e:                                   # e.g. PN2_E_TOO_LARGE on a device with fewer CUs
+            out["b%d" % b] = {"error": repr(e)}
+    return out
 
 
 def concurrent_throughput(dev, rank, path, streams, steps):
@@ -422,7 +479,7 @@ def cpu_baseline_reference(seed, budget_s=5.0):
     t0 = O.now()
     batches = 0
     while True:
-        idx, _ = O.ref_query_ball_point(RADIUS, NS, xyz, new_xyz)
+        idx = O.ref_query_ball_point(RADIUS, NS, xyz, new_xyz)
         O.ref_group_point(xyz, idx)
         batches += 1
         dt = O.now() - t0
@@ -748,6 +805,11 @@ def main():
                 line["sustained"] = {"steps": n_sus, "seconds": dt, "value": b_local * n_sus / dt, "unit": "clouds/s"}
             if conc is not None:
                 line["concurrent"] = conc
+            if world == 1:
+                try:
+                    line["batched"] = batched_throughput(dev, rank)
+                except Exception as e:
+                    line["batched"] = {"error": repr(e)}
             if world == 1 and not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(1000, args.cpu_seconds)
                 try:

@@ -257,6 +257,11 @@ int pn2_query_ball_group_xyz_msg(int b, int n, int m, int nscales, const float *
                                  const float *xyz1, const float *xyz2, int subtract_centroid, int *const *idx,
                                  int *const *pts_cnt, float *const *grouped_xyz, void *stream);
 
+/* pn2_three_nn with the kernel chosen by the caller (results never depend on it; tests force each, scripts time them):
+ * 0 = the library's choice, 1 = the sweep of every known point (round 1), 2 = the cell list (round 6: the known points binned
+ * once per workgroup, 3 x 3 x 3 cells visited per unknown point, an exactness test on the third-best distance and a sweep for
+ * the points that fail it; PN2_E_ARG below 64 or above 8192 known points). */
+int pn2_three_nn_ex(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx, int variant, void *stream);
 /* pn2_group_point / pn2_three_interpolate with the kernel choice per call (parity tests force every kernel,
  * scripts/bw_probe.py times them). group: 0 automatic, 1 flat first-generation kernels, 2 row kernels,
  * 3 row kernels with non-temporal stores; three_interpolate: 0 automatic, 1 flat, 2 row kernel. */
@@ -292,8 +297,8 @@ int pn2_farthest_point_sample_variant(int variant, int b, int n, int m, const fl
  *   grouped_xyz (b,m,nsample,3) f32 (minus the centroid when subtract_centroid != 0).
  * ws: device scratch of pn2_sample_and_group_ws_bytes(b,m) bytes (zeroed here on `stream`): the sample
  * granules and a status word.
- * Returns PN2_E_TOO_LARGE for shapes outside the overlapped launch's envelope (b > 128, n > 8192,
- * n < 64, nsample > 256) and when the device cannot hold all b producer workgroups plus a consumer at once
+ * Returns PN2_E_TOO_LARGE for shapes outside the overlapped launch's envelope (b > 256, n > 8192,
+ * n < 64, nsample > 256) and when the device cannot hold all b producer workgroups at once
  * (occupancy query at launch): use pn2_farthest_point_sample_gather + pn2_query_ball_group_xyz then.
  * Clouds too large for a cell list beside their sorted copy in LDS (n > ~7000) are served by exactly those two launches from
  * inside this call (their consumers would have to sweep the whole cloud per query and no longer hide under the chain:

@@ -44,6 +44,7 @@ _SIGNATURES = {
     "pn2_three_interpolate_ex": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "pn2_group_point_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pn2_three_nn": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pn2_three_nn_ex": [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "pn2_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pn2_three_interpolate_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pn2_det_grad_ws_bytes": [_i, _i, _i],

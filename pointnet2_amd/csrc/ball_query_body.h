@@ -423,8 +423,11 @@ __device__ __forceinline__ bool bq_build_grid(int n, float reach, const float *_
     if (!(ly <= hy)) ly = hy = 0.0f;
     if (!(lz <= hz)) lz = hz = 0.0f;
     // cell edge: at least the reach (so a ball spans <= 3 cells per axis), at least extent/kBqGridMax
-    const float edge_min = reach * 1.0001f;
     const float ex = hx - lx, ey = hy - ly, ez = hz - lz;
+    // reach < 0 (three_nn's cell list, interpolate.hip): no radius is given -- the edge is |reach| times the mean spacing of
+    // the points in their bounding box, cbrt(volume / n); a flat or degenerate cloud (volume 0) gets extent / kBqGridMax
+    if (reach < 0.0f) reach = -reach * cbrtf(fmaxf(ex * ey * ez, 0.0f) / (float)n);
+    const float edge_min = reach * 1.0001f;
     const float cx = fmaxf(edge_min, ex * (1.0f / kBqGridMax));
     const float cy = fmaxf(edge_min, ey * (1.0f / kBqGridMax));
     const float cz = fmaxf(edge_min, ez * (1.0f / kBqGridMax));

@@ -18,7 +18,7 @@
 // strict-< scan implies -- so visiting order is irrelevant and there are no compares or selects.
 // The first version used one lane per point: at the largest FP layer (8 x 8192 unknown points) that
 // is one wave per SIMD, a pure latency chain (115 us); the quad split quadruples the waves in flight.
-#include "pn2_device.h"
+#include "ball_query_body.h"
 
 #include <limits.h>
 #include <math.h>
@@ -121,6 +121,179 @@ __global__ __launch_bounds__(kNnThreads) void three_nn_kernel(int n, int m, cons
         od[2] = __int_as_float(__double2hiint(b3));
         oi[0] = __double2loint(b1); oi[1] = __double2loint(b2); oi[2] = __double2loint(b3);
     }
+}
+
+
+// ---- three_nn with a cell list (round 6) ---------------------------------------------------------
+// The sweep above tests every unknown point against every known point: 67 M pair tests at sem_seg's last feature-propagation
+// level (8 x 8192 unknown, 1024 known), 28 us. But the three nearest known points of an unknown point lie within about one
+// spacing of the known set. Here a workgroup bins its cloud's known points ONCE into a grid (the ball query's counting sort,
+// ball_query_body.h: cell edge = kNnCellFactor x the mean spacing cbrt(box volume / m)), every unknown point -- four lanes,
+// as above -- visits the 3 x 3 runs of three x-adjacent cells around its own cell (35-50 candidates instead of 1024), and
+// keeps the same keyed top-3 network, so the visiting order is irrelevant.
+// EXACT: a known point OUTSIDE the visited block differs from the unknown point's cell by two or more cells along some axis,
+// so it is farther away than the distance `margin` from the unknown point to the nearest face of the block that has cells
+// behind it. If the third-best squared distance found is below margin'^2 (margin' = margin less 0.1 % and a coordinate-scale
+// epsilon: both evaluations' rounding errors are six orders of magnitude smaller), no outside point can enter the triple --
+// the result is the sweep's, bit for bit. Unknown points that fail the test (fewer than three candidates, a sparse
+// neighbourhood, a position outside the known points' box) are collected and answered by a SWEEP of all known points, one
+// wave per point; a workgroup whose cloud cannot be binned (fewer than 64 cells, a crowded cell) sweeps all of its points.
+constexpr float kNnCellFactor = 1.3f;       // simulation (profiles/r06/three_nn_cells.txt): 1.2 -> 2 % of Poisson-sampled points fall back, 35 candidates; 1.6 -> 0 %, 77
+constexpr int kNnCellsThreads = 512;
+
+// the partner's key through a DPP move whose unwritten lanes receive the EMPTY key (+inf : 0) -- never 0.0, which would win
+// every minimum -- so that a lane without a partner merges nothing
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double nn_dpp_or_empty(double v)
+{
+    const int hi = __builtin_amdgcn_update_dpp(0x7F800000, __double2hiint(v), CTRL, ROWS, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ void nn_merge_dpp(double &b1, double &b2, double &b3)
+{
+    const double o1 = nn_dpp_or_empty<CTRL, ROWS>(b1), o2 = nn_dpp_or_empty<CTRL, ROWS>(b2), o3 = nn_dpp_or_empty<CTRL, ROWS>(b3);
+    nn_insert(o1, b1, b2, b3);
+    nn_insert(o2, b1, b2, b3);
+    nn_insert(o3, b1, b2, b3);
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 4) void three_nn_cells_kernel(int n, int m, int rows_per_part, int parts, int b, float factor,
+                                                            const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+                                                            float *__restrict__ dist, int *__restrict__ idx)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *sorted = reinterpret_cast<float4 *>(smem);                                  // [m] known points in cell order, .w = index
+    int *tab = reinterpret_cast<int *>(smem + sizeof(float4) * (size_t)((m + 3) & ~3)); // tab[c] = start of cell c, tab[c + 1] = its end
+    float *misc = reinterpret_cast<float *>(tab + kBqTabInts);
+    int *fail = reinterpret_cast<int *>(reinterpret_cast<char *>(misc) + kBqMiscBytes); // [0] = count, [1 ..] = rows to sweep
+    int cloud, part;
+    decode_cloud_block(blockIdx.x, parts, b, cloud, part);
+    const int rb = part * rows_per_part, re = min(rb + rows_per_part, n);
+    const float *__restrict__ known = xyz2 + (size_t)cloud * m * 3;
+    const float *__restrict__ unk = xyz1 + (size_t)cloud * n * 3;
+    float *__restrict__ od = dist + (size_t)cloud * n * 3;
+    int *__restrict__ oi = idx + (size_t)cloud * n * 3;
+    const int t = threadIdx.x, lane = t & 63, sub = t & 3;
+    const double empty = __hiloint2double(0x7F800000, 0);  // (+inf : 0) = the reference's (float)1e40, index 0 (:67)
+
+    if (t == 0) { tab[0] = 0; fail[0] = 0; }
+    BqGrid g;
+    const bool binned = bq_build_grid<NT>(m, -factor, known, sorted, tab + 1, misc, g);   // block-uniform; ends with a barrier when true
+    if (!binned) {
+        __syncthreads();
+        for (int k = t; k < m; k += NT) {
+            const float *p = known + (size_t)k * 3;
+            sorted[k] = make_float4(p[0], p[1], p[2], __int_as_float(k));
+        }
+        for (int r = rb + t; r < re; r += NT) fail[1 + (r - rb)] = r;
+        if (t == 0) fail[0] = re - rb;
+    } else {
+        const float ex = 1.0f / g.ix, ey = 1.0f / g.iy, ez = 1.0f / g.iz;               // cell edges
+        const float scale = fmaxf(fmaxf(fabsf(g.ox) + ex * g.gx, fabsf(g.oy) + ey * g.gy), fabsf(g.oz) + ez * g.gz);
+        for (int r0 = rb; r0 < re; r0 += NT / 4) {
+            const int j = r0 + (t >> 2);
+            const bool live = j < re;
+            const float *u = unk + (size_t)(live ? j : rb) * 3;
+            const float ux = u[0], uy = u[1], uz = u[2];               // (requested before the binning instead: no gain, and spills at 512 threads)
+            const int cx = bq_cell(ux, g.ox, g.ix, g.gx), cy = bq_cell(uy, g.oy, g.iy, g.gy), cz = bq_cell(uz, g.oz, g.iz, g.gz);
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.gx - 1);
+            int rs[9], rl[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int y = cy + (q % 3) - 1, z = cz + (q / 3) - 1;
+                const bool ok = y >= 0 && y < g.gy && z >= 0 && z < g.gz;
+                const int row = ok ? (z * g.gy + y) * g.gx : 0;
+                const int s0 = tab[row + x0], e0 = tab[row + x1 + 1];
+                rs[q] = s0; rl[q] = ok ? e0 : s0;
+            }
+            double b1 = empty, b2 = empty, b3 = empty;
+            // A run holds 4-9 candidates, i.e. one or two per lane of the quad: the first TWO candidates of all nine runs are
+            // requested at once (eighteen LDS reads in flight, one latency) and inserted without a branch -- a lane whose run
+            // is shorter inserts the empty key, which the network ignores; only runs longer than eight take the loop behind.
+            // (Run by run with a loop each, every run paid its own LDS latency and loop overhead: 4 us per 128 unknown points
+            // against 2 now, scripts/three_nn_probe.py.)
+            float4 pa[9], pb[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int ka = rs[q] + sub, kb = ka + 4;
+                pa[q] = sorted[ka < rl[q] ? ka : 0];
+                pb[q] = sorted[kb < rl[q] ? kb : 0];
+            }
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int ka = rs[q] + sub, kb = ka + 4;
+                const float da = sqdist_key(pa[q].x, pa[q].y, pa[q].z, ux, uy, uz);      // (x2-x1)..., x2 the known point (tf_interpolate.cpp:69-73)
+                const float db = sqdist_key(pb[q].x, pb[q].y, pb[q].z, ux, uy, uz);
+                const double ea = __hiloint2double(__float_as_int(da), __float_as_int(pa[q].w));
+                const double eb = __hiloint2double(__float_as_int(db), __float_as_int(pb[q].w));
+                nn_insert(ka < rl[q] ? ea : empty, b1, b2, b3);
+                nn_insert(kb < rl[q] ? eb : empty, b1, b2, b3);
+            }
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+                for (int k = rs[q] + sub + 8; k < rl[q]; k += 4) {
+                    const float4 p = sorted[k];
+                    const float d = sqdist_key(p.x, p.y, p.z, ux, uy, uz);
+                    nn_insert(__hiloint2double(__float_as_int(d), __float_as_int(p.w)), b1, b2, b3);
+                }
+            nn_merge<0xB1>(b1, b2, b3);
+            nn_merge<0x4E>(b1, b2, b3);
+            // distance to the nearest face of the visited block that has cells behind it
+            float margin = INFINITY;
+            if (cx - 1 > 0) margin = fminf(margin, ux - (g.ox + (float)(cx - 1) * ex));
+            if (cx + 1 < g.gx - 1) margin = fminf(margin, (g.ox + (float)(cx + 2) * ex) - ux);
+            if (cy - 1 > 0) margin = fminf(margin, uy - (g.oy + (float)(cy - 1) * ey));
+            if (cy + 1 < g.gy - 1) margin = fminf(margin, (g.oy + (float)(cy + 2) * ey) - uy);
+            if (cz - 1 > 0) margin = fminf(margin, uz - (g.oz + (float)(cz - 1) * ez));
+            if (cz + 1 < g.gz - 1) margin = fminf(margin, (g.oz + (float)(cz + 2) * ez) - uz);
+            margin = margin * 0.999f - 1e-5f * scale;
+            const float d3 = __int_as_float(__double2hiint(b3));
+            const bool sure = margin > 0.0f && d3 < margin * margin;                      // NaN anywhere -> not sure -> swept
+            if (live && sub == 0) {
+                if (sure) {
+                    od[(size_t)j * 3 + 0] = __int_as_float(__double2hiint(b1)); od[(size_t)j * 3 + 1] = __int_as_float(__double2hiint(b2));
+                    od[(size_t)j * 3 + 2] = d3;
+                    oi[(size_t)j * 3 + 0] = __double2loint(b1); oi[(size_t)j * 3 + 1] = __double2loint(b2); oi[(size_t)j * 3 + 2] = __double2loint(b3);
+                } else {
+                    fail[1 + atomicAdd(&fail[0], 1)] = j;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // the rows the cell list could not answer: a sweep of every known point, one wave per row (lane l takes l, l + 64, ...)
+    const int nf = fail[0];
+    for (int f = t >> 6; f < nf; f += NT / 64) {
+        const int j = fail[1 + f];
+        const float ux = unk[(size_t)j * 3 + 0], uy = unk[(size_t)j * 3 + 1], uz = unk[(size_t)j * 3 + 2];
+        double b1 = empty, b2 = empty, b3 = empty;
+        for (int k = lane; k < m; k += 64) {
+            const float4 p = sorted[k];
+            const float d = sqdist_key(p.x, p.y, p.z, ux, uy, uz);
+            nn_insert(__hiloint2double(__float_as_int(d), __float_as_int(p.w)), b1, b2, b3);
+        }
+        // the wave's 64 triples -> lane 63: quads, half rows, rows (every lane of a merged group holds the group's triple, so
+        // a mirror pairs disjoint groups), then the two row broadcasts (lanes they do not write merge the empty key)
+        nn_merge<0xB1>(b1, b2, b3);
+        nn_merge<0x4E>(b1, b2, b3);
+        nn_merge_dpp<0x141, 0xf>(b1, b2, b3);              // row_half_mirror
+        nn_merge_dpp<0x140, 0xf>(b1, b2, b3);              // row_mirror
+        nn_merge_dpp<0x142, 0xa>(b1, b2, b3);              // row_bcast:15 -> rows 1, 3
+        nn_merge_dpp<0x143, 0xc>(b1, b2, b3);              // row_bcast:31 -> rows 2, 3
+        if (lane == 63) {
+            od[(size_t)j * 3 + 0] = __int_as_float(__double2hiint(b1)); od[(size_t)j * 3 + 1] = __int_as_float(__double2hiint(b2));
+            od[(size_t)j * 3 + 2] = __int_as_float(__double2hiint(b3));
+            oi[(size_t)j * 3 + 0] = __double2loint(b1); oi[(size_t)j * 3 + 1] = __double2loint(b2); oi[(size_t)j * 3 + 2] = __double2loint(b3);
+        }
+    }
+}
+
+static size_t three_nn_cells_lds(int m, int rows_per_part)
+{
+    return sizeof(float4) * (size_t)((m + 3) & ~3) + sizeof(int) * (size_t)kBqTabInts + kBqMiscBytes + sizeof(int) * (size_t)(rows_per_part + 4);
 }
 
 constexpr int kThreads = 256;
@@ -374,17 +547,56 @@ extern "C" int pn2_fp_interp_concat_grad(int b, int n, int m, int c2, int c1, in
     return pn2_three_interpolate_grad_seg(b, n, c2, m, scratch, idx, weight, grad_points2, ws_seg, deterministic, stream);
 }
 
-extern "C" int pn2_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx,
-                            void *stream)
+// variant: 0 = the library's choice, 1 = the sweep (three_nn_kernel), 2 = the cell list (PN2_E_ARG where it does not exist:
+// fewer than 64 or more than 8192 known points)
+static int three_nn_entry(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx, int variant, void *stream)
 {
     using namespace pn2;
     if (b < 0 || n < 0 || m < 0) return PN2_E_SHAPE;
+    // tuning hook of scripts/three_nn_probe.py: variant 2 | cell factor code << 4 | rows per workgroup / 128 << 8 | threads << 16 (0 = the defaults)
+    const int lab_rows = variant > 2 ? ((variant >> 8) & 0xff) * 128 : 0, lab_nt = variant > 2 ? ((variant >> 16) & 0xfff) : 0, lab_f = variant > 2 ? ((variant >> 4) & 0xf) : 0;
+    if (variant > 2 && (variant & 0xf) == 2 && lab_rows <= 1024 && (lab_nt == 0 || lab_nt == 256 || lab_nt == 512 || lab_nt == 1024)) variant = 2;
+    if (variant < 0 || variant > 2) return PN2_E_ARG;
     if (b == 0 || n == 0) return PN2_OK;
     if (!xyz1 || !dist || !idx || (m > 0 && !xyz2)) return PN2_E_NULL;
     if (b > 65535) return PN2_E_TOO_LARGE;
-    if (int rc = launch(three_nn_kernel, dim3((n + kNnPoints - 1) / kNnPoints, b), dim3(kNnThreads), 0,
-                       as_stream(stream), n, m, xyz1, xyz2, dist, idx)) return rc;
-    return PN2_OK;
+    const bool cells_ok = m >= 64 && m <= kBqCellsMaxPoints && (long long)b * 4096 < INT_MAX;
+    if (variant == 2 && !cells_ok) return PN2_E_ARG;
+    // The cell list pays where the sweep is long: from ~48 M pair tests (measured, profiles/r06/three_nn_cells.txt: sem_seg FP4
+    // 8 x 8192 x 1024 = 67 M: 26.5 -> 13.3 us; 32 x 4096 x 1024: 48.6 -> 20.5; part_seg FP3 16 x 2048 x 512 = 17 M: 9.1 -> 9.8, not taken)
+    if (variant == 2 || (variant == 0 && cells_ok && m >= 256 && (long long)b * n * m >= (48ll << 20))) {
+        // 256 unknown points per workgroup (two passes of 128 quads share one binning), 128 for small launches
+        int rows = (long long)b * n >= 256ll * 256 ? 256 : 128;
+        if (lab_rows > 0) rows = lab_rows;
+        const float factor = lab_f == 1 ? 1.2f : lab_f == 2 ? 1.6f : lab_f == 3 ? 2.0f : lab_f == 4 ? 1.45f : kNnCellFactor;
+        const int parts = (n + rows - 1) / rows;
+        const size_t lds = three_nn_cells_lds(m, rows);
+#define PN2_NN_CELLS(NT)                                                                                                          \
+        {                                                                                                                         \
+            auto kern = three_nn_cells_kernel<NT>;                                                                                \
+            if (int rc = allow_dynamic_lds(kern, lds)) return rc;                                                                 \
+            return launch(kern, dim3((unsigned)(parts * b)), dim3(NT), lds, as_stream(stream), n, m, rows, parts, b, factor, xyz1, xyz2,  \
+                          dist, idx);                                                                                             \
+        }
+        if (lab_nt == 256) PN2_NN_CELLS(256)
+        if (lab_nt == 1024) PN2_NN_CELLS(1024)
+        PN2_NN_CELLS(kNnCellsThreads)
+#undef PN2_NN_CELLS
+    }
+    return launch(three_nn_kernel, dim3((n + kNnPoints - 1) / kNnPoints, b), dim3(kNnThreads), 0, as_stream(stream), n, m, xyz1, xyz2,
+                  dist, idx);
+}
+
+extern "C" int pn2_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx,
+                            void *stream)
+{
+    return three_nn_entry(b, n, m, xyz1, xyz2, dist, idx, 0, stream);
+}
+
+extern "C" int pn2_three_nn_ex(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx, int variant,
+                               void *stream)
+{
+    return three_nn_entry(b, n, m, xyz1, xyz2, dist, idx, variant, stream);
 }
 
 static int three_interpolate_entry(int b, int m, int c, int n, const float *points, const int *idx, const float *weight,

@@ -37,8 +37,8 @@
 // Forward progress. Consumers spin until their producer has advanced; that cannot deadlock while the b
 // producer workgroups are running, which holds because (1) workgroups start in block-index order on this
 // hardware (producers are blocks [0, b); MI355X_MICROARCH.md: a 1024-block grid starts first -> last within
-// 0.34-0.69 us) and (2) the launch is refused unless the device can hold b + 1 of these workgroups at once
-// (occupancy query at launch, cached): b <= 128 << 256 CUs, and every workgroup asks for more than half of a
+// 0.34-0.69 us) and (2) the launch is refused unless the device can hold all b producer workgroups at once
+// (occupancy query at launch, cached): b <= 256 = the CUs, and every workgroup asks for more than half of a
 // CU's LDS, so a producer never shares its CU. HIP does not PROMISE (1), so the consumers' spin is bounded
 // (~10 s) and a consumer that gives up records it in the status word of `ws`
 // (pn2_sample_and_group_status_offset) and exits: an error the host can read, not a trap that would take
@@ -60,7 +60,8 @@
 namespace pn2 {
 
 constexpr int kFusedThreads = 512;
-constexpr int kFusedMaxClouds = 128;            // producers must leave most CUs to the consumers
+constexpr int kFusedMaxClouds = 256;            // one producer per CU at most (round 6: beyond 128 clouds the consumers take the CUs the producers leave, the rest
+                                                // of them when chains end -- the `batched` leg of bench.py)
 constexpr size_t kFusedMinLds = 82 * 1024;      // > 160 KiB / 2: one workgroup per CU
 constexpr int kFusedConsumers = 1;              // persistent consumer workgroups per cloud: 1 / 2 / 4 / 16 measured 397.6 / 398.0 / 398.5 /
                                                 // 398.4 us per step at the metric shape (profiles/r05/fused_consumers.txt)
@@ -241,10 +242,12 @@ static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, floa
     auto kern = sa_fused_kernel<P, LPQ, PRUNED>;
     if (int rc = allow_dynamic_lds(kern, lds)) return rc;
     {
-        // residency (header): room for every producer plus at least one consumer at the same time
+        // residency (header): room for every producer at the same time. Consumers only ever wait for producers and producers wait
+        // for nobody, so consumers that find no CU free simply start when a workgroup ends (b > CUs / 2: the last of them after
+        // the chains, where they find every sample published)
         const int room = resident_workgroups(kern, kFusedThreads, lds);
         if (room < 0) return -room;
-        if (room < b + 1) return PN2_E_TOO_LARGE;
+        if (room < b) return PN2_E_TOO_LARGE;
     }
     if (tag == 0) {                                               // caller did not manage generations: clear, use tag 1
         // (never inside a capture: sample_and_group_common has sent captured calls to the two launches.) The counter words of

@@ -355,7 +355,7 @@ def sample_and_group_xyz(npoint, radius, nsample, xyz, subtract_centroid=True, o
     dev = xyz.device
     lib = _C.lib()
     ordered = bool(ordered) and ordered_worthwhile(xyz, m)
-    if b == 0 or not _OVERLAP[0] or not (b <= 128 and 64 <= n <= 8192 and ns <= 256) or ordered:
+    if b == 0 or not _OVERLAP[0] or not (b <= 256 and 64 <= n <= 8192 and ns <= 256) or ordered:
         # (input in farthest-point order: a checked identity + the ball queries in two launches beats a chain of m dependent
         # rounds)
         return _two_launch_path(m, radius, ns, xyz, subtract_centroid, ordered)

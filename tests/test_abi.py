@@ -117,7 +117,7 @@ def test_c_abi_argument_validation_of_the_extra_entry_points():
     assert lib.pn2_knn_point(0, 8, 4, 2, None, None, None, None, None) == 0                    # empty batch
     assert lib.pn2_sample_and_group_xyz_gen(2, 1024, 64, 0.2, 32, one, one, 0, one, one, one, one, one, 1, None) == -3
     assert lib.pn2_sample_and_group_xyz(2, 1024, 64, 0.2, 32, None, None, None, None, None, None, None, 1, None) == -1
-    assert lib.pn2_sample_and_group_xyz(200, 1024, 64, 0.2, 32, one, one, one, one, one, one, one, 1, None) == -4   # envelope
+    assert lib.pn2_sample_and_group_xyz(300, 1024, 64, 0.2, 32, one, one, one, one, one, one, one, 1, None) == -4   # envelope (b <= 256)
     assert lib.pn2_group_point_grad_seg(1, 8, 4, 2, 2, None, None, None, None, 0, None) == -1
     assert lib.pn2_group_point_grad_seg(1, 0, 4, 2, 2, None, None, one, one, 0, None) == -2
     assert lib.pn2_three_interpolate_grad_seg(1, 8, 4, 0, None, None, None, one, one, 0, None) == -2

@@ -168,7 +168,7 @@ def test_static_copy_and_refill(cuda):
         assert _same(net(x, st), net(x), net)
         st.copy_(ahead.compute(_coords(y)))
         assert _same(net(y, st), net(y), net)
-    assert isinstance(ahead, GeometryAhead) and len(st.tensors()) == len(gx.tensors()) == 2 + 3 + 2 + 2
+    assert isinstance(ahead, GeometryAhead) and len(st.tensors()) == len(gx.tensors()) == 3 + 4 + 2 + 2   # (new_xyz, idx..., fps_idx) per SA level, (dist, idx) per FP level
 
 
 def test_argument_checks(cuda):
