@@ -299,7 +299,7 @@ def event_time_batched(fn, inner=20, reps=5):
     return float(np.median(ts)) * 1e-3
 
 
-def bandwidth_rooflines(dev):
+def bandwidth_rooflines(dev, only=None):
     """EXTRA object: the HBM-bound kernels of the path at the shapes where the reference's models
     actually move data (SURVEY 8a per-config table), driver-timed through the C ABI with preallocated buffers: algorithmic
     bytes (SURVEY 8d's formulas: every input read once, every output written once) / time / 8 TB/s, time = 20 launches queued
@@ -318,6 +318,8 @@ def bandwidth_rooflines(dev):
         pass
 
     def row(name, shape, nbytes, fn, kernel):
+        if only is not None and name != only:                    # scripts/profile_bw_rows.sh: one row per profiled process
+            return
         t = event_time_batched(fn)
         rows[name] = {"shape": shape, "kernel": kernel, "us": t * 1e6, "algorithmic_bytes": nbytes, "achieved": nbytes / t / 1e9,
                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS, "traffic": tj.get(name)}

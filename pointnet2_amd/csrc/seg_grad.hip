@@ -21,6 +21,9 @@
 #include <limits.h>
 #include <math.h>
 
+#include <algorithm>
+#include <type_traits>
+
 namespace pn2 {
 
 constexpr int kSegThreads = 256;
@@ -246,21 +249,18 @@ __device__ __forceinline__ int seg_shift(float maxabs, int logcount)
 // The segment's entry numbers are fetched LPR at a time (one per lane) and handed round with a
 // shuffle, and the rows are read four at a time: a lane that first loads an entry number and then the
 // row it names pays two dependent memory round trips per entry (335 us where this form needs ~150).
-template <int LPR, bool VEC4, bool DET, int SRC_DIV>
-__global__ __launch_bounds__(kSegThreads) void seg_reduce_kernel(long long out_rows, int rows, long long entries, int c,
-                                                                 const float *__restrict__ grad_out,
-                                                                 const float *__restrict__ weight,
-                                                                 const int *__restrict__ start,
-                                                                 const int *__restrict__ sorted,
-                                                                 const int *__restrict__ list,
-                                                                 float *__restrict__ out)
+template <int LPR, bool VEC4, bool DET, int SRC_DIV, int NT>
+__device__ __forceinline__ void seg_reduce_body(unsigned blk, unsigned nblk, long long out_rows, int rows, long long entries, int c,
+                                                const float *__restrict__ grad_out, const float *__restrict__ weight,
+                                                const int *__restrict__ start, const int *__restrict__ sorted,
+                                                const int *__restrict__ list, float *__restrict__ out, int long_from)
 {
     constexpr int CH = VEC4 ? 4 : 1;
     constexpr int UNR = 4;
-    const long long group = ((long long)blockIdx.x * kSegThreads + threadIdx.x) / LPR;
+    const long long group = ((long long)blk * NT + threadIdx.x) / LPR;
     const int lane = threadIdx.x & 63;
     const int gl = threadIdx.x % LPR, gbase = lane - gl;            // first lane of this group inside the wave
-    const long long ngroups = (long long)gridDim.x * kSegThreads / LPR;
+    const long long ngroups = (long long)nblk * NT / LPR;
     const long long trips = (out_rows + ngroups - 1) / ngroups;     // wave-uniform loop: shuffles need all lanes
     for (long long trip = 0; trip < trips; ++trip) {
         const long long row_raw = group + trip * ngroups;
@@ -269,7 +269,10 @@ __global__ __launch_bounds__(kSegThreads) void seg_reduce_kernel(long long out_r
         const long long i = row / rows;
         const int r = (int)(row - i * rows);
         const int beg = start[i * (rows + 1) + r];
-        const int end = row_ok ? start[i * (rows + 1) + r + 1] : beg;
+        int end = row_ok ? start[i * (rows + 1) + r + 1] : beg;
+        // rows of long_from entries or more belong to seg_reduce_long_kernel (default mode only; 0 = every row is this kernel's)
+        const bool mine_row = long_from <= 0 || end - beg < long_from;
+        if (!mine_row) end = beg;
         const int *seg = list + i * entries;
         const float *src = grad_out + (size_t)i * (entries / SRC_DIV) * c;
         const float *wsrc = weight ? weight + (size_t)i * entries : nullptr;
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_reduce_kernel(long long out_r
                     }
                 }
             }
-            if (row_ok && ch_ok) {
+            if (row_ok && ch_ok && mine_row) {
                 float res[CH];
 #pragma unroll
                 for (int q = 0; q < CH; ++q)                        // non-finite addends: the fp32 sum propagates them
@@ -350,6 +353,163 @@ __global__ __launch_bounds__(kSegThreads) void seg_reduce_kernel(long long out_r
     }
 }
 
+
+template <int LPR, bool VEC4, bool DET, int SRC_DIV>
+__global__ __launch_bounds__(kSegThreads) void seg_reduce_kernel(long long out_rows, int rows, long long entries, int c,
+                                                                 const float *__restrict__ grad_out,
+                                                                 const float *__restrict__ weight,
+                                                                 const int *__restrict__ start,
+                                                                 const int *__restrict__ sorted,
+                                                                 const int *__restrict__ list,
+                                                                 float *__restrict__ out, int long_from)
+{
+    seg_reduce_body<LPR, VEC4, DET, SRC_DIV, kSegThreads>(blockIdx.x, gridDim.x, out_rows, rows, entries, c, grad_out, weight, start, sorted,
+                                                           list, out, long_from);
+}
+
+// ---- long segments (round 6) -------------------------------------------------------------------------------------------------
+// A ball query that finds fewer than nsample points pads its list with the FIRST hit (tf_grouping_g.cu:24-31), and the first
+// hit is the in-ball point of lowest index: low-numbered points collect a reference from almost every centroid PLUS the
+// padding of every short list -- segments of hundreds to thousands of entries beside an average of 8-16. One lane group summing
+// such a segment alone is a serial chain of row loads the whole launch waits for: group_point's gradient at cls_ssg L2
+// (c = 128) took 104 us for 144 MB, at cls_msg L2 (c = 320, nsample 128) 741 us for 700 MB (profiles/r06). In the default
+// (not bit-reproducible) mode the rows of kSegLongFrom entries or more are therefore left out by the row-per-lane-group body and summed
+// here by a WHOLE workgroup each: its 512 / LPR lane groups take every (512 / LPR)-th batch of four entries, the partial rows
+// meet in LDS and are added in group order (a fixed order: the result does not depend on timing, only the association differs
+// from the serial sum). The reproducible mode keeps the one-group serial sum, whose order is the reference CPU loop's.
+constexpr int kSegLongFrom = 64;
+constexpr int kSegLongThreads = 512;
+
+template <int LPR, int SRC_DIV>
+__device__ __forceinline__ void seg_reduce_long_body(unsigned blk, unsigned nblk, long long out_rows, int rows, long long entries, int c,
+                                                     const float *__restrict__ grad_out, const float *__restrict__ weight,
+                                                     const int *__restrict__ start, const int *__restrict__ list,
+                                                     float *__restrict__ out)
+{
+    constexpr int NG = kSegLongThreads / LPR;                      // lane groups per workgroup
+    __shared__ float4 part[kSegLongThreads];                       // [NG][LPR]
+    __shared__ int row_beg[kSegLongThreads], row_len[kSegLongThreads];
+    __shared__ unsigned long long long_mask[kSegLongThreads / 64];
+    const int t = threadIdx.x, g = t / LPR, gl = t % LPR, lane = t & 63, wv = t >> 6;
+    // the workgroup looks at rows blockIdx.x + k gridDim.x (long rows sit at the low indices of every cloud: interleaved, they
+    // spread over the workgroups), 512 of them per pass, one per thread
+    for (long long base = blk; base < out_rows; base += (long long)nblk * kSegLongThreads) {
+        const long long my = base + (long long)t * nblk;
+        int beg = 0, len = 0;
+        if (my < out_rows) {
+            const long long i = my / rows;
+            const int r = (int)(my - i * rows);
+            beg = start[i * (rows + 1) + r];
+            len = start[i * (rows + 1) + r + 1] - beg;
+        }
+        const bool is_long = len >= kSegLongFrom;
+        row_beg[t] = beg; row_len[t] = len;
+        const unsigned long long m = __ballot(is_long);
+        if (lane == 0) long_mask[wv] = m;
+        __syncthreads();
+        for (int w2 = 0; w2 < kSegLongThreads / 64; ++w2) {
+            unsigned long long todo = long_mask[w2];                // workgroup-uniform
+            while (todo) {
+                const int bit = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int q = w2 * 64 + bit;                        // the thread slot that looked at this row
+                const long long row = base + (long long)q * nblk;
+                const long long i = row / rows;
+                const int rbeg = row_beg[q], rlen = row_len[q];
+                const int *seg = list + i * entries + rbeg;
+                const float *src = grad_out + (size_t)i * (entries / SRC_DIV) * c;
+                const float *wsrc = weight ? weight + (size_t)i * entries : nullptr;
+                // a lane owns the float4s gl and gl + LPR of the row (the second one where the row is wider than LPR float4s:
+                // c = 320 on 64 lanes -- as a second pass over the segment it cost the whole pass again for a quarter of the
+                // lanes); rows wider than 2 LPR float4s take more sweeps of the segment
+                const int per = c / 4;
+                for (int f0 = 0; f0 < per; f0 += 2 * LPR) {
+                    const int fa = f0 + gl, fb = f0 + LPR + gl;
+                    const bool oka = fa < per, okb = fb < per;
+                    const int ca = (oka ? fa : 0) * 4, cb = (okb ? fb : 0) * 4;
+                    const bool wide = f0 + LPR < per;               // workgroup-uniform: somebody owns a second float4
+                    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+                    // eight row loads in flight per lane either way: two batches of four entries (one float4 each), or one
+                    // batch with both float4s of the lane
+                    auto sweep = [&](auto widec) __attribute__((always_inline)) {
+                        constexpr bool WIDE = decltype(widec)::value;
+                        constexpr int NE = WIDE ? 4 : 8;
+                        for (int p = g * 4; p < rlen; p += NG * NE) {
+                            int e[NE];
+                            float wq[NE];
+                            float4 va[NE], vb[WIDE ? NE : 1];
+#pragma unroll
+                            for (int u = 0; u < NE; ++u) {
+                                const int pe = p + (u >> 2) * NG * 4 + (u & 3);
+                                e[u] = seg[pe < rlen ? pe : rlen - 1];
+                            }
+#pragma unroll
+                            for (int u = 0; u < NE; ++u) {
+                                const float *rowp = src + (size_t)(e[u] / SRC_DIV) * c;
+                                va[u] = *reinterpret_cast<const float4 *>(rowp + ca);
+                                if (WIDE) vb[u] = *reinterpret_cast<const float4 *>(rowp + cb);
+                                wq[u] = wsrc ? wsrc[e[u]] : 1.0f;
+                            }
+#pragma unroll
+                            for (int u = 0; u < NE; ++u) {
+                                const int pe = p + (u >> 2) * NG * 4 + (u & 3);
+                                if (pe < rlen) {
+                                    float4 x = va[u];
+                                    if (wsrc) { x.x = __fmul_rn(x.x, wq[u]); x.y = __fmul_rn(x.y, wq[u]); x.z = __fmul_rn(x.z, wq[u]); x.w = __fmul_rn(x.w, wq[u]); }
+                                    acc0.x = __fadd_rn(acc0.x, x.x); acc0.y = __fadd_rn(acc0.y, x.y); acc0.z = __fadd_rn(acc0.z, x.z); acc0.w = __fadd_rn(acc0.w, x.w);
+                                    if (WIDE) {
+                                        float4 y = vb[u];
+                                        if (wsrc) { y.x = __fmul_rn(y.x, wq[u]); y.y = __fmul_rn(y.y, wq[u]); y.z = __fmul_rn(y.z, wq[u]); y.w = __fmul_rn(y.w, wq[u]); }
+                                        acc1.x = __fadd_rn(acc1.x, y.x); acc1.y = __fadd_rn(acc1.y, y.y); acc1.z = __fadd_rn(acc1.z, y.z); acc1.w = __fadd_rn(acc1.w, y.w);
+                                    }
+                                }
+                            }
+                        }
+                    };
+                    if (wide) sweep(std::true_type()); else sweep(std::false_type());
+                    for (int half = 0; half < (wide ? 2 : 1); ++half) {
+                        float4 mine = acc0;
+                        if (half) mine = acc1;
+                        part[g * LPR + gl] = mine;
+                        __syncthreads();
+                        const bool okh = half ? okb : oka;
+                        if (g == 0 && okh) {
+                            float4 sum = part[gl];
+#pragma unroll 4
+                            for (int k = 1; k < NG; ++k) {
+                                const float4 o = part[k * LPR + gl];
+                                sum.x = __fadd_rn(sum.x, o.x); sum.y = __fadd_rn(sum.y, o.y); sum.z = __fadd_rn(sum.z, o.z); sum.w = __fadd_rn(sum.w, o.w);
+                            }
+                            *reinterpret_cast<float4 *>(out + row * c + (half ? cb : ca)) = sum;
+                        }
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+        __syncthreads();                                            // row_beg / row_len / long_mask are rewritten by the next pass
+    }
+}
+
+
+// ONE launch for both (default mode): blocks [0, nlong) sum the long rows -- dependent chains of row loads, dispatched first --,
+// the other blocks the short rows at streaming rate beside them (as two launches: 18 + 38 us at cls_ssg L2, 107 + 147 at
+// cls_msg L2; the long-row kernel alone uses a fraction of the memory system)
+template <int LPR, int SRC_DIV>
+__global__ __launch_bounds__(kSegLongThreads) void seg_reduce_split_kernel(unsigned nlong, long long out_rows, int rows, long long entries,
+                                                                           int c, const float *__restrict__ grad_out,
+                                                                           const float *__restrict__ weight,
+                                                                           const int *__restrict__ start,
+                                                                           const int *__restrict__ sorted,
+                                                                           const int *__restrict__ list, float *__restrict__ out)
+{
+    if (blockIdx.x < nlong)
+        seg_reduce_long_body<LPR, SRC_DIV>(blockIdx.x, nlong, out_rows, rows, entries, c, grad_out, weight, start, list, out);
+    else
+        seg_reduce_body<LPR, true, false, SRC_DIV, kSegLongThreads>(blockIdx.x - nlong, gridDim.x - nlong, out_rows, rows, entries, c, grad_out,
+                                                                     weight, start, sorted, list, out, kSegLongFrom);
+}
+
 template <bool DET, int SRC_DIV>
 static int launch_reduce(long long out_rows, int rows, long long entries, int c, const float *grad_out, const float *weight,
                          const SegWs &w, float *out, hipStream_t st)
@@ -360,13 +520,27 @@ static int launch_reduce(long long out_rows, int rows, long long entries, int c,
     int lpr = 1;
     while (lpr < per && lpr < 64) lpr <<= 1;
     const long long threads = out_rows * lpr;
+    // default mode, 16-byte rows, at least 16 lanes per row: the long rows go to seg_reduce_long_kernel (second launch below)
+    const bool split = !DET && vec4 && lpr >= 16;
 #define PN2_SEG_CASE(L)                                                                                              \
     if (lpr == L) {                                                                                                  \
+        if (split && L >= 16) {                                                                                      \
+            /* ~16 rows looked at per long-row workgroup, at most 1021 of them. The long rows are the LOW point numbers of every \
+               cloud: workgroup w looks at rows w, w + wg, w + 2 wg, ..., so wg must not share a factor with the rows per cloud -- \
+               with wg = rows = 512 every cloud's row r went to workgroup r and thirty workgroups did all the work (1758 us) */ \
+            long long wg = (out_rows + 15) / 16;                                                                     \
+            if (wg > 1021) wg = 1021;                                                                                \
+            wg |= 1;                                                                                                 \
+            while (wg > 1 && (rows % wg == 0 || std::__gcd((long long)rows, wg) > 1)) wg -= 2;                       \
+            const unsigned ga = seg_grid(threads, kSegLongThreads);                                                  \
+            return launch((seg_reduce_split_kernel<(L >= 16 ? L : 16), SRC_DIV>), dim3((unsigned)wg + ga), dim3(kSegLongThreads), 0, st, \
+                          (unsigned)wg, out_rows, rows, entries, c, grad_out, weight, w.start, w.sorted, w.list, out); \
+        }                                                                                                            \
         if (vec4)                                                                                                    \
             return launch((seg_reduce_kernel<L, true, DET, SRC_DIV>), dim3(seg_grid(threads)), dim3(kSegThreads), 0, st, \
-                          out_rows, rows, entries, c, grad_out, weight, w.start, w.sorted, w.list, out);            \
+                          out_rows, rows, entries, c, grad_out, weight, w.start, w.sorted, w.list, out, 0);         \
         return launch((seg_reduce_kernel<L, false, DET, SRC_DIV>), dim3(seg_grid(threads)), dim3(kSegThreads), 0, st, \
-                      out_rows, rows, entries, c, grad_out, weight, w.start, w.sorted, w.list, out);                \
+                      out_rows, rows, entries, c, grad_out, weight, w.start, w.sorted, w.list, out, 0);             \
     }
     PN2_SEG_CASE(1) PN2_SEG_CASE(2) PN2_SEG_CASE(4) PN2_SEG_CASE(8) PN2_SEG_CASE(16) PN2_SEG_CASE(32) PN2_SEG_CASE(64)
 #undef PN2_SEG_CASE

@@ -36,12 +36,17 @@ int main(int argc, char **argv)
     const int replays = argc > 1 ? atoi(argv[1]) : 3000;
     const int noise_per_replay = argc > 2 ? atoi(argv[2]) : 8;
     const int ngraphs = argc > 3 ? atoi(argv[3]) : 4;
-    const int variant = argc > 4 ? atoi(argv[4]) : 0;     // bit 0: instantiate with hipGraphInstantiateFlagAutoFreeOnLaunch (what PyTorch does)
+    const int variant = argc > 4 ? atoi(argv[4]) : 0;     // (bit 3: stream kinds, below; bit 4: capture in thread-local mode) bit 0: instantiate with hipGraphInstantiateFlagAutoFreeOnLaunch (what PyTorch does)
                                                           // bit 1: the noise kernels go to the NULL stream; bit 2: noise with a large argument block
     const size_t bytes = 8 * 16 * 512 + 16, words = bytes / 8;       // part_seg's level-1 workspace
     hipStream_t s, s2;
-    CK(hipStreamCreate(&s));
-    CK(hipStreamCreateWithPriority(&s2, hipStreamDefault, -1));
+    if (variant & 8) {                                    // bit 3: non-blocking streams, the graph's one of high priority (what PyTorch creates)
+        CK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, -1));
+        CK(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, 0));
+    } else {
+        CK(hipStreamCreate(&s));
+        CK(hipStreamCreateWithPriority(&s2, hipStreamDefault, -1));
+    }
     std::vector<unsigned long long *> bufs(ngraphs), outs(ngraphs);
     std::vector<hipGraphExec_t> execs(ngraphs);
     unsigned long long *sink;
@@ -52,7 +57,7 @@ int main(int argc, char **argv)
         // a few eager launches between captures, like a framework's warm-up
         for (int k = 0; k < 5; ++k) hipLaunchKernelGGL(noise, dim3(1), dim3(64), 0, s, sink, 0xAAAA0000ull + k, 0xBBBBull, 0xCCCCull, 1);
         hipGraph_t graph;
-        CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        CK(hipStreamBeginCapture(s, (variant & 16) ? hipStreamCaptureModeThreadLocal : hipStreamCaptureModeGlobal));
         CK(hipMemsetAsync(bufs[g], 0, bytes, s));
         hipLaunchKernelGGL(copy_words, dim3(16), dim3(256), 0, s, outs[g], bufs[g], words);
         CK(hipStreamEndCapture(s, &graph));

@@ -237,3 +237,54 @@ def test_segmented_grad_matches_reference_cpu_order_bit_for_bit(cuda, oracle):
     finally:
         P.set_deterministic(False)
     assert np.array_equal(kn.grad.cpu().numpy(), oracle.three_interpolate_grad((b, m2, c), idx3, w, g2))
+
+
+@pytest.mark.parametrize("c", [64, 128, 320])
+def test_segmented_group_grad_on_padded_ball_query_lists(cuda, c):
+    """Round 6: a ball query that finds fewer than nsample points pads its list with the first hit (tf_grouping_g.cu:24-31), so
+    low-numbered points head segments of hundreds of entries beside an average of 16 -- the rows seg_reduce_long_kernel sums with a
+    whole workgroup in the default mode. Real geometry of cls_ssg's second level (512 points, 128 balls of radius 0.4, 64
+    slots), value against a float64 scatter-add, both modes; the test insists that long AND short segments occur."""
+    import pointnet2_amd as P
+    from pointnet2_amd import synthetic as S
+    b, n, m, ns = 8, 512, 128, 64
+    xyz = torch.from_numpy(S.sphere_clouds(b, n, 41)).to(cuda)
+    _, new_xyz = P.farthest_point_sample_gather(m, xyz)
+    idx, cnt = P.query_ball_point(0.4, ns, xyz, new_xyz)
+    idx_np = idx.cpu().numpy()
+    lens = np.stack([np.bincount(idx_np[i].reshape(-1), minlength=n) for i in range(b)])
+    assert lens.max() >= 256 and (lens < 64).sum() > b * n // 2, (lens.max(), (lens < 64).sum())
+    rng = np.random.default_rng(c)
+    g = rng.standard_normal((b, m, ns, c)).astype(np.float32)
+    want = _exact_scatter(b, n, c, idx_np.reshape(b, -1), g.reshape(b, -1, c))
+    mag = _exact_scatter(b, n, c, idx_np.reshape(b, -1), np.abs(g).reshape(b, -1, c))
+    tol = mag * 2.0 ** -24 * np.maximum(lens[:, :, None], 2) + 1e-30
+    for det in (False, True):
+        pts = torch.zeros(b, n, c, device=cuda, requires_grad=True)
+        P.set_deterministic(det)
+        try:
+            P.group_point(pts, idx).backward(torch.from_numpy(g).to(cuda))
+        finally:
+            P.set_deterministic(False)
+        assert np.all(np.abs(pts.grad.cpu().numpy() - want) <= tol), det
+
+
+def test_segmented_interpolate_grad_with_long_segments(cuda):
+    """three_interpolate's gradient with few known points: every segment is long (2048 x 3 references onto 16 rows), weights
+    applied per entry (tf_interpolate.cpp:131-153), 128 channels."""
+    import pointnet2_amd as P
+    rng = np.random.default_rng(3)
+    b, n, m, c = 4, 2048, 16, 128
+    idx = rng.integers(0, m, size=(b, n, 3)).astype(np.int32)
+    w = rng.random((b, n, 3)).astype(np.float32)
+    g = rng.standard_normal((b, n, c)).astype(np.float32)
+    pts = torch.zeros(b, m, c, device=cuda, requires_grad=True)
+    P.three_interpolate(pts, torch.from_numpy(idx).to(cuda), torch.from_numpy(w).to(cuda)).backward(torch.from_numpy(g).to(cuda))
+    want = np.zeros((b, m, c))
+    mag = np.zeros((b, m, c))
+    for i in range(b):
+        for k in range(3):
+            add = g[i].astype(np.float64) * w[i, :, k:k + 1].astype(np.float64)
+            np.add.at(want[i], idx[i, :, k], add)
+            np.add.at(mag[i], idx[i, :, k], np.abs(add))
+    assert np.all(np.abs(pts.grad.cpu().numpy() - want) <= mag * 2.0 ** -24 * (3 * n / m * 2) + 1e-30)
