@@ -83,7 +83,12 @@ def run_steps(model, opt, bucket, x, labels, kind, steps, warm, batch, ahead=Non
             rec[4].record()
     torch.cuda.synchronize()
     ph = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(4)] for e in ev])
-    return ph.mean(axis=0), float(loss)
+    if os.environ.get("PN2_STEP_DEBUG"):                    # per-step phases (forward, backward, all-reduce, optimiser), ms
+        print("steps:", np.round(ph, 2).tolist(), file=sys.stderr, flush=True)
+    # MEDIAN over the timed steps (round 6): roughly one step in twenty carries a 70-90 ms HOST stall in its forward (a
+    # generation-2 pass of Python's garbage collector over the modules and autograd graphs alive in this process; whichever
+    # variant it lands in -- part_seg "fused" read 12.3 + 2.8 ms as a mean of eight steps, seven of them 1.15-1.4 ms)
+    return np.median(ph, axis=0), float(loss)
 
 
 def graph_step(model, opt, bucket, x, labels, steps):
