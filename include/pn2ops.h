@@ -286,6 +286,7 @@ int pn2_farthest_point_sample_ex(int T, int P, int b, int n, int m, const float 
 #define PN2_FPS_AUTO 0
 #define PN2_FPS_FULL 1
 #define PN2_FPS_PRUNED 2
+#define PN2_FPS_BATCH 3
 int pn2_farthest_point_sample_variant(int variant, int b, int n, int m, const float *inp, float *temp, int *out,
                                       float *out_xyz, void *stream);
 

@@ -37,6 +37,7 @@
 // that keeps the running distances in the caller's `temp` buffer.
 #include "fps_body.h"
 #include "fps_pruned_body.h"
+#include "fps_batch_body.h"
 
 #include <limits.h>
 
@@ -58,6 +59,15 @@ __global__ __launch_bounds__(kPrT) void fps_pruned_kernel(int n, int m, int Q, c
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     fps_pruned_body<P, GS, false>(n, m, Q, blockIdx.x, xyz, out, out_xyz, nullptr, smem);
+}
+
+// Batched tier (fps_batch_body.h): the pruned tier's slots and boxes, several samples per arg-max exchange.
+template <int P, int GS>
+__global__ __launch_bounds__(kBtT) void fps_batch_kernel(int n, int m, int Q, const float *__restrict__ xyz,
+                                                         int *__restrict__ out, float *__restrict__ out_xyz)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    fps_batch_body<P, GS, false>(n, m, Q, blockIdx.x, xyz, out, out_xyz, nullptr, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -318,6 +328,24 @@ static int fps_launch_pruned(int b, int n, int m, const float *inp, int *out, fl
     return launch_pruned<32, 4>(b, n, m, Q, inp, out, oxyz, st);
 }
 
+template <int P, int GS>
+static int launch_batch(int b, int n, int m, int Q, const float *inp, int *out, float *oxyz, hipStream_t st)
+{
+    const size_t lds = fps_batch_lds_bytes(P);
+    auto kern = fps_batch_kernel<P, GS>;
+    if (int rc = allow_dynamic_lds(kern, lds)) return rc;
+    return launch(kern, dim3(b), dim3(kBtT), lds, st, n, m, Q, inp, out, oxyz);
+}
+
+static int fps_launch_batch(int b, int n, int m, const float *inp, int *out, float *oxyz, hipStream_t st)
+{
+    const int Q = (n + kRefThreads - 1) / kRefThreads;
+    const int ranks = kRefThreads * Q;
+    if (!pruned_covers(ranks)) return PN2_E_ARG;
+    if (ranks <= 4096) return launch_batch<16, 2>(b, n, m, Q, inp, out, oxyz, st);
+    return launch_batch<32, 4>(b, n, m, Q, inp, out, oxyz, st);
+}
+
 constexpr int kMaxLdsSlots = 8192;     // 256 B + 16 B per rank slot <= 160 KiB
 constexpr int kMaxRegPoints = 16384;
 
@@ -388,6 +416,7 @@ static int fps_entry(int b, int n, int m, const float *inp, float *temp, int *ou
     }
     const int Q = (n + kRefThreads - 1) / kRefThreads;
     const int ranks = kRefThreads * Q;
+    if (variant == PN2_FPS_BATCH) return fps_launch_batch(b, n, m, inp, out, out_xyz, st);
     if (variant == PN2_FPS_PRUNED || (variant == PN2_FPS_AUTO && fps_pruned_pays(ranks, m)))
         return fps_launch_pruned(b, n, m, inp, out, out_xyz, st);
     // default geometry (measured, scripts/fps_prod_lab.hip, ns per round at n = 1024/2048/4096/8192):
@@ -415,7 +444,7 @@ extern "C" int pn2_farthest_point_sample_gather(int b, int n, int m, const float
 extern "C" int pn2_farthest_point_sample_variant(int variant, int b, int n, int m, const float *inp, float *temp, int *out,
                                                  float *out_xyz, void *stream)
 {
-    if (variant < PN2_FPS_AUTO || variant > PN2_FPS_PRUNED) return PN2_E_ARG;
+    if (variant < PN2_FPS_AUTO || variant > PN2_FPS_BATCH) return PN2_E_ARG;
     return fps_entry(b, n, m, inp, temp, out, out_xyz, stream, variant);
 }
 

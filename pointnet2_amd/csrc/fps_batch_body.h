@@ -1,0 +1,462 @@
+// fps_batch_body.h -- farthest point sampling with SEVERAL samples per arg-max exchange and a wave of its own for the
+// arg-max chain (round 6).
+//
+// Same results as fps_pruned_body / fps_reg_body / the reference kernel (tf_sampling_g.cu:105-170), bit for bit. What changes is
+// the shape of the chain. In every other tier a sample costs one workgroup-wide arg-max: a six-step wave ladder, an LDS write, a
+// barrier, an LDS read, a tournament, a mirror read -- ~700 dependent cycles of which the distance update is ~120. Here the
+// workgroup exchanges a short LIST of candidates once per BATCH; a fifth wave, the PICKER, then works through the list on its
+// own -- one wave ladder and nine vector instructions per sample, no barrier, no LDS trip on its path -- for as many samples as
+// the list provably determines (10-14 on the bench clouds), while the four UPDATER waves apply the samples to the slots as they
+// appear.
+//
+// Why a list determines several samples. Let td[] be the running distances after j samples, ordered by the reference's key
+// (value, then smaller tie rank). Fix a threshold theta below the current maximum. A point whose value is below theta can never
+// become a sample while the sample values stay >= theta, because running distances only fall. So as long as the next sample's
+// value is >= theta, the next sample is the best of the points that are >= theta NOW, after lowering their values by the samples
+// taken since -- and those are few: the points near the covering radius. The batch ends when the best listed candidate falls
+// below the bound; everything taken until then is exactly the reference's sequence (scripts/fps_batch_sim.py checks the rule
+// against the oracle; tests/test_fps_batch_model.py is the CPU model of this file's arithmetic).
+//
+// Organisation. 320 threads: waves 0..3 hold the slots exactly as in the pruned tier (fps_pruned_prologue: spatial groups,
+// rank-ordered LDS mirror, group boxes), wave 4 is the picker.
+//   * COLLECT (updaters, once per batch). Every lane computes the best key and the second-best VALUE of its P slots. Lanes whose best value is >= theta are candidate lanes: at most kBtCap per wave -- a
+//     wave with more raises its own threshold by bisection on the value bits, a wave with none (or with more than kBtCap equal
+//     values) falls back to its exact best lane (one 64-bit wave ladder). A candidate lane writes its best key to the wave's
+//     part of the list; the wave's BOUND -- the smallest value bits a sample must have for the list to be complete -- is the
+//     maximum of its threshold and of (second-best value + 1 ulp) of its candidate lanes (an LDS atomic maximum on the fp32 bit
+//     patterns: the values are >= 0). One barrier, the only one of the batch.
+//   * PICK (picker). Lane i takes candidate i (key from the list, x, y, z, k from the mirror). Per sample: 32-bit wave ladder on
+//     the value bits (v_max_i32 with the DPP operand folded in: six instructions), v_readlane of the maximum, the acceptance
+//     test (first sample of a batch: always -- the list holds every updater wave's best lane, so its maximum is the global one;
+//     later: value bits >= bound), the winner's lane from a ballot of value == maximum (several lanes: the 64-bit keys decide, by
+//     the pruned tier's ladder), the winner lane stores its (x, y, z, k) row and the new count to LDS, three v_readlane, nine
+//     vector instructions for the reference's distance (tf_sampling_g.cu:141-144) from the sample to the other candidates.
+//   * APPLY (updaters, behind the picker). A wave polls the count, takes up to eight new samples at a time -- lane l tests
+//     sample l / 8 against the box of the wave's group l % 8: one distance-to-box computation for 64 (sample, group) pairs --
+//     and updates the touched groups (packed fp32, as in the pruned tier; no key work: keys are only needed at COLLECT). The skip test uses the value of the previous batch's LAST sample as v* (no running distance is above it).
+//   * theta = (1 - g) * (value of the last sample); g adapts so that the list stays about two thirds full. The picker decides
+//     and publishes theta with the end-of-batch flag.
+//
+// Once a sample's value is 0 every running distance is 0 and the reference keeps selecting point 0 (its tie rule): the rest of
+// the output is filled directly.
+//
+// Exactness of the acceptance rule in fp32 bit patterns: values are non-negative floats, so integer comparison of the bits is
+// the value order; "value > second-best" is "bits >= second-best bits + 1". A sample with value bits >= the maximum of the waves'
+// bounds beats (by value alone, no tie rule needed) every point that is not a listed candidate's best point; among the listed
+// ones the 64-bit keys decide, ties included. Degenerate clouds with many EQUAL values at the top (lattices) make short batches
+// (the bound is strict), never different samples.
+//
+// Hand-offs inside the workgroup: LDS only. The picker's row store and count store come from the same lane (LDS executes a
+// wave's operations in order), counts are release stores / acquire loads at workgroup scope. Double-buffered by batch parity:
+// list, counts, bounds and the header; the sample ring is single (a batch's samples are consumed before the next barrier).
+#pragma once
+#include "fps_pruned_body.h"
+
+namespace pn2 {
+
+constexpr int kBtCap = 16;                     // candidate lanes per updater wave
+constexpr int kBtCand = kPrW * kBtCap;         // 64 = the picker's lanes
+constexpr int kBtT = kPrT + PN2_WAVE;          // 320 threads
+static_assert(kBtCand == 64, "one candidate per picker lane");
+constexpr unsigned kBtEnd = 0x100u, kBtFill = 0x200u, kBtCountMask = 0xffu;
+
+struct BtXchg {
+    double list[kBtCand];                      // wave w's candidates at [w * kBtCap, w * kBtCap + cnt[w])
+    unsigned cnt[kPrW];
+    unsigned bound[kPrW];
+    unsigned count;                            // samples of this batch published so far | kBtEnd | kBtFill
+    unsigned pad0;
+    unsigned theta, vlast;                     // for the NEXT collect: threshold bits, value bits of the batch's last sample
+    unsigned pad[4];
+};
+static_assert(sizeof(BtXchg) % 16 == 0, "16-byte rows");
+
+__host__ __device__ constexpr size_t fps_batch_xchg_offset(int P) { return (fps_pruned_lds_bytes(P) + 15) & ~(size_t)15; }
+__host__ __device__ constexpr size_t fps_batch_lds_bytes(int P) { return fps_batch_xchg_offset(P) + 2 * sizeof(BtXchg) + 16 * kBtCand; }
+
+__device__ __forceinline__ float vmax_f32(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmed3_f32(float a, float b, float c)
+{
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// wave-wide signed maximum, result in lane 63: the DPP operand rides on the v_max itself (VOP2), one instruction per step.
+// Lanes without a source (bound_ctrl:0 reads 0) combine with 0 -- harmless for a maximum of values of which at least one is >= 0.
+__device__ __forceinline__ int wave_max_i32_lane63(int v)
+{
+    // written with the builtin so that the compiler folds the v_mov_dpp into the v_max (GCNDPPCombine), keeps track of the DPP
+    // hazards itself and schedules independent work into the wait states
+#define PN2_BT_STEP(ctrl) v = max(v, __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, true))
+    PN2_BT_STEP(0xB1);    // quad_perm:[1,0,3,2]
+    PN2_BT_STEP(0x4E);    // quad_perm:[2,3,0,1]
+    PN2_BT_STEP(0x141);   // row_half_mirror
+    PN2_BT_STEP(0x140);   // row_mirror
+    PN2_BT_STEP(0x142);   // row_bcast:15
+    PN2_BT_STEP(0x143);   // row_bcast:31
+#undef PN2_BT_STEP
+    return v;
+}
+
+// LDS atomic maximum without the compiler's wave-level pre-reduction (a readlane loop over the active lanes: ~50 cycles per
+// lane on a lone wave; the LDS unit serialises same-address atomics in a few cycles each)
+__device__ __forceinline__ void lds_max_u32(unsigned *p, unsigned v)
+{
+    asm volatile("ds_max_u32 %0, %1" :: "v"((unsigned)(size_t)p), "v"(v) : "memory");
+}
+
+#ifdef PN2_BT_STATS
+// lab: [0] batches, [1] samples, [2] exact fallbacks, [3] bisection steps, [4] sum of list sizes, [5] (group, sample) updates,
+// [6] picker cycles in READ, [7] picker cycles in PICK, [8] picker cycles waiting at the barrier, [9] updater 0 cycles in COLLECT,
+// [10] updater 0 cycles from the barrier to the end flag, [11] tie resolutions
+__device__ unsigned long long g_bt_stats[16];
+#ifndef PN2_BT_STATS_FROM
+#define PN2_BT_STATS_FROM 0
+#endif
+#define PN2_BT_STAT(i, v) do { if (lane == 0 && cloud == 0 && j >= PN2_BT_STATS_FROM) atomicAdd(&g_bt_stats[i], (unsigned long long)(v)); } while (0)
+#define PN2_BT_CLOCK() __builtin_readcyclecounter()
+#else
+#define PN2_BT_STAT(i, v) do { } while (0)
+#define PN2_BT_CLOCK() 0ll
+#pragma clang diagnostic ignored "-Wunused-variable"
+#endif
+
+#ifndef PN2_BT_G0
+#define PN2_BT_G0 0.10f               // initial 1 - theta / (last sample value)
+#endif
+
+template <int P, int GS, bool PUBLISH>
+__device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, const float *__restrict__ xyz,
+                                               int *__restrict__ out, float *__restrict__ out_xyz,
+                                               unsigned long long *__restrict__ tagged, char *smem, unsigned tag = 1u)
+{
+    constexpr int T = kPrT, W = kPrW, NS = T * P;
+    constexpr int GW = P / GS;
+    static_assert(W * GW == 32 && GW == 8, "32 groups");
+    float4 *lds_rank = reinterpret_cast<float4 *>(smem + 256);
+    BtXchg *xch = reinterpret_cast<BtXchg *>(smem + fps_batch_xchg_offset(P));
+    float4 *ring = reinterpret_cast<float4 *>(smem + fps_batch_xchg_offset(P) + 2 * sizeof(BtXchg));   // [kBtCand] samples of the batch: x, y, z, k
+
+    const float *__restrict__ src = xyz + (size_t)cloud * n * 3;
+    int *__restrict__ dst = out + (size_t)cloud * m;
+    float *__restrict__ dxyz = out_xyz ? out_xyz + (size_t)cloud * m * 3 : nullptr;
+    pn2_gu64 *gtag = PUBLISH ? (pn2_gu64 *)(tagged + (size_t)cloud * m) : nullptr;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+
+    int j = 1;                                   // samples written so far (wave-uniform, the same in every wave)
+    int fill_k = -1;                             // >= 0: the cloud ran out of distinct points at sample j, the rest is this index
+
+    if (w == W) {
+        // ================================================ the picker ===========================================================
+#ifndef PN2_NO_SETPRIO
+        __builtin_amdgcn_s_setprio(3);           // it shares SIMD 0 with updater wave 0 and is the chain
+#endif
+        if (lane == 0) { xch[0].count = 0u; xch[1].count = 0u; }
+        for (int i = 0; i < kPrPrologueBarriers; ++i) __syncthreads();
+        float g = PN2_BT_G0;
+        int par = 0;
+        for (;;) {
+            const long long q0 = PN2_BT_CLOCK();
+            __syncthreads();                     // the list of this batch is complete
+            const long long q1 = PN2_BT_CLOCK();
+            BtXchg &X = xch[par];
+            if (lane == 0) __hip_atomic_store(&xch[par ^ 1].count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // everybody is past the batch that used it
+            const uint4 c4 = *reinterpret_cast<const uint4 *>(X.cnt);
+            const uint4 b4 = *reinterpret_cast<const uint4 *>(X.bound);
+            const double key = X.list[lane];
+            const int wv = lane >> 4;
+            const unsigned cw = wv == 0 ? c4.x : wv == 1 ? c4.y : wv == 2 ? c4.z : c4.w;
+            const bool valid = (unsigned)(lane & (kBtCap - 1)) < cw;
+            const unsigned lowc = valid ? (unsigned)__double2loint(key) : 0u;
+            typedef float bt_f4 __attribute__((ext_vector_type(4)));
+            const bt_f4 cand = *reinterpret_cast<const bt_f4 *>(&lds_rank[lowc]);   // x, y, z, bits of k
+            const int boundb = __builtin_amdgcn_readfirstlane((int)max(max(b4.x, b4.y), max(b4.z, b4.w)));
+            const int total = __builtin_amdgcn_readfirstlane((int)(c4.x + c4.y + c4.z + c4.w));
+            int cval = valid ? __double2hiint(key) : (int)0xBF800000;             // -1.0f: below every value as an integer, kept by v_min_f32
+            const int clo = (int)lowc;
+            int a = 0;
+            int vlastb = 0;
+            bool fill = false;
+            const unsigned ring_base = (unsigned)(size_t)ring, count_addr = (unsigned)(size_t)&X.count;   // LDS byte addresses
+            const long long q2 = PN2_BT_CLOCK();
+            int bh;
+            unsigned long long eq;                                               // one bit: the winner's lane
+            // the exact arg-max of the current values: value ladder, then the 64-bit keys among equal values
+            auto argmax = [&]() __attribute__((always_inline)) {
+                bh = __builtin_amdgcn_readlane(wave_max_i32_lane63(cval), 63);
+                eq = __ballot(cval == bh);
+                if (__popcll(eq) != 1) {
+                    PN2_BT_STAT(11, 1);
+                    const double kq = cval == bh ? __hiloint2double(cval, clo) : -1.0;
+                    const double km = wave_max_f64_lane63(kq);
+                    const int ml = __builtin_amdgcn_readlane(__double2loint(km), 63);
+                    eq = __ballot(cval == bh && clo == ml);
+                    eq &= 0ull - eq;                                             // equal keys exist only among padding slots
+                }
+            };
+            argmax();                                                            // the batch's first sample: always (the global arg-max)
+            const int amax = min(m - j, kBtCand);
+            unsigned raddr = ring_base, na = 1u;
+            for (;;) {
+                // the winner lane alone stores its row and then the new count: two LDS writes of one wave execute in order, so a
+                // reader that sees the count sees the row (no wait in between, none behind). It also leaves the contest (-1.0f).
+                asm volatile("s_mov_b64 exec, %1\n\t"
+                             "ds_write_b128 %2, %3\n\t"
+                             "ds_write_b32 %4, %5\n\t"
+                             "v_mov_b32 %0, 0xbf800000\n\t"
+                             "s_mov_b64 exec, -1"
+                             : "+v"(cval) : "s"(eq), "v"(raddr), "v"(cand), "v"(count_addr), "v"(na) : "memory");
+                const int wl = (int)__builtin_ctzll(eq);
+                raddr += 16u; na += 1u;
+                a = __builtin_amdgcn_readfirstlane(a + 1);                       // scalar loop control
+                vlastb = bh;
+                if (a >= amax) break;
+                // SPECULATION: the maximum of the values as they are BEFORE this sample's update is computed in the shadow of the
+                // update. Values only fall: a lane that still holds that maximum afterwards is the arg-max -- if it is the only one.
+                // (A sample of value 0 ends the batch by itself: nothing is above the bound afterwards.)
+                const int ms = __builtin_amdgcn_readlane(wave_max_i32_lane63(cval), 63);
+                const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand.x), wl));
+                const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand.y), wl));
+                const float sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand.z), wl));
+                const float d = sqdist(cand.x, cand.y, cand.z, sx, sy, sz);      // tf_sampling_g.cu:141-143
+                cval = __float_as_int(vmin_f32(d, __int_as_float(cval)));        // :144
+                if (ms < boundb) break;                                          // nothing above the bound is left, whatever the update did
+                eq = __ballot(cval == ms);
+                bh = ms;
+                if (__popcll(eq) != 1) {
+                    PN2_BT_STAT(12, 1);
+                    argmax();
+                    if (bh < boundb) break;
+                }
+            }
+            if (vlastb == 0) { fill = true; fill_k = __builtin_amdgcn_readlane(__float_as_int(cand.w), (int)__builtin_ctzll(eq)); }   // every running distance is 0 from here on
+            const long long q3 = PN2_BT_CLOCK();
+            // the list about two thirds full
+            if (total > 44) g = fmaxf(g * 0.8f, 1.0f / 128.0f);
+            else if (total < 28) g = fminf(g * 1.25f, 0.5f);
+            X.theta = __float_as_uint(__fmul_rn(__int_as_float(vlastb), 1.0f - g));
+            X.vlast = (unsigned)vlastb;
+            if (lane == 0)
+                __hip_atomic_store(&X.count, (unsigned)a | kBtEnd | (fill ? kBtFill : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            PN2_BT_STAT(0, 1); PN2_BT_STAT(1, a); PN2_BT_STAT(4, total); PN2_BT_STAT(6, q2 - q1); PN2_BT_STAT(7, q3 - q2); PN2_BT_STAT(8, q1 - q0);
+            j = __builtin_amdgcn_readfirstlane(j + a);
+            if (fill || j >= m) break;
+            par ^= 1;
+        }
+    } else {
+        // ================================================ the updaters =========================================================
+        PrSlots<P> S;
+        fps_pruned_prologue<P, GS>(n, Q, src, smem, S);
+        pn2_f2 (&xx)[P / 2] = S.xx;
+        pn2_f2 (&yy)[P / 2] = S.yy;
+        pn2_f2 (&zz)[P / 2] = S.zz;
+        float (&md)[P] = S.md;
+        unsigned (&low)[P] = S.low;
+        if (lane == 0) { xch[0].bound[w] = 0u; xch[1].bound[w] = 0u; }     // only wave w ever raises bound[.][w]
+        // lane l tests samples against the box of THIS wave's group l % 8
+        float blx, bly, blz, bhx, bhy, bhz;
+        {
+            const float *gbox = reinterpret_cast<const float *>(smem + 256 + (size_t)16 * NS + (size_t)kPrHistRows * kPrBins * 4);
+            const float *o = gbox + (w * GW + (lane & (GW - 1))) * 8;
+            blx = o[0]; bly = o[1]; blz = o[2]; bhx = o[4]; bhy = o[5]; bhz = o[6];
+        }
+        pn2_f2 sxy = {0.f, 0.f}, syy = {0.f, 0.f}, szk = {0.f, 0.f};   // the sample in the LOW halves (fps_body.h: the high-half broadcast form is not safe)
+        auto update_group = [&](auto gic) __attribute__((always_inline)) {
+            constexpr int gi = decltype(gic)::value;
+            constexpr int H = GS / 2;
+            pn2_f2 dx[H], dy[H], dz[H];
+#pragma unroll
+            for (int h = 0; h < H; ++h) dx[h] = pk_sub_bcast_lo(xx[gi * H + h], sxy);
+#pragma unroll
+            for (int h = 0; h < H; ++h) dy[h] = pk_sub_bcast_lo(yy[gi * H + h], syy);
+#pragma unroll
+            for (int h = 0; h < H; ++h) dz[h] = pk_sub_bcast_lo(zz[gi * H + h], szk);
+#pragma unroll
+            for (int h = 0; h < H; ++h) dx[h] = pk_mul(dx[h], dx[h]);
+#pragma unroll
+            for (int h = 0; h < H; ++h) dy[h] = pk_mul(dy[h], dy[h]);
+#pragma unroll
+            for (int h = 0; h < H; ++h) dz[h] = pk_mul(dz[h], dz[h]);
+#pragma unroll
+            for (int h = 0; h < H; ++h) dx[h] = pk_add(dx[h], dy[h]);
+#pragma unroll
+            for (int h = 0; h < H; ++h) dx[h] = pk_add(dx[h], dz[h]);
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const int p0 = gi * GS + 2 * h;
+                md[p0] = vmin_f32(dx[h].x, md[p0]);              // min(d,td), tf_sampling_g.cu:144
+                md[p0 + 1] = vmin_f32(dx[h].y, md[p0 + 1]);
+            }
+        };
+        // sample 0 is point 0 (tf_sampling_g.cu:114-116): every slot against it
+        {
+            const float4 s = lds_rank[NS - 1];
+            sxy.x = s.x; syy.x = s.y; szk.x = s.z;
+            update_group(std::integral_constant<int, 0>()); update_group(std::integral_constant<int, 1>());
+            update_group(std::integral_constant<int, 2>()); update_group(std::integral_constant<int, 3>());
+            update_group(std::integral_constant<int, 4>()); update_group(std::integral_constant<int, 5>());
+            update_group(std::integral_constant<int, 6>()); update_group(std::integral_constant<int, 7>());
+        }
+        if (t == 0) {
+            dst[0] = 0;
+            if (PUBLISH) __hip_atomic_store(gtag, (unsigned long long)tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned vlastb = __float_as_uint(1e38f);    // value bits of the last sample: no running distance is above it
+        unsigned thetab = __float_as_uint(1e38f);    // first batch: nobody reaches it, every wave sends its exact best lane
+        int par = 0;
+        for (;;) {
+            BtXchg &X = xch[par];
+            const long long u0 = PN2_BT_CLOCK();
+            // ---- COLLECT ----------------------------------------------------------------------------------------------------------
+            double kl;
+            float sec;
+            {
+                // best key and the two largest values of the lane's P slots (straight-line: 2 P - 1 tournament nodes)
+                double kd[P];
+                float hv[P / 2], lv[P / 2];
+#pragma unroll
+                for (int p = 0; p < P; ++p) kd[p] = __hiloint2double(__float_as_int(md[p]), (int)low[p]);
+#pragma unroll
+                for (int i = 0; i < P / 2; ++i) { hv[i] = vmax_f32(md[2 * i], md[2 * i + 1]); lv[i] = vmin_f32(md[2 * i], md[2 * i + 1]); }
+#pragma unroll
+                for (int st = 1; st < P; st <<= 1)
+#pragma unroll
+                    for (int i = 0; i + st < P; i += 2 * st)
+                        asm("v_max_f64 %0, %1, %2" : "=v"(kd[i]) : "v"(kd[i]), "v"(kd[i + st]));
+#pragma unroll
+                for (int st = 1; st < P / 2; st <<= 1)
+#pragma unroll
+                    for (int i = 0; i + st < P / 2; i += 2 * st) {
+                        const float ll = vmax_f32(lv[i], lv[i + st]);
+                        lv[i] = vmed3_f32(hv[i], hv[i + st], ll);     // second largest of (h1 >= l1, h2 >= l2)
+                        hv[i] = vmax_f32(hv[i], hv[i + st]);
+                    }
+                kl = kd[0];
+                sec = lv[0];
+            }
+            const unsigned vb = (unsigned)__double2hiint(kl);
+            unsigned long long mask = __ballot(vb >= thetab);
+            int cnt = __popcll(mask);
+            unsigned thb = thetab;                   // this wave's threshold: its points outside the list are below it
+            bool exact = false;
+            if (cnt > kBtCap) {
+                unsigned lob = thetab, hib = vlastb + 1u;       // more than kBtCap lanes at lob, none at hib
+                for (int it = 0; it < 16; ++it) {
+                    const unsigned mid = lob + ((hib - lob) >> 1);
+                    if (mid == lob) break;
+                    const unsigned long long mk = __ballot(vb >= mid);
+                    const int c = __popcll(mk);
+                    PN2_BT_STAT(3, 1);
+                    if (c > kBtCap) lob = mid;
+                    else if (c == 0) hib = mid;
+                    else { mask = mk; cnt = c; thb = mid; break; }
+                }
+                exact = cnt > kBtCap;
+            } else if (cnt == 0) {
+                exact = true;
+            }
+            if (exact) {                              // the wave's best lane alone
+                PN2_BT_STAT(2, 1);
+                const double wk = wave_max_f64_lane63(kl);
+                const int bh = __builtin_amdgcn_readlane(__double2hiint(wk), 63), bl = __builtin_amdgcn_readlane(__double2loint(wk), 63);
+                unsigned long long mk = __ballot(__double2hiint(kl) == bh && __double2loint(kl) == bl);
+                mk &= 0ull - mk;                      // equal keys exist only among padding slots
+                if (cnt != 0) thb = (unsigned)bh + 1u;   // too many equal values: everything else of the wave is <= this lane's value, with a lower key
+                mask = mk;
+                cnt = 1;
+            }
+            if ((mask >> lane) & 1ull) {
+                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                X.list[w * kBtCap + pos] = kl;
+                lds_max_u32(&X.bound[w], __float_as_uint(sec) + 1u);
+            }
+            if (lane == 0) {
+                X.cnt[w] = (unsigned)cnt;
+                lds_max_u32(&X.bound[w], thb);
+            }
+            const long long u1 = PN2_BT_CLOCK();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm LDS operations above are invisible to the compiler's counters
+            __syncthreads();
+            const long long u2 = PN2_BT_CLOCK();
+            if (lane == 0) xch[par ^ 1].bound[w] = 0u;            // next batch's word of this wave (nobody reads it before the next barrier)
+            // ---- APPLY: the picker's samples as they appear ----------------------------------------------------------------------------
+            int done = 0;
+            unsigned c;
+            // v* of the skip test: the previous batch's last sample value bounds every running distance (fps_pruned_body: the exact skip)
+            const float thr = __fadd_rn(__fmul_rn(__uint_as_float(vlastb), 1.00001f), 1e-30f);
+            for (;;) {
+                c = __hip_atomic_load(&X.count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+                const int avail = (int)(c & kBtCountMask);
+                if (avail == done) {
+                    if (c & kBtEnd) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                const int np = min(avail - done, 8);
+                const int pi = lane >> 3;                                        // this lane's sample of the chunk
+                const float4 s = ring[done + (pi < np ? pi : 0)];
+                const float ax = __fsub_rn(s.x, __builtin_amdgcn_fmed3f(s.x, blx, bhx));
+                const float ay = __fsub_rn(s.y, __builtin_amdgcn_fmed3f(s.y, bly, bhy));
+                const float az = __fsub_rn(s.z, __builtin_amdgcn_fmed3f(s.z, blz, bhz));
+                const float bd = __fadd_rn(__fadd_rn(__fmul_rn(ax, ax), __fmul_rn(ay, ay)), __fmul_rn(az, az));
+                unsigned long long touched = ~__ballot(bd >= thr);               // NaN -> not far -> updated
+                if (np < 8) touched &= (1ull << (np * 8)) - 1ull;
+                while (touched) {
+                    const int bit = (int)__builtin_ctzll(touched);
+                    touched &= touched - 1ull;
+                    const int sl = bit & ~7;                                     // a lane that holds the sample
+                    sxy.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.x), sl));
+                    syy.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.y), sl));
+                    szk.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.z), sl));
+                    const int gi = bit & 7;
+                    PN2_BT_STAT(5, 1);
+                    if (gi < 4) {
+                        if (gi < 2) { if (gi == 0) update_group(std::integral_constant<int, 0>()); else update_group(std::integral_constant<int, 1>()); }
+                        else { if (gi == 2) update_group(std::integral_constant<int, 2>()); else update_group(std::integral_constant<int, 3>()); }
+                    } else {
+                        if (gi < 6) { if (gi == 4) update_group(std::integral_constant<int, 4>()); else update_group(std::integral_constant<int, 5>()); }
+                        else { if (gi == 6) update_group(std::integral_constant<int, 6>()); else update_group(std::integral_constant<int, 7>()); }
+                    }
+                }
+                done += np;
+            }
+            const long long u3 = PN2_BT_CLOCK();
+            if (w == 0) { PN2_BT_STAT(9, u1 - u0); PN2_BT_STAT(10, u3 - u2); }
+            const int a = (int)(c & kBtCountMask);
+            // ---- the batch's samples leave in one store ------------------------------------------------------------------------------
+            if (w == 0 && lane < a) {
+                const int k = __float_as_int(ring[lane].w);
+                dst[j + lane] = k;
+                if (PUBLISH)
+                    __hip_atomic_store(gtag + (j + lane), ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)k, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (c & kBtFill) fill_k = __float_as_int(ring[a - 1].w);
+            j += a;
+            if ((c & kBtFill) || j >= m) break;
+            thetab = X.theta;
+            vlastb = X.vlast;
+            par ^= 1;
+        }
+    }
+    if (fill_k >= 0) {
+        for (int i = j + t; i < m; i += kBtT) {
+            dst[i] = fill_k;
+            if (PUBLISH)
+                __hip_atomic_store(gtag + i, ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)fill_k, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    fps_gather_epilogue<kBtT>(m, src, dst, dxyz);
+}
+
+}  // namespace pn2

@@ -106,38 +106,40 @@ __device__ __forceinline__ float pr_minmax_lane63(float v)
     return v;
 }
 
-// P rank slots per thread, GS slots per group (both powers of two, GS even: the update runs on register pairs).
-template <int P, int GS, bool PUBLISH>
-__device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, const float *__restrict__ xyz,
-                                                int *__restrict__ out, float *__restrict__ out_xyz,
-                                                unsigned long long *__restrict__ tagged, char *smem, unsigned tag = 1u)
+// The slots of one thread after the grouping: coordinates as register pairs, running distances, key low words, and (lane l
+// = group l mod 32) the tight bounding box of a group.
+template <int P>
+struct PrSlots {
+    pn2_f2 xx[P / 2], yy[P / 2], zz[P / 2];
+    float md[P];
+    unsigned low[P];
+    float blx, bly, blz, bhx, bhy, bhz;
+};
+
+constexpr int kPrPrologueBarriers = 10;   // __syncthreads() executed by fps_pruned_prologue (a wave that sits the prologue out must match them)
+
+// Grouping prologue shared by the chains of fps_pruned_body (one sample per exchange) and fps_batch_body.h (several): deals the
+// cloud to the slots spatially, writes the rank-ordered LDS mirror and the group boxes. Ends behind a barrier.
+template <int P, int GS>
+__device__ __forceinline__ void fps_pruned_prologue(int n, int Q, const float *__restrict__ src, char *smem, PrSlots<P> &S)
 {
-    // A chain is one dependent instruction after another on b CUs; beside another stream's kernels (the layer stacks of the
-    // previous batch, pointnet2_amd/geometry.py) its waves would queue behind theirs at every issue. Highest wave priority: the
-    // neighbours lose a few issue slots on b of 256 CUs, the chain keeps its pace (sem_seg training step with the geometry one
-    // step ahead: 10.5 ms without this line, profiles/r05/geometry_ahead.txt).
-#ifndef PN2_NO_SETPRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
     constexpr int T = kPrT, W = kPrW, NS = T * P;
     constexpr int GW = P / GS;                    // groups per wave
     constexpr int G = W * GW;                     // groups = leaves = test lanes
     static_assert(G == kPrGroups && GW == 8 && (GS & 1) == 0, "32 groups: 16 slots per thread in groups of 2, 32 in groups of 4");
-
-    unsigned long long *partial = reinterpret_cast<unsigned long long *>(smem);        // [2][W]
     float *scratch = reinterpret_cast<float *>(smem + 64);                              // 48 floats
     float4 *lds_rank = reinterpret_cast<float4 *>(smem + 256);                          // mirror [NS], first the staging copy
     char *tab = smem + 256 + (size_t)16 * NS;
     int *hist = reinterpret_cast<int *>(tab);                                           // [1 + K0 + K0 * K1][64]: one histogram row per segment and level
     float *gbox = reinterpret_cast<float *>(tab + (size_t)kPrHistRows * kPrBins * 4);   // [G][8]
-
-    const float *__restrict__ src = xyz + (size_t)cloud * n * 3;
-    int *__restrict__ dst = out + (size_t)cloud * m;
-    float *__restrict__ dxyz = out_xyz ? out_xyz + (size_t)cloud * m * 3 : nullptr;
-    pn2_gu64 *gtag = PUBLISH ? (pn2_gu64 *)(tagged + (size_t)cloud * m) : nullptr;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    pn2_f2 (&xx)[P / 2] = S.xx;
+    pn2_f2 (&yy)[P / 2] = S.yy;
+    pn2_f2 (&zz)[P / 2] = S.zz;
+    float (&md)[P] = S.md;
+    unsigned (&low)[P] = S.low;
 
     // ---- the items in natural order: item i = point i, or (i >= n) a padding item at point 0's position ----------------
     float px[P], py[P], pz[P];
@@ -239,9 +241,7 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
         lds_rank[dt * P + dp] = make_float4(px[j], py[j], pz[j], __int_as_float(t + j * T));
     }
     __syncthreads();
-    pn2_f2 xx[P / 2], yy[P / 2], zz[P / 2];
-    float md[P];                                        // until the mirror is written: the bits of the slot's item number
-    unsigned low[P];
+    // md: until the mirror is written, the bits of the slot's item number
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const float4 v = lds_rank[t * P + p];
@@ -282,11 +282,49 @@ __device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, 
     }
     __syncthreads();
     // lane l tests group l (lanes beyond G repeat group l mod G; their bits are never looked at)
-    float blx, bly, blz, bhx, bhy, bhz;
     {
         const float *o = gbox + (lane & (G - 1)) * 8;
-        blx = o[0]; bly = o[1]; blz = o[2]; bhx = o[4]; bhy = o[5]; bhz = o[6];
+        S.blx = o[0]; S.bly = o[1]; S.blz = o[2]; S.bhx = o[4]; S.bhy = o[5]; S.bhz = o[6];
     }
+}
+
+// P rank slots per thread, GS slots per group (both powers of two, GS even: the update runs on register pairs).
+template <int P, int GS, bool PUBLISH>
+__device__ __forceinline__ void fps_pruned_body(int n, int m, int Q, int cloud, const float *__restrict__ xyz,
+                                                int *__restrict__ out, float *__restrict__ out_xyz,
+                                                unsigned long long *__restrict__ tagged, char *smem, unsigned tag = 1u)
+{
+    // A chain is one dependent instruction after another on b CUs; beside another stream's kernels (the layer stacks of the
+    // previous batch, pointnet2_amd/geometry.py) its waves would queue behind theirs at every issue. Highest wave priority: the
+    // neighbours lose a few issue slots on b of 256 CUs, the chain keeps its pace (sem_seg training step with the geometry one
+    // step ahead: 10.5 ms without this line, profiles/r05/geometry_ahead.txt).
+#ifndef PN2_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    constexpr int T = kPrT, W = kPrW, NS = T * P;
+    constexpr int GW = P / GS;                    // groups per wave
+    constexpr int G = W * GW;                     // groups = leaves = test lanes
+    static_assert(G == kPrGroups && GW == 8 && (GS & 1) == 0, "32 groups: 16 slots per thread in groups of 2, 32 in groups of 4");
+
+    unsigned long long *partial = reinterpret_cast<unsigned long long *>(smem);        // [2][W]
+    float4 *lds_rank = reinterpret_cast<float4 *>(smem + 256);                          // mirror [NS], first the staging copy
+
+    const float *__restrict__ src = xyz + (size_t)cloud * n * 3;
+    int *__restrict__ dst = out + (size_t)cloud * m;
+    float *__restrict__ dxyz = out_xyz ? out_xyz + (size_t)cloud * m * 3 : nullptr;
+    pn2_gu64 *gtag = PUBLISH ? (pn2_gu64 *)(tagged + (size_t)cloud * m) : nullptr;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+
+    PrSlots<P> S;
+    fps_pruned_prologue<P, GS>(n, Q, src, smem, S);
+    pn2_f2 (&xx)[P / 2] = S.xx;
+    pn2_f2 (&yy)[P / 2] = S.yy;
+    pn2_f2 (&zz)[P / 2] = S.zz;
+    float (&md)[P] = S.md;
+    unsigned (&low)[P] = S.low;
+    const float blx = S.blx, bly = S.bly, blz = S.blz, bhx = S.bhx, bhy = S.bhy, bhz = S.bhz;
 
     // ---- the chain -------------------------------------------------------------------------------------------------------
     // the point selected last (starts at k = 0 = rank 0), every coordinate in the LOW half of a register pair: the

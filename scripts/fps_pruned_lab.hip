@@ -23,7 +23,7 @@ static float timed(int reps, const std::function<void()> &fn)
 int main(int argc, char **argv)
 {
     const int b = 32;
-    for (int n : {4096, 8192, 3000}) {
+    for (int n : {4096, 8192}) {
         for (int kind = 0; kind < 2; ++kind) {
             const int m = n == 3000 ? 750 : 1024;
             std::vector<float> h((size_t)b * n * 3);
@@ -48,6 +48,7 @@ int main(int argc, char **argv)
                 {"full 512", [&](int mm) { return pn2_farthest_point_sample_ex(512, P512, b, n, mm, d_xyz, d_out, nullptr); }},
                 {"full 256", [&](int mm) { return pn2_farthest_point_sample_ex(256, P256, b, n, mm, d_xyz, d_out, nullptr); }},
                 {"pruned", [&](int mm) { return pn2_farthest_point_sample_variant(PN2_FPS_PRUNED, b, n, mm, d_xyz, nullptr, d_out, nullptr, nullptr); }},
+                {"batch", [&](int mm) { return pn2_farthest_point_sample_variant(PN2_FPS_BATCH, b, n, mm, d_xyz, nullptr, d_out, nullptr, nullptr); }},
             };
             for (size_t vi = 0; vi < vs.size(); ++vi) {
                 CK(hipMemset(d_out, 0xff, (size_t)b * m * 4));
@@ -58,6 +59,18 @@ int main(int argc, char **argv)
                 const float us = timed(5, [&]() { vs[vi].run(m); });
                 const float us1 = timed(5, [&]() { vs[vi].run(1); });
                 const float us_half = timed(5, [&]() { vs[vi].run(m / 2); });
+#ifdef PN2_BT_STATS
+                if (vi == 3) {
+                    unsigned long long z[16] = {0}, st[16];
+                    CK(hipMemcpyToSymbol(HIP_SYMBOL(pn2::g_bt_stats), z, sizeof(z)));
+                    vs[vi].run(m); CK(hipDeviceSynchronize());
+                    CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(pn2::g_bt_stats), sizeof(st)));
+                    printf("   cloud 0: batches %llu, samples %llu (%.2f per batch), exact fallbacks %llu, bisection steps %llu, list size %.1f, (group, sample) updates %llu, ties %llu, speculation misses %llu\n"
+                           "   cycles per batch: picker read %.0f, pick %.0f (%.0f per sample), picker at the barrier %.0f | updater 0: collect %.0f, barrier -> end flag %.0f\n",
+                           st[0], st[1], (double)st[1] / st[0], st[2], st[3], (double)st[4] / st[0], st[5], st[11], st[12], (double)st[6] / st[0], (double)st[7] / st[0],
+                           (double)st[7] / st[1], (double)st[8] / st[0], (double)st[9] / st[0], (double)st[10] / st[0]);
+                }
+#endif
                 printf("%-10s n=%5d %s m=%4d : %7.1f us, prologue (m=1) %6.1f us, %6.1f ns/round overall, %6.1f ns/round in the second half  %s\n",
                        vs[vi].name, n, kind ? "sphere" : "cube  ", m, us, us1, (us - us1) * 1e3f / (m - 1), (us - us_half) * 1e3f / (m - m / 2),
                        got == ref ? "same" : "DIFF");
