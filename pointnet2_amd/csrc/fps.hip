@@ -416,7 +416,7 @@ static int fps_entry(int b, int n, int m, const float *inp, float *temp, int *ou
     }
     const int Q = (n + kRefThreads - 1) / kRefThreads;
     const int ranks = kRefThreads * Q;
-    if (variant == PN2_FPS_BATCH) return fps_launch_batch(b, n, m, inp, out, out_xyz, st);
+    if (variant == PN2_FPS_BATCH || (variant == PN2_FPS_AUTO && fps_batch_pays(ranks, m))) return fps_launch_batch(b, n, m, inp, out, out_xyz, st);
     if (variant == PN2_FPS_PRUNED || (variant == PN2_FPS_AUTO && fps_pruned_pays(ranks, m)))
         return fps_launch_pruned(b, n, m, inp, out, out_xyz, st);
     // default geometry (measured, scripts/fps_prod_lab.hip, ns per round at n = 1024/2048/4096/8192):

@@ -34,7 +34,7 @@
 //   * APPLY (updaters, behind the picker). A wave polls the count, takes up to eight new samples at a time -- lane l tests
 //     sample l / 8 against the box of the wave's group l % 8: one distance-to-box computation for 64 (sample, group) pairs --
 //     and updates the touched groups (packed fp32, as in the pruned tier; no key work: keys are only needed at COLLECT). The skip test uses the value of the previous batch's LAST sample as v* (no running distance is above it).
-//   * theta = (1 - g) * (value of the last sample); g adapts so that the list stays about two thirds full. The picker decides
+//   * theta = (1 - g) * (value of the last sample); g adapts so that the list stays about half full. The picker decides
 //     and publishes theta with the end-of-batch flag.
 //
 // Once a sample's value is 0 every running distance is 0 and the reference keeps selecting point 0 (its tie rule): the rest of
@@ -89,7 +89,7 @@ __device__ __forceinline__ float vmed3_f32(float a, float b, float c)
 
 // wave-wide signed maximum, result in lane 63: the DPP operand rides on the v_max itself (VOP2), one instruction per step.
 // Lanes without a source (bound_ctrl:0 reads 0) combine with 0 -- harmless for a maximum of values of which at least one is >= 0.
-__device__ __forceinline__ int wave_max_i32_lane63(int v)
+__device__ __forceinline__ int bt_wave_max_i32_lane63(int v)
 {
     // written with the builtin so that the compiler folds the v_mov_dpp into the v_max (GCNDPPCombine), keeps track of the DPP
     // hazards itself and schedules independent work into the wait states
@@ -111,6 +111,11 @@ __device__ __forceinline__ void lds_max_u32(unsigned *p, unsigned v)
     asm volatile("ds_max_u32 %0, %1" :: "v"((unsigned)(size_t)p), "v"(v) : "memory");
 }
 
+// Where the batched tier pays (measured, profiles/r06/fps_batch.txt): its first ~64 samples come in batches of three or four and
+// cost ~650 ns each against the full tier's 385, from ~200 samples on a sample is 200-210 ns against 325-390 (pruned / full).
+// Break-even against the better of the other two tiers: npoint ~ 320 at 4096 rank slots, ~ 260 at 8192.
+inline bool fps_batch_pays(int ranks, int m) { return ranks > 2048 && ranks <= 8192 && m >= 384; }
+
 #ifdef PN2_BT_STATS
 // lab: [0] batches, [1] samples, [2] exact fallbacks, [3] bisection steps, [4] sum of list sizes, [5] (group, sample) updates,
 // [6] picker cycles in READ, [7] picker cycles in PICK, [8] picker cycles waiting at the barrier, [9] updater 0 cycles in COLLECT,
@@ -127,6 +132,13 @@ __device__ unsigned long long g_bt_stats[16];
 #pragma clang diagnostic ignored "-Wunused-variable"
 #endif
 
+#ifndef PN2_BT_LIST_HI
+#define PN2_BT_LIST_HI 36      // measured: 44 / 28 +1.7 %, 54 / 40 +6 %, 28 / 14 +2 %, 20 / 10 +7 % (profiles/r06/fps_batch.txt)
+#define PN2_BT_LIST_LO 20
+#endif
+#ifndef PN2_BT_ALL_FROM
+#define PN2_BT_ALL_FROM 4          // a sample that reaches this many of a wave's eight groups updates all eight in straight-line code
+#endif
 #ifndef PN2_BT_G0
 #define PN2_BT_G0 0.10f               // initial 1 - theta / (last sample value)
 #endif
@@ -191,7 +203,7 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
             unsigned long long eq;                                               // one bit: the winner's lane
             // the exact arg-max of the current values: value ladder, then the 64-bit keys among equal values
             auto argmax = [&]() __attribute__((always_inline)) {
-                bh = __builtin_amdgcn_readlane(wave_max_i32_lane63(cval), 63);
+                bh = __builtin_amdgcn_readlane(bt_wave_max_i32_lane63(cval), 63);
                 eq = __ballot(cval == bh);
                 if (__popcll(eq) != 1) {
                     PN2_BT_STAT(11, 1);
@@ -222,7 +234,7 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
                 // SPECULATION: the maximum of the values as they are BEFORE this sample's update is computed in the shadow of the
                 // update. Values only fall: a lane that still holds that maximum afterwards is the arg-max -- if it is the only one.
                 // (A sample of value 0 ends the batch by itself: nothing is above the bound afterwards.)
-                const int ms = __builtin_amdgcn_readlane(wave_max_i32_lane63(cval), 63);
+                const int ms = __builtin_amdgcn_readlane(bt_wave_max_i32_lane63(cval), 63);
                 const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand.x), wl));
                 const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand.y), wl));
                 const float sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand.z), wl));
@@ -239,9 +251,9 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
             }
             if (vlastb == 0) { fill = true; fill_k = __builtin_amdgcn_readlane(__float_as_int(cand.w), (int)__builtin_ctzll(eq)); }   // every running distance is 0 from here on
             const long long q3 = PN2_BT_CLOCK();
-            // the list about two thirds full
-            if (total > 44) g = fmaxf(g * 0.8f, 1.0f / 128.0f);
-            else if (total < 28) g = fminf(g * 1.25f, 0.5f);
+            // the list about half full
+            if (total > PN2_BT_LIST_HI) g = fmaxf(g * 0.8f, 1.0f / 128.0f);
+            else if (total < PN2_BT_LIST_LO) g = fminf(g * 1.25f, 0.5f);
             X.theta = __float_as_uint(__fmul_rn(__int_as_float(vlastb), 1.0f - g));
             X.vlast = (unsigned)vlastb;
             if (lane == 0)
@@ -419,6 +431,16 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
                     szk.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.z), sl));
                     const int gi = bit & 7;
                     PN2_BT_STAT(5, 1);
+                    if (__popcll(touched >> sl & 0xffull) >= PN2_BT_ALL_FROM - 1) {
+                        // most of the wave's groups (the first samples of a cloud): straight-line over all of them is cheaper than a
+                        // dispatch per group, and an update of an untouched group changes nothing
+                        touched &= ~(0xffull << sl);
+                        update_group(std::integral_constant<int, 0>()); update_group(std::integral_constant<int, 1>());
+                        update_group(std::integral_constant<int, 2>()); update_group(std::integral_constant<int, 3>());
+                        update_group(std::integral_constant<int, 4>()); update_group(std::integral_constant<int, 5>());
+                        update_group(std::integral_constant<int, 6>()); update_group(std::integral_constant<int, 7>());
+                        continue;
+                    }
                     if (gi < 4) {
                         if (gi < 2) { if (gi == 0) update_group(std::integral_constant<int, 0>()); else update_group(std::integral_constant<int, 1>()); }
                         else { if (gi == 2) update_group(std::integral_constant<int, 2>()); else update_group(std::integral_constant<int, 3>()); }

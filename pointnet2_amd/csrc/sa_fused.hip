@@ -54,6 +54,7 @@
 #include "ball_query_body.h"
 #include "fps_body.h"
 #include "fps_pruned_body.h"
+#include "fps_batch_body.h"
 
 #include <limits.h>
 
@@ -108,9 +109,10 @@ static int g_lab_clear_with_kernel = 0;
 
 // LPQ: lanes per query of the cell-list consumers; 0 = sweep consumers (clouds whose cell list does not fit
 // beside the position table: n > ~6000).
-// PRUNED: the producers run the kd-grouped chain of fps_pruned_body.h (4096 / 8192 rank slots: P = 8, 16) on four waves.
+// TIER of the producers: 0 = fps_reg_body; 1 = the kd-grouped chain of fps_pruned_body.h (4096 / 8192 rank slots: P = 8, 16) on four
+// waves; 2 = the same slots with several samples per exchange (fps_batch_body.h: four updater waves and the picker, 320 threads).
 constexpr int fused_pruned_gs(int P) { return P == 8 ? 2 : 4; }       // slots per group at 16 / 32 slots per thread
-template <int P, int LPQ, bool PRUNED = false>
+template <int P, int LPQ, int TIER = 0>
 __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, int m, int Q, int nsample, float thr,
                                                                  float radius, int qpb, int cpc, unsigned tag,
                                                                  const float *__restrict__ xyz,
@@ -165,7 +167,10 @@ __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, i
         // at n = 1024, 312 vs 326 at 2048: a smaller block-wide arg-max; profiles/r02/fps_experiments.txt), which is what
         // pn2_farthest_point_sample launches at these sizes: the upper four waves of a producer retire at once
         // (a retired wave no longer counts at the workgroup's barriers).
-        if constexpr (PRUNED) {
+        if constexpr (TIER == 2) {
+            if (threadIdx.x >= kBtT) return;
+            fps_batch_body<2 * P, fused_pruned_gs(P), PN2_FUSED_LAB_PUBLISH>(n, m, Q, blk, xyz, fps_idx, nullptr, tagged, smem, tag);
+        } else if constexpr (TIER == 1) {
             if (threadIdx.x >= kPrT) return;
             fps_pruned_body<2 * P, fused_pruned_gs(P), PN2_FUSED_LAB_PUBLISH>(n, m, Q, blk, xyz, fps_idx, nullptr, tagged, smem, tag);
         } else if constexpr (kFusedThreads * P <= 2048) {
@@ -221,7 +226,7 @@ static size_t fused_cells_lds(int n, int nsample, int lpq)
     return cells > sweep ? cells : sweep;
 }
 
-template <int P, int LPQ, bool PRUNED = false>
+template <int P, int LPQ, int TIER = 0>
 static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, float radius, unsigned tag, const float *xyz,
                         unsigned long long *ws, int *fps_idx, float *new_xyz, int *idx, int *pts_cnt,
                         float *grouped, int subtract, hipStream_t st, int consumers)
@@ -232,14 +237,14 @@ static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, floa
     if (qpb > m) qpb = ((m + kGran - 1) / kGran) * kGran;
     const int nranges = (m + qpb - 1) / qpb;
     const int nq = consumers <= 0 ? (nranges < kFusedConsumers ? nranges : kFusedConsumers) : consumers < nranges ? consumers : nranges;
-    size_t lds_f = PRUNED ? fps_pruned_lds_bytes(2 * P)
-                          : 256 + sizeof(float4) * (size_t)kFusedThreads * P;
+    size_t lds_f = TIER == 2 ? fps_batch_lds_bytes(2 * P) : TIER == 1 ? fps_pruned_lds_bytes(2 * P)
+                                                                       : 256 + sizeof(float4) * (size_t)kFusedThreads * P;
     size_t lds_q = LPQ ? fused_cells_lds(n, nsample, LPQ)
                        : sizeof(float4) * (size_t)((n + 127) & ~127) + sizeof(int) * (size_t)nsample * kGran;
     size_t lds = lds_f > lds_q ? lds_f : lds_q;
     if (lds < kFusedMinLds) lds = kFusedMinLds;
     if (lds > 160 * 1024) return PN2_E_TOO_LARGE;
-    auto kern = sa_fused_kernel<P, LPQ, PRUNED>;
+    auto kern = sa_fused_kernel<P, LPQ, TIER>;
     if (int rc = allow_dynamic_lds(kern, lds)) return rc;
     {
         // residency (header): room for every producer at the same time. Consumers only ever wait for producers and producers wait
@@ -300,7 +305,7 @@ static int sample_and_group_common(int b, int n, int m, float radius, int nsampl
         cs = hipStreamCaptureStatusNone;                          // the lab build captures the cleared form, as rounds 2-4 did
 #endif
         if (cs != hipStreamCaptureStatusNone) {
-            if (fps_variant < PN2_FPS_AUTO || fps_variant > PN2_FPS_PRUNED) return PN2_E_ARG;
+            if (fps_variant < PN2_FPS_AUTO || fps_variant > PN2_FPS_BATCH) return PN2_E_ARG;
             if (int rc = pn2_farthest_point_sample_variant(fps_variant, b, n, m, xyz, nullptr, fps_idx, new_xyz, stream)) return rc;
             return pn2_query_ball_group_xyz(b, n, m, radius, nsample, xyz, new_xyz, subtract_centroid, idx, pts_cnt, grouped_xyz, stream);
         }
@@ -322,22 +327,25 @@ static int sample_and_group_common(int b, int n, int m, float radius, int nsampl
     // two launches 459 us (sem_seg SA1, b = 8, 8192 -> 1024; profiles/r05/fused_sweep_consumers.txt). The library's own choice
     // there is the two launches -- same outputs, `ws` untouched; an explicit consumer count still gets the overlapped launch.
     if (lpq == 0 && n >= 1024 && consumers == 0) {
-        if (fps_variant < PN2_FPS_AUTO || fps_variant > PN2_FPS_PRUNED) return PN2_E_ARG;
+        if (fps_variant < PN2_FPS_AUTO || fps_variant > PN2_FPS_BATCH) return PN2_E_ARG;
         if (int rc = pn2_farthest_point_sample_variant(fps_variant, b, n, m, xyz, nullptr, fps_idx, new_xyz, stream)) return rc;
         return pn2_query_ball_group_xyz(b, n, m, radius, nsample, xyz, new_xyz, subtract_centroid, idx, pts_cnt, grouped_xyz, stream);
     }
     // producers: the kd-grouped chain where it exists (4096 / 8192 rank slots) and the chain is long enough to pay for the
     // kd build (the rule of pn2_farthest_point_sample, fps.hip)
-    if (fps_variant < PN2_FPS_AUTO || fps_variant > PN2_FPS_PRUNED) return PN2_E_ARG;
-    if (fps_variant == PN2_FPS_PRUNED && P != 8 && P != 16) return PN2_E_ARG;
-    const bool pruned = fps_variant == PN2_FPS_PRUNED || (fps_variant == PN2_FPS_AUTO && fps_pruned_pays(ranks, m));
+    if (fps_variant < PN2_FPS_AUTO || fps_variant > PN2_FPS_BATCH) return PN2_E_ARG;
+    if ((fps_variant == PN2_FPS_PRUNED || fps_variant == PN2_FPS_BATCH) && P != 8 && P != 16) return PN2_E_ARG;
+    const int tier = fps_variant == PN2_FPS_BATCH || (fps_variant == PN2_FPS_AUTO && fps_batch_pays(ranks, m))     ? 2
+                     : fps_variant == PN2_FPS_PRUNED || (fps_variant == PN2_FPS_AUTO && fps_pruned_pays(ranks, m)) ? 1
+                                                                                                                    : 0;
 #define PN2_FUSED_CASE(PP, LL, PR)                                                                                     \
-    if (P == PP && lpq == LL && pruned == PR)                                                                          \
+    if (P == PP && lpq == LL && tier == PR)                                                                            \
         return launch_fused<PP, LL, PR>(b, n, m, Q, nsample, thr, radius, tag, xyz, w, fps_idx, new_xyz, idx, pts_cnt,   \
                                         grouped_xyz, subtract_centroid, st, consumers)
 #define PN2_FUSED_P(PP, PR) PN2_FUSED_CASE(PP, 0, PR); PN2_FUSED_CASE(PP, 8, PR); PN2_FUSED_CASE(PP, 16, PR); PN2_FUSED_CASE(PP, 32, PR)
-    PN2_FUSED_P(1, false); PN2_FUSED_P(2, false); PN2_FUSED_P(4, false); PN2_FUSED_P(8, false); PN2_FUSED_P(16, false);
-    PN2_FUSED_P(8, true); PN2_FUSED_P(16, true);
+    PN2_FUSED_P(1, 0); PN2_FUSED_P(2, 0); PN2_FUSED_P(4, 0); PN2_FUSED_P(8, 0); PN2_FUSED_P(16, 0);
+    PN2_FUSED_P(8, 1); PN2_FUSED_P(16, 1);
+    PN2_FUSED_P(8, 2); PN2_FUSED_P(16, 2);
 #undef PN2_FUSED_P
 #undef PN2_FUSED_CASE
     return PN2_E_TOO_LARGE;

@@ -91,13 +91,14 @@ def gather_point(inp, idx, out=None):
 
 # Tier of the farthest-point-sampling kernels, passed with every call (pn2_farthest_point_sample_variant): 0 = the
 # library's size rule, 1 = every point updated every round (csrc/fps_body.h), 2 = kd-grouped slots with exact box pruning
-# (csrc/fps_pruned_body.h; 2049..8192 rank slots only). Results never depend on it: the tests force every tier.
-FPS_AUTO, FPS_FULL, FPS_PRUNED = 0, 1, 2
+# (csrc/fps_pruned_body.h; 2049..8192 rank slots only), 3 = the same slots with several samples per arg-max exchange
+# (csrc/fps_batch_body.h, round 6; same sizes). Results never depend on it: the tests force every tier.
+FPS_AUTO, FPS_FULL, FPS_PRUNED, FPS_BATCH = 0, 1, 2, 3
 _FPS_VARIANT = [FPS_AUTO]
 
 
 def set_fps_variant(variant=FPS_AUTO):
-    require(int(variant) in (FPS_AUTO, FPS_FULL, FPS_PRUNED), "fps variant must be 0 (auto), 1 (full) or 2 (pruned)")
+    require(int(variant) in (FPS_AUTO, FPS_FULL, FPS_PRUNED, FPS_BATCH), "fps variant must be 0 (auto), 1 (full), 2 (pruned) or 3 (batched)")
     _FPS_VARIANT[0] = int(variant)
 
 

@@ -25,7 +25,7 @@ int main(int argc, char **argv)
     const int b = 32;
     for (int n : {4096, 8192}) {
         for (int kind = 0; kind < 2; ++kind) {
-            const int m = n == 3000 ? 750 : 1024;
+            const int m = getenv("LAB_M") ? atoi(getenv("LAB_M")) : n == 3000 ? 750 : 1024;
             std::vector<float> h((size_t)b * n * 3);
             uint32_t s = 12345u + kind;
             auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };

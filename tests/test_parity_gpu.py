@@ -146,15 +146,16 @@ def test_fps_pruned_tier_index_exact(cuda, oracle, name, make, m, gs):
     x = dev(xyz, cuda)
     st = torch.cuda.current_stream().cuda_stream
     for rep in range(2):                                             # the kd build's tickets are timing dependent; results are not
-        out = torch.full((b, m), -1, dtype=torch.int32, device=cuda)
-        rc = _C.lib().pn2_farthest_point_sample_variant(2, b, n, m, x.data_ptr(), None, out.data_ptr(), None, st)
-        assert rc == 0, rc
-        got = host(out)
-        assert np.array_equal(got, want), "%s rep %d: first mismatch at %s" % (name, rep, np.argwhere(got != want)[:3])
+        for tier in (2, 3):                                          # pruned, batched (round 6: fps_batch_body.h on the same slots)
+            out = torch.full((b, m), -1, dtype=torch.int32, device=cuda)
+            rc = _C.lib().pn2_farthest_point_sample_variant(tier, b, n, m, x.data_ptr(), None, out.data_ptr(), None, st)
+            assert rc == 0, rc
+            got = host(out)
+            assert np.array_equal(got, want), "%s tier %d rep %d: first mismatch at %s" % (name, tier, rep, np.argwhere(got != want)[:3])
     # the same through the operator with the tier forced, incl. the fused gather
     import pointnet2_amd as P
     from pointnet2_amd import tf_sampling
-    for variant in (tf_sampling.FPS_PRUNED, tf_sampling.FPS_FULL, tf_sampling.FPS_AUTO):
+    for variant in (tf_sampling.FPS_PRUNED, tf_sampling.FPS_BATCH, tf_sampling.FPS_FULL, tf_sampling.FPS_AUTO):
         tf_sampling.set_fps_variant(variant)
         try:
             idx, new_xyz = P.farthest_point_sample_gather(m, x)
@@ -172,6 +173,7 @@ def test_fps_pruned_tier_refuses_other_sizes(cuda):
         x = torch.rand((1, n, 3), device=cuda)
         out = torch.zeros((1, 8), dtype=torch.int32, device=cuda)
         assert _C.lib().pn2_farthest_point_sample_variant(2, 1, n, 8, x.data_ptr(), None, out.data_ptr(), None, st) == -3 or n > 16384
+        assert _C.lib().pn2_farthest_point_sample_variant(3, 1, n, 8, x.data_ptr(), None, out.data_ptr(), None, st) == -3 or n > 16384
 
 
 def test_fps_gather_fused(cuda, oracle):
