@@ -89,7 +89,7 @@ TIMED_KERNEL = {"overlap": "sa_fused_kernel (pn2_sample_and_group_xyz: the whole
 class Stage:
     """The launches of one step, through the C ABI, with preallocated buffers."""
 
-    fps_variant = 0        # PN2_FPS_AUTO / _FULL (1) / _PRUNED (2): --fps-variant, results never depend on it
+    fps_variant = 0        # PN2_FPS_AUTO / _FULL (1) / _PRUNED (2) / _BATCH (3): --fps-variant, results never depend on it
     consumers = 0          # persistent consumer workgroups per cloud of the overlapped launch (0 = the library's choice)
 
     def __init__(self, dev, xyz_np, radius=RADIUS):
@@ -573,7 +573,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--path", choices=("overlap", "fused", "ops"), default="overlap")
-    ap.add_argument("--fps-variant", choices=("auto", "full", "pruned"), default="auto",
+    ap.add_argument("--fps-variant", choices=("auto", "full", "pruned", "batch"), default="auto",
                     help="FPS tier of every launch (pn2_farthest_point_sample_variant): auto = the library's rule")
     ap.add_argument("--consumers", type=int, default=0, help="consumer workgroups per cloud of the overlapped launch (0 = library default)")
     ap.add_argument("--streams", type=int, default=8, help="batches in flight for the extra `concurrent` figure (0 = skip)")
@@ -586,7 +586,7 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(respawn(args))
 
-    Stage.fps_variant = {"auto": 0, "full": 1, "pruned": 2}[args.fps_variant]
+    Stage.fps_variant = {"auto": 0, "full": 1, "pruned": 2, "batch": 3}[args.fps_variant]
     Stage.consumers = args.consumers
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -753,16 +753,20 @@ def main():
             total_k = sum(kt.values())
             t_full = event_time(lambda: stage.fps_(1))
             t_pruned = event_time(lambda: stage.fps_(2))
+            t_batch = event_time(lambda: stage.fps_(3))
             line["fps_latency_model"] = {"rounds": M - 1, "ns_per_round": kt["farthest_point_sample"] / (M - 1) * 1e9,
                                          "kernel_us": kt["farthest_point_sample"] * 1e6,
                                          "tiers": {"full_us": t_full * 1e6, "full_ns_per_round": t_full / (M - 1) * 1e9,
                                                    "pruned_us": t_pruned * 1e6, "pruned_ns_per_round": t_pruned / (M - 1) * 1e9,
+                                                   "batch_us": t_batch * 1e6, "batch_ns_per_sample": t_batch / (M - 1) * 1e9,
                                                    "note": "full = every running distance updated every round (fps_body.h); pruned = "
                                                            "kd-grouped slots, only the groups the new sample can reach are updated "
-                                                           "(fps_pruned_body.h; its kd build is inside the figure); same indices"},
+                                                           "(fps_pruned_body.h; its kd build is inside the figure); batch (round 6, what "
+                                                           "the operator launches at this shape) = the pruned tier's slots, several "
+                                                           "samples per arg-max exchange (fps_batch_body.h); same indices"},
                                          "share_of_step": kt["farthest_point_sample"] / launch_s,
-                                         "note": "m-1 dependent rounds of (distance update, block-wide arg-max); "
-                                                 "per-round floor analysis in DESIGN.md section 4.1"}
+                                         "note": "m-1 dependent samples; rounds 1-5: one block-wide arg-max exchange per sample, round 6: "
+                                                 "one exchange per batch of ~12 samples behind the first 64 (DESIGN.md section 4.1, 4.1d)"}
             line["kernels"] = {k: {"us": v * 1e6, "algorithmic_GBps": BYTES[k] * b_local / v / 1e9,
                                    "frac_of_hbm_peak": BYTES[k] * b_local / v / 1e9 / HBM_PEAK_GBS} for k, v in kt.items()}
             line["fused_kernels"] = {k: {"us": v * 1e6} for k, v in ktf.items()}

@@ -111,10 +111,11 @@ __device__ __forceinline__ void lds_max_u32(unsigned *p, unsigned v)
     asm volatile("ds_max_u32 %0, %1" :: "v"((unsigned)(size_t)p), "v"(v) : "memory");
 }
 
-// Where the batched tier pays (measured, profiles/r06/fps_batch.txt): its first ~64 samples come in batches of three or four and
-// cost ~650 ns each against the full tier's 385, from ~200 samples on a sample is 200-210 ns against 325-390 (pruned / full).
-// Break-even against the better of the other two tiers: npoint ~ 320 at 4096 rank slots, ~ 260 at 8192.
-inline bool fps_batch_pays(int ranks, int m) { return ranks > 2048 && ranks <= 8192 && m >= 384; }
+// Where the batched tier pays (measured, profiles/r06/fps_batch.txt): its grouping prologue costs what the pruned tier's does
+// (8.5 / 14 us more than the full tier's), its first PN2_BT_EARLY samples cost the full tier's round, from ~200 samples on a
+// sample is 200-210 ns against 325-390 (pruned / full). npoint = 256: 95-99 us against 102 (full) at 4096 rank slots, 122-128
+// against 134-143 (pruned) at 8192.
+inline bool fps_batch_pays(int ranks, int m) { return ranks > 2048 && ranks <= 8192 && m >= 256; }
 
 #ifdef PN2_BT_STATS
 // lab: [0] batches, [1] samples, [2] exact fallbacks, [3] bisection steps, [4] sum of list sizes, [5] (group, sample) updates,
@@ -135,6 +136,9 @@ __device__ unsigned long long g_bt_stats[16];
 #ifndef PN2_BT_LIST_HI
 #define PN2_BT_LIST_HI 36      // measured: 44 / 28 +1.7 %, 54 / 40 +6 %, 28 / 14 +2 %, 20 / 10 +7 % (profiles/r06/fps_batch.txt)
 #define PN2_BT_LIST_LO 20
+#endif
+#ifndef PN2_BT_EARLY
+#define PN2_BT_EARLY 48            // the first samples of a cloud are taken one per exchange (below; 32 / 64 / 96 measured: 255.7 / 255.5 / 261.9 us, none: 280.4)
 #endif
 #ifndef PN2_BT_ALL_FROM
 #define PN2_BT_ALL_FROM 4          // a sample that reaches this many of a wave's eight groups updates all eight in straight-line code
@@ -164,6 +168,7 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
 
     int j = 1;                                   // samples written so far (wave-uniform, the same in every wave)
+    const int jE = min(PN2_BT_EARLY, m);         // samples 1 .. jE - 1 are taken one per exchange
     int fill_k = -1;                             // >= 0: the cloud ran out of distinct points at sample j, the rest is this index
 
     if (w == W) {
@@ -173,8 +178,10 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
 #endif
         if (lane == 0) { xch[0].count = 0u; xch[1].count = 0u; }
         for (int i = 0; i < kPrPrologueBarriers; ++i) __syncthreads();
+        for (; j < jE; ++j) __syncthreads();     // the updaters' early rounds: one barrier each
         float g = PN2_BT_G0;
         int par = 0;
+        if (j < m)
         for (;;) {
             const long long q0 = PN2_BT_CLOCK();
             __syncthreads();                     // the list of this batch is complete
@@ -323,7 +330,52 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
         }
         unsigned vlastb = __float_as_uint(1e38f);    // value bits of the last sample: no running distance is above it
         unsigned thetab = __float_as_uint(1e38f);    // first batch: nobody reaches it, every wave sends its exact best lane
+        // ---- EARLY: the first samples, one per exchange (the full tier's round, fps_body.h) --------------------------------------
+        // While the farthest-point distance still halves every few samples a list determines three or four samples and every
+        // sample reaches most groups: a batch then costs more than the classic round (measured: the first 64 samples 44 us in
+        // batches, 25 us like this; the whole chain at 4096 -> 1024 280 -> 255 us). The picker and its barriers: one per round, see its branch.
+        {
+            double *partial = reinterpret_cast<double *>(smem);                  // [2][W]: the pruned layout's wave keys
+            for (; j < jE; ++j) {
+                double kd[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p) kd[p] = __hiloint2double(__float_as_int(md[p]), (int)low[p]);
+#pragma unroll
+                for (int st = 1; st < P; st <<= 1)
+#pragma unroll
+                    for (int i = 0; i + st < P; i += 2 * st)
+                        asm("v_max_f64 %0, %1, %2" : "=v"(kd[i]) : "v"(kd[i]), "v"(kd[i + st]));
+                const double wd = wave_max_f64_lane63(kd[0]);
+                double *slot = partial + (j & 1) * W;
+                if (lane == 63) slot[w] = wd;
+                __syncthreads();
+                double key[W];
+#pragma unroll
+                for (int i = 0; i < W; ++i) key[i] = slot[i];
+#pragma unroll
+                for (int st = 1; st < W; st <<= 1)
+#pragma unroll
+                    for (int i = 0; i + st < W; i += 2 * st)
+                        asm("v_max_f64 %0, %1, %2" : "=v"(key[i]) : "v"(key[i]), "v"(key[i + st]));
+                vlastb = (unsigned)__double2hiint(key[0]);
+                const float4 s = lds_rank[(unsigned)__double2loint(key[0])];    // same address in every lane: LDS broadcast
+                if (t == 0) {
+                    const int k = __float_as_int(s.w);
+                    dst[j] = k;
+                    if (PUBLISH)
+                        __hip_atomic_store(gtag + j, ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)k, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                }
+                sxy.x = s.x; syy.x = s.y; szk.x = s.z;
+                update_group(std::integral_constant<int, 0>()); update_group(std::integral_constant<int, 1>());
+                update_group(std::integral_constant<int, 2>()); update_group(std::integral_constant<int, 3>());
+                update_group(std::integral_constant<int, 4>()); update_group(std::integral_constant<int, 5>());
+                update_group(std::integral_constant<int, 6>()); update_group(std::integral_constant<int, 7>());
+            }
+            if (jE > 1) thetab = __float_as_uint(__fmul_rn(__uint_as_float(vlastb), 1.0f - PN2_BT_G0));
+        }
         int par = 0;
+        if (j < m)
         for (;;) {
             BtXchg &X = xch[par];
             const long long u0 = PN2_BT_CLOCK();
