@@ -62,6 +62,7 @@ __global__ __launch_bounds__(kPrT) void fps_pruned_kernel(int n, int m, int Q, c
 }
 
 // Batched tier (fps_batch_body.h): the pruned tier's slots and boxes, several samples per arg-max exchange.
+// P = slots per updater thread (kBtUT of them), GS slots per group
 template <int P, int GS>
 __global__ __launch_bounds__(kBtT) void fps_batch_kernel(int n, int m, int Q, const float *__restrict__ xyz,
                                                          int *__restrict__ out, float *__restrict__ out_xyz)
@@ -342,8 +343,9 @@ static int fps_launch_batch(int b, int n, int m, const float *inp, int *out, flo
     const int Q = (n + kRefThreads - 1) / kRefThreads;
     const int ranks = kRefThreads * Q;
     if (!pruned_covers(ranks)) return PN2_E_ARG;
-    if (ranks <= 4096) return launch_batch<16, 2>(b, n, m, Q, inp, out, oxyz, st);
-    return launch_batch<32, 4>(b, n, m, Q, inp, out, oxyz, st);
+    // 32 groups either way: at 512 updater threads 8 slots per thread in groups of 2 or 16 in groups of 4
+    if (ranks <= 4096) return launch_batch<4096 / kBtUT, 4096 / kBtUT / (32 / (kBtUT / 64))>(b, n, m, Q, inp, out, oxyz, st);
+    return launch_batch<8192 / kBtUT, 8192 / kBtUT / (32 / (kBtUT / 64))>(b, n, m, Q, inp, out, oxyz, st);
 }
 
 constexpr int kMaxLdsSlots = 8192;     // 256 B + 16 B per rank slot <= 160 KiB

@@ -54,16 +54,19 @@
 
 namespace pn2 {
 
-constexpr int kBtCap = 16;                     // candidate lanes per updater wave
-constexpr int kBtCand = kPrW * kBtCap;         // 64 = the picker's lanes
-constexpr int kBtT = kPrT + PN2_WAVE;          // 320 threads
-static_assert(kBtCand == 64, "one candidate per picker lane");
+constexpr int kBtCand = PN2_WAVE;              // 64 candidates = the picker's lanes: 64 / W candidate lanes per updater wave
+constexpr int kBtMaxW = 8;                     // updater waves: 4 (one per SIMD) or 8 (two per SIMD)
+#ifndef PN2_BT_UT
+#define PN2_BT_UT 512                          // updater threads of the product
+#endif
+constexpr int kBtUT = PN2_BT_UT;
+constexpr int kBtT = kBtUT + PN2_WAVE;         // + the picker
 constexpr unsigned kBtEnd = 0x100u, kBtFill = 0x200u, kBtCountMask = 0xffu;
 
 struct BtXchg {
-    double list[kBtCand];                      // wave w's candidates at [w * kBtCap, w * kBtCap + cnt[w])
-    unsigned cnt[kPrW];
-    unsigned bound[kPrW];
+    double list[kBtCand];                      // wave w's candidates at [w * cap, w * cap + cnt[w]), cap = 64 / W
+    unsigned cnt[kBtMaxW];
+    unsigned bound[kBtMaxW];
     unsigned count;                            // samples of this batch published so far | kBtEnd | kBtFill
     unsigned pad0;
     unsigned theta, vlast;                     // for the NEXT collect: threshold bits, value bits of the batch's last sample
@@ -71,8 +74,9 @@ struct BtXchg {
 };
 static_assert(sizeof(BtXchg) % 16 == 0, "16-byte rows");
 
-__host__ __device__ constexpr size_t fps_batch_xchg_offset(int P) { return (fps_pruned_lds_bytes(P) + 15) & ~(size_t)15; }
-__host__ __device__ constexpr size_t fps_batch_lds_bytes(int P) { return fps_batch_xchg_offset(P) + 2 * sizeof(BtXchg) + 16 * kBtCand; }
+// P = slots per updater thread, UT = updater threads
+__host__ __device__ constexpr size_t fps_batch_xchg_offset(int P, int UT = kBtUT) { return (fps_pruned_lds_bytes(P, UT) + 15) & ~(size_t)15; }
+__host__ __device__ constexpr size_t fps_batch_lds_bytes(int P, int UT = kBtUT) { return fps_batch_xchg_offset(P, UT) + 2 * sizeof(BtXchg) + 16 * kBtCand; }
 
 __device__ __forceinline__ float vmax_f32(float a, float b)
 {
@@ -140,24 +144,23 @@ __device__ unsigned long long g_bt_stats[16];
 #ifndef PN2_BT_EARLY
 #define PN2_BT_EARLY 48            // the first samples of a cloud are taken one per exchange (below; 32 / 64 / 96 measured: 255.7 / 255.5 / 261.9 us, none: 280.4)
 #endif
-#ifndef PN2_BT_ALL_FROM
-#define PN2_BT_ALL_FROM 4          // a sample that reaches this many of a wave's eight groups updates all eight in straight-line code
-#endif
 #ifndef PN2_BT_G0
 #define PN2_BT_G0 0.10f               // initial 1 - theta / (last sample value)
 #endif
 
-template <int P, int GS, bool PUBLISH>
+template <int P, int GS, bool PUBLISH, int UT = kBtUT>
 __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, const float *__restrict__ xyz,
                                                int *__restrict__ out, float *__restrict__ out_xyz,
                                                unsigned long long *__restrict__ tagged, char *smem, unsigned tag = 1u)
 {
-    constexpr int T = kPrT, W = kPrW, NS = T * P;
-    constexpr int GW = P / GS;
-    static_assert(W * GW == 32 && GW == 8, "32 groups");
+    constexpr int W = UT / PN2_WAVE, NS = UT * P;      // updater waves, rank slots
+    constexpr int GW = P / GS;                         // groups per updater wave
+    constexpr int CAP = kBtCand / W;                   // candidate lanes per updater wave
+    constexpr int BT = UT + PN2_WAVE;                  // threads of the workgroup
+    static_assert(W * GW == 32 && (W == 4 || W == 8), "32 groups on four or eight updater waves");
     float4 *lds_rank = reinterpret_cast<float4 *>(smem + 256);
-    BtXchg *xch = reinterpret_cast<BtXchg *>(smem + fps_batch_xchg_offset(P));
-    float4 *ring = reinterpret_cast<float4 *>(smem + fps_batch_xchg_offset(P) + 2 * sizeof(BtXchg));   // [kBtCand] samples of the batch: x, y, z, k
+    BtXchg *xch = reinterpret_cast<BtXchg *>(smem + fps_batch_xchg_offset(P, UT));
+    float4 *ring = reinterpret_cast<float4 *>(smem + fps_batch_xchg_offset(P, UT) + 2 * sizeof(BtXchg));   // [kBtCand] samples of the batch: x, y, z, k
 
     const float *__restrict__ src = xyz + (size_t)cloud * n * 3;
     int *__restrict__ dst = out + (size_t)cloud * m;
@@ -176,7 +179,7 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
 #ifndef PN2_NO_SETPRIO
         __builtin_amdgcn_s_setprio(3);           // it shares SIMD 0 with updater wave 0 and is the chain
 #endif
-        if (lane == 0) { xch[0].count = 0u; xch[1].count = 0u; }
+        for (int i = lane; i < (int)(2 * sizeof(BtXchg) / 4); i += PN2_WAVE) reinterpret_cast<unsigned *>(xch)[i] = 0u;   // counts, bounds, flags
         for (int i = 0; i < kPrPrologueBarriers; ++i) __syncthreads();
         for (; j < jE; ++j) __syncthreads();     // the updaters' early rounds: one barrier each
         float g = PN2_BT_G0;
@@ -188,17 +191,16 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
             const long long q1 = PN2_BT_CLOCK();
             BtXchg &X = xch[par];
             if (lane == 0) __hip_atomic_store(&xch[par ^ 1].count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // everybody is past the batch that used it
-            const uint4 c4 = *reinterpret_cast<const uint4 *>(X.cnt);
-            const uint4 b4 = *reinterpret_cast<const uint4 *>(X.bound);
+            const uint4 c4 = *reinterpret_cast<const uint4 *>(X.cnt), c5 = *reinterpret_cast<const uint4 *>(X.cnt + 4);      // waves beyond W: 0
+            const uint4 b4 = *reinterpret_cast<const uint4 *>(X.bound), b5 = *reinterpret_cast<const uint4 *>(X.bound + 4);
             const double key = X.list[lane];
-            const int wv = lane >> 4;
-            const unsigned cw = wv == 0 ? c4.x : wv == 1 ? c4.y : wv == 2 ? c4.z : c4.w;
-            const bool valid = (unsigned)(lane & (kBtCap - 1)) < cw;
+            const unsigned cw = X.cnt[lane / CAP];
+            const bool valid = (unsigned)(lane & (CAP - 1)) < cw;
             const unsigned lowc = valid ? (unsigned)__double2loint(key) : 0u;
             typedef float bt_f4 __attribute__((ext_vector_type(4)));
             const bt_f4 cand = *reinterpret_cast<const bt_f4 *>(&lds_rank[lowc]);   // x, y, z, bits of k
-            const int boundb = __builtin_amdgcn_readfirstlane((int)max(max(b4.x, b4.y), max(b4.z, b4.w)));
-            const int total = __builtin_amdgcn_readfirstlane((int)(c4.x + c4.y + c4.z + c4.w));
+            const int boundb = __builtin_amdgcn_readfirstlane((int)max(max(max(b4.x, b4.y), max(b4.z, b4.w)), max(max(b5.x, b5.y), max(b5.z, b5.w))));
+            const int total = __builtin_amdgcn_readfirstlane((int)(c4.x + c4.y + c4.z + c4.w + c5.x + c5.y + c5.z + c5.w));
             int cval = valid ? __double2hiint(key) : (int)0xBF800000;             // -1.0f: below every value as an integer, kept by v_min_f32
             const int clo = (int)lowc;
             int a = 0;
@@ -273,14 +275,14 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
     } else {
         // ================================================ the updaters =========================================================
         PrSlots<P> S;
-        fps_pruned_prologue<P, GS>(n, Q, src, smem, S);
+        fps_pruned_prologue<P, GS, UT>(n, Q, src, smem, S);
         pn2_f2 (&xx)[P / 2] = S.xx;
         pn2_f2 (&yy)[P / 2] = S.yy;
         pn2_f2 (&zz)[P / 2] = S.zz;
         float (&md)[P] = S.md;
         unsigned (&low)[P] = S.low;
-        if (lane == 0) { xch[0].bound[w] = 0u; xch[1].bound[w] = 0u; }     // only wave w ever raises bound[.][w]
-        // lane l tests samples against the box of THIS wave's group l % 8
+        // (only wave w ever raises bound[.][w]; the picker has zeroed the exchange area before the prologue's barriers)
+        // lane l tests samples against the box of THIS wave's group l % GW
         float blx, bly, blz, bhx, bhy, bhz;
         {
             const float *gbox = reinterpret_cast<const float *>(smem + 256 + (size_t)16 * NS + (size_t)kPrHistRows * kPrBins * 4);
@@ -315,14 +317,19 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
                 md[p0 + 1] = vmin_f32(dx[h].y, md[p0 + 1]);
             }
         };
+        auto update_all = [&]() __attribute__((always_inline)) {
+            update_group(std::integral_constant<int, 0>()); update_group(std::integral_constant<int, 1>());
+            update_group(std::integral_constant<int, 2>()); update_group(std::integral_constant<int, 3>());
+            if constexpr (GW == 8) {
+                update_group(std::integral_constant<int, 4>()); update_group(std::integral_constant<int, 5>());
+                update_group(std::integral_constant<int, 6>()); update_group(std::integral_constant<int, 7>());
+            }
+        };
         // sample 0 is point 0 (tf_sampling_g.cu:114-116): every slot against it
         {
             const float4 s = lds_rank[NS - 1];
             sxy.x = s.x; syy.x = s.y; szk.x = s.z;
-            update_group(std::integral_constant<int, 0>()); update_group(std::integral_constant<int, 1>());
-            update_group(std::integral_constant<int, 2>()); update_group(std::integral_constant<int, 3>());
-            update_group(std::integral_constant<int, 4>()); update_group(std::integral_constant<int, 5>());
-            update_group(std::integral_constant<int, 6>()); update_group(std::integral_constant<int, 7>());
+            update_all();
         }
         if (t == 0) {
             dst[0] = 0;
@@ -367,10 +374,7 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
                                            __HIP_MEMORY_SCOPE_AGENT);
                 }
                 sxy.x = s.x; syy.x = s.y; szk.x = s.z;
-                update_group(std::integral_constant<int, 0>()); update_group(std::integral_constant<int, 1>());
-                update_group(std::integral_constant<int, 2>()); update_group(std::integral_constant<int, 3>());
-                update_group(std::integral_constant<int, 4>()); update_group(std::integral_constant<int, 5>());
-                update_group(std::integral_constant<int, 6>()); update_group(std::integral_constant<int, 7>());
+                update_all();
             }
             if (jE > 1) thetab = __float_as_uint(__fmul_rn(__uint_as_float(vlastb), 1.0f - PN2_BT_G0));
         }
@@ -411,19 +415,19 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
             int cnt = __popcll(mask);
             unsigned thb = thetab;                   // this wave's threshold: its points outside the list are below it
             bool exact = false;
-            if (cnt > kBtCap) {
-                unsigned lob = thetab, hib = vlastb + 1u;       // more than kBtCap lanes at lob, none at hib
+            if (cnt > CAP) {
+                unsigned lob = thetab, hib = vlastb + 1u;       // more than CAP lanes at lob, none at hib
                 for (int it = 0; it < 16; ++it) {
                     const unsigned mid = lob + ((hib - lob) >> 1);
                     if (mid == lob) break;
                     const unsigned long long mk = __ballot(vb >= mid);
                     const int c = __popcll(mk);
                     PN2_BT_STAT(3, 1);
-                    if (c > kBtCap) lob = mid;
+                    if (c > CAP) lob = mid;
                     else if (c == 0) hib = mid;
                     else { mask = mk; cnt = c; thb = mid; break; }
                 }
-                exact = cnt > kBtCap;
+                exact = cnt > CAP;
             } else if (cnt == 0) {
                 exact = true;
             }
@@ -439,7 +443,7 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
             }
             if ((mask >> lane) & 1ull) {
                 const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                X.list[w * kBtCap + pos] = kl;
+                X.list[w * CAP + pos] = kl;
                 lds_max_u32(&X.bound[w], __float_as_uint(sec) + 1u);
             }
             if (lane == 0) {
@@ -465,40 +469,49 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
                     __builtin_amdgcn_s_sleep(1);
                     continue;
                 }
-                const int np = min(avail - done, 8);
-                const int pi = lane >> 3;                                        // this lane's sample of the chunk
+                constexpr int CH = PN2_WAVE / GW;                                 // samples per chunk: lane l tests sample l / GW against group l % GW
+                constexpr unsigned long long kStride = GW == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;   // one bit per sample
+                const int np = min(avail - done, CH);
+                const int pi = lane / GW;                                        // this lane's sample of the chunk
                 const float4 s = ring[done + (pi < np ? pi : 0)];
                 const float ax = __fsub_rn(s.x, __builtin_amdgcn_fmed3f(s.x, blx, bhx));
                 const float ay = __fsub_rn(s.y, __builtin_amdgcn_fmed3f(s.y, bly, bhy));
                 const float az = __fsub_rn(s.z, __builtin_amdgcn_fmed3f(s.z, blz, bhz));
                 const float bd = __fadd_rn(__fadd_rn(__fmul_rn(ax, ax), __fmul_rn(ay, ay)), __fmul_rn(az, az));
                 unsigned long long touched = ~__ballot(bd >= thr);               // NaN -> not far -> updated
-                if (np < 8) touched &= (1ull << (np * 8)) - 1ull;
-                while (touched) {
-                    const int bit = (int)__builtin_ctzll(touched);
-                    touched &= touched - 1ull;
-                    const int sl = bit & ~7;                                     // a lane that holds the sample
-                    sxy.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.x), sl));
-                    syy.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.y), sl));
-                    szk.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.z), sl));
-                    const int gi = bit & 7;
-                    PN2_BT_STAT(5, 1);
-                    if (__popcll(touched >> sl & 0xffull) >= PN2_BT_ALL_FROM - 1) {
-                        // most of the wave's groups (the first samples of a cloud): straight-line over all of them is cheaper than a
-                        // dispatch per group, and an update of an untouched group changes nothing
-                        touched &= ~(0xffull << sl);
-                        update_group(std::integral_constant<int, 0>()); update_group(std::integral_constant<int, 1>());
-                        update_group(std::integral_constant<int, 2>()); update_group(std::integral_constant<int, 3>());
-                        update_group(std::integral_constant<int, 4>()); update_group(std::integral_constant<int, 5>());
-                        update_group(std::integral_constant<int, 6>()); update_group(std::integral_constant<int, 7>());
-                        continue;
-                    }
-                    if (gi < 4) {
-                        if (gi < 2) { if (gi == 0) update_group(std::integral_constant<int, 0>()); else update_group(std::integral_constant<int, 1>()); }
-                        else { if (gi == 2) update_group(std::integral_constant<int, 2>()); else update_group(std::integral_constant<int, 3>()); }
+                if (np < CH) touched &= (1ull << (np * GW)) - 1ull;
+                // group by group (static): the samples that reach group g, straight into that group's update -- no dispatch on a
+                // group number (three compare-and-branch pairs per (group, sample) otherwise)
+                if (touched) {
+                    // the first samples of a cloud reach most groups: then every sample of the chunk updates all of the wave's
+                    // groups in straight-line code (an update of an untouched group changes nothing)
+                    if (2 * __popcll(touched) >= GW * np) {
+                        for (int p = 0; p < np; ++p) {
+                            sxy.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.x), p * GW));
+                            syy.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.y), p * GW));
+                            szk.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.z), p * GW));
+                            update_all();
+                        }
                     } else {
-                        if (gi < 6) { if (gi == 4) update_group(std::integral_constant<int, 4>()); else update_group(std::integral_constant<int, 5>()); }
-                        else { if (gi == 6) update_group(std::integral_constant<int, 6>()); else update_group(std::integral_constant<int, 7>()); }
+                        auto one_group = [&](auto gic) __attribute__((always_inline)) {
+                            constexpr int g8 = decltype(gic)::value;
+                            unsigned long long mg = touched & (kStride << g8);
+                            while (mg) {
+                                const int sl = (int)__builtin_ctzll(mg) & ~(GW - 1);
+                                mg &= mg - 1ull;
+                                sxy.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.x), sl));
+                                syy.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.y), sl));
+                                szk.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.z), sl));
+                                PN2_BT_STAT(5, 1);
+                                update_group(gic);
+                            }
+                        };
+                        one_group(std::integral_constant<int, 0>()); one_group(std::integral_constant<int, 1>());
+                        one_group(std::integral_constant<int, 2>()); one_group(std::integral_constant<int, 3>());
+                        if constexpr (GW == 8) {
+                            one_group(std::integral_constant<int, 4>()); one_group(std::integral_constant<int, 5>());
+                            one_group(std::integral_constant<int, 6>()); one_group(std::integral_constant<int, 7>());
+                        }
                     }
                 }
                 done += np;
@@ -523,14 +536,14 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
         }
     }
     if (fill_k >= 0) {
-        for (int i = j + t; i < m; i += kBtT) {
+        for (int i = j + t; i < m; i += BT) {
             dst[i] = fill_k;
             if (PUBLISH)
                 __hip_atomic_store(gtag + i, ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)fill_k, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    fps_gather_epilogue<kBtT>(m, src, dst, dxyz);
+    fps_gather_epilogue<BT>(m, src, dst, dxyz);
 }
 
 }  // namespace pn2

@@ -64,9 +64,9 @@ constexpr int kPrHistRows = 1 + kPrK0 + kPrK0 * kPrK1;         // segments of th
 
 // LDS layout (bytes): [0,64) wave keys (2 parities x 4) | [64,256) reduction scratch | mirror / staging 16 * NS |
 // hist 21 x 64 ints | gbox 32 x 8 floats
-__host__ __device__ constexpr size_t fps_pruned_lds_bytes(int P)
+__host__ __device__ constexpr size_t fps_pruned_lds_bytes(int P, int T = kPrT)
 {
-    return 256 + (size_t)16 * kPrT * P + (size_t)kPrHistRows * kPrBins * 4 + (size_t)kPrGroups * 32;
+    return 256 + (size_t)16 * T * P + (size_t)kPrHistRows * kPrBins * 4 + (size_t)kPrGroups * 32;
 }
 
 // Where the pruned tier pays (measured, profiles/r05/fps_pruned.txt): its grouping costs 8.5 us (16 slots per thread) / 14 us
@@ -120,14 +120,15 @@ constexpr int kPrPrologueBarriers = 10;   // __syncthreads() executed by fps_pru
 
 // Grouping prologue shared by the chains of fps_pruned_body (one sample per exchange) and fps_batch_body.h (several): deals the
 // cloud to the slots spatially, writes the rank-ordered LDS mirror and the group boxes. Ends behind a barrier.
-template <int P, int GS>
+// T = 256 threads (four waves of eight groups: the pruned tier) or 512 (eight waves of four groups: the batched tier's updaters).
+template <int P, int GS, int T = kPrT>
 __device__ __forceinline__ void fps_pruned_prologue(int n, int Q, const float *__restrict__ src, char *smem, PrSlots<P> &S)
 {
-    constexpr int T = kPrT, W = kPrW, NS = T * P;
+    constexpr int W = T / PN2_WAVE, NS = T * P;
     constexpr int GW = P / GS;                    // groups per wave
     constexpr int G = W * GW;                     // groups = leaves = test lanes
-    static_assert(G == kPrGroups && GW == 8 && (GS & 1) == 0, "32 groups: 16 slots per thread in groups of 2, 32 in groups of 4");
-    float *scratch = reinterpret_cast<float *>(smem + 64);                              // 48 floats
+    static_assert(G == kPrGroups && (W == 4 || W == 8) && (GS & 1) == 0, "32 groups: four waves of eight or eight waves of four");
+    float *scratch = reinterpret_cast<float *>(smem + (W > 4 ? 0 : 64));                // 8 floats per wave (eight waves: the whole 256-byte header)
     float4 *lds_rank = reinterpret_cast<float4 *>(smem + 256);                          // mirror [NS], first the staging copy
     char *tab = smem + 256 + (size_t)16 * NS;
     int *hist = reinterpret_cast<int *>(tab);                                           // [1 + K0 + K0 * K1][64]: one histogram row per segment and level
@@ -237,7 +238,7 @@ __device__ __forceinline__ void fps_pruned_prologue(int n, int Q, const float *_
     for (int j = 0; j < P; ++j) {
         const int a = seg[j] >> 3, r = seg[j] & 7;
         const int dt = ((r + a) & (W - 1)) * 64 + (rank[j] & 63);
-        const int dp = (2 * a + (r >> 2)) * GS + (rank[j] >> 6);
+        const int dp = (a * (8 / W) + r / W) * GS + (rank[j] >> 6);   // four waves: group 2 a + r / 4, eight waves: group a
         lds_rank[dt * P + dp] = make_float4(px[j], py[j], pz[j], __int_as_float(t + j * T));
     }
     __syncthreads();

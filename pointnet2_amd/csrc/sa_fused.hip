@@ -110,10 +110,10 @@ static int g_lab_clear_with_kernel = 0;
 // LPQ: lanes per query of the cell-list consumers; 0 = sweep consumers (clouds whose cell list does not fit
 // beside the position table: n > ~6000).
 // TIER of the producers: 0 = fps_reg_body; 1 = the kd-grouped chain of fps_pruned_body.h (4096 / 8192 rank slots: P = 8, 16) on four
-// waves; 2 = the same slots with several samples per exchange (fps_batch_body.h: four updater waves and the picker, 320 threads).
+// waves; 2 = the same groups with several samples per exchange (fps_batch_body.h: eight updater waves and the picker, 576 threads).
 constexpr int fused_pruned_gs(int P) { return P == 8 ? 2 : 4; }       // slots per group at 16 / 32 slots per thread
 template <int P, int LPQ, int TIER = 0>
-__global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, int m, int Q, int nsample, float thr,
+__global__ __launch_bounds__(TIER == 2 ? kBtT : kFusedThreads) void sa_fused_kernel(int b, int n, int m, int Q, int nsample, float thr,
                                                                  float radius, int qpb, int cpc, unsigned tag,
                                                                  const float *__restrict__ xyz,
                                                                  unsigned long long *__restrict__ tagged,
@@ -168,8 +168,9 @@ __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, i
         // pn2_farthest_point_sample launches at these sizes: the upper four waves of a producer retire at once
         // (a retired wave no longer counts at the workgroup's barriers).
         if constexpr (TIER == 2) {
-            if (threadIdx.x >= kBtT) return;
-            fps_batch_body<2 * P, fused_pruned_gs(P), PN2_FUSED_LAB_PUBLISH>(n, m, Q, blk, xyz, fps_idx, nullptr, tagged, smem, tag);
+            // eight updater waves of P slots per thread + the picker: the launch's workgroups are kBtT = 576 threads for this tier
+            static_assert(kBtUT == kFusedThreads, "the batched tier's updaters are the workgroup's first 512 threads");
+            fps_batch_body<P, fused_pruned_gs(P), PN2_FUSED_LAB_PUBLISH>(n, m, Q, blk, xyz, fps_idx, nullptr, tagged, smem, tag);
         } else if constexpr (TIER == 1) {
             if (threadIdx.x >= kPrT) return;
             fps_pruned_body<2 * P, fused_pruned_gs(P), PN2_FUSED_LAB_PUBLISH>(n, m, Q, blk, xyz, fps_idx, nullptr, tagged, smem, tag);
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(kFusedThreads) void sa_fused_kernel(int b, int n, i
         // PERSISTENT consumers (round 5): cpc workgroups per cloud; consumer c stages (and bins) its cloud ONCE and walks the
         // query ranges c, c + cpc, c + 2 cpc, ... in the order the producer publishes them. (Rounds 2-4 launched one workgroup per
         // RANGE, m / 64 = 16 per cloud at the metric shape: 512 workgroups spinning on 224 CUs, each re-staging the cloud.)
+        if (TIER == 2 && threadIdx.x >= kFusedThreads) return;      // the picker's wave has no part in a consumer workgroup
         const int id = blk - b;
         const int cloud = id % b;                // consumer number first, cloud second: the consumers that can
         const int q0 = (id / b) * qpb;           // start earliest are dispatched first
@@ -237,7 +239,7 @@ static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, floa
     if (qpb > m) qpb = ((m + kGran - 1) / kGran) * kGran;
     const int nranges = (m + qpb - 1) / qpb;
     const int nq = consumers <= 0 ? (nranges < kFusedConsumers ? nranges : kFusedConsumers) : consumers < nranges ? consumers : nranges;
-    size_t lds_f = TIER == 2 ? fps_batch_lds_bytes(2 * P) : TIER == 1 ? fps_pruned_lds_bytes(2 * P)
+    size_t lds_f = TIER == 2 ? fps_batch_lds_bytes(P) : TIER == 1 ? fps_pruned_lds_bytes(2 * P)
                                                                        : 256 + sizeof(float4) * (size_t)kFusedThreads * P;
     size_t lds_q = LPQ ? fused_cells_lds(n, nsample, LPQ)
                        : sizeof(float4) * (size_t)((n + 127) & ~127) + sizeof(int) * (size_t)nsample * kGran;
@@ -250,7 +252,7 @@ static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, floa
         // residency (header): room for every producer at the same time. Consumers only ever wait for producers and producers wait
         // for nobody, so consumers that find no CU free simply start when a workgroup ends (b > CUs / 2: the last of them after
         // the chains, where they find every sample published)
-        const int room = resident_workgroups(kern, kFusedThreads, lds);
+        const int room = resident_workgroups(kern, TIER == 2 ? kBtT : kFusedThreads, lds);
         if (room < 0) return -room;
         if (room < b) return PN2_E_TOO_LARGE;
     }
@@ -266,7 +268,7 @@ static int launch_fused(int b, int n, int m, int Q, int nsample, float thr, floa
         if (int rc = clear_async(ws, sizeof(unsigned long long) * (size_t)b * m + 16, st)) return rc;
         tag = 1u;
     }
-    if (int rc = launch(kern, dim3(b + nq * b), dim3(kFusedThreads), lds, st, b, n, m, Q, nsample, thr, radius, qpb, nq, tag, xyz, ws,
+    if (int rc = launch(kern, dim3(b + nq * b), dim3(TIER == 2 ? kBtT : kFusedThreads), lds, st, b, n, m, Q, nsample, thr, radius, qpb, nq, tag, xyz, ws,
                        fps_idx, new_xyz, idx, pts_cnt, grouped, subtract)) return rc;
     return PN2_OK;
 }

@@ -1,6 +1,6 @@
 """CPU model of the batched FPS tier's acceptance rule (csrc/fps_batch_body.h): one candidate LIST per batch
 determines several samples. Restated in numpy with the kernel's arithmetic -- values compared as fp32 BIT PATTERNS, threshold
-theta = fl32(v_last * (1 - g)), at most 16 candidate lanes per wave (bisection on the bits, exact best lane when that fails or
+theta = fl32(v_last * (1 - g)), at most 8 candidate lanes per updater wave (bisection on the bits, exact best lane when that fails or
 nobody reaches theta), the bound = max(wave thresholds, second-best value of a candidate lane + 1 ulp), greedy picks by
 (value, tie rank) while the pick's value bits are >= the bound, the list-size feedback on g, the first samples taken one per
 exchange, the tail once a value is 0 -- and run as whole chains against the oracle's sequential sampling. The assertion inside
@@ -13,7 +13,7 @@ from pointnet2_amd import synthetic as S
 
 F = np.float32
 REF_THREADS = 512
-CAP, LIST_HI, LIST_LO, G0, EARLY = 16, 36, 20, F(0.10), 48       # fps_batch_body.h: kBtCap, PN2_BT_LIST_HI / _LO, PN2_BT_G0, PN2_BT_EARLY
+WAVES, CAP, LIST_HI, LIST_LO, G0, EARLY = 8, 8, 36, 20, F(0.10), 48   # fps_batch_body.h: updater waves, 64 / waves, PN2_BT_LIST_HI / _LO, PN2_BT_G0, PN2_BT_EARLY
 
 
 def _bits(v):
@@ -26,7 +26,7 @@ def _sqdist(p, s):
 
 
 def _lanes(x, slots):
-    """point -> (wave, lane): 32 leaves of equal size along the axes sorted by extent, leaf (a, r) -> wave (r + a) % 4, position
+    """point -> (wave, lane): 32 leaves of equal size along the axes sorted by extent, leaf (a, r) -> wave (r + a) % 8, position
     p of the leaf -> lane p % 64 (fps_pruned_prologue; any dealing gives the same samples, this one gives the kernel's lists)"""
     n = x.shape[0]
     ext = x.max(axis=0) - x.min(axis=0)
@@ -37,7 +37,7 @@ def _lanes(x, slots):
         for i1, p1 in enumerate(np.array_split(p0[np.argsort(x[p0, a1], kind="stable")], 4)):
             for i2, p2 in enumerate(np.array_split(p1[np.argsort(x[p1, a2], kind="stable")], 2)):
                 r = i1 * 2 + i2
-                unit[p2] = ((r + a) % 4) * 64 + np.arange(len(p2)) % 64
+                unit[p2] = ((r + a) % WAVES) * 64 + np.arange(len(p2)) % 64
     return unit
 
 
@@ -47,7 +47,7 @@ def _batched_fps(x, m, early=EARLY):
     q = (n + REF_THREADS - 1) // REF_THREADS
     rank = (np.arange(n) % REF_THREADS) * q + np.arange(n) // REF_THREADS             # smaller wins a tie (tf_sampling_g.cu:146,153-163)
     unit = _lanes(x, 16)
-    members = [np.nonzero(unit == u)[0] for u in range(256)]
+    members = [np.nonzero(unit == u)[0] for u in range(64 * WAVES)]
     td = np.minimum(np.full(n, 1e38, dtype=F), _sqdist(x, x[0]))
     out = [0]
 
@@ -67,10 +67,10 @@ def _batched_fps(x, m, early=EARLY):
     batches = []
     while len(out) < m:
         # COLLECT: per lane the best point (value, then rank) and the second-best value
-        lane_best = np.full(256, -1, dtype=np.int64)
-        vb = np.zeros(256, dtype=np.int64)
-        sb = np.zeros(256, dtype=np.int64)
-        for u in range(256):
+        lane_best = np.full(64 * WAVES, -1, dtype=np.int64)
+        vb = np.zeros(64 * WAVES, dtype=np.int64)
+        sb = np.zeros(64 * WAVES, dtype=np.int64)
+        for u in range(64 * WAVES):
             ids = members[u]
             if len(ids) == 0:
                 continue                                                                  # a lane of padding slots: value 0, never a candidate that matters
@@ -79,7 +79,7 @@ def _batched_fps(x, m, early=EARLY):
             vb[u] = _bits(td[ids[o[0]]])
             sb[u] = _bits(td[ids[o[1]]]) if len(ids) > 1 else 0
         cand, bound, total = [], 0, 0
-        for w in range(4):
+        for w in range(WAVES):
             us = np.arange(w * 64, w * 64 + 64)
             us = us[lane_best[us] >= 0]
             thb = theta_b
