@@ -144,6 +144,9 @@ __device__ unsigned long long g_bt_stats[16];
 #ifndef PN2_BT_EARLY
 #define PN2_BT_EARLY 48            // the first samples of a cloud are taken one per exchange (below; 32 / 64 / 96 measured: 255.7 / 255.5 / 261.9 us, none: 280.4)
 #endif
+#ifndef PN2_BT_ASM_LOOP
+#define PN2_BT_ASM_LOOP 1
+#endif
 #ifndef PN2_BT_G0
 #define PN2_BT_G0 0.10f               // initial 1 - theta / (last sample value)
 #endif
@@ -226,6 +229,87 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
             argmax();                                                            // the batch's first sample: always (the global arg-max)
             const int amax = min(m - j, kBtCand);
             unsigned raddr = ring_base, na = 1u;
+#if PN2_BT_ASM_LOOP
+            // The sample loop, hand-scheduled (the compiler's version of the same loop -- #else below -- takes three taken
+            // branches and six more scalar moves per sample; on a lone wave every instruction is an issue slot of ~8 cycles):
+            //   publish: the winner lane alone (exec = eq) stores its row and then the new count -- two LDS writes of one wave
+            //     execute in order, so a reader that sees the count sees the row; no wait in between, none behind -- and leaves
+            //     the contest (-1.0f);
+            //   SPECULATION: the maximum of the values as they are BEFORE this sample's update is computed in the shadow of the
+            //     update (the DPP steps need two independent instructions between them anyway). Values only fall: a lane that
+            //     still holds that maximum afterwards is the arg-max -- if it is the only one. A sample of value 0 ends the batch by
+            //     itself: nothing is above the bound afterwards.
+            // reason: 0 = the batch is full / the cloud is done, 1 = nothing above the bound is left, 2 = the speculative maximum
+            // is gone or not unique (the exact arg-max below decides, then the loop resumes).
+            const float cx = cand.x, cy = cand.y, cz = cand.z;
+            for (;;) {
+                int reason, t_wl, t_sx, t_sy, t_sz, t_ms, t_cnt;
+                int v_t;
+                float v_dx, v_dy, v_dz;
+                asm volatile(
+                    "s_branch 1f\n\t"
+                    "0:\n\t"
+                    "s_mov_b32 %[bh], %[ms]\n\t"                  // the speculative maximum stood: it is the next sample's value
+                    "1:\n\t"
+                    "s_mov_b64 exec, %[eq]\n\t"
+                    "ds_write_b128 %[raddr], %[cand]\n\t"
+                    "ds_write_b32 %[caddr], %[na]\n\t"
+                    "v_mov_b32 %[cval], 0xbf800000\n\t"
+                    "s_mov_b64 exec, -1\n\t"
+                    "s_ff1_i32_b64 %[wl], %[eq]\n\t"
+                    "s_add_i32 %[a], %[a], 1\n\t"
+                    "v_add_u32 %[raddr], 16, %[raddr]\n\t"
+                    "v_add_u32 %[na], 1, %[na]\n\t"
+                    "s_cmp_ge_i32 %[a], %[amax]\n\t"
+                    "s_cbranch_scc1 2f\n\t"
+                    "v_readlane_b32 %[sx], %[cx], %[wl]\n\t"
+                    "v_readlane_b32 %[sy], %[cy], %[wl]\n\t"
+                    "v_max_i32_dpp %[t], %[cval], %[cval] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_readlane_b32 %[sz], %[cz], %[wl]\n\t"
+                    "v_subrev_f32 %[dx], %[sx], %[cx]\n\t"
+                    "v_max_i32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_subrev_f32 %[dy], %[sy], %[cy]\n\t"
+                    "v_subrev_f32 %[dz], %[sz], %[cz]\n\t"
+                    "v_max_i32_dpp %[t], %[t], %[t] row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_mul_f32 %[dx], %[dx], %[dx]\n\t"
+                    "v_mul_f32 %[dy], %[dy], %[dy]\n\t"
+                    "v_max_i32_dpp %[t], %[t], %[t] row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_mul_f32 %[dz], %[dz], %[dz]\n\t"
+                    "v_add_f32 %[dx], %[dx], %[dy]\n\t"
+                    "v_max_i32_dpp %[t], %[t], %[t] row_bcast:15 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32 %[dx], %[dx], %[dz]\n\t"
+                    "s_nop 0\n\t"
+                    "v_max_i32_dpp %[t], %[t], %[t] row_bcast:31 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_min_f32 %[cval], %[dx], %[cval]\n\t"
+                    "s_nop 0\n\t"
+                    "v_readlane_b32 %[ms], %[t], 63\n\t"
+                    "s_nop 0\n\t"
+                    "s_cmp_lt_i32 %[ms], %[bound]\n\t"
+                    "s_cbranch_scc1 3f\n\t"
+                    "v_cmp_eq_u32_e64 %[eq], %[ms], %[cval]\n\t"
+                    "s_bcnt1_i32_b64 %[cnt], %[eq]\n\t"
+                    "s_cmp_eq_u32 %[cnt], 1\n\t"
+                    "s_cbranch_scc1 0b\n\t"
+                    "s_mov_b32 %[reason], 2\n\t"
+                    "s_branch 4f\n\t"
+                    "2:\n\t"
+                    "s_mov_b32 %[reason], 0\n\t"
+                    "s_branch 4f\n\t"
+                    "3:\n\t"
+                    "s_mov_b32 %[reason], 1\n\t"
+                    "4:"
+                    : [cval] "+v"(cval), [raddr] "+v"(raddr), [na] "+v"(na), [eq] "+s"(eq), [a] "+s"(a), [bh] "+s"(bh),
+                      [reason] "=&s"(reason), [wl] "=&s"(t_wl), [sx] "=&s"(t_sx), [sy] "=&s"(t_sy), [sz] "=&s"(t_sz), [ms] "=&s"(t_ms), [cnt] "=&s"(t_cnt),
+                      [t] "=&v"(v_t), [dx] "=&v"(v_dx), [dy] "=&v"(v_dy), [dz] "=&v"(v_dz)
+                    : [cand] "v"(cand), [caddr] "v"(count_addr), [cx] "v"(cx), [cy] "v"(cy), [cz] "v"(cz), [amax] "s"(amax), [bound] "s"(boundb)
+                    : "memory", "scc");
+                vlastb = bh;                                                     // the value of the sample published last
+                if (reason != 2) break;
+                PN2_BT_STAT(12, 1);
+                argmax();
+                if (bh < boundb) break;
+            }
+#else
             for (;;) {
                 // the winner lane alone stores its row and then the new count: two LDS writes of one wave execute in order, so a
                 // reader that sees the count sees the row (no wait in between, none behind). It also leaves the contest (-1.0f).
@@ -258,6 +342,7 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
                     if (bh < boundb) break;
                 }
             }
+#endif
             if (vlastb == 0) { fill = true; fill_k = __builtin_amdgcn_readlane(__float_as_int(cand.w), (int)__builtin_ctzll(eq)); }   // every running distance is 0 from here on
             const long long q3 = PN2_BT_CLOCK();
             // the list about half full
