@@ -277,12 +277,14 @@ int pn2_farthest_point_sample_ex(int T, int P, int b, int n, int m, const float 
 
 /* farthest_point_sample [+ gather_point when out_xyz != NULL] with the TIER chosen by the caller. Every tier returns the
  * reference's indices (tf_sampling_g.cu:105-170); tests force each one, scripts time them.
- *   PN2_FPS_AUTO    what pn2_farthest_point_sample does: the pruned tier where it measured faster (rank slots =
- *                   512 * ceil(n / 512): 2049..4096 with npoint >= 768, 4097..8192 with npoint >= 128), the full tier otherwise;
+ *   PN2_FPS_AUTO    what pn2_farthest_point_sample does: the batched tier at 2049..8192 rank slots (= 512 * ceil(n / 512)) with
+ *                   npoint >= 256, the pruned tier at 4097..8192 with 128 <= npoint < 256, the full tier otherwise;
  *   PN2_FPS_FULL    every point's running distance is updated against every new sample (csrc/fps_body.h);
  *   PN2_FPS_PRUNED  points dealt to the threads by a kd-tree built in LDS; per round only the groups whose bounding box
  *                   lies within the current farthest-point distance of the new sample are updated -- exactly the points
- *                   the reference's min() can change (csrc/fps_pruned_body.h). PN2_E_ARG outside 2049..8192 rank slots. */
+ *                   the reference's min() can change (csrc/fps_pruned_body.h). PN2_E_ARG outside 2049..8192 rank slots;
+ *   PN2_FPS_BATCH   (round 6) the pruned tier's groups, several samples per arg-max exchange: a candidate list per batch, a wave of
+ *                   its own for the arg-max chain, eight updater waves behind it (csrc/fps_batch_body.h). Same sizes. */
 #define PN2_FPS_AUTO 0
 #define PN2_FPS_FULL 1
 #define PN2_FPS_PRUNED 2
@@ -332,7 +334,7 @@ int pn2_sample_and_group_xyz_gen(int b, int n, int m, float radius, int nsample,
  * synchronising the stream. */
 long long pn2_sample_and_group_status_offset(int b, int m);
 /* pn2_sample_and_group_xyz[_gen] with the organisation of the launch chosen by the caller (outputs never depend on it):
- * fps_variant = FPS tier of the producer workgroups (PN2_FPS_AUTO / PN2_FPS_FULL / PN2_FPS_PRUNED as in
+ * fps_variant = FPS tier of the producer workgroups (PN2_FPS_AUTO / PN2_FPS_FULL / PN2_FPS_PRUNED / PN2_FPS_BATCH as in
  * pn2_farthest_point_sample_variant); consumers = persistent consumer workgroups per cloud (0 = the library's choice, which
  * includes the two launches for clouds beyond ~7000 points; > 0 = always the overlapped launch; each
  * stages its cloud once and walks the 64-query ranges c, c + consumers, ... in publish order; the grid is

@@ -4,10 +4,11 @@
 // Same results as fps_pruned_body / fps_reg_body / the reference kernel (tf_sampling_g.cu:105-170), bit for bit. What changes is
 // the shape of the chain. In every other tier a sample costs one workgroup-wide arg-max: a six-step wave ladder, an LDS write, a
 // barrier, an LDS read, a tournament, a mirror read -- ~700 dependent cycles of which the distance update is ~120. Here the
-// workgroup exchanges a short LIST of candidates once per BATCH; a fifth wave, the PICKER, then works through the list on its
+// workgroup exchanges a short LIST of candidates once per BATCH; one more wave, the PICKER, then works through the list on its
 // own -- one wave ladder and nine vector instructions per sample, no barrier, no LDS trip on its path -- for as many samples as
-// the list provably determines (10-14 on the bench clouds), while the four UPDATER waves apply the samples to the slots as they
-// appear.
+// the list provably determines (~20 on the bench clouds once the chain is past its first quarter), while the UPDATER waves
+// apply the samples to the slots as they appear. Measured (profiles/r06/fps_batch.txt): 4096 -> 1024 220 us against the pruned
+// tier's 366, 8192 -> 1024 247 against 416.
 //
 // Why a list determines several samples. Let td[] be the running distances after j samples, ordered by the reference's key
 // (value, then smaller tie rank). Fix a threshold theta below the current maximum. A point whose value is below theta can never
@@ -17,23 +18,33 @@
 // below the bound; everything taken until then is exactly the reference's sequence (scripts/fps_batch_sim.py checks the rule
 // against the oracle; tests/test_fps_batch_model.py is the CPU model of this file's arithmetic).
 //
-// Organisation. 320 threads: waves 0..3 hold the slots exactly as in the pruned tier (fps_pruned_prologue: spatial groups,
-// rank-ordered LDS mirror, group boxes), wave 4 is the picker.
-//   * COLLECT (updaters, once per batch). Every lane computes the best key and the second-best VALUE of its P slots. Lanes whose best value is >= theta are candidate lanes: at most kBtCap per wave -- a
-//     wave with more raises its own threshold by bisection on the value bits, a wave with none (or with more than kBtCap equal
-//     values) falls back to its exact best lane (one 64-bit wave ladder). A candidate lane writes its best key to the wave's
-//     part of the list; the wave's BOUND -- the smallest value bits a sample must have for the list to be complete -- is the
-//     maximum of its threshold and of (second-best value + 1 ulp) of its candidate lanes (an LDS atomic maximum on the fp32 bit
-//     patterns: the values are >= 0). One barrier, the only one of the batch.
-//   * PICK (picker). Lane i takes candidate i (key from the list, x, y, z, k from the mirror). Per sample: 32-bit wave ladder on
-//     the value bits (v_max_i32 with the DPP operand folded in: six instructions), v_readlane of the maximum, the acceptance
-//     test (first sample of a batch: always -- the list holds every updater wave's best lane, so its maximum is the global one;
-//     later: value bits >= bound), the winner's lane from a ballot of value == maximum (several lanes: the 64-bit keys decide, by
-//     the pruned tier's ladder), the winner lane stores its (x, y, z, k) row and the new count to LDS, three v_readlane, nine
-//     vector instructions for the reference's distance (tf_sampling_g.cu:141-144) from the sample to the other candidates.
-//   * APPLY (updaters, behind the picker). A wave polls the count, takes up to eight new samples at a time -- lane l tests
-//     sample l / 8 against the box of the wave's group l % 8: one distance-to-box computation for 64 (sample, group) pairs --
-//     and updates the touched groups (packed fp32, as in the pruned tier; no key work: keys are only needed at COLLECT). The skip test uses the value of the previous batch's LAST sample as v* (no running distance is above it).
+// Organisation. 576 threads: waves 0..7 are the updaters -- they hold the slots as the pruned tier deals them (fps_pruned_prologue
+// on 512 threads: 32 spatial groups, four per wave, rank-ordered LDS mirror, group boxes) --, wave 8 is the picker. EIGHT updater
+// waves, two per SIMD, because a lone wave issues one instruction per ~5-8 cycles whatever its kind (vector, scalar, branch) and
+// the apply loop is half scalar work: two waves share a SIMD's vector and scalar issue (four updater waves of twice the slots:
+// +14 % on the whole chain).
+//   * EARLY. The first PN2_BT_EARLY samples are taken one per exchange (the full tier's round on the updaters; the picker sits
+//     them out at the barriers): while the farthest-point distance still halves every few samples a list yields three or four.
+//   * COLLECT (updaters, once per batch). Every lane computes the best key and the second-best VALUE of its P slots. Lanes whose
+//     best value is >= theta are candidate lanes: at most 64 / W per wave -- a wave with more raises its own threshold by
+//     bisection on the value bits, a wave with none (or with too many equal values) falls back to its exact best lane (one
+//     64-bit wave ladder). A candidate lane writes its best key to the wave's part of the list; the wave's BOUND -- the smallest
+//     value bits a sample must have for the list to be complete -- is the maximum of its threshold and of (second-best value +
+//     1 ulp) of its candidate lanes (an LDS atomic maximum on the fp32 bit patterns: the values are >= 0; issued as a plain
+//     ds_max_u32 -- hipcc turns atomicMax into a readlane loop over the active lanes). One barrier, the only one of the batch.
+//   * PICK (picker). Lane i takes candidate i (key from the list, x, y, z, k from the mirror). Per sample, hand-scheduled (the
+//     asm block below): the winner lane alone (exec = one lane) stores its (x, y, z, k) row and then the new count to LDS and
+//     leaves the contest; three v_readlane of its coordinates; the reference's distance (tf_sampling_g.cu:141-144) from the
+//     sample to the other candidates, nine vector instructions; and, interleaved with those, the 32-bit wave ladder
+//     (v_max_i32 with the DPP operand folded in) over the values as they were BEFORE the update -- values only fall, so a lane
+//     that still holds that maximum afterwards is the arg-max if it is the only one (99 % of the samples); otherwise the exact
+//     arg-max (value ladder, 64-bit keys among equal values, the pruned tier's ladder). A sample is accepted while its value
+//     bits are >= the bound; the first sample of a batch always is: the list holds every updater wave's best lane, so its
+//     maximum is the global one.
+//   * APPLY (updaters, behind the picker). A wave polls the count, takes up to 64 / GW new samples at a time -- lane l tests
+//     sample l / GW against the box of the wave's group l % GW: one distance-to-box computation for 64 (sample, group) pairs --
+//     and updates the touched groups, group by group (packed fp32, as in the pruned tier; no key work: keys are only needed at
+//     COLLECT). The skip test uses the value of the previous batch's LAST sample as v* (no running distance is above it).
 //   * theta = (1 - g) * (value of the last sample); g adapts so that the list stays about half full. The picker decides
 //     and publishes theta with the end-of-batch flag.
 //
@@ -49,6 +60,7 @@
 // Hand-offs inside the workgroup: LDS only. The picker's row store and count store come from the same lane (LDS executes a
 // wave's operations in order), counts are release stores / acquire loads at workgroup scope. Double-buffered by batch parity:
 // list, counts, bounds and the header; the sample ring is single (a batch's samples are consumed before the next barrier).
+// Chains of different clouds now differ in length (the lists are the data's): 248-261 us over the 32 clouds of a bench batch.
 #pragma once
 #include "fps_pruned_body.h"
 

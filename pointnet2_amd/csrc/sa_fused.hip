@@ -375,8 +375,8 @@ extern "C" int pn2_sample_and_group_xyz_gen(int b, int n, int m, float radius, i
                                    grouped_xyz, subtract_centroid, stream);
 }
 
-// The same launch with the FPS tier of the producers (PN2_FPS_AUTO / _FULL / _PRUNED, see pn2_farthest_point_sample_variant;
-// PN2_E_ARG for _PRUNED outside 2049..8192 rank slots) and the number of persistent consumer workgroups per cloud (0 = the
+// The same launch with the FPS tier of the producers (PN2_FPS_AUTO / _FULL / _PRUNED / _BATCH, see pn2_farthest_point_sample_variant;
+// PN2_E_ARG for _PRUNED / _BATCH outside 2049..8192 rank slots) and the number of persistent consumer workgroups per cloud (0 = the
 // library's choice; more than one per 64 queries is clamped) chosen by the caller. generation 0 = clear `ws` first.
 extern "C" int pn2_sample_and_group_xyz_ex(int b, int n, int m, float radius, int nsample, const float *xyz, void *ws,
                                            unsigned generation, int fps_variant, int consumers, int *fps_idx, float *new_xyz,

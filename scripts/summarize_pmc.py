@@ -38,7 +38,7 @@ def main():
     if len(sys.argv) > 3:
         # bench.py reads this file: HBM bytes per launch keyed by operator (the kernel that implements it
         # on the op-level path at the metric shape)
-        ops = {"farthest_point_sample": "fps_pruned_kernel" if any("fps_pruned_kernel" in k for k in traffic) else "fps_reg_kernel",
+        ops = {"farthest_point_sample": next((f for f in ("fps_batch_kernel", "fps_pruned_kernel") if any(f in k for k in traffic)), "fps_reg_kernel"),
                "gather_point": "gather_point_kernel",
                "query_ball_point": "false>(int, int, int, int, float, float, int, int, float const*, float const*, int*, int*",
                "group_point": "group_point_c3_kernel",
