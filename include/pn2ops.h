@@ -277,14 +277,15 @@ int pn2_farthest_point_sample_ex(int T, int P, int b, int n, int m, const float 
 
 /* farthest_point_sample [+ gather_point when out_xyz != NULL] with the TIER chosen by the caller. Every tier returns the
  * reference's indices (tf_sampling_g.cu:105-170); tests force each one, scripts time them.
- *   PN2_FPS_AUTO    what pn2_farthest_point_sample does: the batched tier at 2049..8192 rank slots (= 512 * ceil(n / 512)) with
+ *   PN2_FPS_AUTO    what pn2_farthest_point_sample does: the batched tier at 513..8192 rank slots (= 512 * ceil(n / 512)) with
  *                   npoint >= 256, the pruned tier at 4097..8192 with 128 <= npoint < 256, the full tier otherwise;
  *   PN2_FPS_FULL    every point's running distance is updated against every new sample (csrc/fps_body.h);
  *   PN2_FPS_PRUNED  points dealt to the threads by a kd-tree built in LDS; per round only the groups whose bounding box
  *                   lies within the current farthest-point distance of the new sample are updated -- exactly the points
  *                   the reference's min() can change (csrc/fps_pruned_body.h). PN2_E_ARG outside 2049..8192 rank slots;
  *   PN2_FPS_BATCH   (round 6) the pruned tier's groups, several samples per arg-max exchange: a candidate list per batch, a wave of
- *                   its own for the arg-max chain, eight updater waves behind it (csrc/fps_batch_body.h). Same sizes. */
+ *                   its own for the arg-max chain, eight updater waves behind it (csrc/fps_batch_body.h). PN2_E_ARG outside
+ *                   513..8192 rank slots. */
 #define PN2_FPS_AUTO 0
 #define PN2_FPS_FULL 1
 #define PN2_FPS_PRUNED 2

@@ -342,7 +342,13 @@ static int fps_launch_batch(int b, int n, int m, const float *inp, int *out, flo
 {
     const int Q = (n + kRefThreads - 1) / kRefThreads;
     const int ranks = kRefThreads * Q;
-    if (!pruned_covers(ranks)) return PN2_E_ARG;
+    if (!fps_batch_covers(ranks)) return PN2_E_ARG;
+    if constexpr (kBtUT == 512) {
+        if (ranks <= 1024) return launch_batch<2, 2>(b, n, m, Q, inp, out, oxyz, st);   // 8 groups, one per updater wave
+        if (ranks <= 2048) return launch_batch<4, 2>(b, n, m, Q, inp, out, oxyz, st);   // 16 groups
+    } else if (ranks <= 2048) {
+        return PN2_E_ARG;
+    }
     // 32 groups either way: at 512 updater threads 8 slots per thread in groups of 2 or 16 in groups of 4
     if (ranks <= 4096) return launch_batch<4096 / kBtUT, 4096 / kBtUT / (32 / (kBtUT / 64))>(b, n, m, Q, inp, out, oxyz, st);
     return launch_batch<8192 / kBtUT, 8192 / kBtUT / (32 / (kBtUT / 64))>(b, n, m, Q, inp, out, oxyz, st);

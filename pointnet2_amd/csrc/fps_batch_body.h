@@ -127,11 +127,12 @@ __device__ __forceinline__ void lds_max_u32(unsigned *p, unsigned v)
     asm volatile("ds_max_u32 %0, %1" :: "v"((unsigned)(size_t)p), "v"(v) : "memory");
 }
 
-// Where the batched tier pays (measured, profiles/r06/fps_batch.txt): its grouping prologue costs what the pruned tier's does
-// (8.5 / 14 us more than the full tier's), its first PN2_BT_EARLY samples cost the full tier's round, from ~200 samples on a
-// sample is 200-210 ns against 325-390 (pruned / full). npoint = 256: 95-99 us against 102 (full) at 4096 rank slots, 122-128
-// against 134-143 (pruned) at 8192.
-inline bool fps_batch_pays(int ranks, int m) { return ranks > 2048 && ranks <= 8192 && m >= 256; }
+// Where the batched tier exists and pays (measured, profiles/r06/fps_batch.txt): 513..8192 rank slots (1024 / 2048: 8 / 16 groups,
+// 4096 / 8192: 32). Its grouping prologue costs 2-10 us more than the full tier's staging, its first PN2_BT_EARLY samples cost the
+// full tier's round, from ~200 samples on a sample is 160-175 ns against 250-390. npoint = 256: 61 us against 67 (full) at 1024
+// rank slots, 68 / 81 at 2048, 84 / 102 at 4096, 109 / 134 (pruned) at 8192; npoint = 128: no gain anywhere.
+inline bool fps_batch_covers(int ranks) { return ranks > 512 && ranks <= 8192; }
+inline bool fps_batch_pays(int ranks, int m) { return fps_batch_covers(ranks) && m >= 256; }
 
 #ifdef PN2_BT_STATS
 // lab: [0] batches, [1] samples, [2] exact fallbacks, [3] bisection steps, [4] sum of list sizes, [5] (group, sample) updates,
@@ -172,7 +173,8 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
     constexpr int GW = P / GS;                         // groups per updater wave
     constexpr int CAP = kBtCand / W;                   // candidate lanes per updater wave
     constexpr int BT = UT + PN2_WAVE;                  // threads of the workgroup
-    static_assert(W * GW == 32 && (W == 4 || W == 8), "32 groups on four or eight updater waves");
+    static_assert((W * GW == 32 && (W == 4 || W == 8)) || (W == 8 && (GW == 2 || GW == 1)),
+                  "32 groups on four or eight updater waves; 16 / 8 groups (2048 / 1024 rank slots) on eight");
     float4 *lds_rank = reinterpret_cast<float4 *>(smem + 256);
     BtXchg *xch = reinterpret_cast<BtXchg *>(smem + fps_batch_xchg_offset(P, UT));
     float4 *ring = reinterpret_cast<float4 *>(smem + fps_batch_xchg_offset(P, UT) + 2 * sizeof(BtXchg));   // [kBtCand] samples of the batch: x, y, z, k
@@ -415,8 +417,9 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
             }
         };
         auto update_all = [&]() __attribute__((always_inline)) {
-            update_group(std::integral_constant<int, 0>()); update_group(std::integral_constant<int, 1>());
-            update_group(std::integral_constant<int, 2>()); update_group(std::integral_constant<int, 3>());
+            update_group(std::integral_constant<int, 0>());
+            if constexpr (GW >= 2) update_group(std::integral_constant<int, 1>());
+            if constexpr (GW >= 4) { update_group(std::integral_constant<int, 2>()); update_group(std::integral_constant<int, 3>()); }
             if constexpr (GW == 8) {
                 update_group(std::integral_constant<int, 4>()); update_group(std::integral_constant<int, 5>());
                 update_group(std::integral_constant<int, 6>()); update_group(std::integral_constant<int, 7>());
@@ -567,7 +570,8 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
                     continue;
                 }
                 constexpr int CH = PN2_WAVE / GW;                                 // samples per chunk: lane l tests sample l / GW against group l % GW
-                constexpr unsigned long long kStride = GW == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;   // one bit per sample
+                constexpr unsigned long long kStride = GW == 8 ? 0x0101010101010101ull : GW == 4 ? 0x1111111111111111ull
+                                                       : GW == 2 ? 0x5555555555555555ull : ~0ull;   // one bit per sample
                 const int np = min(avail - done, CH);
                 const int pi = lane / GW;                                        // this lane's sample of the chunk
                 const float4 s = ring[done + (pi < np ? pi : 0)];
@@ -576,7 +580,7 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
                 const float az = __fsub_rn(s.z, __builtin_amdgcn_fmed3f(s.z, blz, bhz));
                 const float bd = __fadd_rn(__fadd_rn(__fmul_rn(ax, ax), __fmul_rn(ay, ay)), __fmul_rn(az, az));
                 unsigned long long touched = ~__ballot(bd >= thr);               // NaN -> not far -> updated
-                if (np < CH) touched &= (1ull << (np * GW)) - 1ull;
+                if (np * GW < 64) touched &= (1ull << (np * GW)) - 1ull;
                 // group by group (static): the samples that reach group g, straight into that group's update -- no dispatch on a
                 // group number (three compare-and-branch pairs per (group, sample) otherwise)
                 if (touched) {
@@ -603,8 +607,9 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
                                 update_group(gic);
                             }
                         };
-                        one_group(std::integral_constant<int, 0>()); one_group(std::integral_constant<int, 1>());
-                        one_group(std::integral_constant<int, 2>()); one_group(std::integral_constant<int, 3>());
+                        one_group(std::integral_constant<int, 0>());
+                        if constexpr (GW >= 2) one_group(std::integral_constant<int, 1>());
+                        if constexpr (GW >= 4) { one_group(std::integral_constant<int, 2>()); one_group(std::integral_constant<int, 3>()); }
                         if constexpr (GW == 8) {
                             one_group(std::integral_constant<int, 4>()); one_group(std::integral_constant<int, 5>());
                             one_group(std::integral_constant<int, 6>()); one_group(std::integral_constant<int, 7>());

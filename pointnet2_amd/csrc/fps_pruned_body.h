@@ -61,6 +61,10 @@ constexpr int kPrBins = 64;            // histogram bins per axis (= one wave)
 constexpr int kPrK0 = 4, kPrK1 = 4, kPrK2 = 2;                 // parts per pass: 32 leaves
 constexpr int kPrGroups = kPrK0 * kPrK1 * kPrK2;
 constexpr int kPrHistRows = 1 + kPrK0 + kPrK0 * kPrK1;         // segments of the three passes
+// small clouds (the batched tier at 1024 / 2048 rank slots) are cut into 8 / 16 leaves: 2 x 2 x 2 and 4 x 2 x 2 parts
+constexpr int pr_k0(int G) { return G >= 16 ? 4 : 2; }
+constexpr int pr_k1(int G) { return G == 32 ? 4 : 2; }
+constexpr int pr_k2(int) { return 2; }
 
 // LDS layout (bytes): [0,64) wave keys (2 parities x 4) | [64,256) reduction scratch | mirror / staging 16 * NS |
 // hist 21 x 64 ints | gbox 32 x 8 floats
@@ -127,7 +131,10 @@ __device__ __forceinline__ void fps_pruned_prologue(int n, int Q, const float *_
     constexpr int W = T / PN2_WAVE, NS = T * P;
     constexpr int GW = P / GS;                    // groups per wave
     constexpr int G = W * GW;                     // groups = leaves = test lanes
-    static_assert(G == kPrGroups && (W == 4 || W == 8) && (GS & 1) == 0, "32 groups: four waves of eight or eight waves of four");
+    static_assert((G == kPrGroups || ((G == 16 || G == 8) && W == 8)) && (W == 4 || W == 8) && (GS & 1) == 0,
+                  "32 groups: four waves of eight or eight waves of four; 16 / 8 groups: eight waves of two / one");
+    constexpr int K0 = pr_k0(G), K1 = pr_k1(G), K2 = pr_k2(G), R = K1 * K2;
+    static_assert(K0 * K1 * K2 == G && NS / G == 64 * GS, "a leaf = GS slots of all 64 lanes of one wave");
     float *scratch = reinterpret_cast<float *>(smem + (W > 4 ? 0 : 64));                // 8 floats per wave (eight waves: the whole 256-byte header)
     float4 *lds_rank = reinterpret_cast<float4 *>(smem + 256);                          // mirror [NS], first the staging copy
     char *tab = smem + 256 + (size_t)16 * NS;
@@ -201,9 +208,9 @@ __device__ __forceinline__ void fps_pruned_prologue(int n, int Q, const float *_
     int seg[P], rank[P];
 #pragma unroll
     for (int j = 0; j < P; ++j) seg[j] = 0;
-    constexpr int kLevelK[3] = {kPrK0, kPrK1, kPrK2};
-    constexpr int kLevelRow[3] = {0, 1, 1 + kPrK0};                   // first histogram row of the level
-    constexpr int kLevelSegs[3] = {1, kPrK0, kPrK0 * kPrK1};
+    constexpr int kLevelK[3] = {K0, K1, K2};
+    constexpr int kLevelRow[3] = {0, 1, 1 + K0};                      // first histogram row of the level
+    constexpr int kLevelSegs[3] = {1, K0, K0 * K1};
 #pragma unroll
     for (int lev = 0; lev < 3; ++lev) {
         int *hl = hist + kLevelRow[lev] * kPrBins;
@@ -222,7 +229,7 @@ __device__ __forceinline__ void fps_pruned_prologue(int n, int Q, const float *_
             hl[sg * kPrBins + lane] = pr_prefix_sum_incl(h) - h;
         }
         __syncthreads();
-        const int child = NS / (lev == 0 ? kPrK0 : lev == 1 ? kPrK0 * kPrK1 : kPrK0 * kPrK1 * kPrK2);   // a power of two, constant once unrolled
+        const int child = NS / (lev == 0 ? K0 : lev == 1 ? K0 * K1 : K0 * K1 * K2);   // a power of two, constant once unrolled
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             rank[j] += hl[seg[j]];
@@ -236,9 +243,11 @@ __device__ __forceinline__ void fps_pruned_prologue(int n, int Q, const float *_
     // with this map, 1.56 with id % 4) --, group 2 * a + r / 4 of that wave; position p of the leaf -> lane p % 64, slot p / 64
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-        const int a = seg[j] >> 3, r = seg[j] & 7;
-        const int dt = ((r + a) & (W - 1)) * 64 + (rank[j] & 63);
-        const int dp = (a * (8 / W) + r / W) * GS + (rank[j] >> 6);   // four waves: group 2 a + r / 4, eight waves: group a
+        const int a = seg[j] / R, r = seg[j] % R;
+        // 32 leaves: wave (r + a) % W, group 2 a + r / 4 (four waves) or a (eight waves); fewer leaves (eight waves): wave id % 8,
+        // group id / 8 -- neighbours along every axis still land on different waves
+        const int dt = (G == kPrGroups ? ((r + a) & (W - 1)) : (seg[j] & (W - 1))) * 64 + (rank[j] & 63);
+        const int dp = (G == kPrGroups ? (a * (8 / W) + r / W) : seg[j] / W) * GS + (rank[j] >> 6);
         lds_rank[dt * P + dp] = make_float4(px[j], py[j], pz[j], __int_as_float(t + j * T));
     }
     __syncthreads();

@@ -111,7 +111,7 @@ static int g_lab_clear_with_kernel = 0;
 // beside the position table: n > ~6000).
 // TIER of the producers: 0 = fps_reg_body; 1 = the kd-grouped chain of fps_pruned_body.h (4096 / 8192 rank slots: P = 8, 16) on four
 // waves; 2 = the same groups with several samples per exchange (fps_batch_body.h: eight updater waves and the picker, 576 threads).
-constexpr int fused_pruned_gs(int P) { return P == 8 ? 2 : 4; }       // slots per group at 16 / 32 slots per thread
+constexpr int fused_pruned_gs(int P) { return P <= 8 ? 2 : 4; }       // slots per group (pruned tier: 16 / 32 slots per thread; batched: 2 .. 16)
 template <int P, int LPQ, int TIER = 0>
 __global__ __launch_bounds__(TIER == 2 ? kBtT : kFusedThreads) void sa_fused_kernel(int b, int n, int m, int Q, int nsample, float thr,
                                                                  float radius, int qpb, int cpc, unsigned tag,
@@ -336,7 +336,8 @@ static int sample_and_group_common(int b, int n, int m, float radius, int nsampl
     // producers: the kd-grouped chain where it exists (4096 / 8192 rank slots) and the chain is long enough to pay for the
     // kd build (the rule of pn2_farthest_point_sample, fps.hip)
     if (fps_variant < PN2_FPS_AUTO || fps_variant > PN2_FPS_BATCH) return PN2_E_ARG;
-    if ((fps_variant == PN2_FPS_PRUNED || fps_variant == PN2_FPS_BATCH) && P != 8 && P != 16) return PN2_E_ARG;
+    if (fps_variant == PN2_FPS_PRUNED && P != 8 && P != 16) return PN2_E_ARG;
+    if (fps_variant == PN2_FPS_BATCH && !fps_batch_covers(ranks)) return PN2_E_ARG;
     const int tier = fps_variant == PN2_FPS_BATCH || (fps_variant == PN2_FPS_AUTO && fps_batch_pays(ranks, m))     ? 2
                      : fps_variant == PN2_FPS_PRUNED || (fps_variant == PN2_FPS_AUTO && fps_pruned_pays(ranks, m)) ? 1
                                                                                                                     : 0;
@@ -347,7 +348,7 @@ static int sample_and_group_common(int b, int n, int m, float radius, int nsampl
 #define PN2_FUSED_P(PP, PR) PN2_FUSED_CASE(PP, 0, PR); PN2_FUSED_CASE(PP, 8, PR); PN2_FUSED_CASE(PP, 16, PR); PN2_FUSED_CASE(PP, 32, PR)
     PN2_FUSED_P(1, 0); PN2_FUSED_P(2, 0); PN2_FUSED_P(4, 0); PN2_FUSED_P(8, 0); PN2_FUSED_P(16, 0);
     PN2_FUSED_P(8, 1); PN2_FUSED_P(16, 1);
-    PN2_FUSED_P(8, 2); PN2_FUSED_P(16, 2);
+    PN2_FUSED_P(2, 2); PN2_FUSED_P(4, 2); PN2_FUSED_P(8, 2); PN2_FUSED_P(16, 2);
 #undef PN2_FUSED_P
 #undef PN2_FUSED_CASE
     return PN2_E_TOO_LARGE;

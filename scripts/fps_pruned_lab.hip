@@ -23,7 +23,7 @@ static float timed(int reps, const std::function<void()> &fn)
 int main(int argc, char **argv)
 {
     const int b = 32;
-    for (int n : {4096, 8192}) {
+    for (int n : {4096, 8192, 1024, 2048}) {
         for (int kind = 0; kind < 2; ++kind) {
             const int m = getenv("LAB_M") ? atoi(getenv("LAB_M")) : n == 3000 ? 750 : 1024;
             std::vector<float> h((size_t)b * n * 3);
@@ -42,7 +42,7 @@ int main(int argc, char **argv)
             CK(hipMalloc(&d_xyz, h.size() * 4)); CK(hipMalloc(&d_out, (size_t)b * m * 4));
             CK(hipMemcpy(d_xyz, h.data(), h.size() * 4, hipMemcpyHostToDevice));
             std::vector<int> ref((size_t)b * m), got((size_t)b * m);
-            const int P512 = n <= 4096 ? 8 : 16, P256 = 2 * P512;
+            const int P512 = n <= 1024 ? 2 : n <= 2048 ? 4 : n <= 4096 ? 8 : 16, P256 = 2 * P512;
             struct V { const char *name; std::function<int(int)> run; };
             std::vector<V> vs = {
                 {"full 512", [&](int mm) { return pn2_farthest_point_sample_ex(512, P512, b, n, mm, d_xyz, d_out, nullptr); }},

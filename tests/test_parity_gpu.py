@@ -166,6 +166,41 @@ def test_fps_pruned_tier_index_exact(cuda, oracle, name, make, m, gs):
         assert np.array_equal(host(new_xyz), oracle.gather_point(xyz, want)), variant
 
 
+# The batched tier also exists at 513..2048 points (8 / 16 groups on its eight updater waves): cls / part_seg level 1.
+BATCH_SMALL_CASES = [
+    ("sphere1024", lambda: S.sphere_clouds(4, 1024, 230), 512),
+    ("cube2048", lambda: S.uniform_clouds(3, 2048, 231), 512),
+    ("dup1024", lambda: S.duplicated_clouds(3, 1024, 232), 400),
+    ("drop1024", lambda: S.dropout_clouds(3, 1024, 233), 512),          # provider.py:227-233: up to 87 % of the cloud on one spot
+    ("lattice2000", lambda: S.lattice_clouds(2, 2000, 234), 700),
+    ("same700", lambda: S.identical_clouds(2, 700, 235), 300),
+    ("n513", lambda: S.sphere_clouds(2, 513, 236), 260),
+    ("n1500_m_gt_n", lambda: S.uniform_clouds(2, 1500, 237), 1600),
+    ("n1025", lambda: S.uniform_clouds(2, 1025, 238), 1025),
+    ("flat2048", lambda: S.sphere_clouds(2, 2048, 239) * np.array([1.0, 0.0, 1.0], np.float32), 300),
+]
+
+
+@pytest.mark.parametrize("name,make,m", BATCH_SMALL_CASES, ids=[c[0] for c in BATCH_SMALL_CASES])
+def test_fps_batched_tier_small_clouds_index_exact(cuda, oracle, name, make, m):
+    from pointnet2_amd import _C
+    import pointnet2_amd as P
+    xyz = np.ascontiguousarray(make(), dtype=np.float32)
+    b, n, _ = xyz.shape
+    want = oracle.farthest_point_sample(m, xyz)
+    x = dev(xyz, cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    for rep in range(2):
+        out = torch.full((b, m), -1, dtype=torch.int32, device=cuda)
+        rc = _C.lib().pn2_farthest_point_sample_variant(3, b, n, m, x.data_ptr(), None, out.data_ptr(), None, st)
+        assert rc == 0, rc
+        got = host(out)
+        assert np.array_equal(got, want), "%s rep %d: first mismatch at %s" % (name, rep, np.argwhere(got != want)[:3])
+    idx, new_xyz = P.farthest_point_sample_gather(m, x)                  # the operator (AUTO: this tier from npoint 256)
+    assert np.array_equal(host(idx), want)
+    assert np.array_equal(host(new_xyz), oracle.gather_point(xyz, want))
+
+
 def test_fps_pruned_tier_refuses_other_sizes(cuda):
     from pointnet2_amd import _C
     st = torch.cuda.current_stream().cuda_stream
@@ -173,7 +208,7 @@ def test_fps_pruned_tier_refuses_other_sizes(cuda):
         x = torch.rand((1, n, 3), device=cuda)
         out = torch.zeros((1, 8), dtype=torch.int32, device=cuda)
         assert _C.lib().pn2_farthest_point_sample_variant(2, 1, n, 8, x.data_ptr(), None, out.data_ptr(), None, st) == -3 or n > 16384
-        assert _C.lib().pn2_farthest_point_sample_variant(3, 1, n, 8, x.data_ptr(), None, out.data_ptr(), None, st) == -3 or n > 16384
+        assert _C.lib().pn2_farthest_point_sample_variant(3, 1, n, 8, x.data_ptr(), None, out.data_ptr(), None, st) == (0 if n == 2048 else -3) or n > 16384
 
 
 def test_fps_gather_fused(cuda, oracle):

@@ -31,9 +31,10 @@ def test_metric_shape_kernels_hold_their_times(cuda):
     stage.overlap_()
     v = stage.verify("overlap")                                    # the timed launch's outputs against the operator path, on the device
     assert v["ok"], v
-    # measured + 5 %: 378 / 367-369 us on every box seen in rounds 5-6; round 4's kernels (417 / 402) must fail here
-    assert t_overlap <= 400.0, "overlapped sample-and-group launch: %.1f us (rounds 5-6: 377-380)" % t_overlap
-    assert t_fps <= 390.0, "farthest_point_sample at the metric shape: %.1f us (rounds 5-6: 367-369)" % t_fps
+    # measured + ~7 % (boxes of the pool differ by a few per cent): round 6's batched FPS tier 228 / 220 us; round 5's
+    # kernels (378 / 367) and the four-updater-wave form of the tier (264 / 255) must fail here
+    assert t_overlap <= 246.0, "overlapped sample-and-group launch: %.1f us (round 6: 228-234; round 5: 377-380)" % t_overlap
+    assert t_fps <= 236.0, "farthest_point_sample at the metric shape: %.1f us (round 6: 218-222; round 5: 367-369)" % t_fps
     assert t_ball <= 36.0, "query_ball_group_xyz: %.1f us (round 5: 29.8)" % t_ball
     stage.overlap_()
     torch.cuda.synchronize()
