@@ -132,7 +132,11 @@ __device__ __forceinline__ void lds_max_u32(unsigned *p, unsigned v)
 // full tier's round, from ~200 samples on a sample is 160-175 ns against 250-390. npoint = 256: 61 us against 67 (full) at 1024
 // rank slots, 68 / 81 at 2048, 84 / 102 at 4096, 109 / 134 (pruned) at 8192; npoint = 128: no gain anywhere.
 inline bool fps_batch_covers(int ranks) { return ranks > 512 && ranks <= 8192; }
+#ifdef PN2_BT_LAB_NEVER_AUTO      // A/B library: the size rule never chooses this tier (scripts/: what did the tier change in a model?)
+inline bool fps_batch_pays(int, int) { return false; }
+#else
 inline bool fps_batch_pays(int ranks, int m) { return fps_batch_covers(ranks) && m >= 256; }
+#endif
 
 #ifdef PN2_BT_STATS
 // lab: [0] batches, [1] samples, [2] exact fallbacks, [3] bisection steps, [4] sum of list sizes, [5] (group, sample) updates,
