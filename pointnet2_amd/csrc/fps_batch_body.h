@@ -80,7 +80,7 @@ struct BtXchg {
     unsigned cnt[kBtMaxW];
     unsigned bound[kBtMaxW];
     unsigned count;                            // samples of this batch published so far | kBtEnd | kBtFill
-    unsigned pad0;
+    unsigned single;                           // after this batch: that many samples one per exchange (SLOW BATCHES below)
     unsigned theta, vlast;                     // for the NEXT collect: threshold bits, value bits of the batch's last sample
     unsigned pad[4];
 };
@@ -141,7 +141,8 @@ inline bool fps_batch_pays(int ranks, int m) { return fps_batch_covers(ranks) &&
 #ifdef PN2_BT_STATS
 // lab: [0] batches, [1] samples, [2] exact fallbacks, [3] bisection steps, [4] sum of list sizes, [5] (group, sample) updates,
 // [6] picker cycles in READ, [7] picker cycles in PICK, [8] picker cycles waiting at the barrier, [9] updater 0 cycles in COLLECT,
-// [10] updater 0 cycles from the barrier to the end flag, [11] tie resolutions
+// [10] updater 0 cycles from the barrier to the end flag, [11] tie resolutions, [12] speculation misses, [13] samples taken one per
+// exchange after slow batches, [14] such runs
 __device__ unsigned long long g_bt_stats[16];
 #ifndef PN2_BT_STATS_FROM
 #define PN2_BT_STATS_FROM 0
@@ -166,6 +167,23 @@ __device__ unsigned long long g_bt_stats[16];
 #endif
 #ifndef PN2_BT_G0
 #define PN2_BT_G0 0.10f               // initial 1 - theta / (last sample value)
+#endif
+// SLOW BATCHES. A batch costs a COLLECT + a barrier + a list read whatever it yields (~0.6 us), and a sample whose arg-max needs
+// the 64-bit keys costs three times the speculative one; the classic round is 0.39 us at 4096 rank slots. Clouds with many EQUAL
+// values at the top (lattices, coordinates quantised to a coarse grid, duplicated points) end most batches after a sample or two
+// -- the bound is strict -- or resolve ties at every sample, and the tier then costs 1.2-2 x the full tier's chain
+// (profiles/r06/fps_tier_by_cloud.txt: 493 / 694 / 778 us against 395 at 4096 -> 1024). The picker therefore CLOCKS both forms:
+// the EARLY rounds give the cost of a one-per-exchange round on this cloud and this device, the interval between two list
+// barriers the cost of a batch. When the batches of a run (decayed sums) cost more per sample than the round -- 1.5 x the round
+// while fewer than PN2_BT_SLOW_MIN batches have been clocked --, the workgroup takes the next R samples one per exchange (the
+// EARLY round), then tries batches again; R doubles (16 .. 512) while the batches stay slow and starts over after eight batches
+// in a row that pay. Same samples either way -- both
+// forms are the reference's arg-max; only the schedule depends on the clock.
+#ifndef PN2_BT_SLOW_MIN
+#define PN2_BT_SLOW_MIN 3
+#define PN2_BT_QUICK 1
+#define PN2_BT_SINGLE0 16
+#define PN2_BT_SINGLE1 512
 #endif
 
 template <int P, int GS, bool PUBLISH, int UT = kBtUT>
@@ -202,12 +220,43 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
 #endif
         for (int i = lane; i < (int)(2 * sizeof(BtXchg) / 4); i += PN2_WAVE) reinterpret_cast<unsigned *>(xch)[i] = 0u;   // counts, bounds, flags
         for (int i = 0; i < kPrPrologueBarriers; ++i) __syncthreads();
-        for (; j < jE; ++j) __syncthreads();     // the updaters' early rounds: one barrier each
+        long long e0 = 0;
+        for (; j < jE; ++j) {                    // the updaters' early rounds: one barrier each
+            if (j == 8) e0 = (long long)__builtin_readcyclecounter();
+            __syncthreads();
+        }
+        // SLOW BATCHES: cycles of a one-per-exchange round (none measured: batches always pay), decayed cycles / samples of the
+        // batches since the last such run, batches counted, length of the next run, clock at the previous idle point
+        const float round_cyc = jE >= 24 ? (float)((long long)__builtin_readcyclecounter() - e0) / (float)(jE - 8) : 1e30f;
+        // The bookkeeping runs in the picker's idle time ahead of a list barrier (the updaters are collecting), not between the last
+        // pick and the end flag: a decision is published with the end flag of the batch that follows it.
+        float bt_cyc = 0.f, bt_smp = 0.f;
+        int bt_n = 0, bt_paid = 0, run = PN2_BT_SINGLE0, a_prev = 0, single_next = 0;
+        long long qb = 0;
         float g = PN2_BT_G0;
         int par = 0;
         if (j < m)
         for (;;) {
             const long long q0 = PN2_BT_CLOCK();
+            // SLOW BATCHES, in the idle time (the clock's latency too: s_memtime shares the LDS counter, behind the barrier it sat
+            // on the list read): the batch that just ended into the decayed sums, then the decision
+            {
+                const long long qn = (long long)__builtin_readcyclecounter();
+                if (bt_n > 0) {
+                    bt_cyc = 0.75f * bt_cyc + (float)(qn - qb); bt_smp = 0.75f * bt_smp + (float)a_prev;
+                    if (bt_n > PN2_BT_QUICK) {       // at least two whole batches of this run have been clocked
+                        if (bt_cyc > bt_smp * round_cyc * (bt_n > PN2_BT_SLOW_MIN ? 1.0f : 1.5f)) {
+                            single_next = run;
+                            run = min(2 * run, PN2_BT_SINGLE1);
+                            bt_n = -1; bt_paid = 0; bt_cyc = 0.f; bt_smp = 0.f;   // the next interval holds the run: not folded
+                        } else if (++bt_paid >= 8) {
+                            run = PN2_BT_SINGLE0;
+                        }
+                    }
+                }
+                qb = qn;
+                ++bt_n;
+            }
             __syncthreads();                     // the list of this batch is complete
             const long long q1 = PN2_BT_CLOCK();
             BtXchg &X = xch[par];
@@ -368,11 +417,20 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
             else if (total < PN2_BT_LIST_LO) g = fminf(g * 1.25f, 0.5f);
             X.theta = __float_as_uint(__fmul_rn(__int_as_float(vlastb), 1.0f - g));
             X.vlast = (unsigned)vlastb;
+            a_prev = a;
+            int single = min(single_next, m - (j + a));
+            if (single_next) { PN2_BT_STAT(13, single); PN2_BT_STAT(14, 1); }
+            single_next = 0;
+            single = __builtin_amdgcn_readfirstlane(single);
+            X.single = (unsigned)single;
             if (lane == 0)
                 __hip_atomic_store(&X.count, (unsigned)a | kBtEnd | (fill ? kBtFill : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             PN2_BT_STAT(0, 1); PN2_BT_STAT(1, a); PN2_BT_STAT(4, total); PN2_BT_STAT(6, q2 - q1); PN2_BT_STAT(7, q3 - q2); PN2_BT_STAT(8, q1 - q0);
             j = __builtin_amdgcn_readfirstlane(j + a);
             if (fill || j >= m) break;
+            for (int i = 0; i < single; ++i) __syncthreads();     // the updaters' one-per-exchange rounds: one barrier each
+            j += single;
+            if (j >= m) break;
             par ^= 1;
         }
     } else {
@@ -445,9 +503,13 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
         // While the farthest-point distance still halves every few samples a list determines three or four samples and every
         // sample reaches most groups: a batch then costs more than the classic round (measured: the first 64 samples 44 us in
         // batches, 25 us like this; the whole chain at 4096 -> 1024 280 -> 255 us). The picker and its barriers: one per round, see its branch.
-        {
+        // The update works on single registers, not pairs, as the full tier does at 512 threads (fps_body.h: two waves per SIMD, 411
+        // against 438 ns per round there; 395 against 440 here). The index is stored at once: behind the next round's key reads
+        // (the full tier's place for it) the overlapped launch lost 6 us. Also what the workgroup falls back to when batches do not
+        // pay (SLOW BATCHES above).
+        auto single_rounds = [&](const int jend) __attribute__((always_inline)) {
             double *partial = reinterpret_cast<double *>(smem);                  // [2][W]: the pruned layout's wave keys
-            for (; j < jE; ++j) {
+            for (; j < jend; ++j) {
                 double kd[P];
 #pragma unroll
                 for (int p = 0; p < P; ++p) kd[p] = __hiloint2double(__float_as_int(md[p]), (int)low[p]);
@@ -477,11 +539,21 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
                         __hip_atomic_store(gtag + j, ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)k, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
                 }
-                sxy.x = s.x; syy.x = s.y; szk.x = s.z;
-                update_all();
+                if constexpr (P >= 16) {                                         // (16 slots on single registers: spills at 576 threads)
+                    sxy.x = s.x; syy.x = s.y; szk.x = s.z;
+                    update_all();
+                } else {
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        const float d = p & 1 ? sqdist(xx[p / 2].y, yy[p / 2].y, zz[p / 2].y, s.x, s.y, s.z)
+                                              : sqdist(xx[p / 2].x, yy[p / 2].x, zz[p / 2].x, s.x, s.y, s.z);   // tf_sampling_g.cu:141-143
+                        md[p] = vmin_f32(d, md[p]);                              // :144
+                    }
+                }
             }
-            if (jE > 1) thetab = __float_as_uint(__fmul_rn(__uint_as_float(vlastb), 1.0f - PN2_BT_G0));
-        }
+            thetab = __float_as_uint(__fmul_rn(__uint_as_float(vlastb), 1.0f - PN2_BT_G0));
+        };
+        if (jE > 1) single_rounds(jE);
         int par = 0;
         if (j < m)
         for (;;) {
@@ -638,6 +710,11 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
             if ((c & kBtFill) || j >= m) break;
             thetab = X.theta;
             vlastb = X.vlast;
+            const int single = __builtin_amdgcn_readfirstlane((int)X.single);    // SLOW BATCHES (the picker's decision, published ahead of the end flag)
+            if (single) {
+                single_rounds(j + single);
+                if (j >= m) break;
+            }
             par ^= 1;
         }
     }

@@ -52,6 +52,12 @@ def identical_clouds(b, n, seed=0):
     return np.repeat(p, n, axis=1).copy()
 
 
+def quantized_clouds(b, n, seed=0, step=1.0 / 64):
+    """Uniform-cube clouds with coordinates rounded to a grid (scanner / voxel output): few distinct distances at the top, so the
+    batched FPS tier's lists end after a sample or two (fps_batch_body.h, SLOW BATCHES)."""
+    return (np.round(uniform_clouds(b, n, seed) / np.float32(step)) * np.float32(step)).astype(np.float32)
+
+
 def lattice_clouds(b, n, seed=0):
     """Points on a coarse integer lattice: many EXACTLY equal distances (stress for tie rules)."""
     rng = np.random.default_rng(seed)

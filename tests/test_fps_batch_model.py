@@ -41,7 +41,9 @@ def _lanes(x, slots):
     return unit
 
 
-def _batched_fps(x, m, early=EARLY):
+def _batched_fps(x, m, early=EARLY, runs=None):
+    """runs: None, or a function batch number -> how many samples to take one per exchange after that batch (the kernel decides
+    that by its clock -- SLOW BATCHES in fps_batch_body.h --, so any schedule must give the oracle's samples)"""
     x = x.astype(F)
     n = x.shape[0]
     q = (n + REF_THREADS - 1) // REF_THREADS
@@ -150,6 +152,14 @@ def _batched_fps(x, m, early=EARLY):
         elif total < LIST_LO:
             g = min(F(g * F(1.25)), F(0.5))
         theta_b = int(_bits(F(_bits_to_float(vlast_b) * F(F(1.0) - g))))
+        single = min(runs(len(batches)) if runs else 0, m - len(out))
+        if single:                                                                       # one per exchange, then lists again from theta = (1 - G0) v_last
+            for _ in range(single):
+                p, vlast = argmax_all()
+                out.append(p)
+                td = np.minimum(td, _sqdist(x, x[p]))
+            vlast_b = int(_bits(vlast))
+            theta_b = int(_bits(F(vlast * F(F(1.0) - G0))))
     return np.array(out, dtype=np.int32), batches
 
 
@@ -176,3 +186,14 @@ def test_batches_without_the_early_phase_are_exact_too(oracle):
     want = oracle.farthest_point_sample(200, clouds)
     got, _ = _batched_fps(clouds[0], 200, early=1)
     assert np.array_equal(got, want[0])
+
+
+@pytest.mark.parametrize("name,make,n,m", CASES[:4], ids=[c[0] for c in CASES[:4]])
+def test_runs_of_single_rounds_between_batches_are_exact(oracle, name, make, n, m):
+    """the kernel leaves batches for R samples when its clock says they do not pay, R = 16, 32, ...: whatever the schedule, the
+    samples are the oracle's (the hand-over is the threshold: theta restarts from the last single sample's value)"""
+    clouds = make(1, n, 29)
+    want = oracle.farthest_point_sample(m, clouds)
+    for runs in (lambda k: 16 if k % 3 == 2 else 0, lambda k: 5 * k % 23, lambda k: 64 if k == 2 else 0):
+        got, _ = _batched_fps(clouds[0], m, runs=runs)
+        assert np.array_equal(got, want[0]), "%s: first mismatch at %s" % (name, np.argwhere(got != want[0])[:3].ravel())

@@ -201,6 +201,51 @@ def test_fps_batched_tier_small_clouds_index_exact(cuda, oracle, name, make, m):
     assert np.array_equal(host(new_xyz), oracle.gather_point(xyz, want))
 
 
+# SLOW BATCHES (fps_batch_body.h): on clouds whose lists end after a sample or two, or whose arg-max needs the 64-bit keys at every
+# sample, the batched tier leaves batches for runs of one-per-exchange rounds -- decided by the picker's CLOCK, so the schedule
+# differs from launch to launch and from cloud to cloud; the samples must not. A few clouds against the oracle, then whole
+# 32-cloud batches (what the bench launches) five times against the full tier, through the plain kernel and through the
+# overlapped sample-and-group launch (the producers publish the singles one by one, the batches in one store).
+SLOW_BATCH_CASES = [
+    ("quantized64_4096", lambda b: S.quantized_clouds(b, 4096, 240), 1024),
+    ("quantized64_2048", lambda b: S.quantized_clouds(b, 2048, 241), 1024),
+    ("quantized16_8192", lambda b: S.quantized_clouds(b, 8192, 242, 1.0 / 16), 1024),
+    ("dup4096", lambda b: S.duplicated_clouds(b, 4096, 243), 1024),
+    ("dup8192", lambda b: S.duplicated_clouds(b, 8192, 244), 700),
+    ("dup1024", lambda b: S.duplicated_clouds(b, 1024, 245), 1024),
+    ("lattice4096", lambda b: S.lattice_clouds(b, 4096, 246), 1024),
+    ("lattice1024", lambda b: S.lattice_clouds(b, 1024, 247), 512),
+]
+
+
+@pytest.mark.parametrize("name,make,m", SLOW_BATCH_CASES, ids=[c[0] for c in SLOW_BATCH_CASES])
+def test_fps_batched_tier_slow_batches_index_exact(cuda, oracle, name, make, m):
+    from pointnet2_amd import _C
+    import pointnet2_amd as P
+    small = np.ascontiguousarray(make(2), dtype=np.float32)
+    want = oracle.farthest_point_sample(m, small)
+    st = torch.cuda.current_stream().cuda_stream
+    lib = _C.lib()
+
+    def run(tier, x):
+        out = torch.full((x.shape[0], m), -1, dtype=torch.int32, device=cuda)
+        rc = lib.pn2_farthest_point_sample_variant(tier, x.shape[0], x.shape[1], m, x.data_ptr(), None, out.data_ptr(), None, st)
+        assert rc == 0, rc
+        return host(out)
+
+    assert np.array_equal(run(3, dev(small, cuda)), want), name
+    big = dev(np.ascontiguousarray(make(32), dtype=np.float32), cuda)
+    full = run(1, big)
+    for rep in range(5):
+        got = run(3, big)
+        assert np.array_equal(got, full), "%s rep %d: clouds %s differ from the full tier" % (name, rep, np.nonzero((got != full).any(axis=1))[0][:8])
+    # the overlapped launch (its producers run this tier from npoint 256): radius / nsample of the metric shape
+    for rep in range(2):
+        fps_idx, new_xyz = P.sample_and_group_xyz(m, 0.2, 32, big)[:2]
+        assert np.array_equal(host(fps_idx), full), (name, rep)
+        assert np.array_equal(host(new_xyz), np.take_along_axis(host(big), full[:, :, None].astype(np.int64).repeat(3, axis=2), axis=1)), (name, rep)
+
+
 def test_fps_pruned_tier_refuses_other_sizes(cuda):
     from pointnet2_amd import _C
     st = torch.cuda.current_stream().cuda_stream
