@@ -60,9 +60,21 @@ __global__ __launch_bounds__(NT, NT / 256) void ball_query_msg_kernel(int b, int
         if (threadIdx.x == 0) tab[0] = 0;
         cells = bq_build_grid<NT>(n, sc.bin_radius * 1.001f, data, sorted, tab + 1, misc, g);
     }
+    // Radii still to be served by the index-ordered sweep: all of them without a cell list; with one, the radii whose block of
+    // visited cells covers half of the grid or more (round 6). There the list prunes nothing -- on a uniform cube binned at 0.2
+    // a ball of radius 0.4 reaches 5 of the 5 cells of every axis, 4096 candidates per query -- while the sweep stops at the
+    // nsample-th hit (crowded balls: ~500 candidates for 128 hits); on the sphere-surface clouds of pointnet2_cls_msg.py:27 the
+    // same radius reaches 5 of 10 cells per axis and stays on the list. uniform-cube level (0.1, 0.2, 0.4): 108 us -> see
+    // profiles/r06/bq_msg_wide.txt. The cloud is restaged in index order once, behind the list passes.
+    unsigned todo = (1u << sc.count) - 1u;
     if (cells) {
         for (int i = 0; i < sc.count; ++i) {
             const BqScale &s = sc.s[i];
+            const float reach = s.radius * 1.001f;
+            const float fx = fminf(1.0f, (2.0f * reach * g.ix + 1.0f) / (float)g.gx);
+            const float fy = fminf(1.0f, (2.0f * reach * g.iy + 1.0f) / (float)g.gy);
+            const float fz = fminf(1.0f, (2.0f * reach * g.iz + 1.0f) / (float)g.gz);
+            if (__builtin_amdgcn_readfirstlane((int)(fx * fy * fz >= 0.5f))) continue;   // block-uniform: the grid is the workgroup's
 #define PN2_MSG_LOOP(LPQ)                                                                                           \
     bq_cells_query_loop<NT, LPQ, true, false>(n, m, s.nsample, s.thr, s.radius, s.radius * 1.001f, cloud, q0, q1, g, data, \
                                               xyz2, nullptr, nullptr, s.idx, s.cnt, s.grouped, subtract, sorted, tab,  \
@@ -71,11 +83,12 @@ __global__ __launch_bounds__(NT, NT / 256) void ball_query_msg_kernel(int b, int
             else if (s.lpq == 16) PN2_MSG_LOOP(16);
             else PN2_MSG_LOOP(32);
 #undef PN2_MSG_LOOP
+            todo &= ~(1u << i);
         }
-        return;
+        if (!todo) return;
     }
     // index-ordered LDS copy, padded to a multiple of 128 with points at +inf (never hit), swept per radius
-    __syncthreads();                                             // the binning pass may still be reading its scratch
+    __syncthreads();                                             // the binning / list passes may still be reading
     float4 *cloud_lds = reinterpret_cast<float4 *>(smem);
     const int npad = (n + 127) & ~127;
     for (int k = threadIdx.x; k < npad; k += NT) {
@@ -88,6 +101,7 @@ __global__ __launch_bounds__(NT, NT / 256) void ball_query_msg_kernel(int b, int
     }
     __syncthreads();
     for (int i = 0; i < sc.count; ++i) {
+        if (!((todo >> i) & 1u)) continue;
         const BqScale &s = sc.s[i];
         bq_block_body<true, true, false, NT, true>(n, m, s.nsample, s.thr, cloud, q0, q1, xyz1, xyz2, nullptr, nullptr, s.idx,
                                                    s.cnt, s.grouped, subtract, smem, 1u, max_ns);

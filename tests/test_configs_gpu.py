@@ -136,6 +136,38 @@ def test_msg_single_binning_at_config_shape(cuda, oracle, level):
         assert torch.equal(i1, idx) and torch.equal(c1, cnt), (label, radius)
 
 
+# Round 6: inside the one launch a radius whose block of visited cells covers half of the workgroup's grid or more is served by
+# the index-ordered sweep (restaged once behind the list passes) -- a per-cloud, per-radius decision taken on the device from the
+# grid the binning found. Volumetric clouds (uniform cube: 5 x 5 x 5 cells at 0.2, a ball of 0.4 reaches all of them), mixtures in
+# one batch (clouds of different extent take different branches), every radius wide, no radius wide.
+MSG_WIDE_CASES = [
+    ("cube_cls_msg_radii", lambda: S.uniform_clouds(4, 4096, 950), 512, [(0.1, 16), (0.2, 32), (0.4, 128)]),
+    ("cube_all_wide", lambda: S.uniform_clouds(3, 2048, 951), 256, [(0.3, 16), (0.5, 64), (0.9, 32)]),
+    ("mixed_extents", lambda: np.concatenate([S.uniform_clouds(2, 4096, 952), S.sphere_clouds(2, 4096, 953),
+                                              S.uniform_clouds(2, 4096, 954) * np.float32(2.5)], axis=0), 512, [(0.1, 16), (0.2, 32), (0.4, 128)]),
+    ("slab", lambda: S.uniform_clouds(3, 4096, 955) * np.array([1.0, 1.0, 0.05], np.float32), 300, [(0.05, 8), (0.1, 32), (0.3, 64)]),
+    ("two_radii", lambda: S.uniform_clouds(3, 3000, 956), 500, [(0.15, 24), (0.45, 100)]),
+]
+
+
+@pytest.mark.parametrize("name,make,npoint,scales", MSG_WIDE_CASES, ids=[c[0] for c in MSG_WIDE_CASES])
+def test_msg_wide_radii_take_the_sweep_inside_the_launch(cuda, oracle, name, make, npoint, scales):
+    import pointnet2_amd as P
+    xyz = np.ascontiguousarray(make(), dtype=np.float32)
+    x = _dev(xyz, cuda)
+    q = P.gather_point(x, P.farthest_point_sample(npoint, x))
+    wq = _host(q)
+    radii = [s[0] for s in scales]
+    nss = [s[1] for s in scales]
+    for rep in range(2):
+        outs = P.query_ball_group_xyz_msg(radii, nss, x, q, True)
+        for (radius, ns), (idx, cnt, grouped) in zip(scales, outs):
+            wi, wc = oracle.query_ball_point(radius, ns, xyz, wq)
+            assert np.array_equal(_host(cnt), wc), (name, radius)
+            assert np.array_equal(_host(idx), wi), (name, radius)
+            assert np.array_equal(_host(grouped), oracle.group_point(xyz, wi) - wq[:, :, None, :]), (name, radius)
+
+
 FP_IDS = [lv[0] for lv in RC.FP_LEVELS]
 
 
