@@ -179,6 +179,9 @@ __device__ unsigned long long g_bt_stats[16];
 // EARLY round), then tries batches again; R doubles (16 .. 512) while the batches stay slow and starts over after eight batches
 // in a row that pay. Same samples either way -- both
 // forms are the reference's arg-max; only the schedule depends on the clock.
+#ifndef PN2_BT_PACKED_FROM
+#define PN2_BT_PACKED_FROM 16       // the one-per-exchange round on register PAIRS from this many slots per thread (all sizes packed: 1024 -> 1024 182 -> 190 us)
+#endif
 #ifndef PN2_BT_SLOW_MIN
 #define PN2_BT_SLOW_MIN 3
 #define PN2_BT_QUICK 1
@@ -539,7 +542,7 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
                         __hip_atomic_store(gtag + j, ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)k, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if constexpr (P >= 16) {                                         // (16 slots on single registers: spills at 576 threads)
+                if constexpr (P >= PN2_BT_PACKED_FROM) {                         // (16 slots on single registers: spills at 576 threads)
                     sxy.x = s.x; syy.x = s.y; szk.x = s.z;
                     update_all();
                 } else {
