@@ -715,7 +715,7 @@ __device__ __forceinline__ void fps_batch_body(int n, int m, int Q, int cloud, c
             vlastb = X.vlast;
             const int single = __builtin_amdgcn_readfirstlane((int)X.single);    // SLOW BATCHES (the picker's decision, published ahead of the end flag)
             if (single) {
-                single_rounds(j + single);
+                single_rounds(min(j + single, m));                               // (the picker has clipped it already: a run never passes the output row)
                 if (j >= m) break;
             }
             par ^= 1;

@@ -228,10 +228,14 @@ def test_fps_batched_tier_slow_batches_index_exact(cuda, oracle, name, make, m):
     lib = _C.lib()
 
     def run(tier, x):
-        out = torch.full((x.shape[0], m), -1, dtype=torch.int32, device=cuda)
-        rc = lib.pn2_farthest_point_sample_variant(tier, x.shape[0], x.shape[1], m, x.data_ptr(), None, out.data_ptr(), None, st)
+        # one guard row behind the output: a run of single rounds that passed the end of a cloud's row would land in the next
+        # cloud's row (a difference below) or, for the last cloud, here
+        buf = torch.full((x.shape[0] + 1, m), -1, dtype=torch.int32, device=cuda)
+        rc = lib.pn2_farthest_point_sample_variant(tier, x.shape[0], x.shape[1], m, x.data_ptr(), None, buf.data_ptr(), None, st)
         assert rc == 0, rc
-        return host(out)
+        got = host(buf)
+        assert (got[-1] == -1).all(), "%s tier %d: wrote past the end of the output" % (name, tier)
+        return got[:-1]
 
     assert np.array_equal(run(3, dev(small, cuda)), want), name
     big = dev(np.ascontiguousarray(make(32), dtype=np.float32), cuda)
