@@ -87,7 +87,7 @@ __global__ __launch_bounds__(NT, NT / 256) void ball_query_cells_kernel(int b, i
     int cloud, part;
     decode_cloud_block(blockIdx.x, parts, b, cloud, part);
     const int q0 = part * qpb;
-    bq_cells_block_body<NT, LPQ, FUSE, false>(n, m, nsample, thr, radius, cloud, q0, min(q0 + qpb, m), xyz1, xyz2,
+    bq_cells_block_body<NT, LPQ, FUSE, false, true>(n, m, nsample, thr, radius, cloud, q0, min(q0 + qpb, m), xyz1, xyz2,   // BLK: crowded balls walk the first half of the indices first (ball_query_body.h)
                                      nullptr, nullptr, idx, pts_cnt, grouped, subtract, smem);
 }
 

@@ -266,6 +266,7 @@ constexpr int kBqMiscBytes = 1024;     // reduction scratch of the binning pass
 struct BqGrid {
     float ox, oy, oz, ix, iy, iz;
     int gx, gy, gz;
+    int nb;                                // index blocks of the cell list (bq_build_grid<NT, true>): 1, or 2 = sorted by (k >= n / 2, cell)
 };
 
 // Monotone non-decreasing in v (every fp32 operation below is), which is all the pruning needs:
@@ -347,9 +348,17 @@ __device__ __forceinline__ void bq_cell_count(int *cellend, int c, bool valid, i
 // better tool for both); `sorted` has not been written in that case.
 // pos_tab (optional, n entries): point k's position in `sorted` -- the overlapped launch's consumers look the
 // query point up by its index (the FPS sample) without a trip to global memory.
-template <int NT>
+// BLK (round 6): CROWDED BALLS. The output is the nsample SMALLEST indices of a ball. When a ball holds several times nsample
+// points (a uniform cube at r = 0.2: 137 of 4096 for nsample 32) the list's 27 cells are ~885 candidates and the sweep reads
+// ~960 until its 32nd hit -- neither prunes. With the cloud sorted by (index block, cell), block = k >= n / 2, a query walks the
+// first block's cells (~440 candidates, ~68 hits) and never reads the second: every hit below n / 2 is in the first block, so
+// nsample hits there ARE the answer. Decided per workgroup after the count pass from the occupancy: expected hits per ball =
+// (n / non-empty cells) x ball volume / cell volume >= 3 nsample (and both blocks' ends fit the table: <= 864 cells); the two
+// halves of the count table are merged otherwise and everything is as without BLK. crowd_nsample <= 0: never.
+template <int NT, bool BLK = false>
 __device__ __forceinline__ bool bq_build_grid(int n, float reach, const float *__restrict__ data, float4 *sorted,
-                                              int *cellend, float *misc, BqGrid &g, unsigned short *pos_tab = nullptr)
+                                              int *cellend, float *misc, BqGrid &g, unsigned short *pos_tab = nullptr,
+                                              int crowd_nsample = 0)
 {
     constexpr int kBqPtsPerThread = kBqCellsMaxPoints / NT, kBqWavesT = NT / 64;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -438,10 +447,13 @@ __device__ __forceinline__ bool bq_build_grid(int n, float reach, const float *_
     g.ox = lx; g.oy = ly; g.oz = lz;
     g.ix = 1.0f / cx; g.iy = 1.0f / cy; g.iz = 1.0f / cz;
     g.gx = dim(ex, cx); g.gy = dim(ey, cy); g.gz = dim(ez, cz);
-    const int ncells = g.gx * g.gy * g.gz;
-    if (ncells < kBqMinCells) return false;
+    g.nb = 1;
+    const int ncells1 = g.gx * g.gy * g.gz;
+    if (ncells1 < kBqMinCells) return false;
+    const bool two = BLK && crowd_nsample > 0 && 2 * ncells1 + 1 <= kBqTabInts - 1;   // block-uniform: count per (block, cell)
+    const int nhalf = n >> 1;
 
-    for (int c = t; c < ncells; c += NT) cellend[c] = 0;
+    for (int c = t; c < (two ? 2 * ncells1 : ncells1); c += NT) cellend[c] = 0;
     __syncthreads();
     int cell[kBqPtsPerThread];
 #pragma unroll
@@ -450,13 +462,41 @@ __device__ __forceinline__ bool bq_build_grid(int n, float reach, const float *_
         if (i * NT < n) {                                        // block-uniform
             cell[i] = (bq_cell(pz[i], g.oz, g.iz, g.gz) * g.gy + bq_cell(py[i], g.oy, g.iy, g.gy)) * g.gx +
                       bq_cell(px[i], g.ox, g.ix, g.gx);
+            if (BLK && two && t + i * NT >= nhalf) cell[i] += ncells1;
             bq_cell_count(cellend, cell[i], t + i * NT < n, lane);
         }
     }
     __syncthreads();
-    // exclusive scan of the counts: a contiguous slab of cells per thread, wave scan, wave offsets
     int *wsum = reinterpret_cast<int *>(misc + 6 * 16);
     int *wmax = wsum + 16;
+    if (BLK && two) {
+        // occupancy of the cells (both halves together) -> are the balls crowded? Otherwise the halves are merged.
+        int *wne = reinterpret_cast<int *>(misc + 9 * 16);
+        const int per1 = (ncells1 + NT - 1) / NT;
+        const int a0 = min(ncells1, t * per1), a1 = min(ncells1, a0 + per1);
+        int ne = 0;
+        for (int c = a0; c < a1; ++c) ne += (cellend[c] + cellend[ncells1 + c]) > 0 ? 1 : 0;
+        ne = wave_prefix_sum_incl(ne);
+        if (lane == 63) wne[w] = ne;
+        __syncthreads();
+        int nonempty = 0;
+#pragma unroll
+        for (int v = 0; v < kBqWavesT; ++v) nonempty += wne[v];
+        const float ball = 4.18879f * reach * reach * reach * g.ix * g.iy * g.iz;        // ball volume / cell volume
+        const float hits = (float)n / (float)max(nonempty, 1) * ball;
+        const bool crowded = hits >= 3.0f * (float)crowd_nsample;
+        if (__builtin_amdgcn_readfirstlane((int)crowded)) {
+            g.nb = 2;
+        } else {
+            for (int c = a0; c < a1; ++c) cellend[c] += cellend[ncells1 + c];
+#pragma unroll
+            for (int i = 0; i < kBqPtsPerThread; ++i)
+                if (t + i * NT >= nhalf) cell[i] -= (i * NT < n) ? ncells1 : 0;
+            __syncthreads();
+        }
+    }
+    const int ncells = g.nb * ncells1;                           // entries of the table: (block, cell)
+    // exclusive scan of the counts: a contiguous slab of cells per thread, wave scan, wave offsets
     const int per = (ncells + NT - 1) / NT;
     const int c0 = min(ncells, t * per), c1 = min(ncells, c0 + per);
     int sum = 0, big = 0;
@@ -524,7 +564,7 @@ __device__ __forceinline__ int group_prefix_sum_incl(int v, int sub)
 // A query's candidates are the <= 3x3 runs of x-adjacent cells around it; its LPQ lanes walk them run
 // by run. Hits go into the query's bitmap (bit k = point k) with LDS atomic ORs; the bitmap is then
 // turned into the ascending index list by a group prefix sum of popcounts and a bit-peeling loop.
-template <int NT, int LPQ, bool FUSE, bool POLL>
+template <int NT, int LPQ, bool FUSE, bool POLL, bool BLK = false>
 __device__ __forceinline__ bool bq_cells_query_loop(int n, int m, int nsample, float thr, float radius, float reach,
                                                     int bi, int q0, int q1, const BqGrid &g,
                                                     const float *__restrict__ data,
@@ -604,21 +644,29 @@ __device__ __forceinline__ bool bq_cells_query_loop(int n, int m, int nsample, f
         const bool wide = ordered && !narrow && sz <= 8;
         const bool everything = !near_origin || !(narrow || wide);
         const int dx1 = cx1 - cx0 + 1;
+        // BLK: the list is sorted by (index block, cell); a query walks block 0 and goes on to block 1 only while it holds fewer
+        // than nsample hits (all of a ball's hits below n / 2 are in block 0, so nsample of them are the nsample smallest)
+        const int nblk = BLK ? __builtin_amdgcn_readfirstlane(g.nb) : 1;
+        const int ncell1 = g.gx * g.gy * g.gz;
+        int hc = 0;                                              // BLK: this lane's hits so far
+        bool more = true;                                        // BLK: this query still needs candidates
+        for (int blk = 0; blk < nblk; ++blk) {
+        const int toff = BLK ? blk * ncell1 : 0;
         int rb[9], re[9];
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             const int ry = r % 3, rz = r / 3;
-            const bool rvalid = qvalid && !everything && (narrow ? (ry <= sy && rz <= sz) : (r <= sz));
+            const bool rvalid = qvalid && more && !everything && (narrow ? (ry <= sy && rz <= sz) : (r <= sz));
             const int nfirst = ((cz0 + rz) * g.gy + (cy0 + ry)) * g.gx + cx0;          // narrow: cells [nfirst, nfirst + dx1)
             const int wfirst = ((cz0 + r) * g.gy + cy0) * g.gx;                         // wide: cells [wfirst, wlast)
             const int wlast = ((cz0 + r) * g.gy + cy1) * g.gx + g.gx;
             const int cfirst = rvalid ? (narrow ? nfirst : wfirst) : 0;
             const int clast = rvalid ? (narrow ? nfirst + dx1 : wlast) : 0;
-            const int b0 = tab[cfirst], e0 = tab[clast];
+            const int b0 = tab[toff + cfirst], e0 = tab[toff + clast];
             rb[r] = rvalid ? b0 : 0;
             re[r] = rvalid ? e0 : 0;
         }
-        if (everything && qvalid) { rb[0] = 0; re[0] = n; }
+        if (everything && qvalid && more) { rb[0] = BLK ? tab[toff] : 0; re[0] = BLK ? tab[toff + ncell1] : n; }
         // The nine runs are walked as ONE candidate stream per query (flat position f -> run by a compare
         // chain against the running lengths; all lanes of a group hold the same bounds). Walking run by
         // run in lockstep left three quarters of the lane slots empty (runs are ~10 points, a group has 8
@@ -648,8 +696,17 @@ __device__ __forceinline__ bool bq_cells_query_loop(int n, int m, int nsample, f
                 // reference operand order: (x2-x1) with x2 the query (query_ball_point.cpp:26-32)
                 const float s = sqdist(qx, qy, qz, p[u].x, p[u].y, p[u].z);
                 const int k = __float_as_int(p[u].w);
-                if (act[u] && s < thr) atomicOr(&bmq[k >> 5], 1u << (k & 31));
+                if (act[u] && s < thr) {
+                    atomicOr(&bmq[k >> 5], 1u << (k & 31));
+                    if (BLK) ++hc;
+                }
             }
+        }
+        if (BLK && blk + 1 < nblk) {                             // hits of the group so far (wave-uniform trip: every lane takes part)
+            const int incl = group_prefix_sum_incl<LPQ>(hc, sub);
+            more = __shfl(incl, lane | (LPQ - 1)) < nsample;
+            if (!__any(more && qvalid)) break;
+        }
         }
         asm volatile("" ::: "memory");                           // LDS ops of one wave execute in order
         int done = 0;                                            // hits of this query so far (group-uniform)
@@ -749,7 +806,7 @@ __device__ __forceinline__ bool bq_cells_query_loop(int n, int m, int nsample, f
 // q_stride > 0: the workgroup is PERSISTENT -- after [q0, q1) it goes on to [q0 + q_stride, q1 + q_stride), ... up to m with
 // the cloud staged and binned ONCE (the overlapped launch's consumers: a few workgroups per cloud walk the query ranges in
 // the order the samples are published).
-template <int NT, int LPQ, bool FUSE, bool POLL>
+template <int NT, int LPQ, bool FUSE, bool POLL, bool BLK = false>
 __device__ __forceinline__ void bq_cells_block_body(int n, int m, int nsample, float thr, float radius, int bi, int q0,
                                                     int q1, const float *__restrict__ xyz1,
                                                     const float *__restrict__ xyz2,
@@ -770,9 +827,9 @@ __device__ __forceinline__ void bq_cells_block_body(int n, int m, int nsample, f
     const int qlen = q1 - q0;
     BqGrid g;
     if (threadIdx.x == 0) tab[0] = 0;
-    if (bq_build_grid<NT>(n, reach, data, sorted, tab + 1, misc, g, pos_tab)) {
+    if (bq_build_grid<NT, BLK>(n, reach, data, sorted, tab + 1, misc, g, pos_tab, BLK ? nsample : 0)) {
         for (int a = q0; a < m; a += q_stride) {
-            if (!bq_cells_query_loop<NT, LPQ, FUSE, POLL>(n, m, nsample, thr, radius, reach, bi, a, min(a + qlen, m), g, data, xyz2, tagged,
+            if (!bq_cells_query_loop<NT, LPQ, FUSE, POLL, BLK>(n, m, nsample, thr, radius, reach, bi, a, min(a + qlen, m), g, data, xyz2, tagged,
                                                        new_xyz, idx, pts_cnt, grouped, subtract, sorted, tab, wave_area, 0, tag,
                                                        status, pos_tab)) return;
             if (q_stride <= 0) break;

@@ -107,3 +107,35 @@ def test_cells_and_sweep_agree_at_metric_shape(cuda, bq_mode):
             outs.append((idx, cnt, g2))
         for o in outs[1:]:
             assert all(torch.equal(a, bb) for a, bb in zip(outs[0], o)), gen.__name__
+
+
+# Round 6: crowded balls (several times nsample points inside) -- the list is sorted by (index block, cell) and a query reads the
+# second half of the indices only while the first half holds fewer than nsample hits (ball_query_body.h, BLK). Decided per cloud
+# from the occupancy, so one batch mixes both forms; queries at the cube's corners (an eighth of a ball) need the second block,
+# far-away / non-finite queries take the full-visit path through both blocks, odd n splits the blocks unevenly.
+CROWDED_CASES = [
+    ("cube_r02_ns32", lambda: S.uniform_clouds(3, 4096, 300), 512, 0.2, 32),
+    ("cube_r03_ns16", lambda: S.uniform_clouds(2, 4097, 301), 300, 0.3, 16),
+    ("cube_r015_ns8_8192", lambda: S.uniform_clouds(2, 8192, 302), 400, 0.15, 8),
+    ("cube_odd_n", lambda: S.uniform_clouds(2, 3001, 303), 257, 0.25, 20),
+    ("mixed_batch", lambda: np.concatenate([S.uniform_clouds(2, 4096, 304), S.sphere_clouds(2, 4096, 305)], axis=0), 384, 0.2, 32),
+    ("cube_ns_gt_half", lambda: S.uniform_clouds(2, 2048, 306), 200, 0.35, 100),
+    ("dup_cube", lambda: S.duplicated_clouds(2, 4096, 307) * np.float32(0.5) + np.float32(0.25), 300, 0.2, 24),
+]
+
+
+@pytest.mark.parametrize("name,make,m,r,ns", CROWDED_CASES, ids=[c[0] for c in CROWDED_CASES])
+def test_cells_crowded_balls_walk_index_blocks(cuda, oracle, bq_mode, name, make, m, r, ns):
+    import pointnet2_amd as P
+    xyz = np.ascontiguousarray(make(), dtype=np.float32)
+    b, n, _ = xyz.shape
+    rng = np.random.default_rng(11)
+    pick = rng.integers(0, n, size=(b, m))
+    q = np.take_along_axis(xyz, pick[:, :, None].repeat(3, axis=2), axis=1).copy()
+    q[:, 1::4] += rng.normal(0, r * 0.5, size=q[:, 1::4].shape).astype(np.float32)
+    q[:, 5] = np.float32(1e6)                                   # far away: the full-visit path
+    q[:, 9, 1] = np.float32(np.nan)
+    q[:, 13] = xyz.min(axis=1)                                  # a corner of the bounding box: an eighth of a ball
+    for mode in (2, 3, 0):
+        bq_mode(mode, 0)
+        _check(P, oracle, cuda, xyz, q, r, ns, (name, mode))
