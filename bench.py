@@ -522,7 +522,7 @@ def cpu_baseline_all_cores(seed, budget_s=10.0):
                       "through oracle/pn2_oracle.c in %.1f s" % (done, cores, dt)}
 
 
-def allreduce_leg(dev, dist, reps=20):
+def allreduce_leg(dev, dist, reps=20, cdev=None):
     """Training's only exchange (train_multi_gpu.py:91-126): the gradient mean over ranks as ONE in-place all-reduce of a
     persistent flat bucket (sharding.GradBucket keeps every parameter's .grad as a view of it), timed at the two
     data-parallel models' gradient sizes. Runs whenever a process group exists -- with ONE rank too: that is how a
@@ -531,6 +531,13 @@ def allreduce_leg(dev, dist, reps=20):
     world = dist.get_world_size()
     for name, floats in GRAD_BUCKET_FLOATS.items():
         g = torch.ones((floats,), dtype=torch.float32, device=dev)
+        try:
+            sharding.allreduce_mean_([g], force_collective=True)
+        except RuntimeError as e:                        # a gloo build without device-memory support (--share-gpu rehearsal only)
+            if cdev is None or cdev == dev:
+                raise
+            out["device_memory_refused"] = str(e).splitlines()[0][:200]
+            g = torch.ones((floats,), dtype=torch.float32, device=cdev)
         for _ in range(3):
             sharding.allreduce_mean_([g], force_collective=True)
         ts = []
@@ -542,7 +549,7 @@ def allreduce_leg(dev, dist, reps=20):
             sharding.allreduce_mean_([g], force_collective=True)
             if dev.type == "cuda":
                 torch.cuda.synchronize()
-            ts.append(sharding.max_over_ranks(time.perf_counter() - t0, dev))
+            ts.append(sharding.max_over_ranks(time.perf_counter() - t0, dev if cdev is None else cdev))
         t = float(np.median(ts))
         nbytes = floats * 4
         out[name] = {"floats": floats, "us": t * 1e6, "algbw_GBps": nbytes / t / 1e9,
@@ -581,6 +588,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-extras", action="store_true", help="only the contract line (profiling runs)")
     ap.add_argument("--stub", action="store_true", help="CPU test mode: gloo, no kernels (tests/test_distributed.py)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="REHEARSAL of the N-rank path on a box with ONE GPU: every rank runs its shard on cuda:0 and the process group "
+                         "is gloo (RCCL refuses two ranks on one device). Executes what an N-GPU run executes except the RCCL "
+                         "collective -- N processes loading the library, per-rank batches and seeds, barriers, max-over-ranks clock, "
+                         "per-rank verify, census, the strong-scaling leg; its figures are NOT scaling figures (the ranks share the "
+                         "GPU) and the line says so (`rehearsal`)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -596,14 +609,15 @@ def main():
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a ROCm GPU (no CPU path)")
-        dev = torch.device("cuda", local_rank)
+        dev = torch.device("cuda", 0 if args.share_gpu else local_rank)
         torch.cuda.set_device(dev)
+    cdev = torch.device("cpu") if args.share_gpu else dev           # where the bookkeeping collectives' tensors live (gloo: host)
     sync = (lambda: None) if args.stub else torch.cuda.synchronize
     dist = None
     if world > 1 or "RANK" in os.environ:      # under torchrun the RCCL path is exercised even at N=1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.stub:
+        if args.stub or args.share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -638,19 +652,19 @@ def main():
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
-    elapsed = sharding.max_over_ranks(elapsed, dev)     # whole-job time = slowest rank
+    elapsed = sharding.max_over_ranks(elapsed, cdev)     # whole-job time = slowest rank
     launch_s = (ev0.elapsed_time(ev1) * 1e-3 / args.steps) if ev0 is not None else elapsed / args.steps
 
     # outputs of the LAST timed step against the four-operator path (and the overlapped launch's status word): every rank
     verified = None
     if not args.stub:
         v = stage.verify(args.path)
-        verified = dict(v, ok=bool(sharding.max_over_ranks(0.0 if v["ok"] else 1.0, dev) == 0.0))   # ok = EVERY rank's outputs verified
+        verified = dict(v, ok=bool(sharding.max_over_ranks(0.0 if v["ok"] else 1.0, cdev) == 0.0))   # ok = EVERY rank's outputs verified
     extras = not args.no_extras and not args.stub
     # who took part: every rank reports (rank, seed of its clouds, verify ok); rank 0 asserts the census is 0 .. N-1 with
     # N different seeds (weak scaling: every rank its own batch) and counts the ranks whose outputs verified
     seed = 1000 + (rank if args.scaling == "weak" else 0)
-    census = sharding.gather_ints([rank, seed, -1 if verified is None else int(v["ok"])], dev)
+    census = sharding.gather_ints([rank, seed, -1 if verified is None else int(v["ok"])], cdev)
     if rank == 0:
         assert sorted(c[0] for c in census) == list(range(world)), census
         if args.scaling == "weak":
@@ -658,7 +672,7 @@ def main():
     # N > 1, weak run: the STRONG-scaling figure too, in the same invocation (one SCALE run captures both): ONE global B=32
     # batch sliced 32/N per rank, same barriers, same max-over-ranks clock
     strong = None
-    if world > 1 and args.scaling == "weak" and B % world == 0 and not args.no_extras:
+    if world > 1 and args.scaling == "weak" and B % world == 0 and (args.share_gpu or not args.no_extras):
         lo, hi = sharding.shard_bounds(B, world, rank)
         st2 = StubStage(hi - lo) if args.stub else Stage(dev, synthetic.sphere_clouds(B, N, 1000)[lo:hi])
         step2 = st2.step(args.path)
@@ -673,15 +687,15 @@ def main():
         sync()
         dist.barrier()
         sync()
-        e2 = sharding.max_over_ranks(time.perf_counter() - t2, dev)
+        e2 = sharding.max_over_ranks(time.perf_counter() - t2, cdev)
         ok2 = True if args.stub else bool(st2.verify(args.path)["ok"])
-        ok2 = sharding.max_over_ranks(0.0 if ok2 else 1.0, dev) == 0.0
+        ok2 = sharding.max_over_ranks(0.0 if ok2 else 1.0, cdev) == 0.0
         strong = {"scaling": "strong", "value": B * args.steps / e2, "unit": "clouds/s", "ms_per_step": e2 / args.steps * 1e3,
                   "clouds_per_gpu": hi - lo, "verified": ok2,
                   "note": "the same K steps on ONE global B=32 batch sliced like tf.slice in the reference's tower loop "
                           "(train_multi_gpu.py:185-188); a rank with 32/N clouds still runs the whole 1023-round chain, so this "
                           "figure is expected flat in N (SURVEY 8e)"}
-    allred = allreduce_leg(dev, dist) if dist is not None else None
+    allred = allreduce_leg(dev, dist, cdev=cdev) if dist is not None else None
     conc = None
     if extras and args.streams > 1 and world == 1:
         conc = concurrent_throughput(dev, rank, args.path, args.streams, max(256, 32 * args.streams))
@@ -735,7 +749,11 @@ def main():
         line["ranks_seen"] = sorted(c[0] for c in census)
         line["ranks_verified"] = None if verified is None else sum(1 for c in census if c[2] == 1)
         line["rank_seeds"] = [c[1] for c in sorted(census)]
-        line["collective_library"] = sharding.collective_library_version(args.stub)
+        line["collective_library"] = "gloo (rehearsal: the ranks share one GPU)" if args.share_gpu else sharding.collective_library_version(args.stub)
+        if args.share_gpu:
+            line["rehearsal"] = ("%d ranks SHARING cuda:0, process group gloo: the N-rank code path on a one-GPU box (library loaded by "
+                                 "every process, per-rank batches / seeds / verify, barriers, max-over-ranks clock, strong leg, the "
+                                 "gradient bucket's all-reduce through gloo on device memory); NOT a scaling measurement" % world)
         if strong is not None:
             line["strong"] = strong
         if verified is not None:

@@ -54,3 +54,30 @@ def test_train_step_harness_under_torchrun(cuda):
     assert len(rows) == 1 and rows[0]["world"] == 1
     f = rows[0]["fused"]
     assert f["allreduce_ms"] > 0 and f["grad_floats"] == 969_013 and all(p == "fused_train" for p in f["paths"])
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 8])
+def test_n_rank_path_rehearsed_on_one_gpu(cuda, world):
+    """bench.py --gpus N --share-gpu: N processes under torch.distributed.run, every rank its own batch (seed 1000 + rank) on
+    cuda:0, gloo for the bookkeeping and for the gradient bucket (RCCL refuses two ranks on one device). Everything an N-GPU run
+    executes except the RCCL collective runs here on device memory: N processes loading the library, barriers, the
+    max-over-ranks clock, every rank's outputs verified against the operator path, the census, the strong-scaling leg
+    (train_multi_gpu.py:185-188: 32 / N clouds per rank). The figures are not scaling figures -- the ranks share the GPU."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--share-gpu", "--steps", "20",
+           "--warmup", "3", "--no-extras", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == world and line["value"] > 0 and "rehearsal" in line
+    assert line["verified"] is True and line["ranks_seen"] == list(range(world)) and line["ranks_verified"] == world
+    assert line["rank_seeds"] == [1000 + r for r in range(world)]
+    assert line["strong"]["verified"] is True and line["strong"]["clouds_per_gpu"] == 32 // world
+    ar = line["allreduce"]
+    assert ar["sem_seg"]["mean_ok"] and ar["cls_ssg"]["mean_ok"]
