@@ -178,10 +178,11 @@ class PointnetSAModule(nn.Module):
 
     def _fused_ok(self, xyz, points):
         """Inference with max pooling on a layer stack pn2_sa_mlp3_maxpool covers (see sa_mlp.py)."""
-        if not self.fused_mlp or self.training or torch.is_grad_enabled() or self.knn:
+        if not self.fused_mlp or self.training or torch.is_grad_enabled():
             return False
-        if self.pooling != "max" or self.mlp2 is not None or not xyz.is_cuda:
+        if self.pooling != "max" or not xyz.is_cuda:
             return False
+        # (mlp2, :142-150, runs on the POOLED (b, npoint, C) rows behind the fused stack: _post)
         # (use_xyz=False: the kernels still gather the coordinates, against three zero rows of weight -- _packed)
         cin = 3 + (points.shape[2] if points is not None else 0)
         if self.group_all:                         # only the cooperative kernel gathers a whole cloud without idx
@@ -191,7 +192,7 @@ class PointnetSAModule(nn.Module):
     def _train_fused_ok(self, xyz, points):
         """Training (batch-statistics batch norm, autograd) with max pooling on a stack pn2_mlp_train_forward covers:
         conv 1x1 + BN + ReLU triples, rows a multiple of 32, nsample 16 or a multiple of 32 (train_mlp.py)."""
-        if not self.fused_mlp or not self.training or self.pooling != "max" or self.mlp2 is not None or not xyz.is_cuda:
+        if not self.fused_mlp or not self.training or self.pooling != "max" or not xyz.is_cuda:
             return False
         if (torch.is_grad_enabled() and xyz.requires_grad) or (points is not None and not self.use_xyz):
             return False
@@ -249,10 +250,10 @@ class PointnetSAModule(nn.Module):
         if self._train_fused_ok(xyz, points):
             self.last_path = "fused_train"
             out, _ = train_mlp.sa_mlp_train(self.mlp.net, xyz, new_xyz, points, idx, True)
-            return new_xyz, out, idx
+            return new_xyz, self._post(out), idx
         if self._fused_ok(xyz, points):
             self.last_path = "fused"
-            return new_xyz, sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, self._packed(xyz.device)), idx
+            return new_xyz, self._post(sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, self._packed(xyz.device))), idx
         self.last_path = "unfused"
         grouped_xyz = group_point(xyz, idx) - new_xyz.unsqueeze(2)            # :45-46
         if points is not None:
@@ -274,14 +275,14 @@ class PointnetSAModule(nn.Module):
                 new_xyz = torch.zeros((b, 1, 3), dtype=torch.float32, device=xyz.device)
                 idx = torch.arange(n, dtype=torch.int32, device=xyz.device).reshape(1, 1, n).repeat(b, 1, 1)
                 out, _ = train_mlp.sa_mlp_train(self.mlp.net, xyz, None, points, None, True)
-                return new_xyz, out, idx
+                return new_xyz, self._post(out), idx
             if self.knn:
                 _, new_xyz = farthest_point_sample_gather(self.npoint, xyz)
                 _, idx = knn_point(self.nsample, xyz, new_xyz)
             else:
                 _, new_xyz, idx, _, _ = sample_and_group_xyz(self.npoint, self.radius, self.nsample, xyz, True)
             out, _ = train_mlp.sa_mlp_train(self.mlp.net, xyz, new_xyz, points, idx, True)
-            return new_xyz, out, idx
+            return new_xyz, self._post(out), idx
         if self.group_all and self._fused_ok(xyz, points):
             # sample_and_group_all (:59-84) + the layer stack + reduce_max in ONE kernel: new_xyz = origin, the
             # group is the whole cloud, channels [xyz, features]
@@ -289,14 +290,18 @@ class PointnetSAModule(nn.Module):
             b, n, _ = xyz.shape
             new_xyz = torch.zeros((b, 1, 3), dtype=torch.float32, device=xyz.device)
             idx = torch.arange(n, dtype=torch.int32, device=xyz.device).reshape(1, 1, n).repeat(b, 1, 1)
-            return new_xyz, sa_mlp.sa_mlp_maxpool(xyz, None, points, None, self._packed(xyz.device, n)), idx
+            return new_xyz, self._post(sa_mlp.sa_mlp_maxpool(xyz, None, points, None, self._packed(xyz.device, n))), idx
         if self._fused_ok(xyz, points):
             # ONE C call (csrc/levels.hip): FPS + ball query in the overlapped launch, then one kernel from idx to the
             # pooled features: the (b, npoint, nsample, C) tensors of pointnet_util.py:44-50 and :117-127 never exist
             self.last_path = "fused"
+            if self.knn:                                              # :41-42: the k nearest points instead of the ball, same stack kernel
+                _, new_xyz = farthest_point_sample_gather(self.npoint, xyz)
+                _, idx = knn_point(self.nsample, xyz, new_xyz)
+                return new_xyz, self._post(sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, self._packed(xyz.device))), idx
             new_xyz, out, idx, _, _, _ = sa_mlp.sa_level(self.npoint, self.radius, self.nsample, xyz, points,
                                                           self._packed(xyz.device), self._level_buffers())
-            return new_xyz, out, idx
+            return new_xyz, self._post(out), idx
         self.last_path = "unfused"
         if self.group_all:
             new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, self.use_xyz)
@@ -304,6 +309,15 @@ class PointnetSAModule(nn.Module):
             new_xyz, new_points, idx, grouped_xyz = sample_and_group(self.npoint, self.radius, self.nsample, xyz,
                                                                      points, self.knn, self.use_xyz)
         return self._stack_and_pool(new_xyz, new_points, idx, grouped_xyz)
+
+    def _post(self, pooled):
+        """mlp2 (:142-150: conv 1x1 + BN + ReLU on the pooled features) behind a fused stack + pool: (b, npoint, C) rows through
+        the same modules the layer-by-layer path applies to its (b, C, npoint, 1) tensor; differentiable (training: behind
+        the fused autograd node)."""
+        if self.mlp2 is None:
+            return pooled
+        x = self.mlp2(pooled.permute(0, 2, 1).unsqueeze(3))
+        return x.squeeze(3).permute(0, 2, 1).contiguous()
 
     def _stack_and_pool(self, new_xyz, new_points, idx, grouped_xyz):
         """The layer stack, the pooling and mlp2 of the layer-by-layer path (:117-152)."""

@@ -149,3 +149,80 @@ def test_use_xyz_false_takes_the_fused_kernels(cuda, kind):
             bare.fused_mlp = False
             b = bare(xyz, None)
         assert (a[1] - b[1]).abs().max().item() <= 1e-5 * max(1.0, b[1].abs().max().item())
+
+
+def _randomise_bn(mod, seed):
+    g = torch.Generator().manual_seed(seed)
+    for bn in [x for x in mod.modules() if isinstance(x, torch.nn.BatchNorm2d)]:
+        bn.running_mean.copy_(torch.randn(bn.num_features, generator=g) * 0.3)
+        bn.running_var.copy_(torch.rand(bn.num_features, generator=g) * 1.5 + 0.5)
+        bn.weight.data.copy_(torch.randn(bn.num_features, generator=g) * 0.3 + 1.0)
+        bn.bias.data.copy_(torch.randn(bn.num_features, generator=g) * 0.3)
+
+
+@pytest.mark.parametrize("pooling", ["max", "avg", "weighted_avg", "max_and_avg"])
+@pytest.mark.parametrize("with_mlp2", [False, True])
+@pytest.mark.parametrize("knn", [False, True])
+def test_sa_module_options_against_the_float64_restatement(cuda, oracle, pooling, with_mlp2, knn):
+    """pointnet_sa_module's options (pointnet_util.py:87-154): the four pooling modes (:128-140), mlp2 (:143-150) and knn=True
+    (:41-42) in inference mode. Geometry = the oracle's operators bit for bit; learned part against oracle/sa_module.py in
+    float64 on that geometry (1e-5 of the output scale: the bar of every fused layer stack); max pooling must stay on the fused
+    kernels with and without mlp2."""
+    from oracle import sa_module as OM
+    from pointnet2_amd.pointnet_util import PointnetSAModule
+    torch.manual_seed(5)
+    b, n, m, ns, cf, r = 3, 512, 128, 32, 6, 0.25
+    xyz = S.sphere_clouds(b, n, 21)
+    feats = np.random.default_rng(22).standard_normal((b, n, cf)).astype(np.float32)
+    mod = PointnetSAModule(cf, m, r, ns, [32, 32, 64], mlp2=[48, 40] if with_mlp2 else None, pooling=pooling, knn=knn)
+    _randomise_bn(mod, 23)
+    mod = mod.to(cuda).eval()
+    with torch.no_grad():
+        new_xyz, out, idx = mod(_dev(xyz, cuda), _dev(feats, cuda))
+    if pooling == "max":
+        assert mod.last_path == "fused"
+    fps = oracle.farthest_point_sample(m, xyz)
+    q = oracle.gather_point(xyz, fps)
+    assert np.array_equal(new_xyz.cpu().numpy(), q)
+    if knn:                                                          # tf_grouping.py:48-73: the k smallest squared distances, ties by index
+        d = ((q[:, :, None, :].astype(np.float32) - xyz[:, None, :, :]) ** 2).sum(-1, dtype=np.float32)
+        oidx = np.argsort(d, axis=2, kind="stable")[:, :, :ns].astype(np.int32)
+        got_idx = idx.cpu().numpy()
+        # the kernel's fp32 distance may round differently from numpy's sum order on near-ties: compare as sets of distances
+        dg = np.take_along_axis(d, got_idx.astype(np.int64), axis=2)
+        do = np.take_along_axis(d, oidx.astype(np.int64), axis=2)
+        assert np.allclose(np.sort(dg, axis=2), np.sort(do, axis=2), rtol=1e-5, atol=1e-7)
+        oidx = got_idx
+    else:
+        oidx, _ = oracle.query_ball_point(r, ns, xyz, q)
+        assert np.array_equal(idx.cpu().numpy(), oidx)
+    gxyz = oracle.group_point(xyz, oidx) - q[:, :, None, :]
+    new_points = np.concatenate([gxyz, oracle.group_point(feats, oidx)], axis=-1)             # :50, xyz first
+    want = OM.sa_learned_part(gxyz, new_points, OM.layers_of(mod.mlp.net), pooling, OM.layers_of(mod.mlp2.net) if with_mlp2 else None)
+    got = out.double().cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+
+
+def test_mlp2_behind_the_fused_training_node(cuda):
+    """Training with mlp2: the stack + max-pool as ONE fused autograd node, mlp2 on the pooled rows behind it; loss and
+    gradients against the layer-by-layer path of the same module (batch-statistics batch norm on both)."""
+    from pointnet2_amd.pointnet_util import PointnetSAModule
+    torch.manual_seed(6)
+    xyz = _dev(S.sphere_clouds(4, 1024, 31), cuda)
+    feat = torch.randn(4, 1024, 8, device=cuda)
+    mod = PointnetSAModule(8, 256, 0.2, 32, [32, 32, 64], mlp2=[64, 32]).to(cuda).train()
+    res = {}
+    for fused in (True, False):
+        mod.fused_mlp = fused
+        mod.zero_grad(set_to_none=True)
+        f = feat.clone().requires_grad_(True)
+        _, out, _ = mod(xyz, f)
+        assert mod.last_path == ("fused_train" if fused else "unfused")
+        loss = (out * out).mean()
+        loss.backward()
+        res[fused] = (loss.item(), f.grad.clone(), [p.grad.clone() for p in mod.parameters()])
+    assert abs(res[True][0] - res[False][0]) <= 1e-5 * abs(res[False][0])
+    scale = max(t.abs().max().item() for t in res[False][2])       # (a conv bias in front of batch norm has gradient 0: noise on one side)
+    for a, b_ in zip([res[True][1]] + res[True][2], [res[False][1]] + res[False][2]):
+        assert (a - b_).abs().max().item() <= 2e-4 * b_.abs().max().item() + 1e-5 * scale

@@ -246,3 +246,30 @@ def test_fps_matches_numpy_on_random_small_clouds(oracle):
         assert got == want.tolist()
 
     run()
+
+
+@pytest.mark.parametrize("pooling", ["max", "avg", "weighted_avg", "max_and_avg"])
+@pytest.mark.parametrize("with_mlp2", [False, True])
+def test_sa_module_restatement_against_torch_float64(pooling, with_mlp2):
+    """oracle/sa_module.py (pointnet_util.py:117-152: layer stack, the four pooling modes, mlp2) against the module's own
+    layer-by-layer host path (PointnetSAModule._stack_and_pool: torch modules in float64, eval-mode batch norm with
+    non-trivial moving statistics) on a random grouping: two independent evaluations of the reference's graph piece."""
+    import torch
+    from oracle import sa_module as OM
+    from pointnet2_amd.pointnet_util import PointnetSAModule
+    torch.manual_seed(11)
+    b, m, ns, cf = 2, 5, 8, 4
+    mod = PointnetSAModule(cf, m, 0.3, ns, [16, 24], mlp2=[12] if with_mlp2 else None, pooling=pooling).double().eval()
+    for bn in [x for x in mod.modules() if isinstance(x, torch.nn.BatchNorm2d)]:
+        bn.running_mean.normal_(0.0, 0.5)
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.data.normal_(1.0, 0.3)
+        bn.bias.data.normal_(0.0, 0.3)
+    gxyz = torch.randn(b, m, ns, 3, dtype=torch.float64) * 0.2
+    new_points = torch.cat([gxyz, torch.randn(b, m, ns, cf, dtype=torch.float64)], dim=-1)
+    with torch.no_grad():
+        _, got, _ = mod._stack_and_pool(None, new_points, None, gxyz)
+    want = OM.sa_learned_part(gxyz.numpy(), new_points.numpy(), OM.layers_of(mod.mlp.net), pooling,
+                              OM.layers_of(mod.mlp2.net) if with_mlp2 else None)
+    assert got.shape == want.shape == (b, m, 12 if with_mlp2 else (48 if pooling == "max_and_avg" else 24))
+    assert np.abs(got.numpy() - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
