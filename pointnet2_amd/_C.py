@@ -59,6 +59,8 @@ _SIGNATURES = {
     "pn2_sa_mlp3_pack": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pn2_sa_mlp3_maxpool": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pn2_sa_mlp3_maxpool_ex": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "pn2_sa_mlp3_pool_supported": [_i, _i, _i, _i, _i, _i],
+    "pn2_sa_mlp3_pool": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "pn2_sa_mlp3_ws_bytes": [_i, _i, _i, _i, _i, _i, _i, _i],
     "pn2_fp_mlp_config": [_i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "pn2_fp_mlp_pack": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],

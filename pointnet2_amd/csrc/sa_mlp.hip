@@ -101,7 +101,13 @@ __device__ __forceinline__ void mlp_layer(const float *wp, const float *bp, cons
 
 // T1, T2, T3: output tiles (32 channels each) of the three layers; the input is one tile (Cin <= 32).
 // SPAN: samples per centroid inside one 32-sample group (32, or 16 when nsample = 16).
-template <int T1, int T2, int T3, int SPAN, int NT>
+// POOL: the reference's pooling modes (utils/pointnet_util.py:128-140): 0 max (the text above), 1 avg, 2 weighted_avg
+// (weights exp(-5 |grouped_xyz|) normalised over the group), 3 max_and_avg (out = [avg (c3), max (c3)] per centroid). An average
+// does not commute with bias + ReLU, so modes 1-3 apply them to every sample's raw sum and accumulate per lane: a lane holds 16
+// samples of one channel, the sums of registers 0-7 and 8-15 are kept apart (SPAN = 16: two centroids), one exchange with
+// lane l ^ 32 at the end. The weights of mode 2 come from the layer-1 operand (lanes 0-31 hold their sample's centred
+// coordinates) through one ds_bpermute per register and 32-sample part.
+template <int T1, int T2, int T3, int SPAN, int NT, int POOL = 0>
 __global__ __launch_bounds__(NT) void sa_mlp3_kernel(int n, int m, int nsample, int cfeat, int c3, long long rows,
                                                               const float *__restrict__ xyz,
                                                               const float *__restrict__ new_xyz,
@@ -185,6 +191,7 @@ __global__ __launch_bounds__(NT) void sa_mlp3_kernel(int n, int m, int nsample, 
     f32x16 x0, cen;
     if (g < groups) x0 = load_x0(g, load_index(g, 0), cen);
     f32x16 best[T3];
+    float sa[T3], sb[T3], ma[T3], mb[T3], ea = 0.0f, eb = 0.0f;      // POOL != 0: sums / maxima of registers 0-7 and 8-15, weight sums
     while (g < groups) {
         // the item after this one
         const bool last_part = part + 1 == parts;
@@ -194,6 +201,7 @@ __global__ __launch_bounds__(NT) void sa_mlp3_kernel(int n, int m, int nsample, 
         int pn = 0;
         if (more) pn = load_index(gn, partn);
         ActSplit s0[1], s1[T1], s2[T2];
+        float e_lane = 0.0f;
         {
             f32x16 in0;
 #pragma unroll
@@ -201,6 +209,8 @@ __global__ __launch_bounds__(NT) void sa_mlp3_kernel(int n, int m, int nsample, 
 #pragma unroll
             for (int v = 4; v < 16; ++v) in0[v] = x0[v];
             s0[0] = split_act(in0);
+            if (POOL == 2)                                       // :133-134, tf.norm + exp(-5 d); lanes 0-31 hold the coordinates
+                e_lane = expf(-5.0f * sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(in0[0], in0[0]), __fmul_rn(in0[1], in0[1])), __fmul_rn(in0[2], in0[2]))));
         }
         {
             f32x16 h1[T1];
@@ -215,7 +225,71 @@ __global__ __launch_bounds__(NT) void sa_mlp3_kernel(int n, int m, int nsample, 
             for (int t = 0; t < T2; ++t) s2[t] = split_act(h2[t]);
         }
         if (more) x0 = load_x0(gn, pn, cen);
-        mlp_layer<T3, T2, true>(w3, b3, s2, best, lane, h, 2, part == 0);
+        mlp_layer<T3, T2, true>(w3, b3, s2, best, lane, h, 2, POOL != 0 || part == 0);
+        if (POOL != 0) {
+            // this part's 16 samples per lane: bias + ReLU per sample, then the (weighted) sums; max_and_avg keeps the raw maxima too
+            float wv[16];
+            if (POOL == 2) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) wv[v] = __shfl(e_lane, 8 * (v >> 2) + 4 * h + (v & 3));
+            }
+            if (part == 0) {
+                ea = eb = 0.0f;
+#pragma unroll
+                for (int t = 0; t < T3; ++t) { sa[t] = sb[t] = 0.0f; ma[t] = mb[t] = -3.0e38f; }
+            }
+            if (POOL == 2) {
+#pragma unroll
+                for (int v = 0; v < 8; ++v) { ea += wv[v]; eb += wv[8 + v]; }
+            }
+#pragma unroll
+            for (int t = 0; t < T3; ++t) {
+                const float bias = b3_at(b3, 32 * t + s);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    float r = fmaxf(__fadd_rn(best[t][v], bias), 0.0f);
+                    if (POOL == 2) r *= wv[v];
+                    if (v < 8) sa[t] += r; else sb[t] += r;
+                    if (POOL == 3) { if (v < 8) ma[t] = fmaxf(ma[t], best[t][v]); else mb[t] = fmaxf(mb[t], best[t][v]); }
+                }
+            }
+            if (!last_part) { part = partn; continue; }
+            const long long row = item_row(g);
+            const int oc = POOL == 3 ? 2 * c3 : c3;                 // floats per output row
+            float d0 = (float)nsample, d1 = (float)nsample;
+            if (POOL == 2) {
+                if (SPAN == 32) { d0 = ea + eb; d0 += __shfl_xor(d0, 32); }
+                else { d0 = ea + __shfl_xor(ea, 32); d1 = eb + __shfl_xor(eb, 32); }
+            }
+#pragma unroll
+            for (int t = 0; t < T3; ++t) {
+                const int ch = 32 * t + s;
+                const float bias = b3_at(b3, ch);
+                if (SPAN == 32) {
+                    float sum = sa[t] + sb[t], mx = fmaxf(ma[t], mb[t]);
+                    sum += __shfl_xor(sum, 32);
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    if (h == 0 && ch < c3) {
+                        out[row * oc + ch] = sum / d0;
+                        if (POOL == 3) out[row * oc + c3 + ch] = fmaxf(__fadd_rn(mx, bias), 0.0f);
+                    }
+                } else {
+                    const float s0_ = sa[t] + __shfl_xor(sa[t], 32), s1_ = sb[t] + __shfl_xor(sb[t], 32);
+                    const float m0 = fmaxf(ma[t], __shfl_xor(ma[t], 32)), m1 = fmaxf(mb[t], __shfl_xor(mb[t], 32));
+                    if (h == 0 && ch < c3) {
+                        out[(2 * g) * oc + ch] = s0_ / d0;
+                        if (POOL == 3) out[(2 * g) * oc + c3 + ch] = fmaxf(__fadd_rn(m0, bias), 0.0f);
+                        if (2 * g + 1 < rows) {
+                            out[(2 * g + 1) * oc + ch] = s1_ / d1;
+                            if (POOL == 3) out[(2 * g + 1) * oc + c3 + ch] = fmaxf(__fadd_rn(m1, bias), 0.0f);
+                        }
+                    }
+                }
+            }
+            g = gn;
+            part = 0;
+            continue;
+        }
         if (!last_part) { part = partn; continue; }
         const long long row = item_row(g);
         // Pool: lane l holds channel 32t + (l & 31) for the samples 8(v >> 2) + 4(l >> 5) + (v & 3), v = 0..15
@@ -559,7 +633,8 @@ static size_t mlp_total_b(const MlpConfig &c) { return mlp_b_floats(c.t1) + mlp_
 
 template <int T1, int T2, int T3>
 static int launch_mlp(int b, int n, int m, int nsample, int cfeat, int c3, const float *xyz, const float *new_xyz,
-                      const float *points, const int *idx, const float *wp, const float *bp, float *out, hipStream_t st, int variant)
+                      const float *points, const int *idx, const float *wp, const float *bp, float *out, hipStream_t st, int variant,
+                      int pooling = 0)
 {
     const MlpConfig cfg = {T1, T2, T3};
     const size_t lds = sizeof(float) * (mlp_total_w(cfg) + mlp_total_b(cfg));
@@ -574,6 +649,22 @@ static int launch_mlp(int b, int n, int m, int nsample, int cfeat, int c3, const
     // ~8k items (metric shape 139 -> 131 us, cls_ssg SA1 36 -> 33), neutral below; four waves x two items is no faster than
     // one item per wave (142 us): kept for tests / A-B only
     if (variant == 0 && pair_ok && groups >= 8192) variant = 3;
+    if (pooling != 0) {
+        // avg / weighted_avg / max_and_avg (pointnet_util.py:130-140): one item per wave, eight waves (sa_mlp3_kernel<.., POOL>)
+        constexpr int NT = 512;
+        long long blocks = (groups + NT / 64 - 1) / (NT / 64);
+        if (blocks > 256) blocks = 256;
+#define PN2_POOL_CASE(P)                                                                                                      \
+        if (pooling == P) {                                                                                                   \
+            auto kern = half ? sa_mlp3_kernel<T1, T2, T3, 16, NT, P> : sa_mlp3_kernel<T1, T2, T3, 32, NT, P>;                 \
+            if (int rc = allow_dynamic_lds(kern, lds)) return rc;                                                             \
+            return launch(kern, dim3((unsigned)blocks), dim3(NT), lds, st, n, m, nsample, cfeat, c3, rows, xyz, new_xyz, points, \
+                          idx, wp, bp, out);                                                                                  \
+        }
+        PN2_POOL_CASE(1) PN2_POOL_CASE(2) PN2_POOL_CASE(3)
+#undef PN2_POOL_CASE
+        return PN2_E_ARG;
+    }
     if (pair_ok && variant >= 2) {
         if constexpr (T2 <= 2) {
           if (variant == 2) {                                           // four waves x two items
@@ -726,6 +817,51 @@ extern "C" int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, 
                                    const float *bpacked, float *out, void *ws, void *stream)
 {
     return pn2_sa_mlp3_maxpool_ex(b, n, m, nsample, cfeat, xyz, new_xyz, points, idx, c1, c2, c3, wpacked, bpacked, out, ws, 0, stream);
+}
+
+// pn2_sa_mlp3_maxpool with the reference's other pooling modes (utils/pointnet_util.py:128-140). pooling: 0 max, 1 avg,
+// 2 weighted_avg, 3 max_and_avg (out is (b, m, 2 c3): [avg, max], the reference's concat order :142). Modes 1-3 exist for the
+// stacks the RESIDENT kernel covers (at most 32 input channels, weights in LDS: pn2_sa_mlp3_config kind 0) -- other shapes
+// return PN2_E_TOO_LARGE and the caller evaluates the level layer by layer.
+extern "C" int pn2_sa_mlp3_pool_supported(int cin, int c1, int c2, int c3, int nsample, int pooling)
+{
+    using namespace pn2;
+    if (pooling < 0 || pooling > 3 || cin < 3 || c1 <= 0 || c2 <= 0 || c3 <= 0 || nsample <= 0) return 0;
+    int kind;
+    MlpConfig rc;
+    MlpStreamConfig sc;
+    MlpCoopConfig cc;
+    if (!mlp_choose(cin, c1, c2, c3, nsample, kind, rc, sc, cc)) return 0;
+    return pooling == 0 || kind == 0;
+}
+
+extern "C" int pn2_sa_mlp3_pool(int b, int n, int m, int nsample, int cfeat, const float *xyz, const float *new_xyz,
+                                const float *points, const int *idx, int c1, int c2, int c3, const float *wpacked,
+                                const float *bpacked, int pooling, float *out, void *ws, void *stream)
+{
+    using namespace pn2;
+    if (pooling < 0 || pooling > 3) return PN2_E_ARG;
+    if (pooling == 0)
+        return pn2_sa_mlp3_maxpool_ex(b, n, m, nsample, cfeat, xyz, new_xyz, points, idx, c1, c2, c3, wpacked, bpacked, out, ws, 0, stream);
+    if (b < 0 || n <= 0 || m < 0 || cfeat < 0) return PN2_E_SHAPE;
+    if (nsample <= 0) return PN2_E_ARG;
+    if (b == 0 || m == 0) return PN2_OK;
+    if (!xyz || !new_xyz || !idx || !wpacked || !bpacked || !out || (cfeat > 0 && !points)) return PN2_E_NULL;
+    int kind;
+    MlpConfig cfg;
+    MlpStreamConfig sc;
+    MlpCoopConfig cc;
+    if (!mlp_choose(3 + cfeat, c1, c2, c3, nsample, kind, cfg, sc, cc) || kind != 0) return PN2_E_TOO_LARGE;
+    hipStream_t st = as_stream(stream);
+    const float *pts = cfeat > 0 ? points : nullptr;
+#define PN2_MLP_CASE(A, B, C) \
+    if (cfg.t1 == A && cfg.t2 == B && cfg.t3 == C) \
+        return launch_mlp<A, B, C>(b, n, m, nsample, cfeat, c3, xyz, new_xyz, pts, idx, wpacked, bpacked, out, st, 1, pooling)
+    PN2_MLP_CASE(1, 1, 2);
+    PN2_MLP_CASE(2, 2, 4);
+    PN2_MLP_CASE(2, 3, 4);
+#undef PN2_MLP_CASE
+    return PN2_E_TOO_LARGE;
 }
 
 // variant: the organisation of the resident kernel -- 0: by the size rule, 1: one item per wave, 2 / 3: two items per wave

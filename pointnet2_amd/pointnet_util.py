@@ -177,11 +177,14 @@ class PointnetSAModule(nn.Module):
         return self._lvl_buffers
 
     def _fused_ok(self, xyz, points):
-        """Inference with max pooling on a layer stack pn2_sa_mlp3_maxpool covers (see sa_mlp.py)."""
+        """Inference on a layer stack pn2_sa_mlp3_maxpool / pn2_sa_mlp3_pool covers (see sa_mlp.py)."""
         if not self.fused_mlp or self.training or torch.is_grad_enabled():
             return False
-        if self.pooling != "max" or not xyz.is_cuda:
+        if not xyz.is_cuda:
             return False
+        if self.pooling != "max":                  # avg / weighted_avg / max_and_avg (:130-140): the resident kernel's stacks
+            cin = 3 + (points.shape[2] if points is not None else 0)
+            return not self.group_all and sa_mlp.pool_supported(cin, self.mlp.widths, self.nsample, self.pooling)
         # (mlp2, :142-150, runs on the POOLED (b, npoint, C) rows behind the fused stack: _post)
         # (use_xyz=False: the kernels still gather the coordinates, against three zero rows of weight -- _packed)
         cin = 3 + (points.shape[2] if points is not None else 0)
@@ -253,7 +256,7 @@ class PointnetSAModule(nn.Module):
             return new_xyz, self._post(out), idx
         if self._fused_ok(xyz, points):
             self.last_path = "fused"
-            return new_xyz, self._post(sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, self._packed(xyz.device))), idx
+            return new_xyz, self._post(sa_mlp.sa_mlp_pool(xyz, new_xyz, points, idx, self._packed(xyz.device), self.pooling)), idx
         self.last_path = "unfused"
         grouped_xyz = group_point(xyz, idx) - new_xyz.unsqueeze(2)            # :45-46
         if points is not None:
@@ -298,7 +301,10 @@ class PointnetSAModule(nn.Module):
             if self.knn:                                              # :41-42: the k nearest points instead of the ball, same stack kernel
                 _, new_xyz = farthest_point_sample_gather(self.npoint, xyz)
                 _, idx = knn_point(self.nsample, xyz, new_xyz)
-                return new_xyz, self._post(sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, self._packed(xyz.device))), idx
+                return new_xyz, self._post(sa_mlp.sa_mlp_pool(xyz, new_xyz, points, idx, self._packed(xyz.device), self.pooling)), idx
+            if self.pooling != "max":                                 # the overlapped launch, then the stack with this pooling
+                _, new_xyz, idx, _, _ = sample_and_group_xyz(self.npoint, self.radius, self.nsample, xyz, True)
+                return new_xyz, self._post(sa_mlp.sa_mlp_pool(xyz, new_xyz, points, idx, self._packed(xyz.device), self.pooling)), idx
             new_xyz, out, idx, _, _, _ = sa_mlp.sa_level(self.npoint, self.radius, self.nsample, xyz, points,
                                                           self._packed(xyz.device), self._level_buffers())
             return new_xyz, self._post(out), idx

@@ -135,6 +135,48 @@ def sa_mlp_maxpool(xyz, new_xyz, points, idx, packed):
     return out
 
 
+POOLING = {"max": 0, "avg": 1, "weighted_avg": 2, "max_and_avg": 3}    # pn2_sa_mlp3_pool's codes (pointnet_util.py:128-140)
+
+
+def pool_supported(cin, widths, nsample, pooling):
+    """Does a fused kernel cover this stack with this pooling mode? max: supported(); the other three: the resident kernel's
+    stacks (at most 32 input channels)."""
+    if pooling not in POOLING or len(widths) != 3 or not nsample:
+        return False
+    return bool(_C.lib().pn2_sa_mlp3_pool_supported(int(cin), int(widths[0]), int(widths[1]), int(widths[2]), int(nsample),
+                                                    POOLING[pooling]))
+
+
+def sa_mlp_pool(xyz, new_xyz, points, idx, packed, pooling):
+    """sa_mlp_maxpool with the reference's other pooling modes (pointnet_util.py:128-140): "avg", "weighted_avg" ->
+    (b, m, c3); "max_and_avg" -> (b, m, 2 c3) = [avg, max]; "max" = sa_mlp_maxpool."""
+    if pooling == "max":
+        return sa_mlp_maxpool(xyz, new_xyz, points, idx, packed)
+    require(pooling in POOLING, "unknown pooling %r" % (pooling,))
+    xyz, new_xyz, idx = f32(xyz, "xyz"), f32(new_xyz, "new_xyz"), i32(idx, "idx")
+    b, n, _ = xyz.shape
+    m, ns = idx.shape[1], idx.shape[2]
+    cfeat = 0
+    if points is not None:
+        points = f32(points, "points")
+        cfeat = points.shape[2]
+        require(points.dim() == 3 and tuple(points.shape[:2]) == (b, n), "points must be (b, n, c) like xyz")
+    require(3 + cfeat == packed.cin, "packed MLP expects %d input channels, got %d" % (packed.cin, 3 + cfeat))
+    require(xyz.dim() == 3 and xyz.shape[2] == 3, "xyz must be (b, n, 3)")
+    require(tuple(new_xyz.shape) == (b, m, 3) and idx.dim() == 3 and idx.shape[0] == b, "new_xyz must be (b, m, 3) with idx (b, m, nsample)")
+    require(ns == packed.nsample or _same_kernel(packed, ns),
+            "weights were packed for nsample=%d (%s kernel); nsample=%d needs a different layout" % (packed.nsample, packed.kind, ns))
+    require(pool_supported(packed.cin, packed.widths, ns, pooling), "no fused kernel for pooling=%r on this stack" % (pooling,))
+    dev = same_device(*[t for t in (xyz, new_xyz, idx, points, packed.wp) if t is not None])
+    c3 = packed.widths[2]
+    out = torch.empty((b, m, 2 * c3 if pooling == "max_and_avg" else c3), dtype=torch.float32, device=dev)
+    with on_device(dev):
+        _C.check(_C.lib().pn2_sa_mlp3_pool(b, n, m, ns, cfeat, ptr(xyz), ptr(new_xyz), ptr(points), ptr(idx), packed.widths[0],
+                                           packed.widths[1], c3, ptr(packed.wp), ptr(packed.bp), POOLING[pooling], ptr(out), None,
+                                           stream_ptr(dev)), "sa_mlp3_pool")
+    return out
+
+
 # ---- feature propagation: three_nn weights + three_interpolate + concat + MLP in one kernel ------------------
 # Two kernels (include/pn2ops.h, pn2_fp_mlp `kind`): 0 = one wave per 32 points with the weights streamed through
 # LDS (csrc/fp_mlp.hip; many points), 1 = four waves per 32 points (csrc/coop_mlp.hip; few points, wide layers).

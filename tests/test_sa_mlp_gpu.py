@@ -260,3 +260,46 @@ def test_group_all_module_takes_the_fused_kernel(cuda):
         _, ref, _ = mod(xyz, feats)
         assert mod.last_path == "unfused"
     assert (out - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+# The reference's other pooling modes on the resident kernel (pn2_sa_mlp3_pool; utils/pointnet_util.py:128-140): every tile
+# configuration, nsample 16 (two centroids per item, odd row count), 32, 64 and 128 (several 32-sample parts per centroid),
+# with and without features, channel counts that are not multiples of 32 -- against the float64 restatement
+# (oracle/sa_module.py: bias + ReLU per sample, THEN the average; weights exp(-5 |grouped_xyz|) normalised over the group).
+@pytest.mark.parametrize("pooling", ["avg", "weighted_avg", "max_and_avg"])
+@pytest.mark.parametrize("cfeat,widths,ns,b,m", [(0, (64, 64, 128), 32, 3, 77), (0, (32, 32, 64), 16, 3, 77), (3, (64, 64, 128), 64, 2, 50),
+                                                 (6, (64, 96, 128), 32, 2, 130), (0, (24, 40, 100), 128, 2, 19), (29, (64, 64, 128), 32, 1, 9),
+                                                 (1, (17, 33, 65), 16, 5, 41), (0, (64, 64, 128), 32, 32, 1024)])
+def test_fused_mlp_other_pooling_modes(cuda, oracle, pooling, cfeat, widths, ns, b, m):
+    import pointnet2_amd as P
+    from oracle import sa_module as OM
+    from pointnet2_amd import sa_mlp
+    rng = np.random.default_rng(cfeat * 100 + ns + m)
+    n = 1024
+    xyz = torch.from_numpy(S.sphere_clouds(b, n, 9)).to(cuda)
+    new_xyz = P.gather_point(xyz, P.farthest_point_sample(m, xyz))
+    idx, _ = P.query_ball_point(0.3, ns, xyz, new_xyz)
+    points = torch.from_numpy(rng.standard_normal((b, n, cfeat)).astype(np.float32)).to(cuda) if cfeat else None
+    dims = (3 + cfeat,) + tuple(widths)
+    layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
+               (0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32)) for i in range(3)]
+    assert sa_mlp.pool_supported(dims[0], widths, ns, pooling)
+    packed = sa_mlp.PackedMLP3(layers, cuda, ns)
+    assert packed.kind == "resident"
+    got = sa_mlp.sa_mlp_pool(xyz, new_xyz, points, idx, packed, pooling).double().cpu().numpy()
+    x, q, ii = xyz.cpu().numpy(), new_xyz.cpu().numpy(), idx.cpu().numpy()
+    gxyz = oracle.group_point(x, ii) - q[:, :, None, :]
+    rows = gxyz if points is None else np.concatenate([gxyz, oracle.group_point(points.cpu().numpy(), ii)], axis=-1)
+    want = OM.sa_learned_part(gxyz, rows, [{"w": w.astype(np.float64), "b": bias.astype(np.float64), "gamma": None} for w, bias in layers], pooling)
+    assert got.shape == want.shape == (b, m, widths[2] * (2 if pooling == "max_and_avg" else 1))
+    err, scale = np.abs(got - want).max(), np.abs(want).max()
+    assert err <= 5e-6 * max(1.0, scale), (err, scale)
+    if pooling == "max_and_avg":                                    # the max half is pn2_sa_mlp3_maxpool's result, bit for bit
+        assert torch.equal(sa_mlp.sa_mlp_pool(xyz, new_xyz, points, idx, packed, pooling)[:, :, widths[2]:],
+                           sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, packed))
+
+
+def test_pooling_modes_outside_the_resident_kernel_are_refused(cuda):
+    from pointnet2_amd import sa_mlp
+    assert sa_mlp.pool_supported(3 + 64, (64, 64, 128), 32, "max") and not sa_mlp.pool_supported(3 + 64, (64, 64, 128), 32, "avg")
+    assert not sa_mlp.pool_supported(3, (64, 64, 128), 24, "avg") and not sa_mlp.pool_supported(3, (64, 64, 128), 32, "median")
