@@ -181,9 +181,10 @@ int pn2_sa_mlp3_maxpool_ex(int b, int n, int m, int nsample, int cfeat, const fl
 /* The reference's other pooling modes behind the same stack (utils/pointnet_util.py:128-140): pooling 0 max
  * (= pn2_sa_mlp3_maxpool), 1 avg (tf.reduce_mean over the group), 2 weighted_avg (weights exp(-5 |grouped_xyz|) normalised
  * over the group, :132-138), 3 max_and_avg (out (b, m, 2 c3) = concat([avg, max]), :139-142). Same operands, same packed
- * weights. Modes 1-3 are served for the stacks the resident kernel covers (pn2_sa_mlp3_config kind 0: at most 32 input
- * channels, nsample 16 or a multiple of 32); pn2_sa_mlp3_pool_supported says 1 / 0, other shapes return PN2_E_TOO_LARGE and
- * the caller evaluates the level layer by layer. idx / new_xyz NULL (group_all) only with pooling 0. */
+ * weights, same scratch (pn2_sa_mlp3_ws_bytes). Modes 1-3 are served for the stacks the resident and the streamed kernel
+ * cover (pn2_sa_mlp3_config kind 0 / 1: widths up to (128, 128, 256), nsample 16 or a multiple of 32);
+ * pn2_sa_mlp3_pool_supported says 1 / 0, the cooperative kernel's shapes return PN2_E_TOO_LARGE and the caller evaluates
+ * the level layer by layer. idx / new_xyz NULL (group_all) only with pooling 0. */
 int pn2_sa_mlp3_pool_supported(int cin, int c1, int c2, int c3, int nsample, int pooling);
 int pn2_sa_mlp3_pool(int b, int n, int m, int nsample, int cfeat, const float *xyz, const float *new_xyz,
                      const float *points, const int *idx, int c1, int c2, int c3, const float *wpacked,

@@ -821,8 +821,9 @@ extern "C" int pn2_sa_mlp3_maxpool(int b, int n, int m, int nsample, int cfeat, 
 
 // pn2_sa_mlp3_maxpool with the reference's other pooling modes (utils/pointnet_util.py:128-140). pooling: 0 max, 1 avg,
 // 2 weighted_avg, 3 max_and_avg (out is (b, m, 2 c3): [avg, max], the reference's concat order :142). Modes 1-3 exist for the
-// stacks the RESIDENT kernel covers (at most 32 input channels, weights in LDS: pn2_sa_mlp3_config kind 0) -- other shapes
-// return PN2_E_TOO_LARGE and the caller evaluates the level layer by layer.
+// stacks the RESIDENT and the STREAMED kernel cover (pn2_sa_mlp3_config kind 0 / 1: widths up to (128, 128, 256), nsample 16 or
+// a multiple of 32; ws as for pn2_sa_mlp3_maxpool) -- the cooperative kernel's shapes return PN2_E_TOO_LARGE and the caller
+// evaluates the level layer by layer.
 extern "C" int pn2_sa_mlp3_pool_supported(int cin, int c1, int c2, int c3, int nsample, int pooling)
 {
     using namespace pn2;
@@ -832,7 +833,7 @@ extern "C" int pn2_sa_mlp3_pool_supported(int cin, int c1, int c2, int c3, int n
     MlpStreamConfig sc;
     MlpCoopConfig cc;
     if (!mlp_choose(cin, c1, c2, c3, nsample, kind, rc, sc, cc)) return 0;
-    return pooling == 0 || kind == 0;
+    return pooling == 0 || kind != 2;
 }
 
 extern "C" int pn2_sa_mlp3_pool(int b, int n, int m, int nsample, int cfeat, const float *xyz, const float *new_xyz,
@@ -851,9 +852,11 @@ extern "C" int pn2_sa_mlp3_pool(int b, int n, int m, int nsample, int cfeat, con
     MlpConfig cfg;
     MlpStreamConfig sc;
     MlpCoopConfig cc;
-    if (!mlp_choose(3 + cfeat, c1, c2, c3, nsample, kind, cfg, sc, cc) || kind != 0) return PN2_E_TOO_LARGE;
+    if (!mlp_choose(3 + cfeat, c1, c2, c3, nsample, kind, cfg, sc, cc) || kind == 2) return PN2_E_TOO_LARGE;
     hipStream_t st = as_stream(stream);
     const float *pts = cfeat > 0 ? points : nullptr;
+    if (kind == 1)
+        return mlp_stream_launch(sc, b, n, m, nsample, cfeat, c3, xyz, new_xyz, pts ? pts : xyz, idx, wpacked, bpacked, out, ws, st, pooling);
 #define PN2_MLP_CASE(A, B, C) \
     if (cfg.t1 == A && cfg.t2 == B && cfg.t3 == C) \
         return launch_mlp<A, B, C>(b, n, m, nsample, cfeat, c3, xyz, new_xyz, pts, idx, wpacked, bpacked, out, st, 1, pooling)

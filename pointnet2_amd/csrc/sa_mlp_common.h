@@ -145,7 +145,7 @@ void mlp_stream_pack(const MlpStreamConfig &c, int cin, int c1, int c2, int c3, 
                      const float *const *bs, float *wpacked, float *bpacked);
 int mlp_stream_launch(const MlpStreamConfig &c, int b, int n, int m, int nsample, int cfeat, int c3, const float *xyz,
                       const float *new_xyz, const float *points, const int *idx, const float *wp, const float *bp,
-                      float *out, void *ws, hipStream_t st);
+                      float *out, void *ws, hipStream_t st, int pooling = 0);
 
 int point_layer_launch(int t1, int cfeat, long long rows, int tif, const float *points, const float *wstream,
                        const float *bias, float *pre, int out_stride, int col0, hipStream_t st);

@@ -249,7 +249,9 @@ __global__ __launch_bounds__(256) void point_layer_few_rows_kernel(int cfeat, lo
     }
 }
 
-template <int T1, int T2, int T3>
+// POOL: 0 max, 1 avg, 2 weighted_avg, 3 max_and_avg (utils/pointnet_util.py:128-140; see sa_mlp3_kernel in sa_mlp.hip: modes 1-3
+// apply bias + ReLU per sample and keep a running (weighted) sum per lane and output tile beside / instead of the raw maximum)
+template <int T1, int T2, int T3, int POOL = 0>
 __global__ __launch_bounds__(kStreamThreads) void sa_mlp3_stream_kernel(int n, int m, int nsample, int c3, long long rows,
                                                                        const float *__restrict__ xyz,
                                                                        const float *__restrict__ new_xyz,
@@ -289,8 +291,10 @@ __global__ __launch_bounds__(kStreamThreads) void sa_mlp3_stream_kernel(int n, i
         const float *c = new_xyz + row * 3;
         const float cx = c[0], cy = c[1], cz = c[2];
         float best[T3];
+        float sum[T3], esum = 0.0f;                  // POOL != 0: running sums of relu(raw + bias) (x weight), the weights' sum
         for (int part = 0; part < parts; ++part) {
             const int p = idx[row * nsample + part * 32 + s];
+            float wv[16];
             // layer 1: the point's precomputed feature part + the xyz part, one K16 step per output tile
             // (relative coordinates are channels 0-2 = registers 0-2 of lanes 0-31)
             f32x16 h1[T1];
@@ -308,6 +312,14 @@ __global__ __launch_bounds__(kStreamThreads) void sa_mlp3_stream_kernel(int n, i
                         const float4 f = *reinterpret_cast<const float4 *>(pp + 32 * t + 8 * q);
                         h1[t][4 * q] = f.x; h1[t][4 * q + 1] = f.y; h1[t][4 * q + 2] = f.z; h1[t][4 * q + 3] = f.w;
                     }
+                if (POOL == 2) {                 // :133-134: exp(-5 |grouped_xyz|) of this lane's sample (lanes 0-31), dealt to the registers' samples
+                    const float e = expf(-5.0f * sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x[0], x[0]), __fmul_rn(x[1], x[1])), __fmul_rn(x[2], x[2]))));
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        wv[v] = __shfl(e, 8 * (v >> 2) + 4 * h + (v & 3));
+                        esum += wv[v];
+                    }
+                }
                 const ActSplit xs = split_act(x);
 #pragma unroll
                 for (int t = 0; t < T1; ++t) {
@@ -351,11 +363,41 @@ __global__ __launch_bounds__(kStreamThreads) void sa_mlp3_stream_kernel(int n, i
                     acc = stream_pair<true>(wbuf[stage & 1], (t * T2 + u) % kS, lane, s2[u], acc);
                     if ((t * T2 + u) % kS == kS - 1) PN2_NEXT_STAGE();
                 }
-                float mx = acc[0];
+                if (POOL != 1 && POOL != 2) {
+                    float mx = acc[0];
 #pragma unroll
-                for (int v = 1; v < 16; ++v) mx = fmaxf(mx, acc[v]);
-                best[t] = part == 0 ? mx : fmaxf(best[t], mx);
+                    for (int v = 1; v < 16; ++v) mx = fmaxf(mx, acc[v]);
+                    best[t] = part == 0 ? mx : fmaxf(best[t], mx);
+                }
+                if (POOL != 0) {
+                    const float bias = b3_at(b3, 32 * t + s);
+                    float sm = 0.0f;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        float r = fmaxf(__fadd_rn(acc[v], bias), 0.0f);
+                        if (POOL == 2) r *= wv[v];
+                        sm += r;
+                    }
+                    sum[t] = part == 0 ? sm : sum[t] + sm;
+                }
             }
+        }
+        if (POOL != 0) {
+            const int oc = POOL == 3 ? 2 * c3 : c3;
+            float den = (float)nsample;
+            if (POOL == 2) den = esum + __shfl_xor(esum, 32);
+#pragma unroll
+            for (int t = 0; t < T3; ++t) {
+                const int ch = 32 * t + s;
+                const float sm = sum[t] + __shfl_xor(sum[t], 32);
+                float mx = 0.0f;
+                if (POOL == 3) mx = fmaxf(best[t], __shfl_xor(best[t], 32));
+                if (h == 0 && ch < c3 && row_ok) {
+                    out[row * oc + ch] = sm / den;
+                    if (POOL == 3) out[row * oc + c3 + ch] = fmaxf(__fadd_rn(mx, b3_at(b3, ch)), 0.0f);
+                }
+            }
+            continue;
         }
 #pragma unroll
         for (int t = 0; t < T3; ++t) {
@@ -465,7 +507,7 @@ int point_layer_few_rows_launch(int tiles, int cfeat, long long rows, int tif, c
 template <int T1, int T2, int T3>
 static int launch_stream(const MlpStreamConfig &c, int b, int n, int m, int nsample, int cfeat, int c3, const float *xyz,
                          const float *new_xyz, const float *points, const int *idx, const float *wp, const float *bp,
-                         float *out, float *pre, hipStream_t st)
+                         float *out, float *pre, hipStream_t st, int pooling)
 {
     const long long cap = 256;                           // one workgroup (one weight stream) per CU
     const long long npoints = (long long)b * n;
@@ -482,20 +524,25 @@ static int launch_stream(const MlpStreamConfig &c, int b, int n, int m, int nsam
     const long long rows = (long long)b * m;
     blocks = (rows + kStreamThreads / 64 - 1) / (kStreamThreads / 64);
     if (blocks > cap) blocks = cap;
-    return launch((sa_mlp3_stream_kernel<T1, T2, T3>), dim3((unsigned)blocks), dim3(kStreamThreads), 0, st, n, m, nsample, c3, rows,
-                  xyz, new_xyz, (const float *)pre, idx, wp, wxyz, bp, out);
+#define PN2_STREAM_POOL(P)                                                                                                   \
+    if (pooling == P)                                                                                                        \
+        return launch((sa_mlp3_stream_kernel<T1, T2, T3, P>), dim3((unsigned)blocks), dim3(kStreamThreads), 0, st, n, m, nsample, c3, \
+                      rows, xyz, new_xyz, (const float *)pre, idx, wp, wxyz, bp, out);
+    PN2_STREAM_POOL(0) PN2_STREAM_POOL(1) PN2_STREAM_POOL(2) PN2_STREAM_POOL(3)
+#undef PN2_STREAM_POOL
+    return PN2_E_ARG;
 }
 
 int mlp_stream_launch(const MlpStreamConfig &c, int b, int n, int m, int nsample, int cfeat, int c3, const float *xyz,
                       const float *new_xyz, const float *points, const int *idx, const float *wp, const float *bp,
-                      float *out, void *ws, hipStream_t st)
+                      float *out, void *ws, hipStream_t st, int pooling)
 {
     if (nsample <= 0 || nsample % 32 != 0) return PN2_E_ARG;
     if (!ws) return PN2_E_NULL;
     if (c.t1 == 2 && c.t2 == 2 && c.t3 == 4)
-        return launch_stream<2, 2, 4>(c, b, n, m, nsample, cfeat, c3, xyz, new_xyz, points, idx, wp, bp, out, (float *)ws, st);
+        return launch_stream<2, 2, 4>(c, b, n, m, nsample, cfeat, c3, xyz, new_xyz, points, idx, wp, bp, out, (float *)ws, st, pooling);
     if (c.t1 == 4 && c.t2 == 4 && c.t3 == 8)
-        return launch_stream<4, 4, 8>(c, b, n, m, nsample, cfeat, c3, xyz, new_xyz, points, idx, wp, bp, out, (float *)ws, st);
+        return launch_stream<4, 4, 8>(c, b, n, m, nsample, cfeat, c3, xyz, new_xyz, points, idx, wp, bp, out, (float *)ws, st, pooling);
     return PN2_E_TOO_LARGE;
 }
 

@@ -139,8 +139,8 @@ POOLING = {"max": 0, "avg": 1, "weighted_avg": 2, "max_and_avg": 3}    # pn2_sa_
 
 
 def pool_supported(cin, widths, nsample, pooling):
-    """Does a fused kernel cover this stack with this pooling mode? max: supported(); the other three: the resident kernel's
-    stacks (at most 32 input channels)."""
+    """Does a fused kernel cover this stack with this pooling mode? max: supported(); the other three: the resident and the
+    streamed kernel's stacks (widths up to (128, 128, 256))."""
     if pooling not in POOLING or len(widths) != 3 or not nsample:
         return False
     return bool(_C.lib().pn2_sa_mlp3_pool_supported(int(cin), int(widths[0]), int(widths[1]), int(widths[2]), int(nsample),
@@ -170,9 +170,13 @@ def sa_mlp_pool(xyz, new_xyz, points, idx, packed, pooling):
     dev = same_device(*[t for t in (xyz, new_xyz, idx, points, packed.wp) if t is not None])
     c3 = packed.widths[2]
     out = torch.empty((b, m, 2 * c3 if pooling == "max_and_avg" else c3), dtype=torch.float32, device=dev)
+    ws = None
+    nbytes = _C.lib().pn2_sa_mlp3_ws_bytes(b, n, m, packed.cin, packed.widths[0], packed.widths[1], c3, ns)
+    if nbytes:
+        ws = torch.empty(((nbytes + 3) // 4,), dtype=torch.float32, device=dev)
     with on_device(dev):
         _C.check(_C.lib().pn2_sa_mlp3_pool(b, n, m, ns, cfeat, ptr(xyz), ptr(new_xyz), ptr(points), ptr(idx), packed.widths[0],
-                                           packed.widths[1], c3, ptr(packed.wp), ptr(packed.bp), POOLING[pooling], ptr(out), None,
+                                           packed.widths[1], c3, ptr(packed.wp), ptr(packed.bp), POOLING[pooling], ptr(out), ptr(ws),
                                            stream_ptr(dev)), "sa_mlp3_pool")
     return out
 

@@ -262,14 +262,18 @@ def test_group_all_module_takes_the_fused_kernel(cuda):
     assert (out - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
 
 
-# The reference's other pooling modes on the resident kernel (pn2_sa_mlp3_pool; utils/pointnet_util.py:128-140): every tile
+# The reference's other pooling modes on the resident and the streamed kernel (pn2_sa_mlp3_pool; utils/pointnet_util.py:128-140): every tile
 # configuration, nsample 16 (two centroids per item, odd row count), 32, 64 and 128 (several 32-sample parts per centroid),
 # with and without features, channel counts that are not multiples of 32 -- against the float64 restatement
 # (oracle/sa_module.py: bias + ReLU per sample, THEN the average; weights exp(-5 |grouped_xyz|) normalised over the group).
 @pytest.mark.parametrize("pooling", ["avg", "weighted_avg", "max_and_avg"])
 @pytest.mark.parametrize("cfeat,widths,ns,b,m", [(0, (64, 64, 128), 32, 3, 77), (0, (32, 32, 64), 16, 3, 77), (3, (64, 64, 128), 64, 2, 50),
                                                  (6, (64, 96, 128), 32, 2, 130), (0, (24, 40, 100), 128, 2, 19), (29, (64, 64, 128), 32, 1, 9),
-                                                 (1, (17, 33, 65), 16, 5, 41), (0, (64, 64, 128), 32, 32, 1024)])
+                                                 (1, (17, 33, 65), 16, 5, 41), (0, (64, 64, 128), 32, 32, 1024),
+                                                 # the streamed kernel: wide inputs / SA2-sized stacks
+                                                 (64, (64, 64, 128), 32, 3, 77), (128, (128, 128, 256), 64, 2, 40),
+                                                 (61, (100, 120, 200), 32, 2, 33), (0, (128, 128, 256), 32, 3, 77),
+                                                 (320, (128, 128, 256), 128, 1, 21)])
 def test_fused_mlp_other_pooling_modes(cuda, oracle, pooling, cfeat, widths, ns, b, m):
     import pointnet2_amd as P
     from oracle import sa_module as OM
@@ -285,7 +289,8 @@ def test_fused_mlp_other_pooling_modes(cuda, oracle, pooling, cfeat, widths, ns,
                (0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32)) for i in range(3)]
     assert sa_mlp.pool_supported(dims[0], widths, ns, pooling)
     packed = sa_mlp.PackedMLP3(layers, cuda, ns)
-    assert packed.kind == "resident"
+    resident = cfeat <= 29 and widths[0] <= 64 and widths[1] <= 96 and widths[2] <= 128
+    assert packed.kind == ("resident" if resident else "streamed")
     got = sa_mlp.sa_mlp_pool(xyz, new_xyz, points, idx, packed, pooling).double().cpu().numpy()
     x, q, ii = xyz.cpu().numpy(), new_xyz.cpu().numpy(), idx.cpu().numpy()
     gxyz = oracle.group_point(x, ii) - q[:, :, None, :]
@@ -299,7 +304,8 @@ def test_fused_mlp_other_pooling_modes(cuda, oracle, pooling, cfeat, widths, ns,
                            sa_mlp.sa_mlp_maxpool(xyz, new_xyz, points, idx, packed))
 
 
-def test_pooling_modes_outside_the_resident_kernel_are_refused(cuda):
+def test_pooling_modes_on_the_cooperative_kernels_shapes_are_refused(cuda):
     from pointnet2_amd import sa_mlp
-    assert sa_mlp.pool_supported(3 + 64, (64, 64, 128), 32, "max") and not sa_mlp.pool_supported(3 + 64, (64, 64, 128), 32, "avg")
+    assert sa_mlp.pool_supported(3 + 64, (64, 64, 128), 32, "max") and sa_mlp.pool_supported(3 + 64, (64, 64, 128), 32, "avg")
+    assert sa_mlp.pool_supported(3 + 256, (256, 256, 512), 32, "max") and not sa_mlp.pool_supported(3 + 256, (256, 256, 512), 32, "avg")
     assert not sa_mlp.pool_supported(3, (64, 64, 128), 24, "avg") and not sa_mlp.pool_supported(3, (64, 64, 128), 32, "median")
