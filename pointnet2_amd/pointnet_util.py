@@ -154,8 +154,12 @@ class PointnetSAModule(nn.Module):
     """reference: pointnet_sa_module, pointnet_util.py:87-154."""
 
     def __init__(self, c_in, npoint, radius, nsample, mlp, mlp2=None, group_all=False, bn=True, pooling="max",
-                 knn=False, use_xyz=True):
+                 knn=False, use_xyz=True, use_nchw=False):
         super().__init__()
+        # use_nchw (:87, :101): the reference's conv2d data-format switch -- "usually faster than NHWC" on its backend, the
+        # same numbers either way. Accepted for signature parity and ignored: the layouts here are the kernels' own.
+        if pooling not in ("max", "avg", "weighted_avg", "max_and_avg"):
+            raise ValueError("unknown pooling %r" % (pooling,))
         self.npoint, self.radius, self.nsample = npoint, radius, nsample
         self.group_all, self.pooling, self.knn, self.use_xyz = group_all, pooling, knn, use_xyz
         self.c_in = c_in
@@ -350,8 +354,8 @@ class PointnetSAModuleMSG(nn.Module):
     """reference: pointnet_sa_module_msg, pointnet_util.py:156-196 (one FPS, several radii;
     concat order features FIRST, :184 -- the opposite of the single-scale module)."""
 
-    def __init__(self, c_in, npoint, radius_list, nsample_list, mlp_list, bn=True, use_xyz=True):
-        super().__init__()
+    def __init__(self, c_in, npoint, radius_list, nsample_list, mlp_list, bn=True, use_xyz=True, use_nchw=False):
+        super().__init__()                                # (use_nchw, :156: accepted and ignored, see PointnetSAModule)
         self.npoint, self.radius_list, self.nsample_list, self.use_xyz = npoint, radius_list, nsample_list, use_xyz
         self.c_in = c_in
         feat = 3 if c_in == 0 else (c_in + 3 if use_xyz else c_in)
