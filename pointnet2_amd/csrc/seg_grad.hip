@@ -137,7 +137,12 @@ __device__ __forceinline__ void seg_rank_sort(int *llist, int beg, int len, int 
         if (gl + G * q < len) llist[beg + rank[q]] = val[q];
 }
 
-template <bool SORT>
+// LDSLIST (always with SORT): the list is built in LDS and leaves the workgroup as one coalesced copy -- scattered 4-byte
+// stores straight to global memory are one request per lane (24 K of them per cloud at sem_seg FP4: ~10 us of the kernel's 20).
+// RUNS: lanes of a wave that hold the SAME target in a row (a ball query's padding repeats its first hit up to nsample times,
+// tf_grouping_g.cu:24-31) take ONE ticket for the run -- the head lane adds the run's length, the others derive their position
+// from it; 64 lanes on one counter otherwise serialise in the LDS atomic unit.
+template <bool SORT, bool LDSLIST = SORT, bool RUNS = false>
 __global__ __launch_bounds__(1024) void seg_invert_lds_kernel(long long entries, int rows, const int *__restrict__ idx,
                                                               int *__restrict__ start, int *__restrict__ sorted,
                                                               int *__restrict__ list)
@@ -155,7 +160,38 @@ __global__ __launch_bounds__(1024) void seg_invert_lds_kernel(long long entries,
     for (int r = t; r < rows; r += 1024) cnt[r] = 0;
     if (t == 0) carry_s = 0;
     __syncthreads();
-    for (long long e = t; e < entries; e += 1024) atomicAdd(&cnt[my[e]], 1);
+    // (both passes over idx fetch eight entries per thread before they touch the counters: a loop of load -> LDS atomic pays
+    // the global latency per entry -- 24 per thread at sem_seg FP4, where the inversion was 17 us of the gradient's 45)
+    constexpr int kInvU = 8;
+    // head lane of this lane's run and the run's length (valid on the head): `same` = this lane continues the previous lane's run
+    auto run_of = [&](bool same, int &hl, int &runlen) __attribute__((always_inline)) {
+        const unsigned long long hm = __ballot(!same);
+        const unsigned long long below = lane == 63 ? hm : (hm & ((2ull << lane) - 1ull));
+        hl = 63 - __clzll((long long)below);
+        const unsigned long long above = lane == 63 ? 0ull : (hm >> (lane + 1));
+        runlen = above ? __ffsll((unsigned long long)above) : 64 - lane;
+    };
+    for (long long b0 = 0; b0 < entries; b0 += 1024 * kInvU) {     // (uniform trip count: the run logic shuffles across the wave)
+        int v[kInvU];
+        bool ok[kInvU];
+#pragma unroll
+        for (int u = 0; u < kInvU; ++u) {
+            const long long e = b0 + t + (long long)u * 1024;
+            ok[u] = e < entries;
+            v[u] = ok[u] ? my[e] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kInvU; ++u) {
+            if (RUNS) {
+                const int prev = __shfl_up(v[u], 1);
+                int hl, runlen;
+                run_of(lane != 0 && v[u] == prev && ok[u], hl, runlen);
+                if (ok[u] && hl == lane) atomicAdd(&cnt[v[u]], runlen);
+            } else if (ok[u]) {
+                atomicAdd(&cnt[v[u]], 1);
+            }
+        }
+    }
     __syncthreads();
     for (int base = 0; base < rows; base += 1024) {
         const int r = base + t;
@@ -179,13 +215,41 @@ __global__ __launch_bounds__(1024) void seg_invert_lds_kernel(long long entries,
         __syncthreads();
     }
     if (t == 0) st[rows] = carry_s;
-    for (long long e = t; e < entries; e += 1024) {
-        const int pos = atomicAdd(&cnt[my[e]], 1);
-        if (SORT) llist[pos] = (int)e;
-        else out[pos] = (int)e;
+    for (long long b0 = 0; b0 < entries; b0 += 1024 * kInvU) {
+        int v[kInvU], pos[kInvU];
+        bool ok[kInvU];
+#pragma unroll
+        for (int u = 0; u < kInvU; ++u) {
+            const long long e = b0 + t + (long long)u * 1024;
+            ok[u] = e < entries;
+            v[u] = ok[u] ? my[e] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kInvU; ++u) {
+            if (RUNS) {
+                const int prev = __shfl_up(v[u], 1);
+                int hl, runlen;
+                run_of(lane != 0 && v[u] == prev && ok[u], hl, runlen);
+                const int base = (ok[u] && hl == lane) ? atomicAdd(&cnt[v[u]], runlen) : 0;
+                pos[u] = __shfl(base, hl) + (lane - hl);
+            } else {
+                pos[u] = ok[u] ? atomicAdd(&cnt[v[u]], 1) : 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kInvU; ++u) {
+            if (!ok[u]) continue;
+            const int e = (int)(b0 + t + (long long)u * 1024);
+            if (LDSLIST) llist[pos[u]] = e;
+            else out[pos[u]] = e;
+        }
     }
     if (!SORT) {
         for (int r = t; r < rows; r += 1024) flags[r] = 0;
+        if (LDSLIST) {
+            __syncthreads();
+            for (long long e = t; e < entries; e += 1024) out[e] = llist[e];
+        }
         return;
     }
     __syncthreads();                                              // cnt[r] is now the END of segment r
@@ -557,9 +621,11 @@ static int seg_grad(int b, int rows, long long entries, int c, const float *grad
     if (rows <= kSegLdsRows && b >= 4) {
         // enough clouds to spread over CUs: the whole inversion of a cloud in one workgroup, LDS counters
         const size_t with_list = sizeof(int) * ((size_t)rows + (size_t)entries);
-        const bool sort = deterministic && with_list <= 144 * 1024;   // + 8 KiB static for the long-row lists
-        const size_t lds = sort ? with_list : sizeof(int) * (size_t)rows;
-        auto kern = sort ? seg_invert_lds_kernel<true> : seg_invert_lds_kernel<false>;
+        const bool fits = with_list <= 144 * 1024;                    // + 8 KiB static for the long-row lists
+        const bool sort = deterministic && fits;
+        const size_t lds = fits ? with_list : sizeof(int) * (size_t)rows;
+        constexpr bool RUNS = SRC_DIV == 1;                           // group_point's idx: padded ball-query lists
+        auto kern = sort ? seg_invert_lds_kernel<true, true, RUNS> : fits ? seg_invert_lds_kernel<false, true, RUNS> : seg_invert_lds_kernel<false, false, RUNS>;
         if (int rc = allow_dynamic_lds(kern, lds)) return rc;
         if (int rc = launch(kern, dim3(b), dim3(1024), lds, st, entries, rows, idx, w.start, w.sorted, w.list)) return rc;
     } else {
