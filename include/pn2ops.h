@@ -275,7 +275,8 @@ int pn2_query_ball_group_xyz_msg(int b, int n, int m, int nscales, const float *
 int pn2_three_nn_ex(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx, int variant, void *stream);
 /* pn2_group_point / pn2_three_interpolate with the kernel choice per call (parity tests force every kernel,
  * scripts/bw_probe.py times them). group: 0 automatic, 1 flat first-generation kernels, 2 row kernels,
- * 3 row kernels with non-temporal stores; three_interpolate: 0 automatic, 1 flat, 2 row kernel. */
+ * 3 row kernels with non-temporal stores; three_interpolate: 0 automatic, 1 flat, 2 row kernel, 3 row kernel with
+ * non-temporal stores. */
 int pn2_group_point_ex(int b, int n, int c, int m, int nsample, const float *points, const int *idx, float *out,
                        int variant, void *stream);
 int pn2_three_interpolate_ex(int b, int m, int c, int n, const float *points, const int *idx, const float *weight,

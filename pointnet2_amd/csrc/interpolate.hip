@@ -604,7 +604,7 @@ static int three_interpolate_entry(int b, int m, int c, int n, const float *poin
 {
     using namespace pn2;
     if (b < 0 || m <= 0 || c <= 0 || n < 0) return PN2_E_SHAPE;
-    if (variant < 0 || variant > 2) return PN2_E_ARG;
+    if (variant < 0 || variant > 3) return PN2_E_ARG;
     const long long rows = (long long)b * n;
     if (rows == 0) return PN2_OK;
     if (!points || !idx || !weight || !out) return PN2_E_NULL;
@@ -619,7 +619,10 @@ static int three_interpolate_entry(int b, int m, int c, int n, const float *poin
         if (parts > most) parts = most;
         if (parts < 1) parts = 1;
         const int rpp = (n + parts - 1) / parts;
-        const bool nt = (long long)b * n * c * 4 > (192ll << 20);  // beyond the Infinity Cache: stream the output
+        // beyond the Infinity Cache: stream the output. Below it non-temporal stores make THIS kernel faster (sem_seg FP4, 34 MB:
+        // 10.7 -> 9.8 us) and the kernel that reads the output slower by more (a column sum behind it: 40.4 -> 42.0 us for the
+        // pair; profiles/r06/nt_stores_lab.txt) -- variant 3 forces them for that measurement
+        const bool nt = variant == 3 || (variant != 2 && (long long)b * n * c * 4 > (192ll << 20));
         auto kern = nt ? three_interpolate_rows_v4_kernel<U, true> : three_interpolate_rows_v4_kernel<U, false>;
         return launch(kern, dim3((unsigned)parts * b), dim3(kThreads), 0, st, n, m, c4,
                       kThreads / c4, kThreads % c4, rpp, parts, b, reinterpret_cast<const float4 *>(points), idx, weight,
@@ -644,7 +647,8 @@ extern "C" int pn2_three_interpolate(int b, int m, int c, int n, const float *po
     return three_interpolate_entry(b, m, c, n, points, idx, weight, out, 0, stream);
 }
 
-// pn2_three_interpolate with the kernel choice per call: 0 automatic, 1 flat first-generation kernels, 2 row kernel.
+// pn2_three_interpolate with the kernel choice per call: 0 automatic, 1 flat first-generation kernels, 2 row kernel, 3 row kernel
+// with non-temporal stores (where the row kernel does not apply, 2 and 3 fall back to the flat kernels).
 extern "C" int pn2_three_interpolate_ex(int b, int m, int c, int n, const float *points, const int *idx,
                                         const float *weight, float *out, int variant, void *stream)
 {

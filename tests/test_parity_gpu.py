@@ -604,3 +604,32 @@ def test_fp_weights_and_interpolation(cuda, oracle):
     feats = np.random.default_rng(98).random((2, 150, 32), dtype=np.float32)
     out = P.three_interpolate(dev(feats, cuda), idx, w)
     np.testing.assert_allclose(host(out), oracle.three_interpolate(feats, wi, host(w)), rtol=0, atol=FEAT_TOL)
+
+
+@pytest.mark.parametrize("c", [4, 64, 128, 320, 6])
+def test_group_and_interpolate_with_every_kernel_forced(cuda, oracle, c):
+    """pn2_group_point_ex (variants 0-3: automatic, flat, row kernel, row kernel with non-temporal stores) and
+    pn2_three_interpolate_ex (0-3 likewise) against the oracle, bit for bit -- the per-call kernel choice the header documents
+    (c = 6: rows the 16-byte kernels do not take; the variants fall back to the flat kernels)."""
+    from pointnet2_amd import _C
+    lib = _C.lib()
+    rng = np.random.default_rng(300 + c)
+    b, n, m, ns = 3, 700, 90, 24
+    pts = rng.standard_normal((b, n, c)).astype(np.float32)
+    idx = rng.integers(0, n, size=(b, m, ns)).astype(np.int32)
+    want = oracle.group_point(pts, idx)
+    p, i = dev(pts, cuda), dev(idx, cuda)
+    st = torch.cuda.current_stream(cuda).cuda_stream
+    for variant in (0, 1, 2, 3):
+        out = torch.full((b, m, ns, c), float("nan"), device=cuda)
+        assert lib.pn2_group_point_ex(b, n, c, m, ns, p.data_ptr(), i.data_ptr(), out.data_ptr(), variant, st) == 0
+        assert np.array_equal(host(out), want), variant
+    un = 650
+    i3 = rng.integers(0, n, size=(b, un, 3)).astype(np.int32)
+    w3 = rng.random((b, un, 3), dtype=np.float32)
+    want3 = oracle.three_interpolate(pts, i3, w3)
+    i3d, w3d = dev(i3, cuda), dev(w3, cuda)
+    for variant in (0, 1, 2, 3):
+        out = torch.full((b, un, c), float("nan"), device=cuda)
+        assert lib.pn2_three_interpolate_ex(b, n, c, un, p.data_ptr(), i3d.data_ptr(), w3d.data_ptr(), out.data_ptr(), variant, st) == 0
+        assert np.array_equal(host(out), want3), variant
