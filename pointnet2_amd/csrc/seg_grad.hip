@@ -498,6 +498,8 @@ __device__ __forceinline__ void seg_reduce_long_body(unsigned blk, unsigned nblk
                     auto sweep = [&](auto widec) __attribute__((always_inline)) {
                         constexpr bool WIDE = decltype(widec)::value;
                         constexpr int NE = WIDE ? 4 : 8;
+                        // (fetching the NEXT batch's entry numbers ahead of this batch's rows -- one round trip per batch instead of two
+                        // -- was measured: c = 320 172 -> 163 us, c = 128 38.5 -> 42.7: not kept)
                         for (int p = g * 4; p < rlen; p += NG * NE) {
                             int e[NE];
                             float wq[NE];
@@ -574,6 +576,34 @@ __global__ __launch_bounds__(kSegLongThreads) void seg_reduce_split_kernel(unsig
                                                                      weight, start, sorted, list, out, kSegLongFrom);
 }
 
+// Workgroups of the long-row part = the stride of the rows a workgroup looks at (row blk + k wg, k = 0, 1, ...). The long rows are
+// the LOW point numbers of every cloud, so what matters is the stride's residue modulo the rows per cloud: with a common factor
+// every cloud's row r goes to the same few workgroups (wg = rows = 512: thirty workgroups did all the work, 1758 us), and with a
+// residue near 0 -- 1021 = 2 x 512 - 3, the rule until the last session of round 6 -- a workgroup's rows walk down three point
+// numbers at a time, so the workgroups that start at a low number get ALL their ~16 rows long and the others none (cls_ssg L2:
+// ~200 of 1021 workgroups summed every long row, 42 us for 144 MB). The residue is therefore put at the golden section of the
+// rows per cloud (consecutive k land far apart and fill in evenly), coprime with it.
+// wide: rows of 64 lanes (c > 128): half as many lane groups per workgroup, a long row takes twice the batches -- twice the
+// workgroups (c = 320 at cls_msg L2: 172 -> 159 us; at c = 128 the extra workgroups cost more than they balance: 38.5 -> 40.2).
+static long long seg_long_blocks(long long out_rows, int rows, bool wide)
+{
+    const int per = wide ? 8 : 16;                                    // rows looked at per workgroup
+    long long cap = (out_rows + per - 1) / per;
+    const long long most = (wide || rows > 1021) ? 2045 : 1021;
+    if (cap > most) cap = most;
+    if (cap < 1) cap = 1;
+    const long long target = (long long)(0.381966 * rows);
+    for (long long d = 0; d < rows; ++d)
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            const long long r = sgn ? target - d : target + d;
+            if (r <= 0 || r >= rows || r > cap || std::__gcd(r, (long long)rows) != 1) continue;
+            return (cap - r) / rows * rows + r;                       // the largest q rows + r within the cap
+        }
+    long long wg = cap | 1;                                           // (rows per cloud of 1 or 2: nothing to spread)
+    while (wg > 1 && std::__gcd((long long)rows, wg) > 1) wg -= 2;
+    return wg;
+}
+
 template <bool DET, int SRC_DIV>
 static int launch_reduce(long long out_rows, int rows, long long entries, int c, const float *grad_out, const float *weight,
                          const SegWs &w, float *out, hipStream_t st)
@@ -592,10 +622,7 @@ static int launch_reduce(long long out_rows, int rows, long long entries, int c,
             /* ~16 rows looked at per long-row workgroup, at most 1021 of them. The long rows are the LOW point numbers of every \
                cloud: workgroup w looks at rows w, w + wg, w + 2 wg, ..., so wg must not share a factor with the rows per cloud -- \
                with wg = rows = 512 every cloud's row r went to workgroup r and thirty workgroups did all the work (1758 us) */ \
-            long long wg = (out_rows + 15) / 16;                                                                     \
-            if (wg > 1021) wg = 1021;                                                                                \
-            wg |= 1;                                                                                                 \
-            while (wg > 1 && (rows % wg == 0 || std::__gcd((long long)rows, wg) > 1)) wg -= 2;                       \
+            const long long wg = seg_long_blocks(out_rows, rows, L >= 64);                                           \
             const unsigned ga = seg_grid(threads, kSegLongThreads);                                                  \
             return launch((seg_reduce_split_kernel<(L >= 16 ? L : 16), SRC_DIV>), dim3((unsigned)wg + ga), dim3(kSegLongThreads), 0, st, \
                           (unsigned)wg, out_rows, rows, entries, c, grad_out, weight, w.start, w.sorted, w.list, out); \
