@@ -320,7 +320,7 @@ __device__ __forceinline__ void seg_reduce_body(unsigned blk, unsigned nblk, lon
                                                 const int *__restrict__ list, float *__restrict__ out, int long_from)
 {
     constexpr int CH = VEC4 ? 4 : 1;
-    constexpr int UNR = 4;
+    constexpr int UNR = DET ? 4 : 8;                                 // row loads in flight per lane (default mode: medium rows are chains of batches)
     const long long group = ((long long)blk * NT + threadIdx.x) / LPR;
     const int lane = threadIdx.x & 63;
     const int gl = threadIdx.x % LPR, gbase = lane - gl;            // first lane of this group inside the wave
@@ -442,13 +442,22 @@ __global__ __launch_bounds__(kSegThreads) void seg_reduce_kernel(long long out_r
 // meet in LDS and are added in group order (a fixed order: the result does not depend on timing, only the association differs
 // from the serial sum). The reproducible mode keeps the one-group serial sum, whose order is the reference CPU loop's.
 constexpr int kSegLongFrom = 64;
+// ... or fewer where the average row is short: a lane group keeps four row loads in flight, so a 63-entry row is sixteen dependent
+// batches -- behind the balanced long rows, those rows were the end of the launch. Twice the average row, between 32 and 64
+// (cls_ssg L2, 16 per row: 38.0 -> 32.8 us with 32; sem_seg FP4's interpolation, 24 per row with little spread: 33.4 -> 32.5 with
+// 48, 37.6 with 32 -- a whole workgroup on a row of 32 entries is mostly idle lanes).
+inline int seg_long_from(long long entries, int rows)
+{
+    const long long twice = 2 * entries / (rows > 0 ? rows : 1);
+    return (int)(twice < 32 ? 32 : twice > kSegLongFrom ? kSegLongFrom : twice);
+}
 constexpr int kSegLongThreads = 512;
 
 template <int LPR, int SRC_DIV>
 __device__ __forceinline__ void seg_reduce_long_body(unsigned blk, unsigned nblk, long long out_rows, int rows, long long entries, int c,
                                                      const float *__restrict__ grad_out, const float *__restrict__ weight,
                                                      const int *__restrict__ start, const int *__restrict__ list,
-                                                     float *__restrict__ out)
+                                                     float *__restrict__ out, int long_from)
 {
     constexpr int NG = kSegLongThreads / LPR;                      // lane groups per workgroup
     __shared__ float4 part[kSegLongThreads];                       // [NG][LPR]
@@ -466,7 +475,7 @@ __device__ __forceinline__ void seg_reduce_long_body(unsigned blk, unsigned nblk
             beg = start[i * (rows + 1) + r];
             len = start[i * (rows + 1) + r + 1] - beg;
         }
-        const bool is_long = len >= kSegLongFrom;
+        const bool is_long = len >= long_from;
         row_beg[t] = beg; row_len[t] = len;
         const unsigned long long m = __ballot(is_long);
         if (lane == 0) long_mask[wv] = m;
@@ -567,13 +576,13 @@ __global__ __launch_bounds__(kSegLongThreads) void seg_reduce_split_kernel(unsig
                                                                            const float *__restrict__ weight,
                                                                            const int *__restrict__ start,
                                                                            const int *__restrict__ sorted,
-                                                                           const int *__restrict__ list, float *__restrict__ out)
+                                                                           const int *__restrict__ list, float *__restrict__ out, int long_from)
 {
     if (blockIdx.x < nlong)
-        seg_reduce_long_body<LPR, SRC_DIV>(blockIdx.x, nlong, out_rows, rows, entries, c, grad_out, weight, start, list, out);
+        seg_reduce_long_body<LPR, SRC_DIV>(blockIdx.x, nlong, out_rows, rows, entries, c, grad_out, weight, start, list, out, long_from);
     else
         seg_reduce_body<LPR, true, false, SRC_DIV, kSegLongThreads>(blockIdx.x - nlong, gridDim.x - nlong, out_rows, rows, entries, c, grad_out,
-                                                                     weight, start, sorted, list, out, kSegLongFrom);
+                                                                     weight, start, sorted, list, out, long_from);
 }
 
 // Workgroups of the long-row part = the stride of the rows a workgroup looks at (row blk + k wg, k = 0, 1, ...). The long rows are
@@ -625,7 +634,7 @@ static int launch_reduce(long long out_rows, int rows, long long entries, int c,
             const long long wg = seg_long_blocks(out_rows, rows, L >= 64);                                           \
             const unsigned ga = seg_grid(threads, kSegLongThreads);                                                  \
             return launch((seg_reduce_split_kernel<(L >= 16 ? L : 16), SRC_DIV>), dim3((unsigned)wg + ga), dim3(kSegLongThreads), 0, st, \
-                          (unsigned)wg, out_rows, rows, entries, c, grad_out, weight, w.start, w.sorted, w.list, out); \
+                          (unsigned)wg, out_rows, rows, entries, c, grad_out, weight, w.start, w.sorted, w.list, out, seg_long_from(entries, rows)); \
         }                                                                                                            \
         if (vec4)                                                                                                    \
             return launch((seg_reduce_kernel<L, true, DET, SRC_DIV>), dim3(seg_grid(threads)), dim3(kSegThreads), 0, st, \
