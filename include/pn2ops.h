@@ -132,6 +132,13 @@ int pn2_three_interpolate_grad_det(int b, int n, int c, int m, const float *grad
  * ws: pn2_seg_grad_ws_bytes(b, rows, entries) bytes of uninitialised device scratch
  * (group_point: rows = n, entries = m * nsample; three_interpolate: rows = m, entries = 3 * n). */
 long long pn2_seg_grad_ws_bytes(int b, int rows, long long entries);
+/* Host logic, no device work (tests, maintainers): how the default mode of pn2_*_grad_seg lays out the long-row part of its
+ * reduction for out_rows = b * rows target rows of c channels with `entries` references per cloud. long_from: rows with that
+ * many references or more are summed by a whole workgroup each (twice the average row, between 32 and 64); long_blocks: the
+ * number of such workgroups = the stride of the rows one of them looks at (rows w, w + long_blocks, ...): coprime with `rows`,
+ * residue at its golden section, so that the low point numbers of every cloud -- where a ball query's padding piles the
+ * references up, tf_grouping_g.cu:24-31 -- spread evenly over the workgroups. */
+int pn2_seg_grad_plan(int rows, long long entries, int c, long long out_rows, int *long_from, int *long_blocks);
 int pn2_group_point_grad_seg(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
                              float *grad_points, void *ws, int deterministic, void *stream);
 int pn2_three_interpolate_grad_seg(int b, int n, int c, int m, const float *grad_out, const int *idx,

@@ -53,6 +53,7 @@ _SIGNATURES = {
     "pn2_three_interpolate_grad_det": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pn2_knn_point": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pn2_seg_grad_ws_bytes": [_i, _i, ctypes.c_longlong],
+    "pn2_seg_grad_plan": [_i, ctypes.c_longlong, _i, ctypes.c_longlong, _vp, _vp],
     "pn2_group_point_grad_seg": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "pn2_three_interpolate_grad_seg": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pn2_sa_mlp3_config": [_i, _i, _i, _i, _i, _vp, _vp, _vp],

@@ -601,7 +601,9 @@ static long long seg_long_blocks(long long out_rows, int rows, bool wide)
     const long long most = (wide || rows > 1021) ? 2045 : 1021;
     if (cap > most) cap = most;
     if (cap < 1) cap = 1;
-    const long long target = (long long)(0.381966 * rows);
+    double tg = 0.381966 * rows;
+    while (tg > (double)cap && tg > 2.0) tg *= 0.618034;              // fewer workgroups than that: the next golden fraction of the rows
+    const long long target = (long long)tg;
     for (long long d = 0; d < rows; ++d)
         for (int sgn = 0; sgn < 2; ++sgn) {
             const long long r = sgn ? target - d : target + d;
@@ -676,6 +678,20 @@ static int seg_grad(int b, int rows, long long entries, int c, const float *grad
 }
 
 }  // namespace pn2
+
+// Host logic of the default mode's long-row part for a shape (no device work): what launch_reduce computes. Tests simulate the
+// assignment of the low point numbers -- where the long rows are -- to workgroups from it (tests/test_seg_plan_model.py).
+extern "C" int pn2_seg_grad_plan(int rows, long long entries, int c, long long out_rows, int *long_from, int *long_blocks)
+{
+    using namespace pn2;
+    if (rows <= 0 || entries < 0 || c <= 0 || out_rows <= 0) return PN2_E_SHAPE;
+    const int per = (c & 3) == 0 ? c / 4 : c;
+    int lpr = 1;
+    while (lpr < per && lpr < 64) lpr <<= 1;
+    if (long_from) *long_from = seg_long_from(entries, rows);
+    if (long_blocks) *long_blocks = (int)seg_long_blocks(out_rows, rows, lpr >= 64);
+    return PN2_OK;
+}
 
 extern "C" long long pn2_seg_grad_ws_bytes(int b, int rows, long long entries)
 {
