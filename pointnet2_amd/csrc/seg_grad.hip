@@ -580,9 +580,15 @@ __global__ __launch_bounds__(kSegLongThreads) void seg_reduce_split_kernel(unsig
 {
     if (blockIdx.x < nlong)
         seg_reduce_long_body<LPR, SRC_DIV>(blockIdx.x, nlong, out_rows, rows, entries, c, grad_out, weight, start, list, out, long_from);
-    else
-        seg_reduce_body<LPR, true, false, SRC_DIV, kSegLongThreads>(blockIdx.x - nlong, gridDim.x - nlong, out_rows, rows, entries, c, grad_out,
+    else {
+        // Workgroups go to the eight XCDs round-robin, each XCD has an L2 of its own, and a gradient row of three_interpolate is
+        // referenced by THREE target rows: target rows dealt to workgroups in launch order put those three readers on three XCDs
+        // (PMC traffic 2.7 x algorithmic at sem_seg FP4). Every eighth workgroup -- one XCD -- therefore takes one CONTIGUOUS
+        // eighth of the target rows, i.e. whole clouds (the short part's workgroup count is a multiple of 8).
+        const unsigned s = blockIdx.x - nlong, n = gridDim.x - nlong;
+        seg_reduce_body<LPR, true, false, SRC_DIV, kSegLongThreads>((s & 7u) * (n >> 3) + (s >> 3), n, out_rows, rows, entries, c, grad_out,
                                                                      weight, start, sorted, list, out, long_from);
+    }
 }
 
 // Workgroups of the long-row part = the stride of the rows a workgroup looks at (row blk + k wg, k = 0, 1, ...). The long rows are
@@ -634,7 +640,7 @@ static int launch_reduce(long long out_rows, int rows, long long entries, int c,
                cloud: workgroup w looks at rows w, w + wg, w + 2 wg, ..., so wg must not share a factor with the rows per cloud -- \
                with wg = rows = 512 every cloud's row r went to workgroup r and thirty workgroups did all the work (1758 us) */ \
             const long long wg = seg_long_blocks(out_rows, rows, L >= 64);                                           \
-            const unsigned ga = seg_grid(threads, kSegLongThreads);                                                  \
+            const unsigned ga = (seg_grid(threads, kSegLongThreads) + 7u) & ~7u;   /* a multiple of 8: seg_reduce_split_kernel's XCD map */ \
             return launch((seg_reduce_split_kernel<(L >= 16 ? L : 16), SRC_DIV>), dim3((unsigned)wg + ga), dim3(kSegLongThreads), 0, st, \
                           (unsigned)wg, out_rows, rows, entries, c, grad_out, weight, w.start, w.sorted, w.list, out, seg_long_from(entries, rows)); \
         }                                                                                                            \
