@@ -1101,11 +1101,14 @@ __global__ __launch_bounds__(256) void tl_top_mats_kernel(const float *__restric
                                                           int NFp, const float *__restrict__ coef, const float *__restrict__ bias,
                                                           float *__restrict__ wp, float *__restrict__ rowc)
 {
+    // (W staged in LDS -- 64 x 128 at the metric shape -- was measured in the last session of round 6: 13.2 -> 24.5 us; the walk
+    // over a row's columns hits the same cache lines trip after trip, the staging loop does not. Not kept.)
+    auto W = [&](int n, int c) __attribute__((always_inline)) -> float { return w[n * sk + c * sn]; };
     const long long total = (long long)(NFp + K + 1) * K;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int r = (int)(i / K), n = (int)(i - (long long)r * K);
         if (r < NFp) {
-            wp[i] = r < NF ? w[n * sk + r * sn] : 0.0f;
+            wp[i] = r < NF ? W(n, r) : 0.0f;
         } else if (r < NFp + K) {
             const int j = r - NFp;
             double acc[4] = {0.0, 0.0, 0.0, 0.0};                  // four chains: the loop is load latency, not arithmetic
@@ -1113,9 +1116,9 @@ __global__ __launch_bounds__(256) void tl_top_mats_kernel(const float *__restric
             for (; c + 4 <= NF; c += 4) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    acc[u] += (double)w[j * sk + (c + u) * sn] * (double)coef[2 * NF + c + u] * (double)w[n * sk + (c + u) * sn];
+                    acc[u] += (double)W(j, c + u) * (double)coef[2 * NF + c + u] * (double)W(n, c + u);
             }
-            for (; c < NF; ++c) acc[0] += (double)w[j * sk + c * sn] * (double)coef[2 * NF + c] * (double)w[n * sk + c * sn];
+            for (; c < NF; ++c) acc[0] += (double)W(j, c) * (double)coef[2 * NF + c] * (double)W(n, c);
             wp[i] = (float)(-((acc[0] + acc[1]) + (acc[2] + acc[3])));
         } else {
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1124,10 +1127,10 @@ __global__ __launch_bounds__(256) void tl_top_mats_kernel(const float *__restric
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     acc[u] += ((double)coef[NF + c + u] + (bias ? (double)bias[c + u] : 0.0) * (double)coef[2 * NF + c + u]) *
-                              (double)w[n * sk + (c + u) * sn];
+                              (double)W(n, c + u);
             }
             for (; c < NF; ++c)
-                acc[0] += ((double)coef[NF + c] + (bias ? (double)bias[c] : 0.0) * (double)coef[2 * NF + c]) * (double)w[n * sk + c * sn];
+                acc[0] += ((double)coef[NF + c] + (bias ? (double)bias[c] : 0.0) * (double)coef[2 * NF + c]) * (double)W(n, c);
             rowc[n] = (float)(-((acc[0] + acc[1]) + (acc[2] + acc[3])));
         }
     }
@@ -1522,33 +1525,62 @@ __global__ __launch_bounds__(256) void tl_l1_wx_reduce_kernel(const float *__res
 // ---- layer 1 of a level without features, weight gradient from moments (TlWgrad::l1x) ----------------------------------------
 // the centred coordinates of every row as (x, y, z, 0) -- the layer above's one-pass backward reads them 16 bytes per row
 // instead of gathering through idx -- and the nine moments sum x, sum x x^T of this workgroup's rows (fp64)
-__global__ __launch_bounds__(256) void tl_l1_xrows_kernel(const TlL1 p, float4 *__restrict__ xg, double *__restrict__ mom)
+constexpr int kL1XrowsThreads = 1024;
+__global__ __launch_bounds__(kL1XrowsThreads) void tl_l1_xrows_kernel(const TlL1 p, float4 *__restrict__ xg, double *__restrict__ mom)
 {
+    // (last session of round 6. The launch is at most 256 workgroups -- one partial row of moments each, summed in fp64 by the
+    // consumer; with 256 threads a thread walked 16 rows one at a time, a chain of idx -> coordinates round trips, and nine
+    // threads then added 256 LDS values each, serially: 20.8 us at the metric shape. Now 1024 threads, four rows in flight per
+    // thread -- one trip at the metric shape -- and the workgroup's sums meet through a shuffle tree + one sum per wave, a fixed order.)
     double s[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) s[i] = 0.0;
-    const unsigned rows = (unsigned)p.rows;
-    for (unsigned r = blockIdx.x * 256u + threadIdx.x; r < rows; r += gridDim.x * 256u) {
+    const unsigned rows = (unsigned)p.rows, stride = gridDim.x * (unsigned)kL1XrowsThreads;
+    auto row_in = [&](unsigned r, float (&x)[3], float (&c)[3]) __attribute__((always_inline)) {
         const unsigned grp = r / (unsigned)p.nsample;
         const size_t pt = (size_t)(grp / (unsigned)p.m) * p.n + p.idx[r];
         const float *px = p.xyz + pt * 3;
-        float x0 = px[0], x1 = px[1], x2 = px[2];
+        x[0] = px[0]; x[1] = px[1]; x[2] = px[2];
+        c[0] = c[1] = c[2] = 0.0f;
         if (p.new_xyz) {
             const float *pc = p.new_xyz + (size_t)grp * 3;
-            x0 = __fsub_rn(x0, pc[0]); x1 = __fsub_rn(x1, pc[1]); x2 = __fsub_rn(x2, pc[2]);      // pointnet_util.py:46
+            c[0] = pc[0]; c[1] = pc[1]; c[2] = pc[2];
         }
+    };
+    auto row_out = [&](unsigned r, const float (&x)[3], const float (&c)[3]) __attribute__((always_inline)) {
+        float x0 = x[0], x1 = x[1], x2 = x[2];
+        if (p.new_xyz) { x0 = __fsub_rn(x0, c[0]); x1 = __fsub_rn(x1, c[1]); x2 = __fsub_rn(x2, c[2]); }      // pointnet_util.py:46
         xg[r] = make_float4(x0, x1, x2, 0.0f);
         const double d0 = x0, d1 = x1, d2 = x2;
         s[0] += d0; s[1] += d1; s[2] += d2;
         s[3] += d0 * d0; s[4] += d0 * d1; s[5] += d0 * d2; s[6] += d1 * d1; s[7] += d1 * d2; s[8] += d2 * d2;
-    }
-    __shared__ double red[9][256];
+    };
+    unsigned r = blockIdx.x * (unsigned)kL1XrowsThreads + threadIdx.x;
+    for (; (unsigned long long)r + 3ull * stride < rows; r += 4u * stride) {
+        float x[4][3], c[4][3];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) red[i][threadIdx.x] = s[i];
+        for (int u = 0; u < 4; ++u) row_in(r + u * stride, x[u], c[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) row_out(r + u * stride, x[u], c[u]);
+    }
+    for (; r < rows; r += stride) {
+        float x[3], c[3];
+        row_in(r, x, c);
+        row_out(r, x, c);
+    }
+    __shared__ double red[kL1XrowsThreads / 64][9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        double v = s[i];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+    }
     __syncthreads();
     if (threadIdx.x < 9) {
         double a = 0.0;
-        for (int t = 0; t < 256; ++t) a += red[threadIdx.x][t];
+#pragma unroll
+        for (int w = 0; w < kL1XrowsThreads / 64; ++w) a += red[w][threadIdx.x];
         mom[(size_t)blockIdx.x * 9 + threadIdx.x] = a;
     }
 }
@@ -2916,10 +2948,10 @@ extern "C" int pn2_mlp_train_backward_ex(long long rows, int nlayers, const pn2_
                     memset(&q, 0, sizeof(q));
                     q.rows = rows; q.n = gd.n; q.m = gd.m; q.nsample = gd.nsample; q.C = D.cout;
                     q.xyz = group->xyz; q.new_xyz = group->new_xyz; q.idx = group->idx;
-                    long long xb = (rows + 255) / 256;
+                    long long xb = (rows + kL1XrowsThreads - 1) / kL1XrowsThreads;
                     if (xb > kMaxParts) xb = kMaxParts;
                     l1_moment_parts = (int)xb;
-                    if (int rc = launch(tl_l1_xrows_kernel, dim3((unsigned)xb), dim3(256), 0, st, q, reinterpret_cast<float4 *>(base + pl.l1xg),
+                    if (int rc = launch(tl_l1_xrows_kernel, dim3((unsigned)xb), dim3(kL1XrowsThreads), 0, st, q, reinterpret_cast<float4 *>(base + pl.l1xg),
                                         reinterpret_cast<double *>(base + pl.l1mom))) return rc;
                     w.l1x = reinterpret_cast<const float4 *>(base + pl.l1xg);
                     w.l1a = reinterpret_cast<double *>(base + pl.l1a);
