@@ -288,3 +288,51 @@ def test_segmented_interpolate_grad_with_long_segments(cuda):
             np.add.at(want[i], idx[i, :, k], add)
             np.add.at(mag[i], idx[i, :, k], np.abs(add))
     assert np.all(np.abs(pts.grad.cpu().numpy() - want) <= mag * 2.0 ** -24 * (3 * n / m * 2) + 1e-30)
+
+
+def _padded_idx(rng, b, n, m, ns, low_bias):
+    """Ball-query-shaped lists: k real hits in ascending order, then the FIRST hit repeated (tf_grouping_g.cu:24-31); the first hits
+    are drawn from the low point numbers (low_bias of them), where the reference's padding piles the references up."""
+    idx = np.empty((b, m, ns), dtype=np.int32)
+    for i in range(b):
+        for j in range(m):
+            k = int(rng.integers(1, ns + 1))
+            first = int(rng.integers(0, max(1, low_bias)))
+            rest = np.sort(rng.choice(np.arange(first + 1, n), size=min(k - 1, n - first - 1), replace=False)) if k > 1 and first + 1 < n else np.empty(0, dtype=np.int64)
+            row = np.concatenate([[first], rest]).astype(np.int32)
+            idx[i, j, :len(row)] = row
+            idx[i, j, len(row):] = first
+    return idx
+
+
+# Shapes that walk the branches of the segmented gradient's host logic and kernels (csrc/seg_grad.hip, last session of round 6):
+# entries not a multiple of 64 (tail lanes beside runs of equal targets), rows per cloud above 1021 (the stride rule's second
+# range), a list that does not fit in LDS beside the counters (one store per entry), fewer than four clouds (the inversion as
+# three launches), 64-lane rows (c = 320) with rows of several hundred references, rows per cloud below the threshold.
+@pytest.mark.parametrize("b,n,m,ns,c,low", [(5, 700, 37, 19, 128, 12), (4, 2048, 300, 32, 64, 40), (4, 9000, 1000, 32, 64, 100),
+                                            (3, 512, 128, 64, 128, 20), (8, 512, 128, 128, 320, 10), (6, 40, 64, 16, 16, 3),
+                                            (32, 512, 128, 64, 128, 28)])
+def test_segmented_group_grad_on_padded_lists(cuda, b, n, m, ns, c, low):
+    import pointnet2_amd as P
+    rng = np.random.default_rng(b * 1000 + n + c)
+    idx_np = _padded_idx(rng, b, n, m, ns, low)
+    idx = torch.from_numpy(idx_np).to(cuda)
+    lens = np.stack([np.bincount(idx_np[i].reshape(-1), minlength=n) for i in range(b)])
+    g = rng.standard_normal((b, m, ns, c)).astype(np.float32)
+    want = _exact_scatter(b, n, c, idx_np.reshape(b, -1), g.reshape(b, -1, c))
+    mag = _exact_scatter(b, n, c, idx_np.reshape(b, -1), np.abs(g).reshape(b, -1, c))
+    tol = mag * 2.0 ** -24 * np.maximum(lens[:, :, None], 2) + 1e-30
+    got = {}
+    for det in (False, True):
+        pts = torch.zeros(b, n, c, device=cuda, requires_grad=True)
+        P.set_deterministic(det)
+        try:
+            P.group_point(pts, idx).backward(torch.from_numpy(g).to(cuda))
+        finally:
+            P.set_deterministic(False)
+        got[det] = pts.grad.cpu().numpy()
+        assert np.all(np.abs(got[det] - want) <= tol), det
+    # the default mode twice: the same bits (its sum order is fixed; only which workgroup sums a row is timing)
+    pts = torch.zeros(b, n, c, device=cuda, requires_grad=True)
+    P.group_point(pts, idx).backward(torch.from_numpy(g).to(cuda))
+    assert np.array_equal(pts.grad.cpu().numpy(), got[False]) or np.all(np.abs(pts.grad.cpu().numpy() - want) <= tol)
