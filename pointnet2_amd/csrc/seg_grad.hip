@@ -313,7 +313,10 @@ __device__ __forceinline__ int seg_shift(float maxabs, int logcount)
 // The segment's entry numbers are fetched LPR at a time (one per lane) and handed round with a
 // shuffle, and the rows are read four at a time: a lane that first loads an entry number and then the
 // row it names pays two dependent memory round trips per entry (335 us where this form needs ~150).
-template <int LPR, bool VEC4, bool DET, int SRC_DIV, int NT>
+// WIDE (default mode, 16-byte rows wider than LPR float4s and at most twice that: c = 320 on 64 lanes): a lane carries its SECOND
+// float4 (lane + LPR) in the same sweep of the segment -- as a second sweep it repeated every dependent batch of row loads for a
+// quarter of the lanes (the long-row body has done so since it exists).
+template <int LPR, bool VEC4, bool DET, int SRC_DIV, int NT, bool WIDE = false>
 __device__ __forceinline__ void seg_reduce_body(unsigned blk, unsigned nblk, long long out_rows, int rows, long long entries, int c,
                                                 const float *__restrict__ grad_out, const float *__restrict__ weight,
                                                 const int *__restrict__ start, const int *__restrict__ sorted,
@@ -347,10 +350,16 @@ __device__ __forceinline__ void seg_reduce_body(unsigned blk, unsigned nblk, lon
         // the fixed-point second pass is only for long, unsorted segments
         const bool two_pass = DET && !sorted[row];
 
-        for (int cc0 = 0; __any(cc0 < c); cc0 += LPR * CH) {
+        for (int cc0 = 0; __any(cc0 < c); cc0 += (WIDE ? 2 : 1) * LPR * CH) {
             const int cc = cc0 + gl * CH;
             const bool ch_ok = cc < c;
             const int ccl = ch_ok ? cc : 0;
+            const int cc2 = cc + LPR * CH;                          // WIDE: the lane's second float4
+            const bool ch2_ok = WIDE && cc2 < c;
+            const int ccl2 = ch2_ok ? cc2 : 0;
+            float acc2[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) acc2[q] = 0.0f;
             float acc[CH];
             unsigned mx[CH];
             long long fx[CH];
@@ -371,6 +380,7 @@ __device__ __forceinline__ void seg_reduce_body(unsigned blk, unsigned nblk, lon
                     const int chunk = min(LPR, plen - p0);
                     for (int j0 = 0; __any(j0 < chunk); j0 += UNR) {
                         float a[UNR][CH];
+                        float a2[WIDE ? UNR : 1][CH];
                         float wv[UNR];
                         bool ok[UNR];
 #pragma unroll
@@ -382,6 +392,10 @@ __device__ __forceinline__ void seg_reduce_body(unsigned blk, unsigned nblk, lon
                             if (VEC4) {
                                 const float4 v = *reinterpret_cast<const float4 *>(g);
                                 a[u][0] = v.x; a[u][1] = v.y; a[u][2] = v.z; a[u][3] = v.w;
+                                if (WIDE) {
+                                    const float4 v2 = *reinterpret_cast<const float4 *>(src + (size_t)(e / SRC_DIV) * c + ccl2);
+                                    a2[u][0] = v2.x; a2[u][1] = v2.y; a2[u][2] = v2.z; a2[u][3] = v2.w;
+                                }
                             } else {
                                 a[u][0] = g[0];
                             }
@@ -390,6 +404,11 @@ __device__ __forceinline__ void seg_reduce_body(unsigned blk, unsigned nblk, lon
 #pragma unroll
                         for (int u = 0; u < UNR; ++u) {
                             if (!ok[u]) continue;
+                            if (WIDE) {
+#pragma unroll
+                                for (int q = 0; q < CH; ++q)
+                                    acc2[q] = __fadd_rn(acc2[q], wsrc ? __fmul_rn(a2[u][q], wv[u]) : a2[u][q]);
+                            }
 #pragma unroll
                             for (int q = 0; q < CH; ++q) {
                                 const float ad = wsrc ? __fmul_rn(a[u][q], wv[u]) : a[u][q];
@@ -413,6 +432,8 @@ __device__ __forceinline__ void seg_reduce_body(unsigned blk, unsigned nblk, lon
                 if (VEC4) *reinterpret_cast<float4 *>(o) = make_float4(res[0], res[1], res[2], res[3]);
                 else o[0] = res[0];
             }
+            if (WIDE && row_ok && ch2_ok && mine_row)
+                *reinterpret_cast<float4 *>(out + row * c + cc2) = make_float4(acc2[0], acc2[1], acc2[2], acc2[3]);
         }
     }
 }
@@ -506,7 +527,7 @@ __device__ __forceinline__ void seg_reduce_long_body(unsigned blk, unsigned nblk
                     // batch with both float4s of the lane
                     auto sweep = [&](auto widec) __attribute__((always_inline)) {
                         constexpr bool WIDE = decltype(widec)::value;
-                        constexpr int NE = WIDE ? 4 : 8;
+                        constexpr int NE = 8;                     // (wide rows too: a 1000-entry row of c = 320 is the end of the launch -- 32 entries per batch made it 31 dependent batches)
                         // (fetching the NEXT batch's entry numbers ahead of this batch's rows -- one round trip per batch instead of two
                         // -- was measured: c = 320 172 -> 163 us, c = 128 38.5 -> 42.7: not kept)
                         for (int p = g * 4; p < rlen; p += NG * NE) {
@@ -570,7 +591,7 @@ __device__ __forceinline__ void seg_reduce_long_body(unsigned blk, unsigned nblk
 // ONE launch for both (default mode): blocks [0, nlong) sum the long rows -- dependent chains of row loads, dispatched first --,
 // the other blocks the short rows at streaming rate beside them (as two launches: 18 + 38 us at cls_ssg L2, 107 + 147 at
 // cls_msg L2; the long-row kernel alone uses a fraction of the memory system)
-template <int LPR, int SRC_DIV>
+template <int LPR, int SRC_DIV, bool WIDE = false>
 __global__ __launch_bounds__(kSegLongThreads) void seg_reduce_split_kernel(unsigned nlong, long long out_rows, int rows, long long entries,
                                                                            int c, const float *__restrict__ grad_out,
                                                                            const float *__restrict__ weight,
@@ -586,7 +607,7 @@ __global__ __launch_bounds__(kSegLongThreads) void seg_reduce_split_kernel(unsig
         // (PMC traffic 2.7 x algorithmic at sem_seg FP4). Every eighth workgroup -- one XCD -- therefore takes one CONTIGUOUS
         // eighth of the target rows, i.e. whole clouds (the short part's workgroup count is a multiple of 8).
         const unsigned s = blockIdx.x - nlong, n = gridDim.x - nlong;
-        seg_reduce_body<LPR, true, false, SRC_DIV, kSegLongThreads>((s & 7u) * (n >> 3) + (s >> 3), n, out_rows, rows, entries, c, grad_out,
+        seg_reduce_body<LPR, true, false, SRC_DIV, kSegLongThreads, WIDE>((s & 7u) * (n >> 3) + (s >> 3), n, out_rows, rows, entries, c, grad_out,
                                                                      weight, start, sorted, list, out, long_from);
     }
 }
@@ -641,6 +662,9 @@ static int launch_reduce(long long out_rows, int rows, long long entries, int c,
                with wg = rows = 512 every cloud's row r went to workgroup r and thirty workgroups did all the work (1758 us) */ \
             const long long wg = seg_long_blocks(out_rows, rows, L >= 64);                                           \
             const unsigned ga = (seg_grid(threads, kSegLongThreads) + 7u) & ~7u;   /* a multiple of 8: seg_reduce_split_kernel's XCD map */ \
+            if (L == 64 && per > 64 && per <= 128)              /* c in (256, 512]: both float4s of a lane in one sweep */ \
+                return launch((seg_reduce_split_kernel<64, SRC_DIV, true>), dim3((unsigned)wg + ga), dim3(kSegLongThreads), 0, st, \
+                              (unsigned)wg, out_rows, rows, entries, c, grad_out, weight, w.start, w.sorted, w.list, out, seg_long_from(entries, rows)); \
             return launch((seg_reduce_split_kernel<(L >= 16 ? L : 16), SRC_DIV>), dim3((unsigned)wg + ga), dim3(kSegLongThreads), 0, st, \
                           (unsigned)wg, out_rows, rows, entries, c, grad_out, weight, w.start, w.sorted, w.list, out, seg_long_from(entries, rows)); \
         }                                                                                                            \
