@@ -142,7 +142,9 @@ __device__ __forceinline__ void seg_rank_sort(int *llist, int beg, int len, int 
 // RUNS: lanes of a wave that hold the SAME target in a row (a ball query's padding repeats its first hit up to nsample times,
 // tf_grouping_g.cu:24-31) take ONE ticket for the run -- the head lane adds the run's length, the others derive their position
 // from it; 64 lanes on one counter otherwise serialise in the LDS atomic unit.
-template <bool SORT, bool LDSLIST = SORT, bool RUNS = false>
+// KEEP > 0: the cloud's entries are at most KEEP x 8192 -- a thread's share (KEEP batches of eight) stays in registers between the
+// counting pass and the placing pass instead of being read again.
+template <bool SORT, bool LDSLIST = SORT, bool RUNS = false, int KEEP = 0>
 __global__ __launch_bounds__(1024) void seg_invert_lds_kernel(long long entries, int rows, const int *__restrict__ idx,
                                                               int *__restrict__ start, int *__restrict__ sorted,
                                                               int *__restrict__ list)
@@ -171,15 +173,16 @@ __global__ __launch_bounds__(1024) void seg_invert_lds_kernel(long long entries,
         const unsigned long long above = lane == 63 ? 0ull : (hm >> (lane + 1));
         runlen = above ? __ffsll((unsigned long long)above) : 64 - lane;
     };
-    for (long long b0 = 0; b0 < entries; b0 += 1024 * kInvU) {     // (uniform trip count: the run logic shuffles across the wave)
-        int v[kInvU];
-        bool ok[kInvU];
+    int keep[KEEP > 0 ? KEEP : 1][kInvU];
+    auto fetch = [&](long long b0, int (&v)[kInvU], bool (&ok)[kInvU]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < kInvU; ++u) {
             const long long e = b0 + t + (long long)u * 1024;
             ok[u] = e < entries;
             v[u] = ok[u] ? my[e] : -1;
         }
+    };
+    auto count = [&](const int (&v)[kInvU], const bool (&ok)[kInvU]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < kInvU; ++u) {
             if (RUNS) {
@@ -190,6 +193,21 @@ __global__ __launch_bounds__(1024) void seg_invert_lds_kernel(long long entries,
             } else if (ok[u]) {
                 atomicAdd(&cnt[v[u]], 1);
             }
+        }
+    };
+    if (KEEP > 0) {
+#pragma unroll
+        for (int bi = 0; bi < (KEEP > 0 ? KEEP : 1); ++bi) {
+            bool ok[kInvU];
+            fetch((long long)bi * 1024 * kInvU, keep[bi], ok);
+            count(keep[bi], ok);
+        }
+    } else {
+        for (long long b0 = 0; b0 < entries; b0 += 1024 * kInvU) {     // (uniform trip count: the run logic shuffles across the wave)
+            int v[kInvU];
+            bool ok[kInvU];
+            fetch(b0, v, ok);
+            count(v, ok);
         }
     }
     __syncthreads();
@@ -215,15 +233,11 @@ __global__ __launch_bounds__(1024) void seg_invert_lds_kernel(long long entries,
         __syncthreads();
     }
     if (t == 0) st[rows] = carry_s;
-    for (long long b0 = 0; b0 < entries; b0 += 1024 * kInvU) {
-        int v[kInvU], pos[kInvU];
+    auto place = [&](long long b0, const int (&v)[kInvU]) __attribute__((always_inline)) {
+        int pos[kInvU];
         bool ok[kInvU];
 #pragma unroll
-        for (int u = 0; u < kInvU; ++u) {
-            const long long e = b0 + t + (long long)u * 1024;
-            ok[u] = e < entries;
-            v[u] = ok[u] ? my[e] : -1;
-        }
+        for (int u = 0; u < kInvU; ++u) ok[u] = b0 + t + (long long)u * 1024 < entries;
 #pragma unroll
         for (int u = 0; u < kInvU; ++u) {
             if (RUNS) {
@@ -242,6 +256,17 @@ __global__ __launch_bounds__(1024) void seg_invert_lds_kernel(long long entries,
             const int e = (int)(b0 + t + (long long)u * 1024);
             if (LDSLIST) llist[pos[u]] = e;
             else out[pos[u]] = e;
+        }
+    };
+    if (KEEP > 0) {
+#pragma unroll
+        for (int bi = 0; bi < (KEEP > 0 ? KEEP : 1); ++bi) place((long long)bi * 1024 * kInvU, keep[bi]);
+    } else {
+        for (long long b0 = 0; b0 < entries; b0 += 1024 * kInvU) {
+            int v[kInvU];
+            bool ok[kInvU];
+            fetch(b0, v, ok);
+            place(b0, v);
         }
     }
     if (!SORT) {
@@ -694,6 +719,13 @@ static int seg_grad(int b, int rows, long long entries, int c, const float *grad
         const size_t lds = fits ? with_list : sizeof(int) * (size_t)rows;
         constexpr bool RUNS = SRC_DIV == 1;                           // group_point's idx: padded ball-query lists
         auto kern = sort ? seg_invert_lds_kernel<true, true, RUNS> : fits ? seg_invert_lds_kernel<false, true, RUNS> : seg_invert_lds_kernel<false, false, RUNS>;
+        if (!sort && fits) {                                          // default mode: the entries stay in registers between the passes
+            const long long nb = (entries + 8191) / 8192;
+            if (nb == 1) kern = seg_invert_lds_kernel<false, true, RUNS, 1>;
+            else if (nb == 2) kern = seg_invert_lds_kernel<false, true, RUNS, 2>;
+            else if (nb == 3) kern = seg_invert_lds_kernel<false, true, RUNS, 3>;
+            else if (nb == 4) kern = seg_invert_lds_kernel<false, true, RUNS, 4>;
+        }
         if (int rc = allow_dynamic_lds(kern, lds)) return rc;
         if (int rc = launch(kern, dim3(b), dim3(1024), lds, st, entries, rows, idx, w.start, w.sorted, w.list)) return rc;
     } else {
