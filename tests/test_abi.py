@@ -138,6 +138,12 @@ def test_c_abi_argument_validation_of_the_extra_entry_points():
     assert lib.pn2_query_ball_group_xyz_msg(1, 8, 4, 2, radii, nss, one, one, 1, None, None, None, None) == -1   # no outputs
     # fused MLP: shape limits are reported, never silently mis-run
     assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 0, 0, one, one, None, one, 64, 64, 128, one, one, one, None, None) == -3    # nsample
+    # ... and the pooling-mode entry (round 6): unknown mode, group_all with a mode other than max, a stack only the cooperative kernel takes
+    assert lib.pn2_sa_mlp3_pool(1, 64, 8, 32, 0, one, one, None, one, 64, 64, 128, one, one, 7, one, None, None) == -3
+    assert lib.pn2_sa_mlp3_pool(1, 64, 8, 32, 0, one, None, None, None, 64, 64, 128, one, one, 1, one, None, None) == -1
+    assert lib.pn2_sa_mlp3_pool(1, 64, 8, 32, 256, one, one, one, one, 256, 256, 512, one, one, 1, one, None, None) == -4
+    assert lib.pn2_sa_mlp3_pool_supported(3, 64, 64, 128, 32, 1) == 1 and lib.pn2_sa_mlp3_pool_supported(3, 64, 64, 128, 32, 4) == 0
+    assert lib.pn2_sa_mlp3_pool_supported(259, 256, 256, 512, 32, 0) == 1 and lib.pn2_sa_mlp3_pool_supported(259, 256, 256, 512, 32, 2) == 0
     assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 24, 0, one, one, None, one, 64, 64, 128, one, one, one, None, None) == -4   # odd nsample: only the cooperative kernel masks, and it has no (64,64,128) form
     assert lib.pn2_sa_mlp3_maxpool(1, 64, 8, 32, 0, one, one, None, one, 512, 512, 512, one, one, one, None, None) == -4
     assert lib.pn2_sa_mlp3_maxpool(2, 64, 3, 64, 0, one, None, None, None, 256, 512, 1024, one, one, one, None, None) == -3  # group_all needs m = 1, nsample = n
